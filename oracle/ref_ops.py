@@ -1,0 +1,234 @@
+"""CPU ORACLE (test infrastructure, never a product path).
+
+Plain-PyTorch restatement of the reference's own pure-PyTorch definitions of
+the hot-path operators.  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s `cpu_baseline` leg may import this package; the product path
+(`segmamba_amd`) must never do so and fails loudly without its HIP library.
+
+Pinning: `tests/golden/make_golden.py` imports the *reference's* functions
+from /root/reference (in the build container) and stores their outputs and
+gradients for seeded inputs under `tests/golden/*.npz`;
+`tests/test_oracle_golden.py` checks every function here against those
+fixtures (fp32, max abs err <= 2e-6 relative to output scale), so this file
+is pinned to the reference's behaviour, not merely to its documentation.
+
+Each function cites the reference lines it restates
+(paths relative to the reference root).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# selective scan
+# --------------------------------------------------------------------------------------
+def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                       return_last_state=False, compute_dtype=torch.float32):
+    """mamba/mamba_ssm/ops/selective_scan_interface.py:86-152 (`selective_scan_ref`),
+    real `A`, input-dependent `B`/`C` (the only case on the SegMamba path).
+
+    u, delta, z : (batch, dim, L)            A : (dim, N)      D, delta_bias : (dim,)
+    B, C        : (batch, N, L) or (batch, G, N, L) with dim % G == 0
+    Returns out (batch, dim, L) in u.dtype [, last_state (batch, dim, N) in compute_dtype].
+
+    h_t = exp(delta_t * A) * h_{t-1} + delta_t * u_t * B_t ; y_t = <C_t, h_t> + D*u_t ; out = y * silu(z)
+
+    The reference materialises (batch, dim, L, N) tensors; this walks t and keeps only the
+    (batch, dim, N) state, which is the same arithmetic in the same order per step.
+    `compute_dtype=torch.float64` gives a higher-precision variant for tolerance studies.
+    """
+    if A.is_complex():
+        raise NotImplementedError("complex A is not on the SegMamba path (SURVEY.md §2.1)")
+    if B.dim() < 3 or C.dim() < 3:
+        raise NotImplementedError("constant B/C is not on the SegMamba path (SURVEY.md §2.1)")
+    dtype_in = u.dtype
+    cd = compute_dtype
+    u_ = u.to(cd)
+    dl = delta.to(cd)
+    if delta_bias is not None:
+        dl = dl + delta_bias.to(cd)[..., None]
+    if delta_softplus:
+        dl = F.softplus(dl)
+    batch, dim, L = u_.shape
+    N = A.shape[1]
+    A_ = A.to(cd)
+    Bm = B.to(cd)
+    Cm = C.to(cd)
+    if Bm.dim() == 3:
+        Bm = Bm[:, None]
+    if Cm.dim() == 3:
+        Cm = Cm[:, None]
+    # (batch, G, N, L) -> (batch, dim, N, L) by repeating each group over its dim//G channels
+    Bm = Bm.repeat_interleave(dim // Bm.shape[1], dim=1)
+    Cm = Cm.repeat_interleave(dim // Cm.shape[1], dim=1)
+
+    h = u_.new_zeros((batch, dim, N))
+    ys = []
+    for t in range(L):
+        dA = torch.exp(dl[:, :, t, None] * A_)                               # (b, d, n)
+        h = dA * h + (dl[:, :, t] * u_[:, :, t])[..., None] * Bm[:, :, :, t]
+        ys.append((h * Cm[:, :, :, t]).sum(-1))
+    y = torch.stack(ys, dim=2)
+    out = y if D is None else y + u_ * D.to(cd)[:, None]
+    if z is not None:
+        out = out * F.silu(z.to(cd))
+    out = out.to(dtype_in)
+    return (out, h) if return_last_state else out
+
+
+# --------------------------------------------------------------------------------------
+# causal depthwise conv1d
+# --------------------------------------------------------------------------------------
+def causal_conv1d_ref(x, weight, bias=None, activation=None):
+    """causal-conv1d/causal_conv1d/causal_conv1d_interface.py:49-65 (`causal_conv1d_ref`).
+
+    x : (batch, dim, L)   weight : (dim, width)   bias : (dim,)
+    out[b, d, t] = bias[d] + sum_w weight[d, w] * x[b, d, t - (width-1-w)]  (zero left pad), then SiLU.
+    """
+    if activation not in (None, "silu", "swish"):
+        raise NotImplementedError("activation must be None, silu, or swish")
+    dtype_in = x.dtype
+    xw = x.to(weight.dtype)
+    L = xw.shape[-1]
+    dim, width = weight.shape
+    out = F.conv1d(xw, weight[:, None, :], bias, padding=width - 1, groups=dim)[..., :L]
+    if activation is not None:
+        out = F.silu(out)
+    return out.to(dtype_in)
+
+
+# --------------------------------------------------------------------------------------
+# fused inner function (conv1d -> x_proj -> dt_proj -> scan), no output projection
+# --------------------------------------------------------------------------------------
+def mamba_inner_no_out_proj_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                                A, D=None, delta_bias=None, delta_softplus=True):
+    """mamba/mamba_ssm/ops/selective_scan_interface.py:636-670 (`mamba_inner_ref`) without the final
+    `F.linear(..., out_proj_weight)`, i.e. the value `MambaInnerFnNoOutProj` returns (:155-224).
+
+    xz : (batch, 2*dim, L) -> out_z : (batch, dim, L)
+    """
+    L = xz.shape[-1]
+    R = delta_proj_weight.shape[1]
+    N = A.shape[-1]
+    x, z = xz.chunk(2, dim=1)
+    xc = causal_conv1d_ref(x, conv1d_weight.reshape(conv1d_weight.shape[0], -1), conv1d_bias, "silu")
+    batch, dim, _ = xc.shape
+    x_dbl = F.linear(xc.permute(0, 2, 1).reshape(batch * L, dim), x_proj_weight)       # (b*l, R+2N)
+    delta = (delta_proj_weight @ x_dbl[:, :R].t()).reshape(dim, batch, L).permute(1, 0, 2)
+    Bm = x_dbl[:, R:R + N].reshape(batch, L, N).permute(0, 2, 1).contiguous()
+    Cm = x_dbl[:, -N:].reshape(batch, L, N).permute(0, 2, 1).contiguous()
+    return selective_scan_ref(xc, delta, A, Bm, Cm, D, z=z, delta_bias=delta_bias,
+                              delta_softplus=delta_softplus)
+
+
+# --------------------------------------------------------------------------------------
+# Mamba block, bimamba_type == "v3"
+# --------------------------------------------------------------------------------------
+def slice_interleave(x, nslices):
+    """mamba_simple.py:245-247: new[..., j*ns + k] = old[..., k*(L/ns) + j]."""
+    L = x.shape[-1]
+    return x.reshape(*x.shape[:-1], nslices, L // nslices).transpose(-1, -2).reshape(*x.shape[:-1], L)
+
+
+def slice_deinterleave(x, nslices):
+    """mamba_simple.py:261: inverse of `slice_interleave`."""
+    L = x.shape[-1]
+    return x.reshape(*x.shape[:-1], L // nslices, nslices).transpose(-1, -2).reshape(*x.shape[:-1], L)
+
+
+def mamba_v3_forward_ref(hidden_states, p, nslices):
+    """mamba/mamba_ssm/modules/mamba_simple.py:188-264, `bimamba_type == "v3"` branch.
+
+    hidden_states : (batch, L, d_model); `p` maps the reference parameter names
+    (`in_proj.weight`, `conv1d.weight`, ..., `A_log`, `D`, `*_b`, `*_s`, `out_proj.weight`) to tensors.
+    """
+    batch, L, _ = hidden_states.shape
+    xz = (p["in_proj.weight"] @ hidden_states.reshape(batch * L, -1).t())           # (2D, b*l)
+    xz = xz.reshape(-1, batch, L).permute(1, 0, 2)                                    # (b, 2D, l)
+    if p.get("in_proj.bias") is not None:
+        xz = xz + p["in_proj.bias"].to(xz.dtype)[:, None]
+
+    def direction(suffix, xz_dir):
+        A = -torch.exp(p["A" + suffix + "_log"].float())
+        return mamba_inner_no_out_proj_ref(
+            xz_dir, p["conv1d" + suffix + ".weight"], p["conv1d" + suffix + ".bias"],
+            p["x_proj" + suffix + ".weight"], p["dt_proj" + suffix + ".weight"], A,
+            p["D" + suffix].float(), delta_bias=p["dt_proj" + suffix + ".bias"].float(), delta_softplus=True)
+
+    out = direction("", xz)
+    out_b = direction("_b", xz.flip([-1])).flip([-1])
+    out_s = slice_deinterleave(direction("_s", slice_interleave(xz, nslices)), nslices)
+    y = (out + out_b + out_s).permute(0, 2, 1)                                        # (b, l, D)
+    return F.linear(y, p["out_proj.weight"], p.get("out_proj.bias"))
+
+
+# --------------------------------------------------------------------------------------
+# closed-form backward of the scan (Appendix A of SURVEY.md), fp64, used as an independent check
+# --------------------------------------------------------------------------------------
+def selective_scan_bwd_closed_form(u, delta, A, B, C, D, z, delta_bias, dout, delta_softplus=True):
+    """Gradients from the explicit recurrences the native kernels implement
+    (mamba/csrc/selective_scan/selective_scan_bwd_kernel.cuh:161-478), evaluated in fp64 with
+    G == 1.  Returns dict(du, ddelta, dA, dB, dC, dD, dz, ddelta_bias).
+    """
+    f8 = torch.float64
+    u, delta, A, B, C, dout = (t.to(f8) for t in (u, delta, A, B, C, dout))
+    if B.dim() == 4:
+        B = B[:, 0]
+    if C.dim() == 4:
+        C = C[:, 0]
+    batch, dim, L = u.shape
+    N = A.shape[1]
+    raw = delta + (delta_bias.to(f8)[:, None] if delta_bias is not None else 0.0)
+    dl = F.softplus(raw) if delta_softplus else raw
+    hs = torch.zeros(batch, dim, L + 1, N, dtype=f8)
+    for t in range(L):
+        a = torch.exp(dl[:, :, t, None] * A)
+        hs[:, :, t + 1] = a * hs[:, :, t] + (dl[:, :, t] * u[:, :, t])[..., None] * B[:, None, :, t]
+    y = torch.einsum("bdtn,bnt->bdt", hs[:, :, 1:], C) + (D.to(f8)[:, None] * u if D is not None else 0.0)
+    if z is not None:
+        zz = z.to(f8)
+        sig = torch.sigmoid(zz)
+        g = dout * zz * sig
+        dz = dout * y * sig * (1 + zz * (1 - sig))
+    else:
+        g, dz = dout, None
+    du = (D.to(f8)[:, None] * g) if D is not None else torch.zeros_like(u)
+    ddl = torch.zeros_like(dl)
+    dA = torch.zeros_like(A)
+    dB = torch.zeros_like(B)
+    dC = torch.einsum("bdt,bdtn->bnt", g, hs[:, :, 1:])
+    dh_next = torch.zeros(batch, dim, N, dtype=f8)     # a_{t+1} * dh_{t+1}
+    for t in range(L - 1, -1, -1):
+        a = torch.exp(dl[:, :, t, None] * A)
+        dh = dh_next + g[:, :, t, None] * C[:, None, :, t]
+        hprev = hs[:, :, t]
+        da = dh * hprev                                 # dL/da_{n,t}
+        du[:, :, t] += dl[:, :, t] * (dh * B[:, None, :, t]).sum(-1)
+        ddl[:, :, t] = (dh * B[:, None, :, t]).sum(-1) * u[:, :, t] + (da * a * A).sum(-1)
+        dA += (da * a * dl[:, :, t, None]).sum(0)
+        dB[:, :, t] = (dh * (dl[:, :, t] * u[:, :, t])[..., None]).sum(1)
+        dh_next = a * dh
+    if delta_softplus:
+        ddelta = ddl * torch.sigmoid(raw)
+    else:
+        ddelta = ddl
+    out = dict(du=du, ddelta=ddelta, dA=dA, dB=dB, dC=dC, dz=dz,
+               dD=(g * u).sum((0, 2)) if D is not None else None,
+               ddelta_bias=ddelta.sum((0, 2)) if delta_bias is not None else None)
+    return out
+
+
+def softplus_inverse(dt):
+    """mamba_simple.py:105 : inv_dt = dt + log(-expm1(-dt))."""
+    return dt + torch.log(-torch.expm1(-dt))
+
+
+def algorithmic_bytes_scan(batch, dim, L, N, esize, G=1, backward=False):
+    """the byte count `roofline.achieved` is computed from."""
+    if not backward:
+        return esize * batch * L * (5 * dim + 2 * G * N)
+    return batch * L * (esize * (8 * dim + 2 * G * N) + 8 * G * N)
