@@ -1,0 +1,187 @@
+/*
+ * segmamba_hip.h - C ABI of libsegmamba_hip.so: the MI355X (gfx950) kernels of SegMamba's hot path.
+ *
+ * Every entry point replaces one native binding of the reference (ge-xing/SegMamba); the reference
+ * line it replaces is cited next to it.  Plain pointers, sizes and strides only - no torch types.
+ *
+ *   - all tensors are caller-allocated DEVICE memory; the library never allocates, frees or retains
+ *     a pointer (SURVEY.md §8b "Ownership");
+ *   - every call is asynchronous on `stream` (a hipStream_t; NULL = the null stream) and may be issued
+ *     concurrently from several host threads / processes;
+ *   - return value: 0 on success, <0 = SEGM_E_* argument error (nothing was launched),
+ *     >0 = the hipError_t reported by a launch.
+ *
+ * Layout.  Sequence tensors are described by explicit element strides for the logical index
+ * (batch, time, channel), so both the reference's channel-first (B, D, L) tensors
+ * (stride_t == 1) and the channel-last (B, L, D) tensors the kernels are tuned for
+ * (stride_d == 1: one lane per channel, coalesced 64-channel rows) are accepted as they are.
+ * Views into larger buffers (e.g. the x / z halves of `xz`, or dx / dz halves of `dxz`,
+ * reference selective_scan_interface.py:175,244-245) are expressed through the strides.
+ *
+ * Time order.  The tri-directional Mamba block (reference mamba_simple.py:215-264) runs the same
+ * operator on the sequence as stored, reversed (`xz.flip(-1)`, :231) and slice-interleaved
+ * (`stack(chunk(nslices))`, :245-247).  Instead of materialising those copies, every operator takes
+ * `time_order`: logical step tau is read from / written to physical index
+ *      FORWARD      t = tau
+ *      REVERSED     t = L-1-tau
+ *      INTERLEAVED  t = (tau % nslices) * (L / nslices) + tau / nslices      (needs L % nslices == 0)
+ * so outputs land where the reference's `.flip(-1)` / inverse permutation (:261,264) would put them.
+ */
+#ifndef SEGMAMBA_HIP_H
+#define SEGMAMBA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEGM_ABI_VERSION 1
+
+enum segm_dtype { SEGM_F32 = 0, SEGM_F16 = 1, SEGM_BF16 = 2 };
+enum segm_time_order { SEGM_TIME_FORWARD = 0, SEGM_TIME_REVERSED = 1, SEGM_TIME_INTERLEAVED = 2 };
+
+enum segm_status {
+    SEGM_OK = 0,
+    SEGM_E_NULL = -1,        /* a required pointer is NULL                                            */
+    SEGM_E_SHAPE = -2,       /* non-positive size, dim % n_groups != 0, L % nslices != 0, ...        */
+    SEGM_E_DSTATE = -3,      /* dstate outside [1, 16]  (reference limit is 256, selective_scan.cpp:247;
+                                SegMamba uses 16)                                                      */
+    SEGM_E_DTYPE = -4,       /* unknown dtype code                                                    */
+    SEGM_E_WIDTH = -5,       /* conv width outside [2, 4]  (reference causal_conv1d.cpp:157)          */
+    SEGM_E_WORKSPACE = -6,   /* workspace pointer NULL or too small                                   */
+    SEGM_E_TIME_ORDER = -7   /* unknown time order                                                    */
+};
+
+/* logical (batch, time, channel) view; strides in ELEMENTS */
+typedef struct segm_seq {
+    void* ptr;
+    int64_t stride_b, stride_t, stride_d;
+} segm_seq;
+
+/* logical (batch, group, time, state) view of the input-dependent B / C matrices; strides in ELEMENTS */
+typedef struct segm_bc {
+    void* ptr;
+    int64_t stride_b, stride_g, stride_t, stride_n;
+} segm_bc;
+
+/* ------------------------------------------------------------------------------------------------
+ * Selective scan, forward.
+ * Replaces  selective_scan_cuda.fwd(u, delta, A, B, C, D?, z?, delta_bias?, delta_softplus)
+ *           -> [out, x, (out_z)]      reference mamba/csrc/selective_scan/selective_scan.cpp:226-336
+ *           (kernel selective_scan_fwd_kernel.cuh:67-303).
+ *
+ *   h_t = exp(delta_t * A) . h_{t-1} + delta_t * u_t * B_t ,  y_t = <C_t, h_t> + D * u_t ,
+ *   out = y ,  out_z = y * silu(z) ,  delta = softplus(delta + delta_bias) if delta_softplus.
+ *
+ * Real A, input-dependent B and C (the only variant on the SegMamba path).
+ * Instead of the reference's opaque `x` (per-2048-chunk scan state, selective_scan.cpp:304-313) the
+ * state needed by the backward is an opaque checkpoint buffer `ckpt` of
+ * segm_selective_scan_ckpt_bytes(); the reference's only other use of `x`
+ * (`last_state = x[:, :, -1, 1::2]`, selective_scan_interface.py:40) is the explicit `last_state`.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_scan_fwd_args {
+    int32_t batch, dim, dstate, n_groups;
+    int64_t seqlen;
+    int32_t dtype;            /* segm_dtype of u, delta, z, B, C, out, out_z                         */
+    int32_t delta_softplus;
+    int32_t time_order;       /* segm_time_order                                                     */
+    int32_t nslices;          /* INTERLEAVED only                                                    */
+    int32_t chunk;            /* steps per work item; 0 = choose. Must match between fwd and bwd     */
+    int32_t reserved;
+    segm_seq u, delta;        /* required                                                            */
+    segm_seq z;               /* ptr NULL = no gate                                                  */
+    segm_seq out;             /* ptr NULL = do not store the un-gated y                              */
+    segm_seq out_z;           /* required iff z.ptr                                                  */
+    segm_bc B, C;             /* required                                                            */
+    const float* A;           /* (dim, dstate) contiguous, fp32                                      */
+    const float* D;           /* (dim) fp32 or NULL                                                  */
+    const float* delta_bias;  /* (dim) fp32 or NULL                                                  */
+    float* last_state;        /* (batch, dim, dstate) contiguous fp32 or NULL                        */
+    float* ckpt;              /* segm_selective_scan_ckpt_bytes() or NULL (inference)                */
+    void* workspace;          /* segm_selective_scan_fwd_workspace_bytes()                           */
+    size_t workspace_bytes;
+    void* stream;
+} segm_scan_fwd_args;
+
+int segm_selective_scan_fwd(const segm_scan_fwd_args* args);
+size_t segm_selective_scan_fwd_workspace_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen,
+                                               int32_t chunk);
+size_t segm_selective_scan_ckpt_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen);
+/* the chunk length `chunk = 0` resolves to (so callers can record it for the backward) */
+int32_t segm_selective_scan_default_chunk(int32_t batch, int32_t dim, int64_t seqlen);
+
+/* ------------------------------------------------------------------------------------------------
+ * Selective scan, backward.
+ * Replaces  selective_scan_cuda.bwd(u, delta, A, B, C, D?, z?, delta_bias?, dout, x?, out?, dz?,
+ *                                   delta_softplus, recompute_out_z)
+ *           -> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]
+ *           reference selective_scan.cpp:338-492 (kernel selective_scan_bwd_kernel.cuh:75-489).
+ *
+ * du / ddelta / dz may alias slices of a larger buffer (dx / dz halves of dxz).  dA, dD,
+ * ddelta_bias, dB, dC are fp32 and are OVERWRITTEN (the reference zero-fills then accumulates,
+ * selective_scan.cpp:460-466; here the library clears what it accumulates into).
+ * `out` (the un-gated y written by the forward) is required iff z.ptr; `ckpt` is the forward's.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_scan_bwd_args {
+    segm_scan_fwd_args f;     /* same meaning as in the forward; f.out = saved y (read), f.out_z ignored,
+                                 f.last_state ignored, f.workspace ignored                             */
+    segm_seq dout;            /* required; gradient w.r.t. out_z (or out when no z)                    */
+    segm_seq du, ddelta;      /* required                                                             */
+    segm_seq dz;              /* required iff f.z.ptr                                                  */
+    segm_bc dB, dC;           /* fp32, logical (batch, group, time, state)                             */
+    float* dA;                /* (dim, dstate) fp32                                                    */
+    float* dD;                /* (dim) fp32 or NULL                                                    */
+    float* ddelta_bias;       /* (dim) fp32 or NULL                                                    */
+    void* workspace;          /* segm_selective_scan_bwd_workspace_bytes()                             */
+    size_t workspace_bytes;
+} segm_scan_bwd_args;
+
+int segm_selective_scan_bwd(const segm_scan_bwd_args* args);
+size_t segm_selective_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen,
+                                               int32_t chunk);
+
+/* ------------------------------------------------------------------------------------------------
+ * Causal depthwise conv1d (+ optional SiLU), forward / backward.
+ * Replaces  causal_conv1d_cuda.causal_conv1d_fwd(x, weight, bias?, silu) -> out
+ *           reference causal-conv1d/csrc/causal_conv1d.cpp:130-189 (kernel causal_conv1d_fwd.cu:39-130)
+ *      and  causal_conv1d_cuda.causal_conv1d_bwd(x, weight, bias?, dout, dx?, silu)
+ *           -> [dx, dweight, dbias]   reference causal_conv1d.cpp:191-268 (kernel causal_conv1d_bwd.cu:46-240).
+ *
+ *   o_t = bias + sum_w weight[d, w] * x_{t-(width-1-w)}   (zero left pad),  out = o * sigmoid(o) if silu.
+ *
+ * weight (dim, width) and bias (dim) are fp32 contiguous (the reference also accepts 16-bit
+ * weights; cast on the host).  dweight / dbias are fp32 and OVERWRITTEN.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_conv1d_args {
+    int32_t batch, dim, width, silu;
+    int64_t seqlen;
+    int32_t dtype;            /* of x, out, dout, dx */
+    int32_t time_order, nslices;
+    int32_t reserved;
+    segm_seq x;               /* required */
+    segm_seq out;             /* forward: required.  backward: ignored */
+    const float* weight;      /* required */
+    const float* bias;        /* or NULL  */
+    /* backward only */
+    segm_seq dout, dx;
+    float* dweight;           /* (dim, width) */
+    float* dbias;             /* (dim) or NULL */
+    void* workspace;          /* backward: segm_causal_conv1d_bwd_workspace_bytes() */
+    size_t workspace_bytes;
+    void* stream;
+} segm_conv1d_args;
+
+int segm_causal_conv1d_fwd(const segm_conv1d_args* args);
+int segm_causal_conv1d_bwd(const segm_conv1d_args* args);
+size_t segm_causal_conv1d_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t width, int64_t seqlen);
+
+/* ------------------------------------------------------------------------------------------------ */
+int segm_abi_version(void);
+const char* segm_status_string(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGMAMBA_HIP_H */

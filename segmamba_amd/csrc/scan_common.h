@@ -1,0 +1,117 @@
+// Shared pieces of the selective-scan forward / backward kernels.
+#pragma once
+#include "segm_device.h"
+
+namespace segm {
+
+constexpr int kCarrySegs = 16;        // waves per workgroup of the carry kernel, each owning 1/16 of the chunks
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Device-side argument block of the scan kernels: one B/C group, channel offset already applied.
+struct ScanDev {
+    Geom gm;
+    TimeMap tm;
+    Seq u, delta, z, out, out_z;          // z.p / out.p / out_z.p may be null
+    BC Bm, Cm;
+    const float* A;                        // (dim, nstate)
+    const float* D;                        // (dim) or null
+    const float* delta_bias;               // (dim) or null
+    int32_t delta_softplus;
+    // forward workspace (fp32), all laid out [batch][chunk][...][dim] so that lanes (channels) are contiguous
+    float* agg_sd;                         // [batch][nchunks][dim]          sum of delta over the chunk
+    float* agg_h;                          // [batch][nchunks][nstate][dim]  chunk end state from a zero start
+    float* carry;                          // [batch][nchunks][nstate][dim]  state entering the chunk
+    float* ckpt;                           // [batch][nck][nstate][dim]      state entering step 32*k (or null)
+    int32_t nck;
+    float* last_state;                     // (batch, dim, nstate) or null
+    int64_t last_state_sb;                 // = full_dim * nstate
+    // backward only
+    Seq dout, du, ddelta, dz;
+    float* dB;  int64_t dB_sb, dB_st, dB_sn;   // fp32 (one group)
+    float* dC;  int64_t dC_sb, dC_st, dC_sn;
+    float* part;                           // [batch][nchunks][nstate + 2][dim]  per-item dA / dD / ddelta_bias partials
+    int32_t atomic_bc;                     // more than one d-tile contributes to dB / dC -> accumulate atomically
+};
+
+// --- staging of the rows shared by all channels (B_t, C_t) ---------------------------------------------
+// Each work item's own RW lanes fetch the TS x NS block of one matrix for the TS consecutive logical steps
+// tau0 .. tau0+TS-1 (`it0` = the item's iterator positioned at tau0) into registers (`stage_fetch`) and
+// later park them in LDS as fp32 (`stage_park`).  LDS layout per item: [s][n] (ROWMAJOR) for the forward
+// (all states of one step are read together), [n][s] for the backward (all steps of one state are read
+// together).  Rows outside [0, L) and states >= nstate are zero.  Loads are unconditional (the address is
+// clamped to element 0 of the batch, the value masked) so no divergent branches are generated.
+template <int TS, int NS, int RW> struct StageRegs { float v[TS * NS / RW]; };
+
+template <typename T, int TS, int NS, int RW>
+__device__ __forceinline__ void stage_fetch(StageRegs<TS, NS, RW>& rg, const BC& m, const TimeMap& tm, const TimeIter& it0,
+                                            int b, int nstate, int r, bool item_ok) {
+    const bool t_fastest = m.st <= m.sn;     // pick the lane -> element order that is contiguous in memory
+    const T* base = reinterpret_cast<const T*>(m.p) + (int64_t)b * m.sb;
+#pragma unroll
+    for (int i = 0; i < TS * NS / RW; ++i) {
+        const int e = r + i * RW;
+        int s, n;
+        if (t_fastest) { n = e / TS; s = e - n * TS; } else { s = e / NS; n = e - s * NS; }
+        const bool ok = item_ok && n < nstate && (it0.tau + s) < tm.L;
+        const int32_t t = ok ? it0.ahead(tm, s) : 0;
+        const float v = to_f32(base[row_off(t, m.st) + (ok ? (int64_t)n * m.sn : 0)]);
+        rg.v[i] = ok ? v : 0.f;
+    }
+}
+
+template <int TS, int NS, int RW, bool ROWMAJOR>
+__device__ __forceinline__ void stage_park(const StageRegs<TS, NS, RW>& rg, float* lds_item, bool t_fastest, int r) {
+#pragma unroll
+    for (int i = 0; i < TS * NS / RW; ++i) {
+        const int e = r + i * RW;
+        int s, n;
+        if (t_fastest) { n = e / TS; s = e - n * TS; } else { s = e / NS; n = e - s * NS; }
+        lds_item[ROWMAJOR ? (s * NS + n) : (n * TS + s)] = rg.v[i];
+    }
+}
+
+// Physical row index of the TS consecutive logical steps starting at `tj` (0 where the step is past L or the
+// lane owns no channel: such rows are loaded from row 0 and masked) and the mask of real rows.
+template <int TS>
+__device__ __forceinline__ uint32_t row_indices(int32_t (&tt)[TS], const TimeMap& tm, TimeIter tj, bool lane_ok) {
+    uint32_t okm = 0;
+#pragma unroll
+    for (int j = 0; j < TS; ++j) {
+        const bool ok = lane_ok && tj.tau < tm.L;
+        tt[j] = ok ? tj.t : 0;
+        okm |= ok ? (1u << j) : 0u;
+        tj.next(tm);
+    }
+    return okm;
+}
+
+// Per-lane rows of a sequence tensor.  Unconditional loads, masked values.
+template <typename T, int TS>
+__device__ __forceinline__ void fetch_rows(float (&dst)[TS], const Seq& s, const T* lane_base, const int32_t (&tt)[TS],
+                                           uint32_t okm) {
+#pragma unroll
+    for (int j = 0; j < TS; ++j) {
+        const float v = to_f32(lane_base[row_off(tt[j], s.st)]);
+        dst[j] = ((okm >> j) & 1u) ? v : 0.f;
+    }
+}
+
+// pointer to (batch b, channel d) of a sequence tensor; channel clamped to 0 for lanes without a channel
+template <typename T> __device__ __forceinline__ T* lane_ptr(const Seq& s, int b, int d, bool lane_ok) {
+    return reinterpret_cast<T*>(s.p) + (int64_t)b * s.sb + (lane_ok ? (int64_t)d * s.sd : 0);
+}
+
+
+// ---- host helpers shared by scan_fwd.hip / scan_bwd.hip -------------------------------------------------
+Geom make_geom(int batch, int dim, int nstate, int64_t L, int chunk);
+int32_t default_chunk(int32_t batch, int32_t dim, int64_t L);
+int validate_scan_common(const segm_scan_fwd_args* a);
+TimeMap make_timemap(int time_order, int nslices, int64_t L);
+Seq seq_at(const segm_seq& s, int64_t d0, size_t esize);
+BC bc_at(const segm_bc& m, int g, size_t esize);
+size_t dtype_size(int dtype);
+void fill_scan_dev(ScanDev& P, const segm_scan_fwd_args* a, int g, int chunk);
+void launch_scan_carry(const ScanDev& P, bool reverse, const float* agg_sd, const float* agg_h, float* carry,
+                       hipStream_t stream);
+
+}  // namespace segm

@@ -1,0 +1,469 @@
+// Selective scan, forward (C ABI: segm_selective_scan_fwd).
+//
+// Replaces reference mamba/csrc/selective_scan/selective_scan_fwd_kernel.cuh:67-303 + selective_scan.cpp:226-336.
+// The reference walks L serially inside one block per (batch, channel) and block-scans 2048-step
+// tiles per state; on 256 CUs that is < 1 block per CU at SegMamba's stage 0.
+// Here L is cut into chunks handled by independent lanes (one lane = one channel, state in registers):
+//
+//   K1  scan_fwd_agg_kernel    per (batch, chunk, channel): chunk end state from a zero start, sum(delta)
+//   K2  scan_carry_kernel      per (batch, channel, state): compose the chunk aggregates into the state
+//                              entering every chunk      (h_in[c+1] = exp(A * sum_delta[c]) * h_in[c] + H[c])
+//   K3  scan_fwd_apply_kernel  per (batch, chunk, channel): re-run the chunk from its true entering state,
+//                              y = <C, h> + D u, out_z = y silu(z); optionally checkpoint h every 32 steps
+//
+// The monoid (a1, b1) o (a0, b0) = (a1 a0, a1 b0 + b1) is the reference's SSMScanOp
+// (selective_scan_common.h:110-115); the product of a's over a chunk is exp(A * sum of delta), so only the
+// sum is stored.  All state / accumulation is fp32; I/O is fp32, fp16 or bf16.
+#include <string.h>
+
+#include "scan_common.h"
+
+namespace segm {
+
+// ------------------------------------------------------------------------------------------------------
+// K1: chunk aggregates
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int NS, int TS, int RW>
+__global__ void __launch_bounds__(kBlock) scan_fwd_agg_kernel(ScanDev P) {
+    constexpr int G = 64 / RW;
+    __shared__ __attribute__((aligned(16))) float s_b[2][kWavesPerBlock][G][TS * NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Geom& gm = P.gm;
+    const TimeMap tm = P.tm;
+    const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const bool item_ok = it.wave_valid && it.chunk < gm.nchunks;
+    const int nstate = gm.nstate;
+
+    float A2[NS], h[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        A2[n] = (it.valid && n < nstate) ? P.A[(int64_t)it.d * nstate + n] * kLog2e : 0.f;
+        h[n] = 0.f;
+    }
+    const float bias = (it.valid && P.delta_bias) ? P.delta_bias[it.d] : 0.f;
+    const T* up = lane_ptr<T>(P.u, it.b, it.d, it.valid);
+    const T* dp = lane_ptr<T>(P.delta, it.b, it.d, it.valid);
+    const bool t_fastest = P.Bm.st <= P.Bm.sn;
+
+    TimeIter ti;
+    ti.seek(tm, item_ok ? it.chunk * gm.chunk : 0);
+
+    float nu[TS], nd[TS];
+    int32_t ntt[TS];
+    StageRegs<TS, NS, RW> sb;
+    uint32_t nok = row_indices<TS>(ntt, tm, ti, it.valid);
+    fetch_rows<T, TS>(nu, P.u, up, ntt, nok);
+    fetch_rows<T, TS>(nd, P.delta, dp, ntt, nok);
+    stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, it.b, nstate, it.r, item_ok);
+
+    float sumd = 0.f;
+    int buf = 0;
+    for (int s0 = 0; s0 < gm.chunk; s0 += TS) {
+        float* lb = &s_b[buf][wave][it.gi][0];
+        stage_park<TS, NS, RW, true>(sb, lb, t_fastest, it.r);
+        __syncthreads();
+        float cu[TS], cd[TS];
+#pragma unroll
+        for (int j = 0; j < TS; ++j) { cu[j] = nu[j]; cd[j] = nd[j]; }
+        const uint32_t cok = nok;
+        ti.jump(tm, TS);
+        // prefetch the next sub-tile (past the chunk end this reads the neighbour's / masked rows: harmless)
+        nok = row_indices<TS>(ntt, tm, ti, it.valid);
+        fetch_rows<T, TS>(nu, P.u, up, ntt, nok);
+        fetch_rows<T, TS>(nd, P.delta, dp, ntt, nok);
+        stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, it.b, nstate, it.r, item_ok);
+#pragma unroll
+        for (int j = 0; j < TS; ++j) {
+            const bool ok = (cok >> j) & 1u;
+            float dl = cd[j] + bias;
+            if (P.delta_softplus) dl = softplus20(dl);
+            dl = ok ? dl : 0.f;
+            const float dlu = dl * cu[j];
+            sumd += dl;
+            const float4* B4 = reinterpret_cast<const float4*>(lb + j * NS);
+#pragma unroll
+            for (int q = 0; q < NS / 4; ++q) {
+                const float4 bv = B4[q];
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = q * 4 + i;
+                    const float a = fast_exp2(dl * A2[n]);
+                    h[n] = fmaf(a, h[n], dlu * bb[i]);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+    if (it.valid) {
+        const int64_t row = (int64_t)it.b * gm.nchunks + it.chunk;
+        P.agg_sd[row * gm.dim + it.d] = sumd;
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+            if (n < nstate) P.agg_h[(row * nstate + n) * gm.dim + it.d] = h[n];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2: compose chunk aggregates into the state entering every chunk.  One thread per (batch, channel, state),
+// 16 waves per workgroup each owning 1/16 of the chunks: local fold, 16-entry LDS fold, re-walk.
+// REVERSE walks the chunks from last to first (backward pass: the adjoint state entering from the right).
+// ------------------------------------------------------------------------------------------------------
+template <bool REVERSE>
+__global__ void __launch_bounds__(kCarrySegs * 64) scan_carry_kernel(ScanDev P, const float* __restrict__ agg_sd,
+                                                                     const float* __restrict__ agg_h,
+                                                                     float* __restrict__ carry) {
+    __shared__ float s_p[kCarrySegs][64];
+    __shared__ float s_h[kCarrySegs][64];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const Geom& gm = P.gm;
+    const int d = blockIdx.x * 64 + lane, n = blockIdx.y, b = blockIdx.z;
+    const bool valid = d < gm.dim;
+    const int dd = valid ? d : 0;
+    const int nstate = gm.nstate;
+    const int nch = gm.nchunks;
+    const int per = (nch + kCarrySegs - 1) / kCarrySegs;
+    const int q0 = seg * per;
+    const int q1 = (q0 + per < nch) ? q0 + per : nch;
+    const float A2 = valid ? P.A[(int64_t)d * nstate + n] * kLog2e : 0.f;
+
+    float acc = 0.f, sds = 0.f;
+#pragma unroll 4
+    for (int q = q0; q < q1; ++q) {
+        const int c = REVERSE ? nch - 1 - q : q;
+        const int64_t row = (int64_t)b * nch + c;
+        const float sd = agg_sd[row * gm.dim + dd];
+        const float hh = agg_h[(row * nstate + n) * gm.dim + dd];
+        acc = fmaf(fast_exp2(A2 * sd), acc, hh);
+        sds += sd;
+    }
+    s_p[seg][lane] = fast_exp2(A2 * sds);
+    s_h[seg][lane] = acc;
+    __syncthreads();
+    float cin = 0.f;
+    for (int s = 0; s < seg; ++s) cin = fmaf(s_p[s][lane], cin, s_h[s][lane]);
+#pragma unroll 4
+    for (int q = q0; q < q1; ++q) {
+        const int c = REVERSE ? nch - 1 - q : q;
+        const int64_t row = (int64_t)b * nch + c;
+        const float sd = agg_sd[row * gm.dim + dd];
+        const float hh = agg_h[(row * nstate + n) * gm.dim + dd];
+        if (valid) carry[(row * nstate + n) * gm.dim + d] = cin;
+        cin = fmaf(fast_exp2(A2 * sd), cin, hh);
+    }
+    if (!REVERSE && P.last_state && valid && q0 < nch && q1 == nch)
+        P.last_state[(int64_t)b * P.last_state_sb + (int64_t)d * nstate + n] = cin;
+}
+
+void launch_scan_carry(const ScanDev& P, bool reverse, const float* agg_sd, const float* agg_h, float* carry,
+                       hipStream_t stream) {
+    const Geom& gm = P.gm;
+    dim3 cgrid((gm.dim + 63) / 64, gm.nstate, gm.batch);
+    if (reverse)
+        hipLaunchKernelGGL((scan_carry_kernel<true>), cgrid, dim3(kCarrySegs * 64), 0, stream, P, agg_sd, agg_h, carry);
+    else
+        hipLaunchKernelGGL((scan_carry_kernel<false>), cgrid, dim3(kCarrySegs * 64), 0, stream, P, agg_sd, agg_h, carry);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3: apply
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int NS, int TS, int RW>
+__global__ void __launch_bounds__(kBlock) scan_fwd_apply_kernel(ScanDev P) {
+    constexpr int G = 64 / RW;
+    __shared__ __attribute__((aligned(16))) float s_bc[2][kWavesPerBlock][G][2][TS * NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Geom& gm = P.gm;
+    const TimeMap tm = P.tm;
+    const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const bool item_ok = it.wave_valid && it.chunk < gm.nchunks;
+    const int nstate = gm.nstate;
+    const bool has_z = P.z.p != nullptr, has_out = P.out.p != nullptr;
+
+    float A2[NS], h[NS];
+    const int64_t crow = (int64_t)it.b * gm.nchunks + it.chunk;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        const bool on = it.valid && n < nstate;
+        A2[n] = on ? P.A[(int64_t)it.d * nstate + n] * kLog2e : 0.f;
+        h[n] = on ? P.carry[(crow * nstate + n) * gm.dim + it.d] : 0.f;
+    }
+    const float bias = (it.valid && P.delta_bias) ? P.delta_bias[it.d] : 0.f;
+    const float Dv = (it.valid && P.D) ? P.D[it.d] : 0.f;
+    const T* up = lane_ptr<T>(P.u, it.b, it.d, it.valid);
+    const T* dp = lane_ptr<T>(P.delta, it.b, it.d, it.valid);
+    const Seq& zs = has_z ? P.z : P.u;                          // without a gate the z stream aliases u (unused)
+    const T* zp = lane_ptr<T>(zs, it.b, it.d, it.valid);
+    T* op = has_out ? lane_ptr<T>(P.out, it.b, it.d, it.valid) : nullptr;
+    T* ozp = has_z ? lane_ptr<T>(P.out_z, it.b, it.d, it.valid) : nullptr;
+    const bool t_fastest = P.Bm.st <= P.Bm.sn;
+
+    TimeIter ti;
+    ti.seek(tm, item_ok ? it.chunk * gm.chunk : 0);
+
+    float nu[TS], nd[TS], nz[TS];
+    int32_t ntt[TS];
+    StageRegs<TS, NS, RW> sb, sc;
+    uint32_t nok = row_indices<TS>(ntt, tm, ti, it.valid);
+    fetch_rows<T, TS>(nu, P.u, up, ntt, nok);
+    fetch_rows<T, TS>(nd, P.delta, dp, ntt, nok);
+    fetch_rows<T, TS>(nz, zs, zp, ntt, nok);
+    stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, it.b, nstate, it.r, item_ok);
+    stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, it.b, nstate, it.r, item_ok);
+
+    int buf = 0;
+    for (int s0 = 0; s0 < gm.chunk; s0 += TS) {
+        float* lb = &s_bc[buf][wave][it.gi][0][0];
+        float* lc = &s_bc[buf][wave][it.gi][1][0];
+        stage_park<TS, NS, RW, true>(sb, lb, t_fastest, it.r);
+        stage_park<TS, NS, RW, true>(sc, lc, t_fastest, it.r);
+        __syncthreads();
+        float cu[TS], cd[TS], cz[TS];
+        int32_t ctt[TS];               // rows of this sub-tile, for the stores
+#pragma unroll
+        for (int j = 0; j < TS; ++j) { cu[j] = nu[j]; cd[j] = nd[j]; cz[j] = nz[j]; ctt[j] = ntt[j]; }
+        const uint32_t cok = nok;
+        const int32_t tau0 = ti.tau;
+        ti.jump(tm, TS);
+        nok = row_indices<TS>(ntt, tm, ti, it.valid);
+        fetch_rows<T, TS>(nu, P.u, up, ntt, nok);
+        fetch_rows<T, TS>(nd, P.delta, dp, ntt, nok);
+        fetch_rows<T, TS>(nz, zs, zp, ntt, nok);
+        stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, it.b, nstate, it.r, item_ok);
+        stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, it.b, nstate, it.r, item_ok);
+        // state entering step tau0, every kCkpt steps (kept for the backward pass)
+        if (P.ckpt && (tau0 % kCkpt) == 0 && it.valid && tau0 < tm.L) {
+            const int64_t krow = (int64_t)it.b * P.nck + tau0 / kCkpt;
+#pragma unroll
+            for (int n = 0; n < NS; ++n)
+                if (n < nstate) P.ckpt[(krow * nstate + n) * gm.dim + it.d] = h[n];
+        }
+#pragma unroll
+        for (int j = 0; j < TS; ++j) {
+            const bool ok = (cok >> j) & 1u;
+            float dl = cd[j] + bias;
+            if (P.delta_softplus) dl = softplus20(dl);
+            dl = ok ? dl : 0.f;
+            const float uu = cu[j];
+            const float dlu = dl * uu;
+            float y = Dv * uu;
+            const float4* B4 = reinterpret_cast<const float4*>(lb + j * NS);
+            const float4* C4 = reinterpret_cast<const float4*>(lc + j * NS);
+#pragma unroll
+            for (int q = 0; q < NS / 4; ++q) {
+                const float4 bv = B4[q], cv = C4[q];
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = q * 4 + i;
+                    const float a = fast_exp2(dl * A2[n]);
+                    h[n] = fmaf(a, h[n], dlu * bb[i]);
+                    y = fmaf(cc[i], h[n], y);
+                }
+            }
+            if (ok) {
+                if (has_out) op[row_off(ctt[j], P.out.st)] = from_f32<T>(y);
+                if (has_z) {
+                    const float zz = cz[j];
+                    ozp[row_off(ctt[j], P.out_z.st)] = from_f32<T>(y * zz * sigmoidf(zz));
+                }
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+static int pick_rw(int dim) {
+    if (dim % 64 == 0) return 64;
+    if (dim % 32 == 0) return 32;
+    if (dim % 16 == 0) return 16;
+    int best = 64, best_pad = ((dim + 63) / 64) * 64;
+    const int cand[2] = {32, 16};
+    for (int c : cand) {
+        int pad = ((dim + c - 1) / c) * c;
+        if (pad < best_pad) { best = c; best_pad = pad; }
+    }
+    return best;
+}
+
+Geom make_geom(int batch, int dim, int nstate, int64_t L, int chunk) {   // L < 2^31 (validated by the caller)
+    Geom g;
+    g.batch = batch; g.dim = dim; g.nstate = nstate; g.L = (int32_t)L;
+    g.rw = pick_rw(dim);
+    g.g = 64 / g.rw;
+    g.ndt = (dim + g.rw - 1) / g.rw;
+    g.chunk = chunk;
+    g.nchunks = (int32_t)((L + chunk - 1) / chunk);
+    g.ncg = (g.nchunks + g.g - 1) / g.g;
+    g.nwaves = (int64_t)batch * g.ndt * g.ncg;
+    return g;
+}
+
+int32_t default_chunk(int32_t batch, int32_t dim, int64_t L) {
+    // aim at ~3 waves per SIMD (256 CUs x 4 SIMDs) while keeping <= 4096 chunks for the carry kernel
+    const double lanes_steps = (double)batch * (double)dim * (double)L;
+    const int64_t c = (int64_t)(lanes_steps / (64.0 * 3072.0));
+    int32_t chunk = kCkpt;
+    while ((int64_t)chunk * 2 <= c && chunk < 4096) chunk *= 2;
+    while ((L + chunk - 1) / chunk > 4096 && chunk < (1 << 20)) chunk *= 2;
+    return chunk;
+}
+
+struct FwdWs { size_t sd, h, carry, total; };
+static FwdWs fwd_ws_layout(int batch, int dim, int nstate, int64_t L, int chunk) {
+    const int64_t nch = (L + chunk - 1) / chunk;
+    FwdWs w;
+    w.sd = 0;
+    w.h = align256((size_t)batch * nch * dim * sizeof(float));
+    w.carry = w.h + align256((size_t)batch * nch * nstate * dim * sizeof(float));
+    w.total = w.carry + align256((size_t)batch * nch * nstate * dim * sizeof(float));
+    return w;
+}
+
+template <typename T, int NS, int RW>
+static int launch_fwd_rw(const ScanDev& P, hipStream_t stream) {
+    constexpr int TS = 8;
+    const Geom& gm = P.gm;
+    const unsigned nblocks = (unsigned)((gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((scan_fwd_agg_kernel<T, NS, TS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+    launch_scan_carry(P, false, P.agg_sd, P.agg_h, P.carry, stream);
+    hipLaunchKernelGGL((scan_fwd_apply_kernel<T, NS, TS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int NS>
+static int launch_fwd(const ScanDev& P, hipStream_t stream) {
+    if (P.gm.rw == 64) return launch_fwd_rw<T, NS, 64>(P, stream);
+    if (P.gm.rw == 32) return launch_fwd_rw<T, NS, 32>(P, stream);
+    return launch_fwd_rw<T, NS, 16>(P, stream);
+}
+
+template <typename T>
+static int launch_fwd_ns(const ScanDev& P, hipStream_t stream) {
+    if (P.gm.nstate <= 4) return launch_fwd<T, 4>(P, stream);
+    if (P.gm.nstate <= 8) return launch_fwd<T, 8>(P, stream);
+    return launch_fwd<T, 16>(P, stream);
+}
+
+// time strides are multiplied as uint32 (row_off)
+static bool strides_ok(const segm_seq& s) { return !s.ptr || (s.stride_t >= 0 && s.stride_t < ((int64_t)1 << 31)); }
+static bool bc_strides_ok(const segm_bc& m) { return !m.ptr || (m.stride_t >= 0 && m.stride_t < ((int64_t)1 << 31)); }
+
+int validate_scan_common(const segm_scan_fwd_args* a) {
+    if (!a) return SEGM_E_NULL;
+    if (a->batch <= 0 || a->dim <= 0 || a->seqlen <= 0 || a->n_groups <= 0) return SEGM_E_SHAPE;
+    if (a->seqlen >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;          // 32-bit time indices
+    if (a->dim % a->n_groups != 0) return SEGM_E_SHAPE;
+    if (a->dstate < 1 || a->dstate > kMaxState) return SEGM_E_DSTATE;
+    if (a->dtype != SEGM_F32 && a->dtype != SEGM_F16 && a->dtype != SEGM_BF16) return SEGM_E_DTYPE;
+    if (a->time_order < SEGM_TIME_FORWARD || a->time_order > SEGM_TIME_INTERLEAVED) return SEGM_E_TIME_ORDER;
+    if (a->time_order == SEGM_TIME_INTERLEAVED && (a->nslices <= 0 || a->seqlen % a->nslices != 0)) return SEGM_E_SHAPE;
+    if (a->chunk < 0 || (a->chunk % kCkpt) != 0) return SEGM_E_SHAPE;
+    if (!a->u.ptr || !a->delta.ptr || !a->B.ptr || !a->C.ptr || !a->A) return SEGM_E_NULL;
+    if (!strides_ok(a->u) || !strides_ok(a->delta) || !strides_ok(a->z) || !strides_ok(a->out) ||
+        !strides_ok(a->out_z) || !bc_strides_ok(a->B) || !bc_strides_ok(a->C))
+        return SEGM_E_SHAPE;
+    return SEGM_OK;
+}
+
+TimeMap make_timemap(int time_order, int nslices, int64_t L) {
+    TimeMap tm;
+    tm.L = (int32_t)L;
+    if (time_order == SEGM_TIME_INTERLEAVED) { tm.ns = nslices; tm.sA = (int32_t)(L / nslices); tm.sW = -(int32_t)(L - 1); tm.base = 0; }
+    else if (time_order == SEGM_TIME_REVERSED) { tm.ns = 1; tm.sA = 0; tm.sW = -1; tm.base = (int32_t)(L - 1); }
+    else { tm.ns = 1; tm.sA = 0; tm.sW = 1; tm.base = 0; }
+    const uint64_t magic = ((uint64_t)1 << 32) / (uint64_t)tm.ns + 1;
+    tm.magic_lo = (uint32_t)magic;
+    tm.magic_hi = (uint32_t)(magic >> 32);
+    return tm;
+}
+
+// offsets a sequence view to channel d0
+Seq seq_at(const segm_seq& s, int64_t d0, size_t esize) {
+    Seq r = make_seq(s);
+    if (r.p) r.p += d0 * s.stride_d * (int64_t)esize;
+    return r;
+}
+BC bc_at(const segm_bc& m, int g, size_t esize) {
+    BC r;
+    r.p = (char*)m.ptr + (int64_t)g * m.stride_g * (int64_t)esize;
+    r.sb = m.stride_b; r.st = m.stride_t; r.sn = m.stride_n;
+    return r;
+}
+size_t dtype_size(int dtype) { return dtype == SEGM_F32 ? 4 : 2; }
+
+// fills the parts of the device argument block shared by forward and backward for B/C group g
+void fill_scan_dev(ScanDev& P, const segm_scan_fwd_args* a, int g, int chunk) {
+    const int G = a->n_groups, Dg = a->dim / G, N = a->dstate;
+    const size_t es = dtype_size(a->dtype);
+    const int64_t d0 = (int64_t)g * Dg;
+    memset(&P, 0, sizeof(P));
+    P.gm = make_geom(a->batch, Dg, N, a->seqlen, chunk);
+    P.tm = make_timemap(a->time_order, a->nslices, a->seqlen);
+    P.u = seq_at(a->u, d0, es); P.delta = seq_at(a->delta, d0, es); P.z = seq_at(a->z, d0, es);
+    P.out = seq_at(a->out, d0, es); P.out_z = seq_at(a->out_z, d0, es);
+    P.Bm = bc_at(a->B, g, es); P.Cm = bc_at(a->C, g, es);
+    P.A = a->A + d0 * N;
+    P.D = a->D ? a->D + d0 : nullptr;
+    P.delta_bias = a->delta_bias ? a->delta_bias + d0 : nullptr;
+    P.delta_softplus = a->delta_softplus;
+    P.nck = (int32_t)((a->seqlen + kCkpt - 1) / kCkpt);
+    P.ckpt = a->ckpt ? a->ckpt + (size_t)g * a->batch * P.nck * N * Dg : nullptr;
+}
+
+}  // namespace segm
+
+using namespace segm;
+
+extern "C" int32_t segm_selective_scan_default_chunk(int32_t batch, int32_t dim, int64_t seqlen) {
+    if (batch <= 0 || dim <= 0 || seqlen <= 0) return kCkpt;
+    return default_chunk(batch, dim, seqlen);
+}
+
+extern "C" size_t segm_selective_scan_fwd_workspace_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen,
+                                                          int32_t chunk) {
+    if (batch <= 0 || dim <= 0 || dstate <= 0 || seqlen <= 0) return 0;
+    if (chunk <= 0) chunk = default_chunk(batch, dim, seqlen);
+    return fwd_ws_layout(batch, dim, dstate, seqlen, chunk).total;
+}
+
+extern "C" size_t segm_selective_scan_ckpt_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen) {
+    if (batch <= 0 || dim <= 0 || dstate <= 0 || seqlen <= 0) return 0;
+    const int64_t nck = (seqlen + kCkpt - 1) / kCkpt;
+    return (size_t)batch * nck * dstate * dim * sizeof(float);
+}
+
+extern "C" int segm_selective_scan_fwd(const segm_scan_fwd_args* a) {
+    int rc = validate_scan_common(a);
+    if (rc != SEGM_OK) return rc;
+    if (a->z.ptr && !a->out_z.ptr) return SEGM_E_NULL;
+    if (!a->z.ptr && !a->out.ptr) return SEGM_E_NULL;
+    const int chunk = a->chunk > 0 ? a->chunk : default_chunk(a->batch, a->dim, a->seqlen);
+    const FwdWs ws = fwd_ws_layout(a->batch, a->dim, a->dstate, a->seqlen, chunk);
+    if (!a->workspace || a->workspace_bytes < ws.total) return SEGM_E_WORKSPACE;
+
+    const int G = a->n_groups, Dg = a->dim / G, N = a->dstate;
+    const int64_t nch = (a->seqlen + chunk - 1) / chunk;
+    hipStream_t stream = (hipStream_t)a->stream;
+    char* wsb = (char*)a->workspace;
+
+    for (int g = 0; g < G; ++g) {
+        ScanDev P;
+        fill_scan_dev(P, a, g, chunk);
+        // per-group slices of the workspace: every region is [batch][rows][Dg]-shaped, group-major
+        P.agg_sd = (float*)(wsb + ws.sd) + (size_t)g * a->batch * nch * Dg;
+        P.agg_h = (float*)(wsb + ws.h) + (size_t)g * a->batch * nch * N * Dg;
+        P.carry = (float*)(wsb + ws.carry) + (size_t)g * a->batch * nch * N * Dg;
+        P.last_state = a->last_state ? a->last_state + (int64_t)g * Dg * N : nullptr;
+        P.last_state_sb = (int64_t)a->dim * N;
+        if (a->dtype == SEGM_F32) rc = launch_fwd_ns<float>(P, stream);
+        else if (a->dtype == SEGM_F16) rc = launch_fwd_ns<f16_t>(P, stream);
+        else rc = launch_fwd_ns<bf16_t>(P, stream);
+        if (rc != 0) return rc;
+    }
+    return SEGM_OK;
+}

@@ -1,0 +1,171 @@
+// Device-side building blocks shared by the scan / conv1d kernels (gfx950, wave64).
+//
+// Work decomposition used by every kernel in this library ("one lane per channel"):
+//   * a LANE owns one channel d of one (batch, chunk) work item and walks `chunk` consecutive logical
+//     time steps sequentially with its recurrence state in registers - no cross-lane scan;
+//   * a WAVE (64 lanes) = G = 64/RW work items x RW adjacent channels (RW in {64, 32, 16}, the largest
+//     that divides the channel count well), the G items being consecutive chunks of one (batch, d-tile);
+//   * the reference parallelises only over (batch, channel) and walks L serially inside a block
+//     (selective_scan_fwd_kernel.cuh:132,318); here L is split into chunks whose carries are
+//     composed by a separate tiny kernel, so the grid is (B * D/RW * L/chunk) / G waves.
+// With channel-last tensors (stride_d == 1) every per-step access of a wave is RW*esize contiguous
+// bytes; quantities shared by all channels (B_t, C_t) are staged once per wave in LDS and read
+// with wave-uniform (broadcast) addresses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/segmamba_hip.h"
+
+namespace segm {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;           // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxState = 16;
+constexpr int kCkpt = 32;             // spacing (steps) of the forward state checkpoints kept for backward
+constexpr float kLog2e = 1.4426950408889634f;
+
+typedef _Float16 f16_t;
+typedef __bf16 bf16_t;
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// ---- math (fast hardware forms; every use is a per-element or per-(element,state) hot op) -------
+// raw v_exp_f32: results below 2^-126 flush to zero, which is benign for decay factors / sigmoid tails
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float sigmoidf(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+
+// softplus with the reference's threshold (selective_scan_fwd_kernel.cuh:153-156: identity above 20)
+__device__ __forceinline__ float softplus20(float x) {
+    float e = fast_exp(x);
+    float sp = (x < -15.0f) ? e : fast_log(1.0f + e);      // log1p(e) ~ e when e < 3e-7
+    return x > 20.0f ? x : sp;
+}
+
+// ---- sequence-tensor view ---------------------------------------------------------------------
+struct Seq {
+    char* p;
+    int64_t sb, st, sd;   // element strides
+};
+__host__ __device__ __forceinline__ Seq make_seq(const segm_seq& s) { return Seq{(char*)s.ptr, s.stride_b, s.stride_t, s.stride_d}; }
+
+struct BC {
+    char* p;
+    int64_t sb, st, sn;   // one group only (group offset already applied)
+};
+
+template <typename T> __device__ __forceinline__ float ld(const Seq& s, int64_t off) {
+    return to_f32(reinterpret_cast<const T*>(s.p)[off]);
+}
+template <typename T> __device__ __forceinline__ void st(const Seq& s, int64_t off, float v) {
+    reinterpret_cast<T*>(s.p)[off] = from_f32<T>(v);
+}
+
+// ---- logical -> physical time ---------------------------------------------------------------------
+// Time indices are 32-bit (the C ABI rejects L >= 2^31); element offsets are formed as
+// base(int64) + uint32 t * uint32 stride, one v_mad_u64_u32.
+//
+// All three orders are one branch-free recurrence: logical tau = j*ns + k (0 <= k < ns) lives at
+//      t = base + k*sA + j*(ns*sA + sW)
+//   FORWARD      ns = 1, sA = 0,    sW = +1,     base = 0      -> t = tau
+//   REVERSED     ns = 1, sA = 0,    sW = -1,     base = L-1    -> t = L-1-tau
+//   INTERLEAVED  ns,     sA = L/ns, sW = -(L-1), base = 0      -> t = k*(L/ns) + j
+// so a step is "t += sA; on k wrapping to 0: t += sW" with wave-uniform (SGPR) constants.
+struct TimeMap {
+    int32_t ns, sA, sW, base;
+    int32_t L;
+    uint32_t magic_lo;   // floor(2^32 / ns) + 1 (low 32 bits) : kk / ns for small kk without a divide
+    uint32_t magic_hi;   // 1 when ns == 1
+};
+
+// floor(kk / ns) for 0 <= kk < 2^15
+__device__ __forceinline__ int32_t small_div(const TimeMap& m, int32_t kk) {
+    const uint64_t magic = ((uint64_t)m.magic_hi << 32) | m.magic_lo;
+    return (int32_t)(((uint64_t)(uint32_t)kk * magic) >> 32);
+}
+
+// Walks logical time tau upward (next) or downward (prev) keeping the physical index t.
+// tau may run past L (tail of the last chunk): t is then meaningless and callers mask with tau < L.
+struct TimeIter {
+    int32_t tau, t, k;
+    __device__ __forceinline__ void seek(const TimeMap& m, int32_t tau0) {
+        tau = tau0;
+        const int32_t j = (int32_t)((uint32_t)tau0 / (uint32_t)m.ns);
+        k = tau0 - j * m.ns;
+        t = m.base + k * m.sA + j * (m.ns * m.sA + m.sW);
+    }
+    __device__ __forceinline__ void next(const TimeMap& m) {
+        ++tau; ++k; t += m.sA;
+        const bool w = k == m.ns;
+        k = w ? 0 : k;
+        t += w ? m.sW : 0;
+    }
+    __device__ __forceinline__ void prev(const TimeMap& m) {
+        --tau; --k; t -= m.sA;
+        const bool w = k < 0;
+        k = w ? m.ns - 1 : k;
+        t -= w ? m.sW : 0;
+    }
+    // move by n steps, |n| <= 64
+    __device__ __forceinline__ void jump(const TimeMap& m, int n) {
+        tau += n;
+        const int32_t kk = k + n + 64 * m.ns;            // >= 0
+        const int32_t q = small_div(m, kk);               // = floor((k+n)/ns) + 64
+        k = kk - q * m.ns;
+        t += n * m.sA + (q - 64) * m.sW;
+    }
+    // physical index of step tau + adv (0 <= adv <= 64) without moving
+    __device__ __forceinline__ int32_t ahead(const TimeMap& m, int adv) const {
+        const int32_t q = small_div(m, k + adv);
+        return t + adv * m.sA + q * m.sW;
+    }
+};
+// row offset in elements: uint32 * uint32 -> 64 bit
+__device__ __forceinline__ int64_t row_off(int32_t t, int64_t stride) {
+    return (int64_t)((uint64_t)(uint32_t)t * (uint64_t)(uint32_t)stride);
+}
+
+// ---- work-item geometry --------------------------------------------------------------------------
+struct Geom {
+    int32_t batch, dim, nstate;
+    int32_t rw;        // channels per work item inside a wave: 64, 32 or 16
+    int32_t g;         // work items per wave = 64 / rw
+    int32_t ndt;       // d-tiles = ceil(dim / rw)
+    int32_t chunk;     // logical steps per work item
+    int32_t L;
+    int32_t nchunks;   // ceil(L / chunk)
+    int32_t ncg;       // chunk groups per (batch, d-tile) = ceil(nchunks / g)
+    int64_t nwaves;    // batch * ndt * ncg
+};
+
+// What this lane works on.
+struct Item {
+    int32_t b, d, dt;      // batch, channel, d-tile
+    int32_t gi, r;         // item index within the wave, channel index within the item
+    int32_t chunk;         // chunk index
+    bool wave_valid;       // the wave has at least something to do
+    bool valid;            // this lane has a real (channel, chunk)
+};
+
+__device__ __forceinline__ Item locate(const Geom& gm, int64_t wave_id, int lane) {
+    Item it;
+    it.gi = lane / gm.rw;
+    it.r = lane - it.gi * gm.rw;
+    it.wave_valid = wave_id < gm.nwaves;
+    uint32_t w = it.wave_valid ? (uint32_t)wave_id : 0u;   // the C ABI keeps nwaves < 2^31
+    uint32_t cg = w % (uint32_t)gm.ncg;
+    uint32_t rest = w / (uint32_t)gm.ncg;
+    it.dt = (int32_t)(rest % (uint32_t)gm.ndt);
+    it.b = (int32_t)(rest / (uint32_t)gm.ndt);
+    it.d = it.dt * gm.rw + it.r;
+    it.chunk = (int32_t)cg * gm.g + it.gi;
+    it.valid = it.wave_valid && it.d < gm.dim && it.chunk < gm.nchunks;
+    return it;
+}
+
+}  // namespace segm

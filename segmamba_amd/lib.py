@@ -1,0 +1,175 @@
+"""ctypes binding of libsegmamba_hip.so (C ABI declared in include/segmamba_hip.h).
+
+The product path loads exactly one thing: the HIP library built in-tree by
+`__graft_entry__.build()` / `segmamba_amd.build`.  There is no CPU fallback: if
+the library is missing, `get_lib()` raises (imports must succeed
+*and* the native path must be the one that runs).
+
+PyTorch is used here only as the owner of device memory and streams: tensors are
+passed as raw pointers + element strides, the current HIP stream as a handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libsegmamba_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+SEGM_F32, SEGM_F16, SEGM_BF16 = 0, 1, 2
+TIME_FORWARD, TIME_REVERSED, TIME_INTERLEAVED = 0, 1, 2
+_DTYPES = {torch.float32: SEGM_F32, torch.float16: SEGM_F16, torch.bfloat16: SEGM_BF16}
+
+_STATUS = {
+    -1: "a required pointer is NULL", -2: "bad shape / stride", -3: "dstate must be in [1, 16]",
+    -4: "unsupported dtype", -5: "conv width must be in [2, 4]", -6: "workspace missing or too small",
+    -7: "unknown time order",
+}
+
+
+class SegmSeq(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("stride_b", C.c_int64), ("stride_t", C.c_int64), ("stride_d", C.c_int64)]
+
+
+class SegmBC(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("stride_b", C.c_int64), ("stride_g", C.c_int64),
+                ("stride_t", C.c_int64), ("stride_n", C.c_int64)]
+
+
+class ScanFwdArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("dim", C.c_int32), ("dstate", C.c_int32), ("n_groups", C.c_int32),
+        ("seqlen", C.c_int64),
+        ("dtype", C.c_int32), ("delta_softplus", C.c_int32), ("time_order", C.c_int32), ("nslices", C.c_int32),
+        ("chunk", C.c_int32), ("reserved", C.c_int32),
+        ("u", SegmSeq), ("delta", SegmSeq), ("z", SegmSeq), ("out", SegmSeq), ("out_z", SegmSeq),
+        ("B", SegmBC), ("C", SegmBC),
+        ("A", C.c_void_p), ("D", C.c_void_p), ("delta_bias", C.c_void_p),
+        ("last_state", C.c_void_p), ("ckpt", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("stream", C.c_void_p),
+    ]
+
+
+class ScanBwdArgs(C.Structure):
+    _fields_ = [
+        ("f", ScanFwdArgs),
+        ("dout", SegmSeq), ("du", SegmSeq), ("ddelta", SegmSeq), ("dz", SegmSeq),
+        ("dB", SegmBC), ("dC", SegmBC),
+        ("dA", C.c_void_p), ("dD", C.c_void_p), ("ddelta_bias", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class Conv1dArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("dim", C.c_int32), ("width", C.c_int32), ("silu", C.c_int32),
+        ("seqlen", C.c_int64),
+        ("dtype", C.c_int32), ("time_order", C.c_int32), ("nslices", C.c_int32), ("reserved", C.c_int32),
+        ("x", SegmSeq), ("out", SegmSeq),
+        ("weight", C.c_void_p), ("bias", C.c_void_p),
+        ("dout", SegmSeq), ("dx", SegmSeq),
+        ("dweight", C.c_void_p), ("dbias", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("stream", C.c_void_p),
+    ]
+
+
+EXPORTS = (
+    "segm_selective_scan_fwd", "segm_selective_scan_fwd_workspace_bytes", "segm_selective_scan_ckpt_bytes",
+    "segm_selective_scan_default_chunk", "segm_selective_scan_bwd", "segm_selective_scan_bwd_workspace_bytes",
+    "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
+    "segm_abi_version", "segm_status_string",
+)
+
+
+class SegmLib:
+    """A loaded C-ABI library (the HIP one in production; tests may load the CPU emulation build)."""
+
+    def __init__(self, path: str):
+        self.path = path
+        self.dll = C.CDLL(path)
+        d = self.dll
+        self.missing = [n for n in EXPORTS if not hasattr(d, n)]
+
+        def sig(name, argtypes, restype):
+            if hasattr(d, name):
+                fn = getattr(d, name)
+                fn.argtypes, fn.restype = argtypes, restype
+
+        sig("segm_selective_scan_fwd", [C.POINTER(ScanFwdArgs)], C.c_int)
+        sig("segm_selective_scan_bwd", [C.POINTER(ScanBwdArgs)], C.c_int)
+        for n in ("segm_selective_scan_fwd_workspace_bytes", "segm_selective_scan_bwd_workspace_bytes"):
+            sig(n, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32], C.c_size_t)
+        sig("segm_selective_scan_ckpt_bytes", [C.c_int32, C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
+        sig("segm_selective_scan_default_chunk", [C.c_int32, C.c_int32, C.c_int64], C.c_int32)
+        sig("segm_causal_conv1d_fwd", [C.POINTER(Conv1dArgs)], C.c_int)
+        sig("segm_causal_conv1d_bwd", [C.POINTER(Conv1dArgs)], C.c_int)
+        sig("segm_causal_conv1d_bwd_workspace_bytes", [C.c_int32, C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
+        sig("segm_abi_version", [], C.c_int)
+        sig("segm_status_string", [C.c_int], C.c_char_p)
+
+    def check(self, rc: int, what: str) -> None:
+        if rc == 0:
+            return
+        if rc < 0:
+            msg = _STATUS.get(rc, "unknown status")
+            raise RuntimeError(f"{what}: {msg} (status {rc})")
+        raise RuntimeError(f"{what}: HIP error {rc}")
+
+
+_lib: Optional[SegmLib] = None
+
+
+def get_lib() -> SegmLib:
+    """The HIP library.  Raises if it has not been built - the product never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  segmamba_amd has no CPU / PyTorch fallback for its kernels.")
+        _lib = SegmLib(LIB_PATH)
+    return _lib
+
+
+# ---------------------------------------------------------------------------------------------------------
+# tensor -> view descriptors
+# ---------------------------------------------------------------------------------------------------------
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {t.dtype}: expected float32, float16 or bfloat16") from None
+
+
+def seq_view(t: Optional[torch.Tensor], channel_last: bool) -> SegmSeq:
+    """Descriptor of a 3-D tensor: (B, L, D) if channel_last else (B, D, L)."""
+    if t is None:
+        return SegmSeq(None, 0, 0, 0)
+    assert t.dim() == 3
+    sb, s1, s2 = t.stride()
+    return SegmSeq(t.data_ptr(), sb, s1, s2) if channel_last else SegmSeq(t.data_ptr(), sb, s2, s1)
+
+
+def bc_view(t: torch.Tensor, channel_last: bool) -> SegmBC:
+    """Descriptor of B / C: (B, L, G, N) if channel_last else (B, G, N, L)."""
+    assert t.dim() == 4
+    s = t.stride()
+    if channel_last:
+        return SegmBC(t.data_ptr(), s[0], s[2], s[1], s[3])
+    return SegmBC(t.data_ptr(), s[0], s[1], s[3], s[2])
+
+
+def stream_handle(t: torch.Tensor) -> Optional[int]:
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return None
+
+
+def fptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()

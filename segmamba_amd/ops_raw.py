@@ -1,0 +1,218 @@
+"""Thin, allocation-owning wrappers around the C ABI: tensors in, tensors out, no autograd.
+
+Every function takes the loaded library first so that the *same* marshalling code is exercised by
+the product (`lib.get_lib()`, the HIP build) and by the CPU-emulation build the tests use to check
+kernel logic without a GPU.  Layout is chosen per call:
+
+  channel_last=True   u, delta, z, out ... are (B, L, D); B / C are (B, L, N) or (B, L, G, N)
+  channel_last=False  the reference's layout: (B, D, L); B / C are (B, N, L) or (B, G, N, L)
+                      (mamba/mamba_ssm/ops/selective_scan_interface.py:31-36)
+
+Error behaviour mirrors the reference's TORCH_CHECKs (selective_scan.cpp:233-303,
+causal_conv1d.cpp:136-170): shape / dtype / stride problems raise RuntimeError.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+
+def _shape_bld(t: torch.Tensor, channel_last: bool):
+    b, x, y = t.shape
+    return (b, x, y) if channel_last else (b, y, x)        # -> (batch, seqlen, dim)
+
+
+def _bc4(t: torch.Tensor, channel_last: bool) -> torch.Tensor:
+    if t.dim() == 3:
+        return t.unsqueeze(2) if channel_last else t.unsqueeze(1)
+    if t.dim() != 4:
+        raise RuntimeError("B / C must have 3 or 4 dimensions (input-dependent B and C only)")
+    return t
+
+
+def _check_seq(name, t, ref, dtype):
+    if t is None:
+        return
+    if t.shape != ref.shape:
+        raise RuntimeError(f"{name} must have shape {tuple(ref.shape)}, got {tuple(t.shape)}")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    if t.device != ref.device:
+        raise RuntimeError(f"{name} must be on {ref.device}")
+
+
+def _check_vec(name, t, n, dev):
+    if t is None:
+        return
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32")
+    if t.numel() != n or not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous with {n} elements")
+    if t.device != dev:
+        raise RuntimeError(f"{name} must be on {dev}")
+
+
+def _fill_scan_args(a: L.ScanFwdArgs, u, delta, A, B, C, D, z, delta_bias, delta_softplus, channel_last,
+                    time_order, nslices, chunk):
+    batch, seqlen, dim = _shape_bld(u, channel_last)
+    if A.dim() != 2 or A.shape[0] != dim:
+        raise RuntimeError(f"A must be (dim={dim}, dstate)")
+    if A.is_complex():
+        raise RuntimeError("complex A is not supported (not on the SegMamba path)")
+    dstate = A.shape[1]
+    if dstate > 16:
+        raise RuntimeError("selective_scan only supports state dimension <= 16 on this backend")
+    B4, C4 = _bc4(B, channel_last), _bc4(C, channel_last)
+    groups = B4.shape[2] if channel_last else B4.shape[1]
+    exp_shape = (batch, seqlen, groups, dstate) if channel_last else (batch, groups, dstate, seqlen)
+    for name, t in (("B", B4), ("C", C4)):
+        if tuple(t.shape) != exp_shape:
+            raise RuntimeError(f"{name} must have shape {exp_shape}, got {tuple(t.shape)}")
+        if t.dtype != u.dtype:
+            raise RuntimeError(f"{name} must have the dtype of u")
+    if dim % groups != 0:
+        raise RuntimeError("dim must be divisible by the number of B/C groups")
+    _check_seq("delta", delta, u, u.dtype)
+    _check_seq("z", z, u, u.dtype)
+    _check_vec("A", A.reshape(-1), dim * dstate, u.device)
+    _check_vec("D", D, dim, u.device)
+    _check_vec("delta_bias", delta_bias, dim, u.device)
+    if time_order == L.TIME_INTERLEAVED and (nslices <= 0 or seqlen % nslices != 0):
+        raise RuntimeError(f"seqlen {seqlen} must be divisible by nslices {nslices}")
+    a.batch, a.dim, a.dstate, a.n_groups, a.seqlen = batch, dim, dstate, groups, seqlen
+    a.dtype = L.dtype_code(u)
+    a.delta_softplus = int(bool(delta_softplus))
+    a.time_order, a.nslices, a.chunk = int(time_order), int(nslices), int(chunk)
+    a.u, a.delta, a.z = L.seq_view(u, channel_last), L.seq_view(delta, channel_last), L.seq_view(z, channel_last)
+    a.B, a.C = L.bc_view(B4, channel_last), L.bc_view(C4, channel_last)
+    a.A, a.D, a.delta_bias = A.data_ptr(), L.fptr(D), L.fptr(delta_bias)
+    a.stream = L.stream_handle(u)
+    return batch, seqlen, dim, dstate, groups, B4, C4
+
+
+def scan_fwd(lib: L.SegmLib, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *,
+             channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, need_out=True,
+             need_ckpt=False, need_last_state=False):
+    """-> dict(out, out_z, ckpt, last_state, chunk).  `out` is the un-gated y (None unless need_out or z is None)."""
+    a = L.ScanFwdArgs()
+    batch, seqlen, dim, dstate, groups, B4, C4 = _fill_scan_args(
+        a, u, delta, A, B, C, D, z, delta_bias, delta_softplus, channel_last, time_order, nslices, chunk)
+    if chunk == 0:
+        chunk = lib.dll.segm_selective_scan_default_chunk(batch, dim, seqlen)
+        a.chunk = chunk
+    dev = u.device
+    out = torch.empty_like(u, memory_format=torch.contiguous_format) if (need_out or z is None) else None
+    out_z = torch.empty_like(u, memory_format=torch.contiguous_format) if z is not None else None
+    ckpt = None
+    if need_ckpt:
+        nbytes = lib.dll.segm_selective_scan_ckpt_bytes(batch, dim, dstate, seqlen)
+        ckpt = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    last_state = torch.empty(batch, dim, dstate, dtype=torch.float32, device=dev) if need_last_state else None
+    ws_bytes = lib.dll.segm_selective_scan_fwd_workspace_bytes(batch, dim, dstate, seqlen, chunk)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    a.out, a.out_z = L.seq_view(out, channel_last), L.seq_view(out_z, channel_last)
+    a.last_state, a.ckpt = L.fptr(last_state), L.fptr(ckpt)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
+    lib.check(lib.dll.segm_selective_scan_fwd(a), "selective_scan_fwd")
+    return dict(out=out, out_z=out_z, ckpt=ckpt, last_state=last_state, chunk=chunk)
+
+
+def scan_bwd(lib: L.SegmLib, u, delta, A, B, C, D, z, delta_bias, dout, out, ckpt, delta_softplus, *,
+             channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, du=None, ddelta=None, dz=None):
+    """-> dict(du, ddelta, dA, dB, dC, dD, ddelta_bias, dz).  du / ddelta / dz may be pre-allocated views
+    (e.g. halves of one dxz buffer, reference selective_scan_interface.py:244-245); dB / dC are fp32 and have
+    the layout and rank of B / C."""
+    a = L.ScanBwdArgs()
+    batch, seqlen, dim, dstate, groups, B4, C4 = _fill_scan_args(
+        a.f, u, delta, A, B, C, D, z, delta_bias, delta_softplus, channel_last, time_order, nslices, chunk)
+    if chunk == 0:
+        raise RuntimeError("scan_bwd needs the chunk length the forward used")
+    if ckpt is None:
+        raise RuntimeError("scan_bwd needs the forward checkpoints (run the forward with need_ckpt=True)")
+    if z is not None and out is None:
+        raise RuntimeError("scan_bwd needs the forward's un-gated output when z is given")
+    _check_seq("dout", dout, u, u.dtype)
+    _check_seq("out", out, u, u.dtype)
+    dev = u.device
+    du = torch.empty_like(u, memory_format=torch.contiguous_format) if du is None else du
+    ddelta = torch.empty_like(u, memory_format=torch.contiguous_format) if ddelta is None else ddelta
+    if z is not None and dz is None:
+        dz = torch.empty_like(u, memory_format=torch.contiguous_format)
+    for name, t in (("du", du), ("ddelta", ddelta), ("dz", dz)):
+        _check_seq(name, t, u, u.dtype)
+    dA = torch.empty(dim, dstate, dtype=torch.float32, device=dev)
+    dB = torch.empty(B4.shape, dtype=torch.float32, device=dev)
+    dC = torch.empty(C4.shape, dtype=torch.float32, device=dev)
+    dD = torch.empty(dim, dtype=torch.float32, device=dev) if D is not None else None
+    ddb = torch.empty(dim, dtype=torch.float32, device=dev) if delta_bias is not None else None
+    ws_bytes = lib.dll.segm_selective_scan_bwd_workspace_bytes(batch, dim, dstate, seqlen, chunk)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    a.f.out = L.seq_view(out, channel_last)
+    a.f.ckpt = ckpt.data_ptr()
+    a.dout, a.du, a.ddelta, a.dz = (L.seq_view(t, channel_last) for t in (dout, du, ddelta, dz))
+    a.dB, a.dC = L.bc_view(dB, channel_last), L.bc_view(dC, channel_last)
+    a.dA, a.dD, a.ddelta_bias = dA.data_ptr(), L.fptr(dD), L.fptr(ddb)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
+    lib.check(lib.dll.segm_selective_scan_bwd(a), "selective_scan_bwd")
+    if B.dim() == 3:
+        dB = dB.squeeze(2 if channel_last else 1)
+    if C.dim() == 3:
+        dC = dC.squeeze(2 if channel_last else 1)
+    return dict(du=du, ddelta=ddelta, dA=dA, dB=dB, dC=dC, dD=dD, ddelta_bias=ddb, dz=dz)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# causal depthwise conv1d
+# ---------------------------------------------------------------------------------------------------------
+def _fill_conv_args(a: L.Conv1dArgs, x, weight, bias, silu, channel_last, time_order, nslices):
+    batch, seqlen, dim = _shape_bld(x, channel_last)
+    if weight.dim() != 2 or weight.shape[0] != dim:
+        raise RuntimeError(f"weight must be (dim={dim}, width)")
+    width = weight.shape[1]
+    if not 2 <= width <= 4:
+        raise RuntimeError("causal_conv1d only supports width between 2 and 4")
+    _check_vec("weight", weight.reshape(-1) if weight.is_contiguous() else weight, dim * width, x.device)
+    _check_vec("bias", bias, dim, x.device)
+    if time_order == L.TIME_INTERLEAVED and (nslices <= 0 or seqlen % nslices != 0):
+        raise RuntimeError(f"seqlen {seqlen} must be divisible by nslices {nslices}")
+    a.batch, a.dim, a.width, a.silu, a.seqlen = batch, dim, width, int(bool(silu)), seqlen
+    a.dtype = L.dtype_code(x)
+    a.time_order, a.nslices = int(time_order), int(nslices)
+    a.x = L.seq_view(x, channel_last)
+    a.weight, a.bias = weight.data_ptr(), L.fptr(bias)
+    a.stream = L.stream_handle(x)
+    return batch, seqlen, dim, width
+
+
+def conv1d_fwd(lib: L.SegmLib, x, weight, bias=None, silu=False, *, channel_last=False,
+               time_order=L.TIME_FORWARD, nslices=1, out=None):
+    a = L.Conv1dArgs()
+    _fill_conv_args(a, x, weight, bias, silu, channel_last, time_order, nslices)
+    out = torch.empty_like(x, memory_format=torch.contiguous_format) if out is None else out
+    _check_seq("out", out, x, x.dtype)
+    a.out = L.seq_view(out, channel_last)
+    lib.check(lib.dll.segm_causal_conv1d_fwd(a), "causal_conv1d_fwd")
+    return out
+
+
+def conv1d_bwd(lib: L.SegmLib, x, weight, bias, dout, silu=False, *, channel_last=False,
+               time_order=L.TIME_FORWARD, nslices=1, dx=None):
+    """-> (dx, dweight fp32 (dim, width), dbias fp32 (dim) or None)"""
+    a = L.Conv1dArgs()
+    batch, seqlen, dim, width = _fill_conv_args(a, x, weight, bias, silu, channel_last, time_order, nslices)
+    _check_seq("dout", dout, x, x.dtype)
+    dx = torch.empty_like(x, memory_format=torch.contiguous_format) if dx is None else dx
+    _check_seq("dx", dx, x, x.dtype)
+    dev = x.device
+    dweight = torch.empty(dim, width, dtype=torch.float32, device=dev)
+    dbias = torch.empty(dim, dtype=torch.float32, device=dev) if bias is not None else None
+    ws_bytes = lib.dll.segm_causal_conv1d_bwd_workspace_bytes(batch, dim, width, seqlen)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    a.dout, a.dx = L.seq_view(dout, channel_last), L.seq_view(dx, channel_last)
+    a.dweight, a.dbias = dweight.data_ptr(), L.fptr(dbias)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
+    lib.check(lib.dll.segm_causal_conv1d_bwd(a), "causal_conv1d_bwd")
+    return dx, dweight, dbias

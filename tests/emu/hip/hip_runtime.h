@@ -1,0 +1,143 @@
+// TEST INFRASTRUCTURE ONLY - never part of the product.
+//
+// A tiny CPU emulation of the subset of the HIP programming model the kernels in
+// segmamba_amd/csrc use, so their index arithmetic / barrier structure can be exercised in the
+// build container (which has no GPU) before a gpurun call is spent.  The kernel sources are
+// compiled UNCHANGED as plain C++ (host clang from ROCm's LLVM) with `-I tests/emu` placed ahead of
+// the ROCm include path, so `#include <hip/hip_runtime.h>` resolves to this file.
+//
+// Model: every HIP thread of a block is an OS thread; blocks run one after another.
+//   __shared__        -> function-local `static` (one copy, shared by the block's threads)
+//   __syncthreads()   -> pthread barrier over the block
+//   __shfl* / ballot  -> exchange through a per-wave buffer + per-wave barrier (wave = 64 threads)
+//   atomicAdd         -> compare-exchange loop
+// It is slow (OS threads) and only meant for tiny problem sizes.
+#pragma once
+#include <pthread.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu { unsigned x, y, z; };
+
+extern thread_local uint3_emu threadIdx;
+extern thread_local uint3_emu blockIdx;
+extern thread_local dim3 blockDim;
+extern thread_local dim3 gridDim;
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+static const hipError_t hipSuccess = 0;
+static const hipError_t hipErrorInvalidValue = 1;
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+
+namespace hipemu {
+struct BlockCtx {
+    pthread_barrier_t block_bar;
+    std::vector<pthread_barrier_t> wave_bar;
+    std::vector<uint64_t> wave_buf;   // 64 slots per wave
+    unsigned nthreads;
+};
+extern BlockCtx* g_ctx;
+extern thread_local unsigned t_linear;   // linear thread id in block
+
+inline void sync_block() { pthread_barrier_wait(&g_ctx->block_bar); }
+inline void sync_wave() { pthread_barrier_wait(&g_ctx->wave_bar[t_linear / 64]); }
+inline uint64_t* wave_slots() { return &g_ctx->wave_buf[(t_linear / 64) * 64]; }
+
+template <typename T> inline T exchange(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "exchange");
+    uint64_t* s = wave_slots();
+    uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
+    s[t_linear % 64] = raw;
+    sync_wave();
+    uint64_t got = s[src_lane & 63];
+    sync_wave();
+    T out; memcpy(&out, &got, sizeof(T));
+    return out;
+}
+
+struct LaunchArgsBase { virtual void run() = 0; virtual ~LaunchArgsBase() {} };
+void launch(dim3 grid, dim3 block, LaunchArgsBase* body);
+
+template <typename F, typename... A> struct LaunchArgs : LaunchArgsBase {
+    F f; std::tuple<A...> args;
+    LaunchArgs(F f_, A... a) : f(f_), args(a...) {}
+    void run() override { std::apply(f, args); }
+};
+}  // namespace hipemu
+
+
+template <typename K, typename... A>
+static inline void hipLaunchKernelGGL_impl(K kernel, dim3 grid, dim3 block, A... args) {
+    hipemu::LaunchArgs<K, A...> la(kernel, args...);
+    hipemu::launch(grid, block, &la);
+}
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL_impl(kernel, dim3(grid), dim3(block), __VA_ARGS__)
+
+static inline void __syncthreads() { hipemu::sync_block(); }
+
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+    int lane = hipemu::t_linear % 64;
+    return hipemu::exchange(v, lane ^ mask);
+}
+template <typename T> static inline T __shfl(T v, int src, int width = 64) {
+    int lane = hipemu::t_linear % 64;
+    int base = lane & ~(width - 1);
+    return hipemu::exchange(v, base + (src & (width - 1)));
+}
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int lane = hipemu::t_linear % 64;
+    int src = lane + (int)d;
+    if ((src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
+    return hipemu::exchange(v, src);
+}
+static inline unsigned long long __ballot(int pred) {
+    unsigned long long bit = pred ? 1ull : 0ull;
+    unsigned long long r = 0;
+    for (int i = 0; i < 64; ++i) r |= (hipemu::exchange(bit, i) << i);
+    return r;
+}
+
+static inline float atomicAdd(float* addr, float val) {
+    uint32_t* ia = reinterpret_cast<uint32_t*>(addr);
+    uint32_t old = __atomic_load_n(ia, __ATOMIC_RELAXED);
+    for (;;) {
+        float f; memcpy(&f, &old, 4); f += val;
+        uint32_t nw; memcpy(&nw, &f, 4);
+        if (__atomic_compare_exchange_n(ia, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+            float o; memcpy(&o, &old, 4); return o;
+        }
+    }
+}
+
+// vector types / raw builtins used by the kernels
+struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
+struct float2 { float x, y; } __attribute__((aligned(8)));
+static inline float hipemu_exp2f(float x) { return exp2f(x); }
+static inline float hipemu_rcpf(float x) { return 1.0f / x; }
+static inline float hipemu_log2f(float x) { return log2f(x); }
+#define __builtin_amdgcn_exp2f hipemu_exp2f
+#define __builtin_amdgcn_rcpf hipemu_rcpf
+#define __builtin_amdgcn_logf hipemu_log2f
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
