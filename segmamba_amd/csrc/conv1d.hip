@@ -1,0 +1,306 @@
+// Causal depthwise conv1d (+SiLU), forward and backward (C ABI: segm_causal_conv1d_fwd / _bwd).
+//
+// Replaces reference causal-conv1d/csrc/causal_conv1d_fwd.cu:39-130 and causal_conv1d_bwd.cu:46-240
+// (+ host causal_conv1d.cpp:130-268).  The reference assigns 128 threads to one (batch, channel) row and
+// exchanges halo elements through shared memory; here a lane owns a channel and walks a chunk of logical
+// time with the last width-1 inputs in registers, so there is no halo traffic at all and - with
+// channel-last tensors - every access of a wave is one contiguous row segment.  Both kernels walk time
+// upwards: the backward is written as "at index i: finish dy'[i], then emit dx[i-(W-1)]", which needs only
+// the last W values of x and dy' (see conv1d_bwd_kernel).
+//
+//   o_t = bias + sum_w weight[d, w] * x_{t-(W-1-w)} ,  out = o * sigmoid(o)              (forward)
+//   dy'_t = dout_t * silu'(o_t) ;  dx_t = sum_w weight[d, w] * dy'_{t+(W-1-w)} ;
+//   dweight[d, w] = sum_{b,t} dy'_t x_{t-(W-1-w)} ;  dbias[d] = sum_{b,t} dy'_t            (backward)
+#include <string.h>
+
+#include "scan_common.h"
+
+namespace segm {
+
+struct ConvDev {
+    Geom gm;             // nstate unused
+    TimeMap tm;
+    Seq x, out, dout, dx;
+    const float* weight; // (dim, W)
+    const float* bias;   // (dim) or null
+    int32_t silu;
+    float* part;         // backward: [batch][nchunks][W + 1][dim] partial dweight / dbias
+};
+
+template <typename T, int W, int TS>
+__global__ void __launch_bounds__(kBlock) conv1d_fwd_kernel(ConvDev P) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Geom& gm = P.gm;
+    const TimeMap tm = P.tm;
+    const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const bool item_ok = it.wave_valid && it.chunk < gm.nchunks;
+
+    float wt[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) wt[w] = it.valid ? P.weight[(int64_t)it.d * W + w] : 0.f;
+    const float bias = (it.valid && P.bias) ? P.bias[it.d] : 0.f;
+    const T* xp = lane_ptr<T>(P.x, it.b, it.d, it.valid);
+    T* op = lane_ptr<T>(P.out, it.b, it.d, it.valid);
+
+    const int32_t tau_begin = item_ok ? it.chunk * gm.chunk : 0;
+    TimeIter ti;
+    ti.seek(tm, tau_begin);
+
+    // the W-1 inputs before the chunk: xh[k] = x[tau_begin - (W-1) + k]
+    float xh[W - 1];
+#pragma unroll
+    for (int k = 0; k < W - 1; ++k) {
+        const int back = (W - 1) - k;
+        TimeIter tb = ti;
+        tb.jump(tm, -back);
+        const bool ok = it.valid && tau_begin - back >= 0;
+        const float v = to_f32(xp[row_off(ok ? tb.t : 0, P.x.st)]);
+        xh[k] = ok ? v : 0.f;
+    }
+
+    float nx[TS];
+    int32_t ntt[TS];
+    uint32_t nok = row_indices<TS>(ntt, tm, ti, it.valid);
+    fetch_rows<T, TS>(nx, P.x, xp, ntt, nok);
+    for (int s0 = 0; s0 < gm.chunk; s0 += TS) {
+        float cx[TS];
+        int32_t ctt[TS];
+#pragma unroll
+        for (int j = 0; j < TS; ++j) { cx[j] = nx[j]; ctt[j] = ntt[j]; }
+        const uint32_t cok = nok;
+        ti.jump(tm, TS);
+        nok = row_indices<TS>(ntt, tm, ti, it.valid);
+        fetch_rows<T, TS>(nx, P.x, xp, ntt, nok);
+#pragma unroll
+        for (int j = 0; j < TS; ++j) {
+            float o = fmaf(wt[W - 1], cx[j], bias);
+#pragma unroll
+            for (int k = 0; k < W - 1; ++k) o = fmaf(wt[k], xh[k], o);
+#pragma unroll
+            for (int k = 0; k + 1 < W - 1; ++k) xh[k] = xh[k + 1];
+            xh[W - 2] = cx[j];
+            if (P.silu) o = o * sigmoidf(o);
+            if ((cok >> j) & 1u) op[row_off(ctt[j], P.out.st)] = from_f32<T>(o);
+        }
+    }
+}
+
+// Backward.  Walks i = tau_begin .. tau_begin + chunk + W - 2.  At index i (all windows hold the last W values):
+//   o_i   = bias + sum_k wt[k] * x[i-(W-1-k)]                      (x window)
+//   g_i   = dout_i * silu'(o_i)                                     (0 for i >= L)
+//   if i in this chunk:  dweight[k] += g_i * x[i-(W-1-k)],  dbias += g_i
+//   tau = i-(W-1):  dx_tau = sum_k wt[k] * g_{tau+(W-1-k)} = sum_k wt[k] * gw[k]   with gw[k] = g_{i-k}... see below
+template <typename T, int W, int TS>
+__global__ void __launch_bounds__(kBlock) conv1d_bwd_kernel(ConvDev P) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Geom& gm = P.gm;
+    const TimeMap tm = P.tm;
+    const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const bool item_ok = it.wave_valid && it.chunk < gm.nchunks;
+
+    float wt[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) wt[w] = it.valid ? P.weight[(int64_t)it.d * W + w] : 0.f;
+    const float bias = (it.valid && P.bias) ? P.bias[it.d] : 0.f;
+    const T* xp = lane_ptr<T>(P.x, it.b, it.d, it.valid);
+    const T* gp = lane_ptr<T>(P.dout, it.b, it.d, it.valid);
+    T* dxp = lane_ptr<T>(P.dx, it.b, it.d, it.valid);
+
+    const int32_t tau_begin = item_ok ? it.chunk * gm.chunk : 0;
+    const int32_t tau_end = tau_begin + gm.chunk;          // exclusive; may exceed L
+    TimeIter ti;
+    ti.seek(tm, tau_begin);
+
+    float xh[W - 1];                                        // xh[k] = x[i - (W-1) + k] before consuming x[i]
+#pragma unroll
+    for (int k = 0; k < W - 1; ++k) {
+        const int back = (W - 1) - k;
+        TimeIter tb = ti;
+        tb.jump(tm, -back);
+        const bool ok = it.valid && tau_begin - back >= 0;
+        const float v = to_f32(xp[row_off(ok ? tb.t : 0, P.x.st)]);
+        xh[k] = ok ? v : 0.f;
+    }
+    float gh[W - 1];                                        // gh[k] = g[i - (W-1) + k]
+    int32_t th[W - 1];                                      // physical row of step i - (W-1) + k
+#pragma unroll
+    for (int k = 0; k < W - 1; ++k) { gh[k] = 0.f; th[k] = 0; }
+    float dw[W], db = 0.f;
+#pragma unroll
+    for (int w = 0; w < W; ++w) dw[w] = 0.f;
+
+    float nx[TS], ng[TS];
+    int32_t ntt[TS];
+    uint32_t nok = row_indices<TS>(ntt, tm, ti, it.valid);
+    fetch_rows<T, TS>(nx, P.x, xp, ntt, nok);
+    fetch_rows<T, TS>(ng, P.dout, gp, ntt, nok);
+    // one extra sub-tile covers the W-1 indices past the chunk whose dy' the last dx of the chunk need
+    for (int s0 = 0; s0 < gm.chunk + TS; s0 += TS) {
+        float cx[TS], cg[TS];
+        int32_t ctt[TS];
+#pragma unroll
+        for (int j = 0; j < TS; ++j) { cx[j] = nx[j]; cg[j] = ng[j]; ctt[j] = ntt[j]; }
+        const uint32_t cok = nok;
+        const int32_t i0 = ti.tau;
+        ti.jump(tm, TS);
+        nok = row_indices<TS>(ntt, tm, ti, it.valid);
+        fetch_rows<T, TS>(nx, P.x, xp, ntt, nok);
+        fetch_rows<T, TS>(ng, P.dout, gp, ntt, nok);
+#pragma unroll
+        for (int j = 0; j < TS; ++j) {
+            const int32_t i = i0 + j;
+            float g = cg[j];                                 // already 0 for i >= L or channel-less lanes
+            if (P.silu) {
+                float o = fmaf(wt[W - 1], cx[j], bias);
+#pragma unroll
+                for (int k = 0; k < W - 1; ++k) o = fmaf(wt[k], xh[k], o);
+                const float s = sigmoidf(o);
+                g *= s * fmaf(o, 1.f - s, 1.f);
+            }
+            if (i < tau_end) {                               // wave-uniform per work item
+                dw[W - 1] = fmaf(g, cx[j], dw[W - 1]);
+#pragma unroll
+                for (int k = 0; k < W - 1; ++k) dw[k] = fmaf(g, xh[k], dw[k]);
+                db += g;
+            }
+            // dx at tau = i-(W-1): weight[k] pairs with g[tau + (W-1-k)] = g[i-k] -> wt[W-1] with g[tau], wt[0] with g[i]
+            float dxv = wt[0] * g;
+#pragma unroll
+            for (int k = 1; k < W; ++k) dxv = fmaf(wt[k], gh[(W - 1) - k], dxv);
+            const int32_t tau = i - (W - 1);
+            if (it.valid && tau >= tau_begin && tau < tau_end && tau < tm.L) dxp[row_off(th[0], P.dx.st)] = from_f32<T>(dxv);
+#pragma unroll
+            for (int k = 0; k + 1 < W - 1; ++k) { xh[k] = xh[k + 1]; gh[k] = gh[k + 1]; th[k] = th[k + 1]; }
+            xh[W - 2] = cx[j];
+            gh[W - 2] = g;
+            th[W - 2] = ctt[j];
+            (void)cok;
+        }
+    }
+    if (it.valid) {
+        const int64_t row = ((int64_t)it.b * gm.nchunks + it.chunk) * (W + 1);
+#pragma unroll
+        for (int w = 0; w < W; ++w) P.part[(row + w) * gm.dim + it.d] = dw[w];
+        P.part[(row + W) * gm.dim + it.d] = db;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// out0[d*K0 + k] = sum_rows part[row][k][d] (k < K0) ; out1[d] = ... k == K0 ; out2[d] = ... k == K0+1
+// grid (ceil(dim/64), K), block 16 waves: wave w sums rows w, w+16, ... then a 16-entry LDS fold.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kCarrySegs * 64) reduce_partials_kernel(const float* __restrict__ part, int64_t nrows,
+                                                                          int K, int dim, float* out0, int K0,
+                                                                          float* out1, float* out2) {
+    __shared__ float s_acc[kCarrySegs][64];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + lane, k = blockIdx.y;
+    const bool valid = d < dim;
+    float acc = 0.f;
+    if (valid)
+        for (int64_t r = seg; r < nrows; r += kCarrySegs) acc += part[(r * K + k) * dim + d];
+    s_acc[seg][lane] = acc;
+    __syncthreads();
+    if (seg == 0 && valid) {
+        float t = 0.f;
+        for (int s = 0; s < kCarrySegs; ++s) t += s_acc[s][lane];
+        if (k < K0) { if (out0) out0[(int64_t)d * K0 + k] = t; }
+        else if (k == K0) { if (out1) out1[d] = t; }
+        else if (out2) out2[d] = t;
+    }
+}
+
+void launch_reduce_partials(const float* part, int64_t nrows, int K, int dim, float* out0, int K0, float* out1,
+                            float* out2, hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 63) / 64, K), dim3(kCarrySegs * 64), 0, stream, part, nrows, K,
+                       dim, out0, K0, out1, out2);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+static int validate_conv(const segm_conv1d_args* a, bool bwd) {
+    if (!a) return SEGM_E_NULL;
+    if (a->batch <= 0 || a->dim <= 0 || a->seqlen <= 0 || a->seqlen >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;
+    if (a->width < 2 || a->width > 4) return SEGM_E_WIDTH;
+    if (a->dtype != SEGM_F32 && a->dtype != SEGM_F16 && a->dtype != SEGM_BF16) return SEGM_E_DTYPE;
+    if (a->time_order < SEGM_TIME_FORWARD || a->time_order > SEGM_TIME_INTERLEAVED) return SEGM_E_TIME_ORDER;
+    if (a->time_order == SEGM_TIME_INTERLEAVED && (a->nslices <= 0 || a->nslices > 4096 || a->seqlen % a->nslices != 0)) return SEGM_E_SHAPE;
+    if (!a->x.ptr || !a->weight) return SEGM_E_NULL;
+    if (!bwd && !a->out.ptr) return SEGM_E_NULL;
+    if (bwd && (!a->dout.ptr || !a->dx.ptr || !a->dweight)) return SEGM_E_NULL;
+    const segm_seq* v[4] = {&a->x, &a->out, &a->dout, &a->dx};
+    for (const segm_seq* s : v)
+        if (s->ptr && (s->stride_t < 0 || s->stride_t >= ((int64_t)1 << 31))) return SEGM_E_SHAPE;
+    return SEGM_OK;
+}
+
+static int conv_chunk(int batch, int dim, int64_t L) {
+    int c = default_chunk(batch, dim, L);
+    return c > 1024 ? 1024 : c;
+}
+
+static void fill_conv_dev(ConvDev& P, const segm_conv1d_args* a) {
+    memset(&P, 0, sizeof(P));
+    P.gm = make_geom(a->batch, a->dim, 1, a->seqlen, conv_chunk(a->batch, a->dim, a->seqlen));
+    P.tm = make_timemap(a->time_order, a->nslices, a->seqlen);
+    P.x = make_seq(a->x); P.out = make_seq(a->out); P.dout = make_seq(a->dout); P.dx = make_seq(a->dx);
+    P.weight = a->weight; P.bias = a->bias; P.silu = a->silu;
+}
+
+template <typename T, int W>
+static int launch_conv(const ConvDev& P, bool bwd, hipStream_t stream) {
+    constexpr int TS = 8;
+    const unsigned nblocks = (unsigned)((P.gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (bwd) hipLaunchKernelGGL((conv1d_bwd_kernel<T, W, TS>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+    else hipLaunchKernelGGL((conv1d_fwd_kernel<T, W, TS>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static int launch_conv_w(const ConvDev& P, int width, bool bwd, hipStream_t stream) {
+    if (width == 2) return launch_conv<T, 2>(P, bwd, stream);
+    if (width == 3) return launch_conv<T, 3>(P, bwd, stream);
+    return launch_conv<T, 4>(P, bwd, stream);
+}
+
+static int launch_conv_t(const ConvDev& P, int dtype, int width, bool bwd, hipStream_t stream) {
+    if (dtype == SEGM_F32) return launch_conv_w<float>(P, width, bwd, stream);
+    if (dtype == SEGM_F16) return launch_conv_w<f16_t>(P, width, bwd, stream);
+    return launch_conv_w<bf16_t>(P, width, bwd, stream);
+}
+
+}  // namespace segm
+
+using namespace segm;
+
+extern "C" size_t segm_causal_conv1d_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t width, int64_t seqlen) {
+    if (batch <= 0 || dim <= 0 || width <= 0 || seqlen <= 0) return 0;
+    const int chunk = conv_chunk(batch, dim, seqlen);
+    const int64_t nch = (seqlen + chunk - 1) / chunk;
+    return align256((size_t)batch * nch * (width + 1) * dim * sizeof(float));
+}
+
+extern "C" int segm_causal_conv1d_fwd(const segm_conv1d_args* a) {
+    int rc = validate_conv(a, false);
+    if (rc != SEGM_OK) return rc;
+    ConvDev P;
+    fill_conv_dev(P, a);
+    return launch_conv_t(P, a->dtype, a->width, false, (hipStream_t)a->stream);
+}
+
+extern "C" int segm_causal_conv1d_bwd(const segm_conv1d_args* a) {
+    int rc = validate_conv(a, true);
+    if (rc != SEGM_OK) return rc;
+    const size_t need = segm_causal_conv1d_bwd_workspace_bytes(a->batch, a->dim, a->width, a->seqlen);
+    if (!a->workspace || a->workspace_bytes < need) return SEGM_E_WORKSPACE;
+    ConvDev P;
+    fill_conv_dev(P, a);
+    P.part = (float*)a->workspace;
+    hipStream_t stream = (hipStream_t)a->stream;
+    rc = launch_conv_t(P, a->dtype, a->width, true, stream);
+    if (rc != 0) return rc;
+    launch_reduce_partials(P.part, (int64_t)a->batch * P.gm.nchunks, a->width + 1, a->dim, a->dweight, a->width,
+                           a->dbias, nullptr, stream);
+    return (int)hipGetLastError();
+}

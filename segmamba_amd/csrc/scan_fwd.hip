@@ -361,7 +361,7 @@ int validate_scan_common(const segm_scan_fwd_args* a) {
     if (a->dstate < 1 || a->dstate > kMaxState) return SEGM_E_DSTATE;
     if (a->dtype != SEGM_F32 && a->dtype != SEGM_F16 && a->dtype != SEGM_BF16) return SEGM_E_DTYPE;
     if (a->time_order < SEGM_TIME_FORWARD || a->time_order > SEGM_TIME_INTERLEAVED) return SEGM_E_TIME_ORDER;
-    if (a->time_order == SEGM_TIME_INTERLEAVED && (a->nslices <= 0 || a->seqlen % a->nslices != 0)) return SEGM_E_SHAPE;
+    if (a->time_order == SEGM_TIME_INTERLEAVED && (a->nslices <= 0 || a->nslices > 4096 || a->seqlen % a->nslices != 0)) return SEGM_E_SHAPE;
     if (a->chunk < 0 || (a->chunk % kCkpt) != 0) return SEGM_E_SHAPE;
     if (!a->u.ptr || !a->delta.ptr || !a->B.ptr || !a->C.ptr || !a->A) return SEGM_E_NULL;
     if (!strides_ok(a->u) || !strides_ok(a->delta) || !strides_ok(a->z) || !strides_ok(a->out) ||
