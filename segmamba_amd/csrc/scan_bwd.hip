@@ -1,0 +1,514 @@
+// Selective scan, backward (C ABI: segm_selective_scan_bwd).
+//
+// Replaces reference mamba/csrc/selective_scan/selective_scan_bwd_kernel.cuh:75-489, reverse_scan.cuh and
+// selective_scan.cpp:338-492.  Same decomposition as the forward (one lane per channel, L cut into chunks):
+//
+//   K1  scan_bwd_agg_kernel   per (batch, chunk, channel): walk the chunk right-to-left with a zero adjoint
+//                             entering from the right; emits E = adjoint leaving on the left, and sum(delta)
+//   K2  scan_carry_kernel<1>  compose E over chunks right-to-left -> adjoint entering every chunk
+//   K3  scan_bwd_main_kernel  per (batch, chunk, channel): 32-step sub-chunks right-to-left; each is re-run
+//                             forward from the forward pass' checkpoint (state entering step 32k) in two
+//                             16-step windows, state by state, keeping a_t, h_t of ONE state in registers
+//                             (the reference keeps them for one state per thread tile too, :235-273), then
+//                             walked backwards:
+//        dh_t  = g_t C_t + e_{t+1}            e_t = a_t dh_t           g = dout * silu(z)
+//        du_t += delta_t <dh_t, B_t> (+ D g_t)     ddelta_t = <dh_t, B_t u_t + A a_t h_{t-1}>
+//        dA   += dh_t a_t h_{t-1} delta_t          dB_t = sum_d dh_t delta_t u_t      dC_t = sum_d g_t h_t
+//      (reference :330-478).  dB / dC sum over channels = over the lanes of a work
+//      item: a reduce-scatter butterfly (log2(RW) shuffle stages, each lane ends with one finished value),
+//      parked in LDS and flushed once per window - no per-element global atomics from every channel as in
+//      the reference (:297-316); atomics are only used between d-tiles.
+//   K4  reduce_partials_kernel  per-item partial dA / dD / ddelta_bias -> final (deterministic, no atomics)
+#include <string.h>
+
+#include "scan_common.h"
+
+namespace segm {
+
+void launch_reduce_partials(const float* part, int64_t nrows, int K, int dim, float* out0, int K0, float* out1,
+                            float* out2, hipStream_t stream);
+
+constexpr int kWin = 16;   // window length of the backward main kernel (kCkpt = 2 windows)
+
+// ------------------------------------------------------------------------------------------------------
+// K1: reverse chunk aggregates
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int NS, int TS, int RW>
+__global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
+    constexpr int G = 64 / RW;
+    __shared__ __attribute__((aligned(16))) float s_c[2][kWavesPerBlock][G][TS * NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Geom& gm = P.gm;
+    const TimeMap tm = P.tm;
+    const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const bool item_ok = it.wave_valid && it.chunk < gm.nchunks;
+    const int nstate = gm.nstate;
+    const bool has_z = P.z.p != nullptr;
+
+    float A2[NS], e[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        A2[n] = (it.valid && n < nstate) ? P.A[(int64_t)it.d * nstate + n] * kLog2e : 0.f;
+        e[n] = 0.f;
+    }
+    const float bias = (it.valid && P.delta_bias) ? P.delta_bias[it.d] : 0.f;
+    const T* dp = lane_ptr<T>(P.delta, it.b, it.d, it.valid);
+    const T* gp = lane_ptr<T>(P.dout, it.b, it.d, it.valid);
+    const Seq& zs = has_z ? P.z : P.dout;
+    const T* zp = lane_ptr<T>(zs, it.b, it.d, it.valid);
+    const bool t_fastest = P.Cm.st <= P.Cm.sn;
+
+    TimeIter ti;
+    ti.seek(tm, item_ok ? it.chunk * gm.chunk : 0);
+    ti.jump(tm, gm.chunk > 64 ? 64 : gm.chunk);          // to the chunk's last sub-tile, in hops of <= 64
+    for (int done = 64; done < gm.chunk; done += 64) ti.jump(tm, gm.chunk - done > 64 ? 64 : gm.chunk - done);
+    ti.jump(tm, -TS);
+
+    float nd[TS], ng[TS], nz[TS];
+    int32_t ntt[TS];
+    StageRegs<TS, NS, RW> sc;
+    uint32_t nok = row_indices<TS>(ntt, tm, ti, it.valid);
+    fetch_rows<T, TS>(nd, P.delta, dp, ntt, nok);
+    fetch_rows<T, TS>(ng, P.dout, gp, ntt, nok);
+    fetch_rows<T, TS>(nz, zs, zp, ntt, nok);
+    stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, it.b, nstate, it.r, item_ok);
+
+    float sumd = 0.f;
+    int buf = 0;
+    for (int s0 = gm.chunk - TS; s0 >= 0; s0 -= TS) {
+        float* lc = &s_c[buf][wave][it.gi][0];
+        stage_park<TS, NS, RW, true>(sc, lc, t_fastest, it.r);
+        __syncthreads();
+        float cd[TS], cg[TS], cz[TS];
+#pragma unroll
+        for (int j = 0; j < TS; ++j) { cd[j] = nd[j]; cg[j] = ng[j]; cz[j] = nz[j]; }
+        const uint32_t cok = nok;
+        ti.jump(tm, -TS);                                  // next (lower) sub-tile; below the chunk start rows are
+        nok = row_indices<TS>(ntt, tm, ti, it.valid);      // the neighbour's or masked (tau < 0): prefetch only
+        fetch_rows<T, TS>(nd, P.delta, dp, ntt, nok);
+        fetch_rows<T, TS>(ng, P.dout, gp, ntt, nok);
+        fetch_rows<T, TS>(nz, zs, zp, ntt, nok);
+        stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, it.b, nstate, it.r, item_ok);
+#pragma unroll
+        for (int jj = 0; jj < TS; ++jj) {
+            const int j = TS - 1 - jj;
+            const bool ok = (cok >> j) & 1u;
+            float dl = cd[j] + bias;
+            if (P.delta_softplus) dl = softplus20(dl);
+            dl = ok ? dl : 0.f;
+            sumd += dl;
+            float g = cg[j];
+            if (has_z) { const float zz = cz[j]; g *= zz * sigmoidf(zz); }
+            const float4* C4 = reinterpret_cast<const float4*>(lc + j * NS);
+#pragma unroll
+            for (int q = 0; q < NS / 4; ++q) {
+                const float4 cv = C4[q];
+                const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = q * 4 + i;
+                    const float a = fast_exp2(dl * A2[n]);
+                    e[n] = a * fmaf(g, cc[i], e[n]);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+    if (it.valid) {
+        const int64_t row = (int64_t)it.b * gm.nchunks + it.chunk;
+        P.agg_sd[row * gm.dim + it.d] = sumd;
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+            if (n < nstate) P.agg_h[(row * nstate + n) * gm.dim + it.d] = e[n];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// reduce-scatter over the RW lanes of a work item: on return lane r holds, in v[0], the sum over the item's
+// lanes of the value the lanes had at index (r mod V).  V = min(RW, 32) values per call.
+// ------------------------------------------------------------------------------------------------------
+template <int RW, int V>
+__device__ __forceinline__ void reduce_scatter(float (&v)[V], int r) {
+#pragma unroll
+    for (int m = V / 2; m >= 1; m >>= 1) {
+        const bool upper = (r & m) != 0;
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+            const float keep = upper ? v[m + i] : v[i];
+            const float send = upper ? v[i] : v[m + i];
+            v[i] = keep + __shfl_xor(send, m);
+        }
+    }
+    if (RW > V) v[0] += __shfl_xor(v[0], V);               // RW == 64: fold the two 32-lane halves
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3: main backward kernel
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int NS, int RW>
+__global__ void __launch_bounds__(kBlock) scan_bwd_main_kernel(ScanDev P) {
+    constexpr int G = 64 / RW;
+    constexpr int V = RW < 32 ? RW : 32;
+    __shared__ __attribute__((aligned(16))) float s_bc[kWavesPerBlock][G][2][NS * kWin];    // [n][s]: B then C
+    __shared__ __attribute__((aligned(16))) float s_dbc[kWavesPerBlock][G][2][kWin * NS];   // [j][n]: dB then dC
+    __shared__ int32_t s_rows[kWavesPerBlock][G][kWin];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Geom& gm = P.gm;
+    const TimeMap tm = P.tm;
+    const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const bool item_ok = it.wave_valid && it.chunk < gm.nchunks;
+    const int nstate = gm.nstate;
+    const bool has_z = P.z.p != nullptr;
+
+    float A2[NS], e[NS], dA[NS];
+    const int64_t crow = (int64_t)it.b * gm.nchunks + it.chunk;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        const bool on = it.valid && n < nstate;
+        A2[n] = on ? P.A[(int64_t)it.d * nstate + n] * kLog2e : 0.f;
+        e[n] = on ? P.carry[(crow * nstate + n) * gm.dim + it.d] : 0.f;
+        dA[n] = 0.f;
+    }
+    const float bias = (it.valid && P.delta_bias) ? P.delta_bias[it.d] : 0.f;
+    const float Dv = (it.valid && P.D) ? P.D[it.d] : 0.f;
+    float dD_acc = 0.f, dbias_acc = 0.f;
+
+    const T* up = lane_ptr<T>(P.u, it.b, it.d, it.valid);
+    const T* dp = lane_ptr<T>(P.delta, it.b, it.d, it.valid);
+    const T* gp = lane_ptr<T>(P.dout, it.b, it.d, it.valid);
+    const Seq& zs = has_z ? P.z : P.dout;
+    const Seq& ys = has_z ? P.out : P.dout;
+    const T* zp = lane_ptr<T>(zs, it.b, it.d, it.valid);
+    const T* yp = lane_ptr<T>(ys, it.b, it.d, it.valid);
+    T* dup = lane_ptr<T>(P.du, it.b, it.d, it.valid);
+    T* ddp = lane_ptr<T>(P.ddelta, it.b, it.d, it.valid);
+    T* dzp = has_z ? lane_ptr<T>(P.dz, it.b, it.d, it.valid) : nullptr;
+    const bool bt_fastest = P.Bm.st <= P.Bm.sn, ct_fastest = P.Cm.st <= P.Cm.sn;
+    float* lb = &s_bc[wave][it.gi][0][0];
+    float* lc = &s_bc[wave][it.gi][1][0];
+    float* ldb = &s_dbc[wave][it.gi][0][0];
+    float* ldc = &s_dbc[wave][it.gi][1][0];
+    int32_t* lrows = &s_rows[wave][it.gi][0];
+
+    const int32_t tau_begin = item_ok ? it.chunk * gm.chunk : 0;
+    const int nsub = gm.chunk / kCkpt;
+
+    for (int sc = nsub - 1; sc >= 0; --sc) {
+        const int32_t tau_s = tau_begin + sc * kCkpt;
+        TimeIter t0;
+        t0.seek(tm, tau_s);
+        // state entering the sub-chunk (forward checkpoint); zero past the end of the sequence
+        float h0[NS], hmid[NS];
+        {
+            const bool ck_ok = it.valid && tau_s < tm.L;
+            const int64_t krow = (int64_t)it.b * P.nck + (ck_ok ? tau_s / kCkpt : 0);
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                const float v = P.ckpt[(krow * nstate + (n < nstate ? n : 0)) * gm.dim + (it.valid ? it.d : 0)];
+                h0[n] = (ck_ok && n < nstate) ? v : 0.f;
+            }
+        }
+        // ---- (1) forward sweep over window 0 to get the state entering window 1 -------------------------
+        {
+            StageRegs<kWin, NS, RW> sb;
+            stage_fetch<T, kWin, NS, RW>(sb, P.Bm, tm, t0, it.b, nstate, it.r, item_ok);
+            int32_t tt[kWin];
+            float wu[kWin], wd[kWin];
+            const uint32_t okm = row_indices<kWin>(tt, tm, t0, it.valid);
+            fetch_rows<T, kWin>(wu, P.u, up, tt, okm);
+            fetch_rows<T, kWin>(wd, P.delta, dp, tt, okm);
+            __syncthreads();                                // previous users of s_bc are done
+            stage_park<kWin, NS, RW, false>(sb, lb, bt_fastest, it.r);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kWin; ++j) {
+                float dl = wd[j] + bias;
+                if (P.delta_softplus) dl = softplus20(dl);
+                wd[j] = ((okm >> j) & 1u) ? dl : 0.f;
+                wu[j] *= wd[j];                             // delta * u
+            }
+#pragma unroll 1
+            for (int n = 0; n < NS; ++n) {                  // runtime loop, registers rotated (see below)
+                float h = h0[0];
+                const float A2n = A2[0];
+                const float4* B4 = reinterpret_cast<const float4*>(lb + n * kWin);
+#pragma unroll
+                for (int q = 0; q < kWin / 4; ++q) {
+                    const float4 bv = B4[q];
+                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = q * 4 + i;
+                        h = fmaf(fast_exp2(wd[j] * A2n), h, wu[j] * bb[i]);
+                    }
+                }
+                // rotate so that the next state sits at index 0; after NS turns every array is back in place
+                const float h0n = h0[0];
+#pragma unroll
+                for (int i = 0; i + 1 < NS; ++i) { h0[i] = h0[i + 1]; A2[i] = A2[i + 1]; hmid[i] = hmid[i + 1]; }
+                h0[NS - 1] = h0n; A2[NS - 1] = A2n; hmid[NS - 1] = h;
+            }
+        }
+        // ---- (2), (3): the two windows, right one first -----------------------------------------------------
+        for (int w = 1; w >= 0; --w) {
+            TimeIter tw = t0;
+            if (w) tw.jump(tm, kWin);
+            StageRegs<kWin, NS, RW> sb, scc;
+            stage_fetch<T, kWin, NS, RW>(sb, P.Bm, tm, tw, it.b, nstate, it.r, item_ok);
+            stage_fetch<T, kWin, NS, RW>(scc, P.Cm, tm, tw, it.b, nstate, it.r, item_ok);
+            int32_t tt[kWin];
+            const uint32_t okm = row_indices<kWin>(tt, tm, tw, it.valid);
+            float wu[kWin], wd[kWin], wg[kWin], du[kWin], dd[kWin];
+            fetch_rows<T, kWin>(wu, P.u, up, tt, okm);
+            fetch_rows<T, kWin>(wd, P.delta, dp, tt, okm);
+            fetch_rows<T, kWin>(wg, P.dout, gp, tt, okm);
+            {
+                float wz[kWin], wy[kWin];
+                fetch_rows<T, kWin>(wz, zs, zp, tt, okm);
+                fetch_rows<T, kWin>(wy, ys, yp, tt, okm);
+#pragma unroll
+                for (int j = 0; j < kWin; ++j) {
+                    const bool ok = (okm >> j) & 1u;
+                    float dl = wd[j] + bias;
+                    if (P.delta_softplus) dl = softplus20(dl);
+                    wd[j] = ok ? dl : 0.f;
+                    if (has_z) {
+                        const float zz = wz[j], sg = sigmoidf(zz);
+                        const float dzv = wg[j] * wy[j] * sg * fmaf(zz, 1.f - sg, 1.f);
+                        if (ok) dzp[row_off(tt[j], P.dz.st)] = from_f32<T>(dzv);
+                        wg[j] *= zz * sg;
+                    }
+                    du[j] = Dv * wg[j];
+                    dd[j] = 0.f;
+                    dD_acc = fmaf(wg[j], wu[j], dD_acc);
+                }
+            }
+            __syncthreads();                                // s_bc / s_dbc / s_rows free again
+            stage_park<kWin, NS, RW, false>(sb, lb, bt_fastest, it.r);
+            stage_park<kWin, NS, RW, false>(scc, lc, ct_fastest, it.r);
+            if (it.r < kWin) {
+                const int32_t tau = tw.tau + it.r;
+                lrows[it.r] = (item_ok && tau < tm.L) ? tw.ahead(tm, it.r) : -1;
+            }
+            __syncthreads();
+
+#pragma unroll 1
+            for (int n = 0; n < NS; ++n) {                  // runtime loop over states, registers rotated
+                const float A2n = A2[0];
+                const float An = A2n * 0.6931471805599453f;
+                const float hp = w ? hmid[0] : h0[0];
+                float en = e[0];
+                float dAn = dA[0];
+                float a[kWin], h[kWin], bn[kWin], cn[kWin];
+                {
+                    const float4* B4 = reinterpret_cast<const float4*>(lb + n * kWin);
+                    const float4* C4 = reinterpret_cast<const float4*>(lc + n * kWin);
+#pragma unroll
+                    for (int q = 0; q < kWin / 4; ++q) {
+                        const float4 bv = B4[q], cv = C4[q];
+                        bn[q * 4 + 0] = bv.x; bn[q * 4 + 1] = bv.y; bn[q * 4 + 2] = bv.z; bn[q * 4 + 3] = bv.w;
+                        cn[q * 4 + 0] = cv.x; cn[q * 4 + 1] = cv.y; cn[q * 4 + 2] = cv.z; cn[q * 4 + 3] = cv.w;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kWin; ++j) {
+                    a[j] = fast_exp2(wd[j] * A2n);
+                    h[j] = fmaf(a[j], j ? h[j - 1] : hp, wd[j] * wu[j] * bn[j]);
+                }
+                float v[2 * kWin];                          // [0,16): dB_j ; [16,32): dC_j   (this state)
+#pragma unroll
+                for (int jj = 0; jj < kWin; ++jj) {
+                    const int j = kWin - 1 - jj;
+                    const float dh = fmaf(wg[j], cn[j], en);
+                    const float t2 = dh * (j ? h[j - 1] : hp) * a[j];
+                    dAn = fmaf(t2, wd[j], dAn);
+                    const float qv = dh * bn[j];
+                    dd[j] = fmaf(t2, An, fmaf(qv, wu[j], dd[j]));
+                    du[j] = fmaf(qv, wd[j], du[j]);
+                    v[j] = dh * wd[j] * wu[j];
+                    v[kWin + j] = wg[j] * h[j];
+                    en = a[j] * dh;
+                }
+                // sum dB / dC contributions over the channels (lanes) of the work item
+                if constexpr (RW >= 32) {
+                    reduce_scatter<RW, V>(v, it.r);
+                    if (it.r < 32) {
+                        const int idx = it.r;               // 0..15 -> dB_j, 16..31 -> dC_j
+                        const int j = idx & (kWin - 1);
+                        (idx < kWin ? ldb : ldc)[j * NS + n] = v[0];
+                    }
+                } else {
+                    float vb[kWin], vc[kWin];
+#pragma unroll
+                    for (int j = 0; j < kWin; ++j) { vb[j] = v[j]; vc[j] = v[kWin + j]; }
+                    reduce_scatter<RW, kWin>(vb, it.r);
+                    reduce_scatter<RW, kWin>(vc, it.r);
+                    ldb[it.r * NS + n] = vb[0];
+                    ldc[it.r * NS + n] = vc[0];
+                }
+                // rotate the per-state registers
+                const float hm0 = hmid[0], h00 = h0[0];
+#pragma unroll
+                for (int i = 0; i + 1 < NS; ++i) {
+                    A2[i] = A2[i + 1]; e[i] = e[i + 1]; dA[i] = dA[i + 1]; hmid[i] = hmid[i + 1]; h0[i] = h0[i + 1];
+                }
+                A2[NS - 1] = A2n; e[NS - 1] = en; dA[NS - 1] = dAn; hmid[NS - 1] = hm0; h0[NS - 1] = h00;
+            }
+            __syncthreads();                                // the dB / dC tile of every item is complete
+            // flush the window's dB / dC tile: rows contiguous in whichever of (t, n) has the smaller stride
+            {
+                const bool n_fast = P.dB_sn <= P.dB_st;
+#pragma unroll
+                for (int i = 0; i < kWin * NS / RW; ++i) {
+                    const int el = it.r + i * RW;
+                    int j, n;
+                    if (n_fast) { j = el / NS; n = el - j * NS; } else { n = el / kWin; j = el - n * kWin; }
+                    const int32_t row = lrows[j];
+                    if (row >= 0 && n < nstate) {
+                        const int64_t ob = (int64_t)it.b * P.dB_sb + row_off(row, P.dB_st) + (int64_t)n * P.dB_sn;
+                        const int64_t oc = (int64_t)it.b * P.dC_sb + row_off(row, P.dC_st) + (int64_t)n * P.dC_sn;
+                        const float xb = ldb[j * NS + n], xc = ldc[j * NS + n];
+                        if (P.atomic_bc) { atomicAdd(P.dB + ob, xb); atomicAdd(P.dC + oc, xc); }
+                        else { P.dB[ob] = xb; P.dC[oc] = xc; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kWin; ++j) {
+                if ((okm >> j) & 1u) {
+                    float ddv = dd[j];
+                    if (P.delta_softplus) ddv *= 1.f - fast_exp(-wd[j]);      // sigmoid(raw) = 1 - exp(-softplus(raw))
+                    dbias_acc += ddv;
+                    dup[row_off(tt[j], P.du.st)] = from_f32<T>(du[j]);
+                    ddp[row_off(tt[j], P.ddelta.st)] = from_f32<T>(ddv);
+                }
+            }
+        }
+    }
+    if (it.valid) {
+        const int64_t row = crow * (nstate + 2);
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+            if (n < nstate) P.part[(row + n) * gm.dim + it.d] = dA[n];
+        P.part[(row + nstate) * gm.dim + it.d] = dD_acc;
+        P.part[(row + nstate + 1) * gm.dim + it.d] = dbias_acc;
+    }
+}
+
+// zero a strided (batch, time, state) fp32 view (dB / dC accumulate atomically across d-tiles)
+__global__ void __launch_bounds__(256) clear_bc_kernel(float* p, int64_t sb, int64_t st, int64_t sn, int32_t L, int nstate) {
+    const int b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)L * nstate;
+    if (i < total) {
+        const int32_t t = (int32_t)(i / nstate);
+        const int n = (int)(i - (int64_t)t * nstate);
+        p[(int64_t)b * sb + row_off(t, st) + (int64_t)n * sn] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+struct BwdWs { size_t sd, e, carry, part, total; };
+static BwdWs bwd_ws_layout(int batch, int dim, int nstate, int64_t L, int chunk) {
+    const int64_t nch = (L + chunk - 1) / chunk;
+    BwdWs w;
+    w.sd = 0;
+    w.e = align256((size_t)batch * nch * dim * sizeof(float));
+    w.carry = w.e + align256((size_t)batch * nch * nstate * dim * sizeof(float));
+    w.part = w.carry + align256((size_t)batch * nch * nstate * dim * sizeof(float));
+    w.total = w.part + align256((size_t)batch * nch * (nstate + 2) * dim * sizeof(float));
+    return w;
+}
+
+template <typename T, int NS, int RW>
+static int launch_bwd_rw(const ScanDev& P, hipStream_t stream) {
+    constexpr int TS = 8;
+    const Geom& gm = P.gm;
+    const unsigned nblocks = (unsigned)((gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((scan_bwd_agg_kernel<T, NS, TS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+    launch_scan_carry(P, true, P.agg_sd, P.agg_h, P.carry, stream);
+    hipLaunchKernelGGL((scan_bwd_main_kernel<T, NS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int NS>
+static int launch_bwd(const ScanDev& P, hipStream_t stream) {
+    if (P.gm.rw == 64) return launch_bwd_rw<T, NS, 64>(P, stream);
+    if (P.gm.rw == 32) return launch_bwd_rw<T, NS, 32>(P, stream);
+    return launch_bwd_rw<T, NS, 16>(P, stream);
+}
+
+template <typename T>
+static int launch_bwd_ns(const ScanDev& P, hipStream_t stream) {
+    if (P.gm.nstate <= 4) return launch_bwd<T, 4>(P, stream);
+    if (P.gm.nstate <= 8) return launch_bwd<T, 8>(P, stream);
+    return launch_bwd<T, 16>(P, stream);
+}
+
+}  // namespace segm
+
+using namespace segm;
+
+extern "C" size_t segm_selective_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen,
+                                                          int32_t chunk) {
+    if (batch <= 0 || dim <= 0 || dstate <= 0 || seqlen <= 0) return 0;
+    if (chunk <= 0) chunk = default_chunk(batch, dim, seqlen);
+    return bwd_ws_layout(batch, dim, dstate, seqlen, chunk).total;
+}
+
+extern "C" int segm_selective_scan_bwd(const segm_scan_bwd_args* b) {
+    if (!b) return SEGM_E_NULL;
+    const segm_scan_fwd_args* a = &b->f;
+    int rc = validate_scan_common(a);
+    if (rc != SEGM_OK) return rc;
+    if (a->chunk <= 0) return SEGM_E_SHAPE;                 // must be the forward's chunk
+    if (!a->ckpt || !b->dout.ptr || !b->du.ptr || !b->ddelta.ptr || !b->dA || !b->dB.ptr || !b->dC.ptr) return SEGM_E_NULL;
+    if (a->z.ptr && (!b->dz.ptr || !a->out.ptr)) return SEGM_E_NULL;
+    const segm_seq* sv[4] = {&b->dout, &b->du, &b->ddelta, &b->dz};
+    for (const segm_seq* s : sv)
+        if (s->ptr && (s->stride_t < 0 || s->stride_t >= ((int64_t)1 << 31))) return SEGM_E_SHAPE;
+    if (b->dB.stride_t < 0 || b->dB.stride_t >= ((int64_t)1 << 31) || b->dC.stride_t < 0 ||
+        b->dC.stride_t >= ((int64_t)1 << 31))
+        return SEGM_E_SHAPE;
+    const int chunk = a->chunk;
+    const BwdWs ws = bwd_ws_layout(a->batch, a->dim, a->dstate, a->seqlen, chunk);
+    if (!b->workspace || b->workspace_bytes < ws.total) return SEGM_E_WORKSPACE;
+
+    const int G = a->n_groups, Dg = a->dim / G, N = a->dstate;
+    const size_t es = dtype_size(a->dtype);
+    const int64_t nch = (a->seqlen + chunk - 1) / chunk;
+    hipStream_t stream = (hipStream_t)a->stream;
+    char* wsb = (char*)b->workspace;
+
+    for (int g = 0; g < G; ++g) {
+        const int64_t d0 = (int64_t)g * Dg;
+        ScanDev P;
+        fill_scan_dev(P, a, g, chunk);
+        P.agg_sd = (float*)(wsb + ws.sd) + (size_t)g * a->batch * nch * Dg;
+        P.agg_h = (float*)(wsb + ws.e) + (size_t)g * a->batch * nch * N * Dg;
+        P.carry = (float*)(wsb + ws.carry) + (size_t)g * a->batch * nch * N * Dg;
+        P.part = (float*)(wsb + ws.part) + (size_t)g * a->batch * nch * (N + 2) * Dg;
+        P.dout = seq_at(b->dout, d0, es); P.du = seq_at(b->du, d0, es);
+        P.ddelta = seq_at(b->ddelta, d0, es); P.dz = seq_at(b->dz, d0, es);
+        P.dB = (float*)b->dB.ptr + (int64_t)g * b->dB.stride_g;
+        P.dB_sb = b->dB.stride_b; P.dB_st = b->dB.stride_t; P.dB_sn = b->dB.stride_n;
+        P.dC = (float*)b->dC.ptr + (int64_t)g * b->dC.stride_g;
+        P.dC_sb = b->dC.stride_b; P.dC_st = b->dC.stride_t; P.dC_sn = b->dC.stride_n;
+        P.atomic_bc = P.gm.ndt > 1;
+        if (P.atomic_bc) {
+            const int64_t total = a->seqlen * N;
+            dim3 cg((unsigned)((total + 255) / 256), a->batch);
+            hipLaunchKernelGGL(clear_bc_kernel, cg, dim3(256), 0, stream, P.dB, P.dB_sb, P.dB_st, P.dB_sn, (int32_t)a->seqlen, N);
+            hipLaunchKernelGGL(clear_bc_kernel, cg, dim3(256), 0, stream, P.dC, P.dC_sb, P.dC_st, P.dC_sn, (int32_t)a->seqlen, N);
+        }
+        if (a->dtype == SEGM_F32) rc = launch_bwd_ns<float>(P, stream);
+        else if (a->dtype == SEGM_F16) rc = launch_bwd_ns<f16_t>(P, stream);
+        else rc = launch_bwd_ns<bf16_t>(P, stream);
+        if (rc != 0) return rc;
+        launch_reduce_partials(P.part, (int64_t)a->batch * nch, N + 2, Dg, b->dA + d0 * N, N,
+                               b->dD ? b->dD + d0 : nullptr, b->ddelta_bias ? b->ddelta_bias + d0 : nullptr, stream);
+    }
+    return (int)hipGetLastError();
+}

@@ -52,7 +52,7 @@ __device__ __forceinline__ void stage_fetch(StageRegs<TS, NS, RW>& rg, const BC&
         const int e = r + i * RW;
         int s, n;
         if (t_fastest) { n = e / TS; s = e - n * TS; } else { s = e / NS; n = e - s * NS; }
-        const bool ok = item_ok && n < nstate && (it0.tau + s) < tm.L;
+        const bool ok = item_ok && n < nstate && (it0.tau + s) < tm.L && (it0.tau + s) >= 0;
         const int32_t t = ok ? it0.ahead(tm, s) : 0;
         const float v = to_f32(base[row_off(t, m.st) + (ok ? (int64_t)n * m.sn : 0)]);
         rg.v[i] = ok ? v : 0.f;
@@ -77,7 +77,7 @@ __device__ __forceinline__ uint32_t row_indices(int32_t (&tt)[TS], const TimeMap
     uint32_t okm = 0;
 #pragma unroll
     for (int j = 0; j < TS; ++j) {
-        const bool ok = lane_ok && tj.tau < tm.L;
+        const bool ok = lane_ok && tj.tau < tm.L && tj.tau >= 0;
         tt[j] = ok ? tj.t : 0;
         okm |= ok ? (1u << j) : 0u;
         tj.next(tm);
