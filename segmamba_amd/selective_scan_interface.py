@@ -1,0 +1,290 @@
+"""`mamba_ssm.ops.selective_scan_interface` on the MI355X kernels.
+
+Host-side mirror of reference mamba/mamba_ssm/ops/selective_scan_interface.py:
+  SelectiveScanFn / selective_scan_fn          :14-83
+  MambaInnerFnNoOutProj / mamba_inner_fn_no_out_proj   :155-289, :627-633   (the one SegMamba uses)
+  mamba_inner_fn / bimamba_inner_fn            :292-624 (same inner pipeline + output projection)
+Same names, argument order, layouts ((batch, dim, seqlen) tensors, B/C as (batch, [groups,] dstate,
+seqlen)) and error behaviour.  What changes underneath:
+
+  * the native ops are `segm_*` entry points of libsegmamba_hip.so (no fallback if it is missing);
+  * the inner pipeline exists once (`MambaInnerCore`) and is layout- and time-order-generic: the reference
+    entry points call it with channel-first views, `Mamba.forward` calls it on the channel-last (B, L, 2D)
+    tensor the in-projection GEMM naturally produces, with the reversed / slice-interleaved directions as
+    an index map inside the kernels instead of `flip` / `stack` / `permute` copies
+    (reference mamba_simple.py:231,245-247,261);
+  * B and C are never transposed into separate contiguous tensors (reference :193,205): the scan reads
+    them as strided views of `x_dbl`, and dB / dC are accumulated straight into the matching columns of
+    the fp32 `dx_dbl` buffer (reference :257-268 does two more transposing copies).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import lib as L
+from . import ops_raw
+
+
+def _custom_fwd(fn):
+    return torch.amp.custom_fwd(fn, device_type="cuda")
+
+
+def _custom_bwd(fn):
+    return torch.amp.custom_bwd(fn, device_type="cuda")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# standalone selective scan
+# ---------------------------------------------------------------------------------------------------------
+class SelectiveScanFn(torch.autograd.Function):
+    """reference: selective_scan_interface.py:14-73"""
+
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                return_last_state=False):
+        if u.stride(-1) != 1:
+            u = u.contiguous()
+        if delta.stride(-1) != 1:
+            delta = delta.contiguous()
+        if D is not None:
+            D = D.contiguous()
+        if B.stride(-1) != 1:
+            B = B.contiguous()
+        if C.stride(-1) != 1:
+            C = C.contiguous()
+        if z is not None and z.stride(-1) != 1:
+            z = z.contiguous()
+        if A.is_complex() or B.dim() < 3 or C.dim() < 3:
+            raise RuntimeError("only real A with input-dependent B and C is supported (the SegMamba path)")
+        A32 = A.float().contiguous()
+        D32 = D.float() if D is not None else None
+        db32 = delta_bias.float().contiguous() if delta_bias is not None else None
+        r = ops_raw.scan_fwd(L.get_lib(), u, delta, A32, B, C, D32, z, db32, delta_softplus, channel_last=False,
+                             need_out=True, need_ckpt=True, need_last_state=return_last_state)
+        ctx.delta_softplus = delta_softplus
+        ctx.has_z = z is not None
+        ctx.chunk = r["chunk"]
+        ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias, r["out"], r["ckpt"])
+        res = r["out_z"] if ctx.has_z else r["out"]
+        if return_last_state:
+            ctx.mark_non_differentiable(r["last_state"])
+            return res, r["last_state"]
+        return res
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        u, delta, A, B, C, D, z, delta_bias, out, ckpt = ctx.saved_tensors
+        if dout.stride(-1) != 1:
+            dout = dout.contiguous()
+        A32 = A.float().contiguous()
+        D32 = D.float() if D is not None else None
+        db32 = delta_bias.float().contiguous() if delta_bias is not None else None
+        g = ops_raw.scan_bwd(L.get_lib(), u, delta, A32, B, C, D32, z, db32, dout, out, ckpt, ctx.delta_softplus,
+                             channel_last=False, chunk=ctx.chunk)
+        return (g["du"], g["ddelta"], g["dA"].to(A.dtype), g["dB"].to(B.dtype), g["dC"].to(C.dtype),
+                g["dD"].to(D.dtype) if D is not None else None,
+                g["dz"] if z is not None else None,
+                g["ddelta_bias"].to(delta_bias.dtype) if delta_bias is not None else None,
+                None, None)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """if return_last_state is True, returns (out, last_state); last_state has shape (batch, dim, dstate)
+    and its gradient is not considered in the backward pass (reference :76-83)."""
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fused inner pipeline: conv1d+SiLU -> x_proj -> dt_proj -> selective scan (gated by silu(z))
+# ---------------------------------------------------------------------------------------------------------
+class MambaInnerCore(torch.autograd.Function):
+    """out_z = scan(silu(conv1d(x)), softplus(dt_proj(x_proj(.)) + bias), A, B(.), C(.), D) * silu(z).
+
+    xz is (batch, 2*dim, seqlen) when `channel_last` is False (the reference layout) and
+    (batch, seqlen, 2*dim) when True; the result has the layout of one half of xz.  `time_order` /
+    `nslices` select the logical direction (lib.TIME_*).  Activations recomputed in backward: the conv output
+    and delta (reference checkpoint_lvl=1, :161,218-219,238-241).
+    """
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
+                B_proj_bias, C_proj_bias, delta_softplus, channel_last, time_order, nslices):
+        lib = L.get_lib()
+        if torch.is_autocast_enabled():
+            act_dtype = torch.get_autocast_dtype("cuda")
+            x_proj_weight = x_proj_weight.to(dtype=act_dtype)
+            delta_proj_weight = delta_proj_weight.to(dtype=act_dtype)
+        cdim = 2 if channel_last else 1
+        if (xz.stride(1) if channel_last else xz.stride(2)) != 1 and xz.stride(cdim) != 1:
+            xz = xz.contiguous()
+        dim = xz.shape[cdim] // 2
+        R = delta_proj_weight.shape[1]
+        N = A.shape[-1]
+        if A.is_complex():
+            raise RuntimeError("complex A is not supported (not on the SegMamba path)")
+        w32 = conv1d_weight.reshape(dim, -1).float().contiguous()
+        cb32 = conv1d_bias.float().contiguous() if conv1d_bias is not None else None
+        A32 = A.float().contiguous()
+        D32 = D.float().contiguous() if D is not None else None
+        db32 = delta_bias.float().contiguous() if delta_bias is not None else None
+        x, z = xz.split(dim, dim=cdim)
+        conv_out = ops_raw.conv1d_fwd(lib, x, w32, cb32, True, channel_last=channel_last, time_order=time_order,
+                                      nslices=nslices)
+        x_dbl, delta, Bv, Cv = _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last,
+                                        B_proj_bias, C_proj_bias)
+        r = ops_raw.scan_fwd(lib, conv_out, delta, A32, Bv, Cv, D32, z, db32, delta_softplus,
+                             channel_last=channel_last, time_order=time_order, nslices=nslices,
+                             need_out=True, need_ckpt=True)
+        ctx.cfg = (bool(delta_softplus), bool(channel_last), int(time_order), int(nslices), r["chunk"], R, N,
+                   B_proj_bias is not None, C_proj_bias is not None)
+        ctx.save_for_backward(xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, A, D,
+                              delta_bias, B_proj_bias, C_proj_bias, r["out"], r["ckpt"])
+        return r["out_z"]
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dout):
+        lib = L.get_lib()
+        (xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, A, D, delta_bias,
+         B_proj_bias, C_proj_bias, out, ckpt) = ctx.saved_tensors
+        delta_softplus, channel_last, time_order, nslices, chunk, R, N, has_Bb, has_Cb = ctx.cfg
+        cdim = 2 if channel_last else 1
+        dim = xz.shape[cdim] // 2
+        batch = xz.shape[0]
+        seqlen = xz.shape[1] if channel_last else xz.shape[2]
+        w32 = conv1d_weight.reshape(dim, -1).float().contiguous()
+        cb32 = conv1d_bias.float().contiguous() if conv1d_bias is not None else None
+        A32 = A.float().contiguous()
+        D32 = D.float().contiguous() if D is not None else None
+        db32 = delta_bias.float().contiguous() if delta_bias is not None else None
+        x, z = xz.split(dim, dim=cdim)
+        if (dout.stride(1) if channel_last else dout.stride(2)) != 1 and dout.stride(cdim) != 1:
+            dout = dout.contiguous()
+        # recompute conv output and delta (checkpoint_lvl 1)
+        conv_out = ops_raw.conv1d_fwd(lib, x, w32, cb32, True, channel_last=channel_last, time_order=time_order,
+                                      nslices=nslices)
+        _, delta, Bv, Cv = _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last,
+                                    B_proj_bias, C_proj_bias, x_dbl=x_dbl)
+        dxz = torch.empty_like(xz, memory_format=torch.contiguous_format)
+        dx, dz = dxz.split(dim, dim=cdim)                 # dx / dz written in place (reference :244-245)
+        g = ops_raw.scan_bwd(lib, conv_out, delta, A32, Bv, Cv, D32, z, db32, dout, out, ckpt, delta_softplus,
+                             channel_last=channel_last, time_order=time_order, nslices=nslices, chunk=chunk, dz=dz)
+        dconv_out, ddelta = g["du"], g["ddelta"]
+        # (b*l, .) matrices for the projection gradients
+        if channel_last:
+            dB2 = g["dB"].reshape(batch * seqlen, N)
+            dC2 = g["dC"].reshape(batch * seqlen, N)
+            ddelta2 = ddelta.reshape(batch * seqlen, dim)                       # (bl, d)
+            conv2 = conv_out.reshape(batch * seqlen, dim)
+            dconv2 = dconv_out.reshape(batch * seqlen, dim)
+        else:
+            dB2 = g["dB"].reshape(batch, N, seqlen).permute(0, 2, 1).reshape(batch * seqlen, N)
+            dC2 = g["dC"].reshape(batch, N, seqlen).permute(0, 2, 1).reshape(batch * seqlen, N)
+            ddelta2 = ddelta.permute(0, 2, 1).reshape(batch * seqlen, dim)
+            conv2 = conv_out.permute(0, 2, 1).reshape(batch * seqlen, dim)
+            dconv2 = dconv_out.permute(0, 2, 1).reshape(batch * seqlen, dim)
+        dx_dbl = torch.empty_like(x_dbl)
+        dx_dbl[:, R:R + N] = dB2
+        dx_dbl[:, R + N:] = dC2
+        dB_proj_bias = dB2.sum(0).to(B_proj_bias.dtype) if has_Bb else None
+        dC_proj_bias = dC2.sum(0).to(C_proj_bias.dtype) if has_Cb else None
+        ddelta_proj_weight = ddelta2.t() @ x_dbl[:, :R]                         # (d, R)    reference :272
+        dx_dbl[:, :R] = ddelta2 @ delta_proj_weight                             # (bl, R)   reference :273
+        dx_proj_weight = dx_dbl.t() @ conv2                                     # (R+2N, d) reference :275
+        dconv2 = torch.addmm(dconv2, dx_dbl, x_proj_weight)                     # (bl, d)   reference :276
+        dconv_full = dconv2.reshape(batch, seqlen, dim)
+        if not channel_last:
+            dconv_full = dconv_full.permute(0, 2, 1)                             # strided (b, d, l) view
+        _, dconv_w, dconv_b = ops_raw.conv1d_bwd(lib, x, w32, cb32, dconv_full, True, channel_last=channel_last,
+                                                 time_order=time_order, nslices=nslices, dx=dx)
+        dconv_w = dconv_w.reshape(conv1d_weight.shape).to(conv1d_weight.dtype)
+        dconv_b = dconv_b.to(conv1d_bias.dtype) if conv1d_bias is not None else None
+        return (dxz, dconv_w, dconv_b, dx_proj_weight.to(x_proj_weight.dtype),
+                ddelta_proj_weight.to(delta_proj_weight.dtype), g["dA"].to(A.dtype),
+                g["dD"].to(D.dtype) if D is not None else None,
+                g["ddelta_bias"].to(delta_bias.dtype) if delta_bias is not None else None,
+                dB_proj_bias, dC_proj_bias, None, None, None, None)
+
+
+def _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last, B_proj_bias, C_proj_bias, x_dbl=None):
+    """x_dbl = x_proj(conv_out) as (b*l, R+2N); delta = dt_proj(x_dbl[:, :R]) in conv_out's layout;
+    B / C as strided views of x_dbl in the layout the scan expects (no transposing copy)."""
+    if channel_last:
+        batch, seqlen, dim = conv_out.shape
+        if x_dbl is None:
+            x_dbl = F.linear(conv_out.reshape(batch * seqlen, dim), x_proj_weight)
+        delta = F.linear(x_dbl[:, :R], delta_proj_weight).reshape(batch, seqlen, dim)
+        v3 = x_dbl.view(batch, seqlen, R + 2 * N)
+        Bv, Cv = v3[:, :, R:R + N], v3[:, :, R + N:]
+    else:
+        batch, dim, seqlen = conv_out.shape
+        if x_dbl is None:
+            x_dbl = F.linear(conv_out.permute(0, 2, 1).reshape(batch * seqlen, dim), x_proj_weight)
+        delta = (delta_proj_weight @ x_dbl[:, :R].t()).reshape(dim, batch, seqlen).permute(1, 0, 2).contiguous()
+        v3 = x_dbl.view(batch, seqlen, R + 2 * N)
+        Bv, Cv = v3[:, :, R:R + N].permute(0, 2, 1), v3[:, :, R + N:].permute(0, 2, 1)
+    if B_proj_bias is not None:
+        Bv = Bv + (B_proj_bias.to(Bv.dtype) if channel_last else B_proj_bias.to(Bv.dtype)[:, None])
+    if C_proj_bias is not None:
+        Cv = Cv + (C_proj_bias.to(Cv.dtype) if channel_last else C_proj_bias.to(Cv.dtype)[:, None])
+    return x_dbl, delta, Bv, Cv
+
+
+def _inner(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias,
+           B_proj_bias, C_proj_bias, delta_softplus, channel_last=False, time_order=L.TIME_FORWARD, nslices=1):
+    if B is not None or C is not None:
+        raise RuntimeError("constant B / C is not supported: B and C must be None (input-dependent), "
+                           "the only case on the SegMamba path")
+    return MambaInnerCore.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
+                                B_proj_bias, C_proj_bias, delta_softplus, channel_last, time_order, nslices)
+
+
+def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                               A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                               C_proj_bias=None, delta_softplus=True):
+    """reference :627-633.  xz: (batch, 2*dim, seqlen) -> (batch, dim, seqlen)"""
+    return _inner(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias,
+                  B_proj_bias, C_proj_bias, delta_softplus)
+
+
+def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                   out_proj_weight, out_proj_bias,
+                   A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                   C_proj_bias=None, delta_softplus=True):
+    """reference :606-614 (MambaInnerFn :292-434): the inner pipeline followed by the output projection."""
+    y = _inner(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias,
+               B_proj_bias, C_proj_bias, delta_softplus)
+    return F.linear(y.transpose(1, 2), out_proj_weight, out_proj_bias)
+
+
+def bimamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                     out_proj_weight, out_proj_bias,
+                     A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                     C_proj_bias=None, delta_softplus=True):
+    """reference :616-624 (BiMambaInnerFn :437-603): forward scan with A plus a scan of the reversed
+    sequence with A_b sharing every other weight, summed, then the output projection."""
+    y = _inner(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias,
+               B_proj_bias, C_proj_bias, delta_softplus)
+    # the reference reverses u, delta, B, C, z *after* the (forward-order) conv and projections
+    # (:478-486), i.e. only the recurrence runs right-to-left; expressed here by flipping its inputs/outputs
+    y_b = _bimamba_reverse(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A_b, D, delta_bias,
+                           B_proj_bias, C_proj_bias, delta_softplus)
+    return F.linear((y + y_b).transpose(1, 2), out_proj_weight, out_proj_bias)
+
+
+def _bimamba_reverse(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A_b, D, delta_bias,
+                     B_proj_bias, C_proj_bias, delta_softplus):
+    from .causal_conv1d_interface import causal_conv1d_fn
+    dim = xz.shape[1] // 2
+    R = delta_proj_weight.shape[1]
+    N = A_b.shape[-1]
+    x, z = xz.split(dim, dim=1)
+    conv_out = causal_conv1d_fn(x, conv1d_weight.reshape(dim, -1), conv1d_bias, "silu")
+    _, delta, Bv, Cv = _project(conv_out, x_proj_weight.to(conv_out.dtype), delta_proj_weight.to(conv_out.dtype),
+                                R, N, False, B_proj_bias, C_proj_bias)
+    y_b = selective_scan_fn(conv_out.flip(-1), delta.flip(-1), A_b, Bv.flip(-1), Cv.flip(-1), D, z.flip(-1),
+                            delta_bias, delta_softplus)
+    return y_b.flip(-1)
