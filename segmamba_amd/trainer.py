@@ -1,0 +1,79 @@
+"""Training-step harness for SegMamba on synthetic BraTS volumes.
+
+Mirrors the body of the reference loop - `Trainer.train_epoch` (light_training/trainer.py:429-483) driving
+`BraTSTrainer.training_step` (3_train.py:57-66):
+
+    zero grads -> autocast forward -> CrossEntropyLoss -> backward -> clip_grad_norm_(12) -> SGD step -> poly LR
+
+with the reference hyper-parameters (3_train.py:51-52: SGD lr 1e-2, weight decay 3e-5, momentum 0.99, nesterov;
+lr_scheduler.py:36 poly 0.9).  Differences, all deliberate:
+  * autocast dtype is bf16 (the north star's dtype; the reference's default fp16 + GradScaler is not needed for bf16);
+  * data come from a device-side synthetic generator instead of the 18-process batchgenerators pipeline
+    (trainer.py:154-162), which is out of scope;
+  * multi-GPU is the same plain DDP (trainer.py:353-357: find_unused_parameters=True) over RCCL; one process per GPU,
+    launched by torchrun - batch per GPU stays 2 (weak scaling), gradients are all-reduced in DDP's buckets.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+
+from .segmamba import SegMamba
+
+
+class SyntheticBraTS:
+    """Random 4-modality volumes + 4-class label maps generated on the device (per-rank seed as trainer.py:331)."""
+
+    def __init__(self, batch: int, size: int, device, seed: int = 42, pool: int = 2):
+        g = torch.Generator(device=device).manual_seed(seed)
+        self.items = []
+        for _ in range(pool):
+            image = torch.rand(batch, 4, size, size, size, device=device, generator=g)
+            label = torch.randint(0, 4, (batch, size, size, size), device=device, generator=g)
+            self.items.append((image, label))
+        self.i = 0
+
+    def next(self):
+        item = self.items[self.i % len(self.items)]
+        self.i += 1
+        return item
+
+
+@dataclass
+class TrainingState:
+    model: nn.Module
+    optimizer: torch.optim.Optimizer
+    scheduler: object
+    loss_fn: nn.Module
+    autocast_dtype: torch.dtype = torch.bfloat16
+    clip: float = 12.0
+    step: int = 0
+
+
+def build_training_state(device, distributed: bool = False, local_rank: int = 0, max_steps: int = 250 * 1000,
+                         model: nn.Module | None = None) -> TrainingState:
+    if model is None:
+        model = SegMamba(in_chans=4, out_chans=4, depths=[2, 2, 2, 2], feat_size=[48, 96, 192, 384])
+    model = model.to(device)
+    if distributed:
+        model = torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=[local_rank] if device.type == "cuda" else None, find_unused_parameters=True)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: (1 - min(s, max_steps - 1) / max_steps) ** 0.9)
+    return TrainingState(model=model, optimizer=opt, scheduler=sched, loss_fn=nn.CrossEntropyLoss())
+
+
+def train_step(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    for p in st.model.parameters():
+        p.grad = None                                              # trainer.py:445
+    with torch.autocast(image.device.type, dtype=st.autocast_dtype, enabled=image.device.type == "cuda"):
+        pred = st.model(image)
+        loss = st.loss_fn(pred, label)                             # 3_train.py:62
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(st.model.parameters(), st.clip)  # trainer.py:464
+    st.optimizer.step()
+    st.scheduler.step()
+    st.step += 1
+    return loss.detach()

@@ -1,0 +1,162 @@
+"""Shared case builders / comparators for the kernel parity tests (CPU-emulation and GPU runs use the same ones)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from oracle import ref_ops
+from segmamba_amd import lib as L
+from segmamba_amd import ops_raw
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def perm(x, order, ns):
+    """Materialise a time order the way the reference does (flip / slice-interleave copies)."""
+    if x is None:
+        return None
+    if order == L.TIME_REVERSED:
+        return x.flip(-1)
+    if order == L.TIME_INTERLEAVED:
+        return ref_ops.slice_interleave(x, ns)
+    return x
+
+
+def iperm(x, order, ns):
+    if order == L.TIME_REVERSED:
+        return x.flip(-1)
+    if order == L.TIME_INTERLEAVED:
+        return ref_ops.slice_deinterleave(x, ns)
+    return x
+
+
+def assert_close(a, b, rtol, atol, what=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; "
+                           f"max abs err {err.max().item():.3e} (rtol {rtol}, atol {atol}, ref max {b.abs().max().item():.3e})")
+
+
+def scan_case(batch, dim, dstate, seqlen, dtype=torch.float32, groups=1, seed=0, has_z=True, has_D=True,
+              has_bias=True):
+    """Reference test distributions: mamba/tests/ops/test_selective_scan.py:53-88."""
+    g = torch.Generator().manual_seed(seed)
+    c = {}
+    c["A"] = -0.5 * torch.rand(dim, dstate, generator=g)
+    shape = (batch, dstate, seqlen) if groups == 1 else (batch, groups, dstate, seqlen)
+    c["B"] = torch.randn(*shape, generator=g).to(dtype)
+    c["C"] = torch.randn(*shape, generator=g).to(dtype)
+    c["D"] = torch.randn(dim, generator=g) if has_D else None
+    c["z"] = torch.randn(batch, dim, seqlen, generator=g).to(dtype) if has_z else None
+    c["delta_bias"] = 0.5 * torch.rand(dim, generator=g) if has_bias else None
+    c["u"] = torch.randn(batch, dim, seqlen, generator=g).to(dtype)
+    c["delta"] = (0.5 * torch.rand(batch, dim, seqlen, generator=g)).to(dtype)
+    c["g"] = torch.randn(batch, dim, seqlen, generator=g).to(dtype)
+    return c
+
+
+def scan_oracle(c, order=L.TIME_FORWARD, ns=1, softplus=True, want_grads=True):
+    """Oracle outputs / gradients in the reference layout, time order applied by explicit copies."""
+    leaves = {k: (c[k].clone().requires_grad_() if c[k] is not None else None)
+              for k in ("u", "delta", "A", "B", "C", "D", "z", "delta_bias")}
+    out, last = ref_ops.selective_scan_ref(
+        perm(leaves["u"], order, ns), perm(leaves["delta"], order, ns), leaves["A"], perm(leaves["B"], order, ns),
+        perm(leaves["C"], order, ns), leaves["D"], z=perm(leaves["z"], order, ns), delta_bias=leaves["delta_bias"],
+        delta_softplus=softplus, return_last_state=True)
+    out = iperm(out, order, ns)
+    res = {"out": out.detach(), "last_state": last.detach()}
+    if want_grads:
+        out.backward(c["g"])
+        for k, v in leaves.items():
+            if v is not None:
+                res["d" + k] = v.grad
+    return res
+
+
+def to_dev_layout(c, device, channel_last):
+    """Move a case to `device` in the requested layout.  channel_last: (B, L, D) tensors, B/C (B, L, [G,] N)."""
+    def seq(t):
+        if t is None:
+            return None
+        t = t.to(device)
+        return t.transpose(1, 2).contiguous() if channel_last else t.contiguous()
+
+    def bc(t):
+        t = t.to(device)
+        if not channel_last:
+            return t.contiguous()
+        return (t.permute(0, 2, 1) if t.dim() == 3 else t.permute(0, 3, 1, 2)).contiguous()
+
+    d = {k: seq(c[k]) for k in ("u", "delta", "z", "g")}
+    d["B"], d["C"] = bc(c["B"]), bc(c["C"])
+    for k in ("A", "D", "delta_bias"):
+        d[k] = c[k].to(device) if c[k] is not None else None
+    return d
+
+
+def from_dev_seq(t, channel_last):
+    return t.transpose(1, 2) if channel_last else t
+
+
+def from_dev_bc(t, channel_last):
+    if not channel_last:
+        return t
+    return t.permute(0, 2, 1) if t.dim() == 3 else t.permute(0, 2, 3, 1)
+
+
+def run_scan(lib, c, device, channel_last, order=L.TIME_FORWARD, ns=1, chunk=0, softplus=True, backward=True):
+    d = to_dev_layout(c, device, channel_last)
+    f = ops_raw.scan_fwd(lib, d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], d["z"], d["delta_bias"], softplus,
+                         channel_last=channel_last, time_order=order, nslices=ns, chunk=chunk, need_out=True,
+                         need_ckpt=True, need_last_state=True)
+    res = {"out": from_dev_seq(f["out_z"] if d["z"] is not None else f["out"], channel_last),
+           "last_state": f["last_state"]}
+    if backward:
+        r = ops_raw.scan_bwd(lib, d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], d["z"], d["delta_bias"], d["g"],
+                             f["out"], f["ckpt"], softplus, channel_last=channel_last, time_order=order, nslices=ns,
+                             chunk=f["chunk"])
+        res.update(du=from_dev_seq(r["du"], channel_last), ddelta=from_dev_seq(r["ddelta"], channel_last),
+                   dA=r["dA"], dB=from_dev_bc(r["dB"], channel_last), dC=from_dev_bc(r["dC"], channel_last),
+                   dD=r["dD"], ddelta_bias=r["ddelta_bias"])
+        if d["z"] is not None:
+            res["dz"] = from_dev_seq(r["dz"], channel_last)
+    return res
+
+
+def scan_tolerances(dtype):
+    """reference tolerances, mamba/tests/ops/test_selective_scan.py:45-51,137-149"""
+    rtol, atol = (6e-4, 2e-3) if dtype == torch.float32 else (3e-3, 5e-3)
+    if dtype == torch.bfloat16:
+        rtol, atol = 3e-2, 5e-2
+    rtolw, atolw = max(1e-3, rtol), max(1e-3, atol)
+    return rtol, atol, rtolw, atolw
+
+
+def check_scan(res, ref, dtype, what=""):
+    rtol, atol, rtolw, atolw = scan_tolerances(dtype)
+    assert_close(res["out"], ref["out"], rtol, atol, what + " out")
+    assert_close(res["last_state"], ref["last_state"], rtol, atol, what + " last_state")
+    if "du" not in res:
+        return
+    assert_close(res["du"], ref["du"], rtol * 2, atol * 2, what + " du")
+    assert_close(res["ddelta"], ref["ddelta"], rtol * 5, atol * 10, what + " ddelta")
+    assert_close(res["dA"], ref["dA"], rtolw, atolw * 5, what + " dA")
+    assert_close(res["dB"], ref["dB"], rtol, atol, what + " dB")
+    assert_close(res["dC"], ref["dC"], rtol, atol, what + " dC")
+    if ref.get("dD") is not None:
+        assert_close(res["dD"], ref["dD"], rtolw, atolw, what + " dD")
+    if ref.get("dz") is not None:
+        assert_close(res["dz"], ref["dz"], rtolw, atolw, what + " dz")
+    if ref.get("ddelta_bias") is not None:
+        assert_close(res["ddelta_bias"], ref["ddelta_bias"], rtolw, atolw, what + " ddelta_bias")

@@ -1,0 +1,204 @@
+"""GPU parity tests: the HIP kernels (through the C ABI of libsegmamba_hip.so) against the CPU oracle and against the
+golden fixtures produced by the reference.  Tolerances are the reference's own (see helpers.scan_tolerances) which are
+at or below the north-star bounds for fp32 (1e-3) / bf16 (1e-2 relative)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from segmamba_amd import lib as L
+from segmamba_amd import ops_raw
+from oracle import ref_ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    return L.get_lib()          # raises if the HIP library is missing: no fallback
+
+
+# ---- reference test matrix: mamba/tests/ops/test_selective_scan.py:18-39 ------------------------------------------
+@pytest.mark.parametrize("seqlen", [128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("groups", [1, 2])
+@pytest.mark.parametrize("channel_last", [False, True])
+def test_scan_reference_matrix(hip, seqlen, groups, channel_last):
+    c = H.scan_case(2, 4, 8, seqlen, groups=groups)
+    ref = H.scan_oracle(c)
+    res = H.run_scan(hip, c, DEV, channel_last)
+    H.check_scan(res, ref, torch.float32, f"L={seqlen} G={groups} cl={channel_last}")
+
+
+@pytest.mark.parametrize("L_", [64, 256])
+@pytest.mark.parametrize("G", [1, 2])
+def test_scan_golden_from_reference(hip, L_, G):
+    """Inputs AND expected outputs/gradients come from the reference's selective_scan_ref (tests/golden)."""
+    f = H.load_golden(f"scan_L{L_}_G{G}.npz")
+    c = {k: f[k] for k in ("u", "delta", "A", "B", "C", "D", "z", "delta_bias", "g")}
+    ref = {k: f[k] for k in ("out", "last_state", "du", "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias")}
+    for cl in (False, True):
+        H.check_scan(H.run_scan(hip, c, DEV, cl), ref, torch.float32, f"golden L={L_} G={G} cl={cl}")
+
+
+# ---- SegMamba shapes (dim = 2*d_model, dstate 16), all three time orders, odd lengths, chunk sizes -------------------
+@pytest.mark.parametrize("dim,seqlen,ns", [(96, 1536, 64), (192, 512, 32), (384, 256, 16), (768, 64, 8)])
+@pytest.mark.parametrize("order", [L.TIME_FORWARD, L.TIME_REVERSED, L.TIME_INTERLEAVED])
+def test_scan_segmamba_shapes(hip, dim, seqlen, ns, order):
+    c = H.scan_case(2, dim, 16, seqlen, seed=dim)
+    ref = H.scan_oracle(c, order, ns)
+    res = H.run_scan(hip, c, DEV, True, order, ns)
+    H.check_scan(res, ref, torch.float32, f"D={dim} L={seqlen} order={order}")
+
+
+@pytest.mark.parametrize("seqlen,chunk", [(1, 32), (7, 32), (33, 32), (100, 64), (777, 128), (1000, 256)])
+def test_scan_ragged_lengths_and_chunks(hip, seqlen, chunk):
+    c = H.scan_case(2, 40, 16, seqlen, seed=seqlen)
+    ref = H.scan_oracle(c)
+    res = H.run_scan(hip, c, DEV, True, chunk=chunk)
+    H.check_scan(res, ref, torch.float32, f"L={seqlen} chunk={chunk}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("channel_last", [False, True])
+def test_scan_half_precision(hip, dtype, channel_last):
+    c = H.scan_case(2, 96, 16, 512, dtype=dtype)
+    ref = H.scan_oracle(c)
+    res = H.run_scan(hip, c, DEV, channel_last)
+    H.check_scan(res, ref, dtype, f"{dtype}")
+
+
+def test_scan_optional_arguments(hip):
+    for has_z, has_D, has_bias, softplus in [(False, True, True, True), (True, False, False, False), (False, False, False, True)]:
+        c = H.scan_case(1, 32, 16, 200, has_z=has_z, has_D=has_D, has_bias=has_bias, seed=3)
+        ref = H.scan_oracle(c, softplus=softplus)
+        res = H.run_scan(hip, c, DEV, True, softplus=softplus)
+        H.check_scan(res, ref, torch.float32, f"z={has_z} D={has_D} bias={has_bias} softplus={softplus}")
+
+
+def test_scan_forward_is_deterministic_and_chunk_invariant(hip):
+    """Bit-identical repeats (reference: test_causal_conv1d_race_condition idea, applied to the scan forward);
+    different chunkings agree to rounding."""
+    c = H.scan_case(2, 96, 16, 4096, seed=11)
+    a = H.run_scan(hip, c, DEV, True, chunk=128, backward=False)["out"]
+    for _ in range(5):
+        b = H.run_scan(hip, c, DEV, True, chunk=128, backward=False)["out"]
+        assert torch.equal(a, b)
+    d = H.run_scan(hip, c, DEV, True, chunk=1024, backward=False)["out"]
+    H.assert_close(d, a, 1e-4, 1e-4, "chunk 1024 vs 128")
+
+
+def test_scan_full_size_properties(hip):
+    """BASELINE config-1 size per direction (B=2, D=768, L=64^3 is 3.2 GB fp32 per tensor: run the stage-0 SegMamba size
+    B=2, D=96, L=262144 instead) through size-independent properties: linearity in u, reversal symmetry, and a
+    64-row spot check against the oracle."""
+    B_, D_, N_, L_ = 2, 96, 16, 262144
+    g = torch.Generator(device=DEV).manual_seed(0)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    u1, u2 = r(B_, L_, D_), r(B_, L_, D_)
+    delta = 0.5 * torch.rand(B_, L_, D_, device=DEV, generator=g)
+    A = -0.5 * torch.rand(D_, N_, device=DEV, generator=g)
+    Bm, Cm = r(B_, L_, N_), r(B_, L_, N_)
+    Dv, db = r(D_), 0.5 * torch.rand(D_, device=DEV, generator=g)
+
+    def fwd(u, order=L.TIME_FORWARD, dl=delta, b=Bm, c=Cm):
+        return ops_raw.scan_fwd(hip, u, dl, A, b, c, Dv, None, db, True, channel_last=True, time_order=order)["out"]
+
+    y1, y2, y12 = fwd(u1), fwd(u2), fwd(u1 + 2.0 * u2)
+    H.assert_close(y12, y1 + 2.0 * y2, 2e-3, 2e-3, "linearity in u")
+    # REVERSED order on explicitly flipped inputs == FORWARD order, flipped
+    yr = fwd(u1.flip(1), L.TIME_REVERSED, delta.flip(1), Bm.flip(1), Cm.flip(1))
+    H.assert_close(yr.flip(1), y1, 1e-4, 1e-4, "reversal symmetry")
+    # spot rows: the first 2048 steps depend only on the first 2048 inputs
+    T = 2048
+    ref = ref_ops.selective_scan_ref(u1[:, :T].transpose(1, 2).cpu(), delta[:, :T].transpose(1, 2).cpu(), A.cpu(),
+                                     Bm[:, :T].transpose(1, 2).cpu(), Cm[:, :T].transpose(1, 2).cpu(), Dv.cpu(),
+                                     delta_bias=db.cpu(), delta_softplus=True)
+    H.assert_close(y1[:, :T].transpose(1, 2), ref, 6e-4, 2e-3, "prefix vs oracle")
+
+
+# ---- causal conv1d: reference matrix causal-conv1d/tests/test_causal_conv1d.py:14-75 (dim reduced) -------------------
+@pytest.mark.parametrize("seqlen", [8, 16, 32, 64, 128, 151, 256, 372, 512, 784, 1024, 1134, 2048, 4096])
+@pytest.mark.parametrize("width", [2, 3, 4])
+@pytest.mark.parametrize("itype", [torch.float32, torch.float16, torch.bfloat16])
+def test_causal_conv1d_reference_matrix(hip, seqlen, width, itype):
+    rtol, atol = (3e-4, 1e-3) if itype == torch.float32 else (3e-3, 5e-3)
+    if itype == torch.bfloat16:
+        rtol, atol = 1e-2, 5e-2
+    torch.manual_seed(0)
+    dim = 96 + 32
+    for channel_last in (False, True):
+        for silu, has_bias in ((True, True), (False, False)):
+            # non-contiguous batch / channel strides: a slice of a larger tensor (reference :42)
+            if channel_last:
+                big = torch.randn(2, seqlen, 64 + dim + 32, device=DEV, dtype=itype)
+                x = big[:, :, 64:64 + dim]
+            else:
+                big = torch.randn(2, 64 + dim + 32, seqlen, device=DEV, dtype=itype)
+                x = big[:, 64:64 + dim, :]
+            w = torch.randn(dim, width, device=DEV)
+            b = torch.randn(dim, device=DEV) if has_bias else None
+            xr = (x.transpose(1, 2) if channel_last else x).detach().float().cpu().requires_grad_()
+            wr = w.cpu().requires_grad_()
+            br = b.cpu().requires_grad_() if has_bias else None
+            ref = ref_ops.causal_conv1d_ref(xr, wr, br, "silu" if silu else None)
+            g = torch.randn(2, dim, seqlen).to(itype).float()       # same rounded upstream gradient on both sides
+            ref.backward(g)
+            out = ops_raw.conv1d_fwd(hip, x, w, b, silu, channel_last=channel_last)
+            gd = (g.transpose(1, 2) if channel_last else g).to(DEV, itype).contiguous()
+            dx, dw, dbias = ops_raw.conv1d_bwd(hip, x, w, b, gd, silu, channel_last=channel_last)
+            tr = (lambda t: t.transpose(1, 2)) if channel_last else (lambda t: t)
+            what = f"conv L={seqlen} W={width} {itype} cl={channel_last} silu={silu}"
+            H.assert_close(tr(out), ref.to(itype), rtol, atol, what + " out")
+            H.assert_close(tr(dx), xr.grad.to(itype), rtol * 3, atol * 3, what + " dx")
+            H.assert_close(dw, wr.grad, 1e-2 if itype != torch.float32 else 1e-3, 2e-1 if itype != torch.float32 else 1e-2, what + " dweight")
+            if has_bias:
+                H.assert_close(dbias, br.grad, 1e-2 if itype != torch.float32 else 1e-3, 2e-1 if itype != torch.float32 else 1e-2, what + " dbias")
+
+
+@pytest.mark.parametrize("order,ns", [(L.TIME_REVERSED, 1), (L.TIME_INTERLEAVED, 8), (L.TIME_INTERLEAVED, 64)])
+def test_causal_conv1d_time_orders(hip, order, ns):
+    torch.manual_seed(1)
+    x = torch.randn(2, 96, 1024)
+    w, b, g = torch.randn(96, 4), torch.randn(96), torch.randn(2, 96, 1024)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = H.iperm(ref_ops.causal_conv1d_ref(H.perm(xr, order, ns), wr, br, "silu"), order, ns)
+    ref.backward(g)
+    xd, gd = x.transpose(1, 2).contiguous().to(DEV), g.transpose(1, 2).contiguous().to(DEV)
+    out = ops_raw.conv1d_fwd(hip, xd, w.to(DEV), b.to(DEV), True, channel_last=True, time_order=order, nslices=ns)
+    dx, dw, db = ops_raw.conv1d_bwd(hip, xd, w.to(DEV), b.to(DEV), gd, True, channel_last=True, time_order=order, nslices=ns)
+    H.assert_close(out.transpose(1, 2), ref, 3e-4, 1e-3, "out")
+    H.assert_close(dx.transpose(1, 2), xr.grad, 3e-4, 1e-3, "dx")
+    H.assert_close(dw, wr.grad, 1e-3, 1e-2, "dw")
+    H.assert_close(db, br.grad, 1e-3, 1e-2, "db")
+
+
+def test_causal_conv1d_repeatability(hip):
+    """reference test_causal_conv1d_race_condition (:117-173): out and dx bit-identical across repeats; here dweight /
+    dbias are too, because the per-chunk partials are reduced in a fixed order (no atomics)."""
+    torch.manual_seed(0)
+    x = torch.randn(2, 2048, 4096 + 32, device=DEV, dtype=torch.bfloat16)
+    w, b = torch.randn(4096 + 32, 4, device=DEV), torch.randn(4096 + 32, device=DEV)
+    g = torch.randn_like(x)
+    out0 = ops_raw.conv1d_fwd(hip, x, w, b, True, channel_last=True)
+    dx0, dw0, db0 = ops_raw.conv1d_bwd(hip, x, w, b, g, True, channel_last=True)
+    for _ in range(50):
+        out = ops_raw.conv1d_fwd(hip, x, w, b, True, channel_last=True)
+        dx, dw, db = ops_raw.conv1d_bwd(hip, x, w, b, g, True, channel_last=True)
+        assert torch.equal(out, out0) and torch.equal(dx, dx0) and torch.equal(dw, dw0) and torch.equal(db, db0)
+
+
+def test_error_behaviour(hip):
+    """reference TORCH_CHECKs (selective_scan.cpp:233-303, causal_conv1d.cpp:136-170) surface as RuntimeError."""
+    x = torch.randn(1, 8, 16, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops_raw.conv1d_fwd(hip, x, torch.randn(8, 5, device=DEV), None, True)            # width 5
+    with pytest.raises(RuntimeError):
+        ops_raw.conv1d_fwd(hip, x.double(), torch.randn(8, 4, device=DEV), None, True)   # dtype
+    c = H.scan_case(1, 8, 17, 16)
+    with pytest.raises(RuntimeError):
+        H.run_scan(hip, c, DEV, False, backward=False)                                    # dstate 17
+    c = H.scan_case(1, 8, 4, 16)
+    c["delta"] = c["delta"][:, :, :8]
+    with pytest.raises(RuntimeError):
+        H.run_scan(hip, c, DEV, False, backward=False)                                    # shape mismatch

@@ -1,0 +1,107 @@
+"""CPU-only checks of the host side: the C ABI exports, the drop-in names and the checkpoint-compatibility contract."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from segmamba_amd import build
+    return build.build(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    """include/segmamba_hip.h is the contract: every function it declares must be exported (no compute call here)."""
+    hdr = open(os.path.join(ROOT, "include", "segmamba_hip.h")).read()
+    declared = set(re.findall(r"\b(segm_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"segm_dtype", "segm_status", "segm_time_order"}
+    assert {"segm_selective_scan_fwd", "segm_selective_scan_bwd", "segm_causal_conv1d_fwd",
+            "segm_causal_conv1d_bwd"} <= declared
+    dll = ctypes.CDLL(built_lib)
+    missing = [n for n in sorted(declared) if not hasattr(dll, n)]
+    assert not missing, missing
+    from segmamba_amd import lib
+    assert lib.SegmLib(built_lib).missing == []
+    assert set(lib.EXPORTS) == declared
+
+
+def test_abi_queries_without_gpu(built_lib):
+    from segmamba_amd import lib
+    l = lib.SegmLib(built_lib)
+    assert l.dll.segm_abi_version() == 1
+    assert l.dll.segm_status_string(-3).decode().startswith("dstate")
+    # SegMamba stage 0: B=2, D=96, L=64^3 -> 256-step work items, 32-step checkpoints
+    assert l.dll.segm_selective_scan_default_chunk(2, 96, 262144) == 256
+    assert l.dll.segm_selective_scan_ckpt_bytes(2, 96, 16, 262144) == 2 * (262144 // 32) * 16 * 96 * 4
+    assert l.dll.segm_selective_scan_fwd_workspace_bytes(2, 96, 16, 262144, 0) > 0
+    # argument errors are reported without touching the device
+    a = lib.ScanFwdArgs()
+    assert l.dll.segm_selective_scan_fwd(a) == -2        # SEGM_E_SHAPE
+    a.batch, a.dim, a.dstate, a.n_groups, a.seqlen = 1, 8, 17, 1, 16
+    assert l.dll.segm_selective_scan_fwd(a) == -3        # SEGM_E_DSTATE
+    c = lib.Conv1dArgs()
+    c.batch, c.dim, c.width, c.seqlen = 1, 8, 5, 16
+    assert l.dll.segm_causal_conv1d_fwd(c) == -5         # SEGM_E_WIDTH
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: no module of the product may import it."""
+    for pkg in ("segmamba_amd", "mamba_ssm", "causal_conv1d", "model_segmamba"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for fn in files:
+                if fn.endswith(".py"):
+                    src = open(os.path.join(dirpath, fn)).read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dirpath, fn)
+                    assert "emu" not in re.findall(r"^\s*(?:from|import)\s+(\S+)", src, re.M)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from segmamba_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", os.path.join(ROOT, "does_not_exist.so"))
+    with pytest.raises(RuntimeError, match="no CPU / PyTorch fallback"):
+        lib.get_lib()
+
+
+def test_dropin_names_import():
+    from mamba_ssm import Mamba                                                          # segmamba.py:19
+    from causal_conv1d import causal_conv1d_fn, causal_conv1d_update                    # mamba_simple.py:14
+    from mamba_ssm.ops.selective_scan_interface import (selective_scan_fn, mamba_inner_fn, bimamba_inner_fn,   # :19
+                                                        mamba_inner_fn_no_out_proj)
+    from model_segmamba.segmamba import SegMamba                                         # 0_inference.py:4
+    assert all(callable(f) for f in (Mamba, causal_conv1d_fn, causal_conv1d_update, selective_scan_fn, mamba_inner_fn,
+                                     bimamba_inner_fn, mamba_inner_fn_no_out_proj, SegMamba))
+
+
+def test_segmamba_state_dict_matches_reference_keys(golden_dir):
+    """291 keys / shapes / 67 416 196 parameters: the checkpoint-compatibility contract."""
+    from model_segmamba.segmamba import SegMamba
+    m = SegMamba(in_chans=4, out_chans=4, depths=[2, 2, 2, 2], feat_size=[48, 96, 192, 384])
+    ours = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    ref = {}
+    for line in open(os.path.join(golden_dir, "segmamba_state_dict_keys.txt")):
+        k, shape = line.rstrip("\n").split(" ", 1)
+        ref[k] = eval(shape)
+    assert set(ours) == set(ref), (sorted(set(ref) - set(ours))[:5], sorted(set(ours) - set(ref))[:5])
+    assert all(ours[k] == ref[k] for k in ref)
+    assert len(ours) == 291
+    assert sum(p.numel() for p in m.parameters()) == 67416196
+
+
+def test_mamba_constructor_contract():
+    from mamba_ssm import Mamba
+    with pytest.raises(AssertionError):
+        Mamba(d_model=16)                                 # reference mamba_simple.py:125: only v3 constructs
+    m = Mamba(d_model=48, bimamba_type="v3", nslices=64)
+    assert m.d_inner == 96 and m.dt_rank == 3
+    assert m.A_log._no_weight_decay and m.D._no_weight_decay and m.dt_proj.bias._no_reinit
+    assert torch.allclose(m.A_s_log.exp()[0], torch.arange(1, 17, dtype=torch.float32))
+    sp = torch.nn.functional.softplus(m.dt_proj.bias)
+    assert (sp >= 1e-3 * 0.99).all() and (sp <= 0.1 * 1.01).all()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 100, 48))                        # L % nslices != 0
