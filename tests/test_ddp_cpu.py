@@ -1,0 +1,59 @@
+"""N > 1 path on CPU: two gloo processes run the training-step harness (segmamba_amd/trainer.py) the way bench.py and the
+reference trainer do - DDP wrap (find_unused_parameters=True), gradient all-reduce, clip, SGD step - and must stay in
+lock-step with each other and with a single process seeing the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _tiny_model():
+    torch.manual_seed(0)
+    # stand-in with the same kinds of layers as the conv stem (the HIP kernels cannot run in a CPU process)
+    return nn.Sequential(nn.Conv3d(4, 8, 3, padding=1), nn.InstanceNorm3d(8), nn.LeakyReLU(0.01), nn.Conv3d(8, 4, 1))
+
+
+def _batch(rank):
+    g = torch.Generator().manual_seed(42 + rank)
+    return torch.rand(2, 4, 8, 8, 8, generator=g), torch.randint(0, 4, (2, 8, 8, 8), generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from segmamba_amd.trainer import build_training_state, train_step
+    st = build_training_state(torch.device("cpu"), distributed=True, model=_tiny_model())
+    img, lab = _batch(rank)
+    for _ in range(2):
+        loss = train_step(st, img, lab)
+    # the bench's timing reduction: max over ranks
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out[rank] = (float(loss), [p.detach().clone() for p in st.model.module.parameters()], float(t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_ddp_matches_single_process():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0][2] == out[1][2] == 2.0
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.equal(a, b), "ranks diverged"
+    # single process, both ranks' batches concatenated: DDP averages the per-rank mean losses == mean over the union
+    from segmamba_amd.trainer import build_training_state, train_step
+    st = build_training_state(torch.device("cpu"), distributed=False, model=_tiny_model())
+    img = torch.cat([_batch(0)[0], _batch(1)[0]])
+    lab = torch.cat([_batch(0)[1], _batch(1)[1]])
+    for _ in range(2):
+        train_step(st, img, lab)
+    for a, b in zip(out[0][1], st.model.parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)

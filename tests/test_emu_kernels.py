@@ -1,0 +1,114 @@
+"""CPU checks of the KERNEL SOURCES themselves: segmamba_amd/csrc/*.hip compiled unchanged against the small CPU
+emulation of the HIP runtime in tests/emu (OS threads for HIP threads, barriers for __syncthreads, ...) and driven
+through the same C ABI + host marshalling as the GPU build.  This is test infrastructure (it lets index arithmetic,
+masking, chunk/carry composition and the time-order maps be validated in the GPU-less build container); parity on the
+real device is tests/test_gpu_*.py."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests import emu_util
+from segmamba_amd import lib as L
+from segmamba_amd import ops_raw
+from oracle import ref_ops
+
+pytestmark = pytest.mark.skipif(not emu_util.emu_available(), reason="ROCm host clang not present")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_util.emu_lib()
+
+
+@pytest.mark.parametrize("dim,dstate,seqlen,chunk,channel_last,order,ns,groups", [
+    (4, 8, 100, 32, True, L.TIME_FORWARD, 1, 1),          # reference test dims, ragged tail
+    (96, 16, 80, 32, True, L.TIME_FORWARD, 1, 1),         # SegMamba stage-0 width: 32-channel work items, 2 per wave
+    (40, 16, 70, 64, False, L.TIME_FORWARD, 1, 1),        # channel-first (reference layout), padded d-tile
+    (64, 16, 96, 32, True, L.TIME_REVERSED, 1, 1),
+    (32, 16, 96, 32, True, L.TIME_INTERLEAVED, 8, 1),
+    (8, 8, 64, 32, True, L.TIME_FORWARD, 1, 2),           # grouped B / C
+])
+def test_scan_forward_backward_emulated(emu, dim, dstate, seqlen, chunk, channel_last, order, ns, groups):
+    c = H.scan_case(2 if dim <= 8 else 1, dim, dstate, seqlen, groups=groups, seed=dim + seqlen)
+    ref = H.scan_oracle(c, order, ns)
+    res = H.run_scan(emu, c, "cpu", channel_last, order, ns, chunk=chunk)
+    H.check_scan(res, ref, torch.float32, f"emu D={dim} L={seqlen}")
+
+
+def test_scan_bf16_and_no_gate_emulated(emu):
+    c = H.scan_case(1, 32, 16, 64, dtype=torch.bfloat16)
+    H.check_scan(H.run_scan(emu, c, "cpu", True, chunk=32), H.scan_oracle(c), torch.bfloat16, "emu bf16")
+    c = H.scan_case(1, 16, 16, 40, has_z=False, has_D=False, has_bias=False)
+    H.check_scan(H.run_scan(emu, c, "cpu", True, chunk=32, softplus=False), H.scan_oracle(c, softplus=False),
+                 torch.float32, "emu plain")
+
+
+@pytest.mark.parametrize("width,order,ns,channel_last", [(4, L.TIME_FORWARD, 1, True), (3, L.TIME_FORWARD, 1, False),
+                                                         (2, L.TIME_REVERSED, 1, True), (4, L.TIME_INTERLEAVED, 8, True)])
+def test_conv1d_emulated(emu, width, order, ns, channel_last):
+    torch.manual_seed(width)
+    b, dim, seqlen = 2, 24, 152
+    x, w, bias, g = torch.randn(b, dim, seqlen), torch.randn(dim, width), torch.randn(dim), torch.randn(b, dim, seqlen)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), bias.clone().requires_grad_()
+    ref = H.iperm(ref_ops.causal_conv1d_ref(H.perm(xr, order, ns), wr, br, "silu"), order, ns)
+    ref.backward(g)
+    tr = (lambda t: t.transpose(1, 2).contiguous()) if channel_last else (lambda t: t)
+    out = ops_raw.conv1d_fwd(emu, tr(x), w, bias, True, channel_last=channel_last, time_order=order, nslices=ns)
+    dx, dw, db = ops_raw.conv1d_bwd(emu, tr(x), w, bias, tr(g), True, channel_last=channel_last, time_order=order, nslices=ns)
+    back = (lambda t: t.transpose(1, 2)) if channel_last else (lambda t: t)
+    H.assert_close(back(out), ref, 3e-4, 1e-3, "out")
+    H.assert_close(back(dx), xr.grad, 3e-4, 1e-3, "dx")
+    H.assert_close(dw, wr.grad, 1e-3, 1e-3, "dweight")
+    H.assert_close(db, br.grad, 1e-3, 1e-3, "dbias")
+
+
+def test_conv1d_golden_from_reference_emulated(emu):
+    f = H.load_golden("conv1d_w4.npz")
+    out = ops_raw.conv1d_fwd(emu, f["x"], f["weight"], f["bias"], True)
+    dx, dw, db = ops_raw.conv1d_bwd(emu, f["x"], f["weight"], f["bias"], f["g"], True)
+    H.assert_close(out, f["out"], 3e-4, 1e-3, "out")
+    H.assert_close(dx, f["dx"], 3e-4, 1e-3, "dx")
+    H.assert_close(dw, f["dweight"], 1e-3, 1e-3, "dweight")
+    H.assert_close(db, f["dbias"], 1e-3, 1e-3, "dbias")
+
+
+def test_scan_golden_from_reference_emulated(emu):
+    f = H.load_golden("scan_L64_G2.npz")
+    c = {k: f[k] for k in ("u", "delta", "A", "B", "C", "D", "z", "delta_bias", "g")}
+    ref = {k: f[k] for k in ("out", "last_state", "du", "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias")}
+    H.check_scan(H.run_scan(emu, c, "cpu", False, chunk=32), ref, torch.float32, "golden")
+
+
+def test_host_autograd_and_mamba_v3_on_emulated_kernels(emu, monkeypatch):
+    """The product's host code (autograd Functions, Mamba module) end to end against the reference's Mamba(v3) fixture,
+    with the kernels emulated.  Patching `lib._lib` is something only a test does."""
+    monkeypatch.setattr(L, "_lib", emu)
+    from mamba_ssm import Mamba
+    from tests.golden.make_golden import named_fill
+    f = H.load_golden("mamba_v3.npz")
+    m = Mamba(d_model=16, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=int(f["nslices"]))
+    m.load_state_dict(named_fill(m.state_dict()))
+    x = f["x"].clone().requires_grad_()
+    y = m(x)
+    y.backward(f["g"])
+    H.assert_close(y, f["y"], 1e-4, 1e-5, "y")
+    H.assert_close(x.grad, f["dx"], 1e-4, 1e-5, "dx")
+    for k, p in m.named_parameters():
+        r = f["grad__" + k]
+        H.assert_close(p.grad, r, 1e-3, 1e-3 * max(1e-3, float(r.abs().max())), "grad " + k)
+
+
+def test_reference_layout_inner_fn_on_emulated_kernels(emu, monkeypatch):
+    monkeypatch.setattr(L, "_lib", emu)
+    from mamba_ssm.ops.selective_scan_interface import mamba_inner_fn_no_out_proj
+    f = H.load_golden("inner_no_out_proj.npz")
+    names = ("xz", "conv_w", "conv_b", "x_proj_w", "dt_proj_w", "A", "D", "delta_bias")
+    t = {k: f[k].clone().requires_grad_() for k in names}
+    out = mamba_inner_fn_no_out_proj(t["xz"], t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"], t["A"], None, None,
+                                     t["D"], delta_bias=t["delta_bias"], delta_softplus=True)
+    out.backward(f["g"])
+    H.assert_close(out, f["out"], 1e-3, 1e-4, "out")
+    for k, gk in (("xz", "dxz"), ("conv_w", "dconv_w"), ("conv_b", "dconv_b"), ("x_proj_w", "dx_proj_w"),
+                  ("dt_proj_w", "ddt_proj_w"), ("A", "dA"), ("D", "dD"), ("delta_bias", "ddelta_bias")):
+        H.assert_close(t[k].grad, f[gk], 1e-3, 1e-3 * max(1.0, float(f[gk].abs().max())), gk)
