@@ -21,7 +21,12 @@ OBJ_DIR = os.path.join(ROOT, "build", "obj")
 LIB_PATH = os.path.join(HERE, "libsegmamba_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
+EXTRA = os.environ.get("SEGM_EXTRA_HIPCC_FLAGS", "").split()      # experiments only (e.g. -DSEGM_BWD_MIN_WAVES=2)
+if os.environ.get("SEGM_LIB_OUT"):
+    LIB_PATH = os.environ["SEGM_LIB_OUT"]
+    OBJ_DIR = OBJ_DIR + "_" + os.path.basename(LIB_PATH)
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics", "-Wall",
+         "-Wno-unused-function"]
 
 
 def _sources():
@@ -44,7 +49,7 @@ def _compile(src: str) -> str:
     hdr_t = max(os.path.getmtime(p) for p in _deps() if not p.endswith(".hip"))
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
         return obj
-    cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *EXTRA, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

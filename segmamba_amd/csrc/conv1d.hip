@@ -33,14 +33,15 @@ __global__ void __launch_bounds__(kBlock) conv1d_fwd_kernel(ConvDev P) {
     const Geom& gm = P.gm;
     const TimeMap tm = P.tm;
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const int ub = uniform_batch(it);
     const bool item_ok = it.wave_valid && it.chunk < gm.nchunks;
 
     float wt[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) wt[w] = it.valid ? P.weight[(int64_t)it.d * W + w] : 0.f;
     const float bias = (it.valid && P.bias) ? P.bias[it.d] : 0.f;
-    const T* xp = lane_ptr<T>(P.x, it.b, it.d, it.valid);
-    T* op = lane_ptr<T>(P.out, it.b, it.d, it.valid);
+    const RowPtr xp = make_rowptr<T>(P.x, ub, it.d, it.valid);
+    const RowPtr op = make_rowptr<T>(P.out, ub, it.d, it.valid);
 
     const int32_t tau_begin = item_ok ? it.chunk * gm.chunk : 0;
     TimeIter ti;
@@ -54,14 +55,14 @@ __global__ void __launch_bounds__(kBlock) conv1d_fwd_kernel(ConvDev P) {
         TimeIter tb = ti;
         tb.jump(tm, -back);
         const bool ok = it.valid && tau_begin - back >= 0;
-        const float v = to_f32(xp[row_off(ok ? tb.t : 0, P.x.st)]);
+        const float v = ld_row<T>(xp, ok ? tb.t : 0);
         xh[k] = ok ? v : 0.f;
     }
 
     float nx[TS];
     int32_t ntt[TS];
     uint32_t nok = row_indices<TS>(ntt, tm, ti, it.valid);
-    fetch_rows<T, TS>(nx, P.x, xp, ntt, nok);
+    fetch_rows<T, TS>(nx, xp, ntt, nok);
     for (int s0 = 0; s0 < gm.chunk; s0 += TS) {
         float cx[TS];
         int32_t ctt[TS];
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(kBlock) conv1d_fwd_kernel(ConvDev P) {
         const uint32_t cok = nok;
         ti.jump(tm, TS);
         nok = row_indices<TS>(ntt, tm, ti, it.valid);
-        fetch_rows<T, TS>(nx, P.x, xp, ntt, nok);
+        fetch_rows<T, TS>(nx, xp, ntt, nok);
 #pragma unroll
         for (int j = 0; j < TS; ++j) {
             float o = fmaf(wt[W - 1], cx[j], bias);
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(kBlock) conv1d_fwd_kernel(ConvDev P) {
             for (int k = 0; k + 1 < W - 1; ++k) xh[k] = xh[k + 1];
             xh[W - 2] = cx[j];
             if (P.silu) o = o * sigmoidf(o);
-            if ((cok >> j) & 1u) op[row_off(ctt[j], P.out.st)] = from_f32<T>(o);
+            if ((cok >> j) & 1u) st_row<T>(op, ctt[j], o);
         }
     }
 }
@@ -96,15 +97,16 @@ __global__ void __launch_bounds__(kBlock) conv1d_bwd_kernel(ConvDev P) {
     const Geom& gm = P.gm;
     const TimeMap tm = P.tm;
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const int ub = uniform_batch(it);
     const bool item_ok = it.wave_valid && it.chunk < gm.nchunks;
 
     float wt[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) wt[w] = it.valid ? P.weight[(int64_t)it.d * W + w] : 0.f;
     const float bias = (it.valid && P.bias) ? P.bias[it.d] : 0.f;
-    const T* xp = lane_ptr<T>(P.x, it.b, it.d, it.valid);
-    const T* gp = lane_ptr<T>(P.dout, it.b, it.d, it.valid);
-    T* dxp = lane_ptr<T>(P.dx, it.b, it.d, it.valid);
+    const RowPtr xp = make_rowptr<T>(P.x, ub, it.d, it.valid);
+    const RowPtr gp = make_rowptr<T>(P.dout, ub, it.d, it.valid);
+    const RowPtr dxp = make_rowptr<T>(P.dx, ub, it.d, it.valid);
 
     const int32_t tau_begin = item_ok ? it.chunk * gm.chunk : 0;
     const int32_t tau_end = tau_begin + gm.chunk;          // exclusive; may exceed L
@@ -118,7 +120,7 @@ __global__ void __launch_bounds__(kBlock) conv1d_bwd_kernel(ConvDev P) {
         TimeIter tb = ti;
         tb.jump(tm, -back);
         const bool ok = it.valid && tau_begin - back >= 0;
-        const float v = to_f32(xp[row_off(ok ? tb.t : 0, P.x.st)]);
+        const float v = ld_row<T>(xp, ok ? tb.t : 0);
         xh[k] = ok ? v : 0.f;
     }
     float gh[W - 1];                                        // gh[k] = g[i - (W-1) + k]
@@ -132,8 +134,8 @@ __global__ void __launch_bounds__(kBlock) conv1d_bwd_kernel(ConvDev P) {
     float nx[TS], ng[TS];
     int32_t ntt[TS];
     uint32_t nok = row_indices<TS>(ntt, tm, ti, it.valid);
-    fetch_rows<T, TS>(nx, P.x, xp, ntt, nok);
-    fetch_rows<T, TS>(ng, P.dout, gp, ntt, nok);
+    fetch_rows<T, TS>(nx, xp, ntt, nok);
+    fetch_rows<T, TS>(ng, gp, ntt, nok);
     // one extra sub-tile covers the W-1 indices past the chunk whose dy' the last dx of the chunk need
     for (int s0 = 0; s0 < gm.chunk + TS; s0 += TS) {
         float cx[TS], cg[TS];
@@ -144,8 +146,8 @@ __global__ void __launch_bounds__(kBlock) conv1d_bwd_kernel(ConvDev P) {
         const int32_t i0 = ti.tau;
         ti.jump(tm, TS);
         nok = row_indices<TS>(ntt, tm, ti, it.valid);
-        fetch_rows<T, TS>(nx, P.x, xp, ntt, nok);
-        fetch_rows<T, TS>(ng, P.dout, gp, ntt, nok);
+        fetch_rows<T, TS>(nx, xp, ntt, nok);
+        fetch_rows<T, TS>(ng, gp, ntt, nok);
 #pragma unroll
         for (int j = 0; j < TS; ++j) {
             const int32_t i = i0 + j;
@@ -168,7 +170,7 @@ __global__ void __launch_bounds__(kBlock) conv1d_bwd_kernel(ConvDev P) {
 #pragma unroll
             for (int k = 1; k < W; ++k) dxv = fmaf(wt[k], gh[(W - 1) - k], dxv);
             const int32_t tau = i - (W - 1);
-            if (it.valid && tau >= tau_begin && tau < tau_end && tau < tm.L) dxp[row_off(th[0], P.dx.st)] = from_f32<T>(dxv);
+            if (it.valid && tau >= tau_begin && tau < tau_end && tau < tm.L) st_row<T>(dxp, th[0], dxv);
 #pragma unroll
             for (int k = 0; k + 1 < W - 1; ++k) { xh[k] = xh[k + 1]; gh[k] = gh[k + 1]; th[k] = th[k + 1]; }
             xh[W - 2] = cx[j];

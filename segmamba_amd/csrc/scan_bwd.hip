@@ -6,9 +6,9 @@
 //   K1  scan_bwd_agg_kernel   per (batch, chunk, channel): walk the chunk right-to-left with a zero adjoint
 //                             entering from the right; emits E = adjoint leaving on the left, and sum(delta)
 //   K2  scan_carry_kernel<1>  compose E over chunks right-to-left -> adjoint entering every chunk
-//   K3  scan_bwd_main_kernel  per (batch, chunk, channel): 32-step sub-chunks right-to-left; each is re-run
-//                             forward from the forward pass' checkpoint (state entering step 32k) in two
-//                             16-step windows, state by state, keeping a_t, h_t of ONE state in registers
+//   K3  scan_bwd_main_kernel  per (batch, chunk, channel): 16-step windows right-to-left; each is re-run forward
+//                             from the forward pass' checkpoint (state entering step 16k), state by state,
+//                             keeping a_t, h_t of ONE state in registers
 //                             (the reference keeps them for one state per thread tile too, :235-273), then
 //                             walked backwards:
 //        dh_t  = g_t C_t + e_{t+1}            e_t = a_t dh_t           g = dout * silu(z)
@@ -28,7 +28,7 @@ namespace segm {
 void launch_reduce_partials(const float* part, int64_t nrows, int K, int dim, float* out0, int K0, float* out1,
                             float* out2, hipStream_t stream);
 
-constexpr int kWin = 16;   // window length of the backward main kernel (kCkpt = 2 windows)
+constexpr int kWin = 16;   // window length of the backward main kernel = spacing of the forward checkpoints
 
 // ------------------------------------------------------------------------------------------------------
 // K1: reverse chunk aggregates
@@ -41,8 +41,10 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
     const Geom& gm = P.gm;
     const TimeMap tm = P.tm;
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const int ub = uniform_batch(it);
     const bool item_ok = it.wave_valid && it.chunk < gm.nchunks;
     const int nstate = gm.nstate;
+    const bool softplus_on = P.delta_softplus != 0;
     const bool has_z = P.z.p != nullptr;
 
     float A2[NS], e[NS];
@@ -52,10 +54,10 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
         e[n] = 0.f;
     }
     const float bias = (it.valid && P.delta_bias) ? P.delta_bias[it.d] : 0.f;
-    const T* dp = lane_ptr<T>(P.delta, it.b, it.d, it.valid);
-    const T* gp = lane_ptr<T>(P.dout, it.b, it.d, it.valid);
+    const RowPtr dp = make_rowptr<T>(P.delta, ub, it.d, it.valid);
+    const RowPtr gp = make_rowptr<T>(P.dout, ub, it.d, it.valid);
     const Seq& zs = has_z ? P.z : P.dout;
-    const T* zp = lane_ptr<T>(zs, it.b, it.d, it.valid);
+    const RowPtr zp = make_rowptr<T>(zs, ub, it.d, it.valid);
     const bool t_fastest = P.Cm.st <= P.Cm.sn;
 
     TimeIter ti;
@@ -68,10 +70,10 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
     int32_t ntt[TS];
     StageRegs<TS, NS, RW> sc;
     uint32_t nok = row_indices<TS>(ntt, tm, ti, it.valid);
-    fetch_rows<T, TS>(nd, P.delta, dp, ntt, nok);
-    fetch_rows<T, TS>(ng, P.dout, gp, ntt, nok);
-    fetch_rows<T, TS>(nz, zs, zp, ntt, nok);
-    stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, it.b, nstate, it.r, item_ok);
+    fetch_rows<T, TS>(nd, dp, ntt, nok);
+    fetch_rows<T, TS>(ng, gp, ntt, nok);
+    fetch_rows<T, TS>(nz, zp, ntt, nok);
+    stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, ub, nstate, it.r, item_ok);
 
     float sumd = 0.f;
     int buf = 0;
@@ -85,16 +87,16 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
         const uint32_t cok = nok;
         ti.jump(tm, -TS);                                  // next (lower) sub-tile; below the chunk start rows are
         nok = row_indices<TS>(ntt, tm, ti, it.valid);      // the neighbour's or masked (tau < 0): prefetch only
-        fetch_rows<T, TS>(nd, P.delta, dp, ntt, nok);
-        fetch_rows<T, TS>(ng, P.dout, gp, ntt, nok);
-        fetch_rows<T, TS>(nz, zs, zp, ntt, nok);
-        stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, it.b, nstate, it.r, item_ok);
+        fetch_rows<T, TS>(nd, dp, ntt, nok);
+        fetch_rows<T, TS>(ng, gp, ntt, nok);
+        fetch_rows<T, TS>(nz, zp, ntt, nok);
+        stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, ub, nstate, it.r, item_ok);
 #pragma unroll
         for (int jj = 0; jj < TS; ++jj) {
             const int j = TS - 1 - jj;
             const bool ok = (cok >> j) & 1u;
             float dl = cd[j] + bias;
-            if (P.delta_softplus) dl = softplus20(dl);
+            dl = softplus_on ? softplus20(dl) : dl;       // select, not a branch: keeps each step one basic block
             dl = ok ? dl : 0.f;
             sumd += dl;
             float g = cg[j];
@@ -111,6 +113,8 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
                     e[n] = a * fmaf(g, cc[i], e[n]);
                 }
             }
+#pragma unroll
+            for (int n = 0; n < NS; ++n) SEGM_PIN_F32(e[n]);     // finish this step before the next one's LDS reads
         }
         buf ^= 1;
     }
@@ -131,11 +135,14 @@ template <int RW, int V>
 __device__ __forceinline__ void reduce_scatter(float (&v)[V], int r) {
 #pragma unroll
     for (int m = V / 2; m >= 1; m >>= 1) {
-        const bool upper = (r & m) != 0;
+        // bit-select instead of `upper ? v[m+i] : v[i]`: the compiler turns a select between two elements of a
+        // register array into a dynamically indexed array (16-way compare/select chains, array pinned in VGPRs)
+        const uint32_t mask = (r & m) ? 0xffffffffu : 0u;
 #pragma unroll
         for (int i = 0; i < m; ++i) {
-            const float keep = upper ? v[m + i] : v[i];
-            const float send = upper ? v[i] : v[m + i];
+            const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[m + i]);
+            const float keep = __uint_as_float((hi & mask) | (lo & ~mask));
+            const float send = __uint_as_float((lo & mask) | (hi & ~mask));
             v[i] = keep + __shfl_xor(send, m);
         }
     }
@@ -145,8 +152,12 @@ __device__ __forceinline__ void reduce_scatter(float (&v)[V], int r) {
 // ------------------------------------------------------------------------------------------------------
 // K3: main backward kernel
 // ------------------------------------------------------------------------------------------------------
+#ifndef SEGM_BWD_MIN_WAVES
+#define SEGM_BWD_MIN_WAVES 1          // waves per SIMD the register allocator must leave room for
+#endif
 template <typename T, int NS, int RW>
-__global__ void __launch_bounds__(kBlock) scan_bwd_main_kernel(ScanDev P) {
+__global__ void __launch_bounds__(kBlock, SEGM_BWD_MIN_WAVES) scan_bwd_main_kernel(ScanDev P) {
+    static_assert(kWin == kCkpt, "one window per forward checkpoint");
     constexpr int G = 64 / RW;
     constexpr int V = RW < 32 ? RW : 32;
     __shared__ __attribute__((aligned(16))) float s_bc[kWavesPerBlock][G][2][NS * kWin];    // [n][s]: B then C
@@ -156,33 +167,40 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_main_kernel(ScanDev P) {
     const Geom& gm = P.gm;
     const TimeMap tm = P.tm;
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const int ub = uniform_batch(it);
     const bool item_ok = it.wave_valid && it.chunk < gm.nchunks;
     const int nstate = gm.nstate;
+    const bool softplus_on = P.delta_softplus != 0;
     const bool has_z = P.z.p != nullptr;
+    const int dsafe = it.valid ? it.d : 0;
 
-    float A2[NS], e[NS], dA[NS];
+    // per-state values that live across windows - the adjoint e and the dA accumulator - sit in LDS, one private
+    // slot per thread and state ([n][thread]: conflict-free), because the loop over states is a runtime loop
+    // (unrolling it 16x would not fit the instruction cache, indexing a register array by n would spill)
+    __shared__ float s_e[NS][kBlock];
+    __shared__ float s_dA[NS][kBlock];
     const int64_t crow = (int64_t)it.b * gm.nchunks + it.chunk;
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
         const bool on = it.valid && n < nstate;
-        A2[n] = on ? P.A[(int64_t)it.d * nstate + n] * kLog2e : 0.f;
-        e[n] = on ? P.carry[(crow * nstate + n) * gm.dim + it.d] : 0.f;
-        dA[n] = 0.f;
+        s_e[n][threadIdx.x] = on ? P.carry[(crow * nstate + n) * gm.dim + it.d] : 0.f;
+        s_dA[n][threadIdx.x] = 0.f;
     }
+    const float* Arow = P.A + (int64_t)dsafe * nstate;       // A[d][.]: re-read per state (L1-resident)
     const float bias = (it.valid && P.delta_bias) ? P.delta_bias[it.d] : 0.f;
     const float Dv = (it.valid && P.D) ? P.D[it.d] : 0.f;
     float dD_acc = 0.f, dbias_acc = 0.f;
 
-    const T* up = lane_ptr<T>(P.u, it.b, it.d, it.valid);
-    const T* dp = lane_ptr<T>(P.delta, it.b, it.d, it.valid);
-    const T* gp = lane_ptr<T>(P.dout, it.b, it.d, it.valid);
+    const RowPtr up = make_rowptr<T>(P.u, ub, it.d, it.valid);
+    const RowPtr dp = make_rowptr<T>(P.delta, ub, it.d, it.valid);
+    const RowPtr gp = make_rowptr<T>(P.dout, ub, it.d, it.valid);
     const Seq& zs = has_z ? P.z : P.dout;
     const Seq& ys = has_z ? P.out : P.dout;
-    const T* zp = lane_ptr<T>(zs, it.b, it.d, it.valid);
-    const T* yp = lane_ptr<T>(ys, it.b, it.d, it.valid);
-    T* dup = lane_ptr<T>(P.du, it.b, it.d, it.valid);
-    T* ddp = lane_ptr<T>(P.ddelta, it.b, it.d, it.valid);
-    T* dzp = has_z ? lane_ptr<T>(P.dz, it.b, it.d, it.valid) : nullptr;
+    const RowPtr zp = make_rowptr<T>(zs, ub, it.d, it.valid);
+    const RowPtr yp = make_rowptr<T>(ys, ub, it.d, it.valid);
+    const RowPtr dup = make_rowptr<T>(P.du, ub, it.d, it.valid);
+    const RowPtr ddp = make_rowptr<T>(P.ddelta, ub, it.d, it.valid);
+    const RowPtr dzp = make_rowptr<T>(P.dz, ub, it.d, it.valid && has_z);
     const bool bt_fastest = P.Bm.st <= P.Bm.sn, ct_fastest = P.Cm.st <= P.Cm.sn;
     float* lb = &s_bc[wave][it.gi][0][0];
     float* lc = &s_bc[wave][it.gi][1][0];
@@ -191,205 +209,162 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_main_kernel(ScanDev P) {
     int32_t* lrows = &s_rows[wave][it.gi][0];
 
     const int32_t tau_begin = item_ok ? it.chunk * gm.chunk : 0;
-    const int nsub = gm.chunk / kCkpt;
+    const int nwin = gm.chunk / kWin;
+    TimeIter tw;
+    tw.seek(tm, tau_begin);
+    for (int done = 0; done < gm.chunk - kWin; done += kWin) tw.jump(tm, kWin);     // -> the chunk's last window
 
-    for (int sc = nsub - 1; sc >= 0; --sc) {
-        const int32_t tau_s = tau_begin + sc * kCkpt;
-        TimeIter t0;
-        t0.seek(tm, tau_s);
-        // state entering the sub-chunk (forward checkpoint); zero past the end of the sequence
-        float h0[NS], hmid[NS];
+    for (int w = nwin - 1; w >= 0; --w) {
+        // ---- window data -------------------------------------------------------------------------------------
+        StageRegs<kWin, NS, RW> sb, scc;
+        stage_fetch<T, kWin, NS, RW>(sb, P.Bm, tm, tw, ub, nstate, it.r, item_ok);
+        stage_fetch<T, kWin, NS, RW>(scc, P.Cm, tm, tw, ub, nstate, it.r, item_ok);
+        float wu[kWin], wd[kWin], wg[kWin], du[kWin], dd[kWin];
+        uint32_t okm;
         {
-            const bool ck_ok = it.valid && tau_s < tm.L;
-            const int64_t krow = (int64_t)it.b * P.nck + (ck_ok ? tau_s / kCkpt : 0);
-#pragma unroll
-            for (int n = 0; n < NS; ++n) {
-                const float v = P.ckpt[(krow * nstate + (n < nstate ? n : 0)) * gm.dim + (it.valid ? it.d : 0)];
-                h0[n] = (ck_ok && n < nstate) ? v : 0.f;
-            }
-        }
-        // ---- (1) forward sweep over window 0 to get the state entering window 1 -------------------------
-        {
-            StageRegs<kWin, NS, RW> sb;
-            stage_fetch<T, kWin, NS, RW>(sb, P.Bm, tm, t0, it.b, nstate, it.r, item_ok);
             int32_t tt[kWin];
-            float wu[kWin], wd[kWin];
-            const uint32_t okm = row_indices<kWin>(tt, tm, t0, it.valid);
-            fetch_rows<T, kWin>(wu, P.u, up, tt, okm);
-            fetch_rows<T, kWin>(wd, P.delta, dp, tt, okm);
-            __syncthreads();                                // previous users of s_bc are done
-            stage_park<kWin, NS, RW, false>(sb, lb, bt_fastest, it.r);
-            __syncthreads();
+            okm = row_indices<kWin>(tt, tm, tw, it.valid);
+            fetch_rows<T, kWin>(wu, up, tt, okm);
+            fetch_rows<T, kWin>(wd, dp, tt, okm);
+            fetch_rows<T, kWin>(wg, gp, tt, okm);
+            float wz[kWin], wy[kWin];
+            fetch_rows<T, kWin>(wz, zp, tt, okm);
+            fetch_rows<T, kWin>(wy, yp, tt, okm);
 #pragma unroll
             for (int j = 0; j < kWin; ++j) {
+                const bool ok = (okm >> j) & 1u;
                 float dl = wd[j] + bias;
-                if (P.delta_softplus) dl = softplus20(dl);
-                wd[j] = ((okm >> j) & 1u) ? dl : 0.f;
-                wu[j] *= wd[j];                             // delta * u
-            }
-#pragma unroll 1
-            for (int n = 0; n < NS; ++n) {                  // runtime loop, registers rotated (see below)
-                float h = h0[0];
-                const float A2n = A2[0];
-                const float4* B4 = reinterpret_cast<const float4*>(lb + n * kWin);
-#pragma unroll
-                for (int q = 0; q < kWin / 4; ++q) {
-                    const float4 bv = B4[q];
-                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int j = q * 4 + i;
-                        h = fmaf(fast_exp2(wd[j] * A2n), h, wu[j] * bb[i]);
-                    }
+                dl = softplus_on ? softplus20(dl) : dl;       // select, not a branch: keeps each step one basic block
+                wd[j] = ok ? dl : 0.f;
+                if (has_z) {
+                    const float zz = wz[j], sg = sigmoidf(zz);
+                    const float dzv = wg[j] * wy[j] * sg * fmaf(zz, 1.f - sg, 1.f);
+                    if (ok) st_row<T>(dzp, tt[j], dzv);
+                    wg[j] *= zz * sg;
                 }
-                // rotate so that the next state sits at index 0; after NS turns every array is back in place
-                const float h0n = h0[0];
-#pragma unroll
-                for (int i = 0; i + 1 < NS; ++i) { h0[i] = h0[i + 1]; A2[i] = A2[i + 1]; hmid[i] = hmid[i + 1]; }
-                h0[NS - 1] = h0n; A2[NS - 1] = A2n; hmid[NS - 1] = h;
+                du[j] = Dv * wg[j];
+                dd[j] = 0.f;
+                dD_acc = fmaf(wg[j], wu[j], dD_acc);
             }
         }
-        // ---- (2), (3): the two windows, right one first -----------------------------------------------------
-        for (int w = 1; w >= 0; --w) {
-            TimeIter tw = t0;
-            if (w) tw.jump(tm, kWin);
-            StageRegs<kWin, NS, RW> sb, scc;
-            stage_fetch<T, kWin, NS, RW>(sb, P.Bm, tm, tw, it.b, nstate, it.r, item_ok);
-            stage_fetch<T, kWin, NS, RW>(scc, P.Cm, tm, tw, it.b, nstate, it.r, item_ok);
-            int32_t tt[kWin];
-            const uint32_t okm = row_indices<kWin>(tt, tm, tw, it.valid);
-            float wu[kWin], wd[kWin], wg[kWin], du[kWin], dd[kWin];
-            fetch_rows<T, kWin>(wu, P.u, up, tt, okm);
-            fetch_rows<T, kWin>(wd, P.delta, dp, tt, okm);
-            fetch_rows<T, kWin>(wg, P.dout, gp, tt, okm);
-            {
-                float wz[kWin], wy[kWin];
-                fetch_rows<T, kWin>(wz, zs, zp, tt, okm);
-                fetch_rows<T, kWin>(wy, ys, yp, tt, okm);
-#pragma unroll
-                for (int j = 0; j < kWin; ++j) {
-                    const bool ok = (okm >> j) & 1u;
-                    float dl = wd[j] + bias;
-                    if (P.delta_softplus) dl = softplus20(dl);
-                    wd[j] = ok ? dl : 0.f;
-                    if (has_z) {
-                        const float zz = wz[j], sg = sigmoidf(zz);
-                        const float dzv = wg[j] * wy[j] * sg * fmaf(zz, 1.f - sg, 1.f);
-                        if (ok) dzp[row_off(tt[j], P.dz.st)] = from_f32<T>(dzv);
-                        wg[j] *= zz * sg;
-                    }
-                    du[j] = Dv * wg[j];
-                    dd[j] = 0.f;
-                    dD_acc = fmaf(wg[j], wu[j], dD_acc);
-                }
-            }
-            __syncthreads();                                // s_bc / s_dbc / s_rows free again
-            stage_park<kWin, NS, RW, false>(sb, lb, bt_fastest, it.r);
-            stage_park<kWin, NS, RW, false>(scc, lc, ct_fastest, it.r);
-            if (it.r < kWin) {
-                const int32_t tau = tw.tau + it.r;
-                lrows[it.r] = (item_ok && tau < tm.L) ? tw.ahead(tm, it.r) : -1;
-            }
-            __syncthreads();
+        __syncthreads();                                    // the previous window is done with s_bc / s_dbc / s_rows
+        stage_park<kWin, NS, RW, false>(sb, lb, bt_fastest, it.r);
+        stage_park<kWin, NS, RW, false>(scc, lc, ct_fastest, it.r);
+        if (it.r < kWin) lrows[it.r] = (item_ok && tw.tau + it.r < tm.L) ? tw.ahead(tm, it.r) : -1;
+        __syncthreads();
 
+        // state entering the window = forward checkpoint (zero past the end of the sequence)
+        const bool ck_ok = it.valid && tw.tau < tm.L;
+        const float* ck = P.ckpt + (((int64_t)it.b * P.nck + (ck_ok ? tw.tau / kCkpt : 0)) * nstate) * gm.dim + dsafe;
+        float A2n_next = Arow[0] * kLog2e;
+        float hp_next = ck[0];
 #pragma unroll 1
-            for (int n = 0; n < NS; ++n) {                  // runtime loop over states, registers rotated
-                const float A2n = A2[0];
-                const float An = A2n * 0.6931471805599453f;
-                const float hp = w ? hmid[0] : h0[0];
-                float en = e[0];
-                float dAn = dA[0];
-                float a[kWin], h[kWin], bn[kWin], cn[kWin];
-                {
-                    const float4* B4 = reinterpret_cast<const float4*>(lb + n * kWin);
-                    const float4* C4 = reinterpret_cast<const float4*>(lc + n * kWin);
+        for (int n = 0; n < NS; ++n) {                      // runtime loop over states
+            const bool on = it.valid && n < nstate;
+            const float A2n = on ? A2n_next : 0.f;
+            const float hp = (on && ck_ok) ? hp_next : 0.f;
+            {
+                const int nn = (n + 1 < nstate) ? n + 1 : nstate - 1;          // prefetch the next state's scalars
+                A2n_next = Arow[nn] * kLog2e;
+                hp_next = ck[(int64_t)nn * gm.dim];
+            }
+            const float An = A2n * 0.6931471805599453f;
+            float en = s_e[n][threadIdx.x];
+            float dAn = s_dA[n][threadIdx.x];
+            float a[kWin], h[kWin];
+            const float4* B4 = reinterpret_cast<const float4*>(lb + n * kWin);
+            const float4* C4 = reinterpret_cast<const float4*>(lc + n * kWin);
 #pragma unroll
-                    for (int q = 0; q < kWin / 4; ++q) {
-                        const float4 bv = B4[q], cv = C4[q];
-                        bn[q * 4 + 0] = bv.x; bn[q * 4 + 1] = bv.y; bn[q * 4 + 2] = bv.z; bn[q * 4 + 3] = bv.w;
-                        cn[q * 4 + 0] = cv.x; cn[q * 4 + 1] = cv.y; cn[q * 4 + 2] = cv.z; cn[q * 4 + 3] = cv.w;
-                    }
-                }
+            for (int q = 0; q < kWin / 4; ++q) {
+                const float4 bv = B4[q];
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-                for (int j = 0; j < kWin; ++j) {
+                for (int i = 0; i < 4; ++i) {
+                    const int j = q * 4 + i;
                     a[j] = fast_exp2(wd[j] * A2n);
-                    h[j] = fmaf(a[j], j ? h[j - 1] : hp, wd[j] * wu[j] * bn[j]);
+                    h[j] = fmaf(a[j], j ? h[j - 1] : hp, wd[j] * wu[j] * bb[i]);
                 }
-                float v[2 * kWin];                          // [0,16): dB_j ; [16,32): dC_j   (this state)
+            }
+            float v[2 * kWin];                              // [0,16): dB_j ; [16,32): dC_j   (this state)
 #pragma unroll
-                for (int jj = 0; jj < kWin; ++jj) {
-                    const int j = kWin - 1 - jj;
-                    const float dh = fmaf(wg[j], cn[j], en);
+            for (int qq = 0; qq < kWin / 4; ++qq) {
+                const int q = kWin / 4 - 1 - qq;
+                const float4 bv = B4[q], cv = C4[q];
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = 3 - ii, j = q * 4 + i;
+                    const float dh = fmaf(wg[j], cc[i], en);
                     const float t2 = dh * (j ? h[j - 1] : hp) * a[j];
                     dAn = fmaf(t2, wd[j], dAn);
-                    const float qv = dh * bn[j];
+                    const float qv = dh * bb[i];
                     dd[j] = fmaf(t2, An, fmaf(qv, wu[j], dd[j]));
                     du[j] = fmaf(qv, wd[j], du[j]);
                     v[j] = dh * wd[j] * wu[j];
                     v[kWin + j] = wg[j] * h[j];
                     en = a[j] * dh;
                 }
-                // sum dB / dC contributions over the channels (lanes) of the work item
-                if constexpr (RW >= 32) {
-                    reduce_scatter<RW, V>(v, it.r);
-                    if (it.r < 32) {
-                        const int idx = it.r;               // 0..15 -> dB_j, 16..31 -> dC_j
-                        const int j = idx & (kWin - 1);
-                        (idx < kWin ? ldb : ldc)[j * NS + n] = v[0];
-                    }
-                } else {
-                    float vb[kWin], vc[kWin];
-#pragma unroll
-                    for (int j = 0; j < kWin; ++j) { vb[j] = v[j]; vc[j] = v[kWin + j]; }
-                    reduce_scatter<RW, kWin>(vb, it.r);
-                    reduce_scatter<RW, kWin>(vc, it.r);
-                    ldb[it.r * NS + n] = vb[0];
-                    ldc[it.r * NS + n] = vc[0];
-                }
-                // rotate the per-state registers
-                const float hm0 = hmid[0], h00 = h0[0];
-#pragma unroll
-                for (int i = 0; i + 1 < NS; ++i) {
-                    A2[i] = A2[i + 1]; e[i] = e[i + 1]; dA[i] = dA[i + 1]; hmid[i] = hmid[i + 1]; h0[i] = h0[i + 1];
-                }
-                A2[NS - 1] = A2n; e[NS - 1] = en; dA[NS - 1] = dAn; hmid[NS - 1] = hm0; h0[NS - 1] = h00;
             }
-            __syncthreads();                                // the dB / dC tile of every item is complete
-            // flush the window's dB / dC tile: rows contiguous in whichever of (t, n) has the smaller stride
-            {
-                const bool n_fast = P.dB_sn <= P.dB_st;
+            // sum the dB / dC contributions over the channels (lanes) of the work item
+            if constexpr (RW >= 32) {
+                reduce_scatter<RW, V>(v, it.r);
+                if (it.r < 32) {
+                    const int j = it.r & (kWin - 1);        // lanes 0..15 -> dB_j, 16..31 -> dC_j
+                    (it.r < kWin ? ldb : ldc)[j * NS + n] = v[0];
+                }
+            } else {
+                float vb[kWin], vc[kWin];
 #pragma unroll
-                for (int i = 0; i < kWin * NS / RW; ++i) {
-                    const int el = it.r + i * RW;
-                    int j, n;
-                    if (n_fast) { j = el / NS; n = el - j * NS; } else { n = el / kWin; j = el - n * kWin; }
-                    const int32_t row = lrows[j];
-                    if (row >= 0 && n < nstate) {
-                        const int64_t ob = (int64_t)it.b * P.dB_sb + row_off(row, P.dB_st) + (int64_t)n * P.dB_sn;
-                        const int64_t oc = (int64_t)it.b * P.dC_sb + row_off(row, P.dC_st) + (int64_t)n * P.dC_sn;
-                        const float xb = ldb[j * NS + n], xc = ldc[j * NS + n];
-                        if (P.atomic_bc) { atomicAdd(P.dB + ob, xb); atomicAdd(P.dC + oc, xc); }
-                        else { P.dB[ob] = xb; P.dC[oc] = xc; }
-                    }
+                for (int j = 0; j < kWin; ++j) { vb[j] = v[j]; vc[j] = v[kWin + j]; }
+                reduce_scatter<RW, kWin>(vb, it.r);
+                reduce_scatter<RW, kWin>(vc, it.r);
+                ldb[it.r * NS + n] = vb[0];
+                ldc[it.r * NS + n] = vc[0];
+            }
+            s_e[n][threadIdx.x] = en;
+            s_dA[n][threadIdx.x] = dAn;
+        }
+        __syncthreads();                                    // the dB / dC tile of every item is complete
+        // flush the window's dB / dC tile: contiguous in whichever of (t, n) has the smaller stride
+        {
+            const bool n_fast = P.dB_sn <= P.dB_st;
+#pragma unroll
+            for (int i = 0; i < kWin * NS / RW; ++i) {
+                const int el = it.r + i * RW;
+                int j, n;
+                if (n_fast) { j = el / NS; n = el - j * NS; } else { n = el / kWin; j = el - n * kWin; }
+                const int32_t row = lrows[j];
+                if (row >= 0 && n < nstate) {
+                    const int64_t ob = (int64_t)it.b * P.dB_sb + row_off(row, P.dB_st) + (int64_t)n * P.dB_sn;
+                    const int64_t oc = (int64_t)it.b * P.dC_sb + row_off(row, P.dC_st) + (int64_t)n * P.dC_sn;
+                    const float xb = ldb[j * NS + n], xc = ldc[j * NS + n];
+                    if (P.atomic_bc) { atomicAdd(P.dB + ob, xb); atomicAdd(P.dC + oc, xc); }
+                    else { P.dB[ob] = xb; P.dC[oc] = xc; }
                 }
             }
+        }
+        {
+            TimeIter ts = tw;
 #pragma unroll
             for (int j = 0; j < kWin; ++j) {
                 if ((okm >> j) & 1u) {
                     float ddv = dd[j];
-                    if (P.delta_softplus) ddv *= 1.f - fast_exp(-wd[j]);      // sigmoid(raw) = 1 - exp(-softplus(raw))
+                    ddv *= softplus_on ? 1.f - fast_exp(-wd[j]) : 1.f;       // sigmoid(raw) = 1 - exp(-softplus(raw))
                     dbias_acc += ddv;
-                    dup[row_off(tt[j], P.du.st)] = from_f32<T>(du[j]);
-                    ddp[row_off(tt[j], P.ddelta.st)] = from_f32<T>(ddv);
+                    st_row<T>(dup, ts.t, du[j]);
+                    st_row<T>(ddp, ts.t, ddv);
                 }
+                ts.next(tm);
             }
         }
+        tw.jump(tm, -kWin);
     }
     if (it.valid) {
         const int64_t row = crow * (nstate + 2);
 #pragma unroll
         for (int n = 0; n < NS; ++n)
-            if (n < nstate) P.part[(row + n) * gm.dim + it.d] = dA[n];
+            if (n < nstate) P.part[(row + n) * gm.dim + it.d] = s_dA[n][threadIdx.x];
         P.part[(row + nstate) * gm.dim + it.d] = dD_acc;
         P.part[(row + nstate + 1) * gm.dim + it.d] = dbias_acc;
     }

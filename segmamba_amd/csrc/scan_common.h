@@ -21,7 +21,7 @@ struct ScanDev {
     float* agg_sd;                         // [batch][nchunks][dim]          sum of delta over the chunk
     float* agg_h;                          // [batch][nchunks][nstate][dim]  chunk end state from a zero start
     float* carry;                          // [batch][nchunks][nstate][dim]  state entering the chunk
-    float* ckpt;                           // [batch][nck][nstate][dim]      state entering step 32*k (or null)
+    float* ckpt;                           // [batch][nck][nstate][dim]      state entering step 16*k (or null)
     int32_t nck;
     float* last_state;                     // (batch, dim, nstate) or null
     int64_t last_state_sb;                 // = full_dim * nstate
@@ -46,15 +46,16 @@ template <typename T, int TS, int NS, int RW>
 __device__ __forceinline__ void stage_fetch(StageRegs<TS, NS, RW>& rg, const BC& m, const TimeMap& tm, const TimeIter& it0,
                                             int b, int nstate, int r, bool item_ok) {
     const bool t_fastest = m.st <= m.sn;     // pick the lane -> element order that is contiguous in memory
-    const T* base = reinterpret_cast<const T*>(m.p) + (int64_t)b * m.sb;
+    const char* base = m.p + (int64_t)b * m.sb * (int64_t)sizeof(T);          // wave-uniform
+    const uint32_t stb = (uint32_t)m.st * (uint32_t)sizeof(T), snb = (uint32_t)m.sn * (uint32_t)sizeof(T);
 #pragma unroll
     for (int i = 0; i < TS * NS / RW; ++i) {
         const int e = r + i * RW;
         int s, n;
         if (t_fastest) { n = e / TS; s = e - n * TS; } else { s = e / NS; n = e - s * NS; }
         const bool ok = item_ok && n < nstate && (it0.tau + s) < tm.L && (it0.tau + s) >= 0;
-        const int32_t t = ok ? it0.ahead(tm, s) : 0;
-        const float v = to_f32(base[row_off(t, m.st) + (ok ? (int64_t)n * m.sn : 0)]);
+        const uint32_t off = ok ? __umul24((uint32_t)it0.ahead(tm, s), stb) + (uint32_t)n * snb : 0u;
+        const float v = to_f32(*reinterpret_cast<const T*>(base + off));
         rg.v[i] = ok ? v : 0.f;
     }
 }
@@ -70,7 +71,30 @@ __device__ __forceinline__ void stage_park(const StageRegs<TS, NS, RW>& rg, floa
     }
 }
 
-// Physical row index of the TS consecutive logical steps starting at `tj` (0 where the step is past L or the
+// --- per-lane access to the rows of a sequence tensor ----------------------------------------------------
+// address = wave-uniform batch base (SGPRs) + 32-bit byte offset  t * row_stride_bytes + lane_offset_bytes,
+// i.e. one v_mad_u32_u24 per access and the saddr + voffset addressing mode.  The C ABI guarantees
+// t < 2^24, row stride < 2^24 bytes and a per-batch span < 4 GiB (validate_spans()).
+struct RowPtr {
+    char* base;        // p + b * stride_b   (uniform over the wave)
+    uint32_t loff;     // d * stride_d       in bytes (0 for lanes without a channel)
+    uint32_t stb;      // stride_t           in bytes
+};
+template <typename T> __device__ __forceinline__ RowPtr make_rowptr(const Seq& s, int b_uniform, int d, bool lane_ok) {
+    RowPtr r;
+    r.base = s.p + (int64_t)b_uniform * s.sb * (int64_t)sizeof(T);
+    r.loff = lane_ok ? (uint32_t)d * (uint32_t)(s.sd * (int64_t)sizeof(T)) : 0u;
+    r.stb = (uint32_t)(s.st * (int64_t)sizeof(T));
+    return r;
+}
+template <typename T> __device__ __forceinline__ float ld_row(const RowPtr& r, int32_t t) {
+    return to_f32(*reinterpret_cast<const T*>(r.base + (uint32_t)(__umul24((uint32_t)t, r.stb) + r.loff)));
+}
+template <typename T> __device__ __forceinline__ void st_row(const RowPtr& r, int32_t t, float v) {
+    *reinterpret_cast<T*>(r.base + (uint32_t)(__umul24((uint32_t)t, r.stb) + r.loff)) = from_f32<T>(v);
+}
+
+// Physical row index of the TS consecutive logical steps starting at `tj` (0 where the step is outside [0, L) or the
 // lane owns no channel: such rows are loaded from row 0 and masked) and the mask of real rows.
 template <int TS>
 __device__ __forceinline__ uint32_t row_indices(int32_t (&tt)[TS], const TimeMap& tm, TimeIter tj, bool lane_ok) {
@@ -87,20 +111,16 @@ __device__ __forceinline__ uint32_t row_indices(int32_t (&tt)[TS], const TimeMap
 
 // Per-lane rows of a sequence tensor.  Unconditional loads, masked values.
 template <typename T, int TS>
-__device__ __forceinline__ void fetch_rows(float (&dst)[TS], const Seq& s, const T* lane_base, const int32_t (&tt)[TS],
-                                           uint32_t okm) {
+__device__ __forceinline__ void fetch_rows(float (&dst)[TS], const RowPtr& rp, const int32_t (&tt)[TS], uint32_t okm) {
 #pragma unroll
     for (int j = 0; j < TS; ++j) {
-        const float v = to_f32(lane_base[row_off(tt[j], s.st)]);
+        const float v = ld_row<T>(rp, tt[j]);
         dst[j] = ((okm >> j) & 1u) ? v : 0.f;
     }
 }
 
-// pointer to (batch b, channel d) of a sequence tensor; channel clamped to 0 for lanes without a channel
-template <typename T> __device__ __forceinline__ T* lane_ptr(const Seq& s, int b, int d, bool lane_ok) {
-    return reinterpret_cast<T*>(s.p) + (int64_t)b * s.sb + (lane_ok ? (int64_t)d * s.sd : 0);
-}
-
+// the batch index of a wave's work items as a scalar (all items of a wave share it by construction)
+__device__ __forceinline__ int uniform_batch(const Item& it) { return __builtin_amdgcn_readfirstlane(it.b); }
 
 // ---- host helpers shared by scan_fwd.hip / scan_bwd.hip -------------------------------------------------
 Geom make_geom(int batch, int dim, int nstate, int64_t L, int chunk);
@@ -111,6 +131,8 @@ Seq seq_at(const segm_seq& s, int64_t d0, size_t esize);
 BC bc_at(const segm_bc& m, int g, size_t esize);
 size_t dtype_size(int dtype);
 void fill_scan_dev(ScanDev& P, const segm_scan_fwd_args* a, int g, int chunk);
+int validate_spans(const segm_seq* const* seqs, int nseq, const segm_bc* const* bcs, int nbc, int batch, int dim,
+                   int dstate, int n_groups, int64_t L, size_t esize);
 void launch_scan_carry(const ScanDev& P, bool reverse, const float* agg_sd, const float* agg_h, float* carry,
                        hipStream_t stream);
 

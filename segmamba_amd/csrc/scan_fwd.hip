@@ -9,7 +9,7 @@
 //   K2  scan_carry_kernel      per (batch, channel, state): compose the chunk aggregates into the state
 //                              entering every chunk      (h_in[c+1] = exp(A * sum_delta[c]) * h_in[c] + H[c])
 //   K3  scan_fwd_apply_kernel  per (batch, chunk, channel): re-run the chunk from its true entering state,
-//                              y = <C, h> + D u, out_z = y silu(z); optionally checkpoint h every 32 steps
+//                              y = <C, h> + D u, out_z = y silu(z); optionally checkpoint h every 16 steps
 //
 // The monoid (a1, b1) o (a0, b0) = (a1 a0, a1 b0 + b1) is the reference's SSMScanOp
 // (selective_scan_common.h:110-115); the product of a's over a chunk is exp(A * sum of delta), so only the
@@ -31,8 +31,10 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_kernel(ScanDev P) {
     const Geom& gm = P.gm;
     const TimeMap tm = P.tm;
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const int ub = uniform_batch(it);
     const bool item_ok = it.wave_valid && it.chunk < gm.nchunks;
     const int nstate = gm.nstate;
+    const bool softplus_on = P.delta_softplus != 0;
 
     float A2[NS], h[NS];
 #pragma unroll
@@ -41,8 +43,8 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_kernel(ScanDev P) {
         h[n] = 0.f;
     }
     const float bias = (it.valid && P.delta_bias) ? P.delta_bias[it.d] : 0.f;
-    const T* up = lane_ptr<T>(P.u, it.b, it.d, it.valid);
-    const T* dp = lane_ptr<T>(P.delta, it.b, it.d, it.valid);
+    const RowPtr up = make_rowptr<T>(P.u, ub, it.d, it.valid);
+    const RowPtr dp = make_rowptr<T>(P.delta, ub, it.d, it.valid);
     const bool t_fastest = P.Bm.st <= P.Bm.sn;
 
     TimeIter ti;
@@ -52,9 +54,9 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_kernel(ScanDev P) {
     int32_t ntt[TS];
     StageRegs<TS, NS, RW> sb;
     uint32_t nok = row_indices<TS>(ntt, tm, ti, it.valid);
-    fetch_rows<T, TS>(nu, P.u, up, ntt, nok);
-    fetch_rows<T, TS>(nd, P.delta, dp, ntt, nok);
-    stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, it.b, nstate, it.r, item_ok);
+    fetch_rows<T, TS>(nu, up, ntt, nok);
+    fetch_rows<T, TS>(nd, dp, ntt, nok);
+    stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, ub, nstate, it.r, item_ok);
 
     float sumd = 0.f;
     int buf = 0;
@@ -69,14 +71,14 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_kernel(ScanDev P) {
         ti.jump(tm, TS);
         // prefetch the next sub-tile (past the chunk end this reads the neighbour's / masked rows: harmless)
         nok = row_indices<TS>(ntt, tm, ti, it.valid);
-        fetch_rows<T, TS>(nu, P.u, up, ntt, nok);
-        fetch_rows<T, TS>(nd, P.delta, dp, ntt, nok);
-        stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, it.b, nstate, it.r, item_ok);
+        fetch_rows<T, TS>(nu, up, ntt, nok);
+        fetch_rows<T, TS>(nd, dp, ntt, nok);
+        stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, ub, nstate, it.r, item_ok);
 #pragma unroll
         for (int j = 0; j < TS; ++j) {
             const bool ok = (cok >> j) & 1u;
             float dl = cd[j] + bias;
-            if (P.delta_softplus) dl = softplus20(dl);
+            dl = softplus_on ? softplus20(dl) : dl;       // select, not a branch: keeps each step one basic block
             dl = ok ? dl : 0.f;
             const float dlu = dl * cu[j];
             sumd += dl;
@@ -92,6 +94,8 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_kernel(ScanDev P) {
                     h[n] = fmaf(a, h[n], dlu * bb[i]);
                 }
             }
+#pragma unroll
+            for (int n = 0; n < NS; ++n) SEGM_PIN_F32(h[n]);     // finish this step before the next one's LDS reads
         }
         buf ^= 1;
     }
@@ -121,6 +125,7 @@ __global__ void __launch_bounds__(kCarrySegs * 64) scan_carry_kernel(ScanDev P, 
     const bool valid = d < gm.dim;
     const int dd = valid ? d : 0;
     const int nstate = gm.nstate;
+    const bool softplus_on = P.delta_softplus != 0;
     const int nch = gm.nchunks;
     const int per = (nch + kCarrySegs - 1) / kCarrySegs;
     const int q0 = seg * per;
@@ -176,8 +181,10 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_apply_kernel(ScanDev P) {
     const Geom& gm = P.gm;
     const TimeMap tm = P.tm;
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const int ub = uniform_batch(it);
     const bool item_ok = it.wave_valid && it.chunk < gm.nchunks;
     const int nstate = gm.nstate;
+    const bool softplus_on = P.delta_softplus != 0;
     const bool has_z = P.z.p != nullptr, has_out = P.out.p != nullptr;
 
     float A2[NS], h[NS];
@@ -190,12 +197,12 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_apply_kernel(ScanDev P) {
     }
     const float bias = (it.valid && P.delta_bias) ? P.delta_bias[it.d] : 0.f;
     const float Dv = (it.valid && P.D) ? P.D[it.d] : 0.f;
-    const T* up = lane_ptr<T>(P.u, it.b, it.d, it.valid);
-    const T* dp = lane_ptr<T>(P.delta, it.b, it.d, it.valid);
+    const RowPtr up = make_rowptr<T>(P.u, ub, it.d, it.valid);
+    const RowPtr dp = make_rowptr<T>(P.delta, ub, it.d, it.valid);
     const Seq& zs = has_z ? P.z : P.u;                          // without a gate the z stream aliases u (unused)
-    const T* zp = lane_ptr<T>(zs, it.b, it.d, it.valid);
-    T* op = has_out ? lane_ptr<T>(P.out, it.b, it.d, it.valid) : nullptr;
-    T* ozp = has_z ? lane_ptr<T>(P.out_z, it.b, it.d, it.valid) : nullptr;
+    const RowPtr zp = make_rowptr<T>(zs, ub, it.d, it.valid);
+    const RowPtr op = make_rowptr<T>(P.out, ub, it.d, it.valid && has_out);
+    const RowPtr ozp = make_rowptr<T>(P.out_z, ub, it.d, it.valid && has_z);
     const bool t_fastest = P.Bm.st <= P.Bm.sn;
 
     TimeIter ti;
@@ -205,11 +212,11 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_apply_kernel(ScanDev P) {
     int32_t ntt[TS];
     StageRegs<TS, NS, RW> sb, sc;
     uint32_t nok = row_indices<TS>(ntt, tm, ti, it.valid);
-    fetch_rows<T, TS>(nu, P.u, up, ntt, nok);
-    fetch_rows<T, TS>(nd, P.delta, dp, ntt, nok);
-    fetch_rows<T, TS>(nz, zs, zp, ntt, nok);
-    stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, it.b, nstate, it.r, item_ok);
-    stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, it.b, nstate, it.r, item_ok);
+    fetch_rows<T, TS>(nu, up, ntt, nok);
+    fetch_rows<T, TS>(nd, dp, ntt, nok);
+    fetch_rows<T, TS>(nz, zp, ntt, nok);
+    stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, ub, nstate, it.r, item_ok);
+    stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, ub, nstate, it.r, item_ok);
 
     int buf = 0;
     for (int s0 = 0; s0 < gm.chunk; s0 += TS) {
@@ -226,11 +233,11 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_apply_kernel(ScanDev P) {
         const int32_t tau0 = ti.tau;
         ti.jump(tm, TS);
         nok = row_indices<TS>(ntt, tm, ti, it.valid);
-        fetch_rows<T, TS>(nu, P.u, up, ntt, nok);
-        fetch_rows<T, TS>(nd, P.delta, dp, ntt, nok);
-        fetch_rows<T, TS>(nz, zs, zp, ntt, nok);
-        stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, it.b, nstate, it.r, item_ok);
-        stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, it.b, nstate, it.r, item_ok);
+        fetch_rows<T, TS>(nu, up, ntt, nok);
+        fetch_rows<T, TS>(nd, dp, ntt, nok);
+        fetch_rows<T, TS>(nz, zp, ntt, nok);
+        stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, ub, nstate, it.r, item_ok);
+        stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, ub, nstate, it.r, item_ok);
         // state entering step tau0, every kCkpt steps (kept for the backward pass)
         if (P.ckpt && (tau0 % kCkpt) == 0 && it.valid && tau0 < tm.L) {
             const int64_t krow = (int64_t)it.b * P.nck + tau0 / kCkpt;
@@ -242,7 +249,7 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_apply_kernel(ScanDev P) {
         for (int j = 0; j < TS; ++j) {
             const bool ok = (cok >> j) & 1u;
             float dl = cd[j] + bias;
-            if (P.delta_softplus) dl = softplus20(dl);
+            dl = softplus_on ? softplus20(dl) : dl;       // select, not a branch: keeps each step one basic block
             dl = ok ? dl : 0.f;
             const float uu = cu[j];
             const float dlu = dl * uu;
@@ -263,12 +270,14 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_apply_kernel(ScanDev P) {
                 }
             }
             if (ok) {
-                if (has_out) op[row_off(ctt[j], P.out.st)] = from_f32<T>(y);
+                if (has_out) st_row<T>(op, ctt[j], y);
                 if (has_z) {
                     const float zz = cz[j];
-                    ozp[row_off(ctt[j], P.out_z.st)] = from_f32<T>(y * zz * sigmoidf(zz));
+                    st_row<T>(ozp, ctt[j], y * zz * sigmoidf(zz));
                 }
             }
+#pragma unroll
+            for (int n = 0; n < NS; ++n) SEGM_PIN_F32(h[n]);     // finish this step before the next one's LDS reads
         }
         buf ^= 1;
     }

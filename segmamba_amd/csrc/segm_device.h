@@ -23,8 +23,16 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;           // 4 waves per workgroup
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxState = 16;
-constexpr int kCkpt = 32;             // spacing (steps) of the forward state checkpoints kept for backward
+constexpr int kCkpt = 16;             // spacing (steps) of the forward state checkpoints kept for backward
 constexpr float kLog2e = 1.4426950408889634f;
+
+// Pins a value to "computed here": an empty asm that reads and writes the register, so the compiler can neither
+// sink the computation producing it below this point nor hoist later memory reads above it.  Used once per time
+// step in the scan loops: without it the optimiser batches the LDS reads of a whole sub-tile ahead of the
+// arithmetic and the kernels need > 200 VGPRs.  (The CPU emulation build defines it away.)
+#ifndef SEGM_PIN_F32
+#define SEGM_PIN_F32(x) asm volatile("" : "+v"(x) : : "memory")
+#endif
 
 typedef _Float16 f16_t;
 typedef __bf16 bf16_t;

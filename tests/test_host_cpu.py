@@ -35,9 +35,9 @@ def test_abi_queries_without_gpu(built_lib):
     l = lib.SegmLib(built_lib)
     assert l.dll.segm_abi_version() == 1
     assert l.dll.segm_status_string(-3).decode().startswith("dstate")
-    # SegMamba stage 0: B=2, D=96, L=64^3 -> 256-step work items, 32-step checkpoints
+    # SegMamba stage 0: B=2, D=96, L=64^3 -> 256-step work items, 16-step checkpoints
     assert l.dll.segm_selective_scan_default_chunk(2, 96, 262144) == 256
-    assert l.dll.segm_selective_scan_ckpt_bytes(2, 96, 16, 262144) == 2 * (262144 // 32) * 16 * 96 * 4
+    assert l.dll.segm_selective_scan_ckpt_bytes(2, 96, 16, 262144) == 2 * (262144 // 16) * 16 * 96 * 4
     assert l.dll.segm_selective_scan_fwd_workspace_bytes(2, 96, 16, 262144, 0) > 0
     # argument errors are reported without touching the device
     a = lib.ScanFwdArgs()

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import helpers as H
 from segmamba_amd import lib as L, ops_raw
 from oracle.ref_ops import algorithmic_bytes_scan
-hip = L.get_lib()
+hip = L.SegmLib(os.environ["SEGM_LIB"]) if os.environ.get("SEGM_LIB") else L.get_lib()
+print("lib", hip.path)
 print(torch.cuda.get_device_name(0))
 for cl in (True, False):
     c = H.scan_case(2, 96, 16, 512)
@@ -27,7 +28,7 @@ for dtype in (torch.float32, torch.bfloat16):
         delta = (0.5*torch.rand(B, Lq, D, device="cuda", generator=g)).to(dtype)
         A = -0.5*torch.rand(D, N, device="cuda", generator=g); Bm, Cm = rn(B, Lq, N), rn(B, Lq, N)
         Dv = torch.randn(D, device="cuda", generator=g); db = 0.5*torch.rand(D, device="cuda", generator=g)
-        for chunk in (0, 64, 128, 512):
+        for chunk in ((0,) if os.environ.get("SEGM_QUICK") else (0, 64, 128, 512)):
             if chunk > Lq: continue
             f = ops_raw.scan_fwd(hip, u, delta, A, Bm, Cm, Dv, z, db, True, channel_last=True, need_out=True, need_ckpt=True, chunk=chunk)
             ms_f = tm(lambda: ops_raw.scan_fwd(hip, u, delta, A, Bm, Cm, Dv, z, db, True, channel_last=True, need_out=True, need_ckpt=True, chunk=chunk))
@@ -41,4 +42,4 @@ for dtype in (torch.float32, torch.bfloat16):
         ms_cb = tm(lambda: ops_raw.conv1d_bwd(hip, u, w, bb, dout, True, channel_last=True))
         print(json.dumps(dict(conv=1, dtype=str(dtype), D=D, L=Lq, fwd_ms=round(ms_cf,4), bwd_ms=round(ms_cb,4),
               fwd_GBps=round(2*es*B*D*Lq/ms_cf*1e-6,1), bwd_GBps=round(3*es*B*D*Lq/ms_cb*1e-6,1))), flush=True)
-json.dump(out, open("gpurun_out/sanity.json","w"))
+json.dump(out, open("gpurun_out/sanity_%s.json" % os.environ.get("SEGM_TAG", "a"),"w"))
