@@ -24,6 +24,11 @@ import os
 import sys
 import time
 
+# MIOpen's find step benchmarks every applicable solver the first time it sees a convolution; its "naive" reference
+# solvers take ~0.4 s per call on these 3-D shapes (profiles/r01_bench_step_kernels.txt) and are never the winner.
+for _k in ("FWD", "BWD", "WRW"):
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + _k, "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

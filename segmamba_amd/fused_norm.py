@@ -35,3 +35,16 @@ def instance_norm_act(x: torch.Tensor, act: str = "none", slope: float = 0.01, e
     if act == "leaky_relu":
         return F.leaky_relu(y, negative_slope=slope)
     raise ValueError(f"unknown activation {act!r}")
+
+
+def pointwise_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """1x1x1 convolution as the GEMM it is (north star: "MFMA only for the 1x1x1 projection GEMMs").
+
+    x (B, C, D, H, W), weight (Cout, C, 1, 1, 1).  MIOpen's conv path is badly tuned for these shapes in bf16 (the
+    48 -> 4 output head's weight-gradient kernel alone took 533 ms of a 983 ms training step, profiles/r01_*):
+    a (B*D*H*W, C) x (C, Cout) matrix product through the BLAS path takes well under a millisecond.  With
+    channels_last_3d activations the permutes below are views, otherwise they cost one transposing copy each way.
+    """
+    cout, cin = weight.shape[0], weight.shape[1]
+    y = F.linear(x.permute(0, 2, 3, 4, 1), weight.reshape(cout, cin), bias)       # (B, D, H, W, Cout)
+    return y.permute(0, 4, 1, 2, 3)

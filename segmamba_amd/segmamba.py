@@ -53,7 +53,8 @@ class MlpChannel(nn.Module):
         self.fc2 = nn.Conv3d(mlp_dim, hidden_size, 1)
 
     def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
+        h = self.act(fused_norm.pointwise_conv3d(x, self.fc1.weight, self.fc1.bias))
+        return fused_norm.pointwise_conv3d(h, self.fc2.weight, self.fc2.bias)
 
 
 class GSC(nn.Module):
@@ -82,8 +83,10 @@ class GSC(nn.Module):
     def forward(self, x):
         x1 = fused_norm.instance_norm_act(self.proj(x), act="relu", eps=self.norm.eps)
         x1 = fused_norm.instance_norm_act(self.proj2(x1), act="relu", eps=self.norm2.eps)
-        x2 = fused_norm.instance_norm_act(self.proj3(x), act="relu", eps=self.norm3.eps)
-        y = fused_norm.instance_norm_act(self.proj4(x1 + x2), act="relu", eps=self.norm4.eps)
+        x2 = fused_norm.instance_norm_act(fused_norm.pointwise_conv3d(x, self.proj3.weight, self.proj3.bias),
+                                          act="relu", eps=self.norm3.eps)
+        y = fused_norm.instance_norm_act(fused_norm.pointwise_conv3d(x1 + x2, self.proj4.weight, self.proj4.bias),
+                                         act="relu", eps=self.norm4.eps)
         return y + x
 
 

@@ -15,6 +15,7 @@ lr_scheduler.py:36 poly 0.9).  Differences, all deliberate:
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -31,6 +32,8 @@ class SyntheticBraTS:
         self.items = []
         for _ in range(pool):
             image = torch.rand(batch, 4, size, size, size, device=device, generator=g)
+            if os.environ.get("SEGM_CHANNELS_LAST_3D", "0") == "1":
+                image = image.contiguous(memory_format=torch.channels_last_3d)
             label = torch.randint(0, 4, (batch, size, size, size), device=device, generator=g)
             self.items.append((image, label))
         self.i = 0
@@ -57,6 +60,8 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
     if model is None:
         model = SegMamba(in_chans=4, out_chans=4, depths=[2, 2, 2, 2], feat_size=[48, 96, 192, 384])
     model = model.to(device)
+    if os.environ.get("SEGM_CHANNELS_LAST_3D", "0") == "1":     # experiment switch: NDHWC activations / weights
+        model = model.to(memory_format=torch.channels_last_3d)
     if distributed:
         model = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[local_rank] if device.type == "cuda" else None, find_unused_parameters=True)

@@ -62,6 +62,12 @@ class ConvOnly(nn.Sequential):
             conv = nn.Conv3d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
                              padding=pad, bias=bias)
         self.add_module("conv", conv)
+        self._pointwise = (not transposed) and kernel_size == 1 and stride == 1
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._pointwise:
+            return fused_norm.pointwise_conv3d(x, self.conv.weight, self.conv.bias)
+        return self.conv(x)
 
 
 class UnetResBlock(nn.Module):

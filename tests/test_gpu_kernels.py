@@ -85,7 +85,7 @@ def test_scan_forward_is_deterministic_and_chunk_invariant(hip):
         b = H.run_scan(hip, c, DEV, True, chunk=128, backward=False)["out"]
         assert torch.equal(a, b)
     d = H.run_scan(hip, c, DEV, True, chunk=1024, backward=False)["out"]
-    H.assert_close(d, a, 1e-4, 1e-4, "chunk 1024 vs 128")
+    H.assert_close(d, a, 1e-4, 1e-5 * float(a.abs().max()), "chunk 1024 vs 128")      # fp32 rounding, different grouping
 
 
 def test_scan_full_size_properties(hip):
