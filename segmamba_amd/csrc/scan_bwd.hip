@@ -91,6 +91,9 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
         fetch_rows<T, TS>(ng, gp, ntt, nok);
         fetch_rows<T, TS>(nz, zp, ntt, nok);
         stage_fetch<T, TS, NS, RW>(sc, P.Cm, tm, ti, ub, nstate, it.r, item_ok);
+        float4 cq[NS / 4];
+#pragma unroll
+        for (int q = 0; q < NS / 4; ++q) cq[q] = reinterpret_cast<const float4*>(lc + (TS - 1) * NS)[q];
 #pragma unroll
         for (int jj = 0; jj < TS; ++jj) {
             const int j = TS - 1 - jj;
@@ -101,11 +104,14 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
             sumd += dl;
             float g = cg[j];
             if (has_z) { const float zz = cz[j]; g *= zz * sigmoidf(zz); }
-            const float4* C4 = reinterpret_cast<const float4*>(lc + j * NS);
+            float4 cn[NS / 4];
+            if (j > 0) {                                   // next (lower) step's C row, one step ahead of its use
+#pragma unroll
+                for (int q = 0; q < NS / 4; ++q) cn[q] = reinterpret_cast<const float4*>(lc + (j - 1) * NS)[q];
+            }
 #pragma unroll
             for (int q = 0; q < NS / 4; ++q) {
-                const float4 cv = C4[q];
-                const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+                const float cc[4] = {cq[q].x, cq[q].y, cq[q].z, cq[q].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int n = q * 4 + i;
@@ -114,7 +120,11 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
                 }
             }
 #pragma unroll
-            for (int n = 0; n < NS; ++n) SEGM_PIN_F32(e[n]);     // finish this step before the next one's LDS reads
+            for (int n = 0; n < NS; ++n) SEGM_PIN_F32(e[n]);     // finish this step before the LDS reads two steps ahead
+            if (j > 0) {
+#pragma unroll
+                for (int q = 0; q < NS / 4; ++q) cq[q] = cn[q];
+            }
         }
         buf ^= 1;
     }

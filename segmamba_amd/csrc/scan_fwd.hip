@@ -74,6 +74,10 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_kernel(ScanDev P) {
         fetch_rows<T, TS>(nu, up, ntt, nok);
         fetch_rows<T, TS>(nd, dp, ntt, nok);
         stage_fetch<T, TS, NS, RW>(sb, P.Bm, tm, ti, ub, nstate, it.r, item_ok);
+        // B rows are read from LDS one step ahead of their use so the LDS latency overlaps the previous step's math
+        float4 bq[NS / 4];
+#pragma unroll
+        for (int q = 0; q < NS / 4; ++q) bq[q] = reinterpret_cast<const float4*>(lb)[q];
 #pragma unroll
         for (int j = 0; j < TS; ++j) {
             const bool ok = (cok >> j) & 1u;
@@ -82,11 +86,14 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_kernel(ScanDev P) {
             dl = ok ? dl : 0.f;
             const float dlu = dl * cu[j];
             sumd += dl;
-            const float4* B4 = reinterpret_cast<const float4*>(lb + j * NS);
+            float4 bn[NS / 4];
+            if (j + 1 < TS) {
+#pragma unroll
+                for (int q = 0; q < NS / 4; ++q) bn[q] = reinterpret_cast<const float4*>(lb + (j + 1) * NS)[q];
+            }
 #pragma unroll
             for (int q = 0; q < NS / 4; ++q) {
-                const float4 bv = B4[q];
-                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                const float bb[4] = {bq[q].x, bq[q].y, bq[q].z, bq[q].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int n = q * 4 + i;
@@ -95,7 +102,11 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_kernel(ScanDev P) {
                 }
             }
 #pragma unroll
-            for (int n = 0; n < NS; ++n) SEGM_PIN_F32(h[n]);     // finish this step before the next one's LDS reads
+            for (int n = 0; n < NS; ++n) SEGM_PIN_F32(h[n]);     // finish this step before the LDS reads two steps ahead
+            if (j + 1 < TS) {
+#pragma unroll
+                for (int q = 0; q < NS / 4; ++q) bq[q] = bn[q];
+            }
         }
         buf ^= 1;
     }
@@ -117,6 +128,7 @@ template <bool REVERSE>
 __global__ void __launch_bounds__(kCarrySegs * 64) scan_carry_kernel(ScanDev P, const float* __restrict__ agg_sd,
                                                                      const float* __restrict__ agg_h,
                                                                      float* __restrict__ carry) {
+    constexpr int TILE = 16;            // chunks whose aggregates are fetched together (independent loads), then folded
     __shared__ float s_p[kCarrySegs][64];
     __shared__ float s_h[kCarrySegs][64];
     const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
@@ -125,36 +137,58 @@ __global__ void __launch_bounds__(kCarrySegs * 64) scan_carry_kernel(ScanDev P, 
     const bool valid = d < gm.dim;
     const int dd = valid ? d : 0;
     const int nstate = gm.nstate;
-    const bool softplus_on = P.delta_softplus != 0;
     const int nch = gm.nchunks;
     const int per = (nch + kCarrySegs - 1) / kCarrySegs;
     const int q0 = seg * per;
     const int q1 = (q0 + per < nch) ? q0 + per : nch;
     const float A2 = valid ? P.A[(int64_t)d * nstate + n] * kLog2e : 0.f;
+    const float* sd_base = agg_sd + (int64_t)b * nch * gm.dim + dd;
+    const float* h_base = agg_h + ((int64_t)b * nch * nstate + n) * gm.dim + dd;
+    const int64_t h_stride = (int64_t)nstate * gm.dim;
 
     float acc = 0.f, sds = 0.f;
-#pragma unroll 4
-    for (int q = q0; q < q1; ++q) {
-        const int c = REVERSE ? nch - 1 - q : q;
-        const int64_t row = (int64_t)b * nch + c;
-        const float sd = agg_sd[row * gm.dim + dd];
-        const float hh = agg_h[(row * nstate + n) * gm.dim + dd];
-        acc = fmaf(fast_exp2(A2 * sd), acc, hh);
-        sds += sd;
+    for (int qb = q0; qb < q1; qb += TILE) {
+        float pv[TILE], hv[TILE];
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) {
+            const int q = qb + i;
+            const bool in = q < q1;
+            const int c = in ? (REVERSE ? nch - 1 - q : q) : 0;
+            const float sd = sd_base[(int64_t)c * gm.dim];
+            const float hh = h_base[(int64_t)c * h_stride];
+            sds += in ? sd : 0.f;
+            pv[i] = in ? fast_exp2(A2 * sd) : 1.f;
+            hv[i] = in ? hh : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) acc = fmaf(pv[i], acc, hv[i]);
     }
     s_p[seg][lane] = fast_exp2(A2 * sds);
     s_h[seg][lane] = acc;
     __syncthreads();
     float cin = 0.f;
     for (int s = 0; s < seg; ++s) cin = fmaf(s_p[s][lane], cin, s_h[s][lane]);
-#pragma unroll 4
-    for (int q = q0; q < q1; ++q) {
-        const int c = REVERSE ? nch - 1 - q : q;
-        const int64_t row = (int64_t)b * nch + c;
-        const float sd = agg_sd[row * gm.dim + dd];
-        const float hh = agg_h[(row * nstate + n) * gm.dim + dd];
-        if (valid) carry[(row * nstate + n) * gm.dim + d] = cin;
-        cin = fmaf(fast_exp2(A2 * sd), cin, hh);
+    for (int qb = q0; qb < q1; qb += TILE) {
+        float pv[TILE], hv[TILE];
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) {
+            const int q = qb + i;
+            const bool in = q < q1;
+            const int c = in ? (REVERSE ? nch - 1 - q : q) : 0;
+            const float sd = sd_base[(int64_t)c * gm.dim];
+            const float hh = h_base[(int64_t)c * h_stride];
+            pv[i] = in ? fast_exp2(A2 * sd) : 1.f;
+            hv[i] = in ? hh : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) {
+            const int q = qb + i;
+            if (valid && q < q1) {
+                const int c = REVERSE ? nch - 1 - q : q;
+                carry[(((int64_t)b * nch + c) * nstate + n) * gm.dim + d] = cin;
+            }
+            cin = fmaf(pv[i], cin, hv[i]);
+        }
     }
     if (!REVERSE && P.last_state && valid && q0 < nch && q1 == nch)
         P.last_state[(int64_t)b * P.last_state_sb + (int64_t)d * nstate + n] = cin;
@@ -245,6 +279,12 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_apply_kernel(ScanDev P) {
             for (int n = 0; n < NS; ++n)
                 if (n < nstate) P.ckpt[(krow * nstate + n) * gm.dim + it.d] = h[n];
         }
+        float4 bq[NS / 4], cq[NS / 4];
+#pragma unroll
+        for (int q = 0; q < NS / 4; ++q) {
+            bq[q] = reinterpret_cast<const float4*>(lb)[q];
+            cq[q] = reinterpret_cast<const float4*>(lc)[q];
+        }
 #pragma unroll
         for (int j = 0; j < TS; ++j) {
             const bool ok = (cok >> j) & 1u;
@@ -254,13 +294,18 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_apply_kernel(ScanDev P) {
             const float uu = cu[j];
             const float dlu = dl * uu;
             float y = Dv * uu;
-            const float4* B4 = reinterpret_cast<const float4*>(lb + j * NS);
-            const float4* C4 = reinterpret_cast<const float4*>(lc + j * NS);
+            float4 bn[NS / 4], cn[NS / 4];
+            if (j + 1 < TS) {                              // next step's B / C rows, one step ahead of their use
+#pragma unroll
+                for (int q = 0; q < NS / 4; ++q) {
+                    bn[q] = reinterpret_cast<const float4*>(lb + (j + 1) * NS)[q];
+                    cn[q] = reinterpret_cast<const float4*>(lc + (j + 1) * NS)[q];
+                }
+            }
 #pragma unroll
             for (int q = 0; q < NS / 4; ++q) {
-                const float4 bv = B4[q], cv = C4[q];
-                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-                const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+                const float bb[4] = {bq[q].x, bq[q].y, bq[q].z, bq[q].w};
+                const float cc[4] = {cq[q].x, cq[q].y, cq[q].z, cq[q].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int n = q * 4 + i;
@@ -277,7 +322,11 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_apply_kernel(ScanDev P) {
                 }
             }
 #pragma unroll
-            for (int n = 0; n < NS; ++n) SEGM_PIN_F32(h[n]);     // finish this step before the next one's LDS reads
+            for (int n = 0; n < NS; ++n) SEGM_PIN_F32(h[n]);     // finish this step before the LDS reads two steps ahead
+            if (j + 1 < TS) {
+#pragma unroll
+                for (int q = 0; q < NS / 4; ++q) { bq[q] = bn[q]; cq[q] = cn[q]; }
+            }
         }
         buf ^= 1;
     }
