@@ -48,3 +48,27 @@ def pointwise_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor |
     cout, cin = weight.shape[0], weight.shape[1]
     y = F.linear(x.permute(0, 2, 3, 4, 1), weight.reshape(cout, cin), bias)       # (B, D, H, W, Cout)
     return y.permute(0, 4, 1, 2, 3)
+
+
+def patch_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, k: int) -> torch.Tensor:
+    """Conv3d with kernel_size == stride == k and no padding (SegMamba's down-sampling convs, segmamba.py:148): the
+    patches do not overlap, so it is one GEMM on a space-to-depth view.  x (B, C, D, H, W), weight (Cout, C, k, k, k)."""
+    B, C, D, H, W = x.shape
+    cout = weight.shape[0]
+    xp = x.reshape(B, C, D // k, k, H // k, k, W // k, k).permute(0, 2, 4, 6, 1, 3, 5, 7)     # (B, d, h, w, C, k, k, k)
+    y = F.linear(xp.reshape(B, D // k, H // k, W // k, C * k ** 3), weight.reshape(cout, C * k ** 3), bias)
+    return y.permute(0, 4, 1, 2, 3)
+
+
+def patch_conv_transpose3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, k: int) -> torch.Tensor:
+    """ConvTranspose3d with kernel_size == stride == k, no padding (the UNETR up-sampling, unetr_block.py:52-60):
+    every input voxel writes its own k^3 output block, so it is one GEMM followed by a depth-to-space permute.
+    x (B, C, D, H, W), weight (C, Cout, k, k, k).  (MIOpen's kernels for these shapes took 0.6 s per training step,
+    profiles/r01_bench_step_kernels_v2.txt.)"""
+    B, C, D, H, W = x.shape
+    cout = weight.shape[1]
+    y = F.linear(x.permute(0, 2, 3, 4, 1), weight.reshape(C, cout * k ** 3).t())              # (B, D, H, W, Cout*k^3)
+    y = y.reshape(B, D, H, W, cout, k, k, k).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(B, cout, D * k, H * k, W * k)
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1, 1)
+    return y

@@ -122,7 +122,15 @@ class MambaEncoder(nn.Module):
     def forward_features(self, x):
         outs = []
         for i in range(4):
-            x = self.downsample_layers[i](x)
+            if i == 0:
+                x = self.downsample_layers[0](x)
+            else:                                           # InstanceNorm -> conv k2 s2 (a GEMM on 2x2x2 patches)
+                norm, conv = self.downsample_layers[i][0], self.downsample_layers[i][1]
+                x = fused_norm.instance_norm_act(x, act="none", eps=norm.eps)
+                if all(s % 2 == 0 for s in x.shape[2:]):
+                    x = fused_norm.patch_conv3d(x, conv.weight, conv.bias, 2)
+                else:
+                    x = conv(x)
             x = self.gscs[i](x)
             x = self.stages[i](x)
             if i in self.out_indices:

@@ -63,10 +63,17 @@ class ConvOnly(nn.Sequential):
                              padding=pad, bias=bias)
         self.add_module("conv", conv)
         self._pointwise = (not transposed) and kernel_size == 1 and stride == 1
+        self._patch = kernel_size == stride and kernel_size > 1 and pad == 0      # non-overlapping: a GEMM
+        self._k = kernel_size
+        self._transposed = transposed
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self._pointwise:
             return fused_norm.pointwise_conv3d(x, self.conv.weight, self.conv.bias)
+        if self._patch and all(s % self._k == 0 for s in x.shape[2:]):
+            if self._transposed:
+                return fused_norm.patch_conv_transpose3d(x, self.conv.weight, self.conv.bias, self._k)
+            return fused_norm.patch_conv3d(x, self.conv.weight, self.conv.bias, self._k)
         return self.conv(x)
 
 
