@@ -1,0 +1,173 @@
+"""Dense 3x3x3 (stride 1, "same") convolutions of the SegMamba stem: an autotuned dispatcher over MIOpen.
+
+SURVEY.md §7 step 6: the stem starts on MIOpen.  Profiling (profiles/r01_probe_convs.log,
+profiles/r01_bench_step_kernels_v3.txt) showed that MIOpen's bf16 3-D solvers are very uneven on these shapes:
+
+  * forward at 48 channels runs at 200-260 TF/s, but 96 -> 96 @64^3 only at 54 TF/s;
+  * backward-data for 48 -> 48 @128^3 takes 12.5 ms while the *forward* kernel on the same shape takes 2.5 ms;
+  * one layer (decoder2.conv1, 96 -> 48 @128^3) picks solvers that need 75 ms (data) + 530 ms (weights) - more than
+    half of a whole training step.
+
+Every quantity below is mathematically the same convolution, only routed to a different library call:
+
+  fwd    y  = conv(x, W)                      or  sum over 48-channel input blocks / concat over output blocks
+  dgrad  dx = conv_bwd_data(dy, W)            or  conv(dy, flip(W)^T)         (a forward convolution)
+  wgrad  dW = conv_bwd_weight(x, dy)          or  per input/output channel block
+
+The first time a (kind, shape, dtype) is seen each candidate is timed once on the real tensors and the fastest is
+cached (what MIOpen's own "find" does, one level up).  Hand-written implicit-GEMM kernels for these layers are the
+first item of the "next" list; this module is their insertion point.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, List, Tuple
+
+import torch
+import torch.nn.functional as F
+
+_BLOCK = 48                      # MIOpen's fast 3-D bf16 kernels on gfx950 are the 48-channel ones
+_cache: Dict[tuple, int] = {}
+_TUNE = os.environ.get("SEGM_CONV_AUTOTUNE", "1") == "1"
+
+
+def _time(fn: Callable[[], torch.Tensor]) -> float:
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
+def _pick(key: tuple, cands: List[Callable[[], torch.Tensor]]) -> torch.Tensor:
+    if len(cands) == 1 or not _TUNE or not torch.cuda.is_available():
+        return cands[0]()
+    i = _cache.get(key)
+    if i is None:
+        times = []
+        for c in cands:
+            try:
+                times.append(_time(c))
+            except RuntimeError:
+                times.append(float("inf"))
+        i = min(range(len(cands)), key=lambda j: times[j])
+        _cache[key] = i
+        if os.environ.get("SEGM_CONV_VERBOSE"):
+            print(f"[conv3d autotune] {key}: " + ", ".join(f"{t:.2f} ms" for t in times) + f" -> {i}", flush=True)
+    return cands[i]()
+
+
+def _blocks(c: int) -> List[slice]:
+    return [slice(i, min(i + _BLOCK, c)) for i in range(0, c, _BLOCK)]
+
+
+def _fwd_native(x, w, pad):
+    return F.conv3d(x, w, None, 1, pad)
+
+
+def _fwd_blocked(x, w, pad):
+    outs = []
+    for ob in _blocks(w.shape[0]):
+        acc = None
+        for ib in _blocks(w.shape[1]):
+            y = F.conv3d(x[:, ib], w[ob, ib], None, 1, pad)
+            acc = y if acc is None else acc + y
+        outs.append(acc)
+    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+
+
+def _dgrad_native(dy, w, x, pad):
+    return torch.ops.aten.convolution_backward(dy, x, w, None,
+                                                [1, 1, 1], [pad] * 3, [1, 1, 1], False, [0, 0, 0], 1,
+                                                [True, False, False])[0]
+
+
+def _flipT(w):
+    return w.flip(2, 3, 4).transpose(0, 1).contiguous()
+
+
+def _dgrad_as_fwd(dy, w, x, pad):
+    return F.conv3d(dy, _flipT(w), None, 1, pad)                 # valid for stride 1 and pad == k // 2
+
+
+def _dgrad_as_fwd_blocked(dy, w, x, pad):
+    return _fwd_blocked(dy, _flipT(w), pad)
+
+
+def _wgrad_native(x, dy, w, pad):
+    return torch.ops.aten.convolution_backward(dy, x, w, None,
+                                                [1, 1, 1], [pad] * 3, [1, 1, 1], False, [0, 0, 0], 1,
+                                                [False, True, False])[1]
+
+
+def _wgrad_blocked(x, dy, w, pad):
+    dw = torch.empty_like(w, memory_format=torch.contiguous_format)
+    for ob in _blocks(w.shape[0]):
+        for ib in _blocks(w.shape[1]):
+            dw[ob, ib] = _wgrad_native(x[:, ib].contiguous(), dy[:, ob].contiguous(), w[ob, ib].contiguous(), pad)
+    return dw
+
+
+class _ConvSame(torch.autograd.Function):
+    """stride-1 "same" convolution, odd kernel, no bias; tensors already in the compute dtype."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        pad = w.shape[2] // 2
+        ctx.save_for_backward(x, w)
+        key = ("fwd", tuple(x.shape), tuple(w.shape), x.dtype)
+        cands = [lambda: _fwd_native(x, w, pad)]
+        if max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0:
+            cands.append(lambda: _fwd_blocked(x, w, pad))
+        return _pick(key, cands)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        pad = w.shape[2] // 2
+        dy = dy.contiguous()
+        dx = dw = None
+        blockable = max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0
+        if ctx.needs_input_grad[0]:
+            cands = [lambda: _dgrad_native(dy, w, x, pad), lambda: _dgrad_as_fwd(dy, w, x, pad)]
+            if blockable:
+                cands.append(lambda: _dgrad_as_fwd_blocked(dy, w, x, pad))
+            dx = _pick(("dgrad", tuple(x.shape), tuple(w.shape), x.dtype), cands)
+        if ctx.needs_input_grad[1]:
+            cands = [lambda: _wgrad_native(x, dy, w, pad)]
+            if blockable:
+                cands.append(lambda: _wgrad_blocked(x, dy, w, pad))
+            dw = _pick(("wgrad", tuple(x.shape), tuple(w.shape), x.dtype), cands)
+        return dx, dw
+
+
+def conv3d_same(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """Conv3d(kernel k odd, stride 1, padding k//2).  Follows autocast like `F.conv3d` does."""
+    if not x.is_cuda:
+        return F.conv3d(x, weight, bias, 1, weight.shape[2] // 2)
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype("cuda")
+        x, weight = x.to(dt), weight.to(dt)
+        bias = bias.to(dt) if bias is not None else None
+    elif weight.dtype != x.dtype:
+        weight = weight.to(x.dtype)
+    y = _ConvSame.apply(x, weight)
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1, 1)
+    return y
+
+
+def conv3d_same_cat(xs: Tuple[torch.Tensor, ...], weight: torch.Tensor) -> torch.Tensor:
+    """conv3d_same(torch.cat(xs, 1), weight) without materialising the concatenation: the convolution is linear in
+    its input channels, so it is the sum of convolutions of the parts with the matching weight slices.  (The UNETR
+    decoder convolves cat(upsampled, skip), unetr_block.py:82-84; MIOpen's 96 -> 48 @128^3 solver is the 600 ms one.)"""
+    out, c0 = None, 0
+    for x in xs:
+        c = x.shape[1]
+        y = conv3d_same(x, weight[:, c0:c0 + c])
+        out = y if out is None else out + y
+        c0 += c
+    return out

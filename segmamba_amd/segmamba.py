@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import fused_norm
+from .conv3d import conv3d_same
 from .mamba_simple import Mamba
 from .unet_blocks import UnetOutBlock, UnetrBasicBlock, UnetrUpBlock
 
@@ -81,8 +82,9 @@ class GSC(nn.Module):
         self.nonliner4 = nn.ReLU()
 
     def forward(self, x):
-        x1 = fused_norm.instance_norm_act(self.proj(x), act="relu", eps=self.norm.eps)
-        x1 = fused_norm.instance_norm_act(self.proj2(x1), act="relu", eps=self.norm2.eps)
+        x1 = fused_norm.instance_norm_act(conv3d_same(x, self.proj.weight, self.proj.bias), act="relu", eps=self.norm.eps)
+        x1 = fused_norm.instance_norm_act(conv3d_same(x1, self.proj2.weight, self.proj2.bias), act="relu",
+                                          eps=self.norm2.eps)
         x2 = fused_norm.instance_norm_act(fused_norm.pointwise_conv3d(x, self.proj3.weight, self.proj3.bias),
                                           act="relu", eps=self.norm3.eps)
         y = fused_norm.instance_norm_act(fused_norm.pointwise_conv3d(x1 + x2, self.proj4.weight, self.proj4.bias),

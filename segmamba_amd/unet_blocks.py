@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import fused_norm
+from .conv3d import conv3d_same, conv3d_same_cat
 
 
 def _same_padding(kernel_size: int, stride: int) -> int:
@@ -66,10 +67,27 @@ class ConvOnly(nn.Sequential):
         self._patch = kernel_size == stride and kernel_size > 1 and pad == 0      # non-overlapping: a GEMM
         self._k = kernel_size
         self._transposed = transposed
+        self._same = (not transposed) and stride == 1 and kernel_size == 3
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x) -> torch.Tensor:
+        """`x` may be a tuple of tensors standing for their channel concatenation (never materialised)."""
+        if isinstance(x, (tuple, list)):
+            if self._same and self.conv.bias is None:
+                return conv3d_same_cat(tuple(x), self.conv.weight)
+            if self._pointwise:
+                out, c0 = None, 0
+                for part in x:
+                    c = part.shape[1]
+                    y = fused_norm.pointwise_conv3d(part, self.conv.weight[:, c0:c0 + c],
+                                                    self.conv.bias if c0 == 0 else None)
+                    out = y if out is None else out + y
+                    c0 += c
+                return out
+            x = torch.cat(tuple(x), dim=1)
         if self._pointwise:
             return fused_norm.pointwise_conv3d(x, self.conv.weight, self.conv.bias)
+        if self._same:
+            return conv3d_same(x, self.conv.weight, self.conv.bias)
         if self._patch and all(s % self._k == 0 for s in x.shape[2:]):
             if self._transposed:
                 return fused_norm.patch_conv_transpose3d(x, self.conv.weight, self.conv.bias, self._k)
@@ -98,14 +116,15 @@ class UnetResBlock(nn.Module):
             self.conv3 = ConvOnly(in_channels, out_channels, 1, stride)
             self.norm3 = nn.InstanceNorm3d(out_channels)
 
-    def forward(self, inp: torch.Tensor) -> torch.Tensor:
+    def forward(self, inp) -> torch.Tensor:
+        """`inp`: a tensor, or a tuple of tensors meaning their channel concatenation (decoder: (upsampled, skip))."""
         out = self.conv1(inp)
         out = fused_norm.instance_norm_act(out, act="leaky_relu", slope=self.NEG_SLOPE, eps=self.norm1.eps)
         out = self.conv2(out)
         if self.downsample:
             residual = fused_norm.instance_norm_act(self.conv3(inp), act="none", eps=self.norm3.eps)
         else:
-            residual = inp
+            residual = torch.cat(tuple(inp), dim=1) if isinstance(inp, (tuple, list)) else inp
         # IN(out) + residual -> LeakyReLU, one pass
         return fused_norm.instance_norm_act(out, act="leaky_relu", slope=self.NEG_SLOPE, eps=self.norm2.eps,
                                             residual=residual)
@@ -137,8 +156,7 @@ class UnetrUpBlock(nn.Module):
 
     def forward(self, inp: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
         out = self.transp_conv(inp)
-        out = torch.cat((out, skip), dim=1)
-        return self.conv_block(out)
+        return self.conv_block((out, skip))               # cat(out, skip) is never materialised
 
 
 class UnetOutBlock(nn.Module):
