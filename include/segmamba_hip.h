@@ -177,6 +177,34 @@ int segm_causal_conv1d_fwd(const segm_conv1d_args* args);
 int segm_causal_conv1d_bwd(const segm_conv1d_args* args);
 size_t segm_causal_conv1d_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t width, int64_t seqlen);
 
+/* ------------------------------------------------------------------------------------------------
+ * Weight gradient of a 3x3x3 stride-1 pad-1 convolution (the stem / decoder convolutions of SegMamba).
+ * The reference gets this from cuDNN through torch.nn.Conv3d (monai/networks/blocks/convolutions.py:143-151,
+ * model_segmamba/segmamba.py:95-99); on MI355X MIOpen's im2col solver for the 48-channel 128^3 layers is the single
+ * largest item of a training step, so this one operator has a hand-written MFMA kernel.
+ *
+ *   dW[co, ci, kz, ky, kx] = sum_{b,z,y,x} dY[b, co, z, y, x] * X[b, ci, z+kz-1, y+ky-1, x+kx-1]
+ *
+ * x, dy: bf16, logical (batch, channel, depth, height, width), W contiguous, every other stride a multiple of 8
+ * elements, 16-byte aligned bases (channel slices of NCDHW tensors qualify).  cin, cout multiples of 48, width a
+ * multiple of 32.  dw: contiguous (cout, cin, 3, 3, 3), fp32 or bf16, OVERWRITTEN.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_conv3d_wgrad_args {
+    int32_t batch, cin, cout, depth, height, width;
+    int32_t dtype;            /* of x and dy: SEGM_BF16 */
+    int32_t dw_dtype;         /* SEGM_BF16 or SEGM_F32  */
+    const void* x;   int64_t x_stride_b, x_stride_c, x_stride_z, x_stride_y;
+    const void* dy;  int64_t dy_stride_b, dy_stride_c, dy_stride_z, dy_stride_y;
+    void* dw;
+    void* workspace;          /* segm_conv3d_k3_wgrad_workspace_bytes() */
+    size_t workspace_bytes;
+    void* stream;
+} segm_conv3d_wgrad_args;
+
+int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* args);
+size_t segm_conv3d_k3_wgrad_workspace_bytes(int32_t batch, int32_t cin, int32_t cout, int32_t depth, int32_t height,
+                                            int32_t width);
+
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);
 const char* segm_status_string(int status);

@@ -13,6 +13,7 @@ Every quantity below is mathematically the same convolution, only routed to a di
   fwd    y  = conv(x, W)                      or  sum over 48-channel input blocks / concat over output blocks
   dgrad  dx = conv_bwd_data(dy, W)            or  conv(dy, flip(W)^T)         (a forward convolution)
   wgrad  dW = conv_bwd_weight(x, dy)          or  per input/output channel block
+                                              or  segm_conv3d_k3_wgrad, the library's own MFMA kernel
 
 The first time a (kind, shape, dtype) is seen each candidate is timed once on the real tensors and the fastest is
 cached (what MIOpen's own "find" does, one level up).  Hand-written implicit-GEMM kernels for these layers are the
@@ -111,6 +112,18 @@ def _wgrad_blocked(x, dy, w, pad):
     return dw
 
 
+def _wgrad_mfma(x, dy, w, pad):
+    """segm_conv3d_k3_wgrad: the hand-written MFMA weight-gradient kernel (csrc/conv3d_wgrad.hip)."""
+    from . import lib as L, ops_raw
+    return ops_raw.conv3d_k3_wgrad(L.get_lib(), x, dy, w.dtype)
+
+
+def _mfma_wgrad_ok(x, dy, w) -> bool:
+    from . import ops_raw
+    return w.shape[2:] == (3, 3, 3) and w.dtype in (torch.bfloat16, torch.float32) and \
+        ops_raw.conv3d_k3_wgrad_supported(x, dy)
+
+
 class _ConvSame(torch.autograd.Function):
     """stride-1 "same" convolution, odd kernel, no bias; tensors already in the compute dtype."""
 
@@ -140,6 +153,8 @@ class _ConvSame(torch.autograd.Function):
             cands = [lambda: _wgrad_native(x, dy, w, pad)]
             if blockable:
                 cands.append(lambda: _wgrad_blocked(x, dy, w, pad))
+            if _mfma_wgrad_ok(x, dy, w):
+                cands.append(lambda: _wgrad_mfma(x, dy, w, pad))
             dw = _pick(("wgrad", tuple(x.shape), tuple(w.shape), x.dtype), cands)
         return dx, dw
 

@@ -14,6 +14,7 @@
 // The monoid (a1, b1) o (a0, b0) = (a1 a0, a1 b0 + b1) is the reference's SSMScanOp
 // (selective_scan_common.h:110-115); the product of a's over a chunk is exp(A * sum of delta), so only the
 // sum is stored.  All state / accumulation is fp32; I/O is fp32, fp16 or bf16.
+#include <stdlib.h>
 #include <string.h>
 
 #include "scan_common.h"
@@ -362,6 +363,8 @@ Geom make_geom(int batch, int dim, int nstate, int64_t L, int chunk) {   // L < 
 }
 
 int32_t default_chunk(int32_t batch, int32_t dim, int64_t L) {
+    static int forced = [] { const char* e = getenv("SEGM_CHUNK"); return e ? atoi(e) : 0; }();   // experiments only
+    if (forced >= kCkpt && forced % kCkpt == 0) return forced;
     // aim at ~3 waves per SIMD (256 CUs x 4 SIMDs) while keeping <= 4096 chunks for the carry kernel
     const double lanes_steps = (double)batch * (double)dim * (double)L;
     const int64_t c = (int64_t)(lanes_steps / (64.0 * 3072.0));
@@ -382,6 +385,13 @@ static FwdWs fwd_ws_layout(int batch, int dim, int nstate, int64_t L, int chunk)
     return w;
 }
 
+// sub-tile length (steps whose rows are prefetched together) of the apply kernel: 8, or 4 (fewer live registers,
+// one more wave per SIMD, twice the barriers).  SEGM_APPLY_TS overrides for experiments.
+static int apply_subtile() {
+    static int ts = [] { const char* e = getenv("SEGM_APPLY_TS"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    return ts;
+}
+
 template <typename T, int NS, int RW>
 static int launch_fwd_rw(const ScanDev& P, hipStream_t stream) {
     constexpr int TS = 8;
@@ -389,7 +399,10 @@ static int launch_fwd_rw(const ScanDev& P, hipStream_t stream) {
     const unsigned nblocks = (unsigned)((gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL((scan_fwd_agg_kernel<T, NS, TS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
     launch_scan_carry(P, false, P.agg_sd, P.agg_h, P.carry, stream);
-    hipLaunchKernelGGL((scan_fwd_apply_kernel<T, NS, TS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+    if (apply_subtile() == 4)
+        hipLaunchKernelGGL((scan_fwd_apply_kernel<T, NS, 4, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+    else
+        hipLaunchKernelGGL((scan_fwd_apply_kernel<T, NS, TS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
     return (int)hipGetLastError();
 }
 

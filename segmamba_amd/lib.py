@@ -79,10 +79,23 @@ class Conv1dArgs(C.Structure):
     ]
 
 
+class Conv3dWgradArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("depth", C.c_int32), ("height", C.c_int32),
+        ("width", C.c_int32), ("dtype", C.c_int32), ("dw_dtype", C.c_int32),
+        ("x", C.c_void_p), ("x_stride_b", C.c_int64), ("x_stride_c", C.c_int64), ("x_stride_z", C.c_int64),
+        ("x_stride_y", C.c_int64),
+        ("dy", C.c_void_p), ("dy_stride_b", C.c_int64), ("dy_stride_c", C.c_int64), ("dy_stride_z", C.c_int64),
+        ("dy_stride_y", C.c_int64),
+        ("dw", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+    ]
+
+
 EXPORTS = (
     "segm_selective_scan_fwd", "segm_selective_scan_fwd_workspace_bytes", "segm_selective_scan_ckpt_bytes",
     "segm_selective_scan_default_chunk", "segm_selective_scan_bwd", "segm_selective_scan_bwd_workspace_bytes",
     "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
+    "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -110,6 +123,8 @@ class SegmLib:
         sig("segm_causal_conv1d_fwd", [C.POINTER(Conv1dArgs)], C.c_int)
         sig("segm_causal_conv1d_bwd", [C.POINTER(Conv1dArgs)], C.c_int)
         sig("segm_causal_conv1d_bwd_workspace_bytes", [C.c_int32, C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
+        sig("segm_conv3d_k3_wgrad", [C.POINTER(Conv3dWgradArgs)], C.c_int)
+        sig("segm_conv3d_k3_wgrad_workspace_bytes", [C.c_int32] * 6, C.c_size_t)
         sig("segm_abi_version", [], C.c_int)
         sig("segm_status_string", [C.c_int], C.c_char_p)
 

@@ -216,3 +216,42 @@ def conv1d_bwd(lib: L.SegmLib, x, weight, bias, dout, silu=False, *, channel_las
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
     lib.check(lib.dll.segm_causal_conv1d_bwd(a), "causal_conv1d_bwd")
     return dx, dweight, dbias
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 3x3x3 convolution weight gradient (stem / decoder)
+# ---------------------------------------------------------------------------------------------------------
+def conv3d_k3_wgrad_supported(x: torch.Tensor, dy: torch.Tensor) -> bool:
+    """Shapes / layouts the MFMA weight-gradient kernel takes (everything else stays on MIOpen)."""
+    if x.dim() != 5 or dy.dim() != 5 or x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
+        return False
+    if x.shape[0] != dy.shape[0] or x.shape[2:] != dy.shape[2:]:
+        return False
+    if x.shape[1] % 48 or dy.shape[1] % 48 or x.shape[4] % 32:
+        return False
+    for t in (x, dy):
+        if t.stride(4) != 1 or any(t.stride(i) % 8 for i in range(4)) or t.data_ptr() % 16:
+            return False
+    return True
+
+
+def conv3d_k3_wgrad(lib: L.SegmLib, x: torch.Tensor, dy: torch.Tensor, out_dtype=torch.bfloat16) -> torch.Tensor:
+    """dW (Cout, Cin, 3, 3, 3) of a stride-1 pad-1 3x3x3 convolution; x (B, Cin, D, H, W), dy (B, Cout, D, H, W), bf16."""
+    if not conv3d_k3_wgrad_supported(x, dy):
+        raise RuntimeError("conv3d_k3_wgrad: unsupported shape / dtype / layout")
+    B, cin, D, H, W = x.shape
+    cout = dy.shape[1]
+    a = L.Conv3dWgradArgs()
+    a.batch, a.cin, a.cout, a.depth, a.height, a.width = B, cin, cout, D, H, W
+    a.dtype = L.SEGM_BF16
+    a.dw_dtype = L.dtype_code(torch.empty(0, dtype=out_dtype))
+    a.x, a.dy = x.data_ptr(), dy.data_ptr()
+    a.x_stride_b, a.x_stride_c, a.x_stride_z, a.x_stride_y = x.stride()[:4]
+    a.dy_stride_b, a.dy_stride_c, a.dy_stride_z, a.dy_stride_y = dy.stride()[:4]
+    dw = torch.empty(cout, cin, 3, 3, 3, dtype=out_dtype, device=x.device)
+    ws_bytes = lib.dll.segm_conv3d_k3_wgrad_workspace_bytes(B, cin, cout, D, H, W)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    a.dw, a.workspace, a.workspace_bytes = dw.data_ptr(), ws.data_ptr(), ws_bytes
+    a.stream = L.stream_handle(x)
+    lib.check(lib.dll.segm_conv3d_k3_wgrad(a), "conv3d_k3_wgrad")
+    return dw

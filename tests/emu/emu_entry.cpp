@@ -4,3 +4,4 @@
 #include "../../segmamba_amd/csrc/scan_fwd.hip"
 #include "../../segmamba_amd/csrc/conv1d.hip"
 #include "../../segmamba_amd/csrc/scan_bwd.hip"
+#include "../../segmamba_amd/csrc/conv3d_wgrad.hip"

@@ -145,3 +145,36 @@ static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4);
 static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 #define __builtin_amdgcn_readfirstlane(x) (x)   /* only used on values that are uniform over the wave */
+
+// ---- MFMA / funnel-shift emulation (conv3d_wgrad.hip) -------------------------------------------------------------
+static inline uint32_t hipemu_alignbyte(uint32_t hi, uint32_t lo, uint32_t n) {
+    uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (uint32_t)(v >> (8 * (n & 3)));
+}
+#define __builtin_amdgcn_alignbyte hipemu_alignbyte
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+namespace hipemu { extern std::vector<unsigned char>* g_wave_big; }   // 64 lanes x 64 bytes per wave
+// D = A * B + C with A[i = l & 15][k = 8 (l >> 4) .. +7], B[k][j = l & 15], D[row = 4 (l >> 4) + r][col = l & 15]
+static inline hipemu_f32x4 hipemu_mfma_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x4 c, int, int, int) {
+    const unsigned lane = hipemu::t_linear % 64, wave = hipemu::t_linear / 64;
+    unsigned char* buf = hipemu::g_wave_big->data() + (size_t)wave * 64 * 64;
+    memcpy(buf + lane * 64, &a, 16);
+    memcpy(buf + lane * 64 + 16, &b, 16);
+    hipemu::sync_wave();
+    hipemu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r, col = lane & 15;
+        float s = 0.f;
+        for (int k = 0; k < 32; ++k) {
+            __bf16 av, bv;
+            memcpy(&av, buf + (row + 16 * (k / 8)) * 64 + 2 * (k % 8), 2);
+            memcpy(&bv, buf + (col + 16 * (k / 8)) * 64 + 16 + 2 * (k % 8), 2);
+            s += (float)av * (float)bv;
+        }
+        d[r] += s;
+    }
+    hipemu::sync_wave();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_16x16x32_bf16

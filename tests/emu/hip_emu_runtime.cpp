@@ -8,6 +8,7 @@ thread_local dim3 gridDim;
 
 namespace hipemu {
 BlockCtx* g_ctx = nullptr;
+std::vector<unsigned char>* g_wave_big = nullptr;
 thread_local unsigned t_linear = 0;
 
 struct ThreadArg { unsigned tid; dim3 grid, block; LaunchArgsBase* body; };
@@ -39,6 +40,8 @@ void launch(dim3 grid, dim3 block, LaunchArgsBase* body) {
     ctx.wave_bar.resize(nw);
     for (unsigned w = 0; w < nw; ++w) pthread_barrier_init(&ctx.wave_bar[w], nullptr, std::min(64u, n - w * 64));
     ctx.wave_buf.assign(nw * 64, 0);
+    std::vector<unsigned char> big((size_t)nw * 64 * 64, 0);
+    g_wave_big = &big;
     g_ctx = &ctx;
     std::vector<pthread_t> th(n);
     std::vector<ThreadArg> args(n);
@@ -49,5 +52,6 @@ void launch(dim3 grid, dim3 block, LaunchArgsBase* body) {
     pthread_barrier_destroy(&ctx.block_bar);
     for (unsigned w = 0; w < nw; ++w) pthread_barrier_destroy(&ctx.wave_bar[w]);
     g_ctx = nullptr;
+    g_wave_big = nullptr;
 }
 }  // namespace hipemu

@@ -112,3 +112,38 @@ def test_reference_layout_inner_fn_on_emulated_kernels(emu, monkeypatch):
     for k, gk in (("xz", "dxz"), ("conv_w", "dconv_w"), ("conv_b", "dconv_b"), ("x_proj_w", "dx_proj_w"),
                   ("dt_proj_w", "ddt_proj_w"), ("A", "dA"), ("D", "dD"), ("delta_bias", "ddelta_bias")):
         H.assert_close(t[k].grad, f[gk], 1e-3, 1e-3 * max(1.0, float(f[gk].abs().max())), gk)
+
+
+def _wgrad_reference(x, dy):
+    w = torch.zeros(dy.shape[1], x.shape[1], 3, 3, 3, requires_grad=True)
+    torch.nn.functional.conv3d(x.float(), w, None, 1, 1).backward(dy.float())
+    return w.grad
+
+
+@pytest.mark.parametrize("shape", [(1, 48, 48, 3, 4, 32), (2, 96, 48, 2, 3, 64)])
+def test_conv3d_k3_wgrad_emulated(emu, shape):
+    """MFMA weight-gradient kernel (fragment layout, halo / funnel-shift x taps, z / y border masking, slab reduce)."""
+    B, cin, cout, D, H_, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, cin, D, H_, W, generator=g).bfloat16()
+    dy = torch.randn(B, cout, D, H_, W, generator=g).bfloat16()
+    ref = _wgrad_reference(x, dy)
+    dw = ops_raw.conv3d_k3_wgrad(emu, x, dy, torch.float32)
+    assert (dw - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-4
+    dwb = ops_raw.conv3d_k3_wgrad(emu, x, dy, torch.bfloat16)
+    assert torch.equal(dwb, dw.bfloat16())
+
+
+def test_conv3d_k3_wgrad_channel_slices_and_errors_emulated(emu):
+    g = torch.Generator().manual_seed(5)
+    xb = torch.randn(1, 96, 2, 2, 32, generator=g).bfloat16()
+    dyb = torch.randn(1, 96, 2, 2, 32, generator=g).bfloat16()
+    xs, dys = xb[:, 48:], dyb[:, :48]                       # views: the cat-free decoder passes channel slices
+    ref = _wgrad_reference(xs, dys)
+    dw = ops_raw.conv3d_k3_wgrad(emu, xs, dys, torch.float32)
+    assert (dw - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-4
+    assert not ops_raw.conv3d_k3_wgrad_supported(xb[:, :40], dyb[:, :48])          # cin % 48
+    assert not ops_raw.conv3d_k3_wgrad_supported(xb[..., :16], dyb[..., :16])      # width % 32
+    assert not ops_raw.conv3d_k3_wgrad_supported(xs.float(), dys.float())          # dtype
+    with pytest.raises(RuntimeError):
+        ops_raw.conv3d_k3_wgrad(emu, xb[:, :40], dyb[:, :48])

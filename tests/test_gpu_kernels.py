@@ -202,3 +202,53 @@ def test_error_behaviour(hip):
     c["delta"] = c["delta"][:, :, :8]
     with pytest.raises(RuntimeError):
         H.run_scan(hip, c, DEV, False, backward=False)                                    # shape mismatch
+
+
+# ---- 3x3x3 weight gradient (stem / decoder convolutions): against aten.convolution_backward -----------------------
+def _aten_wgrad(x, dy):
+    w = torch.empty(dy.shape[1], x.shape[1], 3, 3, 3, device=x.device, dtype=x.dtype)
+    return torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
+                                               [False, True, False])[1]
+
+
+@pytest.mark.parametrize("shape", [(1, 48, 48, 8, 8, 32), (2, 48, 96, 5, 7, 64), (2, 96, 48, 16, 16, 32),
+                                   (1, 48, 48, 32, 32, 128)])
+def test_conv3d_k3_wgrad_matches_fp32_convolution_backward(hip, shape):
+    B, cin, cout, D, H_, W = shape
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(B, cin, D, H_, W, device=DEV, generator=g).bfloat16()
+    dy = torch.randn(B, cout, D, H_, W, device=DEV, generator=g).bfloat16()
+    ref = _aten_wgrad(x.float(), dy.float())                  # fp32 reference on the same bf16-rounded inputs
+    dw = ops_raw.conv3d_k3_wgrad(hip, x, dy, torch.float32)
+    # products of bf16 values are exact in fp32; only the fp32 summation order differs
+    assert (dw - ref).abs().max() <= 2e-5 * ref.abs().max() * max(1.0, (B * D * H_ * W / 4096) ** 0.5)
+    assert torch.equal(ops_raw.conv3d_k3_wgrad(hip, x, dy, torch.float32), dw)       # deterministic
+    assert torch.equal(ops_raw.conv3d_k3_wgrad(hip, x, dy, torch.bfloat16), dw.bfloat16())
+
+
+def test_conv3d_k3_wgrad_channel_slices(hip):
+    g = torch.Generator(device=DEV).manual_seed(11)
+    xb = torch.randn(2, 96, 8, 8, 64, device=DEV, generator=g).bfloat16()
+    dyb = torch.randn(2, 96, 8, 8, 64, device=DEV, generator=g).bfloat16()
+    xs, dys = xb[:, 48:], dyb[:, :48]
+    ref = _aten_wgrad(xs.float().contiguous(), dys.float().contiguous())
+    dw = ops_raw.conv3d_k3_wgrad(hip, xs, dys, torch.float32)
+    assert (dw - ref).abs().max() <= 2e-5 * ref.abs().max()
+
+
+def test_conv3d_same_autograd_with_mfma_wgrad(hip, monkeypatch):
+    """the dispatcher's backward with the library kernel forced in equals torch's own conv3d backward."""
+    from segmamba_amd import conv3d as C3
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(1, 48, 8, 16, 32, device=DEV, generator=g).bfloat16().requires_grad_()
+    w = (0.05 * torch.randn(48, 48, 3, 3, 3, device=DEV, generator=g)).bfloat16().requires_grad_()
+    dy = torch.randn(1, 48, 8, 16, 32, device=DEV, generator=g).bfloat16()
+    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
+    y = C3.conv3d_same(x, w)
+    gx, gw = torch.autograd.grad(y, (x, w), dy)
+    x2, w2 = x.detach().float().requires_grad_(), w.detach().float().requires_grad_()
+    y2 = torch.nn.functional.conv3d(x2, w2, None, 1, 1)
+    gx2, gw2 = torch.autograd.grad(y2, (x2, w2), dy.float())
+    assert (y.float() - y2).abs().max() <= 2e-2 * y2.abs().max()
+    assert (gw.float() - gw2).abs().max() <= 1e-2 * gw2.abs().max()
+    assert (gx.float() - gx2).abs().max() <= 2e-2 * gx2.abs().max()
