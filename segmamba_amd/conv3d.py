@@ -115,13 +115,15 @@ def _wgrad_blocked(x, dy, w, pad):
 def _wgrad_mfma(x, dy, w, pad):
     """segm_conv3d_k3_wgrad: the hand-written MFMA weight-gradient kernel (csrc/conv3d_wgrad.hip)."""
     from . import lib as L, ops_raw
+    if not ops_raw.conv3d_k3_wgrad_supported(x, dy):
+        x = x.contiguous()                       # e.g. the permuted (channel-last) outputs of the Mamba encoder
     return ops_raw.conv3d_k3_wgrad(L.get_lib(), x, dy, w.dtype)
 
 
 def _mfma_wgrad_ok(x, dy, w) -> bool:
-    from . import ops_raw
-    return w.shape[2:] == (3, 3, 3) and w.dtype in (torch.bfloat16, torch.float32) and \
-        ops_raw.conv3d_k3_wgrad_supported(x, dy)
+    if w.shape[2:] != (3, 3, 3) or w.dtype not in (torch.bfloat16, torch.float32) or x.dtype != torch.bfloat16:
+        return False
+    return x.shape[1] % 48 == 0 and dy.shape[1] % 48 == 0 and x.shape[4] % 32 == 0 and x.shape[0] == dy.shape[0]
 
 
 class _ConvSame(torch.autograd.Function):
@@ -153,9 +155,10 @@ class _ConvSame(torch.autograd.Function):
             cands = [lambda: _wgrad_native(x, dy, w, pad)]
             if blockable:
                 cands.append(lambda: _wgrad_blocked(x, dy, w, pad))
-            if _mfma_wgrad_ok(x, dy, w):
+            mfma = _mfma_wgrad_ok(x, dy, w)
+            if mfma:
                 cands.append(lambda: _wgrad_mfma(x, dy, w, pad))
-            dw = _pick(("wgrad", tuple(x.shape), tuple(w.shape), x.dtype), cands)
+            dw = _pick(("wgrad", tuple(x.shape), tuple(w.shape), x.dtype, mfma), cands)
         return dx, dw
 
 

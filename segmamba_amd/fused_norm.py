@@ -18,6 +18,8 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+from . import linear
+
 
 def instance_norm_act(x: torch.Tensor, act: str = "none", slope: float = 0.01, eps: float = 1e-5,
                       residual: torch.Tensor | None = None) -> torch.Tensor:
@@ -42,12 +44,12 @@ def pointwise_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor |
 
     x (B, C, D, H, W), weight (Cout, C, 1, 1, 1).  MIOpen's conv path is badly tuned for these shapes in bf16 (the
     48 -> 4 output head's weight-gradient kernel alone took 533 ms of a 983 ms training step, profiles/r01_*):
-    a (B*D*H*W, C) x (C, Cout) matrix product through the BLAS path takes well under a millisecond.  With
-    channels_last_3d activations the permutes below are views, otherwise they cost one transposing copy each way.
+    W (Cout, C) x (C, D*H*W) per volume through the BLAS path takes well under a millisecond.  The GEMM reads x in
+    whichever memory order it has (channel-first or channel-last) and writes channel-first; the weight gradient is a
+    split-K product (linear.py).
     """
     cout, cin = weight.shape[0], weight.shape[1]
-    y = F.linear(x.permute(0, 2, 3, 4, 1), weight.reshape(cout, cin), bias)       # (B, D, H, W, Cout)
-    return y.permute(0, 4, 1, 2, 3)
+    return linear.pointwise(x, weight.reshape(cout, cin), bias)
 
 
 def patch_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, k: int) -> torch.Tensor:
@@ -56,8 +58,9 @@ def patch_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | Non
     B, C, D, H, W = x.shape
     cout = weight.shape[0]
     xp = x.reshape(B, C, D // k, k, H // k, k, W // k, k).permute(0, 2, 4, 6, 1, 3, 5, 7)     # (B, d, h, w, C, k, k, k)
-    y = F.linear(xp.reshape(B, D // k, H // k, W // k, C * k ** 3), weight.reshape(cout, C * k ** 3), bias)
-    return y.permute(0, 4, 1, 2, 3)
+    xp = xp.reshape(B, (D // k) * (H // k) * (W // k), C * k ** 3)                             # the one gather copy
+    y = linear.pointwise(xp.transpose(1, 2), weight.reshape(cout, C * k ** 3), bias)          # (B, Cout, d*h*w)
+    return y.reshape(B, cout, D // k, H // k, W // k)
 
 
 def patch_conv_transpose3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, k: int) -> torch.Tensor:
@@ -67,8 +70,8 @@ def patch_conv_transpose3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Te
     profiles/r01_bench_step_kernels_v2.txt.)"""
     B, C, D, H, W = x.shape
     cout = weight.shape[1]
-    y = F.linear(x.permute(0, 2, 3, 4, 1), weight.reshape(C, cout * k ** 3).t())              # (B, D, H, W, Cout*k^3)
-    y = y.reshape(B, D, H, W, cout, k, k, k).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(B, cout, D * k, H * k, W * k)
+    y = linear.pointwise(x, weight.reshape(C, cout * k ** 3).t())                              # (B, Cout*k^3, D, H, W)
+    y = y.reshape(B, cout, k, k, k, D, H, W).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(B, cout, D * k, H * k, W * k)
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1, 1)
     return y

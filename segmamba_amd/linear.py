@@ -1,0 +1,140 @@
+"""Projection GEMMs of the hot path (1x1x1 convolutions, patch convolutions, Mamba in/out/x/dt projections).
+
+These stay on the BLAS library (rocBLAS / hipBLASLt through torch - plain library GEMMs), but two things about how
+they are *called* matter on MI355X (profiles/r01_bench_step_kernels_v5.txt, tools/gpu_torch_prof.py):
+
+  * weight gradients are  dW = dY^T X  with a reduction over K = B*D*H*W rows (up to 4.2 M) and only 3 .. 192 output
+    rows / columns.  The library runs such a shape as ONE small tile looping over all of K (1.3 - 5 ms each, ~40 ms
+    of a 283 ms training step).  `tn_matmul` cuts K into slabs that become the batch dimension of a batched GEMM
+    (thousands of independent tiles) and adds the partial products - "split-K", done above the library.
+  * a GEMM can read either operand transposed for free, so a 1x1x1 convolution can consume channel-first or
+    channel-last activations as they are and always emit the channel-first tensor the next operator wants; no
+    transposing copy is materialised around it.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+_SLAB = 4096          # rows of K per partial product
+_MIN_K = 32768        # below this one GEMM is fine
+_FORCE_SPLIT = False  # tests: exercise the split path on CPU tensors too
+
+
+def _split(K: int) -> int:
+    """number of K slabs (a divisor of K close to K / _SLAB), 1 = do not split."""
+    if K < _MIN_K:
+        return 1
+    s = K // _SLAB
+    while s > 1 and K % s:
+        s -= 1
+    return s if K // max(s, 1) <= 4 * _SLAB else 1
+
+
+def tn_matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a^T b for tall operands a (K, M), b (K, N), K >> M, N; fp32 result.  Row slices / column slices of larger
+    matrices are fine (only views are taken)."""
+    K = a.shape[0]
+    s = _split(K) if (a.is_cuda or _FORCE_SPLIT) else 1
+    if s == 1:
+        return (a.t() @ b).float()
+    part = torch.bmm(a.unflatten(0, (s, K // s)).transpose(1, 2), b.unflatten(0, (s, K // s)))      # (s, M, N)
+    return part.sum(0, dtype=torch.float32)
+
+
+def nt_matmul_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """sum over the batch of a[i] b[i]^T for wide operands a (B, M, K), b (B, N, K) with unit stride along K; fp32."""
+    B, M, K = a.shape
+    s = _split(K) if (a.is_cuda or _FORCE_SPLIT) else 1
+    if s == 1 or a.stride(2) != 1 or b.stride(2) != 1:
+        return torch.matmul(a, b.transpose(1, 2)).sum(0, dtype=torch.float32)
+    acc = None
+    for i in range(B):
+        pa = a[i].unflatten(1, (s, K // s)).transpose(0, 1)             # (s, M, K/s), rows strided
+        pb = b[i].unflatten(1, (s, K // s)).transpose(0, 1)             # (s, N, K/s)
+        p = torch.bmm(pa, pb.transpose(1, 2)).sum(0, dtype=torch.float32)
+        acc = p if acc is None else acc + p
+    return acc
+
+
+class _LinearCL(torch.autograd.Function):
+    """y = x W^T + b on a channel-last x (..., Cin); tensors already in the compute dtype."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = db = None
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ w).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = tn_matmul(dy2, x.reshape(-1, x.shape[-1])).to(w.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0, dtype=torch.float32).to(dy.dtype)
+        return dx, dw, db
+
+
+class _Pointwise(torch.autograd.Function):
+    """1x1x1 convolution y[b] = W x[b] on x (B, Cin, S) in either memory order -> y (B, Cout, S) channel-first."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        y = torch.matmul(w, x)
+        if b is not None:
+            y += b.view(1, -1, 1)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = db = None
+        if dy.stride(2) != 1 and dy.stride(1) != 1:
+            dy = dy.contiguous()
+        if ctx.needs_input_grad[0]:
+            dx = torch.matmul(w.t(), dy)
+        if ctx.needs_input_grad[1]:
+            if x.stride(2) == 1 and dy.stride(2) == 1:
+                dw = nt_matmul_rows(dy, x).to(w.dtype)
+            else:                                                          # channel-last operands: (B*S, C) matrices
+                xs, dys = x.transpose(1, 2), dy.transpose(1, 2)
+                if x.stride(1) != 1:
+                    xs = xs.contiguous()
+                if dy.stride(1) != 1:
+                    dys = dys.contiguous()
+                dw = sum(tn_matmul(dys[i], xs[i]) for i in range(x.shape[0])).to(w.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2), dtype=torch.float32).to(dy.dtype)
+        return dx, dw, db
+
+
+def _compute_dtype(x, *ws):
+    if x.is_cuda and torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype("cuda")
+    else:
+        dt = x.dtype
+    return (x.to(dt),) + tuple(w.to(dt) if w is not None else None for w in ws)
+
+
+def linear_cl(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """F.linear with the split-K weight gradient; follows autocast like F.linear."""
+    x, weight, bias = _compute_dtype(x, weight, bias)
+    return _LinearCL.apply(x, weight, bias)
+
+
+def pointwise(x: torch.Tensor, weight2d: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """x (B, Cin, *spatial) in any memory order, weight2d (Cout, Cin) -> (B, Cout, *spatial) channel-first."""
+    x, weight2d, bias = _compute_dtype(x, weight2d, bias)
+    B, C = x.shape[:2]
+    xs = x.flatten(2)
+    if xs.stride(2) != 1 and xs.stride(1) != 1:
+        xs = xs.contiguous()
+    y = _Pointwise.apply(xs, weight2d, bias)
+    return y.reshape(B, weight2d.shape[0], *x.shape[2:])

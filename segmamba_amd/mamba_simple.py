@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import lib as L
+from .linear import linear_cl
 from .selective_scan_interface import _inner
 
 
@@ -138,11 +139,11 @@ class Mamba(nn.Module):
         batch, seqlen, _ = hidden_states.shape
         if seqlen % self.nslices != 0:
             raise RuntimeError(f"sequence length {seqlen} must be divisible by nslices {self.nslices}")
-        xz = F.linear(hidden_states, self.in_proj.weight, self.in_proj.bias)        # (B, L, 2*d_inner)
+        xz = linear_cl(hidden_states, self.in_proj.weight, self.in_proj.bias)        # (B, L, 2*d_inner)
         out = self._direction(xz, "", L.TIME_FORWARD)
         out_b = self._direction(xz, "_b", L.TIME_REVERSED)
         out_s = self._direction(xz, "_s", L.TIME_INTERLEAVED, self.nslices)
-        return F.linear(out + out_b + out_s, self.out_proj.weight, self.out_proj.bias)
+        return linear_cl(out + out_b + out_s, self.out_proj.weight, self.out_proj.bias)
 
     def step(self, hidden_states, conv_state, ssm_state):
         raise NotImplementedError("autoregressive decoding is outside the SegMamba hot path (SURVEY.md §2.1)")

@@ -24,6 +24,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from . import ops_raw
+from .linear import tn_matmul
 
 
 def _custom_fwd(fn):
@@ -191,9 +192,9 @@ class MambaInnerCore(torch.autograd.Function):
         dx_dbl[:, R + N:] = dC2
         dB_proj_bias = dB2.sum(0).to(B_proj_bias.dtype) if has_Bb else None
         dC_proj_bias = dC2.sum(0).to(C_proj_bias.dtype) if has_Cb else None
-        ddelta_proj_weight = ddelta2.t() @ x_dbl[:, :R]                         # (d, R)    reference :272
+        ddelta_proj_weight = tn_matmul(ddelta2, x_dbl[:, :R])                   # (d, R)    reference :272
         dx_dbl[:, :R] = ddelta2 @ delta_proj_weight                             # (bl, R)   reference :273
-        dx_proj_weight = dx_dbl.t() @ conv2                                     # (R+2N, d) reference :275
+        dx_proj_weight = tn_matmul(dx_dbl, conv2)                              # (R+2N, d) reference :275
         dconv2 = torch.addmm(dconv2, dx_dbl, x_proj_weight)                     # (bl, d)   reference :276
         dconv_full = dconv2.reshape(batch, seqlen, dim)
         if not channel_last:

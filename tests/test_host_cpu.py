@@ -105,3 +105,53 @@ def test_mamba_constructor_contract():
     assert (sp >= 1e-3 * 0.99).all() and (sp <= 0.1 * 1.01).all()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 100, 48))                        # L % nslices != 0
+
+
+def test_split_k_projection_gemms_match_torch(monkeypatch):
+    """linear.py: split-K weight gradients / layout-agnostic 1x1x1 convolution == F.linear / F.conv3d autograd."""
+    import torch.nn.functional as F
+    from segmamba_amd import linear as Lm
+    monkeypatch.setattr(Lm, "_FORCE_SPLIT", True)
+    monkeypatch.setattr(Lm, "_MIN_K", 16)
+    monkeypatch.setattr(Lm, "_SLAB", 8)
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.randn(96, 5, generator=g), torch.randn(96, 3, generator=g)
+    assert Lm._split(96) == 12
+    assert torch.allclose(Lm.tn_matmul(a, b), a.t() @ b, atol=1e-4)
+    assert torch.allclose(Lm.tn_matmul(a[:, 1:4], b[:, :2]), a[:, 1:4].t() @ b[:, :2], atol=1e-4)      # column slices
+    x = torch.randn(2, 5, 4, 4, 4, generator=g, requires_grad=True)
+    w = torch.randn(7, 5, generator=g, requires_grad=True)
+    bias = torch.randn(7, generator=g, requires_grad=True)
+    ref = F.conv3d(x, w.view(7, 5, 1, 1, 1), bias)
+    gy = torch.randn(ref.shape, generator=g)
+    gref = torch.autograd.grad(ref, (x, w, bias), gy)
+    for xin in (x, x.detach().permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3).requires_grad_()):
+        y = Lm.pointwise(xin, w, bias)
+        assert y.is_contiguous() and torch.allclose(y, ref, atol=1e-5)
+        for got, want in zip(torch.autograd.grad(y, (xin, w, bias), gy), gref):
+            assert torch.allclose(got, want, atol=1e-4)
+    xl = torch.randn(3, 32, 5, generator=g, requires_grad=True)
+    y, ref = Lm.linear_cl(xl, w, bias), F.linear(xl, w, bias)
+    gy = torch.randn(ref.shape, generator=g)
+    for got, want in zip(torch.autograd.grad(y, (xl, w, bias), gy), torch.autograd.grad(ref, (xl, w, bias), gy)):
+        assert torch.allclose(got, want, atol=1e-4)
+
+
+def test_patch_convs_match_torch():
+    import torch.nn.functional as F
+    from segmamba_amd import fused_norm
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 3, 4, 6, 8, generator=g, requires_grad=True)
+    w = torch.randn(5, 3, 2, 2, 2, generator=g, requires_grad=True)
+    b = torch.randn(5, generator=g, requires_grad=True)
+    y, ref = fused_norm.patch_conv3d(x, w, b, 2), F.conv3d(x, w, b, 2)
+    gy = torch.randn(ref.shape, generator=g)
+    assert torch.allclose(y, ref, atol=1e-5)
+    for got, want in zip(torch.autograd.grad(y, (x, w, b), gy), torch.autograd.grad(ref, (x, w, b), gy)):
+        assert torch.allclose(got, want, atol=1e-4)
+    wt = torch.randn(3, 5, 2, 2, 2, generator=g, requires_grad=True)
+    y, ref = fused_norm.patch_conv_transpose3d(x, wt, b, 2), F.conv_transpose3d(x, wt, b, 2)
+    gy = torch.randn(ref.shape, generator=g)
+    assert torch.allclose(y, ref, atol=1e-5)
+    for got, want in zip(torch.autograd.grad(y, (x, wt, b), gy), torch.autograd.grad(ref, (x, wt, b), gy)):
+        assert torch.allclose(got, want, atol=1e-4)
