@@ -205,6 +205,53 @@ int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* args);
 size_t segm_conv3d_k3_wgrad_workspace_bytes(int32_t batch, int32_t cin, int32_t cout, int32_t depth, int32_t height,
                                             int32_t width);
 
+/* ------------------------------------------------------------------------------------------------
+ * InstanceNorm3d (+ residual) (+ activation), forward and backward.
+ * Replaces the torch.nn.InstanceNorm3d -> [+ residual] -> ReLU / LeakyReLU chains of the stem and decoder
+ * (reference model_segmamba/segmamba.py:96-130,147,169-187; monai/networks/blocks/dynunet_block.py:98-111), which the
+ * reference runs as three to four separate ATen kernels per call: no affine parameters, no running statistics,
+ * biased variance, y = act((x - mean) / sqrt(var + eps) + residual).
+ *
+ * x, residual, y, dy, dx, dresidual: (instances, spatial) contiguous, instances = batch * channels, one dtype.
+ * mean, rstd: (instances) fp32, written by the forward and read by the backward.
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
+ * Backward: `y` (the forward's output) is required iff act != 0 and a residual was added (the activation mask is then
+ * not recomputable from x); pass NULL otherwise.  dresidual (NULL = not wanted) receives dy * act'(.).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_instnorm_fwd_args {
+    int32_t instances, dtype, act, reserved;
+    int64_t spatial;
+    float slope, eps;
+    const void* x;
+    const void* residual;     /* or NULL */
+    void* y;
+    float* mean;
+    float* rstd;
+    void* workspace;          /* segm_instnorm_workspace_bytes() */
+    size_t workspace_bytes;
+    void* stream;
+} segm_instnorm_fwd_args;
+
+typedef struct segm_instnorm_bwd_args {
+    int32_t instances, dtype, act, reserved;
+    int64_t spatial;
+    float slope, reserved2;
+    const void* x;
+    const void* dy;
+    const void* y;            /* see above; or NULL */
+    const float* mean;
+    const float* rstd;
+    void* dx;
+    void* dresidual;          /* or NULL */
+    void* workspace;
+    size_t workspace_bytes;
+    void* stream;
+} segm_instnorm_bwd_args;
+
+int segm_instnorm_fwd(const segm_instnorm_fwd_args* args);
+int segm_instnorm_bwd(const segm_instnorm_bwd_args* args);
+size_t segm_instnorm_workspace_bytes(int32_t instances, int64_t spatial);
+
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);
 const char* segm_status_string(int status);

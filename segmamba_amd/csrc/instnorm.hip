@@ -1,0 +1,395 @@
+// InstanceNorm3d (+ residual) (+ ReLU / LeakyReLU), forward and backward (C ABI: segm_instnorm_fwd / _bwd).
+//
+// Replaces the torch.nn.InstanceNorm3d -> (+ residual) -> activation chains of the SegMamba stem and decoder
+// (reference model_segmamba/segmamba.py:96-130 GSC, :147,169-187; monai/networks/blocks/dynunet_block.py:98-111):
+// no affine parameters, no running statistics, biased variance, eps inside the square root.
+//
+// An instance is one (batch, channel) volume of S contiguous elements (2 M at stage 0).  Everything here is HBM
+// bound byte work: 16-byte accesses, every instance cut into slabs so that the grid is a few thousand workgroups
+// whatever B*C is, fp32 statistics merged with Chan's (count, mean, M2) update.
+//
+//   forward   K1 stats   per (instance, slab): sum, sum of squares            -> partials
+//             K2 apply   merge the instance's partials -> mean, rstd; y = act((x - mean) rstd + residual)
+//   backward  K3 stats   g = dy act'(v);  per (instance, slab): sum g, sum g xhat  (g is parked in dresidual if asked)
+//             K4 apply   dx = rstd (g - mean(g) - xhat mean(g xhat))
+// The activation mask is taken from y when a residual was added (v is not recomputable from x alone), else from xhat.
+#include <string.h>
+
+#include "segm_device.h"
+
+namespace segm {
+
+constexpr int kNormMaxSplit = 64;
+
+struct NormDev {
+    const void* x; const void* res; void* y;
+    const void* dy; const void* ymask; void* dx; void* dres;
+    float* mean; float* rstd;
+    float2* part;
+    int64_t S;
+    int64_t slab;          // elements per slab (multiple of 8 * 256)
+    int32_t nsplit;
+    int32_t act;           // 0 none, 1 relu, 2 leaky relu
+    float slope, eps;
+};
+
+template <typename T> struct Vec;       // 16-byte packets
+template <> struct Vec<float> { static constexpr int N = 4; };
+template <> struct Vec<f16_t> { static constexpr int N = 8; };
+template <> struct Vec<bf16_t> { static constexpr int N = 8; };
+
+template <typename T, bool VEC> struct Pack {
+    static constexpr int N = VEC ? Vec<T>::N : 1;
+    float v[N];
+    __device__ __forceinline__ void load(const T* p) {
+        if (VEC) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(p);
+            T tmp[N];
+            memcpy(tmp, &raw, 16);
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = to_f32(tmp[i]);
+        } else {
+            v[0] = to_f32(p[0]);
+        }
+    }
+    __device__ __forceinline__ void store(T* p) const {
+        if (VEC) {
+            T tmp[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) tmp[i] = from_f32<T>(v[i]);
+            uint4 raw;
+            memcpy(&raw, tmp, 16);
+            *reinterpret_cast<uint4*>(p) = raw;
+        } else {
+            p[0] = from_f32<T>(v[0]);
+        }
+    }
+};
+
+// sum over the workgroup of two values; result valid in every thread
+__device__ __forceinline__ float2 block_sum2(float a, float b, float2* lds) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        a += __shfl_xor(a, m);
+        b += __shfl_xor(b, m);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds[wave] = make_float2(a, b);
+    __syncthreads();
+    float2 r = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) { r.x += lds[w].x; r.y += lds[w].y; }
+    return r;
+}
+
+__device__ __forceinline__ void slab_range(const NormDev& P, int split, int64_t& e0, int64_t& e1) {
+    e0 = (int64_t)split * P.slab;
+    e1 = e0 + P.slab;
+    if (e1 > P.S) e1 = P.S;
+    if (e0 > P.S) e0 = P.S;
+}
+
+// merges the (sum, sumsq) partials of an instance into mean / rstd (every thread gets the result)
+__device__ __forceinline__ float2 merge_stats(const NormDev& P, int inst, float2* lds) {
+    if (threadIdx.x == 0) {
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int s = 0; s < P.nsplit; ++s) {
+            int64_t e0, e1;
+            slab_range(P, s, e0, e1);
+            const float ns = (float)(e1 - e0);
+            if (ns <= 0.f) continue;
+            const float2 p = P.part[(int64_t)inst * P.nsplit + s];
+            const float ms = p.x / ns;
+            const float m2s = fmaxf(p.y - p.x * ms, 0.f);
+            const float d = ms - mean, nt = n + ns;
+            mean += d * (ns / nt);
+            m2 += m2s + d * d * (n * ns / nt);
+            n = nt;
+        }
+        const float var = m2 / n;
+        lds[0] = make_float2(mean, 1.0f / sqrtf(var + P.eps));
+    }
+    __syncthreads();
+    const float2 r = lds[0];
+    __syncthreads();
+    return r;
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBlock) inorm_fwd_stats_kernel(NormDev P) {
+    using Pk = Pack<T, VEC>;
+    __shared__ float2 lds[kWavesPerBlock];
+    const int split = blockIdx.x, inst = blockIdx.y;
+    const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.S;
+    int64_t e0, e1;
+    slab_range(P, split, e0, e1);
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t step = (int64_t)kBlock * Pk::N;
+    int64_t i = e0 + (int64_t)threadIdx.x * Pk::N;
+    for (; i + 3 * step < e1; i += 4 * step) {             // 4 independent packets in flight per thread
+        Pk p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k].load(x + i + k * step);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < Pk::N; ++j) { s[k] += p[k].v[j]; q[k] = fmaf(p[k].v[j], p[k].v[j], q[k]); }
+    }
+    for (; i < e1; i += step) {
+        Pk p;
+        p.load(x + i);
+#pragma unroll
+        for (int j = 0; j < Pk::N; ++j) { s[0] += p.v[j]; q[0] = fmaf(p.v[j], p.v[j], q[0]); }
+    }
+    const float2 r = block_sum2((s[0] + s[1]) + (s[2] + s[3]), (q[0] + q[1]) + (q[2] + q[3]), lds);
+    if (threadIdx.x == 0) P.part[(int64_t)inst * P.nsplit + split] = r;
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act, float slope) {
+    if (act == 0) return v;
+    return v > 0.f ? v : v * slope;                      // relu: slope == 0
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBlock) inorm_fwd_apply_kernel(NormDev P) {
+    using Pk = Pack<T, VEC>;
+    __shared__ float2 lds[kWavesPerBlock];
+    const int split = blockIdx.x, inst = blockIdx.y;
+    const float2 st = merge_stats(P, inst, lds);
+    const float mean = st.x, rstd = st.y;
+    if (split == 0 && threadIdx.x == 0) { P.mean[inst] = mean; P.rstd[inst] = rstd; }
+    const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.S;
+    const T* res = P.res ? reinterpret_cast<const T*>(P.res) + (int64_t)inst * P.S : nullptr;
+    T* y = reinterpret_cast<T*>(P.y) + (int64_t)inst * P.S;
+    const float slope = P.act == 1 ? 0.f : P.slope;
+    const float shift = -mean * rstd;
+    int64_t e0, e1;
+    slab_range(P, split, e0, e1);
+    const int64_t step = (int64_t)kBlock * Pk::N;
+    for (int64_t i = e0 + (int64_t)threadIdx.x * Pk::N; i < e1; i += 2 * step) {
+        const bool two = i + step < e1;
+        Pk a, b, ra, rb;
+        a.load(x + i);
+        if (two) b.load(x + i + step);
+        if (res) { ra.load(res + i); if (two) rb.load(res + i + step); }
+#pragma unroll
+        for (int j = 0; j < Pk::N; ++j) {
+            float v = fmaf(a.v[j], rstd, shift);
+            if (res) v += ra.v[j];
+            a.v[j] = act_fwd(v, P.act, slope);
+        }
+        a.store(y + i);
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < Pk::N; ++j) {
+                float v = fmaf(b.v[j], rstd, shift);
+                if (res) v += rb.v[j];
+                b.v[j] = act_fwd(v, P.act, slope);
+            }
+            b.store(y + i + step);
+        }
+    }
+}
+
+// g = dy * act'(v) for one packet
+template <typename Pk>
+__device__ __forceinline__ void grad_through_act(Pk& g, const Pk& xh, const Pk& ym, bool use_y, int act, float slope) {
+    if (act == 0) return;
+#pragma unroll
+    for (int j = 0; j < Pk::N; ++j) {
+        const float v = use_y ? ym.v[j] : xh.v[j];
+        g.v[j] = v > 0.f ? g.v[j] : g.v[j] * slope;
+    }
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBlock) inorm_bwd_stats_kernel(NormDev P) {
+    using Pk = Pack<T, VEC>;
+    __shared__ float2 lds[kWavesPerBlock];
+    const int split = blockIdx.x, inst = blockIdx.y;
+    const int64_t base = (int64_t)inst * P.S;
+    const T* x = reinterpret_cast<const T*>(P.x) + base;
+    const T* dy = reinterpret_cast<const T*>(P.dy) + base;
+    const T* ym = P.ymask ? reinterpret_cast<const T*>(P.ymask) + base : nullptr;
+    T* dres = P.dres ? reinterpret_cast<T*>(P.dres) + base : nullptr;
+    const float mean = P.mean[inst], rstd = P.rstd[inst];
+    const float shift = -mean * rstd;
+    const float slope = P.act == 1 ? 0.f : P.slope;
+    const bool use_y = ym != nullptr;
+    int64_t e0, e1;
+    slab_range(P, split, e0, e1);
+    float sg[2] = {0.f, 0.f}, sgx[2] = {0.f, 0.f};
+    const int64_t step = (int64_t)kBlock * Pk::N;
+    for (int64_t i = e0 + (int64_t)threadIdx.x * Pk::N; i < e1; i += 2 * step) {
+        const bool two = i + step < e1;
+        Pk xa, xb, ga, gb, ya, yb;
+        xa.load(x + i); ga.load(dy + i);
+        if (use_y && P.act) ya.load(ym + i);
+        if (two) {
+            xb.load(x + i + step); gb.load(dy + i + step);
+            if (use_y && P.act) yb.load(ym + i + step);
+        }
+#pragma unroll
+        for (int j = 0; j < Pk::N; ++j) xa.v[j] = fmaf(xa.v[j], rstd, shift);
+        grad_through_act(ga, xa, ya, use_y, P.act, slope);
+#pragma unroll
+        for (int j = 0; j < Pk::N; ++j) { sg[0] += ga.v[j]; sgx[0] = fmaf(ga.v[j], xa.v[j], sgx[0]); }
+        if (dres) ga.store(dres + i);
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < Pk::N; ++j) xb.v[j] = fmaf(xb.v[j], rstd, shift);
+            grad_through_act(gb, xb, yb, use_y, P.act, slope);
+#pragma unroll
+            for (int j = 0; j < Pk::N; ++j) { sg[1] += gb.v[j]; sgx[1] = fmaf(gb.v[j], xb.v[j], sgx[1]); }
+            if (dres) gb.store(dres + i + step);
+        }
+    }
+    const float2 r = block_sum2(sg[0] + sg[1], sgx[0] + sgx[1], lds);
+    if (threadIdx.x == 0) P.part[(int64_t)inst * P.nsplit + split] = r;
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBlock) inorm_bwd_apply_kernel(NormDev P) {
+    using Pk = Pack<T, VEC>;
+    __shared__ float2 lds[kWavesPerBlock];
+    const int split = blockIdx.x, inst = blockIdx.y;
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (int s = 0; s < P.nsplit; ++s) {
+            const float2 p = P.part[(int64_t)inst * P.nsplit + s];
+            a += p.x; b += p.y;
+        }
+        lds[0] = make_float2(a / (float)P.S, b / (float)P.S);
+    }
+    __syncthreads();
+    const float mg = lds[0].x, mgx = lds[0].y;
+    const int64_t base = (int64_t)inst * P.S;
+    const T* x = reinterpret_cast<const T*>(P.x) + base;
+    const T* dy = reinterpret_cast<const T*>(P.dy) + base;
+    const T* ym = P.ymask ? reinterpret_cast<const T*>(P.ymask) + base : nullptr;
+    const T* gsrc = P.dres ? reinterpret_cast<const T*>(P.dres) + base : nullptr;     // g parked by the stats pass
+    T* dx = reinterpret_cast<T*>(P.dx) + base;
+    const float mean = P.mean[inst], rstd = P.rstd[inst];
+    const float shift = -mean * rstd;
+    const float slope = P.act == 1 ? 0.f : P.slope;
+    const bool use_y = ym != nullptr;
+    int64_t e0, e1;
+    slab_range(P, split, e0, e1);
+    const int64_t step = (int64_t)kBlock * Pk::N;
+    for (int64_t i = e0 + (int64_t)threadIdx.x * Pk::N; i < e1; i += step) {
+        Pk xa, ga, ya;
+        xa.load(x + i);
+#pragma unroll
+        for (int j = 0; j < Pk::N; ++j) xa.v[j] = fmaf(xa.v[j], rstd, shift);
+        if (gsrc) {
+            ga.load(gsrc + i);
+        } else {
+            ga.load(dy + i);
+            if (use_y && P.act) ya.load(ym + i);
+            grad_through_act(ga, xa, ya, use_y, P.act, slope);
+        }
+#pragma unroll
+        for (int j = 0; j < Pk::N; ++j) ga.v[j] = rstd * (ga.v[j] - mg - xa.v[j] * mgx);
+        ga.store(dx + i);
+    }
+}
+
+static void norm_plan(int instances, int64_t S, int vecn, int& nsplit, int64_t& slab) {
+    const int64_t quantum = (int64_t)kBlock * vecn * 4;           // the stats loop's full stride
+    int64_t want = (4096 + instances - 1) / instances;            // ~4096 workgroups in total
+    const int64_t maxs = (S + quantum - 1) / quantum;
+    if (want > maxs) want = maxs;
+    if (want > kNormMaxSplit) want = kNormMaxSplit;
+    if (want < 1) want = 1;
+    slab = (S + want - 1) / want;
+    slab = (slab + quantum - 1) / quantum * quantum;
+    nsplit = (int)((S + slab - 1) / slab);
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <typename T>
+static int launch_norm_fwd(NormDev& P, int instances, bool vec, hipStream_t st) {
+    dim3 grid(P.nsplit, instances);
+    if (vec) {
+        hipLaunchKernelGGL((inorm_fwd_stats_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
+        hipLaunchKernelGGL((inorm_fwd_apply_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
+    } else {
+        hipLaunchKernelGGL((inorm_fwd_stats_kernel<T, false>), grid, dim3(kBlock), 0, st, P);
+        hipLaunchKernelGGL((inorm_fwd_apply_kernel<T, false>), grid, dim3(kBlock), 0, st, P);
+    }
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static int launch_norm_bwd(NormDev& P, int instances, bool vec, hipStream_t st) {
+    dim3 grid(P.nsplit, instances);
+    if (vec) {
+        hipLaunchKernelGGL((inorm_bwd_stats_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
+        hipLaunchKernelGGL((inorm_bwd_apply_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
+    } else {
+        hipLaunchKernelGGL((inorm_bwd_stats_kernel<T, false>), grid, dim3(kBlock), 0, st, P);
+        hipLaunchKernelGGL((inorm_bwd_apply_kernel<T, false>), grid, dim3(kBlock), 0, st, P);
+    }
+    return (int)hipGetLastError();
+}
+
+static int vec_width(int dtype) { return dtype == SEGM_F32 ? 4 : 8; }
+
+}  // namespace segm
+
+using namespace segm;
+
+extern "C" size_t segm_instnorm_workspace_bytes(int32_t instances, int64_t spatial) {
+    if (instances <= 0 || spatial <= 0) return 0;
+    return (size_t)instances * kNormMaxSplit * sizeof(float2);
+}
+
+static int norm_common(int32_t instances, int64_t spatial, int32_t dtype, int32_t act, const void* ws, size_t ws_bytes) {
+    if (instances <= 0 || spatial <= 0) return SEGM_E_SHAPE;
+    if (dtype != SEGM_F32 && dtype != SEGM_F16 && dtype != SEGM_BF16) return SEGM_E_DTYPE;
+    if (act < 0 || act > 2) return SEGM_E_SHAPE;
+    if (!ws || ws_bytes < segm_instnorm_workspace_bytes(instances, spatial)) return SEGM_E_WORKSPACE;
+    return SEGM_OK;
+}
+
+extern "C" int segm_instnorm_fwd(const segm_instnorm_fwd_args* a) {
+    if (!a) return SEGM_E_NULL;
+    int rc = norm_common(a->instances, a->spatial, a->dtype, a->act, a->workspace, a->workspace_bytes);
+    if (rc != SEGM_OK) return rc;
+    if (!a->x || !a->y || !a->mean || !a->rstd) return SEGM_E_NULL;
+    NormDev P;
+    memset(&P, 0, sizeof(P));
+    P.x = a->x; P.res = a->residual; P.y = a->y; P.mean = a->mean; P.rstd = a->rstd;
+    P.part = (float2*)a->workspace;
+    P.S = a->spatial; P.act = a->act; P.slope = a->slope; P.eps = a->eps;
+    const int vn = vec_width(a->dtype);
+    const bool vec = a->spatial % vn == 0 && aligned16(a->x) && aligned16(a->y) && (!a->residual || aligned16(a->residual));
+    norm_plan(a->instances, a->spatial, vn, P.nsplit, P.slab);
+    hipStream_t st = (hipStream_t)a->stream;
+    if (a->dtype == SEGM_F32) return launch_norm_fwd<float>(P, a->instances, vec, st);
+    if (a->dtype == SEGM_F16) return launch_norm_fwd<f16_t>(P, a->instances, vec, st);
+    return launch_norm_fwd<bf16_t>(P, a->instances, vec, st);
+}
+
+extern "C" int segm_instnorm_bwd(const segm_instnorm_bwd_args* a) {
+    if (!a) return SEGM_E_NULL;
+    int rc = norm_common(a->instances, a->spatial, a->dtype, a->act, a->workspace, a->workspace_bytes);
+    if (rc != SEGM_OK) return rc;
+    if (!a->x || !a->dy || !a->dx || !a->mean || !a->rstd) return SEGM_E_NULL;
+    NormDev P;
+    memset(&P, 0, sizeof(P));
+    P.x = a->x; P.dy = a->dy; P.ymask = a->act ? a->y : nullptr; P.dx = a->dx; P.dres = a->dresidual;
+    P.mean = (float*)a->mean; P.rstd = (float*)a->rstd;
+    P.part = (float2*)a->workspace;
+    P.S = a->spatial; P.act = a->act; P.slope = a->slope; P.eps = 0.f;
+    const int vn = vec_width(a->dtype);
+    const bool vec = a->spatial % vn == 0 && aligned16(a->x) && aligned16(a->dy) && aligned16(a->dx) &&
+                     (!P.ymask || aligned16(P.ymask)) && (!a->dresidual || aligned16(a->dresidual));
+    norm_plan(a->instances, a->spatial, vn, P.nsplit, P.slab);
+    hipStream_t st = (hipStream_t)a->stream;
+    if (a->dtype == SEGM_F32) return launch_norm_bwd<float>(P, a->instances, vec, st);
+    if (a->dtype == SEGM_F16) return launch_norm_bwd<f16_t>(P, a->instances, vec, st);
+    return launch_norm_bwd<bf16_t>(P, a->instances, vec, st);
+}

@@ -8,10 +8,11 @@ IN -> +residual -> LeakyReLU).
 `torch.nn.InstanceNorm3d` defaults apply everywhere on the path: no affine
 parameters, no running statistics, eps = 1e-5, biased variance.
 
-Round 1: the math is expressed with ATen ops (SURVEY.md §8f rank 1 lists the
-hand-written fused kernel as the first "next" item once rows a-e are done).
-Keeping every call site behind this one function means the HIP kernel drops
-in here without touching the model code.
+On the GPU every call is two launches of the library's own kernels per direction (csrc/instnorm.hip:
+statistics, then normalise + residual + activation in one pass; the backward likewise) instead of the three to four
+ATen kernels per direction the reference runs (batch_norm statistics / transform, add, leaky_relu and their
+backward counterparts: 41 ms of a 283 ms training step, profiles/r01_bench_step_kernels_v5.txt).  CPU tensors
+(unit tests of the host logic) take the ATen expression of the same math.
 """
 from __future__ import annotations
 
@@ -21,12 +22,41 @@ import torch.nn.functional as F
 from . import linear
 
 
+class _InstNormAct(torch.autograd.Function):
+    """y = act(IN(x) + residual) through segm_instnorm_fwd / segm_instnorm_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, residual, act, slope, eps):
+        from . import lib as L, ops_raw
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.to(x.dtype).contiguous()
+        y, mean, rstd = ops_raw.instnorm_fwd(L.get_lib(), x, residual, act, slope, eps)
+        need_y = residual is not None and act != "none"
+        ctx.save_for_backward(x, mean, rstd, y if need_y else None)
+        ctx.cfg = (act, slope, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L, ops_raw
+        x, mean, rstd, y = ctx.saved_tensors
+        act, slope, has_res = ctx.cfg
+        dx, dres = ops_raw.instnorm_bwd(L.get_lib(), x, dy, mean, rstd, y, act, slope,
+                                        want_dresidual=has_res and ctx.needs_input_grad[1])
+        return dx, dres, None, None, None
+
+
 def instance_norm_act(x: torch.Tensor, act: str = "none", slope: float = 0.01, eps: float = 1e-5,
                       residual: torch.Tensor | None = None) -> torch.Tensor:
     """y = act(IN(x) [+ residual]) for x of shape (B, C, D, H, W).
 
     act in {"none", "relu", "leaky_relu"}.
     """
+    if act not in ("none", "relu", "leaky_relu"):
+        raise ValueError(f"unknown activation {act!r}")
+    if x.is_cuda:
+        return _InstNormAct.apply(x, residual, act, slope, eps)
     y = F.instance_norm(x, eps=eps)
     if residual is not None:
         y = y + residual

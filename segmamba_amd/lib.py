@@ -91,11 +91,31 @@ class Conv3dWgradArgs(C.Structure):
     ]
 
 
+class InstNormFwdArgs(C.Structure):
+    _fields_ = [
+        ("instances", C.c_int32), ("dtype", C.c_int32), ("act", C.c_int32), ("reserved", C.c_int32),
+        ("spatial", C.c_int64), ("slope", C.c_float), ("eps", C.c_float),
+        ("x", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+    ]
+
+
+class InstNormBwdArgs(C.Structure):
+    _fields_ = [
+        ("instances", C.c_int32), ("dtype", C.c_int32), ("act", C.c_int32), ("reserved", C.c_int32),
+        ("spatial", C.c_int64), ("slope", C.c_float), ("reserved2", C.c_float),
+        ("x", C.c_void_p), ("dy", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+        ("dx", C.c_void_p), ("dresidual", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+    ]
+
+
 EXPORTS = (
     "segm_selective_scan_fwd", "segm_selective_scan_fwd_workspace_bytes", "segm_selective_scan_ckpt_bytes",
     "segm_selective_scan_default_chunk", "segm_selective_scan_bwd", "segm_selective_scan_bwd_workspace_bytes",
     "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
     "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes",
+    "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -125,6 +145,9 @@ class SegmLib:
         sig("segm_causal_conv1d_bwd_workspace_bytes", [C.c_int32, C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
         sig("segm_conv3d_k3_wgrad", [C.POINTER(Conv3dWgradArgs)], C.c_int)
         sig("segm_conv3d_k3_wgrad_workspace_bytes", [C.c_int32] * 6, C.c_size_t)
+        sig("segm_instnorm_fwd", [C.POINTER(InstNormFwdArgs)], C.c_int)
+        sig("segm_instnorm_bwd", [C.POINTER(InstNormBwdArgs)], C.c_int)
+        sig("segm_instnorm_workspace_bytes", [C.c_int32, C.c_int64], C.c_size_t)
         sig("segm_abi_version", [], C.c_int)
         sig("segm_status_string", [C.c_int], C.c_char_p)
 

@@ -255,3 +255,57 @@ def conv3d_k3_wgrad(lib: L.SegmLib, x: torch.Tensor, dy: torch.Tensor, out_dtype
     a.stream = L.stream_handle(x)
     lib.check(lib.dll.segm_conv3d_k3_wgrad(a), "conv3d_k3_wgrad")
     return dw
+
+
+# ---------------------------------------------------------------------------------------------------------
+# InstanceNorm3d (+ residual) (+ activation)
+# ---------------------------------------------------------------------------------------------------------
+ACT_CODES = {"none": 0, "relu": 1, "leaky_relu": 2}
+
+
+def _norm_geom(x):
+    if x.dim() < 3 or not x.is_contiguous():
+        raise RuntimeError("instnorm: x must be a contiguous (B, C, *spatial) tensor")
+    inst = x.shape[0] * x.shape[1]
+    return inst, x.numel() // inst
+
+
+def instnorm_fwd(lib: L.SegmLib, x, residual=None, act="none", slope=0.01, eps=1e-5):
+    """-> (y, mean, rstd): y = act(IN(x) + residual); mean / rstd fp32 (B * C)."""
+    inst, S = _norm_geom(x)
+    if residual is not None and (residual.shape != x.shape or residual.dtype != x.dtype or not residual.is_contiguous()):
+        raise RuntimeError("instnorm: residual must match x (shape, dtype, contiguous)")
+    a = L.InstNormFwdArgs()
+    a.instances, a.dtype, a.act, a.spatial = inst, L.dtype_code(x), ACT_CODES[act], S
+    a.slope, a.eps = float(slope), float(eps)
+    y = torch.empty_like(x)
+    mean = torch.empty(inst, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(inst, dtype=torch.float32, device=x.device)
+    ws_bytes = lib.dll.segm_instnorm_workspace_bytes(inst, S)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    a.x, a.residual, a.y = x.data_ptr(), (residual.data_ptr() if residual is not None else None), y.data_ptr()
+    a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
+    a.workspace, a.workspace_bytes, a.stream = ws.data_ptr(), ws_bytes, L.stream_handle(x)
+    lib.check(lib.dll.segm_instnorm_fwd(a), "instnorm_fwd")
+    return y, mean, rstd
+
+
+def instnorm_bwd(lib: L.SegmLib, x, dy, mean, rstd, y=None, act="none", slope=0.01, want_dresidual=False):
+    """-> (dx, dresidual or None).  `y` is needed iff act != none and the forward added a residual."""
+    inst, S = _norm_geom(x)
+    if dy.shape != x.shape or dy.dtype != x.dtype:
+        raise RuntimeError("instnorm: dy must match x")
+    dy = dy.contiguous()
+    a = L.InstNormBwdArgs()
+    a.instances, a.dtype, a.act, a.spatial = inst, L.dtype_code(x), ACT_CODES[act], S
+    a.slope = float(slope)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dresidual else None
+    ws_bytes = lib.dll.segm_instnorm_workspace_bytes(inst, S)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    a.x, a.dy, a.y = x.data_ptr(), dy.data_ptr(), (y.data_ptr() if y is not None else None)
+    a.mean, a.rstd, a.dx = mean.data_ptr(), rstd.data_ptr(), dx.data_ptr()
+    a.dresidual = dres.data_ptr() if dres is not None else None
+    a.workspace, a.workspace_bytes, a.stream = ws.data_ptr(), ws_bytes, L.stream_handle(x)
+    lib.check(lib.dll.segm_instnorm_bwd(a), "instnorm_bwd")
+    return dx, dres

@@ -134,6 +134,8 @@ static inline float atomicAdd(float* addr, float val) {
 // vector types / raw builtins used by the kernels
 struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
 struct float2 { float x, y; } __attribute__((aligned(8)));
+struct uint4 { unsigned x, y, z, w; } __attribute__((aligned(16)));
+static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
 static inline float hipemu_exp2f(float x) { return exp2f(x); }
 static inline float hipemu_rcpf(float x) { return 1.0f / x; }
 static inline float hipemu_log2f(float x) { return log2f(x); }

@@ -147,3 +147,46 @@ def test_conv3d_k3_wgrad_channel_slices_and_errors_emulated(emu):
     assert not ops_raw.conv3d_k3_wgrad_supported(xs.float(), dys.float())          # dtype
     with pytest.raises(RuntimeError):
         ops_raw.conv3d_k3_wgrad(emu, xb[:, :40], dyb[:, :48])
+
+
+def _instnorm_reference(x, res, act, slope, gy):
+    import torch.nn.functional as F
+    x = x.double().requires_grad_()
+    res = res.double().requires_grad_() if res is not None else None
+    y = F.instance_norm(x, eps=1e-5)
+    if res is not None:
+        y = y + res
+    if act == "relu":
+        y = F.relu(y)
+    elif act == "leaky_relu":
+        y = F.leaky_relu(y, slope)
+    grads = torch.autograd.grad(y, (x,) if res is None else (x, res), gy.double())
+    return y, grads
+
+
+@pytest.mark.parametrize("shape,act,with_res,dtype", [
+    ((2, 3, 4, 8, 16), "leaky_relu", False, torch.float32),      # vector path, one slab
+    ((1, 2, 3, 5, 7), "relu", True, torch.float32),              # odd size: scalar path
+    ((1, 2, 16, 32, 48), "leaky_relu", True, torch.float32),     # several slabs per instance (Chan merge)
+    ((2, 2, 4, 8, 16), "none", False, torch.bfloat16),
+    ((1, 3, 4, 8, 16), "leaky_relu", True, torch.bfloat16),
+])
+def test_instance_norm_act_emulated(emu, shape, act, with_res, dtype):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(dtype)
+    res = torch.randn(shape, generator=g).to(dtype) if with_res else None
+    gy = torch.randn(shape, generator=g).to(dtype)
+    ref_y, ref_g = _instnorm_reference(x, res, act, 0.01, gy)
+    y, mean, rstd = ops_raw.instnorm_fwd(emu, x, res, act, 0.01, 1e-5)
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert (y.double() - ref_y).abs().max() < tol
+    xd = x.double().flatten(2)
+    assert torch.allclose(mean.double(), xd.mean(-1).flatten(), atol=1e-5)
+    assert torch.allclose(rstd.double(), (xd.var(-1, unbiased=False) + 1e-5).rsqrt().flatten(), rtol=1e-4)
+    dx, dres = ops_raw.instnorm_bwd(emu, x, gy, mean, rstd, y if (with_res and act != "none") else None, act, 0.01,
+                                    want_dresidual=with_res)
+    # the activation mask of the oracle is computed in fp64, the kernel's from the dtype-rounded values: compare away
+    # from the kink
+    assert (dx.double() - ref_g[0]).abs().max() < tol * 4
+    if with_res:
+        assert (dres.double() - ref_g[1]).abs().max() < tol
