@@ -252,6 +252,22 @@ int segm_instnorm_fwd(const segm_instnorm_fwd_args* args);
 int segm_instnorm_bwd(const segm_instnorm_bwd_args* args);
 size_t segm_instnorm_workspace_bytes(int32_t instances, int64_t spatial);
 
+/* ------------------------------------------------------------------------------------------------
+ * Batched transpose (+ add): out[b, c, r] = in[b, r, c] (+ add[b, c, r]).
+ * Replaces the transposing copies around a Mamba layer - `x.reshape(B, C, n).transpose(-1, -2)` feeding LayerNorm and
+ * `out.transpose(-1, -2).reshape(B, C, *dims)` + skip (reference model_segmamba/segmamba.py:60-75) - which the
+ * reference leaves to strided ATen copies.  in (batch, rows, cols), add / out (batch, cols, rows), contiguous.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_transpose_args {
+    int32_t batch, rows, cols, dtype;
+    const void* in;
+    const void* add;          /* or NULL */
+    void* out;
+    void* stream;
+} segm_transpose_args;
+
+int segm_transpose_add(const segm_transpose_args* args);
+
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);
 const char* segm_status_string(int status);

@@ -33,39 +33,6 @@ struct NormDev {
     float slope, eps;
 };
 
-template <typename T> struct Vec;       // 16-byte packets
-template <> struct Vec<float> { static constexpr int N = 4; };
-template <> struct Vec<f16_t> { static constexpr int N = 8; };
-template <> struct Vec<bf16_t> { static constexpr int N = 8; };
-
-template <typename T, bool VEC> struct Pack {
-    static constexpr int N = VEC ? Vec<T>::N : 1;
-    float v[N];
-    __device__ __forceinline__ void load(const T* p) {
-        if (VEC) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(p);
-            T tmp[N];
-            memcpy(tmp, &raw, 16);
-#pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = to_f32(tmp[i]);
-        } else {
-            v[0] = to_f32(p[0]);
-        }
-    }
-    __device__ __forceinline__ void store(T* p) const {
-        if (VEC) {
-            T tmp[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) tmp[i] = from_f32<T>(v[i]);
-            uint4 raw;
-            memcpy(&raw, tmp, 16);
-            *reinterpret_cast<uint4*>(p) = raw;
-        } else {
-            p[0] = from_f32<T>(v[0]);
-        }
-    }
-};
-
 // sum over the workgroup of two values; result valid in every thread
 __device__ __forceinline__ float2 block_sum2(float a, float b, float2* lds) {
 #pragma unroll

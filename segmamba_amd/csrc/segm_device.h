@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/segmamba_hip.h"
 
@@ -39,6 +40,40 @@ typedef __bf16 bf16_t;
 
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// ---- 16-byte packets of a tensor's element type (HBM-bound elementwise kernels) ------------------------------
+template <typename T> struct Vec;       // 16-byte packets
+template <> struct Vec<float> { static constexpr int N = 4; };
+template <> struct Vec<f16_t> { static constexpr int N = 8; };
+template <> struct Vec<bf16_t> { static constexpr int N = 8; };
+
+template <typename T, bool VEC> struct Pack {
+    static constexpr int N = VEC ? Vec<T>::N : 1;
+    float v[N];
+    __device__ __forceinline__ void load(const T* p) {
+        if (VEC) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(p);
+            T tmp[N];
+            memcpy(tmp, &raw, 16);
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = to_f32(tmp[i]);
+        } else {
+            v[0] = to_f32(p[0]);
+        }
+    }
+    __device__ __forceinline__ void store(T* p) const {
+        if (VEC) {
+            T tmp[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) tmp[i] = from_f32<T>(v[i]);
+            uint4 raw;
+            memcpy(&raw, tmp, 16);
+            *reinterpret_cast<uint4*>(p) = raw;
+        } else {
+            p[0] = from_f32<T>(v[0]);
+        }
+    }
+};
 
 // ---- math (fast hardware forms; every use is a per-element or per-(element,state) hot op) -------
 // raw v_exp_f32: results below 2^-126 flush to zero, which is benign for decay factors / sigmoid tails

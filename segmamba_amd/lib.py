@@ -110,12 +110,19 @@ class InstNormBwdArgs(C.Structure):
     ]
 
 
+class TransposeArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("dtype", C.c_int32),
+        ("in_", C.c_void_p), ("add", C.c_void_p), ("out", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
 EXPORTS = (
     "segm_selective_scan_fwd", "segm_selective_scan_fwd_workspace_bytes", "segm_selective_scan_ckpt_bytes",
     "segm_selective_scan_default_chunk", "segm_selective_scan_bwd", "segm_selective_scan_bwd_workspace_bytes",
     "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
     "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes",
-    "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes",
+    "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -148,6 +155,7 @@ class SegmLib:
         sig("segm_instnorm_fwd", [C.POINTER(InstNormFwdArgs)], C.c_int)
         sig("segm_instnorm_bwd", [C.POINTER(InstNormBwdArgs)], C.c_int)
         sig("segm_instnorm_workspace_bytes", [C.c_int32, C.c_int64], C.c_size_t)
+        sig("segm_transpose_add", [C.POINTER(TransposeArgs)], C.c_int)
         sig("segm_abi_version", [], C.c_int)
         sig("segm_status_string", [C.c_int], C.c_char_p)
 

@@ -309,3 +309,22 @@ def instnorm_bwd(lib: L.SegmLib, x, dy, mean, rstd, y=None, act="none", slope=0.
     a.workspace, a.workspace_bytes, a.stream = ws.data_ptr(), ws_bytes, L.stream_handle(x)
     lib.check(lib.dll.segm_instnorm_bwd(a), "instnorm_bwd")
     return dx, dres
+
+
+# ---------------------------------------------------------------------------------------------------------
+# channel-first <-> channel-last
+# ---------------------------------------------------------------------------------------------------------
+def transpose_add(lib: L.SegmLib, x: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (B, R, C) contiguous -> (B, C, R) contiguous (+ add, which already has the output layout)."""
+    if x.dim() != 3 or not x.is_contiguous():
+        raise RuntimeError("transpose_add: x must be a contiguous (B, R, C) tensor")
+    B, R, Cc = x.shape
+    out = torch.empty(B, Cc, R, dtype=x.dtype, device=x.device)
+    if add is not None and (add.shape != out.shape or add.dtype != x.dtype or not add.is_contiguous()):
+        raise RuntimeError("transpose_add: add must be a contiguous (B, C, R) tensor of x's dtype")
+    a = L.TransposeArgs()
+    a.batch, a.rows, a.cols, a.dtype = B, R, Cc, L.dtype_code(x)
+    a.in_, a.add, a.out = x.data_ptr(), (add.data_ptr() if add is not None else None), out.data_ptr()
+    a.stream = L.stream_handle(x)
+    lib.check(lib.dll.segm_transpose_add(a), "transpose_add")
+    return out

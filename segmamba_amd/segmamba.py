@@ -18,7 +18,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import fused_norm
+from . import fused_norm, layout
 from .conv3d import conv3d_same
 from .mamba_simple import Mamba
 from .unet_blocks import UnetOutBlock, UnetrBasicBlock, UnetrUpBlock
@@ -39,9 +39,9 @@ class MambaLayer(nn.Module):
         assert C == self.dim
         img_dims = x.shape[2:]
         n_tokens = img_dims.numel()
-        tokens = x.reshape(B, C, n_tokens).transpose(-1, -2)        # (B, L, C) view
+        tokens = layout.volume_to_tokens(x)                          # (B, L, C), one tiled transpose
         mixed = self.mamba(self.norm(tokens))                        # (B, L, C)
-        return mixed.transpose(-1, -2).reshape(B, C, *img_dims) + x
+        return layout.tokens_to_volume_add(mixed, x)                 # transpose back fused with the skip
 
 
 class MlpChannel(nn.Module):

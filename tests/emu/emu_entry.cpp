@@ -6,3 +6,4 @@
 #include "../../segmamba_amd/csrc/scan_bwd.hip"
 #include "../../segmamba_amd/csrc/conv3d_wgrad.hip"
 #include "../../segmamba_amd/csrc/instnorm.hip"
+#include "../../segmamba_amd/csrc/layout.hip"

@@ -190,3 +190,15 @@ def test_instance_norm_act_emulated(emu, shape, act, with_res, dtype):
     assert (dx.double() - ref_g[0]).abs().max() < tol * 4
     if with_res:
         assert (dres.double() - ref_g[1]).abs().max() < tol
+
+
+@pytest.mark.parametrize("shape,dtype,with_add", [((2, 48, 200), torch.bfloat16, True), ((1, 130, 72), torch.float32, False),
+                                                  ((1, 7, 13), torch.float32, True), ((2, 64, 64), torch.float16, False)])
+def test_transpose_add_emulated(emu, shape, dtype, with_add):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(dtype)
+    add = torch.randn(shape[0], shape[2], shape[1], generator=g).to(dtype) if with_add else None
+    out = ops_raw.transpose_add(emu, x, add)
+    ref = x.transpose(1, 2).float() + (add.float() if with_add else 0)
+    assert out.shape == (shape[0], shape[2], shape[1]) and out.is_contiguous()
+    assert torch.equal(out, ref.to(dtype))

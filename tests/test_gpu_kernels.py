@@ -309,3 +309,29 @@ def test_instance_norm_full_size_properties(hip):
     dxf = dx.float().flatten(2)
     assert dxf.mean(-1).abs().max() < 2e-3                         # dx is orthogonal to 1 ...
     assert (dxf * yf).mean(-1).abs().max() < 5e-3                  # ... and to xhat
+
+
+# ---- channel-first <-> channel-last transposes ----------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 48, 32768), (2, 4096, 384), (1, 130, 72), (3, 7, 13), (2, 768, 512)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_transpose_add_bit_exact(hip, shape, dtype):
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(shape, device=DEV, generator=g).to(dtype)
+    add = torch.randn(shape[0], shape[2], shape[1], device=DEV, generator=g).to(dtype)
+    assert torch.equal(ops_raw.transpose_add(hip, x), x.transpose(1, 2).contiguous())           # a pure move: bit exact
+    assert torch.equal(ops_raw.transpose_add(hip, x, add), (x.transpose(1, 2).float() + add.float()).to(dtype))
+
+
+def test_token_layout_autograd_full_size(hip):
+    from segmamba_amd import layout
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(2, 48, 128, 128, 128, device=DEV, generator=g).bfloat16().requires_grad_()
+    tok = layout.volume_to_tokens(x)
+    assert tok.shape == (2, 128 ** 3, 48) and torch.equal(tok, x.detach().flatten(2).transpose(1, 2))
+    w = torch.randn(2, 128 ** 3, 48, device=DEV, generator=g).bfloat16()
+    y = layout.tokens_to_volume_add(tok * w, x)                     # round trip + skip
+    gy = torch.randn(y.shape, device=DEV, generator=g).bfloat16()
+    (gx,) = torch.autograd.grad(y, x, gy)
+    wv = w.transpose(1, 2).reshape(x.shape)
+    assert torch.equal(y, (x.detach() * wv).float().add(x.detach().float()).bfloat16())
+    assert (gx.float() - (gy.float() * wv.float() + gy.float())).abs().max() <= 0.05      # one bf16 rounding of each term
