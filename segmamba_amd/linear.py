@@ -80,6 +80,12 @@ class _LinearCL(torch.autograd.Function):
         return dx, dw, db
 
 
+def _bmm_w(w: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """w (M, K) times every x[b] (K, S) -> (B, M, S) contiguous.  (torch.matmul would fold the batch into the rows of
+    a transposed product, which costs a transposing copy of x and returns a channel-last result.)"""
+    return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
+
+
 class _Pointwise(torch.autograd.Function):
     """1x1x1 convolution y[b] = W x[b] on x (B, Cin, S) in either memory order -> y (B, Cout, S) channel-first."""
 
@@ -87,7 +93,7 @@ class _Pointwise(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        y = torch.matmul(w, x)
+        y = _bmm_w(w, x)
         if b is not None:
             y += b.view(1, -1, 1)
         return y
@@ -99,7 +105,7 @@ class _Pointwise(torch.autograd.Function):
         if dy.stride(2) != 1 and dy.stride(1) != 1:
             dy = dy.contiguous()
         if ctx.needs_input_grad[0]:
-            dx = torch.matmul(w.t(), dy)
+            dx = _bmm_w(w.t(), dy)
         if ctx.needs_input_grad[1]:
             if x.stride(2) == 1 and dy.stride(2) == 1:
                 dw = nt_matmul_rows(dy, x).to(w.dtype)
