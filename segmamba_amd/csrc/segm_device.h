@@ -35,6 +35,11 @@ constexpr float kLog2e = 1.4426950408889634f;
 #define SEGM_PIN_F32(x) asm volatile("" : "+v"(x) : : "memory")
 #endif
 
+// Nothing is scheduled across this point (machine scheduler fence); defined away in the CPU emulation build.
+#ifndef SEGM_SCHED_FENCE
+#define SEGM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 typedef _Float16 f16_t;
 typedef __bf16 bf16_t;
 

@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out
+export MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD=0 MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD=0 MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW=0
+timeout 300 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "conv3d" > gpurun_out/r9_wgrad_tests.log 2>&1
+tail -3 gpurun_out/r9_wgrad_tests.log
+timeout 300 python tools/gpu_wgrad_time.py > gpurun_out/r9_wgrad_time.log 2>&1
+grep -v amdgpu.ids gpurun_out/r9_wgrad_time.log | tail -4
