@@ -187,7 +187,7 @@ size_t segm_causal_conv1d_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_
  *
  * x, dy: bf16, logical (batch, channel, depth, height, width), W contiguous, every other stride a multiple of 8
  * elements, 16-byte aligned bases (channel slices of NCDHW tensors qualify).  cin, cout multiples of 48, width a
- * multiple of 32.  dw: contiguous (cout, cin, 3, 3, 3), fp32 or bf16, OVERWRITTEN.
+ * multiple of 8.  dw: contiguous (cout, cin, 3, 3, 3), fp32 or bf16, OVERWRITTEN.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct segm_conv3d_wgrad_args {
     int32_t batch, cin, cout, depth, height, width;

@@ -123,7 +123,7 @@ def _wgrad_mfma(x, dy, w, pad):
 def _mfma_wgrad_ok(x, dy, w) -> bool:
     if w.shape[2:] != (3, 3, 3) or w.dtype not in (torch.bfloat16, torch.float32) or x.dtype != torch.bfloat16:
         return False
-    return x.shape[1] % 48 == 0 and dy.shape[1] % 48 == 0 and x.shape[4] % 32 == 0 and x.shape[0] == dy.shape[0]
+    return x.shape[1] % 48 == 0 and dy.shape[1] % 48 == 0 and x.shape[4] % 8 == 0 and x.shape[0] == dy.shape[0]
 
 
 class _ConvSame(torch.autograd.Function):

@@ -12,17 +12,24 @@
 // per lane = one 16-byte load).  The three x-shifts are built from ONE aligned 16-byte load plus two halo dwords with
 // v_alignbyte, so every global access stays aligned.
 //
-//   workgroup = 3 waves: wave ky of workgroup (slab, co block, kz, ci block) owns the three kx taps of tap row
-//               (kz, ky) for a 32 x 48 (co, ci) block: 2 (co tiles) x 3 (kx) x 3 (ci tiles) accumulators of 16x16
-//               (72 VGPRs, fp32).  One step = one row (b, z, y) of dY times the row (z+kz-1, y+ky-1) of X over 32 x
-//               positions: 2 + 3 aligned 16-byte loads and 6 halo dwords (all unconditional: clamped addresses,
-//               masked values, issued together) feed 18 MFMAs.  Small workgroups and <= 128 VGPRs keep 4 waves per
-//               SIMD resident, which is what hides the latency of the channel-strided NCDHW rows; the three ky
-//               waves of a workgroup read the same dY rows and X rows one / two steps apart (L1 hits).
-//               An odd last co tile (cout = 48) is a second launch with one co tile per workgroup.
-//   grid      = (row slabs, co blocks of 32, ci blocks of 48); each workgroup walks its slab of (b, z, y) rows and
-//               writes its partial 27 x 32 x 48 block; a second kernel sums the slabs in a fixed order
-//               (deterministic, no atomics) and converts to the weight dtype.
+// What bounds it is operand traffic, not arithmetic: with only 48 channels every X element feeds 27 x 32 MACs, so
+// fetching operands per tap from L2 (a first version: 15.6 GB of L1 fills for 0.8 GB of tensors, 4 ms) leaves the MFMA
+// pipe idle.  Operands are therefore staged once per workgroup in LDS:
+//
+//   workgroup = 3 waves (ky = wave) for one tap plane kz, one 32 x 48 (co, ci) block and one work item
+//               (batch b, depth z, 64-wide x block, y range).  It walks y; an LDS ring of 4 rows holds
+//               X[ci block][z+kz-1][y-1 .. y+2][x block + 8 halo columns each side] (each X row is fetched ONCE and
+//               used by the three ky waves on three consecutive steps), a double buffer holds the dY row.  While the
+//               waves run the 36 MFMAs of step y (2 k-chunks x 2 co tiles x 3 kx x 3 ci tiles), the row y+2 and the
+//               next dY row are already in flight global -> registers; they are parked in LDS after the MFMAs; one
+//               barrier per step.
+//   fragments   A (dY) and B (X) fragments are 16-byte LDS reads; the kx = 0 / 2 operands are built from the aligned
+//               read plus two halo dwords with v_alignbyte.  Zero padding in x / y / z is materialised as zero rows /
+//               columns in LDS, so the inner loop has no masks.  Row pitch 88 elements (44 dwords): the 16 lanes of a
+//               fragment read hit 16 distinct 4-bank groups.
+//   grid      = (work items, 3 kz x co blocks of 32, ci blocks of 48); every workgroup writes its 9 x 32 x 48 partial
+//               taps; a second kernel sums the work items in a fixed order (deterministic, no atomics) and converts
+//               to the weight dtype.  An odd last co tile (cout = 48) is a second launch with one co tile.
 // v_mfma_f32_16x16x32_bf16 operand layout (cdna_hip_programming.md §3): lane l holds A[i = l & 15][k = 8 (l >> 4) .. +7],
 // B[k = 8 (l >> 4) .. +7][j = l & 15]; result D[row = 4 (l >> 4) + r][col = l & 15], r = 0..3.
 #include <string.h>
@@ -38,127 +45,155 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWgBlock = 48;                 // input channels per block; cin and cout must be multiples of it
 constexpr int kWgCo = 32;                    // output channels per workgroup (2 MFMA tiles)
 constexpr int kWgWaves = 3;                  // ky
+constexpr int kWgThreads = kWgWaves * 64;
+constexpr int kPitch = 88;                   // LDS row pitch (elements): 8 halo + 64 + 8 halo + 8 (bank spread)
+constexpr int kXGran = 10;                   // 16-byte granules of an X row in LDS (NQ = 2): halo, 8 data, halo
+constexpr int kCopies = 4;                   // granules per thread per step: ceil((48 * 10 + 32 * 8) / 192)
 
 struct WgradDev {
     const char* x;   int64_t x_sb, x_sc, x_sz, x_sy;      // element strides, x contiguous
     const char* dy;  int64_t dy_sb, dy_sc, dy_sz, dy_sy;
-    float* part;                                          // [co blk][ci blk][slab][27][32][48]
+    float* part;                                          // [co blk][ci blk][item][27][32][48]
     int32_t B, D, H, W, cob0;
-    int32_t rows_per_slab, nslab;
+    int32_t nxb, ysplit, rows_per_part, nitems;
     int32_t ncob, ncib;
 };
 
-// operands of one step, as loaded
-struct WgStep {
-    u32x4 a[2];                // dY fragments, one per co tile
-    u32x4 v[3];                // X fragments (aligned), one per ci tile
-    uint32_t hl[3], hr[3];     // halo dwords: elements (x-2, x-1) and (x+8, x+9), unmasked as loaded
-    bool has_l, has_r;         // whether those exist (zero padding in x otherwise): applied when the step is used,
-                               // so that nothing waits on the loads at issue time
-    bool ok;                   // the step contributes (wave-uniform): its X row is not in the z / y zero padding
+// One thread's share of the per-step global -> LDS copy: up to kCopies 16-byte granules.
+struct WgCopy {
+    int64_t src[kCopies];      // element offset from the row base (X granules: from the X row, dY granules: from the dY row)
+    int32_t dst[kCopies];      // element offset inside an X ring slot / a dY buffer
+    bool is_x[kCopies], live[kCopies], inside[kCopies];   // inside: the granule's x range is inside the volume
 };
 
-// position of a step inside the volume (all wave-uniform)
-struct WgPos {
-    int b, z, y, q;
-    __device__ __forceinline__ void advance(const WgradDev& P, int nq) {
-        if (++q < nq) return;
-        q = 0;
-        if (++y < P.H) return;
-        y = 0;
-        if (++z < P.D) return;
-        z = 0; ++b;
-    }
-};
-
-__device__ __forceinline__ void wg_load(WgStep& f, const WgradDev& P, const WgPos& p, int kz, int ky, int g,
-                                        const __bf16* dyp, const __bf16* xp, int64_t dy_t1) {
-    const int zz = p.z + kz - 1, yy = p.y + ky - 1;
-    const bool ok = zz >= 0 && zz < P.D && yy >= 0 && yy < P.H;       // zero padding in z / y: the step contributes nothing
-    const int zc = ok ? zz : p.z, yc = ok ? yy : p.y;
-    const __bf16* dyr = dyp + (int64_t)p.b * P.dy_sb + (int64_t)p.z * P.dy_sz + (int64_t)p.y * P.dy_sy + 32 * p.q;
-    const __bf16* xr = xp + (int64_t)p.b * P.x_sb + (int64_t)zc * P.x_sz + (int64_t)yc * P.x_sy + 32 * p.q;
-    const int xoff = 32 * p.q + 8 * g;                                // first x of this lane's 8 reduction elements
-    f.has_l = xoff > 0;
-    f.has_r = xoff + 8 < P.W;
-    f.ok = ok;
-    f.a[0] = *reinterpret_cast<const u32x4*>(dyr);
-    f.a[1] = *reinterpret_cast<const u32x4*>(dyr + dy_t1);           // dy_t1 = 0 when the block has a single co tile
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const __bf16* xc = xr + (int64_t)(16 * t) * P.x_sc;
-        f.v[t] = *reinterpret_cast<const u32x4*>(xc);
-        f.hl[t] = *reinterpret_cast<const uint32_t*>(xc + (f.has_l ? -2 : 0));
-        f.hr[t] = *reinterpret_cast<const uint32_t*>(xc + (f.has_r ? 8 : 6));
-    }
-}
-
-// the 18 (NCO = 2) or 9 MFMAs of one step.  Straight-line code: every loaded register is consumed on every path
-// (a step in the z / y padding multiplies by a zeroed dY fragment instead of being skipped), otherwise the compiler
-// has to drain all outstanding loads before the next look-ahead load may overwrite the buffer.
-template <int NCO>
-__device__ __forceinline__ void wg_compute(f32x4 (&acc)[2][3][3], const WgStep& f) {
-    const u32x4 zero = {0u, 0u, 0u, 0u};
-    bf16x8 a[NCO];
-#pragma unroll
-    for (int co = 0; co < NCO; ++co) a[co] = __builtin_bit_cast(bf16x8, f.ok ? f.a[co] : zero);
-#pragma unroll
-    for (int ci = 0; ci < 3; ++ci) {
-        const u32x4 v = f.v[ci];
-        const uint32_t hl = f.has_l ? f.hl[ci] : 0u, hr = f.has_r ? f.hr[ci] : 0u;
-        const uint32_t s1 = __builtin_amdgcn_alignbyte(v[1], v[0], 2);
-        const uint32_t s2 = __builtin_amdgcn_alignbyte(v[2], v[1], 2);
-        const uint32_t s3 = __builtin_amdgcn_alignbyte(v[3], v[2], 2);
-        const u32x4 vl = {__builtin_amdgcn_alignbyte(v[0], hl, 2), s1, s2, s3};   // X[x-1 ..]  (kx = 0)
-        const u32x4 vr = {s1, s2, s3, __builtin_amdgcn_alignbyte(hr, v[3], 2)};   // X[x+1 ..]  (kx = 2)
-#pragma unroll
-        for (int co = 0; co < NCO; ++co) {
-            acc[co][0][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[co], __builtin_bit_cast(bf16x8, vl), acc[co][0][ci], 0, 0, 0);
-            acc[co][1][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[co], __builtin_bit_cast(bf16x8, v), acc[co][1][ci], 0, 0, 0);
-            acc[co][2][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[co], __builtin_bit_cast(bf16x8, vr), acc[co][2][ci], 0, 0, 0);
-        }
-    }
-}
-
-template <int NCO>
-__global__ void __launch_bounds__(kWgWaves * 64, 4) conv3d_k3_wgrad_kernel(WgradDev P) {
-    const int lane = threadIdx.x & 63;
-    const int ky = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // scalar: row / tap arithmetic stays on the SALU
-    const int kz = blockIdx.y % 3;
+template <int NCO, int NQ>
+__global__ void __launch_bounds__(kWgThreads, 3) conv3d_k3_wgrad_kernel(WgradDev P) {
+    __shared__ __attribute__((aligned(16))) __bf16 xs[4][kWgBlock][kPitch];
+    __shared__ __attribute__((aligned(16))) __bf16 dys[2][kWgCo][kPitch];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ky = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: row / tap arithmetic stays on the SALU
     const int i16 = lane & 15, g = lane >> 4;
-    const int slab = blockIdx.x, cob = blockIdx.y / 3 + P.cob0, cib = blockIdx.z;
-    const int nrows = P.B * P.D * P.H;
-    const int r0 = slab * P.rows_per_slab;
-    const int r1 = (r0 + P.rows_per_slab < nrows) ? r0 + P.rows_per_slab : nrows;
-    const int nq = P.W / 32;                              // 32-wide reduction chunks per row
-    const int nsteps = (r1 > r0 ? r1 - r0 : 0) * nq;
+    const int kz = blockIdx.y % 3, cob = blockIdx.y / 3 + P.cob0, cib = blockIdx.z;
+    int item = blockIdx.x;
+    const int ypart = item % P.ysplit;  item /= P.ysplit;
+    const int xb = item % P.nxb;        item /= P.nxb;
+    const int z = item % P.D, b = item / P.D;
+    const int zz = z + kz - 1;
+    const bool plane_ok = zz >= 0 && zz < P.D;                       // else: the whole tap plane reads z padding -> zeros
+    const int y0 = ypart * P.rows_per_part;
+    const int y1 = (y0 + P.rows_per_part < P.H) ? y0 + P.rows_per_part : P.H;
+    constexpr int XB = 32 * NQ;
+    const int x0 = xb * XB;
 
     f32x4 acc[2][3][3];                                   // [co tile][kx][ci tile]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int d = 0; d < 3; ++d) acc[a][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const __bf16* dyp = reinterpret_cast<const __bf16*>(P.dy) + (int64_t)(cob * kWgCo + i16) * P.dy_sc + 8 * g;
-    const int64_t dy_t1 = NCO == 2 ? 16 * P.dy_sc : 0;
-    const __bf16* xp = reinterpret_cast<const __bf16*>(P.x) + (int64_t)(cib * kWgBlock + i16) * P.x_sc + 8 * g;
+    if (plane_ok && y1 > y0) {
+        // ---- copy plan -------------------------------------------------------------------------------------------
+        constexpr int XG = 4 * NQ + 2;                    // granules per X row: left halo, data, right halo
+        constexpr int DG = 4 * NQ;                        // granules per dY row
+        constexpr int NX = kWgBlock * XG, ND = NCO * 16 * DG;
+        WgCopy cp;
+#pragma unroll
+        for (int k = 0; k < kCopies; ++k) {
+            const int id = tid + k * kWgThreads;
+            cp.is_x[k] = id < NX;
+            cp.live[k] = id < NX + ND;
+            if (cp.is_x[k]) {
+                const int ci = id / XG, gr = id - ci * XG;
+                const int xg = x0 - 8 + 8 * gr;           // first x of the granule (W % 8 == 0: all inside or all outside)
+                cp.inside[k] = xg >= 0 && xg < P.W;
+                cp.src[k] = (int64_t)(cib * kWgBlock + ci) * P.x_sc + (cp.inside[k] ? xg : 0);
+                cp.dst[k] = ci * kPitch + 8 * gr;
+            } else {
+                const int j = cp.live[k] ? id - NX : 0;
+                const int co = j / DG, gr = j - co * DG;
+                cp.inside[k] = x0 + 8 * gr < P.W;         // widths below 32: the rest of the k-chunk is zero
+                cp.src[k] = (int64_t)(cob * kWgCo + co) * P.dy_sc + (cp.inside[k] ? x0 + 8 * gr : 0);
+                cp.dst[k] = co * kPitch + 8 * gr;
+            }
+        }
+        const __bf16* xplane = reinterpret_cast<const __bf16*>(P.x) + (int64_t)b * P.x_sb + (int64_t)zz * P.x_sz;
+        const __bf16* dyplane = reinterpret_cast<const __bf16*>(P.dy) + (int64_t)b * P.dy_sb + (int64_t)z * P.dy_sz;
+        const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-    WgPos pos;
-    pos.q = 0;
-    pos.y = r0 % P.H;
-    pos.z = (r0 / P.H) % P.D;
-    pos.b = r0 / (P.H * P.D);
-    for (int s = 0; s < nsteps; ++s) {
-        WgStep f;
-        wg_load(f, P, pos, kz, ky, g, dyp, xp, dy_t1);
-        SEGM_SCHED_FENCE();        // all 11 loads are issued before the first MFMA (the scheduler otherwise trickles them)
-        wg_compute<NCO>(acc, f);
-        pos.advance(P, nq);
+        // fetch X row yy and dY row yd into registers (rows outside the volume / range read a valid row and are zeroed)
+        auto fetch = [&](u32x4 (&r)[kCopies], int yy, int yd) {
+            const bool x_ok = yy >= 0 && yy < P.H;
+            const __bf16* xr = xplane + (int64_t)(x_ok ? yy : 0) * P.x_sy;
+            const __bf16* dr = dyplane + (int64_t)(yd < P.H ? yd : 0) * P.dy_sy;
+#pragma unroll
+            for (int k = 0; k < kCopies; ++k) {
+                const __bf16* src = (cp.is_x[k] ? xr : dr) + cp.src[k];
+                r[k] = *reinterpret_cast<const u32x4*>(src);
+            }
+        };
+        auto park = [&](const u32x4 (&r)[kCopies], int yy, int slot, int buf) {
+            const bool x_ok = yy >= 0 && yy < P.H;
+#pragma unroll
+            for (int k = 0; k < kCopies; ++k) {
+                if (!cp.live[k]) continue;
+                const bool keep = cp.is_x[k] ? (x_ok && cp.inside[k]) : cp.inside[k];
+                __bf16* dst = (cp.is_x[k] ? &xs[slot][0][0] : &dys[buf][0][0]) + cp.dst[k];
+                *reinterpret_cast<u32x4*>(dst) = keep ? r[k] : zero4;
+            }
+        };
+
+        // ---- prologue: rows y0 - 1, y0, y0 + 1 and dY row y0 ---------------------------------------------------------
+        {
+            u32x4 r[kCopies];
+#pragma unroll
+            for (int d = -1; d <= 1; ++d) {
+                fetch(r, y0 + d, y0);
+                park(r, y0 + d, (y0 + d + 4) & 3, 0);     // the dY row is parked three times (same data): harmless
+            }
+        }
+        __syncthreads();
+
+        // ---- main loop ------------------------------------------------------------------------------------------------
+        for (int y = y0; y < y1; ++y) {
+            u32x4 r[kCopies];
+            fetch(r, y + 2, y + 1);                       // in flight during this step's MFMAs
+            SEGM_SCHED_FENCE();
+            const int slot = (y + ky - 1 + 4) & 3, buf = (y - y0) & 1;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                u32x4 av[NCO];
+#pragma unroll
+                for (int co = 0; co < NCO; ++co)
+                    av[co] = *reinterpret_cast<const u32x4*>(&dys[buf][co * 16 + i16][32 * q + 8 * g]);
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const __bf16* xc = &xs[slot][ci * 16 + i16][8 + 32 * q + 8 * g];
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(xc);
+                    const uint32_t hl = *reinterpret_cast<const uint32_t*>(xc - 2);     // elements (x-2, x-1)
+                    const uint32_t hr = *reinterpret_cast<const uint32_t*>(xc + 8);     // elements (x+8, x+9)
+                    const uint32_t s1 = __builtin_amdgcn_alignbyte(v[1], v[0], 2);
+                    const uint32_t s2 = __builtin_amdgcn_alignbyte(v[2], v[1], 2);
+                    const uint32_t s3 = __builtin_amdgcn_alignbyte(v[3], v[2], 2);
+                    const u32x4 vl = {__builtin_amdgcn_alignbyte(v[0], hl, 2), s1, s2, s3};   // X[x-1 ..]  (kx = 0)
+                    const u32x4 vr = {s1, s2, s3, __builtin_amdgcn_alignbyte(hr, v[3], 2)};   // X[x+1 ..]  (kx = 2)
+#pragma unroll
+                    for (int co = 0; co < NCO; ++co) {
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, av[co]);
+                        acc[co][0][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, vl), acc[co][0][ci], 0, 0, 0);
+                        acc[co][1][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, v), acc[co][1][ci], 0, 0, 0);
+                        acc[co][2][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, vr), acc[co][2][ci], 0, 0, 0);
+                    }
+                }
+            }
+            SEGM_SCHED_FENCE();
+            park(r, y + 2, (y + 2) & 3, buf ^ 1);
+            __syncthreads();
+        }
     }
-    // partial block: part[((cob * ncib + cib) * nslab + slab)][tap = kz*9 + ky*3 + kx][co (32)][ci (48)]
-    float* out = P.part + ((((int64_t)cob * P.ncib + cib) * P.nslab + slab) * 27) * (kWgCo * kWgBlock);
+    // partial block: part[((cob * ncib + cib) * nitems + item)][tap = kz*9 + ky*3 + kx][co (32)][ci (48)]
+    float* out = P.part + ((((int64_t)cob * P.ncib + cib) * P.nitems + blockIdx.x) * 27) * (kWgCo * kWgBlock);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -200,10 +235,19 @@ __global__ void __launch_bounds__(256) conv3d_k3_wgrad_reduce_kernel(const float
     }
 }
 
-static int wgrad_slabs(int nrows) {
-    int ns = 512;                                         // ~2 workgroups per CU
-    if (ns > nrows) ns = nrows;
-    return ns;
+// work decomposition: items = (batch, depth) planes x 64-wide (32 if W % 64) x blocks x y parts
+struct WgPlan { int nq, nxb, ysplit, rows_per_part, nitems; };
+static WgPlan wgrad_plan(int batch, int cin, int cout, int d, int h, int w) {
+    WgPlan p;
+    p.nq = (w % 64 == 0) ? 2 : 1;
+    p.nxb = (w + 32 * p.nq - 1) / (32 * p.nq);
+    const int64_t wgs = (int64_t)batch * d * p.nxb * 3 * ((cout + kWgCo - 1) / kWgCo) * (cin / kWgBlock);
+    int split = 1;                                        // cut y when there are too few workgroups to fill 256 CUs x 3
+    while (wgs * split < 1536 && h / (split * 2) >= 8) split *= 2;
+    p.ysplit = split;
+    p.rows_per_part = (h + split - 1) / split;
+    p.nitems = batch * d * p.nxb * split;
+    return p;
 }
 
 }  // namespace segm
@@ -212,8 +256,8 @@ using namespace segm;
 
 extern "C" size_t segm_conv3d_k3_wgrad_workspace_bytes(int32_t batch, int32_t cin, int32_t cout, int32_t d, int32_t h, int32_t w) {
     if (batch <= 0 || cin <= 0 || cout <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;
-    const int ns = wgrad_slabs(batch * d * h);
-    return (size_t)((cout + kWgCo - 1) / kWgCo) * (cin / kWgBlock) * ns * 27 * kWgCo * kWgBlock * sizeof(float);
+    const WgPlan pl = wgrad_plan(batch, cin, cout, d, h, w);
+    return (size_t)((cout + kWgCo - 1) / kWgCo) * (cin / kWgBlock) * pl.nitems * 27 * kWgCo * kWgBlock * sizeof(float);
 }
 
 extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
@@ -221,7 +265,7 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
     if (!a->x || !a->dy || !a->dw || !a->workspace) return SEGM_E_NULL;
     if (a->batch <= 0 || a->depth <= 0 || a->height <= 0 || a->width <= 0) return SEGM_E_SHAPE;
     if (a->cin % kWgBlock != 0 || a->cout % kWgBlock != 0 || a->cin <= 0 || a->cout <= 0) return SEGM_E_SHAPE;
-    if (a->width % 32 != 0) return SEGM_E_SHAPE;
+    if (a->width % 8 != 0) return SEGM_E_SHAPE;
     if (a->dtype != SEGM_BF16) return SEGM_E_DTYPE;
     if (a->dw_dtype != SEGM_BF16 && a->dw_dtype != SEGM_F32) return SEGM_E_DTYPE;
     // 16-byte aligned rows: every stride a multiple of 8 elements, base pointers 16-byte aligned
@@ -239,25 +283,29 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
     P.dy = (const char*)a->dy; P.dy_sb = a->dy_stride_b; P.dy_sc = a->dy_stride_c; P.dy_sz = a->dy_stride_z; P.dy_sy = a->dy_stride_y;
     P.part = (float*)a->workspace;
     P.B = a->batch; P.D = a->depth; P.H = a->height; P.W = a->width;
-    const int nrows = a->batch * a->depth * a->height;
-    P.nslab = wgrad_slabs(nrows);
-    P.rows_per_slab = (nrows + P.nslab - 1) / P.nslab;
+    const WgPlan pl = wgrad_plan(a->batch, a->cin, a->cout, a->depth, a->height, a->width);
+    P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part; P.nitems = pl.nitems;
     P.ncob = (a->cout + kWgCo - 1) / kWgCo; P.ncib = a->cin / kWgBlock;
     hipStream_t stream = (hipStream_t)a->stream;
     const int full = a->cout / kWgCo;                    // blocks with two co tiles; cout % 32 == 16 leaves one with a single tile
     P.cob0 = 0;
-    if (full > 0)
-        hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<2>), dim3(P.nslab, full * 3, P.ncib), dim3(kWgWaves * 64), 0, stream, P);
+    if (full > 0) {
+        const dim3 grid(P.nitems, full * 3, P.ncib);
+        if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<2, 2>), grid, dim3(kWgThreads), 0, stream, P);
+        else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<2, 1>), grid, dim3(kWgThreads), 0, stream, P);
+    }
     if (P.ncob > full) {
         P.cob0 = full;
-        hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<1>), dim3(P.nslab, 3, P.ncib), dim3(kWgWaves * 64), 0, stream, P);
+        const dim3 grid(P.nitems, 3, P.ncib);
+        if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<1, 2>), grid, dim3(kWgThreads), 0, stream, P);
+        else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<1, 1>), grid, dim3(kWgThreads), 0, stream, P);
     }
     const int total = a->cout * a->cin * 27;
     if (a->dw_dtype == SEGM_F32)
         hipLaunchKernelGGL((conv3d_k3_wgrad_reduce_kernel<float>), dim3((total + 63) / 64), dim3(256), 0, stream,
-                           (const float*)P.part, (float*)a->dw, P.nslab, P.ncib, a->cout, a->cin);
+                           (const float*)P.part, (float*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
     else
         hipLaunchKernelGGL((conv3d_k3_wgrad_reduce_kernel<bf16_t>), dim3((total + 63) / 64), dim3(256), 0, stream,
-                           (const float*)P.part, (bf16_t*)a->dw, P.nslab, P.ncib, a->cout, a->cin);
+                           (const float*)P.part, (bf16_t*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
     return (int)hipGetLastError();
 }

@@ -227,7 +227,7 @@ def conv3d_k3_wgrad_supported(x: torch.Tensor, dy: torch.Tensor) -> bool:
         return False
     if x.shape[0] != dy.shape[0] or x.shape[2:] != dy.shape[2:]:
         return False
-    if x.shape[1] % 48 or dy.shape[1] % 48 or x.shape[4] % 32:
+    if x.shape[1] % 48 or dy.shape[1] % 48 or x.shape[4] % 8:
         return False
     for t in (x, dy):
         if t.stride(4) != 1 or any(t.stride(i) % 8 for i in range(4)) or t.data_ptr() % 16:

@@ -212,7 +212,7 @@ def _aten_wgrad(x, dy):
 
 
 @pytest.mark.parametrize("shape", [(1, 48, 48, 8, 8, 32), (2, 48, 96, 5, 7, 64), (2, 96, 48, 16, 16, 32),
-                                   (1, 48, 48, 32, 32, 128)])
+                                   (1, 48, 48, 32, 32, 128), (2, 96, 48, 8, 8, 8), (1, 48, 96, 6, 16, 16), (1, 48, 48, 3, 9, 40)])
 def test_conv3d_k3_wgrad_matches_fp32_convolution_backward(hip, shape):
     B, cin, cout, D, H_, W = shape
     g = torch.Generator(device=DEV).manual_seed(sum(shape))
