@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
     for (int s0 = gm.chunk - TS; s0 >= 0; s0 -= TS) {
         float* lc = &s_c[buf][wave][it.gi][0];
         stage_park<TS, NS, RW, true>(sc, lc, t_fastest, it.r);
-        __syncthreads();
+        SEGM_WAVE_LDS_SYNC();
         float cd[TS], cg[TS], cz[TS];
 #pragma unroll
         for (int j = 0; j < TS; ++j) { cd[j] = nd[j]; cg[j] = ng[j]; cz[j] = nz[j]; }
@@ -257,11 +257,11 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MIN_WAVES) scan_bwd_main_kern
                 dD_acc = fmaf(wg[j], wu[j], dD_acc);
             }
         }
-        __syncthreads();                                    // the previous window is done with s_bc / s_dbc / s_rows
+        SEGM_WAVE_LDS_SYNC();                                    // the previous window is done with s_bc / s_dbc / s_rows
         stage_park<kWin, NS, RW, false>(sb, lb, bt_fastest, it.r);
         stage_park<kWin, NS, RW, false>(scc, lc, ct_fastest, it.r);
         if (it.r < kWin) lrows[it.r] = (item_ok && tw.tau + it.r < tm.L) ? tw.ahead(tm, it.r) : -1;
-        __syncthreads();
+        SEGM_WAVE_LDS_SYNC();
 
         // state entering the window = forward checkpoint (zero past the end of the sequence)
         const bool ck_ok = it.valid && tw.tau < tm.L;
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MIN_WAVES) scan_bwd_main_kern
             s_e[n][threadIdx.x] = en;
             s_dA[n][threadIdx.x] = dAn;
         }
-        __syncthreads();                                    // the dB / dC tile of every item is complete
+        SEGM_WAVE_LDS_SYNC();                                    // the dB / dC tile of every item is complete
         // flush the window's dB / dC tile: contiguous in whichever of (t, n) has the smaller stride
         {
             const bool n_fast = P.dB_sn <= P.dB_st;

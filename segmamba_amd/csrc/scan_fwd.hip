@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_kernel(ScanDev P) {
     for (int s0 = 0; s0 < gm.chunk; s0 += TS) {
         float* lb = &s_b[buf][wave][it.gi][0];
         stage_park<TS, NS, RW, true>(sb, lb, t_fastest, it.r);
-        __syncthreads();
+        SEGM_WAVE_LDS_SYNC();
         float cu[TS], cd[TS];
 #pragma unroll
         for (int j = 0; j < TS; ++j) { cu[j] = nu[j]; cd[j] = nd[j]; }
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_apply_kernel(ScanDev P) {
         float* lc = &s_bc[buf][wave][it.gi][1][0];
         stage_park<TS, NS, RW, true>(sb, lb, t_fastest, it.r);
         stage_park<TS, NS, RW, true>(sc, lc, t_fastest, it.r);
-        __syncthreads();
+        SEGM_WAVE_LDS_SYNC();
         float cu[TS], cd[TS], cz[TS];
         int32_t ctt[TS];               // rows of this sub-tile, for the stores
 #pragma unroll
@@ -390,6 +390,12 @@ static FwdWs fwd_ws_layout(int batch, int dim, int nstate, int64_t L, int chunk)
 static int apply_subtile() {
     static int ts = [] { const char* e = getenv("SEGM_APPLY_TS"); return (e && atoi(e) == 4) ? 4 : 8; }();
     return ts;
+}
+
+// SEGM_SCAN_FAST=0 forces the general kernels (A/B timing, and the tests that must exercise them on regular shapes)
+static bool use_fast_path() {
+    const char* e = getenv("SEGM_SCAN_FAST");
+    return !(e && e[0] == '0');
 }
 
 template <typename T, int NS, int RW>
@@ -531,7 +537,12 @@ extern "C" int segm_selective_scan_fwd(const segm_scan_fwd_args* a) {
         P.carry = (float*)(wsb + ws.carry) + (size_t)g * a->batch * nch * N * Dg;
         P.last_state = a->last_state ? a->last_state + (int64_t)g * Dg * N : nullptr;
         P.last_state_sb = (int64_t)a->dim * N;
-        if (a->dtype == SEGM_F32) rc = launch_fwd_ns<float>(P, stream);
+        if (use_fast_path() && scan_fast_shape(P)) {       // regular shapes (every SegMamba stage): scan_fwd_fast.hip
+            launch_scan_fwd_fast(P, a->dtype, false, stream);
+            launch_scan_carry(P, false, P.agg_sd, P.agg_h, P.carry, stream);
+            launch_scan_fwd_fast(P, a->dtype, true, stream);
+            rc = (int)hipGetLastError();
+        } else if (a->dtype == SEGM_F32) rc = launch_fwd_ns<float>(P, stream);
         else if (a->dtype == SEGM_F16) rc = launch_fwd_ns<f16_t>(P, stream);
         else rc = launch_fwd_ns<bf16_t>(P, stream);
         if (rc != 0) return rc;

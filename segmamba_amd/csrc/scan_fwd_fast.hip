@@ -1,0 +1,372 @@
+// Selective scan forward, the "regular shape" kernels (same algorithm and workspace as scan_fwd.hip's K1 / K3).
+//
+// scan_fwd.hip handles every shape: ragged chunk tails, padded channel tiles, arbitrary slice counts.  That generality
+// costs instructions the SegMamba shapes never need - per-lane time-index arithmetic, bounds masks and the selects that
+// apply them are ~45 % of the issue slots of its apply kernel (tools/isa_mix.py), and the kernel is VALU-issue bound
+// (profiles/r01_probe_valu.log: v_exp_f32 is half rate, nothing co-issues).  When
+//     nstate == 16,  dim % RW == 0,  L % chunk == 0,  nchunks % (64/RW) == 0,  and the time order is affine inside a
+//     sub-tile and identical for every work item  (FORWARD / REVERSED always; INTERLEAVED when nslices % 8 == 0 and
+//     chunk % nslices == 0)
+// the host launches these kernels instead:
+//   * address = wave-uniform base (SGPR arithmetic: batch, sub-tile, step) + one per-lane byte offset that is constant
+//     for the whole kernel - no per-access VALU address math, no masks;
+//   * the 16-state update runs on packed fp32 (v_pk_mul_f32 / v_pk_fma_f32: two states per instruction), which halves
+//     the non-transcendental issue slots of a step:  per state pair  2 v_exp + 2 v_pk_mul + 1 (agg) or 2 (apply) v_pk_fma.
+// Results are bit-identical in structure to the general kernels (same operation order per state), so the backward pass
+// and the checkpoint format are unchanged.
+#include <limits.h>
+
+#include "scan_common.h"
+
+namespace segm {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#ifndef SEGM_PIN_F2
+#define SEGM_PIN_F2(x) asm volatile("" : "+v"(x) : : "memory")
+#endif
+
+#ifndef SEGM_FAST_MIN_WAVES
+#define SEGM_FAST_MIN_WAVES 2       // waves per SIMD the apply kernel is register-limited to
+#endif
+
+constexpr int kFS = 16;     // states
+constexpr int kFT = 8;      // steps per sub-tile
+
+// Wave-uniform description of where sub-tile s of every work item lives: physical row = T_item + U(s) + i * dT.
+struct FastClock {
+    int32_t dT;             // rows between consecutive logical steps inside a sub-tile
+    int32_t ns;             // INTERLEAVED: slices (a sub-tile never wraps); otherwise INT_MAX
+    int32_t sA;
+    int32_t kk, jj, U;
+    __device__ __forceinline__ void init(const TimeMap& tm) {
+        const bool inter = tm.ns > 1;
+        dT = inter ? tm.sA : tm.sA + tm.sW;                // FORWARD +1, REVERSED -1, INTERLEAVED L / ns
+        ns = inter ? tm.ns : INT_MAX;
+        sA = tm.sA;
+        kk = 0; jj = 0; U = 0;
+    }
+    __device__ __forceinline__ int32_t next_U() const {     // U of the following sub-tile
+        return (kk + kFT == ns) ? jj + 1 : U + kFT * dT;
+    }
+    __device__ __forceinline__ void advance() {
+        U = next_U();
+        kk += kFT;
+        if (kk == ns) { kk = 0; ++jj; }
+    }
+};
+// physical row of the first step of a work item (chunk start tau0; tau0 % ns == 0 for INTERLEAVED)
+__device__ __forceinline__ int32_t fast_item_row(const TimeMap& tm, int32_t tau0) {
+    if (tm.ns > 1) return (int32_t)((uint32_t)tau0 / (uint32_t)tm.ns);
+    return tm.base + tau0 * (tm.sA + tm.sW);
+}
+
+// A per-lane stream of one sequence tensor: uniform base + constant lane offset.
+struct FastRow {
+    const char* base;       // p + b * stride_b                    (uniform)
+    int64_t stb;            // stride_t in bytes                   (uniform)
+    uint32_t loff;          // T_item * stride_t + d * stride_d    (bytes, per lane)
+};
+template <typename T> __device__ __forceinline__ FastRow fast_row(const Seq& s, int b_uniform, int32_t t_item, int d) {
+    FastRow r;
+    r.base = s.p + (int64_t)b_uniform * s.sb * (int64_t)sizeof(T);
+    r.stb = s.st * (int64_t)sizeof(T);
+    r.loff = (uint32_t)t_item * (uint32_t)r.stb + (uint32_t)d * (uint32_t)(s.sd * (int64_t)sizeof(T));
+    return r;
+}
+// the kFT rows of the sub-tile at uniform row offset U
+template <typename T>
+__device__ __forceinline__ void fast_fetch(float (&dst)[kFT], const FastRow& r, int32_t U, int32_t dT) {
+    const char* p = r.base + (int64_t)U * r.stb;
+    const int64_t inc = (int64_t)dT * r.stb;
+#pragma unroll
+    for (int j = 0; j < kFT; ++j) dst[j] = to_f32(*reinterpret_cast<const T*>(p + (int64_t)j * inc + r.loff));
+}
+
+// B / C staging: lane r of a work item fetches elements e = r + i * RW of the kFT x 16 block of its sub-tile.
+template <int RW> struct FastStage {
+    static constexpr int EPL = kFT * kFS / RW;   // elements per lane: 2, 4 or 8
+    const char* base;       // uniform
+    int64_t stb;            // row stride in bytes (uniform)
+    int64_t inc;            // byte distance between a lane's consecutive elements (uniform)
+    uint32_t loff;          // per lane
+    int32_t lds0, ldsinc;   // LDS index ([s][n] layout) of element 0 and the step between elements
+};
+template <typename T, int RW>
+__device__ __forceinline__ FastStage<RW> fast_stage(const BC& m, int b_uniform, int32_t t_item, int32_t dT, int r) {
+    FastStage<RW> st;
+    st.base = m.p + (int64_t)b_uniform * m.sb * (int64_t)sizeof(T);
+    st.stb = m.st * (int64_t)sizeof(T);
+    const int64_t snb = m.sn * (int64_t)sizeof(T);
+    if (m.st <= m.sn) {                                    // time fastest in memory: e -> (n = e / kFT, s = e % kFT)
+        const int s = r % kFT, n = r / kFT;
+        st.loff = (uint32_t)(t_item + s * dT) * (uint32_t)st.stb + (uint32_t)n * (uint32_t)snb;
+        st.inc = (int64_t)(RW / kFT) * snb;
+        st.lds0 = s * kFS + n;
+        st.ldsinc = RW / kFT;
+    } else {                                               // state fastest: e -> (s = e / 16, n = e % 16)
+        const int s = r / kFS, n = r % kFS;
+        st.loff = (uint32_t)(t_item + s * dT) * (uint32_t)st.stb + (uint32_t)n * (uint32_t)snb;
+        st.inc = (int64_t)((RW >= kFS ? RW / kFS : 1) * dT) * st.stb;
+        st.lds0 = s * kFS + n;
+        st.ldsinc = (RW >= kFS ? RW / kFS : 1) * kFS;
+    }
+    return st;
+}
+template <typename T, int RW>
+__device__ __forceinline__ void fast_stage_fetch(float (&v)[FastStage<RW>::EPL], const FastStage<RW>& st, int32_t U) {
+    const char* p = st.base + (int64_t)U * st.stb;
+#pragma unroll
+    for (int i = 0; i < FastStage<RW>::EPL; ++i) v[i] = to_f32(*reinterpret_cast<const T*>(p + (int64_t)i * st.inc + st.loff));
+}
+template <int RW>
+__device__ __forceinline__ void fast_stage_park(const float (&v)[FastStage<RW>::EPL], const FastStage<RW>& st, float* lds_item) {
+#pragma unroll
+    for (int i = 0; i < FastStage<RW>::EPL; ++i) lds_item[st.lds0 + i * st.ldsinc] = v[i];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K1 (regular shapes): chunk aggregates
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int RW>
+__global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDev P) {
+    constexpr int G = 64 / RW, EPL = FastStage<RW>::EPL;
+    __shared__ __attribute__((aligned(16))) float s_b[2][kWavesPerBlock][G][kFT * kFS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Geom& gm = P.gm;
+    const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const int ub = uniform_batch(it);
+    const bool softplus_on = P.delta_softplus != 0;
+    FastClock ck;
+    ck.init(P.tm);
+    const int32_t t_item = fast_item_row(P.tm, it.chunk * gm.chunk);
+
+    f2 A2[kFS / 2], h[kFS / 2];
+#pragma unroll
+    for (int n = 0; n < kFS / 2; ++n) {
+        A2[n] = f2{P.A[(int64_t)it.d * kFS + 2 * n] * kLog2e, P.A[(int64_t)it.d * kFS + 2 * n + 1] * kLog2e};
+        h[n] = f2{0.f, 0.f};
+    }
+    const float bias = P.delta_bias ? P.delta_bias[it.d] : 0.f;
+    const FastRow up = fast_row<T>(P.u, ub, t_item, it.d);
+    const FastRow dp = fast_row<T>(P.delta, ub, t_item, it.d);
+    const FastStage<RW> sb = fast_stage<T, RW>(P.Bm, ub, t_item, ck.dT, it.r);
+
+    float nu[kFT], nd[kFT], nb[EPL];
+    fast_fetch<T>(nu, up, ck.U, ck.dT);
+    fast_fetch<T>(nd, dp, ck.U, ck.dT);
+    fast_stage_fetch<T, RW>(nb, sb, ck.U);
+
+    float sumd = 0.f;
+    int buf = 0;
+    const int nsub = gm.chunk / kFT;
+    for (int s = 0; s < nsub; ++s) {
+        float* lb = &s_b[buf][wave][it.gi][0];
+        fast_stage_park<RW>(nb, sb, lb);
+        SEGM_WAVE_LDS_SYNC();
+        float cu[kFT], cd[kFT];
+#pragma unroll
+        for (int j = 0; j < kFT; ++j) { cu[j] = nu[j]; cd[j] = nd[j]; }
+        // prefetch the next sub-tile (after the last one: re-read this one, never past the chunk)
+        const int32_t Un = (s + 1 < nsub) ? ck.next_U() : ck.U;
+        fast_fetch<T>(nu, up, Un, ck.dT);
+        fast_fetch<T>(nd, dp, Un, ck.dT);
+        fast_stage_fetch<T, RW>(nb, sb, Un);
+        ck.advance();
+        float4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = reinterpret_cast<const float4*>(lb)[q];
+#pragma unroll
+        for (int j = 0; j < kFT; ++j) {
+            float dl = cd[j] + bias;
+            dl = softplus_on ? softplus20(dl) : dl;
+            const float dlu = dl * cu[j];
+            sumd += dl;
+            float4 bn[4];
+            if (j + 1 < kFT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bn[q] = reinterpret_cast<const float4*>(lb + (j + 1) * kFS)[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f2 b0 = {bq[q].x, bq[q].y}, b1 = {bq[q].z, bq[q].w};
+                const f2 da0 = A2[2 * q] * dl, da1 = A2[2 * q + 1] * dl;
+                const f2 a0 = {fast_exp2(da0.x), fast_exp2(da0.y)};
+                const f2 a1 = {fast_exp2(da1.x), fast_exp2(da1.y)};
+                h[2 * q] = a0 * h[2 * q] + b0 * dlu;
+                h[2 * q + 1] = a1 * h[2 * q + 1] + b1 * dlu;
+            }
+#pragma unroll
+            for (int n = 0; n < kFS / 2; ++n) SEGM_PIN_F2(h[n]);      // finish this step before the LDS reads two steps ahead
+            if (j + 1 < kFT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bq[q] = bn[q];
+            }
+        }
+        buf ^= 1;
+    }
+    const int64_t row = (int64_t)it.b * gm.nchunks + it.chunk;
+    P.agg_sd[row * gm.dim + it.d] = sumd;
+#pragma unroll
+    for (int n = 0; n < kFS / 2; ++n) {
+        P.agg_h[(row * kFS + 2 * n) * gm.dim + it.d] = h[n].x;
+        P.agg_h[(row * kFS + 2 * n + 1) * gm.dim + it.d] = h[n].y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3 (regular shapes): apply
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int RW>
+__global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fast_kernel(ScanDev P) {
+    constexpr int G = 64 / RW, EPL = FastStage<RW>::EPL;
+    __shared__ __attribute__((aligned(16))) float s_bc[2][kWavesPerBlock][G][2][kFT * kFS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Geom& gm = P.gm;
+    const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    const int ub = uniform_batch(it);
+    const bool softplus_on = P.delta_softplus != 0;
+    const bool has_z = P.z.p != nullptr, has_out = P.out.p != nullptr;
+    FastClock ck;
+    ck.init(P.tm);
+    const int32_t tau0 = it.chunk * gm.chunk;
+    const int32_t t_item = fast_item_row(P.tm, tau0);
+
+    f2 A2[kFS / 2], h[kFS / 2];
+    const int64_t crow = (int64_t)it.b * gm.nchunks + it.chunk;
+#pragma unroll
+    for (int n = 0; n < kFS / 2; ++n) {
+        A2[n] = f2{P.A[(int64_t)it.d * kFS + 2 * n] * kLog2e, P.A[(int64_t)it.d * kFS + 2 * n + 1] * kLog2e};
+        h[n] = f2{P.carry[(crow * kFS + 2 * n) * gm.dim + it.d], P.carry[(crow * kFS + 2 * n + 1) * gm.dim + it.d]};
+    }
+    const float bias = P.delta_bias ? P.delta_bias[it.d] : 0.f;
+    const float Dv = P.D ? P.D[it.d] : 0.f;
+    const FastRow up = fast_row<T>(P.u, ub, t_item, it.d);
+    const FastRow dp = fast_row<T>(P.delta, ub, t_item, it.d);
+    const FastRow zp = fast_row<T>(has_z ? P.z : P.u, ub, t_item, it.d);          // without a gate: aliases u, unused
+    const FastRow op = fast_row<T>(has_out ? P.out : P.u, ub, t_item, it.d);
+    const FastRow ozp = fast_row<T>(has_z ? P.out_z : P.u, ub, t_item, it.d);
+    const FastStage<RW> sb = fast_stage<T, RW>(P.Bm, ub, t_item, ck.dT, it.r);
+    const FastStage<RW> sc = fast_stage<T, RW>(P.Cm, ub, t_item, ck.dT, it.r);
+    // checkpoints: state entering step 16 k of the sequence, [batch][nck][16][dim]
+    float* ckp = P.ckpt ? P.ckpt + (((int64_t)it.b * P.nck + tau0 / kCkpt) * kFS) * gm.dim + it.d : nullptr;
+
+    float nu[kFT], nd[kFT], nz[kFT], nb[EPL], nc[EPL];
+    fast_fetch<T>(nu, up, ck.U, ck.dT);
+    fast_fetch<T>(nd, dp, ck.U, ck.dT);
+    fast_fetch<T>(nz, zp, ck.U, ck.dT);
+    fast_stage_fetch<T, RW>(nb, sb, ck.U);
+    fast_stage_fetch<T, RW>(nc, sc, ck.U);
+
+    int buf = 0;
+    const int nsub = gm.chunk / kFT;
+    for (int s = 0; s < nsub; ++s) {
+        float* lb = &s_bc[buf][wave][it.gi][0][0];
+        float* lc = &s_bc[buf][wave][it.gi][1][0];
+        fast_stage_park<RW>(nb, sb, lb);
+        fast_stage_park<RW>(nc, sc, lc);
+        SEGM_WAVE_LDS_SYNC();
+        float cu[kFT], cd[kFT], cz[kFT];
+#pragma unroll
+        for (int j = 0; j < kFT; ++j) { cu[j] = nu[j]; cd[j] = nd[j]; cz[j] = nz[j]; }
+        const int32_t Uc = ck.U;
+        const int32_t Un = (s + 1 < nsub) ? ck.next_U() : ck.U;
+        fast_fetch<T>(nu, up, Un, ck.dT);
+        fast_fetch<T>(nd, dp, Un, ck.dT);
+        fast_fetch<T>(nz, zp, Un, ck.dT);
+        fast_stage_fetch<T, RW>(nb, sb, Un);
+        fast_stage_fetch<T, RW>(nc, sc, Un);
+        ck.advance();
+        if (ckp && (s & 1) == 0) {                         // kCkpt = 2 sub-tiles
+            float* kp = ckp + (int64_t)(s >> 1) * kFS * gm.dim;
+#pragma unroll
+            for (int n = 0; n < kFS / 2; ++n) {
+                kp[(int64_t)(2 * n) * gm.dim] = h[n].x;
+                kp[(int64_t)(2 * n + 1) * gm.dim] = h[n].y;
+            }
+        }
+        char* orow = const_cast<char*>(op.base) + (int64_t)Uc * op.stb;
+        char* ozrow = const_cast<char*>(ozp.base) + (int64_t)Uc * ozp.stb;
+        const int64_t oinc = (int64_t)ck.dT * op.stb, ozinc = (int64_t)ck.dT * ozp.stb;
+        float4 bq[4], cq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bq[q] = reinterpret_cast<const float4*>(lb)[q];
+            cq[q] = reinterpret_cast<const float4*>(lc)[q];
+        }
+#pragma unroll
+        for (int j = 0; j < kFT; ++j) {
+            float dl = cd[j] + bias;
+            dl = softplus_on ? softplus20(dl) : dl;
+            const float uu = cu[j];
+            const float dlu = dl * uu;
+            f2 y2 = {Dv * uu, 0.f};
+            float4 bn[4], cn[4];
+            if (j + 1 < kFT) {                             // next step's B / C rows, one step ahead of their use
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bn[q] = reinterpret_cast<const float4*>(lb + (j + 1) * kFS)[q];
+                    cn[q] = reinterpret_cast<const float4*>(lc + (j + 1) * kFS)[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f2 b0 = {bq[q].x, bq[q].y}, b1 = {bq[q].z, bq[q].w};
+                const f2 c0 = {cq[q].x, cq[q].y}, c1 = {cq[q].z, cq[q].w};
+                const f2 da0 = A2[2 * q] * dl, da1 = A2[2 * q + 1] * dl;
+                const f2 a0 = {fast_exp2(da0.x), fast_exp2(da0.y)};
+                const f2 a1 = {fast_exp2(da1.x), fast_exp2(da1.y)};
+                h[2 * q] = a0 * h[2 * q] + b0 * dlu;
+                h[2 * q + 1] = a1 * h[2 * q + 1] + b1 * dlu;
+                y2 = c0 * h[2 * q] + y2;
+                y2 = c1 * h[2 * q + 1] + y2;
+            }
+            const float y = y2.x + y2.y;
+            if (has_out) *reinterpret_cast<T*>(orow + (int64_t)j * oinc + op.loff) = from_f32<T>(y);
+            if (has_z) {
+                const float zz = cz[j];
+                *reinterpret_cast<T*>(ozrow + (int64_t)j * ozinc + ozp.loff) = from_f32<T>(y * zz * sigmoidf(zz));
+            }
+#pragma unroll
+            for (int n = 0; n < kFS / 2; ++n) SEGM_PIN_F2(h[n]);      // finish this step before the LDS reads two steps ahead
+            if (j + 1 < kFT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { bq[q] = bn[q]; cq[q] = cn[q]; }
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+bool scan_fast_shape(const ScanDev& P) {
+    const Geom& gm = P.gm;
+    if (gm.nstate != kFS) return false;
+    if (gm.dim % gm.rw != 0 || gm.L % gm.chunk != 0 || gm.nchunks % gm.g != 0) return false;
+    if (gm.chunk % kFT != 0) return false;
+    if (P.tm.ns > 1 && (P.tm.ns % kFT != 0 || gm.chunk % P.tm.ns != 0)) return false;
+    return true;
+}
+
+template <typename T, int RW>
+static void launch_fast_rw(const ScanDev& P, bool apply, hipStream_t stream) {
+    const unsigned nblocks = (unsigned)((P.gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (apply) hipLaunchKernelGGL((scan_fwd_apply_fast_kernel<T, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+    else hipLaunchKernelGGL((scan_fwd_agg_fast_kernel<T, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+}
+template <typename T>
+static void launch_fast_t(const ScanDev& P, bool apply, hipStream_t stream) {
+    if (P.gm.rw == 64) launch_fast_rw<T, 64>(P, apply, stream);
+    else if (P.gm.rw == 32) launch_fast_rw<T, 32>(P, apply, stream);
+    else launch_fast_rw<T, 16>(P, apply, stream);
+}
+// launches K1 (apply == false) or K3 (apply == true) of the regular-shape path
+void launch_scan_fwd_fast(const ScanDev& P, int dtype, bool apply, hipStream_t stream) {
+    if (dtype == SEGM_F32) launch_fast_t<float>(P, apply, stream);
+    else if (dtype == SEGM_F16) launch_fast_t<f16_t>(P, apply, stream);
+    else launch_fast_t<bf16_t>(P, apply, stream);
+}
+
+}  // namespace segm

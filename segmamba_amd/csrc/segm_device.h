@@ -40,6 +40,14 @@ constexpr float kLog2e = 1.4426950408889634f;
 #define SEGM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// Orders a wave's LDS writes before its later LDS reads of data written by OTHER lanes of the same wave.  Every LDS
+// region of the scan kernels is private to one wave, so no workgroup barrier is needed: the LDS unit executes one
+// wave's operations in order; this only stops the compiler from reordering across it (and drains the counter).
+// (The CPU emulation build maps it to its wave-level barrier.)
+#ifndef SEGM_WAVE_LDS_SYNC
+#define SEGM_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
 typedef _Float16 f16_t;
 typedef __bf16 bf16_t;
 

@@ -2,6 +2,7 @@
 // of the HIP runtime (tests/emu/hip/hip_runtime.h) into libsegmamba_emu.so, exposing the same C ABI.
 #include "../../segmamba_amd/csrc/capi.hip"
 #include "../../segmamba_amd/csrc/scan_fwd.hip"
+#include "../../segmamba_amd/csrc/scan_fwd_fast.hip"
 #include "../../segmamba_amd/csrc/conv1d.hip"
 #include "../../segmamba_amd/csrc/scan_bwd.hip"
 #include "../../segmamba_amd/csrc/conv3d_wgrad.hip"

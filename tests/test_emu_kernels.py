@@ -202,3 +202,25 @@ def test_transpose_add_emulated(emu, shape, dtype, with_add):
     ref = x.transpose(1, 2).float() + (add.float() if with_add else 0)
     assert out.shape == (shape[0], shape[2], shape[1]) and out.is_contiguous()
     assert torch.equal(out, ref.to(dtype))
+
+
+@pytest.mark.parametrize("dim,seqlen,chunk,channel_last,order,ns,dtype", [
+    (32, 128, 32, True, L.TIME_FORWARD, 1, torch.float32),         # RW = 32, two work items per wave
+    (64, 64, 32, True, L.TIME_REVERSED, 1, torch.float32),         # RW = 64
+    (16, 256, 64, True, L.TIME_INTERLEAVED, 8, torch.float32),     # RW = 16, sub-tiles hop between slices
+    (32, 128, 64, False, L.TIME_INTERLEAVED, 16, torch.float32),   # reference layout: time-fastest B / C staging
+    (96, 64, 32, True, L.TIME_FORWARD, 1, torch.bfloat16),         # SegMamba stage-0 width
+])
+def test_scan_regular_shape_kernels_emulated(emu, monkeypatch, dim, seqlen, chunk, channel_last, order, ns, dtype):
+    """scan_fwd_fast.hip (uniform addressing, packed fp32) against the oracle AND against the general kernels."""
+    c = H.scan_case(1, dim, 16, seqlen, dtype=dtype, seed=dim + seqlen)
+    ref = H.scan_oracle(c, order, ns)
+    monkeypatch.delenv("SEGM_SCAN_FAST", raising=False)
+    fast = H.run_scan(emu, c, "cpu", channel_last, order, ns, chunk=chunk)
+    H.check_scan(fast, ref, dtype, f"emu fast D={dim} L={seqlen}")
+    monkeypatch.setenv("SEGM_SCAN_FAST", "0")
+    slow = H.run_scan(emu, c, "cpu", channel_last, order, ns, chunk=chunk)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for k in ("out", "out_z"):
+        if fast.get(k) is not None:
+            assert (fast[k].float() - slow[k].float()).abs().max() <= tol * max(1.0, float(slow[k].float().abs().max())), k
