@@ -457,6 +457,15 @@ extern "C" int segm_selective_scan_bwd(const segm_scan_bwd_args* b) {
     if (b->dB.stride_t < 0 || b->dB.stride_t >= ((int64_t)1 << 31) || b->dC.stride_t < 0 ||
         b->dC.stride_t >= ((int64_t)1 << 31))
         return SEGM_E_SHAPE;
+    {
+        const segm_seq* all[9] = {&a->u, &a->delta, &a->z, &a->out, &b->dout, &b->du, &b->ddelta, &b->dz, nullptr};
+        const segm_bc* bv[2] = {&a->B, &a->C};
+        rc = validate_spans(all, 8, bv, 2, a->dim, a->dstate, a->seqlen, dtype_size(a->dtype));
+        if (rc != SEGM_OK) return rc;
+        const segm_bc* gv[2] = {&b->dB, &b->dC};                       // fp32
+        rc = validate_spans(nullptr, 0, gv, 2, a->dim, a->dstate, a->seqlen, sizeof(float));
+        if (rc != SEGM_OK) return rc;
+    }
     const int chunk = a->chunk;
     const BwdWs ws = bwd_ws_layout(a->batch, a->dim, a->dstate, a->seqlen, chunk);
     if (!b->workspace || b->workspace_bytes < ws.total) return SEGM_E_WORKSPACE;

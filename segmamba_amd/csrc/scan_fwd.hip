@@ -447,6 +447,25 @@ int validate_scan_common(const segm_scan_fwd_args* a) {
     return SEGM_OK;
 }
 
+int validate_spans(const segm_seq* const* seqs, int nseq, const segm_bc* const* bcs, int nbc, int dim, int dstate,
+                   int64_t L, size_t esize) {
+    const int64_t es = (int64_t)esize, lim24 = (int64_t)1 << 24, lim32 = (int64_t)1 << 32;
+    if (L >= lim24) return SEGM_E_SHAPE;
+    for (int i = 0; i < nseq; ++i) {
+        const segm_seq* s = seqs[i];
+        if (!s || !s->ptr) continue;
+        if (s->stride_t < 0 || s->stride_d < 0 || s->stride_t * es >= lim24) return SEGM_E_SHAPE;
+        if (((L - 1) * s->stride_t + (int64_t)(dim - 1) * s->stride_d + 1) * es >= lim32) return SEGM_E_SHAPE;
+    }
+    for (int i = 0; i < nbc; ++i) {
+        const segm_bc* m = bcs[i];
+        if (!m || !m->ptr) continue;
+        if (m->stride_t < 0 || m->stride_n < 0 || m->stride_t * es >= lim24) return SEGM_E_SHAPE;
+        if (((L - 1) * m->stride_t + (int64_t)(dstate - 1) * m->stride_n + 1) * es >= lim32) return SEGM_E_SHAPE;
+    }
+    return SEGM_OK;
+}
+
 TimeMap make_timemap(int time_order, int nslices, int64_t L) {
     TimeMap tm;
     tm.L = (int32_t)L;
@@ -519,6 +538,12 @@ extern "C" int segm_selective_scan_fwd(const segm_scan_fwd_args* a) {
     if (rc != SEGM_OK) return rc;
     if (a->z.ptr && !a->out_z.ptr) return SEGM_E_NULL;
     if (!a->z.ptr && !a->out.ptr) return SEGM_E_NULL;
+    {
+        const segm_seq* sv[5] = {&a->u, &a->delta, &a->z, &a->out, &a->out_z};
+        const segm_bc* bv[2] = {&a->B, &a->C};
+        rc = validate_spans(sv, 5, bv, 2, a->dim, a->dstate, a->seqlen, dtype_size(a->dtype));
+        if (rc != SEGM_OK) return rc;
+    }
     const int chunk = a->chunk > 0 ? a->chunk : default_chunk(a->batch, a->dim, a->seqlen);
     const FwdWs ws = fwd_ws_layout(a->batch, a->dim, a->dstate, a->seqlen, chunk);
     if (!a->workspace || a->workspace_bytes < ws.total) return SEGM_E_WORKSPACE;

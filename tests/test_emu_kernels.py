@@ -224,3 +224,23 @@ def test_scan_regular_shape_kernels_emulated(emu, monkeypatch, dim, seqlen, chun
     for k in ("out", "out_z"):
         if fast.get(k) is not None:
             assert (fast[k].float() - slow[k].float()).abs().max() <= tol * max(1.0, float(slow[k].float().abs().max())), k
+
+
+def test_scan_rejects_views_beyond_32bit_offsets(emu):
+    """L >= 2^24 or a row stride >= 2^24 bytes is outside the kernels' 32-bit offset arithmetic: SEGM_E_SHAPE, nothing launched."""
+    a = L.ScanFwdArgs()
+    buf = torch.zeros(64)
+    a.batch, a.dim, a.dstate, a.n_groups, a.seqlen = 1, 4, 16, 1, 1 << 24
+    a.dtype, a.time_order, a.nslices, a.chunk = L.SEGM_F32, L.TIME_FORWARD, 1, 16
+    for name in ("u", "delta", "out"):
+        v = getattr(a, name)
+        v.ptr, v.stride_b, v.stride_t, v.stride_d = buf.data_ptr(), 0, 4, 1
+    for name in ("B", "C"):
+        v = getattr(a, name)
+        v.ptr, v.stride_b, v.stride_g, v.stride_t, v.stride_n = buf.data_ptr(), 0, 0, 16, 1
+    a.A = buf.data_ptr()
+    a.workspace, a.workspace_bytes = buf.data_ptr(), 1 << 40
+    assert emu.dll.segm_selective_scan_fwd(a) == -2
+    a.seqlen = 64
+    a.u.stride_t = 1 << 23                                 # 2^23 elements * 4 bytes = 2^25 bytes per row
+    assert emu.dll.segm_selective_scan_fwd(a) == -2
