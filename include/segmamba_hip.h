@@ -206,6 +206,30 @@ size_t segm_conv3d_k3_wgrad_workspace_bytes(int32_t batch, int32_t cin, int32_t 
                                             int32_t width);
 
 /* ------------------------------------------------------------------------------------------------
+ * 3x3x3 stride-1 pad-1 convolution, forward (and data gradient, given flipped / transposed weights).
+ * Replaces torch.nn.Conv3d -> cuDNN for the 48-input-channel 3x3x3 layers (reference model_segmamba/segmamba.py:95-131,
+ * monai/networks/blocks/dynunet_block.py:44-111; the data gradient is what autograd asks cuDNN for in their backward).
+ *
+ *   y[b, co, z, y, x] = bias[co] + sum_{ci, kz, ky, kx} w[co, ci, kz, ky, kx] * x[b, ci, z+kz-1, y+ky-1, x+kx-1]
+ *
+ * x: bf16 (batch, 48, depth, height, width); y: bf16 (batch, cout, depth, height, width); W contiguous, every other stride a
+ * multiple of 8 elements, 16-byte aligned bases.  cin == 48, cout a multiple of 16, width a multiple of 8.
+ * w_packed: bf16 (cout, 3, 3, 3, 48) contiguous, i.e. weight.permute(0, 2, 3, 4, 1) - the input channel fastest.
+ * bias: (cout) fp32 or NULL.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_conv3d_fwd_args {
+    int32_t batch, cin, cout, depth, height, width;
+    int32_t dtype, reserved;
+    const void* x;   int64_t x_stride_b, x_stride_c, x_stride_z, x_stride_y;
+    void* y;         int64_t y_stride_b, y_stride_c, y_stride_z, y_stride_y;
+    const void* w_packed;
+    const float* bias;
+    void* stream;
+} segm_conv3d_fwd_args;
+
+int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* args);
+
+/* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d (+ residual) (+ activation), forward and backward.
  * Replaces the torch.nn.InstanceNorm3d -> [+ residual] -> ReLU / LeakyReLU chains of the stem and decoder
  * (reference model_segmamba/segmamba.py:96-130,147,169-187; monai/networks/blocks/dynunet_block.py:98-111), which the

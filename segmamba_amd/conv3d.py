@@ -11,7 +11,9 @@ profiles/r01_bench_step_kernels_v3.txt) showed that MIOpen's bf16 3-D solvers ar
 Every quantity below is mathematically the same convolution, only routed to a different library call:
 
   fwd    y  = conv(x, W)                      or  sum over 48-channel input blocks / concat over output blocks
-  dgrad  dx = conv_bwd_data(dy, W)            or  conv(dy, flip(W)^T)         (a forward convolution)
+                                              or  segm_conv3d_k3_fwd, the library's own NCDHW MFMA kernel (per 48-channel
+                                                  input block; csrc/conv3d_fwd.hip)
+  dgrad  dx = conv_bwd_data(dy, W)            or  conv(dy, flip(W)^T)         (a forward convolution, any of the above)
   wgrad  dW = conv_bwd_weight(x, dy)          or  per input/output channel block
                                               or  segm_conv3d_k3_wgrad, the library's own MFMA kernel
 
@@ -69,6 +71,23 @@ def _fwd_native(x, w, pad):
     return F.conv3d(x, w, None, 1, pad)
 
 
+def _hip_fwd_ok(x, w) -> bool:
+    from . import ops_raw
+    return w.shape[2:] == (3, 3, 3) and w.shape[1] % _BLOCK == 0 and w.shape[0] % 16 == 0 and x.dtype == torch.bfloat16 \
+        and w.dtype == torch.bfloat16 and ops_raw.conv3d_k3_fwd_supported(x[:, :_BLOCK], w.shape[0])
+
+
+def _fwd_hip(x, w, pad, bias=None):
+    """segm_conv3d_k3_fwd per 48-channel input block (the kernel keeps one block's weights in registers)."""
+    from . import lib as L, ops_raw
+    hip = L.get_lib()
+    out = None
+    for i, ib in enumerate(_blocks(w.shape[1])):
+        y = ops_raw.conv3d_k3_fwd(hip, x[:, ib], ops_raw.pack_conv3d_weight(w[:, ib]), bias if i == 0 else None)
+        out = y if out is None else out + y
+    return out
+
+
 def _fwd_blocked(x, w, pad):
     outs = []
     for ob in _blocks(w.shape[0]):
@@ -96,6 +115,10 @@ def _dgrad_as_fwd(dy, w, x, pad):
 
 def _dgrad_as_fwd_blocked(dy, w, x, pad):
     return _fwd_blocked(dy, _flipT(w), pad)
+
+
+def _dgrad_hip(dy, w, x, pad):
+    return _fwd_hip(dy, _flipT(w), pad)
 
 
 def _wgrad_native(x, dy, w, pad):
@@ -127,16 +150,24 @@ def _mfma_wgrad_ok(x, dy, w) -> bool:
 
 
 class _ConvSame(torch.autograd.Function):
-    """stride-1 "same" convolution, odd kernel, no bias; tensors already in the compute dtype."""
+    """stride-1 "same" convolution, odd kernel; tensors already in the compute dtype."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, bias):
         pad = w.shape[2] // 2
         ctx.save_for_backward(x, w)
-        key = ("fwd", tuple(x.shape), tuple(w.shape), x.dtype)
-        cands = [lambda: _fwd_native(x, w, pad)]
+        ctx.has_bias = bias is not None
+        hip = _hip_fwd_ok(x, w)
+        key = ("fwd", tuple(x.shape), tuple(w.shape), x.dtype, hip)
+
+        def with_bias(y):
+            return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
+
+        cands = [lambda: F.conv3d(x, w, bias, 1, pad)]
         if max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0:
-            cands.append(lambda: _fwd_blocked(x, w, pad))
+            cands.append(lambda: with_bias(_fwd_blocked(x, w, pad)))
+        if hip:
+            cands.append(lambda: _fwd_hip(x, w, pad, bias))        # bias fused into the kernel's epilogue
         return _pick(key, cands)
 
     @staticmethod
@@ -144,13 +175,16 @@ class _ConvSame(torch.autograd.Function):
         x, w = ctx.saved_tensors
         pad = w.shape[2] // 2
         dy = dy.contiguous()
-        dx = dw = None
+        dx = dw = db = None
         blockable = max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0
         if ctx.needs_input_grad[0]:
             cands = [lambda: _dgrad_native(dy, w, x, pad), lambda: _dgrad_as_fwd(dy, w, x, pad)]
             if blockable:
                 cands.append(lambda: _dgrad_as_fwd_blocked(dy, w, x, pad))
-            dx = _pick(("dgrad", tuple(x.shape), tuple(w.shape), x.dtype), cands)
+            hip = _hip_fwd_ok(dy, w.transpose(0, 1))
+            if hip:
+                cands.append(lambda: _dgrad_hip(dy, w, x, pad))
+            dx = _pick(("dgrad", tuple(x.shape), tuple(w.shape), x.dtype, hip), cands)
         if ctx.needs_input_grad[1]:
             cands = [lambda: _wgrad_native(x, dy, w, pad)]
             if blockable:
@@ -159,7 +193,9 @@ class _ConvSame(torch.autograd.Function):
             if mfma:
                 cands.append(lambda: _wgrad_mfma(x, dy, w, pad))
             dw = _pick(("wgrad", tuple(x.shape), tuple(w.shape), x.dtype, mfma), cands)
-        return dx, dw
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3, 4), dtype=torch.float32).to(dy.dtype)
+        return dx, dw, db
 
 
 def conv3d_same(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
@@ -172,10 +208,7 @@ def conv3d_same(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
         bias = bias.to(dt) if bias is not None else None
     elif weight.dtype != x.dtype:
         weight = weight.to(x.dtype)
-    y = _ConvSame.apply(x, weight)
-    if bias is not None:
-        y = y + bias.view(1, -1, 1, 1, 1)
-    return y
+    return _ConvSame.apply(x, weight, bias)
 
 
 def conv3d_same_cat(xs: Tuple[torch.Tensor, ...], weight: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,256 @@
+// Forward (and, with flipped weights, data-gradient) 3x3x3 stride-1 pad-1 convolution on channel-first bf16 volumes
+// (C ABI: segm_conv3d_k3_fwd).
+//
+// Replaces torch.nn.Conv3d -> cuDNN for the 48-channel 3x3x3 layers of SegMamba's stem / GSC / decoder (reference
+// model_segmamba/segmamba.py:95-131, monai/networks/blocks/dynunet_block.py:44-111).  MIOpen's best solver for them is a
+// CK implicit GEMM on channel-last data: two layout-transposing kernels around a 2.2 ms GEMM per 48 -> 48 @128^3 call
+// (profiles/r01_bench_step_kernels_v8.txt: 44 ms of a 145 ms training step).  This kernel works on NCDHW directly:
+//
+//   Y[b, co, z, y, x] = bias[co] + sum_{ci, kz, ky, kx} W[co, ci, kz, ky, kx] * X[b, ci, z+kz-1, y+ky-1, x+kx-1]
+//
+// as the GEMM  D[x][co] = sum_k A[x][k] B[k][co],  k = (kz, ky, kx, ci), per output row (b, z, y) and 64-wide x block.
+// MFMA fragments want 8 consecutive k per lane; in NCDHW the contiguous index is x, so X rows are TRANSPOSED while they are
+// staged: the LDS ring holds X as [row][x][ci] (ci contiguous), and an A fragment is one aligned 16-byte LDS read at
+// [x + kx][ci0] - the three kx taps are just three row offsets, no shifting.
+//
+//   workgroup = 12 waves = 3 (kz) x 4 (16-wide x tiles) for one work item (b, z, x block, y range) and a block of 32
+//               output channels.  Wave (kz, xt) keeps its slice of the weights - k in (ky, kx, ci), 432 values per output
+//               channel, 13.5 MFMA k-chunks - STATIONARY in registers (2 co tiles x 14 fragments), so per step it only
+//               reads 14 A fragments from LDS for 28 MFMAs (16x16x32 bf16).  The three kz partial sums are added
+//               through LDS; wave (0, xt) adds the bias, converts and stores 4 consecutive x per lane.
+//   LDS         ring of 4 rows x 3 planes (z-1, z, z+1) of [66 x][56 ci] bf16 (each X row is fetched once per work item
+//               and used on three consecutive steps), double-buffered 16 KB reduction buffer: 121 KB, one workgroup per CU.
+//               The next row of every plane is in flight global -> registers during the MFMAs of the current step and is
+//               parked (transposed, two channels per dword) afterwards; one barrier per step.
+//   padding     zero rows / columns are materialised in LDS; a tap plane outside the volume is skipped by its waves.
+//
+// v_mfma_f32_16x16x32_bf16: lane l holds A[i = l & 15][k = 8 (l >> 4) .. +7], B[k = 8 (l >> 4) .. +7][j = l & 15];
+// result D[row = 4 (l >> 4) + r][col = l & 15].  Here row = x, col = co.
+#include <string.h>
+
+#include "segm_device.h"
+
+namespace segm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kFwCi = 48;                    // input channels (K = 27 * 48)
+constexpr int kFwCo = 32;                    // output channels per workgroup (2 MFMA tiles)
+constexpr int kFwXB = 64;                    // x positions per workgroup
+constexpr int kFwWaves = 12;                 // 3 kz x 4 x tiles
+constexpr int kFwThreads = kFwWaves * 64;
+constexpr int kFwCP = 56;                    // ci pitch (elements) of an LDS x position: 28 dwords -> conflict-free b128 reads
+constexpr int kFwXP = kFwXB + 2;             // x positions per ring row: x0 - 1 .. x0 + 64
+constexpr int kFwSlot = kFwXP * kFwCP;       // elements per ring row
+constexpr int kFwKSlice = 9 * kFwCi;         // k values per kz: (ky, kx, ci) = 432
+constexpr int kFwChunks = (kFwKSlice + 31) / 32;     // 14 (the last one half empty)
+constexpr int kFwGran = kFwXB / 8 + 2;       // 16-byte granules fetched per (ci, row): 8 data + one halo granule each side
+constexpr int kFwTasks = 3 * (kFwCi / 2) * kFwGran;  // copy tasks per step: (plane, ci pair, granule) = 720
+
+struct ConvFwdDev {
+    const char* x;  int64_t x_sb, x_sc, x_sz, x_sy;       // element strides, x contiguous
+    char* y;        int64_t y_sb, y_sc, y_sz, y_sy;
+    const __bf16* wp;                                     // packed weights [cout][27 * 48], k = ((kz*3 + ky)*3 + kx)*48 + ci
+    const float* bias;                                    // (cout) or null
+    int32_t B, D, H, W, cout, cob0;
+    int32_t nxb, ysplit, rows_per_part;
+};
+
+template <int NCO>
+__global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P) {
+    __shared__ __attribute__((aligned(16))) __bf16 xs[3][4][kFwSlot];
+    __shared__ __attribute__((aligned(16))) float red[2][8][2][4][64];      // [buffer][(kz - 1) * 4 + xt][co tile][r][lane]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kz = wave >> 2, xt = wave & 3;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int cob = blockIdx.y + P.cob0;
+    int item = blockIdx.x;
+    const int ypart = item % P.ysplit;  item /= P.ysplit;
+    const int xb = item % P.nxb;        item /= P.nxb;
+    const int z = item % P.D, b = item / P.D;
+    const int y0 = ypart * P.rows_per_part;
+    const int y1 = (y0 + P.rows_per_part < P.H) ? y0 + P.rows_per_part : P.H;
+    const int x0 = xb * kFwXB;
+    const int zz = z + kz - 1;
+    const bool plane_ok = zz >= 0 && zz < P.D;            // this wave's tap plane exists (else it contributes zero)
+
+    // ---- stationary weights: B[k][co] fragments of this wave's kz slice -----------------------------------------------
+    // chunk c, lane group g: k = 32 c + 8 g .. + 7 inside the slice -> tap (ky, kx) = k / 48, ci0 = k % 48
+    bf16x8 wf[NCO][kFwChunks];
+    int32_t aoff[kFwChunks];                              // LDS element offset of the matching A fragment, without the row slot
+    int32_t aky[kFwChunks];
+#pragma unroll
+    for (int c = 0; c < kFwChunks; ++c) {
+        const int k = 32 * c + 8 * g;
+        const bool live = k < kFwKSlice;
+        const int kk = live ? k : 0;
+        const int tap = kk / kFwCi, ci0 = kk - tap * kFwCi;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        aky[c] = ky;
+        aoff[c] = (xt * 16 + i16 + kx) * kFwCP + ci0;
+#pragma unroll
+        for (int t = 0; t < NCO; ++t) {
+            const int co = cob * kFwCo + t * 16 + i16;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(P.wp + ((int64_t)co * 27 + kz * 9) * kFwCi + kk);
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            wf[t][c] = __builtin_bit_cast(bf16x8, (live && plane_ok) ? w : zero);
+        }
+    }
+    float bias[NCO];
+#pragma unroll
+    for (int t = 0; t < NCO; ++t) bias[t] = P.bias ? P.bias[cob * kFwCo + t * 16 + i16] : 0.f;
+
+    // ---- copy plan: task = (plane, ci pair, granule), ci pair fastest (adjacent LDS dwords) ---------------------------------
+    const int task = tid;                                 // kFwTasks = 720 <= 768 threads: at most one task per thread
+    const bool has_task = task < kFwTasks;
+    const int tpl = has_task ? task / (24 * kFwGran) : 0;
+    const int trem = has_task ? task - tpl * (24 * kFwGran) : 0;
+    const int tgr = trem / 24, tcp = trem - tgr * 24;     // granule 0 = left halo (x0-8 .. x0-1), 1..8 data, 9 = right halo
+    const int txg = x0 - 8 + 8 * tgr;                     // first x of the granule
+    const bool t_inside = txg >= 0 && txg < P.W;          // W % 8 == 0: entirely inside or outside
+    const int tzz = z + tpl - 1;
+    const bool t_plane = tzz >= 0 && tzz < P.D;
+    const __bf16* tsrc = reinterpret_cast<const __bf16*>(P.x) + (int64_t)b * P.x_sb + (int64_t)(t_plane ? tzz : z) * P.x_sz +
+                         (int64_t)(2 * tcp) * P.x_sc + (t_inside ? txg : 0);
+    // ring positions p = x - (x0 - 1): the granule covers p = 8 tgr - 7 .. 8 tgr; only 0 <= p < kFwXP is stored
+    const int tp0 = 8 * tgr - 7;
+
+    auto fetch = [&](u32x4 (&r)[2], int yy) {
+        const bool ok = yy >= 0 && yy < P.H;
+        const __bf16* s = tsrc + (int64_t)(ok ? yy : 0) * P.x_sy;
+        r[0] = *reinterpret_cast<const u32x4*>(s);
+        r[1] = *reinterpret_cast<const u32x4*>(s + P.x_sc);
+    };
+    auto park = [&](const u32x4 (&r)[2], int yy, int slot) {
+        if (!has_task) return;
+        const bool keep = yy >= 0 && yy < P.H && t_inside && t_plane;
+        __bf16* row = &xs[tpl][slot][0];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int p = tp0 + e;
+            if (p < 0 || p >= kFwXP) continue;
+            // element e of channel 2 tcp (low half) and 2 tcp + 1 (high half)
+            const uint32_t a = r[0][e >> 1], c = r[1][e >> 1];
+            const uint32_t lo = (e & 1) ? (a >> 16) : (a & 0xffffu);
+            const uint32_t hi = (e & 1) ? (c & 0xffff0000u) : (c << 16);
+            *reinterpret_cast<uint32_t*>(row + p * kFwCP + 2 * tcp) = keep ? (lo | hi) : 0u;
+        }
+    };
+
+    if (y1 > y0) {
+        {   // prologue: rows y0 - 1, y0, y0 + 1 of the three planes
+            u32x4 r[2];
+#pragma unroll
+            for (int d = -1; d <= 1; ++d) {
+                fetch(r, y0 + d);
+                park(r, y0 + d, (y0 + d + 4) & 3);
+            }
+        }
+        __syncthreads();
+        for (int y = y0; y < y1; ++y) {
+            u32x4 r[2];
+            fetch(r, y + 2);                              // in flight during this step's MFMAs
+            SEGM_SCHED_FENCE();
+            f32x4 acc[NCO];
+#pragma unroll
+            for (int t = 0; t < NCO; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (plane_ok) {
+                const __bf16* pl = &xs[kz][0][0];
+#pragma unroll
+                for (int c = 0; c < kFwChunks; ++c) {
+                    const int slot = (y + aky[c] - 1 + 4) & 3;
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(pl + slot * kFwSlot + aoff[c]);
+#pragma unroll
+                    for (int t = 0; t < NCO; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[t][c], acc[t], 0, 0, 0);
+                }
+            }
+            SEGM_SCHED_FENCE();
+            const int rb = (y - y0) & 1;
+            if (kz > 0) {
+#pragma unroll
+                for (int t = 0; t < NCO; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[rb][(kz - 1) * 4 + xt][t][q][lane] = acc[t][q];
+            }
+            park(r, y + 2, (y + 2) & 3);
+            __syncthreads();
+            if (kz == 0) {
+                const int xg = x0 + xt * 16 + 4 * g;      // this lane's 4 output positions
+                if (xg < P.W) {
+#pragma unroll
+                    for (int t = 0; t < NCO; ++t) {
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            v[q] = acc[t][q] + red[rb][xt][t][q][lane] + red[rb][4 + xt][t][q][lane] + bias[t];
+                        __bf16 o[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = (__bf16)v[q];
+                        u32x2 pk;
+                        memcpy(&pk, o, 8);
+                        const int co = cob * kFwCo + t * 16 + i16;
+                        __bf16* dst = reinterpret_cast<__bf16*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
+                                      (int64_t)z * P.y_sz + (int64_t)y * P.y_sy + xg;
+                        *reinterpret_cast<u32x2*>(dst) = pk;
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct FwPlan { int nxb, ysplit, rows_per_part, nitems; };
+static FwPlan fwd_plan(int batch, int cout, int d, int h, int w) {
+    FwPlan p;
+    p.nxb = (w + kFwXB - 1) / kFwXB;
+    const int64_t wgs = (int64_t)batch * d * p.nxb * ((cout + kFwCo - 1) / kFwCo);
+    int split = 1;                                        // cut y when there are too few workgroups for 256 CUs
+    while (wgs * split < 512 && h / (split * 2) >= 8) split *= 2;
+    p.ysplit = split;
+    p.rows_per_part = (h + split - 1) / split;
+    p.nitems = batch * d * p.nxb * split;
+    return p;
+}
+
+}  // namespace segm
+
+using namespace segm;
+
+extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
+    if (!a) return SEGM_E_NULL;
+    if (!a->x || !a->y || !a->w_packed) return SEGM_E_NULL;
+    if (a->batch <= 0 || a->depth <= 0 || a->height <= 0 || a->width <= 0) return SEGM_E_SHAPE;
+    if (a->cin != kFwCi || a->cout <= 0 || a->cout % 16 != 0) return SEGM_E_SHAPE;
+    if (a->width % 8 != 0) return SEGM_E_SHAPE;
+    if (a->dtype != SEGM_BF16) return SEGM_E_DTYPE;
+    const int64_t st[8] = {a->x_stride_b, a->x_stride_c, a->x_stride_z, a->x_stride_y,
+                           a->y_stride_b, a->y_stride_c, a->y_stride_z, a->y_stride_y};
+    for (int64_t s : st)
+        if (s % 8 != 0) return SEGM_E_SHAPE;              // 16-byte aligned rows
+    if (((uintptr_t)a->x & 15) || ((uintptr_t)a->y & 15) || ((uintptr_t)a->w_packed & 15)) return SEGM_E_SHAPE;
+
+    ConvFwdDev P;
+    memset(&P, 0, sizeof(P));
+    P.x = (const char*)a->x; P.x_sb = a->x_stride_b; P.x_sc = a->x_stride_c; P.x_sz = a->x_stride_z; P.x_sy = a->x_stride_y;
+    P.y = (char*)a->y; P.y_sb = a->y_stride_b; P.y_sc = a->y_stride_c; P.y_sz = a->y_stride_z; P.y_sy = a->y_stride_y;
+    P.wp = (const __bf16*)a->w_packed;
+    P.bias = a->bias;
+    P.B = a->batch; P.D = a->depth; P.H = a->height; P.W = a->width; P.cout = a->cout;
+    const FwPlan pl = fwd_plan(a->batch, a->cout, a->depth, a->height, a->width);
+    P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part;
+    hipStream_t stream = (hipStream_t)a->stream;
+    const int full = a->cout / kFwCo;                     // blocks with two co tiles; cout % 32 == 16 leaves one with a single tile
+    P.cob0 = 0;
+    if (full > 0)
+        hipLaunchKernelGGL((conv3d_k3_fwd_kernel<2>), dim3(pl.nitems, full), dim3(kFwThreads), 0, stream, P);
+    if (a->cout % kFwCo) {
+        P.cob0 = full;
+        hipLaunchKernelGGL((conv3d_k3_fwd_kernel<1>), dim3(pl.nitems, 1), dim3(kFwThreads), 0, stream, P);
+    }
+    return (int)hipGetLastError();
+}

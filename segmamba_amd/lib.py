@@ -91,6 +91,18 @@ class Conv3dWgradArgs(C.Structure):
     ]
 
 
+class Conv3dFwdArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("depth", C.c_int32), ("height", C.c_int32),
+        ("width", C.c_int32), ("dtype", C.c_int32), ("reserved", C.c_int32),
+        ("x", C.c_void_p), ("x_stride_b", C.c_int64), ("x_stride_c", C.c_int64), ("x_stride_z", C.c_int64),
+        ("x_stride_y", C.c_int64),
+        ("y", C.c_void_p), ("y_stride_b", C.c_int64), ("y_stride_c", C.c_int64), ("y_stride_z", C.c_int64),
+        ("y_stride_y", C.c_int64),
+        ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
 class InstNormFwdArgs(C.Structure):
     _fields_ = [
         ("instances", C.c_int32), ("dtype", C.c_int32), ("act", C.c_int32), ("reserved", C.c_int32),
@@ -121,7 +133,7 @@ EXPORTS = (
     "segm_selective_scan_fwd", "segm_selective_scan_fwd_workspace_bytes", "segm_selective_scan_ckpt_bytes",
     "segm_selective_scan_default_chunk", "segm_selective_scan_bwd", "segm_selective_scan_bwd_workspace_bytes",
     "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
-    "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes",
+    "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes", "segm_conv3d_k3_fwd",
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add",
     "segm_abi_version", "segm_status_string",
 )
@@ -152,6 +164,7 @@ class SegmLib:
         sig("segm_causal_conv1d_bwd_workspace_bytes", [C.c_int32, C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
         sig("segm_conv3d_k3_wgrad", [C.POINTER(Conv3dWgradArgs)], C.c_int)
         sig("segm_conv3d_k3_wgrad_workspace_bytes", [C.c_int32] * 6, C.c_size_t)
+        sig("segm_conv3d_k3_fwd", [C.POINTER(Conv3dFwdArgs)], C.c_int)
         sig("segm_instnorm_fwd", [C.POINTER(InstNormFwdArgs)], C.c_int)
         sig("segm_instnorm_bwd", [C.POINTER(InstNormBwdArgs)], C.c_int)
         sig("segm_instnorm_workspace_bytes", [C.c_int32, C.c_int64], C.c_size_t)

@@ -258,6 +258,50 @@ def conv3d_k3_wgrad(lib: L.SegmLib, x: torch.Tensor, dy: torch.Tensor, out_dtype
 
 
 # ---------------------------------------------------------------------------------------------------------
+# 3x3x3 convolution forward / data gradient (48 input channels)
+# ---------------------------------------------------------------------------------------------------------
+def pack_conv3d_weight(weight: torch.Tensor) -> torch.Tensor:
+    """(Cout, 48, 3, 3, 3) -> (Cout, 3, 3, 3, 48) contiguous bf16: the layout segm_conv3d_k3_fwd keeps in registers."""
+    return weight.permute(0, 2, 3, 4, 1).contiguous().to(torch.bfloat16)
+
+
+def pack_conv3d_weight_for_dgrad(weight: torch.Tensor) -> torch.Tensor:
+    """The data gradient of a stride-1 pad-1 3x3x3 convolution is the forward convolution of dy with the spatially
+    flipped, channel-transposed weights: (Cout, Cin, 3, 3, 3) -> packed (Cin, 3, 3, 3, Cout)."""
+    return pack_conv3d_weight(weight.flip(2, 3, 4).transpose(0, 1))
+
+
+def conv3d_k3_fwd_supported(x: torch.Tensor, cout: int) -> bool:
+    if x.dim() != 5 or x.dtype != torch.bfloat16 or x.shape[1] != 48 or cout % 16 or x.shape[4] % 8:
+        return False
+    return x.stride(4) == 1 and not any(x.stride(i) % 8 for i in range(4)) and x.data_ptr() % 16 == 0
+
+
+def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y (B, Cout, D, H, W) bf16 = conv3d(x, w, bias, stride 1, padding 1); x (B, 48, D, H, W) bf16, w_packed from
+    pack_conv3d_weight()."""
+    cout = w_packed.shape[0]
+    if not conv3d_k3_fwd_supported(x, cout):
+        raise RuntimeError("conv3d_k3_fwd: unsupported shape / dtype / layout")
+    if tuple(w_packed.shape[1:]) != (3, 3, 3, 48) or w_packed.dtype != torch.bfloat16 or not w_packed.is_contiguous():
+        raise RuntimeError("conv3d_k3_fwd: w_packed must be a contiguous bf16 (Cout, 3, 3, 3, 48) tensor")
+    B, _, D, H, W = x.shape
+    y = torch.empty(B, cout, D, H, W, dtype=x.dtype, device=x.device)
+    if bias is not None:
+        bias = bias.float().contiguous()
+    a = L.Conv3dFwdArgs()
+    a.batch, a.cin, a.cout, a.depth, a.height, a.width = B, 48, cout, D, H, W
+    a.dtype = L.SEGM_BF16
+    a.x, a.y, a.w_packed = x.data_ptr(), y.data_ptr(), w_packed.data_ptr()
+    a.x_stride_b, a.x_stride_c, a.x_stride_z, a.x_stride_y = x.stride()[:4]
+    a.y_stride_b, a.y_stride_c, a.y_stride_z, a.y_stride_y = y.stride()[:4]
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.stream = L.stream_handle(x)
+    lib.check(lib.dll.segm_conv3d_k3_fwd(a), "conv3d_k3_fwd")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------------
 # InstanceNorm3d (+ residual) (+ activation)
 # ---------------------------------------------------------------------------------------------------------
 ACT_CODES = {"none": 0, "relu": 1, "leaky_relu": 2}

@@ -6,5 +6,6 @@
 #include "../../segmamba_amd/csrc/conv1d.hip"
 #include "../../segmamba_amd/csrc/scan_bwd.hip"
 #include "../../segmamba_amd/csrc/conv3d_wgrad.hip"
+#include "../../segmamba_amd/csrc/conv3d_fwd.hip"
 #include "../../segmamba_amd/csrc/instnorm.hip"
 #include "../../segmamba_amd/csrc/layout.hip"

@@ -244,3 +244,29 @@ def test_scan_rejects_views_beyond_32bit_offsets(emu):
     a.seqlen = 64
     a.u.stride_t = 1 << 23                                 # 2^23 elements * 4 bytes = 2^25 bytes per row
     assert emu.dll.segm_selective_scan_fwd(a) == -2
+
+
+@pytest.mark.parametrize("shape", [(1, 48, 2, 3, 16), (1, 32, 3, 5, 64), (2, 16, 2, 4, 72), (1, 48, 1, 20, 8)])
+def test_conv3d_k3_fwd_emulated(emu, shape):
+    """forward 3x3x3 convolution: transposed LDS staging, stationary weight fragments, kz reduction, zero padding."""
+    B, cout, D, H_, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, 48, D, H_, W, generator=g).bfloat16()
+    w = (0.1 * torch.randn(cout, 48, 3, 3, 3, generator=g)).bfloat16()
+    bias = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), bias, 1, 1)
+    y = ops_raw.conv3d_k3_fwd(emu, x, ops_raw.pack_conv3d_weight(w), bias)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    assert (y.float() - ref).abs().max() <= 1e-2 * max(1.0, float(ref.abs().max()))
+    y0 = ops_raw.conv3d_k3_fwd(emu, x, ops_raw.pack_conv3d_weight(w))
+    assert (y0.float() - (ref - bias.view(1, -1, 1, 1, 1))).abs().max() <= 1e-2 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv3d_k3_dgrad_as_forward_emulated(emu):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 48, 2, 4, 16, generator=g, requires_grad=True)
+    w = (0.1 * torch.randn(48, 48, 3, 3, 3, generator=g)).bfloat16()
+    dy = torch.randn(1, 48, 2, 4, 16, generator=g).bfloat16()
+    torch.nn.functional.conv3d(x, w.float(), None, 1, 1).backward(dy.float())
+    dx = ops_raw.conv3d_k3_fwd(emu, dy, ops_raw.pack_conv3d_weight_for_dgrad(w))
+    assert (dx.float() - x.grad).abs().max() <= 1e-2 * max(1.0, float(x.grad.abs().max()))

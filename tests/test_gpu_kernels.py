@@ -336,3 +336,40 @@ def test_token_layout_autograd_full_size(hip):
     assert torch.equal(y, (x.detach() * wv).float().add(x.detach().float()).bfloat16())
     want = gy.float() * wv.float() + gy.float()
     assert ((gx.float() - want).abs() <= 2.0 ** -6 * (gy.float() * wv.float()).abs() + 2.0 ** -7 * want.abs() + 1e-6).all()
+
+
+# ---- 3x3x3 forward / data-gradient kernel: against fp32 conv3d on the same bf16-rounded operands -----------------------
+@pytest.mark.parametrize("shape", [(1, 48, 8, 8, 32), (2, 32, 5, 7, 64), (2, 48, 16, 16, 128), (1, 96, 6, 16, 16),
+                                   (1, 16, 3, 9, 72), (2, 48, 2, 20, 8)])
+def test_conv3d_k3_fwd_matches_fp32_conv(hip, shape):
+    B, cout, D, H_, W = shape
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(B, 48, D, H_, W, device=DEV, generator=g).bfloat16()
+    w = (0.05 * torch.randn(cout, 48, 3, 3, 3, device=DEV, generator=g)).bfloat16()
+    bias = torch.randn(cout, device=DEV, generator=g)
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), bias, 1, 1)
+    y = ops_raw.conv3d_k3_fwd(hip, x, ops_raw.pack_conv3d_weight(w), bias)
+    assert (y.float() - ref).abs().max() <= 2.0 ** -7 * max(1.0, float(ref.abs().max()))       # one bf16 rounding of the result
+    assert torch.equal(ops_raw.conv3d_k3_fwd(hip, x, ops_raw.pack_conv3d_weight(w), bias), y)   # deterministic
+    xs = torch.randn(B, 96, D, H_, W, device=DEV, generator=g).bfloat16()[:, 48:]               # channel slice (strided view)
+    ref = torch.nn.functional.conv3d(xs.float(), w.float(), None, 1, 1)
+    y = ops_raw.conv3d_k3_fwd(hip, xs, ops_raw.pack_conv3d_weight(w))
+    assert (y.float() - ref).abs().max() <= 2.0 ** -7 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv3d_same_autograd_with_library_kernels(hip, monkeypatch):
+    """the dispatcher with the library's fwd / dgrad / wgrad kernels forced in == torch's conv3d autograd (fp32)."""
+    from segmamba_amd import conv3d as C3
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(2, 48, 8, 16, 32, device=DEV, generator=g).bfloat16().requires_grad_()
+    w = (0.05 * torch.randn(48, 48, 3, 3, 3, device=DEV, generator=g)).bfloat16().requires_grad_()
+    bias = torch.randn(48, device=DEV, generator=g).bfloat16().requires_grad_()
+    dy = torch.randn(2, 48, 8, 16, 32, device=DEV, generator=g).bfloat16()
+    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
+    y = C3.conv3d_same(x, w, bias)
+    gx, gw, gb = torch.autograd.grad(y, (x, w, bias), dy)
+    x2, w2, b2 = (t.detach().float().requires_grad_() for t in (x, w, bias))
+    y2 = torch.nn.functional.conv3d(x2, w2, b2, 1, 1)
+    gx2, gw2, gb2 = torch.autograd.grad(y2, (x2, w2, b2), dy.float())
+    for got, want in ((y, y2), (gx, gx2), (gw, gw2), (gb, gb2)):
+        assert (got.float() - want).abs().max() <= 2e-2 * max(1.0, float(want.abs().max()))

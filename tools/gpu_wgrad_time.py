@@ -34,3 +34,15 @@ for (B, cin, cout, S) in ((2, 48, 48, 128), (2, 96, 96, 64), (2, 48, 48, 64)):
     err = ((got - ref).abs().max() / ref.abs().max()).item()
     print(f"wgrad B={B} {cin}->{cout} @{S}^3: mfma {ms:.3f} ms ({flops / ms * 1e-9:.1f} TF/s, "
           f"{(x.numel() + dy.numel()) * 2 / ms * 1e-6:.0f} GB/s), MIOpen {ms_ref:.3f} ms, rel err {err:.2e}", flush=True)
+
+for (B, cout, S) in ((2, 48, 128), (2, 48, 64), (2, 96, 64), (2, 48, 32)):
+    x = torch.randn(B, 48, S, S, S, device=dev).bfloat16()
+    w = (0.05 * torch.randn(cout, 48, 3, 3, 3, device=dev)).bfloat16()
+    wp = ops_raw.pack_conv3d_weight(w)
+    ms = t(lambda: ops_raw.conv3d_k3_fwd(hip, x, wp))
+    ms_ref = t(lambda: torch.nn.functional.conv3d(x, w, None, 1, 1), 3)
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), None, 1, 1)
+    err = ((ops_raw.conv3d_k3_fwd(hip, x, wp).float() - ref).abs().max() / ref.abs().max()).item()
+    flops = 2.0 * B * S ** 3 * 48 * cout * 27
+    print(f"fwd B={B} 48->{cout} @{S}^3: hip {ms:.3f} ms ({flops / ms * 1e-9:.1f} TF/s), MIOpen {ms_ref:.3f} ms, rel err {err:.2e}",
+          flush=True)
