@@ -13,7 +13,11 @@ clip 12, SGD(lr 1e-2, momentum 0.99, nesterov, wd 3e-5) step - the loop body of 
 Rank 0 prints ONE JSON line.  `value` = volumes / s over all GPUs.  `roofline` = the selective-scan forward at
 SegMamba's largest stage (B=2, D=96, N=16, L=64^3, same dtype as the step): algorithmic bytes (SURVEY.md §8d:
 e*B*L*(5D+2N)) / its measured duration (HIP events on the launch stream), against 8 TB/s HBM; the backward is reported
-next to it.  `cpu_baseline` = the CPU oracle (a port of the reference's pure-PyTorch selective_scan_ref) timed on this
+next to it.  `traffic` = HBM-side bytes of one forward launch from rocprofv3 PMC counters (FETCH_SIZE + WRITE_SIZE,
+separate passes, calibrated on kernels with known byte counts: profiles/r01_scan_pmc_hbm_traffic.txt) - a constant
+measured once per shape, since counters cannot be read from inside the timed process.  It is ~2x the algorithmic
+bytes by construction: the chunked scan reads u / delta / B twice (aggregate + apply passes) and, in training mode,
+writes the fp32 state checkpoints the backward starts from (as many bytes as out + out_z).  `cpu_baseline` = the CPU oracle (a port of the reference's pure-PyTorch selective_scan_ref) timed on this
 box's host cores on a bounded sample of the same operator.
 """
 from __future__ import annotations
@@ -36,6 +40,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per forward launch at the roofline shape, bf16 (tools/gpu_pmc_scan.sh ->
+# profiles/r01_scan_pmc_hbm_traffic.txt; reads scaled by the 2-byte-row calibration 100.66 MB / 67.47 MB):
+#   agg 167.3 MB*1.49 + 12.8 MB, carry 11.8 + 12.0 MB, apply 276.7 MB*1.49 + 394.1 MB
+SCAN_FWD_TRAFFIC_BF16 = int((167.27 * 1.49 + 12.75 + 11.76 + 12.0 + 276.67 * 1.49 + 394.08) * 2 ** 20)
 
 
 def parse():
@@ -95,7 +103,9 @@ def scan_roofline(dtype, device):
         "bound": "hbm", "kernel": "selective_scan_fwd (scan_fwd_agg + scan_carry + scan_fwd_apply)",
         "shape": {"B": B, "D": D, "N": N, "L": Lq, "layout": "channel-last", "chunk": f["chunk"]},
         "achieved": round(gf, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gf / HBM_PEAK_GBPS, 4),
-        "ms": round(ms_f, 4), "algorithmic_bytes": bytes_f, "traffic": None,
+        "ms": round(ms_f, 4), "algorithmic_bytes": bytes_f,
+        "traffic": SCAN_FWD_TRAFFIC_BF16 if dtype == torch.bfloat16 else None,
+        "note": "VALU-issue bound (one v_exp_f32 per step and state per pass, two passes): DESIGN.md section 4",
         "backward": {"achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4), "ms": round(ms_b, 4),
                      "algorithmic_bytes": bytes_b},
     }
