@@ -353,6 +353,9 @@ Geom make_geom(int batch, int dim, int nstate, int64_t L, int chunk) {   // L < 
     Geom g;
     g.batch = batch; g.dim = dim; g.nstate = nstate; g.L = (int32_t)L;
     g.rw = pick_rw(dim);
+    // the lanes of a work item stage the 8 x NS block of B / C of a sub-tile: an item must not be wider than that block
+    const int ns_pad = nstate <= 4 ? 4 : (nstate <= 8 ? 8 : 16);
+    if (g.rw > 8 * ns_pad) g.rw = 8 * ns_pad;
     g.g = 64 / g.rw;
     g.ndt = (dim + g.rw - 1) / g.rw;
     g.chunk = chunk;

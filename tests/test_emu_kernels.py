@@ -28,6 +28,8 @@ def emu():
     (64, 16, 96, 32, True, L.TIME_REVERSED, 1, 1),
     (32, 16, 96, 32, True, L.TIME_INTERLEAVED, 8, 1),
     (8, 8, 64, 32, True, L.TIME_FORWARD, 1, 2),           # grouped B / C
+    (64, 4, 64, 32, True, L.TIME_FORWARD, 1, 1),          # 4 states: a work item is narrowed to the 8 x 4 staging block
+    (64, 3, 48, 16, False, L.TIME_REVERSED, 1, 1),
 ])
 def test_scan_forward_backward_emulated(emu, dim, dstate, seqlen, chunk, channel_last, order, ns, groups):
     c = H.scan_case(2 if dim <= 8 else 1, dim, dstate, seqlen, groups=groups, seed=dim + seqlen)

@@ -68,6 +68,12 @@ def test_scan_half_precision(hip, dtype, channel_last):
     H.check_scan(res, ref, dtype, f"{dtype}")
 
 
+@pytest.mark.parametrize("dim,dstate", [(64, 4), (128, 3), (64, 8), (192, 2)])
+def test_scan_small_state_wide_channels(hip, dim, dstate):
+    c = H.scan_case(2, dim, dstate, 200, seed=dim + dstate)
+    H.check_scan(H.run_scan(hip, c, DEV, True), H.scan_oracle(c), torch.float32, f"D={dim} N={dstate}")
+
+
 def test_scan_optional_arguments(hip):
     for has_z, has_D, has_bias, softplus in [(False, True, True, True), (True, False, False, False), (False, False, False, True)]:
         c = H.scan_case(1, 32, 16, 200, has_z=has_z, has_D=has_D, has_bias=has_bias, seed=3)
