@@ -137,7 +137,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("SEGM_FORCE_DDP") == "1"     # the latter: exercise the DDP path on one GPU
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -10,7 +10,7 @@ lr_scheduler.py:36 poly 0.9).  Differences, all deliberate:
   * autocast dtype is bf16 (the north star's dtype; the reference's default fp16 + GradScaler is not needed for bf16);
   * data come from a device-side synthetic generator instead of the 18-process batchgenerators pipeline
     (trainer.py:154-162), which is out of scope (SURVEY.md §2.1);
-  * multi-GPU is the same plain DDP (trainer.py:353-357: find_unused_parameters=True) over RCCL; one process per GPU,
+  * multi-GPU is the same plain DDP (trainer.py:353-357) over RCCL; one process per GPU,
     launched by torchrun - batch per GPU stays 2 (weak scaling), gradients are all-reduced in DDP's buckets.
 """
 from __future__ import annotations
@@ -63,8 +63,15 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
     if os.environ.get("SEGM_CHANNELS_LAST_3D", "0") == "1":     # experiment switch: NDHWC activations / weights
         model = model.to(memory_format=torch.channels_last_3d)
     if distributed:
+        # The reference passes find_unused_parameters=True (trainer.py:354-357); every SegMamba parameter takes part in
+        # every step (DDP itself reports "did not find any unused parameters"), so the extra per-step graph traversal
+        # is dropped.  Gradients live in the communication buckets (no copy in, no copy out), and the buckets are
+        # large: xGMI rings are per-link bound, a few 64 MB all-reduces beat many 25 MB ones.  SEGM_DDP_FIND_UNUSED=1
+        # restores the reference's flag.
         model = torch.nn.parallel.DistributedDataParallel(
-            model, device_ids=[local_rank] if device.type == "cuda" else None, find_unused_parameters=True)
+            model, device_ids=[local_rank] if device.type == "cuda" else None,
+            find_unused_parameters=os.environ.get("SEGM_DDP_FIND_UNUSED", "0") == "1",
+            gradient_as_bucket_view=True, bucket_cap_mb=64)
     opt = torch.optim.SGD(model.parameters(), lr=1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: (1 - min(s, max_steps - 1) / max_steps) ** 0.9)
     return TrainingState(model=model, optimizer=opt, scheduler=sched, loss_fn=nn.CrossEntropyLoss())
