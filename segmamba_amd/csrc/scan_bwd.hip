@@ -141,12 +141,12 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
 // reduce-scatter over the RW lanes of a work item: on return lane r holds, in v[0], the sum over the item's
 // lanes of the value the lanes had at index (r mod V).  V = min(RW, 32) values per call.
 // ------------------------------------------------------------------------------------------------------
+#ifdef SEGM_EMU
+// portable form (CPU emulation build): wave shuffles
 template <int RW, int V>
 __device__ __forceinline__ void reduce_scatter(float (&v)[V], int r) {
 #pragma unroll
     for (int m = V / 2; m >= 1; m >>= 1) {
-        // bit-select instead of `upper ? v[m+i] : v[i]`: the compiler turns a select between two elements of a
-        // register array into a dynamically indexed array (16-way compare/select chains, array pinned in VGPRs)
         const uint32_t mask = (r & m) ? 0xffffffffu : 0u;
 #pragma unroll
         for (int i = 0; i < m; ++i) {
@@ -158,6 +158,60 @@ __device__ __forceinline__ void reduce_scatter(float (&v)[V], int r) {
     }
     if (RW > V) v[0] += __shfl_xor(v[0], V);               // RW == 64: fold the two 32-lane halves
 }
+#else
+// gfx950 form: no LDS traffic.  A stage with partner lane ^ m keeps v[i] on lanes with bit m clear and v[m + i] on
+// lanes with it set, and adds the partner's copy of the same element.
+//   m = 16  v_permlane16_swap_b32 exchanges the odd 16-lane rows of one register with the even rows of another: after
+//           swapping (v[i], v[16 + i]) every lane holds its own and its partner's copy of the element it keeps.
+//   m <= 8  partners are in the same row of 16: DPP operands (row_ror:8, row_shl/shr:4 with bank masks, quad_perm).
+template <int CTRL> __device__ __forceinline__ float dpp_get(float x) {      // x of the lane CTRL selects (0 if none)
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, true));
+}
+template <int RW, int V>
+__device__ __forceinline__ void reduce_scatter(float (&v)[V], int r) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    if constexpr (V >= 32) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const u32x2_t sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[16 + i]), false, false);
+            v[i] = __uint_as_float(sw.x) + __uint_as_float(sw.y);
+        }
+    }
+    if constexpr (V >= 16) {
+        const bool up = (r & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float slo = v[i] + dpp_get<0x128>(v[i]);                   // row_ror:8 = lane ^ 8
+            const float shi = v[8 + i] + dpp_get<0x128>(v[8 + i]);
+            v[i] = up ? shi : slo;
+        }
+    }
+    if constexpr (V >= 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[4 + i]);
+            // lanes with bit 2 clear (banks 0, 2) receive lo of lane + 4, the others hi of lane - 4
+            uint32_t recv = __builtin_amdgcn_update_dpp(0u, lo, 0x104, 0xf, 0x5, false);       // row_shl:4
+            recv = __builtin_amdgcn_update_dpp(recv, hi, 0x114, 0xf, 0xa, false);              // row_shr:4
+            const uint32_t keep = __builtin_amdgcn_update_dpp(lo, hi, 0xe4, 0xf, 0xa, false);  // identity on banks 1, 3
+            v[i] = __uint_as_float(keep) + __uint_as_float(recv);
+        }
+    }
+    {
+        const bool up2 = (r & 2) != 0, up1 = (r & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float slo = v[i] + dpp_get<0x4e>(v[i]);                    // quad_perm:[2,3,0,1] = lane ^ 2
+            const float shi = v[2 + i] + dpp_get<0x4e>(v[2 + i]);
+            v[i] = up2 ? shi : slo;
+        }
+        const float slo = v[0] + dpp_get<0xb1>(v[0]);                        // quad_perm:[1,0,3,2] = lane ^ 1
+        const float shi = v[1] + dpp_get<0xb1>(v[1]);
+        v[0] = up1 ? shi : slo;
+    }
+    if (RW > V) v[0] += __shfl_xor(v[0], V);               // RW == 64: fold the two 32-lane halves
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------------
 // K3: main backward kernel
@@ -229,7 +283,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MIN_WAVES) scan_bwd_main_kern
         StageRegs<kWin, NS, RW> sb, scc;
         stage_fetch<T, kWin, NS, RW>(sb, P.Bm, tm, tw, ub, nstate, it.r, item_ok);
         stage_fetch<T, kWin, NS, RW>(scc, P.Cm, tm, tw, ub, nstate, it.r, item_ok);
-        float wu[kWin], wd[kWin], wg[kWin], du[kWin], dd[kWin];
+        float wu[kWin], wd[kWin], wg[kWin], du[kWin], dd[kWin], wdu[kWin];     // wdu = delta * u, shared by all states
         uint32_t okm;
         {
             int32_t tt[kWin];
@@ -254,6 +308,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MIN_WAVES) scan_bwd_main_kern
                 }
                 du[j] = Dv * wg[j];
                 dd[j] = 0.f;
+                wdu[j] = wd[j] * wu[j];
                 dD_acc = fmaf(wg[j], wu[j], dD_acc);
             }
         }
@@ -292,7 +347,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MIN_WAVES) scan_bwd_main_kern
                 for (int i = 0; i < 4; ++i) {
                     const int j = q * 4 + i;
                     a[j] = fast_exp2(wd[j] * A2n);
-                    h[j] = fmaf(a[j], j ? h[j - 1] : hp, wd[j] * wu[j] * bb[i]);
+                    h[j] = fmaf(a[j], j ? h[j - 1] : hp, wdu[j] * bb[i]);
                 }
             }
             float v[2 * kWin];                              // [0,16): dB_j ; [16,32): dC_j   (this state)
@@ -311,7 +366,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MIN_WAVES) scan_bwd_main_kern
                     const float qv = dh * bb[i];
                     dd[j] = fmaf(t2, An, fmaf(qv, wu[j], dd[j]));
                     du[j] = fmaf(qv, wd[j], du[j]);
-                    v[j] = dh * wd[j] * wu[j];
+                    v[j] = dh * wdu[j];
                     v[kWin + j] = wg[j] * h[j];
                     en = a[j] * dh;
                 }

@@ -27,7 +27,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #endif
 
 #ifndef SEGM_FAST_MIN_WAVES
-#define SEGM_FAST_MIN_WAVES 2       // waves per SIMD the apply kernel is register-limited to
+#define SEGM_FAST_MIN_WAVES 3       // waves per SIMD the apply kernel is register-limited to (3072 waves at stage 0 = 3 per SIMD)
 #endif
 
 constexpr int kFS = 16;     // states
@@ -288,27 +288,21 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
         char* orow = const_cast<char*>(op.base) + (int64_t)Uc * op.stb;
         char* ozrow = const_cast<char*>(ozp.base) + (int64_t)Uc * ozp.stb;
         const int64_t oinc = (int64_t)ck.dT * op.stb, ozinc = (int64_t)ck.dT * ozp.stb;
-        float4 bq[4], cq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bq[q] = reinterpret_cast<const float4*>(lb)[q];
-            cq[q] = reinterpret_cast<const float4*>(lc)[q];
-        }
 #pragma unroll
         for (int j = 0; j < kFT; ++j) {
             float dl = cd[j] + bias;
             dl = softplus_on ? softplus20(dl) : dl;
             const float uu = cu[j];
             const float dlu = dl * uu;
-            f2 y2 = {Dv * uu, 0.f};
-            float4 bn[4], cn[4];
-            if (j + 1 < kFT) {                             // next step's B / C rows, one step ahead of their use
+            // this step's B / C rows (wave-uniform addresses: LDS broadcast reads); with 3 waves per SIMD resident the
+            // read latency is covered by the other waves, so nothing is prefetched into registers
+            float4 bq[4], cq[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    bn[q] = reinterpret_cast<const float4*>(lb + (j + 1) * kFS)[q];
-                    cn[q] = reinterpret_cast<const float4*>(lc + (j + 1) * kFS)[q];
-                }
+            for (int q = 0; q < 4; ++q) {
+                bq[q] = reinterpret_cast<const float4*>(lb + j * kFS)[q];
+                cq[q] = reinterpret_cast<const float4*>(lc + j * kFS)[q];
             }
+            f2 ya = {Dv * uu, 0.f}, yb = {0.f, 0.f};       // two independent accumulation chains
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f2 b0 = {bq[q].x, bq[q].y}, b1 = {bq[q].z, bq[q].w};
@@ -318,21 +312,17 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
                 const f2 a1 = {fast_exp2(da1.x), fast_exp2(da1.y)};
                 h[2 * q] = a0 * h[2 * q] + b0 * dlu;
                 h[2 * q + 1] = a1 * h[2 * q + 1] + b1 * dlu;
-                y2 = c0 * h[2 * q] + y2;
-                y2 = c1 * h[2 * q + 1] + y2;
+                ya = c0 * h[2 * q] + ya;
+                yb = c1 * h[2 * q + 1] + yb;
             }
-            const float y = y2.x + y2.y;
+            const float y = (ya.x + yb.x) + (ya.y + yb.y);
             if (has_out) *reinterpret_cast<T*>(orow + (int64_t)j * oinc + op.loff) = from_f32<T>(y);
             if (has_z) {
                 const float zz = cz[j];
                 *reinterpret_cast<T*>(ozrow + (int64_t)j * ozinc + ozp.loff) = from_f32<T>(y * zz * sigmoidf(zz));
             }
 #pragma unroll
-            for (int n = 0; n < kFS / 2; ++n) SEGM_PIN_F2(h[n]);      // finish this step before the LDS reads two steps ahead
-            if (j + 1 < kFT) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { bq[q] = bn[q]; cq[q] = cn[q]; }
-            }
+            for (int n = 0; n < kFS / 2; ++n) SEGM_PIN_F2(h[n]);      // keeps the LDS reads of later steps from being hoisted here
         }
         buf ^= 1;
     }

@@ -20,7 +20,7 @@ def build_emu(force: bool = False) -> str:
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + EMU_DIR, "-Wno-unused-value", "-DSEGM_PIN_F32(x)=", "-DSEGM_SCHED_FENCE()=", "-DSEGM_PIN_F2(x)=", "-DSEGM_WAVE_LDS_SYNC()=hipemu::sync_wave()",
+    cmd = [CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + EMU_DIR, "-Wno-unused-value", "-DSEGM_PIN_F32(x)=", "-DSEGM_SCHED_FENCE()=", "-DSEGM_EMU=1", "-DSEGM_PIN_F2(x)=", "-DSEGM_WAVE_LDS_SYNC()=hipemu::sync_wave()",
            os.path.join(EMU_DIR, "emu_entry.cpp"), os.path.join(EMU_DIR, "hip_emu_runtime.cpp"), "-o", OUT]
     subprocess.run(cmd, check=True, cwd=ROOT)
     return OUT
