@@ -19,9 +19,10 @@
 //      parked in LDS and flushed once per window - no per-element global atomics from every channel as in
 //      the reference (:297-316); atomics are only used between d-tiles.
 //   K4  reduce_partials_kernel  per-item partial dA / dD / ddelta_bias -> final (deterministic, no atomics)
+#include <stdlib.h>
 #include <string.h>
 
-#include "scan_common.h"
+#include "scan_fast.h"
 
 namespace segm {
 
@@ -136,82 +137,6 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
             if (n < nstate) P.agg_h[(row * nstate + n) * gm.dim + it.d] = e[n];
     }
 }
-
-// ------------------------------------------------------------------------------------------------------
-// reduce-scatter over the RW lanes of a work item: on return lane r holds, in v[0], the sum over the item's
-// lanes of the value the lanes had at index (r mod V).  V = min(RW, 32) values per call.
-// ------------------------------------------------------------------------------------------------------
-#ifdef SEGM_EMU
-// portable form (CPU emulation build): wave shuffles
-template <int RW, int V>
-__device__ __forceinline__ void reduce_scatter(float (&v)[V], int r) {
-#pragma unroll
-    for (int m = V / 2; m >= 1; m >>= 1) {
-        const uint32_t mask = (r & m) ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int i = 0; i < m; ++i) {
-            const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[m + i]);
-            const float keep = __uint_as_float((hi & mask) | (lo & ~mask));
-            const float send = __uint_as_float((lo & mask) | (hi & ~mask));
-            v[i] = keep + __shfl_xor(send, m);
-        }
-    }
-    if (RW > V) v[0] += __shfl_xor(v[0], V);               // RW == 64: fold the two 32-lane halves
-}
-#else
-// gfx950 form: no LDS traffic.  A stage with partner lane ^ m keeps v[i] on lanes with bit m clear and v[m + i] on
-// lanes with it set, and adds the partner's copy of the same element.
-//   m = 16  v_permlane16_swap_b32 exchanges the odd 16-lane rows of one register with the even rows of another: after
-//           swapping (v[i], v[16 + i]) every lane holds its own and its partner's copy of the element it keeps.
-//   m <= 8  partners are in the same row of 16: DPP operands (row_ror:8, row_shl/shr:4 with bank masks, quad_perm).
-template <int CTRL> __device__ __forceinline__ float dpp_get(float x) {      // x of the lane CTRL selects (0 if none)
-    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, true));
-}
-template <int RW, int V>
-__device__ __forceinline__ void reduce_scatter(float (&v)[V], int r) {
-    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-    if constexpr (V >= 32) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const u32x2_t sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[16 + i]), false, false);
-            v[i] = __uint_as_float(sw.x) + __uint_as_float(sw.y);
-        }
-    }
-    if constexpr (V >= 16) {
-        const bool up = (r & 8) != 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float slo = v[i] + dpp_get<0x128>(v[i]);                   // row_ror:8 = lane ^ 8
-            const float shi = v[8 + i] + dpp_get<0x128>(v[8 + i]);
-            v[i] = up ? shi : slo;
-        }
-    }
-    if constexpr (V >= 8) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[4 + i]);
-            // lanes with bit 2 clear (banks 0, 2) receive lo of lane + 4, the others hi of lane - 4
-            uint32_t recv = __builtin_amdgcn_update_dpp(0u, lo, 0x104, 0xf, 0x5, false);       // row_shl:4
-            recv = __builtin_amdgcn_update_dpp(recv, hi, 0x114, 0xf, 0xa, false);              // row_shr:4
-            const uint32_t keep = __builtin_amdgcn_update_dpp(lo, hi, 0xe4, 0xf, 0xa, false);  // identity on banks 1, 3
-            v[i] = __uint_as_float(keep) + __uint_as_float(recv);
-        }
-    }
-    {
-        const bool up2 = (r & 2) != 0, up1 = (r & 1) != 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float slo = v[i] + dpp_get<0x4e>(v[i]);                    // quad_perm:[2,3,0,1] = lane ^ 2
-            const float shi = v[2 + i] + dpp_get<0x4e>(v[2 + i]);
-            v[i] = up2 ? shi : slo;
-        }
-        const float slo = v[0] + dpp_get<0xb1>(v[0]);                        // quad_perm:[1,0,3,2] = lane ^ 1
-        const float shi = v[1] + dpp_get<0xb1>(v[1]);
-        v[0] = up1 ? shi : slo;
-    }
-    if (RW > V) v[0] += __shfl_xor(v[0], V);               // RW == 64: fold the two 32-lane halves
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------------
 // K3: main backward kernel
@@ -480,6 +405,12 @@ static int launch_bwd(const ScanDev& P, hipStream_t stream) {
     return launch_bwd_rw<T, NS, 16>(P, stream);
 }
 
+// SEGM_SCAN_FAST=0 forces the general kernels (A/B timing, and the tests that must exercise them on regular shapes)
+static bool use_fast_bwd() {
+    const char* e = getenv("SEGM_SCAN_FAST");
+    return !(e && e[0] == '0');
+}
+
 template <typename T>
 static int launch_bwd_ns(const ScanDev& P, hipStream_t stream) {
     if (P.gm.nstate <= 4) return launch_bwd<T, 4>(P, stream);
@@ -552,7 +483,12 @@ extern "C" int segm_selective_scan_bwd(const segm_scan_bwd_args* b) {
             hipLaunchKernelGGL(clear_bc_kernel, cg, dim3(256), 0, stream, P.dB, P.dB_sb, P.dB_st, P.dB_sn, (int32_t)a->seqlen, N);
             hipLaunchKernelGGL(clear_bc_kernel, cg, dim3(256), 0, stream, P.dC, P.dC_sb, P.dC_st, P.dC_sn, (int32_t)a->seqlen, N);
         }
-        if (a->dtype == SEGM_F32) rc = launch_bwd_ns<float>(P, stream);
+        if (use_fast_bwd() && scan_bwd_fast_shape(P)) {     // regular shapes (every SegMamba stage): scan_bwd_fast.hip
+            launch_scan_bwd_fast(P, a->dtype, false, stream);
+            launch_scan_carry(P, true, P.agg_sd, P.agg_h, P.carry, stream);
+            launch_scan_bwd_fast(P, a->dtype, true, stream);
+            rc = (int)hipGetLastError();
+        } else if (a->dtype == SEGM_F32) rc = launch_bwd_ns<float>(P, stream);
         else if (a->dtype == SEGM_F16) rc = launch_bwd_ns<f16_t>(P, stream);
         else rc = launch_bwd_ns<bf16_t>(P, stream);
         if (rc != 0) return rc;

@@ -136,6 +136,8 @@ int validate_spans(const segm_seq* const* seqs, int nseq, const segm_bc* const* 
                    int64_t L, size_t esize);
 bool scan_fast_shape(const ScanDev& P);                        // scan_fwd_fast.hip: shapes its kernels take
 void launch_scan_fwd_fast(const ScanDev& P, int dtype, bool apply, hipStream_t stream);
+bool scan_bwd_fast_shape(const ScanDev& P);                    // scan_bwd_fast.hip
+void launch_scan_bwd_fast(const ScanDev& P, int dtype, bool main, hipStream_t stream);
 void launch_scan_carry(const ScanDev& P, bool reverse, const float* agg_sd, const float* agg_h, float* carry,
                        hipStream_t stream);
 

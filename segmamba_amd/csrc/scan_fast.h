@@ -1,0 +1,201 @@
+// Pieces shared by the "regular shape" scan kernels (scan_fwd_fast.hip, scan_bwd_fast.hip): wave-uniform time
+// arithmetic, uniform-base + constant-lane-offset row streams, B / C staging, packed fp32 pairs.
+#pragma once
+#include <limits.h>
+
+#include "scan_common.h"
+
+namespace segm {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#ifndef SEGM_PIN_F2
+#define SEGM_PIN_F2(x) asm volatile("" : "+v"(x) : : "memory")
+#endif
+
+#ifndef SEGM_FAST_MIN_WAVES
+#define SEGM_FAST_MIN_WAVES 3       // waves per SIMD the apply kernel is register-limited to (3072 waves at stage 0 = 3 per SIMD)
+#endif
+
+constexpr int kFS = 16;     // states
+constexpr int kFT = 8;      // steps per sub-tile
+
+// Wave-uniform description of where sub-tile s of every work item lives: physical row = T_item + U(s) + i * dT.
+struct FastClock {
+    int32_t dT;             // rows between consecutive logical steps inside a sub-tile
+    int32_t ns;             // INTERLEAVED: slices (a sub-tile never wraps); otherwise INT_MAX
+    int32_t sA;
+    int32_t kk, jj, U;
+    __device__ __forceinline__ void init(const TimeMap& tm) {
+        const bool inter = tm.ns > 1;
+        dT = inter ? tm.sA : tm.sA + tm.sW;                // FORWARD +1, REVERSED -1, INTERLEAVED L / ns
+        ns = inter ? tm.ns : INT_MAX;
+        sA = tm.sA;
+        kk = 0; jj = 0; U = 0;
+    }
+    __device__ __forceinline__ int32_t next_U() const {     // U of the following sub-tile
+        return (kk + kFT == ns) ? jj + 1 : U + kFT * dT;
+    }
+    __device__ __forceinline__ void advance() {
+        U = next_U();
+        kk += kFT;
+        if (kk == ns) { kk = 0; ++jj; }
+    }
+};
+// physical row of the first step of a work item (chunk start tau0; tau0 % ns == 0 for INTERLEAVED)
+__device__ __forceinline__ int32_t fast_item_row(const TimeMap& tm, int32_t tau0) {
+    if (tm.ns > 1) return (int32_t)((uint32_t)tau0 / (uint32_t)tm.ns);
+    return tm.base + tau0 * (tm.sA + tm.sW);
+}
+
+// A per-lane stream of one sequence tensor: uniform base + constant lane offset.
+struct FastRow {
+    const char* base;       // p + b * stride_b                    (uniform)
+    int64_t stb;            // stride_t in bytes                   (uniform)
+    uint32_t loff;          // T_item * stride_t + d * stride_d    (bytes, per lane)
+};
+template <typename T> __device__ __forceinline__ FastRow fast_row(const Seq& s, int b_uniform, int32_t t_item, int d) {
+    FastRow r;
+    r.base = s.p + (int64_t)b_uniform * s.sb * (int64_t)sizeof(T);
+    r.stb = s.st * (int64_t)sizeof(T);
+    r.loff = (uint32_t)t_item * (uint32_t)r.stb + (uint32_t)d * (uint32_t)(s.sd * (int64_t)sizeof(T));
+    return r;
+}
+// the kFT rows of the sub-tile at uniform row offset U
+template <typename T>
+__device__ __forceinline__ void fast_fetch(float (&dst)[kFT], const FastRow& r, int32_t U, int32_t dT) {
+    const char* p = r.base + (int64_t)U * r.stb;
+    const int64_t inc = (int64_t)dT * r.stb;
+#pragma unroll
+    for (int j = 0; j < kFT; ++j) dst[j] = to_f32(*reinterpret_cast<const T*>(p + (int64_t)j * inc + r.loff));
+}
+
+// B / C staging: lane r of a work item fetches elements e = r + i * RW of the kFT x 16 block of its sub-tile.
+template <int RW> struct FastStage {
+    static constexpr int EPL = kFT * kFS / RW;   // elements per lane: 2, 4 or 8
+    const char* base;       // uniform
+    int64_t stb;            // row stride in bytes (uniform)
+    int64_t inc;            // byte distance between a lane's consecutive elements (uniform)
+    uint32_t loff;          // per lane
+    int32_t lds0, ldsinc;   // LDS index ([s][n] layout) of element 0 and the step between elements
+};
+template <typename T, int RW>
+__device__ __forceinline__ FastStage<RW> fast_stage(const BC& m, int b_uniform, int32_t t_item, int32_t dT, int r) {
+    FastStage<RW> st;
+    st.base = m.p + (int64_t)b_uniform * m.sb * (int64_t)sizeof(T);
+    st.stb = m.st * (int64_t)sizeof(T);
+    const int64_t snb = m.sn * (int64_t)sizeof(T);
+    if (m.st <= m.sn) {                                    // time fastest in memory: e -> (n = e / kFT, s = e % kFT)
+        const int s = r % kFT, n = r / kFT;
+        st.loff = (uint32_t)(t_item + s * dT) * (uint32_t)st.stb + (uint32_t)n * (uint32_t)snb;
+        st.inc = (int64_t)(RW / kFT) * snb;
+        st.lds0 = s * kFS + n;
+        st.ldsinc = RW / kFT;
+    } else {                                               // state fastest: e -> (s = e / 16, n = e % 16)
+        const int s = r / kFS, n = r % kFS;
+        st.loff = (uint32_t)(t_item + s * dT) * (uint32_t)st.stb + (uint32_t)n * (uint32_t)snb;
+        st.inc = (int64_t)((RW >= kFS ? RW / kFS : 1) * dT) * st.stb;
+        st.lds0 = s * kFS + n;
+        st.ldsinc = (RW >= kFS ? RW / kFS : 1) * kFS;
+    }
+    return st;
+}
+template <typename T, int RW>
+__device__ __forceinline__ void fast_stage_fetch(float (&v)[FastStage<RW>::EPL], const FastStage<RW>& st, int32_t U) {
+    const char* p = st.base + (int64_t)U * st.stb;
+#pragma unroll
+    for (int i = 0; i < FastStage<RW>::EPL; ++i) v[i] = to_f32(*reinterpret_cast<const T*>(p + (int64_t)i * st.inc + st.loff));
+}
+template <int RW>
+__device__ __forceinline__ void fast_stage_park(const float (&v)[FastStage<RW>::EPL], const FastStage<RW>& st, float* lds_item) {
+#pragma unroll
+    for (int i = 0; i < FastStage<RW>::EPL; ++i) lds_item[st.lds0 + i * st.ldsinc] = v[i];
+}
+
+// U of sub-tile s computed directly (the backward walks the sub-tiles downwards)
+__device__ __forceinline__ int32_t fast_U_of(const TimeMap& tm, int32_t s) {
+    if (tm.ns > 1) {
+        const uint32_t t8 = (uint32_t)s * (uint32_t)kFT;
+        const uint32_t jj = t8 / (uint32_t)tm.ns, kk = t8 - jj * (uint32_t)tm.ns;
+        return (int32_t)(kk * (uint32_t)tm.sA + jj);
+    }
+    return s * kFT * (tm.sA + tm.sW);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// reduce-scatter over the RW lanes of a work item: on return lane r holds, in v[0], the sum over the item's
+// lanes of the value the lanes had at index (r mod V).  V = min(RW, 32) values per call.
+// ------------------------------------------------------------------------------------------------------
+#ifdef SEGM_EMU
+// portable form (CPU emulation build): wave shuffles
+template <int RW, int V>
+__device__ __forceinline__ void reduce_scatter(float (&v)[V], int r) {
+#pragma unroll
+    for (int m = V / 2; m >= 1; m >>= 1) {
+        const uint32_t mask = (r & m) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+            const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[m + i]);
+            const float keep = __uint_as_float((hi & mask) | (lo & ~mask));
+            const float send = __uint_as_float((lo & mask) | (hi & ~mask));
+            v[i] = keep + __shfl_xor(send, m);
+        }
+    }
+    if (RW > V) v[0] += __shfl_xor(v[0], V);               // RW == 64: fold the two 32-lane halves
+}
+#else
+// gfx950 form: no LDS traffic.  A stage with partner lane ^ m keeps v[i] on lanes with bit m clear and v[m + i] on
+// lanes with it set, and adds the partner's copy of the same element.
+//   m = 16  v_permlane16_swap_b32 exchanges the odd 16-lane rows of one register with the even rows of another: after
+//           swapping (v[i], v[16 + i]) every lane holds its own and its partner's copy of the element it keeps.
+//   m <= 8  partners are in the same row of 16: DPP operands (row_ror:8, row_shl/shr:4 with bank masks, quad_perm).
+template <int CTRL> __device__ __forceinline__ float dpp_get(float x) {      // x of the lane CTRL selects (0 if none)
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, true));
+}
+template <int RW, int V>
+__device__ __forceinline__ void reduce_scatter(float (&v)[V], int r) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    if constexpr (V >= 32) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const u32x2_t sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[16 + i]), false, false);
+            v[i] = __uint_as_float(sw.x) + __uint_as_float(sw.y);
+        }
+    }
+    if constexpr (V >= 16) {
+        const bool up = (r & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float slo = v[i] + dpp_get<0x128>(v[i]);                   // row_ror:8 = lane ^ 8
+            const float shi = v[8 + i] + dpp_get<0x128>(v[8 + i]);
+            v[i] = up ? shi : slo;
+        }
+    }
+    if constexpr (V >= 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[4 + i]);
+            // lanes with bit 2 clear (banks 0, 2) receive lo of lane + 4, the others hi of lane - 4
+            uint32_t recv = __builtin_amdgcn_update_dpp(0u, lo, 0x104, 0xf, 0x5, false);       // row_shl:4
+            recv = __builtin_amdgcn_update_dpp(recv, hi, 0x114, 0xf, 0xa, false);              // row_shr:4
+            const uint32_t keep = __builtin_amdgcn_update_dpp(lo, hi, 0xe4, 0xf, 0xa, false);  // identity on banks 1, 3
+            v[i] = __uint_as_float(keep) + __uint_as_float(recv);
+        }
+    }
+    {
+        const bool up2 = (r & 2) != 0, up1 = (r & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float slo = v[i] + dpp_get<0x4e>(v[i]);                    // quad_perm:[2,3,0,1] = lane ^ 2
+            const float shi = v[2 + i] + dpp_get<0x4e>(v[2 + i]);
+            v[i] = up2 ? shi : slo;
+        }
+        const float slo = v[0] + dpp_get<0xb1>(v[0]);                        // quad_perm:[1,0,3,2] = lane ^ 1
+        const float shi = v[1] + dpp_get<0xb1>(v[1]);
+        v[0] = up1 ? shi : slo;
+    }
+    if (RW > V) v[0] += __shfl_xor(v[0], V);               // RW == 64: fold the two 32-lane halves
+}
+#endif
+
+}  // namespace segm

@@ -14,116 +14,9 @@
 //     the non-transcendental issue slots of a step:  per state pair  2 v_exp + 2 v_pk_mul + 1 (agg) or 2 (apply) v_pk_fma.
 // Results are bit-identical in structure to the general kernels (same operation order per state), so the backward pass
 // and the checkpoint format are unchanged.
-#include <limits.h>
-
-#include "scan_common.h"
+#include "scan_fast.h"
 
 namespace segm {
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-#ifndef SEGM_PIN_F2
-#define SEGM_PIN_F2(x) asm volatile("" : "+v"(x) : : "memory")
-#endif
-
-#ifndef SEGM_FAST_MIN_WAVES
-#define SEGM_FAST_MIN_WAVES 3       // waves per SIMD the apply kernel is register-limited to (3072 waves at stage 0 = 3 per SIMD)
-#endif
-
-constexpr int kFS = 16;     // states
-constexpr int kFT = 8;      // steps per sub-tile
-
-// Wave-uniform description of where sub-tile s of every work item lives: physical row = T_item + U(s) + i * dT.
-struct FastClock {
-    int32_t dT;             // rows between consecutive logical steps inside a sub-tile
-    int32_t ns;             // INTERLEAVED: slices (a sub-tile never wraps); otherwise INT_MAX
-    int32_t sA;
-    int32_t kk, jj, U;
-    __device__ __forceinline__ void init(const TimeMap& tm) {
-        const bool inter = tm.ns > 1;
-        dT = inter ? tm.sA : tm.sA + tm.sW;                // FORWARD +1, REVERSED -1, INTERLEAVED L / ns
-        ns = inter ? tm.ns : INT_MAX;
-        sA = tm.sA;
-        kk = 0; jj = 0; U = 0;
-    }
-    __device__ __forceinline__ int32_t next_U() const {     // U of the following sub-tile
-        return (kk + kFT == ns) ? jj + 1 : U + kFT * dT;
-    }
-    __device__ __forceinline__ void advance() {
-        U = next_U();
-        kk += kFT;
-        if (kk == ns) { kk = 0; ++jj; }
-    }
-};
-// physical row of the first step of a work item (chunk start tau0; tau0 % ns == 0 for INTERLEAVED)
-__device__ __forceinline__ int32_t fast_item_row(const TimeMap& tm, int32_t tau0) {
-    if (tm.ns > 1) return (int32_t)((uint32_t)tau0 / (uint32_t)tm.ns);
-    return tm.base + tau0 * (tm.sA + tm.sW);
-}
-
-// A per-lane stream of one sequence tensor: uniform base + constant lane offset.
-struct FastRow {
-    const char* base;       // p + b * stride_b                    (uniform)
-    int64_t stb;            // stride_t in bytes                   (uniform)
-    uint32_t loff;          // T_item * stride_t + d * stride_d    (bytes, per lane)
-};
-template <typename T> __device__ __forceinline__ FastRow fast_row(const Seq& s, int b_uniform, int32_t t_item, int d) {
-    FastRow r;
-    r.base = s.p + (int64_t)b_uniform * s.sb * (int64_t)sizeof(T);
-    r.stb = s.st * (int64_t)sizeof(T);
-    r.loff = (uint32_t)t_item * (uint32_t)r.stb + (uint32_t)d * (uint32_t)(s.sd * (int64_t)sizeof(T));
-    return r;
-}
-// the kFT rows of the sub-tile at uniform row offset U
-template <typename T>
-__device__ __forceinline__ void fast_fetch(float (&dst)[kFT], const FastRow& r, int32_t U, int32_t dT) {
-    const char* p = r.base + (int64_t)U * r.stb;
-    const int64_t inc = (int64_t)dT * r.stb;
-#pragma unroll
-    for (int j = 0; j < kFT; ++j) dst[j] = to_f32(*reinterpret_cast<const T*>(p + (int64_t)j * inc + r.loff));
-}
-
-// B / C staging: lane r of a work item fetches elements e = r + i * RW of the kFT x 16 block of its sub-tile.
-template <int RW> struct FastStage {
-    static constexpr int EPL = kFT * kFS / RW;   // elements per lane: 2, 4 or 8
-    const char* base;       // uniform
-    int64_t stb;            // row stride in bytes (uniform)
-    int64_t inc;            // byte distance between a lane's consecutive elements (uniform)
-    uint32_t loff;          // per lane
-    int32_t lds0, ldsinc;   // LDS index ([s][n] layout) of element 0 and the step between elements
-};
-template <typename T, int RW>
-__device__ __forceinline__ FastStage<RW> fast_stage(const BC& m, int b_uniform, int32_t t_item, int32_t dT, int r) {
-    FastStage<RW> st;
-    st.base = m.p + (int64_t)b_uniform * m.sb * (int64_t)sizeof(T);
-    st.stb = m.st * (int64_t)sizeof(T);
-    const int64_t snb = m.sn * (int64_t)sizeof(T);
-    if (m.st <= m.sn) {                                    // time fastest in memory: e -> (n = e / kFT, s = e % kFT)
-        const int s = r % kFT, n = r / kFT;
-        st.loff = (uint32_t)(t_item + s * dT) * (uint32_t)st.stb + (uint32_t)n * (uint32_t)snb;
-        st.inc = (int64_t)(RW / kFT) * snb;
-        st.lds0 = s * kFS + n;
-        st.ldsinc = RW / kFT;
-    } else {                                               // state fastest: e -> (s = e / 16, n = e % 16)
-        const int s = r / kFS, n = r % kFS;
-        st.loff = (uint32_t)(t_item + s * dT) * (uint32_t)st.stb + (uint32_t)n * (uint32_t)snb;
-        st.inc = (int64_t)((RW >= kFS ? RW / kFS : 1) * dT) * st.stb;
-        st.lds0 = s * kFS + n;
-        st.ldsinc = (RW >= kFS ? RW / kFS : 1) * kFS;
-    }
-    return st;
-}
-template <typename T, int RW>
-__device__ __forceinline__ void fast_stage_fetch(float (&v)[FastStage<RW>::EPL], const FastStage<RW>& st, int32_t U) {
-    const char* p = st.base + (int64_t)U * st.stb;
-#pragma unroll
-    for (int i = 0; i < FastStage<RW>::EPL; ++i) v[i] = to_f32(*reinterpret_cast<const T*>(p + (int64_t)i * st.inc + st.loff));
-}
-template <int RW>
-__device__ __forceinline__ void fast_stage_park(const float (&v)[FastStage<RW>::EPL], const FastStage<RW>& st, float* lds_item) {
-#pragma unroll
-    for (int i = 0; i < FastStage<RW>::EPL; ++i) lds_item[st.lds0 + i * st.ldsinc] = v[i];
-}
 
 // ------------------------------------------------------------------------------------------------------
 // K1 (regular shapes): chunk aggregates
@@ -135,6 +28,7 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDev P) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    if (!it.wave_valid) return;                           // the last workgroup may have spare waves (no workgroup barriers here)
     const int ub = uniform_batch(it);
     const bool softplus_on = P.delta_softplus != 0;
     FastClock ck;
@@ -224,6 +118,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
+    if (!it.wave_valid) return;                           // the last workgroup may have spare waves (no workgroup barriers here)
     const int ub = uniform_batch(it);
     const bool softplus_on = P.delta_softplus != 0;
     const bool has_z = P.z.p != nullptr, has_out = P.out.p != nullptr;

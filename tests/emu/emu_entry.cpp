@@ -5,6 +5,7 @@
 #include "../../segmamba_amd/csrc/scan_fwd_fast.hip"
 #include "../../segmamba_amd/csrc/conv1d.hip"
 #include "../../segmamba_amd/csrc/scan_bwd.hip"
+#include "../../segmamba_amd/csrc/scan_bwd_fast.hip"
 #include "../../segmamba_amd/csrc/conv3d_wgrad.hip"
 #include "../../segmamba_amd/csrc/conv3d_fwd.hip"
 #include "../../segmamba_amd/csrc/instnorm.hip"

@@ -379,3 +379,20 @@ def test_conv3d_same_autograd_with_library_kernels(hip, monkeypatch):
     gx2, gw2, gb2 = torch.autograd.grad(y2, (x2, w2, b2), dy.float())
     for got, want in ((y, y2), (gx, gx2), (gw, gw2), (gb, gb2)):
         assert (got.float() - want).abs().max() <= 2e-2 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("dim,seqlen,order,ns,dtype", [(96, 4096, L.TIME_FORWARD, 1, torch.bfloat16),
+                                                       (96, 4096, L.TIME_INTERLEAVED, 64, torch.float32),
+                                                       (192, 2048, L.TIME_REVERSED, 1, torch.float32),
+                                                       (384, 512, L.TIME_INTERLEAVED, 16, torch.bfloat16)])
+def test_scan_regular_and_general_kernels_agree(hip, monkeypatch, dim, seqlen, order, ns, dtype):
+    """the regular-shape kernels (scan_*_fast.hip) and the general ones compute the same forward and gradients."""
+    c = H.scan_case(2, dim, 16, seqlen, dtype=dtype, seed=dim + seqlen)
+    monkeypatch.delenv("SEGM_SCAN_FAST", raising=False)
+    fast = H.run_scan(hip, c, DEV, True, order, ns)
+    monkeypatch.setenv("SEGM_SCAN_FAST", "0")
+    slow = H.run_scan(hip, c, DEV, True, order, ns)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for k in ("out", "du", "ddelta", "dz", "dB", "dC", "dA", "dD", "ddelta_bias", "last_state"):
+        a, b = fast[k].float(), slow[k].float()
+        assert (a - b).abs().max() <= tol * max(1.0, float(b.abs().max())), k

@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "regular_and_general or golden or half_precision" > gpurun_out/r15_scan_tests.log 2>&1
+tail -3 gpurun_out/r15_scan_tests.log
+bash tools/gpu_scan_prof.sh
