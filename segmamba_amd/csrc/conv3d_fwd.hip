@@ -26,6 +26,7 @@
 //
 // v_mfma_f32_16x16x32_bf16: lane l holds A[i = l & 15][k = 8 (l >> 4) .. +7], B[k = 8 (l >> 4) .. +7][j = l & 15];
 // result D[row = 4 (l >> 4) + r][col = l & 15].  Here row = x, col = co.
+#include <stdlib.h>
 #include <string.h>
 
 #include "segm_device.h"
@@ -204,6 +205,179 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 48 output channels per workgroup (cout % 48 == 0: every SegMamba layer this kernel family is picked for).
+// With the kz split above, 48 channels are a 32 + 16 pair of workgroups that stage the same X rows twice.  Here the
+// reduction index is cut four ways instead - k in (kz, ky, kx, ci) order, 1296 values = 40.5 MFMA chunks, parts of
+// 11 / 10 / 10 / 10 chunks - so one wave's stationary weights for THREE co tiles fit in registers (3 x 11 fragments) and
+// every A fragment read from LDS feeds 3 MFMAs.  8 waves = 4 K parts x 2 pairs of x tiles; the K parts are added through
+// a single 36 KB LDS buffer (two barriers per step: ring + partials ready, partials consumed).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kF48Waves = 8;
+constexpr int kF48Threads = kF48Waves * 64;
+constexpr int kF48Chunks = 11;                    // chunks per K part (parts 1..3 use 10; the last chunk of all is half empty)
+constexpr int kF48K = 27 * kFwCi;                 // 1296
+
+__global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwdDev P) {
+    __shared__ __attribute__((aligned(16))) __bf16 xs[3][4][kFwSlot];
+    __shared__ __attribute__((aligned(16))) float red[6][3][2][4][64];      // [(part - 1) * 2 + xp][co tile][x tile][r][lane]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = wave >> 1, xp = wave & 1;            // K part, pair of x tiles (x0 + 32 xp .. + 31)
+    const int i16 = lane & 15, g = lane >> 4;
+    const int cob = blockIdx.y;                           // block of 48 output channels
+    int item = blockIdx.x;
+    const int ypart = item % P.ysplit;  item /= P.ysplit;
+    const int xb = item % P.nxb;        item /= P.nxb;
+    const int z = item % P.D, b = item / P.D;
+    const int y0 = ypart * P.rows_per_part;
+    const int y1 = (y0 + P.rows_per_part < P.H) ? y0 + P.rows_per_part : P.H;
+    const int x0 = xb * kFwXB;
+    const int c_begin = part == 0 ? 0 : 11 + 10 * (part - 1);     // first chunk of this K part
+    const int c_count = part == 0 ? 11 : 10;
+
+    // ---- stationary weights and the matching A fragment offsets ------------------------------------------------------
+    bf16x8 wf[3][kF48Chunks];
+    int32_t aoff[kF48Chunks];                             // LDS element offset without the row slot; ky in bits 28..29
+#pragma unroll
+    for (int c = 0; c < kF48Chunks; ++c) {
+        const int k = 32 * (c_begin + c) + 8 * g;
+        const bool live = c < c_count && k < kF48K;
+        const int kk = live ? k : 0;
+        const int tap = kk / kFwCi, ci0 = kk - tap * kFwCi;
+        const int tz = tap / 9, ty = (tap - tz * 9) / 3, tx = tap - tz * 9 - ty * 3;
+        aoff[c] = (tz * 4 * kFwSlot + (xp * 32 + i16 + tx) * kFwCP + ci0) | (ty << 28);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int co = cob * 48 + t * 16 + i16;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(P.wp + (int64_t)co * kF48K + kk);
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            wf[t][c] = __builtin_bit_cast(bf16x8, live ? w : zero);
+        }
+    }
+    float bias[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bias[t] = P.bias ? P.bias[cob * 48 + t * 16 + i16] : 0.f;
+
+    // ---- copy plan: 720 tasks (plane, granule, ci pair) over 512 threads: two per thread ------------------------------------
+    int tpl[2], tcp[2], tp0[2];
+    bool has_task[2], t_keep[2];
+    const __bf16* tsrc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int task = tid + q * kF48Threads;
+        has_task[q] = task < kFwTasks;
+        const int tt = has_task[q] ? task : 0;
+        tpl[q] = tt / (24 * kFwGran);
+        const int trem = tt - tpl[q] * (24 * kFwGran);
+        const int tgr = trem / 24;
+        tcp[q] = trem - tgr * 24;
+        const int txg = x0 - 8 + 8 * tgr;                 // first x of the granule
+        const bool inside = txg >= 0 && txg < P.W;
+        const int tzz = z + tpl[q] - 1;
+        const bool plane = tzz >= 0 && tzz < P.D;
+        t_keep[q] = inside && plane;
+        tsrc[q] = reinterpret_cast<const __bf16*>(P.x) + (int64_t)b * P.x_sb + (int64_t)(plane ? tzz : z) * P.x_sz +
+                  (int64_t)(2 * tcp[q]) * P.x_sc + (inside ? txg : 0);
+        tp0[q] = 8 * tgr - 7;
+    }
+    auto fetch = [&](u32x4 (&r)[2][2], int yy) {
+        const bool ok = yy >= 0 && yy < P.H;
+        const int64_t ro = (int64_t)(ok ? yy : 0) * P.x_sy;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            r[q][0] = *reinterpret_cast<const u32x4*>(tsrc[q] + ro);
+            r[q][1] = *reinterpret_cast<const u32x4*>(tsrc[q] + ro + P.x_sc);
+        }
+    };
+    auto park = [&](const u32x4 (&r)[2][2], int yy, int slot) {
+        const bool row_ok = yy >= 0 && yy < P.H;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!has_task[q]) continue;
+            const bool keep = row_ok && t_keep[q];
+            __bf16* row = &xs[tpl[q]][slot][0];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int p = tp0[q] + e;
+                if (p < 0 || p >= kFwXP) continue;
+                const uint32_t a = r[q][0][e >> 1], c = r[q][1][e >> 1];
+                const uint32_t lo = (e & 1) ? (a >> 16) : (a & 0xffffu);
+                const uint32_t hi = (e & 1) ? (c & 0xffff0000u) : (c << 16);
+                *reinterpret_cast<uint32_t*>(row + p * kFwCP + 2 * tcp[q]) = keep ? (lo | hi) : 0u;
+            }
+        }
+    };
+
+    if (y1 > y0) {
+        {
+            u32x4 r[2][2];
+#pragma unroll
+            for (int d = -1; d <= 1; ++d) {
+                fetch(r, y0 + d);
+                park(r, y0 + d, (y0 + d + 4) & 3);
+            }
+        }
+        __syncthreads();
+        for (int y = y0; y < y1; ++y) {
+            u32x4 r[2][2];
+            fetch(r, y + 2);                              // in flight during this step's MFMAs
+            SEGM_SCHED_FENCE();
+            f32x4 acc[3][2];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const __bf16* pl = &xs[0][0][0];
+#pragma unroll
+            for (int c = 0; c < kF48Chunks; ++c) {
+                const int slot = (y + (aoff[c] >> 28) + 3) & 3;
+                const __bf16* ap = pl + slot * kFwSlot + (aoff[c] & 0x0fffffff);
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 16 * kFwCP);       // the pair's second x tile
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[t][c], acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[t][c], acc[t][1], 0, 0, 0);
+                }
+            }
+            SEGM_SCHED_FENCE();
+            if (part > 0) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) red[(part - 1) * 2 + xp][t][u][q][lane] = acc[t][u][q];
+            }
+            park(r, y + 2, (y + 2) & 3);
+            __syncthreads();                              // ring row y + 2 and the partial sums are in LDS
+            if (part == 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int xg = x0 + xp * 32 + u * 16 + 4 * g;      // this lane's 4 output positions
+                    if (xg >= P.W) continue;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        __bf16 o[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            o[q] = (__bf16)(acc[t][u][q] + red[xp][t][u][q][lane] + red[2 + xp][t][u][q][lane] +
+                                            red[4 + xp][t][u][q][lane] + bias[t]);
+                        u32x2 pk;
+                        memcpy(&pk, o, 8);
+                        const int co = cob * 48 + t * 16 + i16;
+                        __bf16* dst = reinterpret_cast<__bf16*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
+                                      (int64_t)z * P.y_sz + (int64_t)y * P.y_sy + xg;
+                        *reinterpret_cast<u32x2*>(dst) = pk;
+                    }
+                }
+            }
+            __syncthreads();                              // the partial sums are consumed: the buffer may be rewritten
+        }
+    }
+}
+
 struct FwPlan { int nxb, ysplit, rows_per_part, nitems; };
 static FwPlan fwd_plan(int batch, int cout, int d, int h, int w) {
     FwPlan p;
@@ -244,6 +418,10 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     const FwPlan pl = fwd_plan(a->batch, a->cout, a->depth, a->height, a->width);
     P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part;
     hipStream_t stream = (hipStream_t)a->stream;
+    if (a->cout % 48 == 0 && !getenv("SEGM_CONV_FWD_KZ_SPLIT")) {      // the env switch forces the 32 + 16 kernels (A/B timing)
+        hipLaunchKernelGGL(conv3d_k3_fwd48_kernel, dim3(pl.nitems, a->cout / 48), dim3(kF48Threads), 0, stream, P);
+        return (int)hipGetLastError();
+    }
     const int full = a->cout / kFwCo;                     // blocks with two co tiles; cout % 32 == 16 leaves one with a single tile
     P.cob0 = 0;
     if (full > 0)

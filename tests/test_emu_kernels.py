@@ -248,7 +248,7 @@ def test_scan_rejects_views_beyond_32bit_offsets(emu):
     assert emu.dll.segm_selective_scan_fwd(a) == -2
 
 
-@pytest.mark.parametrize("shape", [(1, 48, 2, 3, 16), (1, 32, 3, 5, 64), (2, 16, 2, 4, 72), (1, 48, 1, 20, 8)])
+@pytest.mark.parametrize("shape", [(1, 48, 2, 3, 16), (1, 32, 3, 5, 64), (2, 16, 2, 4, 72), (1, 48, 1, 20, 8), (1, 96, 2, 5, 72)])
 def test_conv3d_k3_fwd_emulated(emu, shape):
     """forward 3x3x3 convolution: transposed LDS staging, stationary weight fragments, kz reduction, zero padding."""
     B, cout, D, H_, W = shape
