@@ -16,20 +16,20 @@
 // fetching operands per tap from L2 (a first version: 15.6 GB of L1 fills for 0.8 GB of tensors, 4 ms) leaves the MFMA
 // pipe idle.  Operands are therefore staged once per workgroup in LDS:
 //
-//   workgroup = 3 waves (ky = wave) for one tap plane kz, one 32 x 48 (co, ci) block and one work item
+//   workgroup = 3 waves (ky = wave) for one tap plane kz, one 48 x 48 (co, ci) block and one work item
 //               (batch b, depth z, 64-wide x block, y range).  It walks y; an LDS ring of 4 rows holds
 //               X[ci block][z+kz-1][y-1 .. y+2][x block + 8 halo columns each side] (each X row is fetched ONCE and
 //               used by the three ky waves on three consecutive steps), a double buffer holds the dY row.  While the
-//               waves run the 36 MFMAs of step y (2 k-chunks x 2 co tiles x 3 kx x 3 ci tiles), the row y+2 and the
+//               waves run the 54 MFMAs of step y (2 k-chunks x 3 co tiles x 3 kx x 3 ci tiles), the row y+2 and the
 //               next dY row are already in flight global -> registers; they are parked in LDS after the MFMAs; one
 //               barrier per step.
 //   fragments   A (dY) and B (X) fragments are 16-byte LDS reads; the kx = 0 / 2 operands are built from the aligned
 //               read plus two halo dwords with v_alignbyte.  Zero padding in x / y / z is materialised as zero rows /
 //               columns in LDS, so the inner loop has no masks.  Row pitch 88 elements (44 dwords): the 16 lanes of a
 //               fragment read hit 16 distinct 4-bank groups.
-//   grid      = (work items, 3 kz x co blocks of 32, ci blocks of 48); every workgroup writes its 9 x 32 x 48 partial
+//   grid      = (work items, 3 kz x co blocks of 48, ci blocks of 48); every workgroup writes its 9 x 48 x 48 partial
 //               taps; a second kernel sums the work items in a fixed order (deterministic, no atomics) and converts
-//               to the weight dtype.  An odd last co tile (cout = 48) is a second launch with one co tile.
+//               to the weight dtype.
 // v_mfma_f32_16x16x32_bf16 operand layout (cdna_hip_programming.md §3): lane l holds A[i = l & 15][k = 8 (l >> 4) .. +7],
 // B[k = 8 (l >> 4) .. +7][j = l & 15]; result D[row = 4 (l >> 4) + r][col = l & 15], r = 0..3.
 #include <string.h>
@@ -43,18 +43,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWgBlock = 48;                 // input channels per block; cin and cout must be multiples of it
-constexpr int kWgCo = 32;                    // output channels per workgroup (2 MFMA tiles)
+constexpr int kWgCo = 48;                    // output channels per workgroup (3 MFMA tiles)
 constexpr int kWgWaves = 3;                  // ky
 constexpr int kWgThreads = kWgWaves * 64;
 constexpr int kPitch = 88;                   // LDS row pitch (elements): 8 halo + 64 + 8 halo + 8 (bank spread)
 constexpr int kXGran = 10;                   // 16-byte granules of an X row in LDS (NQ = 2): halo, 8 data, halo
-constexpr int kCopies = 4;                   // granules per thread per step: ceil((48 * 10 + 32 * 8) / 192)
+constexpr int kCopies = 5;                   // granules per thread per step: ceil((48 * 10 + 48 * 8) / 192)
 
 struct WgradDev {
     const char* x;   int64_t x_sb, x_sc, x_sz, x_sy;      // element strides, x contiguous
     const char* dy;  int64_t dy_sb, dy_sc, dy_sz, dy_sy;
     float* part;                                          // [co blk][ci blk][item][27][32][48]
-    int32_t B, D, H, W, cob0;
+    int32_t B, D, H, W;
     int32_t nxb, ysplit, rows_per_part, nitems;
     int32_t ncob, ncib;
 };
@@ -66,14 +66,15 @@ struct WgCopy {
     bool is_x[kCopies], live[kCopies], inside[kCopies];   // inside: the granule's x range is inside the volume
 };
 
-template <int NCO, int NQ>
-__global__ void __launch_bounds__(kWgThreads, 3) conv3d_k3_wgrad_kernel(WgradDev P) {
+template <int NQ>
+__global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev P) {
+    constexpr int NCO = kWgCo / 16;
     __shared__ __attribute__((aligned(16))) __bf16 xs[4][kWgBlock][kPitch];
     __shared__ __attribute__((aligned(16))) __bf16 dys[2][kWgCo][kPitch];
     const int tid = threadIdx.x, lane = tid & 63;
     const int ky = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: row / tap arithmetic stays on the SALU
     const int i16 = lane & 15, g = lane >> 4;
-    const int kz = blockIdx.y % 3, cob = blockIdx.y / 3 + P.cob0, cib = blockIdx.z;
+    const int kz = blockIdx.y % 3, cob = blockIdx.y / 3, cib = blockIdx.z;
     int item = blockIdx.x;
     const int ypart = item % P.ysplit;  item /= P.ysplit;
     const int xb = item % P.nxb;        item /= P.nxb;
@@ -85,9 +86,9 @@ __global__ void __launch_bounds__(kWgThreads, 3) conv3d_k3_wgrad_kernel(WgradDev
     constexpr int XB = 32 * NQ;
     const int x0 = xb * XB;
 
-    f32x4 acc[2][3][3];                                   // [co tile][kx][ci tile]
+    f32x4 acc[NCO][3][3];                                 // [co tile][kx][ci tile]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NCO; ++a)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(kWgThreads, 3) conv3d_k3_wgrad_kernel(WgradDev
     // partial block: part[((cob * ncib + cib) * nitems + item)][tap = kz*9 + ky*3 + kx][co (32)][ci (48)]
     float* out = P.part + ((((int64_t)cob * P.ncib + cib) * P.nitems + blockIdx.x) * 27) * (kWgCo * kWgBlock);
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < NCO; ++ct)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(kWgThreads, 3) conv3d_k3_wgrad_kernel(WgradDev
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = ct * 16 + g * 4 + r, cin = ci * 16 + i16;
-                    if (ct < NCO) out[((int64_t)(kz * 9 + ky * 3 + kx) * kWgCo + co) * kWgBlock + cin] = acc[ct][kx][ci][r];
+                    out[((int64_t)(kz * 9 + ky * 3 + kx) * kWgCo + co) * kWgBlock + cin] = acc[ct][kx][ci][r];
                 }
 }
 
@@ -287,18 +288,10 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
     P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part; P.nitems = pl.nitems;
     P.ncob = (a->cout + kWgCo - 1) / kWgCo; P.ncib = a->cin / kWgBlock;
     hipStream_t stream = (hipStream_t)a->stream;
-    const int full = a->cout / kWgCo;                    // blocks with two co tiles; cout % 32 == 16 leaves one with a single tile
-    P.cob0 = 0;
-    if (full > 0) {
-        const dim3 grid(P.nitems, full * 3, P.ncib);
-        if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<2, 2>), grid, dim3(kWgThreads), 0, stream, P);
-        else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<2, 1>), grid, dim3(kWgThreads), 0, stream, P);
-    }
-    if (P.ncob > full) {
-        P.cob0 = full;
-        const dim3 grid(P.nitems, 3, P.ncib);
-        if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<1, 2>), grid, dim3(kWgThreads), 0, stream, P);
-        else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<1, 1>), grid, dim3(kWgThreads), 0, stream, P);
+    {
+        const dim3 grid(P.nitems, P.ncob * 3, P.ncib);
+        if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<2>), grid, dim3(kWgThreads), 0, stream, P);
+        else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<1>), grid, dim3(kWgThreads), 0, stream, P);
     }
     const int total = a->cout * a->cin * 27;
     if (a->dw_dtype == SEGM_F32)
