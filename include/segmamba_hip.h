@@ -292,6 +292,41 @@ typedef struct segm_transpose_args {
 
 int segm_transpose_add(const segm_transpose_args* args);
 
+/* ------------------------------------------------------------------------------------------------
+ * Volume -> tokens with LayerNorm over the channels, forward and backward.
+ * Replaces `x.reshape(B, C, n).transpose(-1, -2)` followed by `nn.LayerNorm(C)` at the entry of a Mamba layer
+ * (reference model_segmamba/segmamba.py:60-66): a transposing copy, an fp32 LayerNorm and a cast in the reference.
+ *
+ *   forward   x (batch, channels, spatial) -> y (batch, spatial, channels) = (x - mean_c) * rstd_c * gamma + beta,
+ *             mean / rstd (batch, spatial) fp32 (kept for the backward)
+ *   backward  dy (batch, spatial, channels), x, mean, rstd, gamma -> dx (batch, channels, spatial), dgamma, dbeta (fp32,
+ *             OVERWRITTEN)
+ * x, y, dy, dx: one dtype, contiguous.  gamma, beta, dgamma, dbeta: fp32 (channels).  channels and spatial multiples of 8
+ * (4 for fp32); channels <= 384 (192 for fp32).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_layernorm_args {
+    int32_t batch, channels, dtype, reserved;
+    int64_t spatial;
+    float eps, reserved2;
+    const void* x;
+    void* y;                  /* forward */
+    const float* gamma;
+    const float* beta;        /* forward */
+    float* mean;
+    float* rstd;
+    const void* dy;           /* backward ... */
+    void* dx;
+    float* dgamma;
+    float* dbeta;
+    void* workspace;          /* segm_layernorm_tokens_workspace_bytes(); backward only */
+    size_t workspace_bytes;
+    void* stream;
+} segm_layernorm_args;
+
+int segm_layernorm_tokens_fwd(const segm_layernorm_args* args);
+int segm_layernorm_tokens_bwd(const segm_layernorm_args* args);
+size_t segm_layernorm_tokens_workspace_bytes(int32_t batch, int32_t channels, int64_t spatial);
+
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);
 const char* segm_status_string(int status);

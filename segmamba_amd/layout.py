@@ -23,6 +23,37 @@ class _TransposeAdd(torch.autograd.Function):
         return dx, (dout if ctx.has_add and ctx.needs_input_grad[1] else None)
 
 
+class _TokensLayerNorm(torch.autograd.Function):
+    """(B, C, S) volume -> LayerNorm'ed (B, S, C) tokens through segm_layernorm_tokens_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        from . import lib as L, ops_raw
+        y, mean, rstd = ops_raw.layernorm_tokens_fwd(L.get_lib(), x, weight, bias, eps)
+        ctx.save_for_backward(x, mean, rstd, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L, ops_raw
+        x, mean, rstd, weight = ctx.saved_tensors
+        dx, dg, db = ops_raw.layernorm_tokens_bwd(L.get_lib(), x, dy.to(x.dtype), mean, rstd, weight)
+        return dx, dg.to(weight.dtype), db.to(weight.dtype), None
+
+
+def volume_to_tokens_layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
+    """LayerNorm(C)(x.reshape(B, C, n).transpose(-1, -2)) as one kernel per direction (reference segmamba.py:60-66).
+    Like autocast's LayerNorm the statistics are fp32; the result is returned in x's dtype."""
+    B, C = x.shape[:2]
+    x3 = x.reshape(B, C, -1)
+    if x.is_cuda:
+        from . import ops_raw
+        x3 = x3.contiguous()
+        if ops_raw.layernorm_tokens_supported(x3):
+            return _TokensLayerNorm.apply(x3, weight, bias, eps)
+    return torch.nn.functional.layer_norm(transpose_add(x3), (C,), weight, bias, eps)
+
+
 def transpose_add(x: torch.Tensor, add: torch.Tensor | None = None) -> torch.Tensor:
     """x (B, R, C) -> (B, C, R) contiguous, plus `add` (B, C, R) if given."""
     if not x.is_cuda:

@@ -122,6 +122,16 @@ class InstNormBwdArgs(C.Structure):
     ]
 
 
+class LayerNormArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("channels", C.c_int32), ("dtype", C.c_int32), ("reserved", C.c_int32),
+        ("spatial", C.c_int64), ("eps", C.c_float), ("reserved2", C.c_float),
+        ("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p),
+        ("rstd", C.c_void_p), ("dy", C.c_void_p), ("dx", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+    ]
+
+
 class TransposeArgs(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("dtype", C.c_int32),
@@ -135,6 +145,7 @@ EXPORTS = (
     "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
     "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes", "segm_conv3d_k3_fwd",
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add",
+    "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -169,6 +180,9 @@ class SegmLib:
         sig("segm_instnorm_bwd", [C.POINTER(InstNormBwdArgs)], C.c_int)
         sig("segm_instnorm_workspace_bytes", [C.c_int32, C.c_int64], C.c_size_t)
         sig("segm_transpose_add", [C.POINTER(TransposeArgs)], C.c_int)
+        sig("segm_layernorm_tokens_fwd", [C.POINTER(LayerNormArgs)], C.c_int)
+        sig("segm_layernorm_tokens_bwd", [C.POINTER(LayerNormArgs)], C.c_int)
+        sig("segm_layernorm_tokens_workspace_bytes", [C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
         sig("segm_abi_version", [], C.c_int)
         sig("segm_status_string", [C.c_int], C.c_char_p)
 

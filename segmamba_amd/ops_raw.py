@@ -372,3 +372,56 @@ def transpose_add(lib: L.SegmLib, x: torch.Tensor, add: Optional[torch.Tensor] =
     a.stream = L.stream_handle(x)
     lib.check(lib.dll.segm_transpose_add(a), "transpose_add")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# volume -> tokens with LayerNorm
+# ---------------------------------------------------------------------------------------------------------
+def layernorm_tokens_supported(x: torch.Tensor) -> bool:
+    if x.dim() != 3 or not x.is_contiguous() or x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        return False
+    n = 4 if x.dtype == torch.float32 else 8
+    return x.shape[1] % n == 0 and x.shape[2] % n == 0 and x.shape[1] <= (192 if x.dtype == torch.float32 else 384)
+
+
+def _ln_args(x, gamma, eps):
+    B, Cc, S = x.shape
+    a = L.LayerNormArgs()
+    a.batch, a.channels, a.dtype, a.spatial, a.eps = B, Cc, L.dtype_code(x), S, float(eps)
+    a.x, a.gamma, a.stream = x.data_ptr(), gamma.data_ptr(), L.stream_handle(x)
+    return a
+
+
+def layernorm_tokens_fwd(lib: L.SegmLib, x, gamma, beta, eps=1e-5):
+    """x (B, C, S) contiguous -> (y (B, S, C), mean (B, S), rstd (B, S)); gamma / beta fp32 (C)."""
+    if not layernorm_tokens_supported(x):
+        raise RuntimeError("layernorm_tokens: unsupported shape / dtype / layout")
+    B, Cc, S = x.shape
+    gamma, beta = gamma.float().contiguous(), beta.float().contiguous()
+    y = torch.empty(B, S, Cc, dtype=x.dtype, device=x.device)
+    mean = torch.empty(B, S, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, S, dtype=torch.float32, device=x.device)
+    a = _ln_args(x, gamma, eps)
+    a.y, a.beta, a.mean, a.rstd = y.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    lib.check(lib.dll.segm_layernorm_tokens_fwd(a), "layernorm_tokens_fwd")
+    return y, mean, rstd
+
+
+def layernorm_tokens_bwd(lib: L.SegmLib, x, dy, mean, rstd, gamma):
+    """-> (dx (B, C, S), dgamma (C) fp32, dbeta (C) fp32)."""
+    B, Cc, S = x.shape
+    if dy.shape != (B, S, Cc) or dy.dtype != x.dtype:
+        raise RuntimeError("layernorm_tokens: dy must be (B, S, C) of x's dtype")
+    dy = dy.contiguous()
+    gamma = gamma.float().contiguous()
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    ws_bytes = lib.dll.segm_layernorm_tokens_workspace_bytes(B, Cc, S)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    a = _ln_args(x, gamma, 0.0)
+    a.mean, a.rstd, a.dy, a.dx = mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr()
+    a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
+    lib.check(lib.dll.segm_layernorm_tokens_bwd(a), "layernorm_tokens_bwd")
+    return dx, dgamma, dbeta

@@ -39,8 +39,9 @@ class MambaLayer(nn.Module):
         assert C == self.dim
         img_dims = x.shape[2:]
         n_tokens = img_dims.numel()
-        tokens = layout.volume_to_tokens(x)                          # (B, L, C), one tiled transpose
-        mixed = self.mamba(self.norm(tokens))                        # (B, L, C)
+        # (B, L, C) LayerNorm'ed tokens: the transpose and the normalisation are one kernel
+        tokens = layout.volume_to_tokens_layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        mixed = self.mamba(tokens)                                   # (B, L, C)
         return layout.tokens_to_volume_add(mixed, x)                 # transpose back fused with the skip
 
 

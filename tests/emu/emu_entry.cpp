@@ -10,3 +10,4 @@
 #include "../../segmamba_amd/csrc/conv3d_fwd.hip"
 #include "../../segmamba_amd/csrc/instnorm.hip"
 #include "../../segmamba_amd/csrc/layout.hip"
+#include "../../segmamba_amd/csrc/layernorm.hip"

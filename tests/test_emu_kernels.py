@@ -272,3 +272,24 @@ def test_conv3d_k3_dgrad_as_forward_emulated(emu):
     torch.nn.functional.conv3d(x, w.float(), None, 1, 1).backward(dy.float())
     dx = ops_raw.conv3d_k3_fwd(emu, dy, ops_raw.pack_conv3d_weight_for_dgrad(w))
     assert (dx.float() - x.grad).abs().max() <= 1e-2 * max(1.0, float(x.grad.abs().max()))
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 48, 200), torch.float32), ((1, 96, 72), torch.bfloat16), ((1, 192, 136), torch.float32),
+                                         ((1, 384, 64), torch.bfloat16)])
+def test_layernorm_tokens_emulated(emu, shape, dtype):
+    B, Cc, S = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (1.5 * torch.randn(shape, generator=g) + 0.5).to(dtype)
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    dy = torch.randn(B, S, Cc, generator=g).to(dtype)
+    xr = x.double().requires_grad_()
+    gr, br = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xr.transpose(1, 2), (Cc,), gr, br, 1e-5)
+    gx, gg, gb = torch.autograd.grad(ref, (xr, gr, br), dy.double())
+    y, mean, rstd = ops_raw.layernorm_tokens_fwd(emu, x, gamma, beta, 1e-5)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert (y.double() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    dx, dgm, dbt = ops_raw.layernorm_tokens_bwd(emu, x, dy, mean, rstd, gamma)
+    assert (dx.double() - gx).abs().max() <= tol * max(1.0, float(gx.abs().max()))
+    assert (dgm.double() - gg).abs().max() <= 1e-3 * max(1.0, float(gg.abs().max()))
+    assert (dbt.double() - gb).abs().max() <= 1e-3 * max(1.0, float(gb.abs().max()))

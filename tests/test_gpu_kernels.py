@@ -396,3 +396,29 @@ def test_scan_regular_and_general_kernels_agree(hip, monkeypatch, dim, seqlen, o
     for k in ("out", "du", "ddelta", "dz", "dB", "dC", "dA", "dD", "ddelta_bias", "last_state"):
         a, b = fast[k].float(), slow[k].float()
         assert (a - b).abs().max() <= tol * max(1.0, float(b.abs().max())), k
+
+
+# ---- volume -> tokens with LayerNorm: against F.layer_norm of the transposed tensor (fp32 reference) ------------------
+@pytest.mark.parametrize("shape", [(2, 48, 4096), (2, 96, 1000), (1, 192, 512), (2, 384, 64), (1, 8, 24)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_tokens_matches_layer_norm(hip, shape, dtype):
+    B, Cc, S = shape
+    if dtype == torch.float32 and Cc > 192:
+        pytest.skip("fp32 tiles are limited to 192 channels")
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = (1.5 * torch.randn(shape, device=DEV, generator=g) + 0.5).to(dtype)
+    gamma, beta = torch.randn(Cc, device=DEV, generator=g), torch.randn(Cc, device=DEV, generator=g)
+    dy = torch.randn(B, S, Cc, device=DEV, generator=g).to(dtype)
+    xr = x.float().requires_grad_()
+    gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xr.transpose(1, 2), (Cc,), gr, br, 1e-5)
+    gx, gg, gb = torch.autograd.grad(ref, (xr, gr, br), dy.float())
+    y, mean, rstd = ops_raw.layernorm_tokens_fwd(hip, x, gamma, beta, 1e-5)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert (y.float() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    dx, dgm, dbt = ops_raw.layernorm_tokens_bwd(hip, x, dy, mean, rstd, gamma)
+    assert (dx.float() - gx).abs().max() <= tol * max(1.0, float(gx.abs().max()))
+    assert (dgm - gg).abs().max() <= 2e-3 * max(1.0, float(gg.abs().max()))
+    assert (dbt - gb).abs().max() <= 2e-3 * max(1.0, float(gb.abs().max()))
+    d2 = ops_raw.layernorm_tokens_bwd(hip, x, dy, mean, rstd, gamma)
+    assert torch.equal(d2[0], dx) and torch.equal(d2[1], dgm) and torch.equal(d2[2], dbt)      # deterministic
