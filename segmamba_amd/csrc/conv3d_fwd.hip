@@ -56,7 +56,7 @@ struct ConvFwdDev {
     char* y;        int64_t y_sb, y_sc, y_sz, y_sy;
     const __bf16* wp;                                     // packed weights [cout][27 * 48], k = ((kz*3 + ky)*3 + kx)*48 + ci
     const float* bias;                                    // (cout) or null
-    int32_t B, D, H, W, cout, cob0;
+    int32_t B, D, H, W, cout, cob0, cin;
     int32_t nxb, ysplit, rows_per_part;
 };
 
@@ -115,8 +115,11 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
     const bool t_inside = txg >= 0 && txg < P.W;          // W % 8 == 0: entirely inside or outside
     const int tzz = z + tpl - 1;
     const bool t_plane = tzz >= 0 && tzz < P.D;
+    // channels at or beyond cin (a narrow first layer) are zero: read a valid channel, drop the value
+    const bool t_c0 = 2 * tcp < P.cin, t_c1 = 2 * tcp + 1 < P.cin;
     const __bf16* tsrc = reinterpret_cast<const __bf16*>(P.x) + (int64_t)b * P.x_sb + (int64_t)(t_plane ? tzz : z) * P.x_sz +
-                         (int64_t)(2 * tcp) * P.x_sc + (t_inside ? txg : 0);
+                         (int64_t)(t_c0 ? 2 * tcp : 0) * P.x_sc + (t_inside ? txg : 0);
+    const int64_t tc1 = t_c1 ? P.x_sc : 0;
     // ring positions p = x - (x0 - 1): the granule covers p = 8 tgr - 7 .. 8 tgr; only 0 <= p < kFwXP is stored
     const int tp0 = 8 * tgr - 7;
 
@@ -124,7 +127,7 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
         const bool ok = yy >= 0 && yy < P.H;
         const __bf16* s = tsrc + (int64_t)(ok ? yy : 0) * P.x_sy;
         r[0] = *reinterpret_cast<const u32x4*>(s);
-        r[1] = *reinterpret_cast<const u32x4*>(s + P.x_sc);
+        r[1] = *reinterpret_cast<const u32x4*>(s + tc1);
     };
     auto park = [&](const u32x4 (&r)[2], int yy, int slot) {
         if (!has_task) return;
@@ -136,8 +139,8 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
             if (p < 0 || p >= kFwXP) continue;
             // element e of channel 2 tcp (low half) and 2 tcp + 1 (high half)
             const uint32_t a = r[0][e >> 1], c = r[1][e >> 1];
-            const uint32_t lo = (e & 1) ? (a >> 16) : (a & 0xffffu);
-            const uint32_t hi = (e & 1) ? (c & 0xffff0000u) : (c << 16);
+            const uint32_t lo = t_c0 ? ((e & 1) ? (a >> 16) : (a & 0xffffu)) : 0u;
+            const uint32_t hi = t_c1 ? ((e & 1) ? (c & 0xffff0000u) : (c << 16)) : 0u;
             *reinterpret_cast<uint32_t*>(row + p * kFwCP + 2 * tcp) = keep ? (lo | hi) : 0u;
         }
     };
@@ -261,8 +264,9 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 
     // ---- copy plan: 720 tasks (plane, granule, ci pair) over 512 threads: two per thread ------------------------------------
     int tpl[2], tcp[2], tp0[2];
-    bool has_task[2], t_keep[2];
+    bool has_task[2], t_keep[2], t_c0[2], t_c1[2];
     const __bf16* tsrc[2];
+    int64_t tc1[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int task = tid + q * kF48Threads;
@@ -277,8 +281,11 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
         const int tzz = z + tpl[q] - 1;
         const bool plane = tzz >= 0 && tzz < P.D;
         t_keep[q] = inside && plane;
+        t_c0[q] = 2 * tcp[q] < P.cin;                     // channels at or beyond cin (a narrow first layer) are zero
+        t_c1[q] = 2 * tcp[q] + 1 < P.cin;
         tsrc[q] = reinterpret_cast<const __bf16*>(P.x) + (int64_t)b * P.x_sb + (int64_t)(plane ? tzz : z) * P.x_sz +
-                  (int64_t)(2 * tcp[q]) * P.x_sc + (inside ? txg : 0);
+                  (int64_t)(t_c0[q] ? 2 * tcp[q] : 0) * P.x_sc + (inside ? txg : 0);
+        tc1[q] = t_c1[q] ? P.x_sc : 0;
         tp0[q] = 8 * tgr - 7;
     }
     auto fetch = [&](u32x4 (&r)[2][2], int yy) {
@@ -287,7 +294,7 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             r[q][0] = *reinterpret_cast<const u32x4*>(tsrc[q] + ro);
-            r[q][1] = *reinterpret_cast<const u32x4*>(tsrc[q] + ro + P.x_sc);
+            r[q][1] = *reinterpret_cast<const u32x4*>(tsrc[q] + ro + tc1[q]);
         }
     };
     auto park = [&](const u32x4 (&r)[2][2], int yy, int slot) {
@@ -302,8 +309,8 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
                 const int p = tp0[q] + e;
                 if (p < 0 || p >= kFwXP) continue;
                 const uint32_t a = r[q][0][e >> 1], c = r[q][1][e >> 1];
-                const uint32_t lo = (e & 1) ? (a >> 16) : (a & 0xffffu);
-                const uint32_t hi = (e & 1) ? (c & 0xffff0000u) : (c << 16);
+                const uint32_t lo = t_c0[q] ? ((e & 1) ? (a >> 16) : (a & 0xffffu)) : 0u;
+                const uint32_t hi = t_c1[q] ? ((e & 1) ? (c & 0xffff0000u) : (c << 16)) : 0u;
                 *reinterpret_cast<uint32_t*>(row + p * kFwCP + 2 * tcp[q]) = keep ? (lo | hi) : 0u;
             }
         }
@@ -399,7 +406,7 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     if (!a) return SEGM_E_NULL;
     if (!a->x || !a->y || !a->w_packed) return SEGM_E_NULL;
     if (a->batch <= 0 || a->depth <= 0 || a->height <= 0 || a->width <= 0) return SEGM_E_SHAPE;
-    if (a->cin != kFwCi || a->cout <= 0 || a->cout % 16 != 0) return SEGM_E_SHAPE;
+    if (a->cin < 1 || a->cin > kFwCi || a->cout <= 0 || a->cout % 16 != 0) return SEGM_E_SHAPE;
     if (a->width % 8 != 0) return SEGM_E_SHAPE;
     if (a->dtype != SEGM_BF16) return SEGM_E_DTYPE;
     const int64_t st[8] = {a->x_stride_b, a->x_stride_c, a->x_stride_z, a->x_stride_y,
@@ -414,7 +421,7 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     P.y = (char*)a->y; P.y_sb = a->y_stride_b; P.y_sc = a->y_stride_c; P.y_sz = a->y_stride_z; P.y_sy = a->y_stride_y;
     P.wp = (const __bf16*)a->w_packed;
     P.bias = a->bias;
-    P.B = a->batch; P.D = a->depth; P.H = a->height; P.W = a->width; P.cout = a->cout;
+    P.B = a->batch; P.D = a->depth; P.H = a->height; P.W = a->width; P.cout = a->cout; P.cin = a->cin;
     const FwPlan pl = fwd_plan(a->batch, a->cout, a->depth, a->height, a->width);
     P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part;
     hipStream_t stream = (hipStream_t)a->stream;

@@ -54,7 +54,7 @@ struct WgradDev {
     const char* x;   int64_t x_sb, x_sc, x_sz, x_sy;      // element strides, x contiguous
     const char* dy;  int64_t dy_sb, dy_sc, dy_sz, dy_sy;
     float* part;                                          // [co blk][ci blk][item][27][32][48]
-    int32_t B, D, H, W;
+    int32_t B, D, H, W, cin;
     int32_t nxb, ysplit, rows_per_part, nitems;
     int32_t ncob, ncib;
 };
@@ -108,8 +108,9 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
             if (cp.is_x[k]) {
                 const int ci = id / XG, gr = id - ci * XG;
                 const int xg = x0 - 8 + 8 * gr;           // first x of the granule (W % 8 == 0: all inside or all outside)
-                cp.inside[k] = xg >= 0 && xg < P.W;
-                cp.src[k] = (int64_t)(cib * kWgBlock + ci) * P.x_sc + (cp.inside[k] ? xg : 0);
+                const int cg = cib * kWgBlock + ci;       // channels at or beyond cin (a narrow first layer) are zero rows
+                cp.inside[k] = xg >= 0 && xg < P.W && cg < P.cin;
+                cp.src[k] = (int64_t)(cg < P.cin ? cg : 0) * P.x_sc + (xg >= 0 && xg < P.W ? xg : 0);
                 cp.dst[k] = ci * kPitch + 8 * gr;
             } else {
                 const int j = cp.live[k] ? id - NX : 0;
@@ -242,7 +243,7 @@ static WgPlan wgrad_plan(int batch, int cin, int cout, int d, int h, int w) {
     WgPlan p;
     p.nq = (w % 64 == 0) ? 2 : 1;
     p.nxb = (w + 32 * p.nq - 1) / (32 * p.nq);
-    const int64_t wgs = (int64_t)batch * d * p.nxb * 3 * ((cout + kWgCo - 1) / kWgCo) * (cin / kWgBlock);
+    const int64_t wgs = (int64_t)batch * d * p.nxb * 3 * ((cout + kWgCo - 1) / kWgCo) * ((cin + kWgBlock - 1) / kWgBlock);
     int split = 1;                                        // cut y when there are too few workgroups to fill 256 CUs x 3
     while (wgs * split < 1536 && h / (split * 2) >= 8) split *= 2;
     p.ysplit = split;
@@ -258,14 +259,15 @@ using namespace segm;
 extern "C" size_t segm_conv3d_k3_wgrad_workspace_bytes(int32_t batch, int32_t cin, int32_t cout, int32_t d, int32_t h, int32_t w) {
     if (batch <= 0 || cin <= 0 || cout <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;
     const WgPlan pl = wgrad_plan(batch, cin, cout, d, h, w);
-    return (size_t)((cout + kWgCo - 1) / kWgCo) * (cin / kWgBlock) * pl.nitems * 27 * kWgCo * kWgBlock * sizeof(float);
+    return (size_t)((cout + kWgCo - 1) / kWgCo) * ((cin + kWgBlock - 1) / kWgBlock) * pl.nitems * 27 * kWgCo * kWgBlock * sizeof(float);
 }
 
 extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
     if (!a) return SEGM_E_NULL;
     if (!a->x || !a->dy || !a->dw || !a->workspace) return SEGM_E_NULL;
     if (a->batch <= 0 || a->depth <= 0 || a->height <= 0 || a->width <= 0) return SEGM_E_SHAPE;
-    if (a->cin % kWgBlock != 0 || a->cout % kWgBlock != 0 || a->cin <= 0 || a->cout <= 0) return SEGM_E_SHAPE;
+    if (a->cin <= 0 || a->cout <= 0 || a->cout % kWgBlock != 0) return SEGM_E_SHAPE;
+    if (a->cin % kWgBlock != 0 && a->cin > kWgBlock) return SEGM_E_SHAPE;      // a multiple of 48, or one narrow block
     if (a->width % 8 != 0) return SEGM_E_SHAPE;
     if (a->dtype != SEGM_BF16) return SEGM_E_DTYPE;
     if (a->dw_dtype != SEGM_BF16 && a->dw_dtype != SEGM_F32) return SEGM_E_DTYPE;
@@ -283,10 +285,10 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
     P.x = (const char*)a->x; P.x_sb = a->x_stride_b; P.x_sc = a->x_stride_c; P.x_sz = a->x_stride_z; P.x_sy = a->x_stride_y;
     P.dy = (const char*)a->dy; P.dy_sb = a->dy_stride_b; P.dy_sc = a->dy_stride_c; P.dy_sz = a->dy_stride_z; P.dy_sy = a->dy_stride_y;
     P.part = (float*)a->workspace;
-    P.B = a->batch; P.D = a->depth; P.H = a->height; P.W = a->width;
+    P.B = a->batch; P.D = a->depth; P.H = a->height; P.W = a->width; P.cin = a->cin;
     const WgPlan pl = wgrad_plan(a->batch, a->cin, a->cout, a->depth, a->height, a->width);
     P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part; P.nitems = pl.nitems;
-    P.ncob = (a->cout + kWgCo - 1) / kWgCo; P.ncib = a->cin / kWgBlock;
+    P.ncob = (a->cout + kWgCo - 1) / kWgCo; P.ncib = (a->cin + kWgBlock - 1) / kWgBlock;
     hipStream_t stream = (hipStream_t)a->stream;
     {
         const dim3 grid(P.nitems, P.ncob * 3, P.ncib);

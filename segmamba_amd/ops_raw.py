@@ -227,7 +227,7 @@ def conv3d_k3_wgrad_supported(x: torch.Tensor, dy: torch.Tensor) -> bool:
         return False
     if x.shape[0] != dy.shape[0] or x.shape[2:] != dy.shape[2:]:
         return False
-    if x.shape[1] % 48 or dy.shape[1] % 48 or x.shape[4] % 8:
+    if (x.shape[1] % 48 and x.shape[1] > 48) or dy.shape[1] % 48 or x.shape[4] % 8:
         return False
     for t in (x, dy):
         if t.stride(4) != 1 or any(t.stride(i) % 8 for i in range(4)) or t.data_ptr() % 16:
@@ -262,7 +262,10 @@ def conv3d_k3_wgrad(lib: L.SegmLib, x: torch.Tensor, dy: torch.Tensor, out_dtype
 # ---------------------------------------------------------------------------------------------------------
 def pack_conv3d_weight(weight: torch.Tensor) -> torch.Tensor:
     """(Cout, 48, 3, 3, 3) -> (Cout, 3, 3, 3, 48) contiguous bf16: the layout segm_conv3d_k3_fwd keeps in registers."""
-    return weight.permute(0, 2, 3, 4, 1).contiguous().to(torch.bfloat16)
+    w = weight.permute(0, 2, 3, 4, 1)
+    if w.shape[-1] < 48:                                   # a narrow first layer: zero input channels up to 48
+        w = torch.nn.functional.pad(w, (0, 48 - w.shape[-1]))
+    return w.contiguous().to(torch.bfloat16)
 
 
 def pack_conv3d_weight_for_dgrad(weight: torch.Tensor) -> torch.Tensor:
@@ -272,7 +275,7 @@ def pack_conv3d_weight_for_dgrad(weight: torch.Tensor) -> torch.Tensor:
 
 
 def conv3d_k3_fwd_supported(x: torch.Tensor, cout: int) -> bool:
-    if x.dim() != 5 or x.dtype != torch.bfloat16 or x.shape[1] != 48 or cout % 16 or x.shape[4] % 8:
+    if x.dim() != 5 or x.dtype != torch.bfloat16 or not 1 <= x.shape[1] <= 48 or cout % 16 or x.shape[4] % 8:
         return False
     return x.stride(4) == 1 and not any(x.stride(i) % 8 for i in range(4)) and x.data_ptr() % 16 == 0
 
@@ -290,7 +293,7 @@ def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias:
     if bias is not None:
         bias = bias.float().contiguous()
     a = L.Conv3dFwdArgs()
-    a.batch, a.cin, a.cout, a.depth, a.height, a.width = B, 48, cout, D, H, W
+    a.batch, a.cin, a.cout, a.depth, a.height, a.width = B, x.shape[1], cout, D, H, W
     a.dtype = L.SEGM_BF16
     a.x, a.y, a.w_packed = x.data_ptr(), y.data_ptr(), w_packed.data_ptr()
     a.x_stride_b, a.x_stride_c, a.x_stride_z, a.x_stride_y = x.stride()[:4]

@@ -144,11 +144,11 @@ def test_conv3d_k3_wgrad_channel_slices_and_errors_emulated(emu):
     ref = _wgrad_reference(xs, dys)
     dw = ops_raw.conv3d_k3_wgrad(emu, xs, dys, torch.float32)
     assert (dw - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-4
-    assert not ops_raw.conv3d_k3_wgrad_supported(xb[:, :40], dyb[:, :48])          # cin % 48
+    assert not ops_raw.conv3d_k3_wgrad_supported(xb[:, :56], dyb[:, :48])          # cin > 48 and not a multiple of 48
     assert not ops_raw.conv3d_k3_wgrad_supported(xb[..., :12], dyb[..., :12])      # width % 8
     assert not ops_raw.conv3d_k3_wgrad_supported(xs.float(), dys.float())          # dtype
     with pytest.raises(RuntimeError):
-        ops_raw.conv3d_k3_wgrad(emu, xb[:, :40], dyb[:, :48])
+        ops_raw.conv3d_k3_wgrad(emu, xb[:, :56], dyb[:, :48])
 
 
 def _instnorm_reference(x, res, act, slope, gy):
@@ -293,3 +293,18 @@ def test_layernorm_tokens_emulated(emu, shape, dtype):
     assert (dx.double() - gx).abs().max() <= tol * max(1.0, float(gx.abs().max()))
     assert (dgm.double() - gg).abs().max() <= 1e-3 * max(1.0, float(gg.abs().max()))
     assert (dbt.double() - gb).abs().max() <= 1e-3 * max(1.0, float(gb.abs().max()))
+
+
+def test_conv3d_kernels_narrow_first_layer_emulated(emu):
+    """4 input channels (SegMamba's first convolution): the kernels zero-fill the missing channels of the 48-channel block."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 4, 2, 5, 16, generator=g).bfloat16()
+    w = (0.2 * torch.randn(48, 4, 3, 3, 3, generator=g)).bfloat16()
+    dy = torch.randn(1, 48, 2, 5, 16, generator=g).bfloat16()
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), None, 1, 1)
+    y = ops_raw.conv3d_k3_fwd(emu, x, ops_raw.pack_conv3d_weight(w))
+    assert (y.float() - ref).abs().max() <= 1e-2 * max(1.0, float(ref.abs().max()))
+    dw = ops_raw.conv3d_k3_wgrad(emu, x, dy, torch.float32)
+    assert dw.shape == (48, 4, 3, 3, 3)
+    ref_dw = _wgrad_reference(x, dy)
+    assert (dw - ref_dw).abs().max() <= 1e-5 * ref_dw.abs().max() + 1e-4

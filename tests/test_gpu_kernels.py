@@ -422,3 +422,17 @@ def test_layernorm_tokens_matches_layer_norm(hip, shape, dtype):
     assert (dbt - gb).abs().max() <= 2e-3 * max(1.0, float(gb.abs().max()))
     d2 = ops_raw.layernorm_tokens_bwd(hip, x, dy, mean, rstd, gamma)
     assert torch.equal(d2[0], dx) and torch.equal(d2[1], dgm) and torch.equal(d2[2], dbt)      # deterministic
+
+
+def test_conv3d_kernels_narrow_first_layer(hip):
+    """4 -> 48 (the first SegMamba convolution): forward and weight gradient against fp32 torch."""
+    g = torch.Generator(device=DEV).manual_seed(8)
+    x = torch.randn(2, 4, 16, 16, 64, device=DEV, generator=g).bfloat16()
+    w = (0.2 * torch.randn(48, 4, 3, 3, 3, device=DEV, generator=g)).bfloat16()
+    dy = torch.randn(2, 48, 16, 16, 64, device=DEV, generator=g).bfloat16()
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), None, 1, 1)
+    y = ops_raw.conv3d_k3_fwd(hip, x, ops_raw.pack_conv3d_weight(w))
+    assert (y.float() - ref).abs().max() <= 2.0 ** -7 * max(1.0, float(ref.abs().max()))
+    dw = ops_raw.conv3d_k3_wgrad(hip, x, dy, torch.float32)
+    ref_dw = _aten_wgrad(x.float(), dy.float())
+    assert dw.shape == (48, 4, 3, 3, 3) and (dw - ref_dw).abs().max() <= 1e-4 * ref_dw.abs().max()
