@@ -1,6 +1,7 @@
-"""Dense 3x3x3 (stride 1, "same") convolutions of the SegMamba stem: an autotuned dispatcher over MIOpen.
+"""Dense 3x3x3 (stride 1, "same") convolutions of the SegMamba stem: an autotuned dispatcher over the library's own
+MFMA kernels and MIOpen.
 
-SURVEY.md §7 step 6: the stem starts on MIOpen.  Profiling (profiles/r01_probe_convs.log,
+SURVEY.md §7 step 6: the stem started on MIOpen.  Profiling (profiles/r01_probe_convs.log,
 profiles/r01_bench_step_kernels_v3.txt) showed that MIOpen's bf16 3-D solvers are very uneven on these shapes:
 
   * forward at 48 channels runs at 200-260 TF/s, but 96 -> 96 @64^3 only at 54 TF/s;
@@ -18,8 +19,9 @@ Every quantity below is mathematically the same convolution, only routed to a di
                                               or  segm_conv3d_k3_wgrad, the library's own MFMA kernel
 
 The first time a (kind, shape, dtype) is seen each candidate is timed once on the real tensors and the fastest is
-cached (what MIOpen's own "find" does, one level up).  Hand-written implicit-GEMM kernels for these layers are the
-first item of the "next" list; this module is their insertion point.
+cached (what MIOpen's own "find" does, one level up).  On the SegMamba shapes the library's kernels win every layer
+with W >= 32 (profiles/r01_conv_autotune_v2.log); the 16^3 / 8^3 bottleneck layers stay on MIOpen.
+SEGM_CONV_AUTOTUNE=0 always takes the first candidate (the plain library call); SEGM_CONV_VERBOSE=1 prints the timings.
 """
 from __future__ import annotations
 
@@ -29,7 +31,7 @@ from typing import Callable, Dict, List, Tuple
 import torch
 import torch.nn.functional as F
 
-_BLOCK = 48                      # MIOpen's fast 3-D bf16 kernels on gfx950 are the 48-channel ones
+_BLOCK = 48                      # channel block of the library's kernels (and of MIOpen's fast 3-D bf16 solvers)
 _cache: Dict[tuple, int] = {}
 _TUNE = os.environ.get("SEGM_CONV_AUTOTUNE", "1") == "1"
 
