@@ -47,7 +47,6 @@ constexpr int kWgCo = 48;                    // output channels per workgroup (3
 constexpr int kWgWaves = 3;                  // ky
 constexpr int kWgThreads = kWgWaves * 64;
 constexpr int kPitch = 88;                   // LDS row pitch (elements): 8 halo + 64 + 8 halo + 8 (bank spread)
-constexpr int kXGran = 10;                   // 16-byte granules of an X row in LDS (NQ = 2): halo, 8 data, halo
 constexpr int kCopies = 5;                   // granules per thread per step: ceil((48 * 10 + 48 * 8) / 192)
 
 struct WgradDev {

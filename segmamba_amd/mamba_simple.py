@@ -18,7 +18,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import lib as L
 from .linear import linear_cl

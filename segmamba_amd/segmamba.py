@@ -15,7 +15,6 @@ What differs from the reference is only *how* the tensors move:
 """
 from __future__ import annotations
 
-import torch
 import torch.nn as nn
 
 from . import fused_norm, layout

@@ -1,5 +1,5 @@
 """Quick on-GPU sanity (not a test): small parity numbers + scan / conv timings at SegMamba's stage shapes."""
-import sys, os, time, json, torch
+import sys, os, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import helpers as H
 from segmamba_amd import lib as L, ops_raw

@@ -1,6 +1,6 @@
 """GPU probe (not product): per-configuration time of SegMamba's 3-D convolutions through MIOpen (bf16, NCDHW),
 forward / grad-input / grad-weight separately."""
-import os, sys, json, time, torch, torch.nn.functional as F
+import os, torch, torch.nn.functional as F
 for k in ("FWD", "BWD", "WRW"): os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + k, "0")
 dev = "cuda"
 def tm(fn, it=3):
