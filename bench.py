@@ -187,7 +187,7 @@ def main():
         if not args.no_roofline:
             out["roofline"] = scan_roofline(torch.bfloat16, device)
             out["roofline_fp32"] = scan_roofline(torch.float32, device)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the host-core baseline is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if distributed:
