@@ -175,7 +175,7 @@ def main():
     if rank == 0:
         vols = world * args.batch * args.steps
         out = {
-            "metric": "volumes/sec fwd+bwd+step, SegMamba 128^3x4 (whole job; divide by n_gpus for per-GPU)",
+            "metric": f"volumes/sec fwd+bwd+step, SegMamba {args.size}^3x4 (whole job; divide by n_gpus for per-GPU)",
             "value": round(vols / elapsed, 4), "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
