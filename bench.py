@@ -111,6 +111,23 @@ def scan_roofline(dtype, device):
     }
 
 
+def inference_rate(state, device, size):
+    """Forward-only SegMamba on one 4 x size^3 volume (eval, no_grad, bf16 autocast): the setting of the only throughput the
+    reference publishes (README table 5: 1.51 case/s at 128^3, hardware not stated - context, not a baseline)."""
+    model = state.model.module if hasattr(state.model, "module") else state.model
+    x = torch.rand(1, 4, size, size, size, device=device)
+    was_training = model.training
+    model.eval()
+
+    def run():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return model(x)
+    ms = time_gpu(run, 10, warmup=3)
+    model.train(was_training)
+    return {"cases_per_s": round(1e3 / ms, 2), "ms_per_case": round(ms, 3), "input": [1, 4, size, size, size],
+            "published_reference": {"cases_per_s": 1.51, "hardware": "not stated (reference README table 5)"}}
+
+
 def cpu_baseline():
     """The oracle's selective_scan_ref (fp32, pure PyTorch - a port of the reference's CPU path) on the host cores."""
     from oracle import ref_ops
@@ -185,6 +202,7 @@ def main():
                        "loss": round(float(loss), 5)},
         }
         if not args.no_roofline:
+            out["inference"] = inference_rate(state, device, args.size)
             out["roofline"] = scan_roofline(torch.bfloat16, device)
             out["roofline_fp32"] = scan_roofline(torch.float32, device)
         if not args.no_cpu_baseline and world == 1:       # the host-core baseline is reported at N = 1 only

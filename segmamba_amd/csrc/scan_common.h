@@ -131,7 +131,7 @@ Seq seq_at(const segm_seq& s, int64_t d0, size_t esize);
 BC bc_at(const segm_bc& m, int g, size_t esize);
 size_t dtype_size(int dtype);
 void fill_scan_dev(ScanDev& P, const segm_scan_fwd_args* a, int g, int chunk);
-// the kernels' 32-bit offset arithmetic: L < 2^24, |stride_t| * esize < 2^24, per-batch span of every view < 4 GiB
+// the kernels' 32-bit offset arithmetic: L <= 2^24, |stride_t| * esize < 2^24, per-batch span of every view < 4 GiB
 int validate_spans(const segm_seq* const* seqs, int nseq, const segm_bc* const* bcs, int nbc, int dim, int dstate,
                    int64_t L, size_t esize);
 bool scan_fast_shape(const ScanDev& P);                        // scan_fwd_fast.hip: shapes its kernels take

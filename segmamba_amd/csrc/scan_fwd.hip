@@ -453,7 +453,7 @@ int validate_scan_common(const segm_scan_fwd_args* a) {
 int validate_spans(const segm_seq* const* seqs, int nseq, const segm_bc* const* bcs, int nbc, int dim, int dstate,
                    int64_t L, size_t esize) {
     const int64_t es = (int64_t)esize, lim24 = (int64_t)1 << 24, lim32 = (int64_t)1 << 32;
-    if (L >= lim24) return SEGM_E_SHAPE;
+    if (L > lim24) return SEGM_E_SHAPE;                    // time indices 0 .. L-1 must fit 24 bits
     for (int i = 0; i < nseq; ++i) {
         const segm_seq* s = seqs[i];
         if (!s || !s->ptr) continue;

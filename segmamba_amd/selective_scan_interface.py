@@ -136,9 +136,11 @@ class MambaInnerCore(torch.autograd.Function):
                                       nslices=nslices)
         x_dbl, delta, Bv, Cv = _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last,
                                         B_proj_bias, C_proj_bias)
+        # the un-gated y and the state checkpoints are only what the backward starts from: inference skips both stores
+        train = any(ctx.needs_input_grad)
         r = ops_raw.scan_fwd(lib, conv_out, delta, A32, Bv, Cv, D32, z, db32, delta_softplus,
                              channel_last=channel_last, time_order=time_order, nslices=nslices,
-                             need_out=True, need_ckpt=True)
+                             need_out=train, need_ckpt=train)
         ctx.cfg = (bool(delta_softplus), bool(channel_last), int(time_order), int(nslices), r["chunk"], R, N,
                    B_proj_bias is not None, C_proj_bias is not None)
         ctx.save_for_backward(xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, A, D,

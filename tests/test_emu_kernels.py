@@ -229,10 +229,10 @@ def test_scan_regular_shape_kernels_emulated(emu, monkeypatch, dim, seqlen, chun
 
 
 def test_scan_rejects_views_beyond_32bit_offsets(emu):
-    """L >= 2^24 or a row stride >= 2^24 bytes is outside the kernels' 32-bit offset arithmetic: SEGM_E_SHAPE, nothing launched."""
+    """L > 2^24 or a row stride >= 2^24 bytes is outside the kernels' 32-bit offset arithmetic: SEGM_E_SHAPE, nothing launched."""
     a = L.ScanFwdArgs()
     buf = torch.zeros(64)
-    a.batch, a.dim, a.dstate, a.n_groups, a.seqlen = 1, 4, 16, 1, 1 << 24
+    a.batch, a.dim, a.dstate, a.n_groups, a.seqlen = 1, 4, 16, 1, (1 << 24) + 16
     a.dtype, a.time_order, a.nslices, a.chunk = L.SEGM_F32, L.TIME_FORWARD, 1, 16
     for name in ("u", "delta", "out"):
         v = getattr(a, name)

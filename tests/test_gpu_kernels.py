@@ -123,6 +123,44 @@ def test_scan_full_size_properties(hip):
     H.assert_close(y1[:, :T].transpose(1, 2), ref, 6e-4, 2e-3, "prefix vs oracle")
 
 
+@pytest.mark.parametrize("log2_len", [21, 24])
+def test_scan_long_sequence_stress(hip, log2_len):
+    """BASELINE config 4: B=1, D=96, N=16, bf16, L = 2^21 (what the reference stem yields for a 256^3 volume) and
+    L = 2^24 = 16.7 M (the figure BASELINE.json quotes; the largest L the 24-bit time indices take).  No CPU oracle can
+    walk these lengths, so: the first 2048 steps against the oracle (the scan is causal), determinism, chunk-length
+    invariance of the forward, and a finite, repeatable backward."""
+    B_, D_, N_, L_ = 1, 96, 16, 1 << log2_len
+    g = torch.Generator(device=DEV).manual_seed(log2_len)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g).bfloat16()
+    u, z, dout = r(B_, L_, D_), r(B_, L_, D_), r(B_, L_, D_)
+    delta = (0.5 * torch.rand(B_, L_, D_, device=DEV, generator=g)).bfloat16()
+    A = -0.5 * torch.rand(D_, N_, device=DEV, generator=g)
+    Bm, Cm = r(B_, L_, N_), r(B_, L_, N_)
+    Dv, db = torch.randn(D_, device=DEV, generator=g), 0.5 * torch.rand(D_, device=DEV, generator=g)
+
+    def fwd(chunk=0):
+        return ops_raw.scan_fwd(hip, u, delta, A, Bm, Cm, Dv, z, db, True, channel_last=True, chunk=chunk, need_out=True,
+                                need_ckpt=True, need_last_state=True)
+    f = fwd()
+    assert torch.isfinite(f["out_z"].float()).all() and torch.isfinite(f["last_state"]).all()
+    f2 = fwd()
+    assert torch.equal(f["out_z"], f2["out_z"]) and torch.equal(f["last_state"], f2["last_state"])
+    fc = fwd(chunk=2 * f["chunk"])
+    assert (fc["out_z"].float() - f["out_z"].float()).abs().max() <= 2e-2 * float(f["out_z"].float().abs().max())
+    T = 2048
+    cpu = lambda t: t[:, :T].transpose(1, 2).float().cpu()
+    ref = ref_ops.selective_scan_ref(cpu(u), cpu(delta), A.cpu(), cpu(Bm), cpu(Cm), Dv.cpu(), z=cpu(z), delta_bias=db.cpu(),
+                                     delta_softplus=True)
+    H.assert_close(f["out_z"][:, :T].transpose(1, 2).float(), ref, 3e-2, 5e-2, "prefix vs oracle")
+    bw = lambda: ops_raw.scan_bwd(hip, u, delta, A, Bm, Cm, Dv, z, db, dout, f["out"], f["ckpt"], True, channel_last=True,
+                                  chunk=f["chunk"])
+    g1, g2 = bw(), bw()
+    for k in ("du", "ddelta", "dz", "dA", "dD", "ddelta_bias"):
+        assert torch.isfinite(g1[k].float()).all(), k
+        assert torch.equal(g1[k], g2[k]), k
+    assert torch.isfinite(g1["dB"]).all() and torch.isfinite(g1["dC"]).all()
+
+
 # ---- causal conv1d: reference matrix causal-conv1d/tests/test_causal_conv1d.py:14-75 (dim reduced) -------------------
 @pytest.mark.parametrize("seqlen", [8, 16, 32, 64, 128, 151, 256, 372, 512, 784, 1024, 1134, 2048, 4096])
 @pytest.mark.parametrize("width", [2, 3, 4])
