@@ -127,9 +127,13 @@ class SlidingWindowInferer:
 class Predictor:
     """reference light_training/prediction.py:29-159, device-resident."""
 
-    def __init__(self, window_infer, mirror_axes=None) -> None:
+    def __init__(self, window_infer, mirror_axes=None, autocast_dtype: torch.dtype = torch.bfloat16) -> None:
+        """`autocast_dtype`: the reference runs the network under `torch.autocast("cuda")`, i.e. fp16 (prediction.py:124);
+        on MI355X the path's 16-bit type is bf16 (BASELINE north star; the library's MFMA convolution kernels are bf16), so
+        that is the default.  Pass torch.float16 for the reference's behaviour."""
         self.window_infer = window_infer
         self.mirror_axes = mirror_axes
+        self.autocast_dtype = autocast_dtype
 
     def maybe_mirror_and_predict(self, x: torch.Tensor, model, device=torch.device("cpu"), **kwargs) -> torch.Tensor:
         """Mean over the 2^len(mirror_axes) mirrored sliding-window predictions (reference :110-159).  The sum runs in the
@@ -145,7 +149,7 @@ class Predictor:
             ordered = sorted(axes)
             for k in range(1, len(ordered) + 1):
                 combos += list(itertools.combinations(ordered, k))
-        with torch.no_grad(), torch.autocast("cuda", enabled=device.type == "cuda"):
+        with torch.no_grad(), torch.autocast("cuda", dtype=self.autocast_dtype, enabled=device.type == "cuda"):
             total = None
             for c in combos:
                 dims = tuple(a + 2 for a in c)
