@@ -185,14 +185,14 @@ size_t segm_causal_conv1d_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_
  *
  *   dW[co, ci, kz, ky, kx] = sum_{b,z,y,x} dY[b, co, z, y, x] * X[b, ci, z+kz-1, y+ky-1, x+kx-1]
  *
- * x, dy: bf16, logical (batch, channel, depth, height, width), W contiguous, every other stride a multiple of 8
+ * x, dy: bf16 or fp16, logical (batch, channel, depth, height, width), W contiguous, every other stride a multiple of 8
  * elements, 16-byte aligned bases (channel slices of NCDHW tensors qualify).  cout a multiple of 48, cin a multiple of
  * 48 or below 48 (a narrow first layer), width a multiple of 8.  dw: contiguous (cout, cin, 3, 3, 3), fp32 or bf16, OVERWRITTEN.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct segm_conv3d_wgrad_args {
     int32_t batch, cin, cout, depth, height, width;
-    int32_t dtype;            /* of x and dy: SEGM_BF16 */
-    int32_t dw_dtype;         /* SEGM_BF16 or SEGM_F32  */
+    int32_t dtype;            /* of x and dy: SEGM_BF16 or SEGM_F16      */
+    int32_t dw_dtype;         /* SEGM_BF16, SEGM_F16 or SEGM_F32         */
     const void* x;   int64_t x_stride_b, x_stride_c, x_stride_z, x_stride_y;
     const void* dy;  int64_t dy_stride_b, dy_stride_c, dy_stride_z, dy_stride_y;
     void* dw;
@@ -212,10 +212,11 @@ size_t segm_conv3d_k3_wgrad_workspace_bytes(int32_t batch, int32_t cin, int32_t 
  *
  *   y[b, co, z, y, x] = bias[co] + sum_{ci, kz, ky, kx} w[co, ci, kz, ky, kx] * x[b, ci, z+kz-1, y+ky-1, x+kx-1]
  *
- * x: bf16 (batch, cin, depth, height, width); y: bf16 (batch, cout, depth, height, width); W contiguous, every other stride a
+ * x, y, w_packed: bf16 or fp16 (one dtype).  x (batch, cin, depth, height, width); y (batch, cout, depth, height,
+ * width); W contiguous, every other stride a
  * multiple of 8 elements, 16-byte aligned bases.  1 <= cin <= 48 (wider layers are sums over 48-channel blocks), cout a
  * multiple of 16, width a multiple of 8.
- * w_packed: bf16 (cout, 3, 3, 3, 48) contiguous, i.e. weight.permute(0, 2, 3, 4, 1) - the input channel fastest - zero
+ * w_packed: (cout, 3, 3, 3, 48) contiguous, i.e. weight.permute(0, 2, 3, 4, 1) - the input channel fastest - zero
  * padded to 48 input channels.
  * bias: (cout) fp32 or NULL.
  * ------------------------------------------------------------------------------------------------ */

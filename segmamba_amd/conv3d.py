@@ -76,7 +76,8 @@ def _fwd_native(x, w, pad):
 def _hip_fwd_ok(x, w) -> bool:
     from . import ops_raw
     return w.shape[2:] == (3, 3, 3) and (w.shape[1] % _BLOCK == 0 or w.shape[1] < _BLOCK) and w.shape[0] % 16 == 0 \
-        and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and ops_raw.conv3d_k3_fwd_supported(x[:, :_BLOCK], w.shape[0])
+        and x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and \
+        ops_raw.conv3d_k3_fwd_supported(x[:, :_BLOCK], w.shape[0])
 
 
 def _fwd_hip(x, w, pad, bias=None):
@@ -85,7 +86,7 @@ def _fwd_hip(x, w, pad, bias=None):
     hip = L.get_lib()
     out = None
     for i, ib in enumerate(_blocks(w.shape[1])):
-        y = ops_raw.conv3d_k3_fwd(hip, x[:, ib], ops_raw.pack_conv3d_weight(w[:, ib]), bias if i == 0 else None)
+        y = ops_raw.conv3d_k3_fwd(hip, x[:, ib], ops_raw.pack_conv3d_weight(w[:, ib], x.dtype), bias if i == 0 else None)
         out = y if out is None else out + y
     return out
 
@@ -146,7 +147,8 @@ def _wgrad_mfma(x, dy, w, pad):
 
 
 def _mfma_wgrad_ok(x, dy, w) -> bool:
-    if w.shape[2:] != (3, 3, 3) or w.dtype not in (torch.bfloat16, torch.float32) or x.dtype != torch.bfloat16:
+    if w.shape[2:] != (3, 3, 3) or w.dtype not in (torch.bfloat16, torch.float16, torch.float32) or \
+            x.dtype not in (torch.bfloat16, torch.float16):
         return False
     return (x.shape[1] % 48 == 0 or x.shape[1] < 48) and dy.shape[1] % 48 == 0 and x.shape[4] % 8 == 0 and \
         x.shape[0] == dy.shape[0]

@@ -33,7 +33,6 @@
 
 namespace segm {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -54,15 +53,16 @@ constexpr int kFwTasks = 3 * (kFwCi / 2) * kFwGran;  // copy tasks per step: (pl
 struct ConvFwdDev {
     const char* x;  int64_t x_sb, x_sc, x_sz, x_sy;       // element strides, x contiguous
     char* y;        int64_t y_sb, y_sc, y_sz, y_sy;
-    const __bf16* wp;                                     // packed weights [cout][27 * 48], k = ((kz*3 + ky)*3 + kx)*48 + ci
+    const void* wp;                                       // packed weights [cout][27 * 48], k = ((kz*3 + ky)*3 + kx)*48 + ci
     const float* bias;                                    // (cout) or null
     int32_t B, D, H, W, cout, cob0, cin;
     int32_t nxb, ysplit, rows_per_part;
 };
 
-template <int NCO>
+template <typename T, int NCO>
 __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P) {
-    __shared__ __attribute__((aligned(16))) __bf16 xs[3][4][kFwSlot];
+    typedef typename Mfma16<T>::v8 frag8;
+    __shared__ __attribute__((aligned(16))) T xs[3][4][kFwSlot];
     __shared__ __attribute__((aligned(16))) float red[2][8][2][4][64];      // [buffer][(kz - 1) * 4 + xt][co tile][r][lane]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
 
     // ---- stationary weights: B[k][co] fragments of this wave's kz slice -----------------------------------------------
     // chunk c, lane group g: k = 32 c + 8 g .. + 7 inside the slice -> tap (ky, kx) = k / 48, ci0 = k % 48
-    bf16x8 wf[NCO][kFwChunks];
+    frag8 wf[NCO][kFwChunks];
     int32_t aoff[kFwChunks];                              // LDS element offset of the matching A fragment, without the row slot
     int32_t aky[kFwChunks];
 #pragma unroll
@@ -96,9 +96,9 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
 #pragma unroll
         for (int t = 0; t < NCO; ++t) {
             const int co = cob * kFwCo + t * 16 + i16;
-            const u32x4 w = *reinterpret_cast<const u32x4*>(P.wp + ((int64_t)co * 27 + kz * 9) * kFwCi + kk);
+            const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(P.wp) + ((int64_t)co * 27 + kz * 9) * kFwCi + kk);
             const u32x4 zero = {0u, 0u, 0u, 0u};
-            wf[t][c] = __builtin_bit_cast(bf16x8, (live && plane_ok) ? w : zero);
+            wf[t][c] = __builtin_bit_cast(frag8, (live && plane_ok) ? w : zero);
         }
     }
     float bias[NCO];
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
     const bool t_plane = tzz >= 0 && tzz < P.D;
     // channels at or beyond cin (a narrow first layer) are zero: read a valid channel, drop the value
     const bool t_c0 = 2 * tcp < P.cin, t_c1 = 2 * tcp + 1 < P.cin;
-    const __bf16* tsrc = reinterpret_cast<const __bf16*>(P.x) + (int64_t)b * P.x_sb + (int64_t)(t_plane ? tzz : z) * P.x_sz +
+    const T* tsrc = reinterpret_cast<const T*>(P.x) + (int64_t)b * P.x_sb + (int64_t)(t_plane ? tzz : z) * P.x_sz +
                          (int64_t)(t_c0 ? 2 * tcp : 0) * P.x_sc + (t_inside ? txg : 0);
     const int64_t tc1 = t_c1 ? P.x_sc : 0;
     // ring positions p = x - (x0 - 1): the granule covers p = 8 tgr - 7 .. 8 tgr; only 0 <= p < kFwXP is stored
@@ -125,14 +125,14 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
 
     auto fetch = [&](u32x4 (&r)[2], int yy) {
         const bool ok = yy >= 0 && yy < P.H;
-        const __bf16* s = tsrc + (int64_t)(ok ? yy : 0) * P.x_sy;
+        const T* s = tsrc + (int64_t)(ok ? yy : 0) * P.x_sy;
         r[0] = *reinterpret_cast<const u32x4*>(s);
         r[1] = *reinterpret_cast<const u32x4*>(s + tc1);
     };
     auto park = [&](const u32x4 (&r)[2], int yy, int slot) {
         if (!has_task) return;
         const bool keep = yy >= 0 && yy < P.H && t_inside && t_plane;
-        __bf16* row = &xs[tpl][slot][0];
+        T* row = &xs[tpl][slot][0];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int p = tp0 + e;
@@ -163,14 +163,14 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
 #pragma unroll
             for (int t = 0; t < NCO; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (plane_ok) {
-                const __bf16* pl = &xs[kz][0][0];
+                const T* pl = &xs[kz][0][0];
 #pragma unroll
                 for (int c = 0; c < kFwChunks; ++c) {
                     const int slot = (y + aky[c] - 1 + 4) & 3;
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(pl + slot * kFwSlot + aoff[c]);
+                    const frag8 a = *reinterpret_cast<const frag8*>(pl + slot * kFwSlot + aoff[c]);
 #pragma unroll
                     for (int t = 0; t < NCO; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[t][c], acc[t], 0, 0, 0);
+                        acc[t] = Mfma16<T>::run(a, wf[t][c], acc[t]);
                 }
             }
             SEGM_SCHED_FENCE();
@@ -192,13 +192,13 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             v[q] = acc[t][q] + red[rb][xt][t][q][lane] + red[rb][4 + xt][t][q][lane] + bias[t];
-                        __bf16 o[4];
+                        T o[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) o[q] = (__bf16)v[q];
+                        for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(v[q]);
                         u32x2 pk;
                         memcpy(&pk, o, 8);
                         const int co = cob * kFwCo + t * 16 + i16;
-                        __bf16* dst = reinterpret_cast<__bf16*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
+                        T* dst = reinterpret_cast<T*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
                                       (int64_t)z * P.y_sz + (int64_t)y * P.y_sy + xg;
                         *reinterpret_cast<u32x2*>(dst) = pk;
                     }
@@ -221,8 +221,10 @@ constexpr int kF48Threads = kF48Waves * 64;
 constexpr int kF48Chunks = 11;                    // chunks per K part (parts 1..3 use 10; the last chunk of all is half empty)
 constexpr int kF48K = 27 * kFwCi;                 // 1296
 
+template <typename T>
 __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwdDev P) {
-    __shared__ __attribute__((aligned(16))) __bf16 xs[3][4][kFwSlot];
+    typedef typename Mfma16<T>::v8 frag8;
+    __shared__ __attribute__((aligned(16))) T xs[3][4][kFwSlot];
     __shared__ __attribute__((aligned(16))) float red[6][3][2][4][64];      // [(part - 1) * 2 + xp][co tile][x tile][r][lane]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -240,7 +242,7 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
     const int c_count = part == 0 ? 11 : 10;
 
     // ---- stationary weights and the matching A fragment offsets ------------------------------------------------------
-    bf16x8 wf[3][kF48Chunks];
+    frag8 wf[3][kF48Chunks];
     int32_t aoff[kF48Chunks];                             // LDS element offset without the row slot; ky in bits 28..29
 #pragma unroll
     for (int c = 0; c < kF48Chunks; ++c) {
@@ -253,9 +255,9 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int co = cob * 48 + t * 16 + i16;
-            const u32x4 w = *reinterpret_cast<const u32x4*>(P.wp + (int64_t)co * kF48K + kk);
+            const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(P.wp) + (int64_t)co * kF48K + kk);
             const u32x4 zero = {0u, 0u, 0u, 0u};
-            wf[t][c] = __builtin_bit_cast(bf16x8, live ? w : zero);
+            wf[t][c] = __builtin_bit_cast(frag8, live ? w : zero);
         }
     }
     float bias[3];
@@ -265,7 +267,7 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
     // ---- copy plan: 720 tasks (plane, granule, ci pair) over 512 threads: two per thread ------------------------------------
     int tpl[2], tcp[2], tp0[2];
     bool has_task[2], t_keep[2], t_c0[2], t_c1[2];
-    const __bf16* tsrc[2];
+    const T* tsrc[2];
     int64_t tc1[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
         t_keep[q] = inside && plane;
         t_c0[q] = 2 * tcp[q] < P.cin;                     // channels at or beyond cin (a narrow first layer) are zero
         t_c1[q] = 2 * tcp[q] + 1 < P.cin;
-        tsrc[q] = reinterpret_cast<const __bf16*>(P.x) + (int64_t)b * P.x_sb + (int64_t)(plane ? tzz : z) * P.x_sz +
+        tsrc[q] = reinterpret_cast<const T*>(P.x) + (int64_t)b * P.x_sb + (int64_t)(plane ? tzz : z) * P.x_sz +
                   (int64_t)(t_c0[q] ? 2 * tcp[q] : 0) * P.x_sc + (inside ? txg : 0);
         tc1[q] = t_c1[q] ? P.x_sc : 0;
         tp0[q] = 8 * tgr - 7;
@@ -303,7 +305,7 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
         for (int q = 0; q < 2; ++q) {
             if (!has_task[q]) continue;
             const bool keep = row_ok && t_keep[q];
-            __bf16* row = &xs[tpl[q]][slot][0];
+            T* row = &xs[tpl[q]][slot][0];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int p = tp0[q] + e;
@@ -335,17 +337,17 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const __bf16* pl = &xs[0][0][0];
+            const T* pl = &xs[0][0][0];
 #pragma unroll
             for (int c = 0; c < kF48Chunks; ++c) {
                 const int slot = (y + (aoff[c] >> 28) + 3) & 3;
-                const __bf16* ap = pl + slot * kFwSlot + (aoff[c] & 0x0fffffff);
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 16 * kFwCP);       // the pair's second x tile
+                const T* ap = pl + slot * kFwSlot + (aoff[c] & 0x0fffffff);
+                const frag8 a0 = *reinterpret_cast<const frag8*>(ap);
+                const frag8 a1 = *reinterpret_cast<const frag8*>(ap + 16 * kFwCP);       // the pair's second x tile
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[t][c], acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[t][c], acc[t][1], 0, 0, 0);
+                    acc[t][0] = Mfma16<T>::run(a0, wf[t][c], acc[t][0]);
+                    acc[t][1] = Mfma16<T>::run(a1, wf[t][c], acc[t][1]);
                 }
             }
             SEGM_SCHED_FENCE();
@@ -366,15 +368,15 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
                     if (xg >= P.W) continue;
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
-                        __bf16 o[4];
+                        T o[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            o[q] = (__bf16)(acc[t][u][q] + red[xp][t][u][q][lane] + red[2 + xp][t][u][q][lane] +
-                                            red[4 + xp][t][u][q][lane] + bias[t]);
+                            o[q] = from_f32<T>(acc[t][u][q] + red[xp][t][u][q][lane] + red[2 + xp][t][u][q][lane] +
+                                               red[4 + xp][t][u][q][lane] + bias[t]);
                         u32x2 pk;
                         memcpy(&pk, o, 8);
                         const int co = cob * 48 + t * 16 + i16;
-                        __bf16* dst = reinterpret_cast<__bf16*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
+                        T* dst = reinterpret_cast<T*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
                                       (int64_t)z * P.y_sz + (int64_t)y * P.y_sy + xg;
                         *reinterpret_cast<u32x2*>(dst) = pk;
                     }
@@ -408,7 +410,7 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     if (a->batch <= 0 || a->depth <= 0 || a->height <= 0 || a->width <= 0) return SEGM_E_SHAPE;
     if (a->cin < 1 || a->cin > kFwCi || a->cout <= 0 || a->cout % 16 != 0) return SEGM_E_SHAPE;
     if (a->width % 8 != 0) return SEGM_E_SHAPE;
-    if (a->dtype != SEGM_BF16) return SEGM_E_DTYPE;
+    if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
     const int64_t st[8] = {a->x_stride_b, a->x_stride_c, a->x_stride_z, a->x_stride_y,
                            a->y_stride_b, a->y_stride_c, a->y_stride_z, a->y_stride_y};
     for (int64_t s : st)
@@ -419,23 +421,31 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     memset(&P, 0, sizeof(P));
     P.x = (const char*)a->x; P.x_sb = a->x_stride_b; P.x_sc = a->x_stride_c; P.x_sz = a->x_stride_z; P.x_sy = a->x_stride_y;
     P.y = (char*)a->y; P.y_sb = a->y_stride_b; P.y_sc = a->y_stride_c; P.y_sz = a->y_stride_z; P.y_sy = a->y_stride_y;
-    P.wp = (const __bf16*)a->w_packed;
+    P.wp = a->w_packed;
     P.bias = a->bias;
     P.B = a->batch; P.D = a->depth; P.H = a->height; P.W = a->width; P.cout = a->cout; P.cin = a->cin;
     const FwPlan pl = fwd_plan(a->batch, a->cout, a->depth, a->height, a->width);
     P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part;
     hipStream_t stream = (hipStream_t)a->stream;
+    const bool f16 = a->dtype == SEGM_F16;
     if (a->cout % 48 == 0 && !getenv("SEGM_CONV_FWD_KZ_SPLIT")) {      // the env switch forces the 32 + 16 kernels (A/B timing)
-        hipLaunchKernelGGL(conv3d_k3_fwd48_kernel, dim3(pl.nitems, a->cout / 48), dim3(kF48Threads), 0, stream, P);
+        const dim3 grid(pl.nitems, a->cout / 48);
+        if (f16) hipLaunchKernelGGL((conv3d_k3_fwd48_kernel<f16_t>), grid, dim3(kF48Threads), 0, stream, P);
+        else hipLaunchKernelGGL((conv3d_k3_fwd48_kernel<bf16_t>), grid, dim3(kF48Threads), 0, stream, P);
         return (int)hipGetLastError();
     }
     const int full = a->cout / kFwCo;                     // blocks with two co tiles; cout % 32 == 16 leaves one with a single tile
     P.cob0 = 0;
-    if (full > 0)
-        hipLaunchKernelGGL((conv3d_k3_fwd_kernel<2>), dim3(pl.nitems, full), dim3(kFwThreads), 0, stream, P);
+    if (full > 0) {
+        const dim3 grid(pl.nitems, full);
+        if (f16) hipLaunchKernelGGL((conv3d_k3_fwd_kernel<f16_t, 2>), grid, dim3(kFwThreads), 0, stream, P);
+        else hipLaunchKernelGGL((conv3d_k3_fwd_kernel<bf16_t, 2>), grid, dim3(kFwThreads), 0, stream, P);
+    }
     if (a->cout % kFwCo) {
         P.cob0 = full;
-        hipLaunchKernelGGL((conv3d_k3_fwd_kernel<1>), dim3(pl.nitems, 1), dim3(kFwThreads), 0, stream, P);
+        const dim3 grid(pl.nitems, 1);
+        if (f16) hipLaunchKernelGGL((conv3d_k3_fwd_kernel<f16_t, 1>), grid, dim3(kFwThreads), 0, stream, P);
+        else hipLaunchKernelGGL((conv3d_k3_fwd_kernel<bf16_t, 1>), grid, dim3(kFwThreads), 0, stream, P);
     }
     return (int)hipGetLastError();
 }

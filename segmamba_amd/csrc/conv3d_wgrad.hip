@@ -38,7 +38,6 @@
 
 namespace segm {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -65,11 +64,12 @@ struct WgCopy {
     bool is_x[kCopies], live[kCopies], inside[kCopies];   // inside: the granule's x range is inside the volume
 };
 
-template <int NQ>
+template <typename T, int NQ>
 __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev P) {
+    typedef typename Mfma16<T>::v8 frag8;
     constexpr int NCO = kWgCo / 16;
-    __shared__ __attribute__((aligned(16))) __bf16 xs[4][kWgBlock][kPitch];
-    __shared__ __attribute__((aligned(16))) __bf16 dys[2][kWgCo][kPitch];
+    __shared__ __attribute__((aligned(16))) T xs[4][kWgBlock][kPitch];
+    __shared__ __attribute__((aligned(16))) T dys[2][kWgCo][kPitch];
     const int tid = threadIdx.x, lane = tid & 63;
     const int ky = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: row / tap arithmetic stays on the SALU
     const int i16 = lane & 15, g = lane >> 4;
@@ -119,18 +119,18 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
                 cp.dst[k] = co * kPitch + 8 * gr;
             }
         }
-        const __bf16* xplane = reinterpret_cast<const __bf16*>(P.x) + (int64_t)b * P.x_sb + (int64_t)zz * P.x_sz;
-        const __bf16* dyplane = reinterpret_cast<const __bf16*>(P.dy) + (int64_t)b * P.dy_sb + (int64_t)z * P.dy_sz;
+        const T* xplane = reinterpret_cast<const T*>(P.x) + (int64_t)b * P.x_sb + (int64_t)zz * P.x_sz;
+        const T* dyplane = reinterpret_cast<const T*>(P.dy) + (int64_t)b * P.dy_sb + (int64_t)z * P.dy_sz;
         const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
         // fetch X row yy and dY row yd into registers (rows outside the volume / range read a valid row and are zeroed)
         auto fetch = [&](u32x4 (&r)[kCopies], int yy, int yd) {
             const bool x_ok = yy >= 0 && yy < P.H;
-            const __bf16* xr = xplane + (int64_t)(x_ok ? yy : 0) * P.x_sy;
-            const __bf16* dr = dyplane + (int64_t)(yd < P.H ? yd : 0) * P.dy_sy;
+            const T* xr = xplane + (int64_t)(x_ok ? yy : 0) * P.x_sy;
+            const T* dr = dyplane + (int64_t)(yd < P.H ? yd : 0) * P.dy_sy;
 #pragma unroll
             for (int k = 0; k < kCopies; ++k) {
-                const __bf16* src = (cp.is_x[k] ? xr : dr) + cp.src[k];
+                const T* src = (cp.is_x[k] ? xr : dr) + cp.src[k];
                 r[k] = *reinterpret_cast<const u32x4*>(src);
             }
         };
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
             for (int k = 0; k < kCopies; ++k) {
                 if (!cp.live[k]) continue;
                 const bool keep = cp.is_x[k] ? (x_ok && cp.inside[k]) : cp.inside[k];
-                __bf16* dst = (cp.is_x[k] ? &xs[slot][0][0] : &dys[buf][0][0]) + cp.dst[k];
+                T* dst = (cp.is_x[k] ? &xs[slot][0][0] : &dys[buf][0][0]) + cp.dst[k];
                 *reinterpret_cast<u32x4*>(dst) = keep ? r[k] : zero4;
             }
         };
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
                     av[co] = *reinterpret_cast<const u32x4*>(&dys[buf][co * 16 + i16][32 * q + 8 * g]);
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) {
-                    const __bf16* xc = &xs[slot][ci * 16 + i16][8 + 32 * q + 8 * g];
+                    const T* xc = &xs[slot][ci * 16 + i16][8 + 32 * q + 8 * g];
                     const u32x4 v = *reinterpret_cast<const u32x4*>(xc);
                     const uint32_t hl = *reinterpret_cast<const uint32_t*>(xc - 2);     // elements (x-2, x-1)
                     const uint32_t hr = *reinterpret_cast<const uint32_t*>(xc + 8);     // elements (x+8, x+9)
@@ -181,10 +181,10 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
                     const u32x4 vr = {s1, s2, s3, __builtin_amdgcn_alignbyte(hr, v[3], 2)};   // X[x+1 ..]  (kx = 2)
 #pragma unroll
                     for (int co = 0; co < NCO; ++co) {
-                        const bf16x8 a = __builtin_bit_cast(bf16x8, av[co]);
-                        acc[co][0][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, vl), acc[co][0][ci], 0, 0, 0);
-                        acc[co][1][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, v), acc[co][1][ci], 0, 0, 0);
-                        acc[co][2][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, vr), acc[co][2][ci], 0, 0, 0);
+                        const frag8 a = __builtin_bit_cast(frag8, av[co]);
+                        acc[co][0][ci] = Mfma16<T>::run(a, __builtin_bit_cast(frag8, vl), acc[co][0][ci]);
+                        acc[co][1][ci] = Mfma16<T>::run(a, __builtin_bit_cast(frag8, v), acc[co][1][ci]);
+                        acc[co][2][ci] = Mfma16<T>::run(a, __builtin_bit_cast(frag8, vr), acc[co][2][ci]);
                     }
                 }
             }
@@ -268,8 +268,8 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
     if (a->cin <= 0 || a->cout <= 0 || a->cout % kWgBlock != 0) return SEGM_E_SHAPE;
     if (a->cin % kWgBlock != 0 && a->cin > kWgBlock) return SEGM_E_SHAPE;      // a multiple of 48, or one narrow block
     if (a->width % 8 != 0) return SEGM_E_SHAPE;
-    if (a->dtype != SEGM_BF16) return SEGM_E_DTYPE;
-    if (a->dw_dtype != SEGM_BF16 && a->dw_dtype != SEGM_F32) return SEGM_E_DTYPE;
+    if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
+    if (a->dw_dtype != SEGM_BF16 && a->dw_dtype != SEGM_F16 && a->dw_dtype != SEGM_F32) return SEGM_E_DTYPE;
     // 16-byte aligned rows: every stride a multiple of 8 elements, base pointers 16-byte aligned
     const int64_t st[8] = {a->x_stride_b, a->x_stride_c, a->x_stride_z, a->x_stride_y,
                            a->dy_stride_b, a->dy_stride_c, a->dy_stride_z, a->dy_stride_y};
@@ -291,13 +291,21 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
     hipStream_t stream = (hipStream_t)a->stream;
     {
         const dim3 grid(P.nitems, P.ncob * 3, P.ncib);
-        if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<2>), grid, dim3(kWgThreads), 0, stream, P);
-        else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<1>), grid, dim3(kWgThreads), 0, stream, P);
+        if (a->dtype == SEGM_F16) {
+            if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 2>), grid, dim3(kWgThreads), 0, stream, P);
+            else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 1>), grid, dim3(kWgThreads), 0, stream, P);
+        } else {
+            if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 2>), grid, dim3(kWgThreads), 0, stream, P);
+            else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 1>), grid, dim3(kWgThreads), 0, stream, P);
+        }
     }
     const int total = a->cout * a->cin * 27;
     if (a->dw_dtype == SEGM_F32)
         hipLaunchKernelGGL((conv3d_k3_wgrad_reduce_kernel<float>), dim3((total + 63) / 64), dim3(256), 0, stream,
                            (const float*)P.part, (float*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
+    else if (a->dw_dtype == SEGM_F16)
+        hipLaunchKernelGGL((conv3d_k3_wgrad_reduce_kernel<f16_t>), dim3((total + 63) / 64), dim3(256), 0, stream,
+                           (const float*)P.part, (f16_t*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
     else
         hipLaunchKernelGGL((conv3d_k3_wgrad_reduce_kernel<bf16_t>), dim3((total + 63) / 64), dim3(256), 0, stream,
                            (const float*)P.part, (bf16_t*)a->dw, P.nitems, P.ncib, a->cout, a->cin);

@@ -54,6 +54,22 @@ typedef __bf16 bf16_t;
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 
+// ---- v_mfma_f32_16x16x32 for the two 16-bit element types (conv3d_fwd.hip, conv3d_wgrad.hip) -----------------------
+typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct Mfma16;
+template <> struct Mfma16<bf16_t> {
+    typedef bf16_t v8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ mfma_f32x4 run(v8 a, v8 b, mfma_f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma16<f16_t> {
+    typedef f16_t v8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ mfma_f32x4 run(v8 a, v8 b, mfma_f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
 // ---- 16-byte packets of a tensor's element type (HBM-bound elementwise kernels) ------------------------------
 template <typename T> struct Vec;       // 16-byte packets
 template <> struct Vec<float> { static constexpr int N = 4; };

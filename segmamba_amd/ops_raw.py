@@ -223,7 +223,7 @@ def conv1d_bwd(lib: L.SegmLib, x, weight, bias, dout, silu=False, *, channel_las
 # ---------------------------------------------------------------------------------------------------------
 def conv3d_k3_wgrad_supported(x: torch.Tensor, dy: torch.Tensor) -> bool:
     """Shapes / layouts the MFMA weight-gradient kernel takes (everything else stays on MIOpen)."""
-    if x.dim() != 5 or dy.dim() != 5 or x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
+    if x.dim() != 5 or dy.dim() != 5 or x.dtype not in (torch.bfloat16, torch.float16) or dy.dtype != x.dtype:
         return False
     if x.shape[0] != dy.shape[0] or x.shape[2:] != dy.shape[2:]:
         return False
@@ -243,7 +243,7 @@ def conv3d_k3_wgrad(lib: L.SegmLib, x: torch.Tensor, dy: torch.Tensor, out_dtype
     cout = dy.shape[1]
     a = L.Conv3dWgradArgs()
     a.batch, a.cin, a.cout, a.depth, a.height, a.width = B, cin, cout, D, H, W
-    a.dtype = L.SEGM_BF16
+    a.dtype = L.dtype_code(x)
     a.dw_dtype = L.dtype_code(torch.empty(0, dtype=out_dtype))
     a.x, a.dy = x.data_ptr(), dy.data_ptr()
     a.x_stride_b, a.x_stride_c, a.x_stride_z, a.x_stride_y = x.stride()[:4]
@@ -260,22 +260,23 @@ def conv3d_k3_wgrad(lib: L.SegmLib, x: torch.Tensor, dy: torch.Tensor, out_dtype
 # ---------------------------------------------------------------------------------------------------------
 # 3x3x3 convolution forward / data gradient (48 input channels)
 # ---------------------------------------------------------------------------------------------------------
-def pack_conv3d_weight(weight: torch.Tensor) -> torch.Tensor:
-    """(Cout, 48, 3, 3, 3) -> (Cout, 3, 3, 3, 48) contiguous bf16: the layout segm_conv3d_k3_fwd keeps in registers."""
+def pack_conv3d_weight(weight: torch.Tensor, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """(Cout, Cin <= 48, 3, 3, 3) -> (Cout, 3, 3, 3, 48) contiguous in the activations' 16-bit dtype: the layout
+    segm_conv3d_k3_fwd keeps in registers."""
     w = weight.permute(0, 2, 3, 4, 1)
     if w.shape[-1] < 48:                                   # a narrow first layer: zero input channels up to 48
         w = torch.nn.functional.pad(w, (0, 48 - w.shape[-1]))
-    return w.contiguous().to(torch.bfloat16)
+    return w.contiguous().to(dtype)
 
 
-def pack_conv3d_weight_for_dgrad(weight: torch.Tensor) -> torch.Tensor:
+def pack_conv3d_weight_for_dgrad(weight: torch.Tensor, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
     """The data gradient of a stride-1 pad-1 3x3x3 convolution is the forward convolution of dy with the spatially
     flipped, channel-transposed weights: (Cout, Cin, 3, 3, 3) -> packed (Cin, 3, 3, 3, Cout)."""
-    return pack_conv3d_weight(weight.flip(2, 3, 4).transpose(0, 1))
+    return pack_conv3d_weight(weight.flip(2, 3, 4).transpose(0, 1), dtype)
 
 
 def conv3d_k3_fwd_supported(x: torch.Tensor, cout: int) -> bool:
-    if x.dim() != 5 or x.dtype != torch.bfloat16 or not 1 <= x.shape[1] <= 48 or cout % 16 or x.shape[4] % 8:
+    if x.dim() != 5 or x.dtype not in (torch.bfloat16, torch.float16) or not 1 <= x.shape[1] <= 48 or cout % 16 or x.shape[4] % 8:
         return False
     return x.stride(4) == 1 and not any(x.stride(i) % 8 for i in range(4)) and x.data_ptr() % 16 == 0
 
@@ -286,15 +287,15 @@ def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias:
     cout = w_packed.shape[0]
     if not conv3d_k3_fwd_supported(x, cout):
         raise RuntimeError("conv3d_k3_fwd: unsupported shape / dtype / layout")
-    if tuple(w_packed.shape[1:]) != (3, 3, 3, 48) or w_packed.dtype != torch.bfloat16 or not w_packed.is_contiguous():
-        raise RuntimeError("conv3d_k3_fwd: w_packed must be a contiguous bf16 (Cout, 3, 3, 3, 48) tensor")
+    if tuple(w_packed.shape[1:]) != (3, 3, 3, 48) or w_packed.dtype != x.dtype or not w_packed.is_contiguous():
+        raise RuntimeError("conv3d_k3_fwd: w_packed must be a contiguous (Cout, 3, 3, 3, 48) tensor of x's dtype")
     B, _, D, H, W = x.shape
     y = torch.empty(B, cout, D, H, W, dtype=x.dtype, device=x.device)
     if bias is not None:
         bias = bias.float().contiguous()
     a = L.Conv3dFwdArgs()
     a.batch, a.cin, a.cout, a.depth, a.height, a.width = B, x.shape[1], cout, D, H, W
-    a.dtype = L.SEGM_BF16
+    a.dtype = L.dtype_code(x)
     a.x, a.y, a.w_packed = x.data_ptr(), y.data_ptr(), w_packed.data_ptr()
     a.x_stride_b, a.x_stride_c, a.x_stride_z, a.x_stride_y = x.stride()[:4]
     a.y_stride_b, a.y_stride_c, a.y_stride_z, a.y_stride_y = y.stride()[:4]

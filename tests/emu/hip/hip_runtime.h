@@ -180,3 +180,26 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf1
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_16x16x32_bf16
+typedef _Float16 hipemu_f16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x4 hipemu_mfma_16x16x32_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x4 c, int, int, int) {
+    const unsigned lane = hipemu::t_linear % 64, wave = hipemu::t_linear / 64;
+    unsigned char* buf = hipemu::g_wave_big->data() + (size_t)wave * 64 * 64;
+    memcpy(buf + lane * 64, &a, 16);
+    memcpy(buf + lane * 64 + 16, &b, 16);
+    hipemu::sync_wave();
+    hipemu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r, col = lane & 15;
+        float s = 0.f;
+        for (int k = 0; k < 32; ++k) {
+            _Float16 av, bv;
+            memcpy(&av, buf + (row + 16 * (k / 8)) * 64 + 2 * (k % 8), 2);
+            memcpy(&bv, buf + (col + 16 * (k / 8)) * 64 + 16 + 2 * (k % 8), 2);
+            s += (float)av * (float)bv;
+        }
+        d[r] += s;
+    }
+    hipemu::sync_wave();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 hipemu_mfma_16x16x32_f16

@@ -308,3 +308,17 @@ def test_conv3d_kernels_narrow_first_layer_emulated(emu):
     assert dw.shape == (48, 4, 3, 3, 3)
     ref_dw = _wgrad_reference(x, dy)
     assert (dw - ref_dw).abs().max() <= 1e-5 * ref_dw.abs().max() + 1e-4
+
+
+def test_conv3d_kernels_fp16_emulated(emu):
+    """the fp16 instantiations (v_mfma_f32_16x16x32_f16) of the forward and weight-gradient kernels"""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(1, 48, 2, 4, 16, generator=g).half()
+    w = (0.1 * torch.randn(48, 48, 3, 3, 3, generator=g)).half()
+    dy = torch.randn(1, 48, 2, 4, 16, generator=g).half()
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), None, 1, 1)
+    y = ops_raw.conv3d_k3_fwd(emu, x, ops_raw.pack_conv3d_weight(w, torch.float16))
+    assert y.dtype == torch.float16 and (y.float() - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
+    dw = ops_raw.conv3d_k3_wgrad(emu, x, dy, torch.float16)
+    ref_dw = _wgrad_reference(x, dy)
+    assert dw.dtype == torch.float16 and (dw.float() - ref_dw).abs().max() <= 2e-3 * max(1.0, float(ref_dw.abs().max()))

@@ -474,3 +474,20 @@ def test_conv3d_kernels_narrow_first_layer(hip):
     dw = ops_raw.conv3d_k3_wgrad(hip, x, dy, torch.float32)
     ref_dw = _aten_wgrad(x.float(), dy.float())
     assert dw.shape == (48, 4, 3, 3, 3) and (dw - ref_dw).abs().max() <= 1e-4 * ref_dw.abs().max()
+
+
+def test_conv3d_kernels_fp16(hip):
+    """fp16 (the reference's autocast default) through the same kernels: forward, data gradient as forward, weight gradient."""
+    g = torch.Generator(device=DEV).manual_seed(12)
+    x = torch.randn(2, 48, 8, 16, 64, device=DEV, generator=g).half()
+    w = (0.05 * torch.randn(48, 48, 3, 3, 3, device=DEV, generator=g)).half()
+    dy = torch.randn(2, 48, 8, 16, 64, device=DEV, generator=g).half()
+    xr, wr = x.float().requires_grad_(), w.float().requires_grad_()
+    ref = torch.nn.functional.conv3d(xr, wr, None, 1, 1)
+    gx, gw = torch.autograd.grad(ref, (xr, wr), dy.float())
+    y = ops_raw.conv3d_k3_fwd(hip, x, ops_raw.pack_conv3d_weight(w, torch.float16))
+    assert (y.float() - ref).abs().max() <= 2.0 ** -10 * max(1.0, float(ref.abs().max()))
+    dx = ops_raw.conv3d_k3_fwd(hip, dy, ops_raw.pack_conv3d_weight_for_dgrad(w, torch.float16))
+    assert (dx.float() - gx).abs().max() <= 2.0 ** -10 * max(1.0, float(gx.abs().max()))
+    dw = ops_raw.conv3d_k3_wgrad(hip, x, dy, torch.float32)
+    assert (dw - gw).abs().max() <= 1e-4 * float(gw.abs().max())
