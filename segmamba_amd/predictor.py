@@ -129,8 +129,8 @@ class Predictor:
 
     def __init__(self, window_infer, mirror_axes=None, autocast_dtype: torch.dtype = torch.bfloat16) -> None:
         """`autocast_dtype`: the reference runs the network under `torch.autocast("cuda")`, i.e. fp16 (prediction.py:124);
-        on MI355X the path's 16-bit type is bf16 (BASELINE north star; the library's MFMA convolution kernels are bf16), so
-        that is the default.  Pass torch.float16 for the reference's behaviour."""
+        on MI355X the path's 16-bit type is bf16 (BASELINE north star), so that is the default.  Pass torch.float16 for
+        the reference's behaviour (same kernels, same speed)."""
         self.window_infer = window_infer
         self.mirror_axes = mirror_axes
         self.autocast_dtype = autocast_dtype
