@@ -155,3 +155,35 @@ def test_patch_convs_match_torch():
     assert torch.allclose(y, ref, atol=1e-5)
     for got, want in zip(torch.autograd.grad(y, (x, wt, b), gy), torch.autograd.grad(ref, (x, wt, b), gy)):
         assert torch.allclose(got, want, atol=1e-4)
+
+
+def test_conv_dispatcher_routings_are_the_same_convolution():
+    """conv3d.py: every candidate the autotuner may pick (channel-blocked forward, data gradient as a forward convolution
+    with flipped weights, blocked weight gradient, cat-free decoder convolution) equals torch's conv3d autograd."""
+    import torch.nn.functional as F
+    from segmamba_amd import conv3d as C3
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 96, 4, 5, 6, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(48, 96, 3, 3, 3, generator=g, dtype=torch.float64, requires_grad=True) * 0.1
+    ref = F.conv3d(x, w, None, 1, 1)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    gx, gw = torch.autograd.grad(ref, (x, w), dy)
+    xd, wd = x.detach(), w.detach()
+    assert torch.allclose(C3._fwd_blocked(xd, wd, 1), ref, atol=1e-10)
+    assert torch.allclose(C3._dgrad_native(dy, wd, xd, 1), gx, atol=1e-10)
+    assert torch.allclose(C3._dgrad_as_fwd(dy, wd, xd, 1), gx, atol=1e-10)
+    assert torch.allclose(C3._dgrad_as_fwd_blocked(dy, wd, xd, 1), gx, atol=1e-10)
+    assert torch.allclose(C3._wgrad_native(xd, dy, wd, 1), gw, atol=1e-10)
+    assert torch.allclose(C3._wgrad_blocked(xd, dy, wd, 1), gw, atol=1e-10)
+    # cat-free decoder convolution == convolution of the concatenation (unetr_block.py:82-84), values and gradients
+    a = torch.randn(1, 48, 4, 5, 6, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(1, 48, 4, 5, 6, generator=g, dtype=torch.float64, requires_grad=True)
+    y = C3.conv3d_same_cat((a, b), w)
+    ref2 = F.conv3d(torch.cat((a, b), 1), w, None, 1, 1)
+    assert torch.allclose(y, ref2, atol=1e-10)
+    for got, want in zip(torch.autograd.grad(y, (a, b, w), dy), torch.autograd.grad(ref2, (a, b, w), dy)):
+        assert torch.allclose(got, want, atol=1e-10)
+    # bias path of the autograd node (CPU tensors take the plain library call)
+    bias = torch.randn(48, generator=g, dtype=torch.float64, requires_grad=True)
+    yb = C3.conv3d_same(x, w, bias)
+    assert torch.allclose(yb, F.conv3d(x, w, bias, 1, 1), atol=1e-10)
