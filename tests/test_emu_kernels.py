@@ -3,6 +3,8 @@ emulation of the HIP runtime in tests/emu (OS threads for HIP threads, barriers 
 through the same C ABI + host marshalling as the GPU build.  This is test infrastructure (it lets index arithmetic,
 masking, chunk/carry composition and the time-order maps be validated in the GPU-less build container); parity on the
 real device is tests/test_gpu_*.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -322,3 +324,14 @@ def test_conv3d_kernels_fp16_emulated(emu):
     dw = ops_raw.conv3d_k3_wgrad(emu, x, dy, torch.float16)
     ref_dw = _wgrad_reference(x, dy)
     assert dw.dtype == torch.float16 and (dw.float() - ref_dw).abs().max() <= 2e-3 * max(1.0, float(ref_dw.abs().max()))
+
+
+def test_randomised_scan_sweep_emulated(emu):
+    """a fixed-seed slice of tools/emu_random_sweep.py: random shapes / layouts / time orders / dtypes / optional arguments of
+    the scan (forward and all gradients) against the oracle; half of the cases drawn from the regular-shape family."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in (["10", "3"], ["8", "5", "regular"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "emu_random_sweep.py"), *extra], capture_output=True,
+                           text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
