@@ -124,7 +124,7 @@ def _wgrad_reference(x, dy):
     return w.grad
 
 
-@pytest.mark.parametrize("shape", [(1, 48, 48, 3, 4, 32), (2, 96, 48, 2, 3, 64), (1, 48, 48, 1, 20, 128), (1, 48, 48, 2, 5, 16), (1, 48, 48, 2, 3, 40)])
+@pytest.mark.parametrize("shape", [(1, 48, 48, 3, 4, 32), (1, 96, 48, 2, 3, 64), (1, 48, 48, 1, 20, 64), (1, 48, 48, 2, 5, 16), (1, 48, 48, 2, 3, 40), (1, 48, 48, 1, 3, 128)])
 def test_conv3d_k3_wgrad_emulated(emu, shape):
     """MFMA weight-gradient kernel (fragment layout, halo / funnel-shift x taps, z / y border masking, slab reduce)."""
     B, cin, cout, D, H_, W = shape
@@ -331,7 +331,7 @@ def test_randomised_scan_sweep_emulated(emu):
     the scan (forward and all gradients) against the oracle; half of the cases drawn from the regular-shape family."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in (["10", "3"], ["8", "5", "regular"]):
+    for extra in (["6", "3"], ["4", "5", "regular"]):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "emu_random_sweep.py"), *extra], capture_output=True,
                            text=True, timeout=1500)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
