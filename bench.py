@@ -131,7 +131,7 @@ def inference_rate(state, device, size):
 def cpu_baseline():
     """The oracle's selective_scan_ref (fp32, pure PyTorch - a port of the reference's CPU path) on the host cores."""
     from oracle import ref_ops
-    B, D, N, Lq = 2, 96, 16, 8192
+    B, D, N, Lq = 2, 96, 16, 16384          # ~15 s of host work on the GPU box (7 s at L = 8192)
     g = torch.Generator().manual_seed(0)
     u, z = torch.randn(B, D, Lq, generator=g), torch.randn(B, D, Lq, generator=g)
     delta = 0.5 * torch.rand(B, D, Lq, generator=g)
