@@ -145,7 +145,7 @@ def cpu_baseline():
     nbytes = ref_ops.algorithmic_bytes_scan(B, D, Lq, N, 4)
     return {"value": round(nbytes / dt * 1e-9, 4), "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
             "seconds": round(dt, 2),
-            "sample": f"oracle selective_scan_ref forward, fp32, B={B} D={D} N={N} L={Lq} (1/32 of the roofline shape's L; "
+            "sample": f"oracle selective_scan_ref forward, fp32, B={B} D={D} N={N} L={Lq} (1/16 of the roofline shape's L; "
                       "cost is linear in L), same algorithmic-bytes formula"}
 
 
