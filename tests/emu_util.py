@@ -20,9 +20,21 @@ def build_emu(force: bool = False) -> str:
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + EMU_DIR, "-Wno-unused-value", "-DSEGM_PIN_F32(x)=", "-DSEGM_SCHED_FENCE()=", "-DSEGM_EMU=1", "-DSEGM_PIN_F2(x)=", "-DSEGM_WAVE_LDS_SYNC()=hipemu::sync_wave()",
-           os.path.join(EMU_DIR, "emu_entry.cpp"), os.path.join(EMU_DIR, "hip_emu_runtime.cpp"), "-o", OUT]
-    subprocess.run(cmd, check=True, cwd=ROOT)
+    flags = ["-O1", "-std=c++17", "-fPIC", "-pthread", "-I" + EMU_DIR, "-Wno-unused-value", "-DSEGM_PIN_F32(x)=",
+             "-DSEGM_SCHED_FENCE()=", "-DSEGM_EMU=1", "-DSEGM_PIN_F2(x)=", "-DSEGM_WAVE_LDS_SYNC()=hipemu::sync_wave()"]
+    # one object per kernel translation unit (as in the product build), compiled in parallel as plain C++
+    units = sorted(glob.glob(os.path.join(ROOT, "segmamba_amd", "csrc", "*.hip"))) + [os.path.join(EMU_DIR, "hip_emu_runtime.cpp")]
+    objdir = os.path.join(os.path.dirname(OUT), "obj")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        subprocess.run([CLANG, *flags, "-x", "c++", "-c", src, "-o", obj], check=True, cwd=ROOT)
+        return obj
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, units))
+    subprocess.run([CLANG, "-shared", "-pthread", *objs, "-o", OUT], check=True, cwd=ROOT)
     return OUT
 
 
