@@ -219,10 +219,15 @@ size_t segm_conv3d_k3_wgrad_workspace_bytes(int32_t batch, int32_t cin, int32_t 
  * w_packed: (cout, 3, 3, 3, 48) contiguous, i.e. weight.permute(0, 2, 3, 4, 1) - the input channel fastest - zero
  * padded to 48 input channels.
  * bias: (cout) fp32 or NULL.
+ * flags: SEGM_CONV_FWD_ACCUMULATE adds the result to what `y` already holds (the 48-channel blocks of a wider layer
+ * accumulate in place); SEGM_CONV_FWD_CHAIN (cout % 48 == 0 only) selects the kernel whose K parts are pipelined
+ * through LDS instead of reduced at every output row - same results up to the order of fp32 additions.
  * ------------------------------------------------------------------------------------------------ */
+enum segm_conv_fwd_flags { SEGM_CONV_FWD_ACCUMULATE = 1, SEGM_CONV_FWD_CHAIN = 2 };
+
 typedef struct segm_conv3d_fwd_args {
     int32_t batch, cin, cout, depth, height, width;
-    int32_t dtype, reserved;
+    int32_t dtype, flags;
     const void* x;   int64_t x_stride_b, x_stride_c, x_stride_z, x_stride_y;
     void* y;         int64_t y_stride_b, y_stride_c, y_stride_z, y_stride_y;
     const void* w_packed;

@@ -80,15 +80,26 @@ def _hip_fwd_ok(x, w) -> bool:
         ops_raw.conv3d_k3_fwd_supported(x[:, :_BLOCK], w.shape[0])
 
 
-def _fwd_hip(x, w, pad, bias=None):
-    """segm_conv3d_k3_fwd per 48-channel input block (the kernel keeps one block's weights in registers)."""
+def _fwd_hip(x, w, pad, bias=None, chain=False):
+    """segm_conv3d_k3_fwd per 48-channel input block (the kernel keeps one block's weights in registers).  With
+    Cout % 48 == 0 the later blocks accumulate into the first block's output in place; `chain` picks the kernel whose K
+    parts are pipelined (csrc/conv3d_fwd.hip, variant 1)."""
     from . import lib as L, ops_raw
     hip = L.get_lib()
+    inplace = w.shape[0] % _BLOCK == 0
     out = None
     for i, ib in enumerate(_blocks(w.shape[1])):
-        y = ops_raw.conv3d_k3_fwd(hip, x[:, ib], ops_raw.pack_conv3d_weight(w[:, ib], x.dtype), bias if i == 0 else None)
-        out = y if out is None else out + y
+        wp = ops_raw.pack_conv3d_weight(w[:, ib], x.dtype)
+        if inplace:
+            out = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None, out=out, accumulate=i > 0, chain=chain)
+        else:
+            y = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None)
+            out = y if out is None else out + y
     return out
+
+
+def _hip_chain_ok(w) -> bool:
+    return w.shape[0] % _BLOCK == 0 and os.environ.get("SEGM_CONV_FWD_CHAIN", "1") != "0"
 
 
 def _fwd_blocked(x, w, pad):
@@ -120,8 +131,8 @@ def _dgrad_as_fwd_blocked(dy, w, x, pad):
     return _fwd_blocked(dy, _flipT(w), pad)
 
 
-def _dgrad_hip(dy, w, x, pad):
-    return _fwd_hip(dy, _flipT(w), pad)
+def _dgrad_hip(dy, w, x, pad, chain=False):
+    return _fwd_hip(dy, _flipT(w), pad, None, chain)
 
 
 def _wgrad_native(x, dy, w, pad):
@@ -163,7 +174,8 @@ class _ConvSame(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         hip = _hip_fwd_ok(x, w)
-        key = ("fwd", tuple(x.shape), tuple(w.shape), x.dtype, hip)
+        chain = hip and _hip_chain_ok(w)
+        key = ("fwd", tuple(x.shape), tuple(w.shape), x.dtype, hip, chain)
 
         def with_bias(y):
             return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
@@ -173,6 +185,8 @@ class _ConvSame(torch.autograd.Function):
             cands.append(lambda: with_bias(_fwd_blocked(x, w, pad)))
         if hip:
             cands.append(lambda: _fwd_hip(x, w, pad, bias))        # bias fused into the kernel's epilogue
+        if chain:
+            cands.append(lambda: _fwd_hip(x, w, pad, bias, True))
         return _pick(key, cands)
 
     @staticmethod
@@ -189,7 +203,10 @@ class _ConvSame(torch.autograd.Function):
             hip = _hip_fwd_ok(dy, w.transpose(0, 1))
             if hip:
                 cands.append(lambda: _dgrad_hip(dy, w, x, pad))
-            dx = _pick(("dgrad", tuple(x.shape), tuple(w.shape), x.dtype, hip), cands)
+            chain = hip and _hip_chain_ok(w.transpose(0, 1))
+            if chain:
+                cands.append(lambda: _dgrad_hip(dy, w, x, pad, True))
+            dx = _pick(("dgrad", tuple(x.shape), tuple(w.shape), x.dtype, hip, chain), cands)
         if ctx.needs_input_grad[1]:
             cands = [lambda: _wgrad_native(x, dy, w, pad)]
             if blockable:

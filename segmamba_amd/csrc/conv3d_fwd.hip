@@ -59,6 +59,25 @@ struct ConvFwdDev {
     int32_t nxb, ysplit, rows_per_part;
 };
 
+// four consecutive outputs of one lane: convert and store, optionally on top of what y holds (a later 48-channel block
+// of a wider layer)
+template <typename T, bool ACC>
+__device__ __forceinline__ void store4(T* dst, const float (&v)[4]) {
+    T o[4];
+    if (ACC) {
+        u32x2 old = *reinterpret_cast<const u32x2*>(dst);
+        memcpy(o, &old, 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(v[q] + to_f32(o[q]));
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(v[q]);
+    }
+    u32x2 pk;
+    memcpy(&pk, o, 8);
+    *reinterpret_cast<u32x2*>(dst) = pk;
+}
+
 template <typename T, int NCO>
 __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P) {
     typedef typename Mfma16<T>::v8 frag8;
@@ -192,15 +211,10 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             v[q] = acc[t][q] + red[rb][xt][t][q][lane] + red[rb][4 + xt][t][q][lane] + bias[t];
-                        T o[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(v[q]);
-                        u32x2 pk;
-                        memcpy(&pk, o, 8);
                         const int co = cob * kFwCo + t * 16 + i16;
                         T* dst = reinterpret_cast<T*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
                                       (int64_t)z * P.y_sz + (int64_t)y * P.y_sy + xg;
-                        *reinterpret_cast<u32x2*>(dst) = pk;
+                        store4<T, false>(dst, v);
                     }
                 }
             }
@@ -221,7 +235,7 @@ constexpr int kF48Threads = kF48Waves * 64;
 constexpr int kF48Chunks = 11;                    // chunks per K part (parts 1..3 use 10; the last chunk of all is half empty)
 constexpr int kF48K = 27 * kFwCi;                 // 1296
 
-template <typename T>
+template <typename T, bool ACC>
 __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwdDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     __shared__ __attribute__((aligned(16))) T xs[3][4][kFwSlot];
@@ -368,22 +382,221 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
                     if (xg >= P.W) continue;
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
-                        T o[4];
+                        float v[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            o[q] = from_f32<T>(acc[t][u][q] + red[xp][t][u][q][lane] + red[2 + xp][t][u][q][lane] +
-                                               red[4 + xp][t][u][q][lane] + bias[t]);
-                        u32x2 pk;
-                        memcpy(&pk, o, 8);
+                            v[q] = acc[t][u][q] + red[xp][t][u][q][lane] + red[2 + xp][t][u][q][lane] +
+                                   red[4 + xp][t][u][q][lane] + bias[t];
                         const int co = cob * 48 + t * 16 + i16;
                         T* dst = reinterpret_cast<T*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
                                       (int64_t)z * P.y_sz + (int64_t)y * P.y_sy + xg;
-                        *reinterpret_cast<u32x2*>(dst) = pk;
+                        store4<T, ACC>(dst, v);
                     }
                 }
             }
             __syncthreads();                              // the partial sums are consumed: the buffer may be rewritten
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 48 output channels per workgroup, K parts chained in time ("variant 1").
+// The kernel above adds its four K parts through LDS once per output row: six waves write, two waves read, sum,
+// convert and store while the other six wait at the barrier, and with 255 VGPRs per wave at two waves per SIMD there
+// is room for one A fragment pair in flight, so every chunk's MFMAs start with an exposed LDS read.  Here the same
+// four K parts form a pipeline instead:
+//   * 4 waves (one per SIMD, up to 512 registers each), wave p = K part p for all four x tiles and three co tiles:
+//     33 stationary weight fragments, 12 accumulator tiles, and the A fragments of a whole chunk (4) read ahead;
+//   * at step s part p works on output row s - p: it starts from the partial sums part p - 1 left for that row one step
+//     earlier (double-buffered LDS hand-off, float4 per lane and tile), adds its own chunks and either hands the
+//     tiles on or - part 3 - adds the bias, converts and stores.  All waves do the same amount of MFMA work between
+//     two barriers, one barrier per step, three drain steps per work item;
+//   * the skew makes each tap plane's ring run at its own row offset (the K parts are in (kz, ky, kx, ci) order:
+//     plane 0 is read by parts 0 - 1, plane 1 by parts 1 - 2, plane 2 by parts 2 - 3): during step s the incoming rows
+//     are s + 2 (plane 0), s (plane 1) and s - 1 (plane 2); four slots per plane as before.
+// LDS: 88.7 KB ring + 2 x 36.9 KB hand-off = 162 432 B of the 163 840 B a workgroup may declare.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kFcWaves = 4;
+constexpr int kFcThreads = kFcWaves * 64;
+constexpr int kFcTasks = (kFwTasks + kFcThreads - 1) / kFcThreads;     // copy tasks per thread: 3
+
+template <typename T, bool ACC>
+__global__ void __launch_bounds__(kFcThreads) conv3d_k3_fwd48_chain_kernel(ConvFwdDev P) {
+    typedef typename Mfma16<T>::v8 frag8;
+    __shared__ __attribute__((aligned(16))) T xs[3][4][kFwSlot];
+    __shared__ __attribute__((aligned(16))) f32x4 hand[2][3][12][64];        // [buffer][link p -> p + 1][co tile * 4 + x tile][lane]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int part = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int cob = blockIdx.y;                           // block of 48 output channels
+    int item = blockIdx.x;
+    const int ypart = item % P.ysplit;  item /= P.ysplit;
+    const int xb = item % P.nxb;        item /= P.nxb;
+    const int z = item % P.D, b = item / P.D;
+    const int y0 = ypart * P.rows_per_part;
+    const int y1 = (y0 + P.rows_per_part < P.H) ? y0 + P.rows_per_part : P.H;
+    const int x0 = xb * kFwXB;
+    const int c_begin = part == 0 ? 0 : 11 + 10 * (part - 1);     // first chunk of this K part
+    const int c_count = part == 0 ? 11 : 10;
+
+    // ---- stationary weights and the matching A fragment offsets (x tile 0) ---------------------------------------------
+    frag8 wf[3][kF48Chunks];
+    int32_t aoff[kF48Chunks];                             // LDS element offset without the row slot; ky in bits 28..29
+#pragma unroll
+    for (int c = 0; c < kF48Chunks; ++c) {
+        const int k = 32 * (c_begin + c) + 8 * g;
+        const bool live = c < c_count && k < kF48K;
+        const int kk = live ? k : 0;
+        const int tap = kk / kFwCi, ci0 = kk - tap * kFwCi;
+        const int tz = tap / 9, ty = (tap - tz * 9) / 3, tx = tap - tz * 9 - ty * 3;
+        aoff[c] = (tz * 4 * kFwSlot + (i16 + tx) * kFwCP + ci0) | (ty << 28);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int co = cob * 48 + t * 16 + i16;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(P.wp) + (int64_t)co * kF48K + kk);
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            wf[t][c] = __builtin_bit_cast(frag8, live ? w : zero);
+        }
+    }
+    float bias[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bias[t] = P.bias ? P.bias[cob * 48 + t * 16 + i16] : 0.f;
+
+    // ---- copy plan: 720 tasks (plane, granule, ci pair) over 256 threads: three per thread ---------------------------------
+    int tpl[kFcTasks], tcp[kFcTasks], tp0[kFcTasks], trow[kFcTasks];
+    bool has_task[kFcTasks], t_keep[kFcTasks], t_c0[kFcTasks], t_c1[kFcTasks];
+    const T* tsrc[kFcTasks];
+    int64_t tc1[kFcTasks];
+#pragma unroll
+    for (int q = 0; q < kFcTasks; ++q) {
+        const int task = tid + q * kFcThreads;
+        has_task[q] = task < kFwTasks;
+        const int tt = has_task[q] ? task : 0;
+        tpl[q] = tt / (24 * kFwGran);
+        const int trem = tt - tpl[q] * (24 * kFwGran);
+        const int tgr = trem / 24;
+        tcp[q] = trem - tgr * 24;
+        const int txg = x0 - 8 + 8 * tgr;                 // first x of the granule
+        const bool inside = txg >= 0 && txg < P.W;
+        const int tzz = z + tpl[q] - 1;
+        const bool plane = tzz >= 0 && tzz < P.D;
+        t_keep[q] = inside && plane;
+        t_c0[q] = 2 * tcp[q] < P.cin;                     // channels at or beyond cin (a narrow first layer) are zero
+        t_c1[q] = 2 * tcp[q] + 1 < P.cin;
+        tsrc[q] = reinterpret_cast<const T*>(P.x) + (int64_t)b * P.x_sb + (int64_t)(plane ? tzz : z) * P.x_sz +
+                  (int64_t)(t_c0[q] ? 2 * tcp[q] : 0) * P.x_sc + (inside ? txg : 0);
+        tc1[q] = t_c1[q] ? P.x_sc : 0;
+        tp0[q] = 8 * tgr - 7;
+        trow[q] = tpl[q] == 0 ? 2 : (tpl[q] == 1 ? 0 : -1);      // incoming row of this plane during step s: s + trow
+    }
+    // rows are fetched / parked at (base + shift[plane]): the prologue uses the same row for all planes (shift 0)
+    auto fetch = [&](u32x4 (&r)[kFcTasks][2], int base, bool skewed) {
+#pragma unroll
+        for (int q = 0; q < kFcTasks; ++q) {
+            const int yy = base + (skewed ? trow[q] : 0);
+            const bool ok = yy >= 0 && yy < P.H;
+            const int64_t ro = (int64_t)(ok ? yy : 0) * P.x_sy;
+            r[q][0] = *reinterpret_cast<const u32x4*>(tsrc[q] + ro);
+            r[q][1] = *reinterpret_cast<const u32x4*>(tsrc[q] + ro + tc1[q]);
+        }
+    };
+    auto park = [&](const u32x4 (&r)[kFcTasks][2], int base, bool skewed) {
+#pragma unroll
+        for (int q = 0; q < kFcTasks; ++q) {
+            if (!has_task[q]) continue;
+            const int yy = base + (skewed ? trow[q] : 0);
+            const bool keep = yy >= 0 && yy < P.H && t_keep[q];
+            T* row = &xs[tpl[q]][(yy + 8) & 3][0];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int p = tp0[q] + e;
+                if (p < 0 || p >= kFwXP) continue;
+                const uint32_t a = r[q][0][e >> 1], c = r[q][1][e >> 1];
+                const uint32_t lo = t_c0[q] ? ((e & 1) ? (a >> 16) : (a & 0xffffu)) : 0u;
+                const uint32_t hi = t_c1[q] ? ((e & 1) ? (c & 0xffff0000u) : (c << 16)) : 0u;
+                *reinterpret_cast<uint32_t*>(row + p * kFwCP + 2 * tcp[q]) = keep ? (lo | hi) : 0u;
+            }
+        }
+    };
+
+    if (y1 <= y0) return;
+    {   // prologue: rows y0 - 1, y0, y0 + 1 of every plane (planes 1 and 2 re-park theirs on schedule; same slot, same data)
+        u32x4 r[kFcTasks][2];
+#pragma unroll
+        for (int d = -1; d <= 1; ++d) {
+            fetch(r, y0 + d, false);
+            park(r, y0 + d, false);
+        }
+    }
+    __syncthreads();
+    for (int s = y0; s < y1 + 3; ++s) {
+        const int row = s - part;                         // this part's output row
+        const bool active = row >= y0 && row < y1;
+        // the partial sums of the previous K part for this row, then the first chunk's A fragments: issued before the
+        // global fetches so that their latency is covered by the address arithmetic
+        f32x4 acc[3][4];
+        frag8 a[2][4];
+        const T* pl = &xs[0][0][0];
+        auto load_a = [&](frag8 (&dst)[4], int c) {
+            const int slot = (row + (aoff[c] >> 28) + 7) & 3;              // input row = row + ky - 1
+            const T* ap = pl + slot * kFwSlot + (aoff[c] & 0x0fffffff);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dst[u] = *reinterpret_cast<const frag8*>(ap + u * 16 * kFwCP);
+        };
+        if (active) {
+            if (part == 0) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[t][u] = hand[(s + 1) & 1][part - 1][t * 4 + u][lane];
+            }
+            load_a(a[0], 0);
+        }
+        u32x4 r[kFcTasks][2];
+        fetch(r, s, true);                                // in flight during this step's MFMAs
+        SEGM_SCHED_FENCE();
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < kF48Chunks; ++c) {
+                if (c + 1 < kF48Chunks) load_a(a[(c + 1) & 1], c + 1);     // one chunk (12 MFMAs) ahead of its use
+                SEGM_SCHED_FENCE();
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[t][u] = Mfma16<T>::run(a[c & 1][u], wf[t][c], acc[t][u]);
+                SEGM_SCHED_FENCE();
+            }
+            if (part < 3) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) hand[s & 1][part][t * 4 + u][lane] = acc[t][u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int xg = x0 + u * 16 + 4 * g;   // this lane's 4 output positions
+                    if (xg >= P.W) continue;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = acc[t][u][q] + bias[t];
+                        const int co = cob * 48 + t * 16 + i16;
+                        T* dst = reinterpret_cast<T*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
+                                      (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + xg;
+                        store4<T, ACC>(dst, v);
+                    }
+                }
+            }
+        }
+        SEGM_SCHED_FENCE();
+        park(r, s, true);
+        __syncthreads();                                  // incoming rows and the hand-off tiles are in LDS
     }
 }
 
@@ -400,6 +613,18 @@ static FwPlan fwd_plan(int batch, int cout, int d, int h, int w) {
     return p;
 }
 
+template <bool CHAIN>
+static void launch48(const ConvFwdDev& P, dim3 grid, bool f16, bool acc, hipStream_t stream) {
+#define SEGM_L48(T, A)                                                                                          \
+    do {                                                                                                        \
+        if (CHAIN) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, A>), grid, dim3(kFcThreads), 0, stream, P); \
+        else hipLaunchKernelGGL((conv3d_k3_fwd48_kernel<T, A>), grid, dim3(kF48Threads), 0, stream, P);         \
+    } while (0)
+    if (f16) { if (acc) SEGM_L48(f16_t, true); else SEGM_L48(f16_t, false); }
+    else { if (acc) SEGM_L48(bf16_t, true); else SEGM_L48(bf16_t, false); }
+#undef SEGM_L48
+}
+
 }  // namespace segm
 
 using namespace segm;
@@ -411,6 +636,8 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     if (a->cin < 1 || a->cin > kFwCi || a->cout <= 0 || a->cout % 16 != 0) return SEGM_E_SHAPE;
     if (a->width % 8 != 0) return SEGM_E_SHAPE;
     if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
+    if (a->flags & ~(SEGM_CONV_FWD_ACCUMULATE | SEGM_CONV_FWD_CHAIN)) return SEGM_E_SHAPE;
+    if ((a->flags & SEGM_CONV_FWD_CHAIN) && a->cout % 48 != 0) return SEGM_E_SHAPE;
     const int64_t st[8] = {a->x_stride_b, a->x_stride_c, a->x_stride_z, a->x_stride_y,
                            a->y_stride_b, a->y_stride_c, a->y_stride_z, a->y_stride_y};
     for (int64_t s : st)
@@ -428,12 +655,16 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part;
     hipStream_t stream = (hipStream_t)a->stream;
     const bool f16 = a->dtype == SEGM_F16;
-    if (a->cout % 48 == 0 && !getenv("SEGM_CONV_FWD_KZ_SPLIT")) {      // the env switch forces the 32 + 16 kernels (A/B timing)
-        const dim3 grid(pl.nitems, a->cout / 48);
-        if (f16) hipLaunchKernelGGL((conv3d_k3_fwd48_kernel<f16_t>), grid, dim3(kF48Threads), 0, stream, P);
-        else hipLaunchKernelGGL((conv3d_k3_fwd48_kernel<bf16_t>), grid, dim3(kF48Threads), 0, stream, P);
+    const bool acc = (a->flags & SEGM_CONV_FWD_ACCUMULATE) != 0;
+    if (a->flags & SEGM_CONV_FWD_CHAIN) {
+        launch48<true>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
         return (int)hipGetLastError();
     }
+    if (a->cout % 48 == 0 && (acc || !getenv("SEGM_CONV_FWD_KZ_SPLIT"))) {     // the env switch forces the 32 + 16 kernels (A/B timing)
+        launch48<false>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
+        return (int)hipGetLastError();
+    }
+    if (acc) return SEGM_E_SHAPE;                         // in-place accumulation is a feature of the 48-channel kernels
     const int full = a->cout / kFwCo;                     // blocks with two co tiles; cout % 32 == 16 leaves one with a single tile
     P.cob0 = 0;
     if (full > 0) {

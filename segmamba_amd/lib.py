@@ -94,7 +94,7 @@ class Conv3dWgradArgs(C.Structure):
 class Conv3dFwdArgs(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("depth", C.c_int32), ("height", C.c_int32),
-        ("width", C.c_int32), ("dtype", C.c_int32), ("reserved", C.c_int32),
+        ("width", C.c_int32), ("dtype", C.c_int32), ("flags", C.c_int32),
         ("x", C.c_void_p), ("x_stride_b", C.c_int64), ("x_stride_c", C.c_int64), ("x_stride_z", C.c_int64),
         ("x_stride_y", C.c_int64),
         ("y", C.c_void_p), ("y_stride_b", C.c_int64), ("y_stride_c", C.c_int64), ("y_stride_z", C.c_int64),

@@ -281,21 +281,37 @@ def conv3d_k3_fwd_supported(x: torch.Tensor, cout: int) -> bool:
     return x.stride(4) == 1 and not any(x.stride(i) % 8 for i in range(4)) and x.data_ptr() % 16 == 0
 
 
-def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y (B, Cout, D, H, W) bf16 = conv3d(x, w, bias, stride 1, padding 1); x (B, 48, D, H, W) bf16, w_packed from
-    pack_conv3d_weight()."""
+CONV_FWD_ACCUMULATE, CONV_FWD_CHAIN = 1, 2            # segm_conv_fwd_flags
+
+
+def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None, accumulate: bool = False, chain: bool = False) -> torch.Tensor:
+    """y (B, Cout, D, H, W) = conv3d(x, w, bias, stride 1, padding 1); x (B, <= 48, D, H, W) bf16 / fp16, w_packed from
+    pack_conv3d_weight().  `out` + `accumulate`: add to an existing result (the next 48-channel block of a wider
+    layer; Cout % 48 == 0).  `chain`: the pipelined-K-parts kernel (Cout % 48 == 0)."""
     cout = w_packed.shape[0]
     if not conv3d_k3_fwd_supported(x, cout):
         raise RuntimeError("conv3d_k3_fwd: unsupported shape / dtype / layout")
     if tuple(w_packed.shape[1:]) != (3, 3, 3, 48) or w_packed.dtype != x.dtype or not w_packed.is_contiguous():
         raise RuntimeError("conv3d_k3_fwd: w_packed must be a contiguous (Cout, 3, 3, 3, 48) tensor of x's dtype")
+    if (accumulate or chain) and cout % 48:
+        raise RuntimeError("conv3d_k3_fwd: accumulate / chain need Cout % 48 == 0")
     B, _, D, H, W = x.shape
-    y = torch.empty(B, cout, D, H, W, dtype=x.dtype, device=x.device)
+    if out is None:
+        if accumulate:
+            raise RuntimeError("conv3d_k3_fwd: accumulate needs `out`")
+        y = torch.empty(B, cout, D, H, W, dtype=x.dtype, device=x.device)
+    else:
+        y = out
+        if tuple(y.shape) != (B, cout, D, H, W) or y.dtype != x.dtype or y.device != x.device or y.stride(4) != 1 or \
+                any(y.stride(i) % 8 for i in range(4)) or y.data_ptr() % 16:
+            raise RuntimeError("conv3d_k3_fwd: `out` must be a (B, Cout, D, H, W) tensor of x's dtype, W contiguous, 16-byte rows")
     if bias is not None:
         bias = bias.float().contiguous()
     a = L.Conv3dFwdArgs()
     a.batch, a.cin, a.cout, a.depth, a.height, a.width = B, x.shape[1], cout, D, H, W
     a.dtype = L.dtype_code(x)
+    a.flags = (CONV_FWD_ACCUMULATE if accumulate else 0) | (CONV_FWD_CHAIN if chain else 0)
     a.x, a.y, a.w_packed = x.data_ptr(), y.data_ptr(), w_packed.data_ptr()
     a.x_stride_b, a.x_stride_c, a.x_stride_z, a.x_stride_y = x.stride()[:4]
     a.y_stride_b, a.y_stride_c, a.y_stride_z, a.y_stride_y = y.stride()[:4]

@@ -250,7 +250,7 @@ def test_scan_rejects_views_beyond_32bit_offsets(emu):
     assert emu.dll.segm_selective_scan_fwd(a) == -2
 
 
-@pytest.mark.parametrize("shape", [(1, 48, 2, 3, 16), (1, 32, 3, 5, 64), (2, 16, 2, 4, 72), (1, 48, 1, 20, 8), (1, 96, 2, 5, 72)])
+@pytest.mark.parametrize("shape", [(1, 48, 2, 3, 16), (1, 32, 3, 5, 64), (2, 16, 2, 4, 72), (1, 48, 1, 20, 8), (1, 96, 2, 3, 72)])
 def test_conv3d_k3_fwd_emulated(emu, shape):
     """forward 3x3x3 convolution: transposed LDS staging, stationary weight fragments, kz reduction, zero padding."""
     B, cout, D, H_, W = shape
@@ -264,6 +264,33 @@ def test_conv3d_k3_fwd_emulated(emu, shape):
     assert (y.float() - ref).abs().max() <= 1e-2 * max(1.0, float(ref.abs().max()))
     y0 = ops_raw.conv3d_k3_fwd(emu, x, ops_raw.pack_conv3d_weight(w))
     assert (y0.float() - (ref - bias.view(1, -1, 1, 1, 1))).abs().max() <= 1e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(1, 48, 2, 2, 16), (1, 48, 1, 16, 8), (1, 96, 1, 3, 72), (2, 48, 1, 2, 8)])
+def test_conv3d_k3_fwd_chained_k_parts_emulated(emu, shape):
+    """the pipelined variant (SEGM_CONV_FWD_CHAIN): K parts skewed in time, per-plane ring offsets, double-buffered
+    hand-off, drain steps, y split; on the first shape also in-place accumulation of a second 48-channel input block
+    (SEGM_CONV_FWD_ACCUMULATE) with both 48-channel kernels."""
+    B, cout, D, H_, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(B, 96, D, H_, W, generator=g).bfloat16()
+    w = (0.1 * torch.randn(cout, 96, 3, 3, 3, generator=g)).bfloat16()
+    bias = torch.randn(cout, generator=g)
+    ref0 = torch.nn.functional.conv3d(x[:, :48].float(), w[:, :48].float(), bias, 1, 1)
+    tol = 1e-2 * max(1.0, float(ref0.abs().max()))
+    y = ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:, :48]), bias, chain=True)
+    assert (y.float() - ref0).abs().max() <= tol
+    if shape != (1, 48, 2, 2, 16):
+        return
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), bias, 1, 1)
+    w1 = ops_raw.pack_conv3d_weight(w[:, 48:])
+    y2 = ops_raw.conv3d_k3_fwd(emu, x[:, 48:], w1, None, out=y, accumulate=True, chain=True)
+    assert y2 is y and (y.float() - ref).abs().max() <= 2 * tol
+    y3 = ref0.bfloat16()
+    ops_raw.conv3d_k3_fwd(emu, x[:, 48:], w1, None, out=y3, accumulate=True)                 # the reduce-per-row kernel
+    assert (y3.float() - ref).abs().max() <= 2 * tol
+    with pytest.raises(RuntimeError):
+        ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:32, :48]), None, chain=True)      # Cout % 48 != 0
 
 
 def test_conv3d_k3_dgrad_as_forward_emulated(emu):

@@ -401,6 +401,30 @@ def test_conv3d_k3_fwd_matches_fp32_conv(hip, shape):
     assert (y.float() - ref).abs().max() <= 2.0 ** -7 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(1, 48, 8, 8, 32), (2, 48, 16, 16, 128), (1, 96, 6, 16, 16), (2, 48, 2, 20, 8), (1, 48, 3, 40, 72)])
+def test_conv3d_k3_fwd_chained_k_parts(hip, shape):
+    """SEGM_CONV_FWD_CHAIN (K parts pipelined through LDS, 160 KB of LDS per workgroup) and SEGM_CONV_FWD_ACCUMULATE
+    (a second 48-channel input block added in place) against fp32 conv3d and against the default kernel."""
+    B, cout, D, H_, W = shape
+    g = torch.Generator(device=DEV).manual_seed(sum(shape) + 5)
+    x = torch.randn(B, 96, D, H_, W, device=DEV, generator=g).bfloat16()
+    w = (0.05 * torch.randn(cout, 96, 3, 3, 3, device=DEV, generator=g)).bfloat16()
+    bias = torch.randn(cout, device=DEV, generator=g)
+    w0, w1 = ops_raw.pack_conv3d_weight(w[:, :48]), ops_raw.pack_conv3d_weight(w[:, 48:])
+    ref0 = torch.nn.functional.conv3d(x[:, :48].float(), w[:, :48].float(), bias, 1, 1)
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), bias, 1, 1)
+    tol = 2.0 ** -7 * max(1.0, float(ref.abs().max()))
+    y = ops_raw.conv3d_k3_fwd(hip, x[:, :48], w0, bias, chain=True)
+    assert (y.float() - ref0).abs().max() <= tol
+    assert torch.equal(ops_raw.conv3d_k3_fwd(hip, x[:, :48], w0, bias, chain=True), y)          # deterministic
+    yd = ops_raw.conv3d_k3_fwd(hip, x[:, :48], w0, bias)
+    assert (y.float() - yd.float()).abs().max() <= tol                                           # same sums, other order
+    for chain in (True, False):
+        acc = yd.clone()
+        ops_raw.conv3d_k3_fwd(hip, x[:, 48:], w1, None, out=acc, accumulate=True, chain=chain)
+        assert (acc.float() - ref).abs().max() <= 2 * tol
+
+
 def test_conv3d_same_autograd_with_library_kernels(hip, monkeypatch):
     """the dispatcher with the library's fwd / dgrad / wgrad kernels forced in == torch's conv3d autograd (fp32)."""
     from segmamba_amd import conv3d as C3
