@@ -335,6 +335,61 @@ int segm_layernorm_tokens_fwd(const segm_layernorm_args* args);
 int segm_layernorm_tokens_bwd(const segm_layernorm_args* args);
 size_t segm_layernorm_tokens_workspace_bytes(int32_t batch, int32_t channels, int64_t spatial);
 
+/* ------------------------------------------------------------------------------------------------
+ * Gradient clipping + SGD (momentum, Nesterov, weight decay) over a list of fp32 tensors, in two passes.
+ * Replaces `torch.nn.utils.clip_grad_norm_(model.parameters(), 12)` followed by `optimizer.step()` of
+ * `torch.optim.SGD(lr=1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)` (reference light_training/trainer.py:461-470,
+ * 3_train.py:51-52):
+ *
+ *   norm = ||all gradients||_2 ;  c = min(1, max_norm / (norm + 1e-6))        (max_norm <= 0: c = 1)
+ *   g' = c g + weight_decay p ;  m = momentum m + g' ;  p -= lr (nesterov ? g' + momentum m : m)
+ *
+ * params / grads / momenta / numel are HOST arrays of `ntensors` entries (device pointers; numel may be 0).  Momentum
+ * buffers start at zero (torch's first step, buf = g', is then the same formula).  The gradients are read, not
+ * rescaled in place.  workspace: segm_sgd_clip_step_workspace_bytes(); on return (stream order) its first two floats hold
+ * {c, norm}.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_sgd_args {
+    int32_t ntensors, nesterov;
+    float* const* params;
+    const float* const* grads;
+    float* const* momenta;
+    const int64_t* numel;
+    float lr, momentum, weight_decay, max_norm;
+    void* workspace;
+    size_t workspace_bytes;
+    void* stream;
+} segm_sgd_args;
+
+int segm_sgd_clip_step(const segm_sgd_args* args);
+size_t segm_sgd_clip_step_workspace_bytes(int32_t ntensors, const int64_t* numel);
+
+/* ------------------------------------------------------------------------------------------------
+ * Cross entropy over the class axis of (batch, classes, spatial) logits, forward and gradient in one pass.
+ * Replaces `nn.CrossEntropyLoss()(pred, label)` and its backward (reference 3_train.py:48,57-66).
+ *
+ *   loss_v = logsumexp_c(x[b, :, s]) - x[b, label, s] ;  dlogits[b, c, s] = softmax_c(x)[c] - [c == label]
+ *   voxels whose label == ignore_index contribute neither loss nor gradient.
+ *
+ * logits, dlogits: (batch, classes, spatial) contiguous, one dtype (fp32 / fp16 / bf16; arithmetic in fp32); labels
+ * (batch, spatial) int64; classes <= 16.  loss_partial / count_partial: fp32 arrays of segm_cross_entropy_partials()
+ * entries (per-workgroup sums of the losses and of the number of counted voxels; the caller adds them and divides -
+ * `mean` reduction - and scales dlogits by 1 / count).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_cross_entropy_args {
+    int32_t batch, classes, dtype, reserved;
+    int64_t spatial, ignore_index;
+    const void* logits;
+    const int64_t* labels;
+    void* dlogits;
+    float* loss_partial;
+    float* count_partial;
+    void* stream;
+} segm_cross_entropy_args;
+
+int segm_cross_entropy(const segm_cross_entropy_args* args);
+int32_t segm_cross_entropy_partials(int32_t batch, int64_t spatial);
+
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);
 const char* segm_status_string(int status);

@@ -132,6 +132,24 @@ class LayerNormArgs(C.Structure):
     ]
 
 
+class SgdArgs(C.Structure):
+    _fields_ = [
+        ("ntensors", C.c_int32), ("nesterov", C.c_int32),
+        ("params", C.c_void_p), ("grads", C.c_void_p), ("momenta", C.c_void_p), ("numel", C.c_void_p),
+        ("lr", C.c_float), ("momentum", C.c_float), ("weight_decay", C.c_float), ("max_norm", C.c_float),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+    ]
+
+
+class CrossEntropyArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("classes", C.c_int32), ("dtype", C.c_int32), ("reserved", C.c_int32),
+        ("spatial", C.c_int64), ("ignore_index", C.c_int64),
+        ("logits", C.c_void_p), ("labels", C.c_void_p), ("dlogits", C.c_void_p), ("loss_partial", C.c_void_p),
+        ("count_partial", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
 class TransposeArgs(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("dtype", C.c_int32),
@@ -146,6 +164,7 @@ EXPORTS = (
     "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes", "segm_conv3d_k3_fwd",
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add",
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
+    "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -183,6 +202,10 @@ class SegmLib:
         sig("segm_layernorm_tokens_fwd", [C.POINTER(LayerNormArgs)], C.c_int)
         sig("segm_layernorm_tokens_bwd", [C.POINTER(LayerNormArgs)], C.c_int)
         sig("segm_layernorm_tokens_workspace_bytes", [C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
+        sig("segm_sgd_clip_step", [C.POINTER(SgdArgs)], C.c_int)
+        sig("segm_sgd_clip_step_workspace_bytes", [C.c_int32, C.c_void_p], C.c_size_t)
+        sig("segm_cross_entropy", [C.POINTER(CrossEntropyArgs)], C.c_int)
+        sig("segm_cross_entropy_partials", [C.c_int32, C.c_int64], C.c_int32)
         sig("segm_abi_version", [], C.c_int)
         sig("segm_status_string", [C.c_int], C.c_char_p)
 

@@ -13,6 +13,7 @@ causal_conv1d.cpp:136-170): shape / dtype / stride problems raise RuntimeError.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional
 
 import torch
@@ -445,3 +446,62 @@ def layernorm_tokens_bwd(lib: L.SegmLib, x, dy, mean, rstd, gamma):
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
     lib.check(lib.dll.segm_layernorm_tokens_bwd(a), "layernorm_tokens_bwd")
     return dx, dgamma, dbeta
+
+
+# ---------------------------------------------------------------------------------------------------------
+# training-step glue: gradient clipping + SGD over a tensor list, cross entropy with its gradient
+# ---------------------------------------------------------------------------------------------------------
+def sgd_clip_step(lib: L.SegmLib, params, grads, momenta, lr: float, momentum: float, weight_decay: float,
+                  nesterov: bool, max_norm: float) -> torch.Tensor:
+    """In place: clip_grad_norm_(max_norm) + SGD step over lists of contiguous fp32 tensors (params / momenta updated,
+    grads only read).  Returns the 4-float workspace head {clip coefficient, gradient norm, -, -} (device tensor)."""
+    n = len(params)
+    if not (len(grads) == len(momenta) == n):
+        raise RuntimeError("sgd_clip_step: params, grads and momenta must have the same length")
+    if n == 0:
+        return torch.ones(4)
+    for p, g, m in zip(params, grads, momenta):
+        if not (p.dtype == g.dtype == m.dtype == torch.float32) or not (p.is_contiguous() and g.is_contiguous() and m.is_contiguous()) \
+                or not (p.numel() == g.numel() == m.numel()) or not (p.device == g.device == m.device == params[0].device):
+            raise RuntimeError("sgd_clip_step: tensors must be contiguous fp32, same size per entry, one device")
+    ptr_t, i64_t = C.c_void_p * n, C.c_int64 * n
+    pp, gp, mp = ptr_t(*[p.data_ptr() for p in params]), ptr_t(*[g.data_ptr() for g in grads]), ptr_t(*[m.data_ptr() for m in momenta])
+    ne = i64_t(*[p.numel() for p in params])
+    ws_bytes = lib.dll.segm_sgd_clip_step_workspace_bytes(n, C.cast(ne, C.c_void_p))
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=params[0].device)
+    a = L.SgdArgs()
+    a.ntensors, a.nesterov = n, int(bool(nesterov))
+    a.params, a.grads, a.momenta, a.numel = C.cast(pp, C.c_void_p), C.cast(gp, C.c_void_p), C.cast(mp, C.c_void_p), C.cast(ne, C.c_void_p)
+    a.lr, a.momentum, a.weight_decay, a.max_norm = lr, momentum, weight_decay, max_norm
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
+    a.stream = L.stream_handle(params[0])
+    lib.check(lib.dll.segm_sgd_clip_step(a), "sgd_clip_step")
+    return ws[:4]
+
+
+def cross_entropy_supported(logits: torch.Tensor, labels: torch.Tensor) -> bool:
+    return logits.dim() >= 2 and 1 <= logits.shape[1] <= 16 and labels.dtype == torch.int64 and \
+        logits.dtype in (torch.float32, torch.float16, torch.bfloat16) and \
+        tuple(labels.shape) == (logits.shape[0],) + tuple(logits.shape[2:]) and logits.numel() > 0
+
+
+def cross_entropy(lib: L.SegmLib, logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100):
+    """-> (loss_sum fp32 scalar, count fp32 scalar, dlogits): sum over counted voxels of the cross entropy, the number of
+    counted voxels, and d(loss_sum)/d(logits) (logits' dtype and shape)."""
+    if not cross_entropy_supported(logits, labels):
+        raise RuntimeError("cross_entropy: logits (B, C <= 16, *spatial) fp32 / fp16 / bf16 and int64 labels (B, *spatial)")
+    logits, labels = logits.contiguous(), labels.contiguous()
+    B, Cc = logits.shape[:2]
+    S = logits.numel() // (B * Cc)
+    nparts = lib.dll.segm_cross_entropy_partials(B, S)
+    parts = torch.empty(2, nparts, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    a = L.CrossEntropyArgs()
+    a.batch, a.classes, a.dtype = B, Cc, L.dtype_code(logits)
+    a.spatial, a.ignore_index = S, ignore_index
+    a.logits, a.labels, a.dlogits = logits.data_ptr(), labels.data_ptr(), dlogits.data_ptr()
+    a.loss_partial, a.count_partial = parts[0].data_ptr(), parts[1].data_ptr()
+    a.stream = L.stream_handle(logits)
+    lib.check(lib.dll.segm_cross_entropy(a), "cross_entropy")
+    tot = parts.sum(1)
+    return tot[0], tot[1], dlogits

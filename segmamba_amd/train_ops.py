@@ -1,0 +1,116 @@
+"""Device-side training-step glue: fused cross entropy and clip + SGD, on the HIP library.
+
+  * `cross_entropy(logits, labels)` == `nn.CrossEntropyLoss()(logits, labels)` (reference 3_train.py:48,62; mean
+    reduction, ignore_index -100) as one kernel that also produces d(loss)/d(logits);
+  * `FusedClipSGD` == `torch.nn.utils.clip_grad_norm_(params, max_norm)` + `torch.optim.SGD(..., nesterov=True).step()`
+    (reference light_training/trainer.py:461-470, 3_train.py:51-52) in two passes over the parameters.  State layout
+    (`momentum_buffer` per parameter) and `param_groups` are those of torch.optim.SGD, so checkpoints interchange.
+
+CPU tensors (the unit tests of the host logic) take the ATen path; CUDA tensors always call the library.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        from . import lib as L, ops_raw
+        loss_sum, count, dlogits = ops_raw.cross_entropy(L.get_lib(), logits, labels, ignore_index)
+        ctx.save_for_backward(dlogits, count)
+        return loss_sum / count
+
+    @staticmethod
+    def backward(ctx, grad):
+        dlogits, count = ctx.saved_tensors
+        return dlogits * (grad / count).to(dlogits.dtype), None, None
+
+
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """Mean cross entropy over the class axis (dim 1); fp32 scalar.  Under autocast the logits are used in the dtype they
+    arrive in (the kernel computes in fp32 either way), which skips ATen's fp32 copy of the logits."""
+    if not logits.is_cuda:
+        return F.cross_entropy(logits.float(), labels, ignore_index=ignore_index)
+    from . import ops_raw
+    if not ops_raw.cross_entropy_supported(logits, labels):
+        raise RuntimeError("cross_entropy: expected logits (B, C <= 16, *spatial) fp32 / fp16 / bf16 and int64 labels (B, *spatial)")
+    with torch.autocast("cuda", enabled=False):
+        return _CrossEntropy.apply(logits, labels, ignore_index)
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """Drop-in for the `nn.CrossEntropyLoss()` of the reference trainer (3_train.py:48)."""
+
+    def __init__(self, ignore_index: int = -100):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, logits, labels):
+        return cross_entropy(logits, labels, self.ignore_index)
+
+
+class FusedClipSGD(torch.optim.Optimizer):
+    """SGD(momentum, nesterov, weight_decay, dampening 0) whose `step()` also applies `clip_grad_norm_(max_norm)` over ALL
+    its parameters first (max_norm None / <= 0: no clipping).  The gradients themselves are left unscaled."""
+
+    def __init__(self, params: Iterable, lr: float = 1e-2, momentum: float = 0.0, weight_decay: float = 0.0,
+                 nesterov: bool = False, max_norm: Optional[float] = None):
+        if nesterov and momentum <= 0:
+            raise ValueError("Nesterov momentum requires a momentum")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov,
+                                      dampening=0, maximize=False, foreach=None, differentiable=False, fused=None))
+        self.max_norm = max_norm
+        self.last_clip = None                 # device tensor {clip coefficient, gradient norm, -, -} of the last step
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        groups = []
+        for gr in self.param_groups:
+            ps = [p for p in gr["params"] if p.grad is not None]
+            for p in ps:
+                st = self.state[p]
+                if "momentum_buffer" not in st or st["momentum_buffer"] is None:
+                    st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            groups.append((gr, ps))
+        allp = [p for _, ps in groups for p in ps]
+        if not allp:
+            return loss
+        max_norm = float(self.max_norm) if self.max_norm else 0.0
+        if allp[0].is_cuda:
+            self._step_hip(groups, allp, max_norm)
+        else:
+            self._step_aten(groups, allp, max_norm)
+        return loss
+
+    def _step_hip(self, groups, allp, max_norm):
+        from . import lib as L, ops_raw
+        hip = L.get_lib()
+        same = len({(g["lr"], g["momentum"], g["weight_decay"], g["nesterov"]) for g, _ in groups}) == 1
+        if not same and max_norm > 0:
+            raise RuntimeError("FusedClipSGD: clipping needs one set of hyper-parameters over all groups")
+        for gr, ps in ([(groups[0][0], allp)] if same else groups):
+            if not ps:
+                continue
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            self.last_clip = ops_raw.sgd_clip_step(hip, [p.data for p in ps], grads, [self.state[p]["momentum_buffer"] for p in ps],
+                                                   gr["lr"], gr["momentum"], gr["weight_decay"], gr["nesterov"], max_norm)
+
+    def _step_aten(self, groups, allp, max_norm):
+        coef = 1.0
+        if max_norm > 0:
+            norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.grad) for p in allp]))
+            coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        for gr, ps in groups:
+            for p in ps:
+                g = p.grad * coef + gr["weight_decay"] * p
+                m = self.state[p]["momentum_buffer"]
+                m.mul_(gr["momentum"]).add_(g)
+                p.sub_(gr["lr"] * (g + gr["momentum"] * m if gr["nesterov"] else m))

@@ -72,9 +72,18 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
             model, device_ids=[local_rank] if device.type == "cuda" else None,
             find_unused_parameters=os.environ.get("SEGM_DDP_FIND_UNUSED", "0") == "1",
             gradient_as_bucket_view=True, bucket_cap_mb=64)
-    opt = torch.optim.SGD(model.parameters(), lr=1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    fused = device.type == "cuda" and os.environ.get("SEGM_FUSED_TRAIN_OPS", "1") != "0"
+    if fused:
+        # clip_grad_norm_(12) + SGD step as two passes of the library's multi-tensor kernels, cross entropy with its
+        # gradient as one (csrc/trainstep.hip); SEGM_FUSED_TRAIN_OPS=0 restores the ATen calls of the reference loop
+        from .train_ops import CrossEntropyLoss, FusedClipSGD
+        opt = FusedClipSGD(model.parameters(), lr=1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True, max_norm=12.0)
+        loss_fn = CrossEntropyLoss()
+    else:
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+        loss_fn = nn.CrossEntropyLoss()
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: (1 - min(s, max_steps - 1) / max_steps) ** 0.9)
-    return TrainingState(model=model, optimizer=opt, scheduler=sched, loss_fn=nn.CrossEntropyLoss())
+    return TrainingState(model=model, optimizer=opt, scheduler=sched, loss_fn=loss_fn)
 
 
 def train_step(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
@@ -84,8 +93,9 @@ def train_step(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> t
         pred = st.model(image)
         loss = st.loss_fn(pred, label)                             # 3_train.py:62
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(st.model.parameters(), st.clip)  # trainer.py:464
-    st.optimizer.step()
+    if getattr(st.optimizer, "max_norm", None) is None:
+        torch.nn.utils.clip_grad_norm_(st.model.parameters(), st.clip)  # trainer.py:464
+    st.optimizer.step()                                            # FusedClipSGD clips inside step()
     st.scheduler.step()
     st.step += 1
     return loss.detach()

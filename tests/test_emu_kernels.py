@@ -362,3 +362,57 @@ def test_randomised_scan_sweep_emulated(emu):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "emu_random_sweep.py"), *extra], capture_output=True,
                            text=True, timeout=1500)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def _torch_clip_sgd_reference(params, grads, steps, lr, mu, wd, nesterov, max_norm):
+    ps = [torch.nn.Parameter(p.clone()) for p in params]
+    opt = torch.optim.SGD(ps, lr=lr, momentum=mu, weight_decay=wd, nesterov=nesterov)
+    norms = []
+    for s in range(steps):
+        for p, g in zip(ps, grads[s]):
+            p.grad = g.clone()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(ps, max_norm)) if max_norm > 0 else None)
+        opt.step()
+    return [p.detach() for p in ps], norms
+
+
+@pytest.mark.parametrize("max_norm,nesterov", [(0.5, True), (0.0, False)])
+def test_sgd_clip_step_emulated(emu, max_norm, nesterov):
+    """two-pass clip + SGD over a tensor list == clip_grad_norm_ + torch.optim.SGD: several launches' worth of tensors
+    (> 96), sizes around the 16384-element workgroup chunk, an unaligned view, an empty tensor; two steps (momentum)."""
+    g = torch.Generator().manual_seed(3)
+    sizes = [1, 5, 16384, 16385, 40000, 0, 7] + [3 + i for i in range(100)]
+    flat = torch.randn(sum(sizes) + 1, generator=g)
+    params, off = [], 1                                    # views at odd offsets: not 16-byte aligned
+    for n in sizes:
+        params.append(flat[off:off + n].clone() if n % 2 else flat[off:off + n])
+        off += n
+    params = [p.contiguous() for p in params]
+    grads = [[torch.randn(n, generator=g) for n in sizes] for _ in range(2)]
+    lr, mu, wd = 0.05, 0.9, 1e-2
+    want, norms = _torch_clip_sgd_reference(params, grads, 2, lr, mu, wd, nesterov, max_norm)
+    mine = [p.clone() for p in params]
+    mom = [torch.zeros_like(p) for p in mine]
+    for s in range(2):
+        head = ops_raw.sgd_clip_step(emu, mine, grads[s], mom, lr, mu, wd, nesterov, max_norm)
+        if max_norm > 0:
+            assert abs(float(head[1]) - norms[s]) <= 1e-5 * norms[s]
+            assert abs(float(head[0]) - min(1.0, max_norm / (norms[s] + 1e-6))) <= 1e-5
+    for a, b in zip(mine, want):
+        assert a.shape == b.shape and (a.numel() == 0 or (a - b).abs().max() <= 1e-5 * max(1.0, float(b.abs().max())))
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 4, 3, 5, 7), torch.float32), ((1, 13, 300), torch.bfloat16), ((3, 2, 10), torch.float16)])
+def test_cross_entropy_emulated(emu, shape, dtype):
+    g = torch.Generator().manual_seed(sum(shape))
+    logits = (3 * torch.randn(shape, generator=g)).to(dtype)
+    labels = torch.randint(0, shape[1], (shape[0],) + shape[2:], generator=g)
+    labels.view(-1)[::7] = -100                           # ignored voxels
+    ref_in = logits.double().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(ref_in, labels, reduction="sum")
+    ref.backward()
+    loss_sum, count, dlogits = ops_raw.cross_entropy(emu, logits, labels)
+    assert float(count) == float((labels != -100).sum())
+    assert abs(float(loss_sum) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
+    tol = 1e-6 if dtype == torch.float32 else (1e-3 if dtype == torch.float16 else 8e-3)
+    assert dlogits.dtype == dtype and (dlogits.double() - ref_in.grad).abs().max() <= tol

@@ -515,3 +515,48 @@ def test_conv3d_kernels_fp16(hip):
     assert (dx.float() - gx).abs().max() <= 2.0 ** -10 * max(1.0, float(gx.abs().max()))
     dw = ops_raw.conv3d_k3_wgrad(hip, x, dy, torch.float32)
     assert (dw - gw).abs().max() <= 1e-4 * float(gw.abs().max())
+
+
+# ---- training-step glue: clip + SGD over a tensor list, cross entropy with its gradient ----------------------------------
+@pytest.mark.parametrize("max_norm", [2.0, 0.0])
+def test_sgd_clip_step_matches_torch(hip, max_norm):
+    g = torch.Generator(device=DEV).manual_seed(11)
+    sizes = [1, 7, 16384, 16385, 1 << 20, 48 * 48 * 27, 768] + [5 + 3 * i for i in range(200)]
+    flat = torch.randn(sum(sizes) + 1, device=DEV, generator=g)
+    params, off = [], 1
+    for n in sizes:                                       # views at odd element offsets: the unaligned (scalar) path too
+        params.append(flat[off:off + n])
+        off += n
+    ref_p = [torch.nn.Parameter(p.clone()) for p in params]
+    opt = torch.optim.SGD(ref_p, lr=1e-2, momentum=0.99, weight_decay=3e-5, nesterov=True)
+    mine = [p.clone() for p in params]
+    mom = [torch.zeros_like(p) for p in mine]
+    for step in range(3):
+        grads = [torch.randn(n, device=DEV, generator=g) for n in sizes]
+        for p, gr in zip(ref_p, grads):
+            p.grad = gr.clone()
+        norm = torch.nn.utils.clip_grad_norm_(ref_p, max_norm) if max_norm > 0 else None
+        opt.step()
+        head = ops_raw.sgd_clip_step(hip, mine, grads, mom, 1e-2, 0.99, 3e-5, True, max_norm)
+        if norm is not None:
+            assert abs(float(head[1]) - float(norm)) <= 1e-5 * float(norm)
+    for a, b in zip(mine, ref_p):
+        assert (a - b.detach()).abs().max() <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 4, 32, 32, 32), torch.bfloat16), ((1, 13, 1000), torch.float32), ((3, 2, 77), torch.float16)])
+def test_cross_entropy_matches_torch(hip, shape, dtype):
+    from segmamba_amd import train_ops
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    logits = (3 * torch.randn(shape, device=DEV, generator=g)).to(dtype).requires_grad_()
+    labels = torch.randint(0, shape[1], (shape[0],) + shape[2:], device=DEV, generator=g)
+    labels.view(-1)[::11] = -100
+    ref_in = logits.detach().double().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(ref_in, labels)
+    ref.backward()
+    loss = train_ops.cross_entropy(logits, labels)
+    loss.backward()
+    assert loss.dtype == torch.float32 and abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    scale = float(ref_in.grad.abs().max())
+    tol = 1e-6 if dtype == torch.float32 else (2e-3 if dtype == torch.float16 else 1e-2)
+    assert (logits.grad.double() - ref_in.grad).abs().max() <= tol * scale

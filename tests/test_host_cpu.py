@@ -187,3 +187,30 @@ def test_conv_dispatcher_routings_are_the_same_convolution():
     bias = torch.randn(48, generator=g, dtype=torch.float64, requires_grad=True)
     yb = C3.conv3d_same(x, w, bias)
     assert torch.allclose(yb, F.conv3d(x, w, bias, 1, 1), atol=1e-10)
+
+
+def test_fused_clip_sgd_host_logic_matches_torch_sgd():
+    """FusedClipSGD (ATen path on CPU tensors): clip_grad_norm_ + SGD(nesterov) semantics, torch-compatible state."""
+    from segmamba_amd.train_ops import FusedClipSGD, cross_entropy
+    torch.manual_seed(0)
+    net_a = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    net_b = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    net_b.load_state_dict(net_a.state_dict())
+    kw = dict(lr=0.1, momentum=0.9, weight_decay=1e-2, nesterov=True)
+    opt_a = torch.optim.SGD(net_a.parameters(), **kw)
+    opt_b = FusedClipSGD(net_b.parameters(), max_norm=0.3, **kw)
+    for step in range(4):
+        x, y = torch.randn(8, 6), torch.randint(0, 3, (8,))
+        for net, opt in ((net_a, opt_a), (net_b, opt_b)):
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.cross_entropy(net(x), y) if net is net_a else cross_entropy(net(x), y)
+            loss.backward()
+            if net is net_a:
+                torch.nn.utils.clip_grad_norm_(net.parameters(), 0.3)
+            opt.step()
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert (pa - pb).abs().max() <= 1e-6
+    opt_c = torch.optim.SGD(net_a.parameters(), **kw)
+    opt_c.load_state_dict(opt_b.state_dict())              # checkpoints interchange with torch.optim.SGD
+    bufs = [opt_c.state[p]["momentum_buffer"] for p in net_a.parameters()]
+    assert all((b - opt_b.state[p]["momentum_buffer"]).abs().max() == 0 for b, p in zip(bufs, net_b.parameters()))
