@@ -99,7 +99,9 @@ def _fwd_hip(x, w, pad, bias=None, chain=False):
 
 
 def _hip_chain_ok(w) -> bool:
-    return w.shape[0] % _BLOCK == 0 and os.environ.get("SEGM_CONV_FWD_CHAIN", "1") != "0"
+    """The chained-K-parts kernel as an extra autotune candidate: opt-in (SEGM_CONV_FWD_CHAIN=1) - on MI355X it lost to
+    the default kernel on every SegMamba shape (profiles/r01_conv_chain_ab.log)."""
+    return w.shape[0] % _BLOCK == 0 and os.environ.get("SEGM_CONV_FWD_CHAIN", "0") == "1"
 
 
 def _fwd_blocked(x, w, pad):

@@ -223,6 +223,87 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Row staging of the two 48-channel kernels below.
+// The copy plan of the kernel above spends ~220 VALU instructions per task on per-element selects, bounds tests and 64-bit
+// address arithmetic; with two tasks per thread that was 5 500 cycles of every SIMD per output row against 2 100 cycles
+// of MFMA (static count of the loop body; profiles/r01_conv_chain_ab.log).  Here one "slot" moves one X row
+// (b, plane, row) into one ring slot with four waves, and everything that depends on the row or the plane is
+// wave-uniform (SGPR): waves 0 - 2 of the slot own the 192 granule tasks (8 granules x 24 channel pairs: two 16-byte loads
+// at [uniform row base + per-lane 32-bit offset], eight v_perm_b32 + ds_write_b32 with immediate offsets), wave 3 owns
+// the 48 halo tasks (columns x0 - 1 and x0 + 64: two 2-byte loads, one ds_write_b32).  Per lane: two global byte
+// offsets, one LDS byte offset, three flags.
+// ------------------------------------------------------------------------------------------------------
+struct CopyLane {
+    uint32_t goff0, goff1;      // byte offsets of channels 2 tcp and 2 tcp + 1 from the row base
+    uint32_t loff;              // byte offset of the lane's first ring position inside a ring row
+    bool has, live0, live1;     // lane owns a task; its x range is inside the volume and the channel exists
+};
+struct RowRegs { u32x4 a, c; };  // 8 x values of channels 2 tcp / 2 tcp + 1 (halo wave: one value each, in a[0] / c[0])
+
+template <typename T>
+__device__ __forceinline__ CopyLane copy_lane(const ConvFwdDev& P, int wslot, int lane, int x0) {
+    CopyLane L;
+    int tcp, x, pos;
+    if (wslot < 3) {
+        const int j = wslot * 64 + lane, gr = j / 24;
+        tcp = j - gr * 24;
+        x = x0 + 8 * gr;
+        pos = 1 + 8 * gr;
+        L.has = true;
+    } else {
+        const int side = lane >= 24 ? 1 : 0;
+        tcp = lane - side * 24;
+        L.has = lane < 48;
+        if (!L.has) tcp = 0;
+        x = side ? x0 + kFwXB : x0 - 1;
+        pos = side ? kFwXB + 1 : 0;
+    }
+    const bool inside = L.has && x >= 0 && x < P.W;
+    L.live0 = inside && 2 * tcp < P.cin;                  // channels at or beyond cin (a narrow first layer) are zero
+    L.live1 = inside && 2 * tcp + 1 < P.cin;
+    const int64_t xs = inside ? x : 0;
+    L.goff0 = (uint32_t)(((int64_t)(L.live0 ? 2 * tcp : 0) * P.x_sc + xs) * (int64_t)sizeof(T));
+    L.goff1 = (uint32_t)(((int64_t)(L.live1 ? 2 * tcp + 1 : 0) * P.x_sc + xs) * (int64_t)sizeof(T));
+    L.loff = (uint32_t)((pos * kFwCP + 2 * tcp) * (int)sizeof(T));
+    return L;
+}
+// uniform base of row (b, zz, yy); null when the row lies outside the volume (a zero row)
+template <typename T>
+__device__ __forceinline__ const char* row_base(const ConvFwdDev& P, int b, int zz, int yy) {
+    const bool ok = zz >= 0 && zz < P.D && yy >= 0 && yy < P.H;
+    return ok ? P.x + ((int64_t)b * P.x_sb + (int64_t)zz * P.x_sz + (int64_t)yy * P.x_sy) * (int64_t)sizeof(T) : nullptr;
+}
+template <typename T>
+__device__ __forceinline__ void row_fetch(RowRegs& r, const char* rb, const CopyLane& L, bool halo_wave) {
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    r.a = zero; r.c = zero;
+    if (rb == nullptr) return;                            // uniform
+    if (!halo_wave) {
+        r.a = *reinterpret_cast<const u32x4*>(rb + L.goff0);
+        r.c = *reinterpret_cast<const u32x4*>(rb + L.goff1);
+    } else {
+        r.a[0] = *reinterpret_cast<const uint16_t*>(rb + L.goff0);
+        r.c[0] = *reinterpret_cast<const uint16_t*>(rb + L.goff1);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void row_park(const RowRegs& r, char* ring_row, const CopyLane& L, bool halo_wave) {
+    char* dst = ring_row + L.loff;
+    if (!halo_wave) {
+        u32x4 a = r.a, c = r.c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = L.live0 ? a[i] : 0u; c[i] = L.live1 ? c[i] : 0u; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)                       // {channel 2 tcp, channel 2 tcp + 1} at x position e
+            *reinterpret_cast<uint32_t*>(dst + e * kFwCP * (int)sizeof(T)) =
+                __builtin_amdgcn_perm(c[e >> 1], a[e >> 1], (e & 1) ? 0x07060302u : 0x05040100u);
+    } else if (L.has) {
+        const uint32_t lo = L.live0 ? r.a[0] : 0u, hi = L.live1 ? r.c[0] : 0u;
+        *reinterpret_cast<uint32_t*>(dst) = lo | (hi << 16);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // 48 output channels per workgroup (cout % 48 == 0: every SegMamba layer this kernel family is picked for).
 // With the kz split above, 48 channels are a 32 + 16 pair of workgroups that stage the same X rows twice.  Here the
 // reduction index is cut four ways instead - k in (kz, ky, kx, ci) order, 1296 values = 40.5 MFMA chunks, parts of
@@ -278,72 +359,34 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 #pragma unroll
     for (int t = 0; t < 3; ++t) bias[t] = P.bias ? P.bias[cob * 48 + t * 16 + i16] : 0.f;
 
-    // ---- copy plan: 720 tasks (plane, granule, ci pair) over 512 threads: two per thread ------------------------------------
-    int tpl[2], tcp[2], tp0[2];
-    bool has_task[2], t_keep[2], t_c0[2], t_c1[2];
-    const T* tsrc[2];
-    int64_t tc1[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int task = tid + q * kF48Threads;
-        has_task[q] = task < kFwTasks;
-        const int tt = has_task[q] ? task : 0;
-        tpl[q] = tt / (24 * kFwGran);
-        const int trem = tt - tpl[q] * (24 * kFwGran);
-        const int tgr = trem / 24;
-        tcp[q] = trem - tgr * 24;
-        const int txg = x0 - 8 + 8 * tgr;                 // first x of the granule
-        const bool inside = txg >= 0 && txg < P.W;
-        const int tzz = z + tpl[q] - 1;
-        const bool plane = tzz >= 0 && tzz < P.D;
-        t_keep[q] = inside && plane;
-        t_c0[q] = 2 * tcp[q] < P.cin;                     // channels at or beyond cin (a narrow first layer) are zero
-        t_c1[q] = 2 * tcp[q] + 1 < P.cin;
-        tsrc[q] = reinterpret_cast<const T*>(P.x) + (int64_t)b * P.x_sb + (int64_t)(plane ? tzz : z) * P.x_sz +
-                  (int64_t)(t_c0[q] ? 2 * tcp[q] : 0) * P.x_sc + (inside ? txg : 0);
-        tc1[q] = t_c1[q] ? P.x_sc : 0;
-        tp0[q] = 8 * tgr - 7;
-    }
-    auto fetch = [&](u32x4 (&r)[2][2], int yy) {
-        const bool ok = yy >= 0 && yy < P.H;
-        const int64_t ro = (int64_t)(ok ? yy : 0) * P.x_sy;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            r[q][0] = *reinterpret_cast<const u32x4*>(tsrc[q] + ro);
-            r[q][1] = *reinterpret_cast<const u32x4*>(tsrc[q] + ro + tc1[q]);
-        }
+    // ---- row staging: slot A = plane 0 (waves 0 - 3) and plane 1 (waves 4 - 7), slot B = plane 2 (waves 0 - 3) -----------------
+    const int wslot = wave & 3;
+    const bool halo_wave = wslot == 3, second = wave < 4;
+    const int plane_a = wave >> 2;
+    const CopyLane cl = copy_lane<T>(P, wslot, lane, x0);
+    char* ring = reinterpret_cast<char*>(&xs[0][0][0]);
+    auto fetch = [&](RowRegs (&r)[2], int yy) {
+        row_fetch<T>(r[0], row_base<T>(P, b, z + plane_a - 1, yy), cl, halo_wave);
+        if (second) row_fetch<T>(r[1], row_base<T>(P, b, z + 1, yy), cl, halo_wave);
     };
-    auto park = [&](const u32x4 (&r)[2][2], int yy, int slot) {
-        const bool row_ok = yy >= 0 && yy < P.H;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (!has_task[q]) continue;
-            const bool keep = row_ok && t_keep[q];
-            T* row = &xs[tpl[q]][slot][0];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int p = tp0[q] + e;
-                if (p < 0 || p >= kFwXP) continue;
-                const uint32_t a = r[q][0][e >> 1], c = r[q][1][e >> 1];
-                const uint32_t lo = t_c0[q] ? ((e & 1) ? (a >> 16) : (a & 0xffffu)) : 0u;
-                const uint32_t hi = t_c1[q] ? ((e & 1) ? (c & 0xffff0000u) : (c << 16)) : 0u;
-                *reinterpret_cast<uint32_t*>(row + p * kFwCP + 2 * tcp[q]) = keep ? (lo | hi) : 0u;
-            }
-        }
+    auto park = [&](const RowRegs (&r)[2], int yy) {
+        const int slot = (yy + 4) & 3;
+        row_park<T>(r[0], ring + (plane_a * 4 + slot) * kFwSlot * (int)sizeof(T), cl, halo_wave);
+        if (second) row_park<T>(r[1], ring + (2 * 4 + slot) * kFwSlot * (int)sizeof(T), cl, halo_wave);
     };
 
     if (y1 > y0) {
         {
-            u32x4 r[2][2];
+            RowRegs r[2];
 #pragma unroll
             for (int d = -1; d <= 1; ++d) {
                 fetch(r, y0 + d);
-                park(r, y0 + d, (y0 + d + 4) & 3);
+                park(r, y0 + d);
             }
         }
         __syncthreads();
         for (int y = y0; y < y1; ++y) {
-            u32x4 r[2][2];
+            RowRegs r[2];
             fetch(r, y + 2);                              // in flight during this step's MFMAs
             SEGM_SCHED_FENCE();
             f32x4 acc[3][2];
@@ -373,7 +416,7 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 #pragma unroll
                         for (int q = 0; q < 4; ++q) red[(part - 1) * 2 + xp][t][u][q][lane] = acc[t][u][q];
             }
-            park(r, y + 2, (y + 2) & 3);
+            park(r, y + 2);
             __syncthreads();                              // ring row y + 2 and the partial sums are in LDS
             if (part == 0) {
 #pragma unroll
@@ -418,7 +461,6 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 // ------------------------------------------------------------------------------------------------------
 constexpr int kFcWaves = 4;
 constexpr int kFcThreads = kFcWaves * 64;
-constexpr int kFcTasks = (kFwTasks + kFcThreads - 1) / kFcThreads;     // copy tasks per thread: 3
 
 template <typename T, bool ACC>
 __global__ void __launch_bounds__(kFcThreads) conv3d_k3_fwd48_chain_kernel(ConvFwdDev P) {
@@ -462,70 +504,28 @@ __global__ void __launch_bounds__(kFcThreads) conv3d_k3_fwd48_chain_kernel(ConvF
 #pragma unroll
     for (int t = 0; t < 3; ++t) bias[t] = P.bias ? P.bias[cob * 48 + t * 16 + i16] : 0.f;
 
-    // ---- copy plan: 720 tasks (plane, granule, ci pair) over 256 threads: three per thread ---------------------------------
-    int tpl[kFcTasks], tcp[kFcTasks], tp0[kFcTasks], trow[kFcTasks];
-    bool has_task[kFcTasks], t_keep[kFcTasks], t_c0[kFcTasks], t_c1[kFcTasks];
-    const T* tsrc[kFcTasks];
-    int64_t tc1[kFcTasks];
-#pragma unroll
-    for (int q = 0; q < kFcTasks; ++q) {
-        const int task = tid + q * kFcThreads;
-        has_task[q] = task < kFwTasks;
-        const int tt = has_task[q] ? task : 0;
-        tpl[q] = tt / (24 * kFwGran);
-        const int trem = tt - tpl[q] * (24 * kFwGran);
-        const int tgr = trem / 24;
-        tcp[q] = trem - tgr * 24;
-        const int txg = x0 - 8 + 8 * tgr;                 // first x of the granule
-        const bool inside = txg >= 0 && txg < P.W;
-        const int tzz = z + tpl[q] - 1;
-        const bool plane = tzz >= 0 && tzz < P.D;
-        t_keep[q] = inside && plane;
-        t_c0[q] = 2 * tcp[q] < P.cin;                     // channels at or beyond cin (a narrow first layer) are zero
-        t_c1[q] = 2 * tcp[q] + 1 < P.cin;
-        tsrc[q] = reinterpret_cast<const T*>(P.x) + (int64_t)b * P.x_sb + (int64_t)(plane ? tzz : z) * P.x_sz +
-                  (int64_t)(t_c0[q] ? 2 * tcp[q] : 0) * P.x_sc + (inside ? txg : 0);
-        tc1[q] = t_c1[q] ? P.x_sc : 0;
-        tp0[q] = 8 * tgr - 7;
-        trow[q] = tpl[q] == 0 ? 2 : (tpl[q] == 1 ? 0 : -1);      // incoming row of this plane during step s: s + trow
-    }
-    // rows are fetched / parked at (base + shift[plane]): the prologue uses the same row for all planes (shift 0)
-    auto fetch = [&](u32x4 (&r)[kFcTasks][2], int base, bool skewed) {
-#pragma unroll
-        for (int q = 0; q < kFcTasks; ++q) {
-            const int yy = base + (skewed ? trow[q] : 0);
-            const bool ok = yy >= 0 && yy < P.H;
-            const int64_t ro = (int64_t)(ok ? yy : 0) * P.x_sy;
-            r[q][0] = *reinterpret_cast<const u32x4*>(tsrc[q] + ro);
-            r[q][1] = *reinterpret_cast<const u32x4*>(tsrc[q] + ro + tc1[q]);
-        }
+    // ---- row staging: three slots per step, plane q's incoming row during step s is s + {2, 0, -1}[q] -----------------------
+    const bool halo_wave = part == 3;
+    const CopyLane cl = copy_lane<T>(P, part, lane, x0);
+    char* ring = reinterpret_cast<char*>(&xs[0][0][0]);
+    auto fetch = [&](RowRegs (&r)[3], int r0, int r1, int r2) {
+        row_fetch<T>(r[0], row_base<T>(P, b, z - 1, r0), cl, halo_wave);
+        row_fetch<T>(r[1], row_base<T>(P, b, z, r1), cl, halo_wave);
+        row_fetch<T>(r[2], row_base<T>(P, b, z + 1, r2), cl, halo_wave);
     };
-    auto park = [&](const u32x4 (&r)[kFcTasks][2], int base, bool skewed) {
-#pragma unroll
-        for (int q = 0; q < kFcTasks; ++q) {
-            if (!has_task[q]) continue;
-            const int yy = base + (skewed ? trow[q] : 0);
-            const bool keep = yy >= 0 && yy < P.H && t_keep[q];
-            T* row = &xs[tpl[q]][(yy + 8) & 3][0];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int p = tp0[q] + e;
-                if (p < 0 || p >= kFwXP) continue;
-                const uint32_t a = r[q][0][e >> 1], c = r[q][1][e >> 1];
-                const uint32_t lo = t_c0[q] ? ((e & 1) ? (a >> 16) : (a & 0xffffu)) : 0u;
-                const uint32_t hi = t_c1[q] ? ((e & 1) ? (c & 0xffff0000u) : (c << 16)) : 0u;
-                *reinterpret_cast<uint32_t*>(row + p * kFwCP + 2 * tcp[q]) = keep ? (lo | hi) : 0u;
-            }
-        }
+    auto park = [&](const RowRegs (&r)[3], int r0, int r1, int r2) {
+        row_park<T>(r[0], ring + (0 * 4 + ((r0 + 8) & 3)) * kFwSlot * (int)sizeof(T), cl, halo_wave);
+        row_park<T>(r[1], ring + (1 * 4 + ((r1 + 8) & 3)) * kFwSlot * (int)sizeof(T), cl, halo_wave);
+        row_park<T>(r[2], ring + (2 * 4 + ((r2 + 8) & 3)) * kFwSlot * (int)sizeof(T), cl, halo_wave);
     };
 
     if (y1 <= y0) return;
     {   // prologue: rows y0 - 1, y0, y0 + 1 of every plane (planes 1 and 2 re-park theirs on schedule; same slot, same data)
-        u32x4 r[kFcTasks][2];
+        RowRegs r[3];
 #pragma unroll
         for (int d = -1; d <= 1; ++d) {
-            fetch(r, y0 + d, false);
-            park(r, y0 + d, false);
+            fetch(r, y0 + d, y0 + d, y0 + d);
+            park(r, y0 + d, y0 + d, y0 + d);
         }
     }
     __syncthreads();
@@ -557,8 +557,8 @@ __global__ void __launch_bounds__(kFcThreads) conv3d_k3_fwd48_chain_kernel(ConvF
             }
             load_a(a[0], 0);
         }
-        u32x4 r[kFcTasks][2];
-        fetch(r, s, true);                                // in flight during this step's MFMAs
+        RowRegs r[3];
+        fetch(r, s + 2, s, s - 1);                        // in flight during this step's MFMAs
         SEGM_SCHED_FENCE();
         if (active) {
 #pragma unroll
@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(kFcThreads) conv3d_k3_fwd48_chain_kernel(ConvF
             }
         }
         SEGM_SCHED_FENCE();
-        park(r, s, true);
+        park(r, s + 2, s, s - 1);
         __syncthreads();                                  // incoming rows and the hand-off tiles are in LDS
     }
 }
@@ -656,11 +656,14 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     hipStream_t stream = (hipStream_t)a->stream;
     const bool f16 = a->dtype == SEGM_F16;
     const bool acc = (a->flags & SEGM_CONV_FWD_ACCUMULATE) != 0;
+    // the 48-channel kernels address a row as [uniform base + 32-bit lane offset]: 48 channel strides must fit
+    const bool off32 = ((int64_t)47 * a->x_stride_c + a->width) * 2 < ((int64_t)1 << 32);
+    if ((a->flags & SEGM_CONV_FWD_CHAIN) && !off32) return SEGM_E_SHAPE;
     if (a->flags & SEGM_CONV_FWD_CHAIN) {
         launch48<true>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
         return (int)hipGetLastError();
     }
-    if (a->cout % 48 == 0 && (acc || !getenv("SEGM_CONV_FWD_KZ_SPLIT"))) {     // the env switch forces the 32 + 16 kernels (A/B timing)
+    if (a->cout % 48 == 0 && off32 && (acc || !getenv("SEGM_CONV_FWD_KZ_SPLIT"))) {     // the env switch forces the 32 + 16 kernels (A/B timing)
         launch48<false>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
         return (int)hipGetLastError();
     }

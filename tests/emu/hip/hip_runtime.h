@@ -154,6 +154,14 @@ static inline uint32_t hipemu_alignbyte(uint32_t hi, uint32_t lo, uint32_t n) {
     return (uint32_t)(v >> (8 * (n & 3)));
 }
 #define __builtin_amdgcn_alignbyte hipemu_alignbyte
+// v_perm_b32: result byte i = byte sel[i] of the pool {lo = bytes 0..3, hi = bytes 4..7} (selectors 0..7 only)
+static inline uint32_t hipemu_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+    const uint64_t pool = ((uint64_t)hi << 32) | lo;
+    uint32_t out = 0;
+    for (int i = 0; i < 4; ++i) out |= (uint32_t)((pool >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+    return out;
+}
+#define __builtin_amdgcn_perm hipemu_perm
 typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
 namespace hipemu { extern std::vector<unsigned char>* g_wave_big; }   // 64 lanes x 64 bytes per wave
