@@ -224,14 +224,16 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
 
 // ------------------------------------------------------------------------------------------------------
 // Row staging of the two 48-channel kernels below.
-// The copy plan of the kernel above spends ~220 VALU instructions per task on per-element selects, bounds tests and 64-bit
-// address arithmetic; with two tasks per thread that was 5 500 cycles of every SIMD per output row against 2 100 cycles
-// of MFMA (static count of the loop body; profiles/r01_conv_chain_ab.log).  Here one "slot" moves one X row
-// (b, plane, row) into one ring slot with four waves, and everything that depends on the row or the plane is
-// wave-uniform (SGPR): waves 0 - 2 of the slot own the 192 granule tasks (8 granules x 24 channel pairs: two 16-byte loads
-// at [uniform row base + per-lane 32-bit offset], eight v_perm_b32 + ds_write_b32 with immediate offsets), wave 3 owns
-// the 48 halo tasks (columns x0 - 1 and x0 + 64: two 2-byte loads, one ds_write_b32).  Per lane: two global byte
-// offsets, one LDS byte offset, three flags.
+// The copy plan of the kernel above keeps per-thread task tables (plane, granule, channel pair) and packs each element
+// with shifts, masks and selects: ~850 VALU instructions (86 of them quarter-rate 32 x 32 multiplies) per wave and output
+// row in the 48-channel kernel, against 66 MFMAs.  Here one "slot" moves one X row (b, plane, row) into one ring slot
+// with four waves, and everything that depends on the row or the plane is wave-uniform (SGPR): waves 0 - 2 of the slot
+// own the 192 granule tasks (8 granules x 24 channel pairs: two 16-byte loads at [uniform row base + per-lane 32-bit
+// offset], eight v_perm_b32 + ds_write_b32 with immediate offsets), wave 3 owns the 48 halo tasks (columns x0 - 1 and
+// x0 + 64: two 2-byte loads, one ds_write_b32).  Per lane: two global byte offsets, one LDS byte offset, three flags.
+// The loop body of the 48-channel kernel went from ~1500 to 636 instructions per wave; measured 0.871 -> 0.799 ms at
+// 48 -> 48 @128^3 x 2 (profiles/r01_conv_chain_ab.log) - the kernel is bound by instruction issue and LDS / barrier
+// latency at two waves per SIMD, not by the MFMA pipe (2 100 of ~6 900 cycles per output row).
 // ------------------------------------------------------------------------------------------------------
 struct CopyLane {
     uint32_t goff0, goff1;      // byte offsets of channels 2 tcp and 2 tcp + 1 from the row base
@@ -443,13 +445,15 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 }
 
 // ------------------------------------------------------------------------------------------------------
-// 48 output channels per workgroup, K parts chained in time ("variant 1").
+// 48 output channels per workgroup, K parts chained in time (SEGM_CONV_FWD_CHAIN).  An experiment that LOST on MI355X -
+// 0.94 ms against 0.80 ms at 48 -> 48 @128^3 x 2, slower on every SegMamba shape (profiles/r01_conv_chain_ab.log) - and
+// is therefore opt-in; kept because it is the parity-tested starting point for the next attempt.
 // The kernel above adds its four K parts through LDS once per output row: six waves write, two waves read, sum,
-// convert and store while the other six wait at the barrier, and with 255 VGPRs per wave at two waves per SIMD there
+// convert and store while the other six wait at the barrier, and with ~240 VGPRs per wave at two waves per SIMD there
 // is room for one A fragment pair in flight, so every chunk's MFMAs start with an exposed LDS read.  Here the same
 // four K parts form a pipeline instead:
 //   * 4 waves (one per SIMD, up to 512 registers each), wave p = K part p for all four x tiles and three co tiles:
-//     33 stationary weight fragments, 12 accumulator tiles, and the A fragments of a whole chunk (4) read ahead;
+//     33 stationary weight fragments, 12 accumulator tiles, and the A fragments of the next chunk (4) read ahead;
 //   * at step s part p works on output row s - p: it starts from the partial sums part p - 1 left for that row one step
 //     earlier (double-buffered LDS hand-off, float4 per lane and tile), adds its own chunks and either hands the
 //     tiles on or - part 3 - adds the bias, converts and stores.  All waves do the same amount of MFMA work between
@@ -458,6 +462,9 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 //     plane 0 is read by parts 0 - 1, plane 1 by parts 1 - 2, plane 2 by parts 2 - 3): during step s the incoming rows
 //     are s + 2 (plane 0), s (plane 1) and s - 1 (plane 2); four slots per plane as before.
 // LDS: 88.7 KB ring + 2 x 36.9 KB hand-off = 162 432 B of the 163 840 B a workgroup may declare.
+// Why it lost: with ONE wave per SIMD nothing overlaps that wave's ~680 non-MFMA instructions per step (hand-off, staging,
+// address arithmetic, AGPR moves) with its 132 MFMAs; the step costs ~8 600 cycles against 2 250 of MFMA.  The hand-off
+// pipeline itself (no epilogue phase, one barrier) should go back onto the eight-wave layout.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kFcWaves = 4;
 constexpr int kFcThreads = kFcWaves * 64;
