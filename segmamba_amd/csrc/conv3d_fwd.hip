@@ -466,16 +466,18 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 // address arithmetic, AGPR moves) with its 132 MFMAs; the step costs ~8 600 cycles against 2 250 of MFMA.  The hand-off
 // pipeline itself (no epilogue phase, one barrier) should go back onto the eight-wave layout.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kFcWaves = 4;
-constexpr int kFcThreads = kFcWaves * 64;
-
-template <typename T, bool ACC>
-__global__ void __launch_bounds__(kFcThreads) conv3d_k3_fwd48_chain_kernel(ConvFwdDev P) {
+// XT = x tiles per wave: 4 -> four waves (one per SIMD, A fragments double-buffered), 2 -> eight waves = 4 K parts x 2 x pairs
+// (two per SIMD, the layout of the kernel above with the hand-off pipeline in place of its reduce + epilogue phase).
+template <typename T, bool ACC, int XT>
+__global__ void __launch_bounds__(1024 / XT, XT == 2 ? 2 : 1) conv3d_k3_fwd48_chain_kernel(ConvFwdDev P) {
     typedef typename Mfma16<T>::v8 frag8;
+    constexpr int XP = 4 / XT;                            // waves per K part
+    constexpr int NBUF = 2;                               // A fragment buffers: the next chunk is read ahead of its use
     __shared__ __attribute__((aligned(16))) T xs[3][4][kFwSlot];
-    __shared__ __attribute__((aligned(16))) f32x4 hand[2][3][12][64];        // [buffer][link p -> p + 1][co tile * 4 + x tile][lane]
+    __shared__ __attribute__((aligned(16))) f32x4 hand[2][3][XP][3 * XT][64];     // [buffer][link p -> p + 1][x part][co tile * XT + x tile][lane]
     const int tid = threadIdx.x, lane = tid & 63;
-    const int part = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = wave / XP, xp = wave % XP;
     const int i16 = lane & 15, g = lane >> 4;
     const int cob = blockIdx.y;                           // block of 48 output channels
     int item = blockIdx.x;
@@ -488,7 +490,7 @@ __global__ void __launch_bounds__(kFcThreads) conv3d_k3_fwd48_chain_kernel(ConvF
     const int c_begin = part == 0 ? 0 : 11 + 10 * (part - 1);     // first chunk of this K part
     const int c_count = part == 0 ? 11 : 10;
 
-    // ---- stationary weights and the matching A fragment offsets (x tile 0) ---------------------------------------------
+    // ---- stationary weights and the matching A fragment offsets (the wave's first x tile) ------------------------------------
     frag8 wf[3][kF48Chunks];
     int32_t aoff[kF48Chunks];                             // LDS element offset without the row slot; ky in bits 28..29
 #pragma unroll
@@ -498,7 +500,7 @@ __global__ void __launch_bounds__(kFcThreads) conv3d_k3_fwd48_chain_kernel(ConvF
         const int kk = live ? k : 0;
         const int tap = kk / kFwCi, ci0 = kk - tap * kFwCi;
         const int tz = tap / 9, ty = (tap - tz * 9) / 3, tx = tap - tz * 9 - ty * 3;
-        aoff[c] = (tz * 4 * kFwSlot + (i16 + tx) * kFwCP + ci0) | (ty << 28);
+        aoff[c] = (tz * 4 * kFwSlot + (xp * XT * 16 + i16 + tx) * kFwCP + ci0) | (ty << 28);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int co = cob * 48 + t * 16 + i16;
@@ -511,28 +513,44 @@ __global__ void __launch_bounds__(kFcThreads) conv3d_k3_fwd48_chain_kernel(ConvF
 #pragma unroll
     for (int t = 0; t < 3; ++t) bias[t] = P.bias ? P.bias[cob * 48 + t * 16 + i16] : 0.f;
 
-    // ---- row staging: three slots per step, plane q's incoming row during step s is s + {2, 0, -1}[q] -----------------------
-    const bool halo_wave = part == 3;
-    const CopyLane cl = copy_lane<T>(P, part, lane, x0);
+    // ---- row staging: plane q's incoming row during step s is s + {2, 0, -1}[q].  Four waves: three slots each; eight
+    //      waves: slot A = plane 0 (waves 0 - 3) / plane 1 (waves 4 - 7), slot B = plane 2 (waves 0 - 3) -----------------------------
+    constexpr int NS = XT == 4 ? 3 : 2;                   // staging slots per wave
+    const int wslot = wave & 3;
+    const bool halo_wave = wslot == 3;
+    const CopyLane cl = copy_lane<T>(P, wslot, lane, x0);
     char* ring = reinterpret_cast<char*>(&xs[0][0][0]);
-    auto fetch = [&](RowRegs (&r)[3], int r0, int r1, int r2) {
-        row_fetch<T>(r[0], row_base<T>(P, b, z - 1, r0), cl, halo_wave);
-        row_fetch<T>(r[1], row_base<T>(P, b, z, r1), cl, halo_wave);
-        row_fetch<T>(r[2], row_base<T>(P, b, z + 1, r2), cl, halo_wave);
+    int spl[NS], soff[NS];                                // plane and row offset of this wave's slots (-1: no slot)
+    if (XT == 4) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) spl[q] = q;
+    } else {
+        spl[0] = wave >> 2;
+        spl[NS - 1] = wave < 4 ? 2 : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) soff[q] = spl[q] == 0 ? 2 : (spl[q] == 1 ? 0 : -1);
+    auto fetch = [&](RowRegs (&r)[NS], int base, bool skewed) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+            if (spl[q] >= 0) row_fetch<T>(r[q], row_base<T>(P, b, z + spl[q] - 1, base + (skewed ? soff[q] : 0)), cl, halo_wave);
     };
-    auto park = [&](const RowRegs (&r)[3], int r0, int r1, int r2) {
-        row_park<T>(r[0], ring + (0 * 4 + ((r0 + 8) & 3)) * kFwSlot * (int)sizeof(T), cl, halo_wave);
-        row_park<T>(r[1], ring + (1 * 4 + ((r1 + 8) & 3)) * kFwSlot * (int)sizeof(T), cl, halo_wave);
-        row_park<T>(r[2], ring + (2 * 4 + ((r2 + 8) & 3)) * kFwSlot * (int)sizeof(T), cl, halo_wave);
+    auto park = [&](const RowRegs (&r)[NS], int base, bool skewed) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+            if (spl[q] >= 0) {
+                const int yy = base + (skewed ? soff[q] : 0);
+                row_park<T>(r[q], ring + (spl[q] * 4 + ((yy + 8) & 3)) * kFwSlot * (int)sizeof(T), cl, halo_wave);
+            }
     };
 
     if (y1 <= y0) return;
     {   // prologue: rows y0 - 1, y0, y0 + 1 of every plane (planes 1 and 2 re-park theirs on schedule; same slot, same data)
-        RowRegs r[3];
+        RowRegs r[NS];
 #pragma unroll
         for (int d = -1; d <= 1; ++d) {
-            fetch(r, y0 + d, y0 + d, y0 + d);
-            park(r, y0 + d, y0 + d, y0 + d);
+            fetch(r, y0 + d, false);
+            park(r, y0 + d, false);
         }
     }
     __syncthreads();
@@ -541,52 +559,56 @@ __global__ void __launch_bounds__(kFcThreads) conv3d_k3_fwd48_chain_kernel(ConvF
         const bool active = row >= y0 && row < y1;
         // the partial sums of the previous K part for this row, then the first chunk's A fragments: issued before the
         // global fetches so that their latency is covered by the address arithmetic
-        f32x4 acc[3][4];
-        frag8 a[2][4];
+        f32x4 acc[3][XT];
+        frag8 a[NBUF][XT];
         const T* pl = &xs[0][0][0];
-        auto load_a = [&](frag8 (&dst)[4], int c) {
+        auto load_a = [&](frag8 (&dst)[XT], int c) {
             const int slot = (row + (aoff[c] >> 28) + 7) & 3;              // input row = row + ky - 1
             const T* ap = pl + slot * kFwSlot + (aoff[c] & 0x0fffffff);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dst[u] = *reinterpret_cast<const frag8*>(ap + u * 16 * kFwCP);
+            for (int u = 0; u < XT; ++u) dst[u] = *reinterpret_cast<const frag8*>(ap + u * 16 * kFwCP);
         };
         if (active) {
             if (part == 0) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int u = 0; u < XT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
             } else {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[t][u] = hand[(s + 1) & 1][part - 1][t * 4 + u][lane];
+                    for (int u = 0; u < XT; ++u) acc[t][u] = hand[(s + 1) & 1][part - 1][xp][t * XT + u][lane];
             }
-            load_a(a[0], 0);
+            if (NBUF == 2) load_a(a[0], 0);
         }
-        RowRegs r[3];
-        fetch(r, s + 2, s, s - 1);                        // in flight during this step's MFMAs
+        RowRegs r[NS];
+        fetch(r, s, true);                                // in flight during this step's MFMAs
         SEGM_SCHED_FENCE();
         if (active) {
 #pragma unroll
             for (int c = 0; c < kF48Chunks; ++c) {
-                if (c + 1 < kF48Chunks) load_a(a[(c + 1) & 1], c + 1);     // one chunk (12 MFMAs) ahead of its use
-                SEGM_SCHED_FENCE();
+                if (NBUF == 2) {
+                    if (c + 1 < kF48Chunks) load_a(a[(c + 1) & 1], c + 1);     // one chunk (12 MFMAs) ahead of its use
+                    SEGM_SCHED_FENCE();
+                } else {
+                    load_a(a[0], c);
+                }
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[t][u] = Mfma16<T>::run(a[c & 1][u], wf[t][c], acc[t][u]);
-                SEGM_SCHED_FENCE();
+                    for (int u = 0; u < XT; ++u) acc[t][u] = Mfma16<T>::run(a[NBUF == 2 ? (c & 1) : 0][u], wf[t][c], acc[t][u]);
+                if (NBUF == 2) SEGM_SCHED_FENCE();
             }
             if (part < 3) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) hand[s & 1][part][t * 4 + u][lane] = acc[t][u];
+                    for (int u = 0; u < XT; ++u) hand[s & 1][part][xp][t * XT + u][lane] = acc[t][u];
             } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int xg = x0 + u * 16 + 4 * g;   // this lane's 4 output positions
+                for (int u = 0; u < XT; ++u) {
+                    const int xg = x0 + (xp * XT + u) * 16 + 4 * g;        // this lane's 4 output positions
                     if (xg >= P.W) continue;
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
@@ -602,7 +624,7 @@ __global__ void __launch_bounds__(kFcThreads) conv3d_k3_fwd48_chain_kernel(ConvF
             }
         }
         SEGM_SCHED_FENCE();
-        park(r, s + 2, s, s - 1);
+        park(r, s, true);
         __syncthreads();                                  // incoming rows and the hand-off tiles are in LDS
     }
 }
@@ -620,11 +642,11 @@ static FwPlan fwd_plan(int batch, int cout, int d, int h, int w) {
     return p;
 }
 
-template <bool CHAIN>
+template <int CHAIN>                                    // 0: reduce-per-row kernel, 2 / 4: chained kernel with that many x tiles per wave
 static void launch48(const ConvFwdDev& P, dim3 grid, bool f16, bool acc, hipStream_t stream) {
 #define SEGM_L48(T, A)                                                                                          \
     do {                                                                                                        \
-        if (CHAIN) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, A>), grid, dim3(kFcThreads), 0, stream, P); \
+        if (CHAIN) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, A, CHAIN ? CHAIN : 2>), grid, dim3(1024 / (CHAIN ? CHAIN : 2)), 0, stream, P); \
         else hipLaunchKernelGGL((conv3d_k3_fwd48_kernel<T, A>), grid, dim3(kF48Threads), 0, stream, P);         \
     } while (0)
     if (f16) { if (acc) SEGM_L48(f16_t, true); else SEGM_L48(f16_t, false); }
@@ -667,11 +689,13 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     const bool off32 = ((int64_t)47 * a->x_stride_c + a->width) * 2 < ((int64_t)1 << 32);
     if ((a->flags & SEGM_CONV_FWD_CHAIN) && !off32) return SEGM_E_SHAPE;
     if (a->flags & SEGM_CONV_FWD_CHAIN) {
-        launch48<true>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
+        const char* w4 = getenv("SEGM_CONV_CHAIN_WAVES");             // "4": the one-wave-per-SIMD variant (A/B timing)
+        if (w4 && w4[0] == '4') launch48<4>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
+        else launch48<2>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
         return (int)hipGetLastError();
     }
     if (a->cout % 48 == 0 && off32 && (acc || !getenv("SEGM_CONV_FWD_KZ_SPLIT"))) {     // the env switch forces the 32 + 16 kernels (A/B timing)
-        launch48<false>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
+        launch48<0>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
         return (int)hipGetLastError();
     }
     if (acc) return SEGM_E_SHAPE;                         // in-place accumulation is a feature of the 48-channel kernels

@@ -1,5 +1,5 @@
 """A/B timings on the GPU box: conv3d forward default vs chained-K-parts kernel, fused clip+SGD / cross entropy vs ATen."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 import torch
 from segmamba_amd import lib as L, ops_raw, train_ops
@@ -38,6 +38,9 @@ for (B, cin, cout, S) in [(2, 48, 48, 128), (2, 48, 48, 64), (2, 96, 96, 64), (2
         print(f"conv fwd {cin}->{cout} @{S}^3 B={B}: default {t0:.3f} ms ({fl / t0 / 1e9:.0f} TF/s)  chain {t1:.3f} ms ({fl / t1 / 1e9:.0f} TF/s)  maxdiff {d:.3g}", flush=True)
     except RuntimeError as e:
         print(f"conv fwd {cin}->{cout} @{S}^3: {e}", flush=True)
+
+if os.environ.get("SEGM_TIME_CONV_ONLY"):
+    sys.exit(0)
 
 # optimizer: 67 M fp32 parameters in ~290 tensors (SegMamba-like size mix)
 sizes = [768 * 768 * 27] * 2 + [384 * 384 * 27] * 6 + [192 * 192 * 27] * 8 + [96 * 96 * 27] * 10 + [48 * 48 * 27] * 12 + [384 * 768] * 8 + [96] * 120 + [768] * 120
