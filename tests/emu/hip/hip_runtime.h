@@ -6,12 +6,15 @@
 // compiled UNCHANGED as plain C++ (host clang from ROCm's LLVM) with `-I tests/emu` placed ahead of
 // the ROCm include path, so `#include <hip/hip_runtime.h>` resolves to this file.
 //
-// Model: every HIP thread of a block is an OS thread; blocks run one after another.
+// Model: every wave of a block is an OS thread and every lane a fiber (a hand-switched stack) of it; blocks run one
+// after another.  A lane runs until its next synchronisation point, then the wave's scheduler resumes the next lane;
+// when every live lane of the wave has arrived the wave goes on (wave-level sync) or first meets the other waves at a
+// pthread barrier (block-level sync).  Kernels must be convergent at sync points, as on the hardware.
 //   __shared__        -> function-local `static` (one copy, shared by the block's threads)
-//   __syncthreads()   -> pthread barrier over the block
-//   __shfl* / ballot  -> exchange through a per-wave buffer + per-wave barrier (wave = 64 threads)
+//   __syncthreads()   -> all lanes yield, then a pthread barrier over the block's waves
+//   __shfl* / ballot  -> exchange through a per-wave buffer between two wave-level syncs (wave = 64 threads)
 //   atomicAdd         -> compare-exchange loop
-// It is slow (OS threads) and only meant for tiny problem sizes.
+// Switching fibers costs tens of nanoseconds, so problem sizes are bounded by the arithmetic, not by futex traffic.
 #pragma once
 #include <pthread.h>
 #include <math.h>
@@ -51,18 +54,11 @@ static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 
 namespace hipemu {
-struct BlockCtx {
-    pthread_barrier_t block_bar;
-    std::vector<pthread_barrier_t> wave_bar;
-    std::vector<uint64_t> wave_buf;   // 64 slots per wave
-    unsigned nthreads;
-};
-extern BlockCtx* g_ctx;
-extern thread_local unsigned t_linear;   // linear thread id in block
-
-inline void sync_block() { pthread_barrier_wait(&g_ctx->block_bar); }
-inline void sync_wave() { pthread_barrier_wait(&g_ctx->wave_bar[t_linear / 64]); }
-inline uint64_t* wave_slots() { return &g_ctx->wave_buf[(t_linear / 64) * 64]; }
+extern thread_local unsigned t_linear;      // linear thread id in block (of the lane that is running)
+extern thread_local uint64_t* t_wave_buf;   // 64 exchange slots of this wave
+void sync_block();                          // every lane of the block
+void sync_wave();                           // every lane of the calling lane's wave
+inline uint64_t* wave_slots() { return t_wave_buf; }
 
 template <typename T> inline T exchange(T v, int src_lane) {
     static_assert(sizeof(T) <= 8, "exchange");
