@@ -221,9 +221,10 @@ size_t segm_conv3d_k3_wgrad_workspace_bytes(int32_t batch, int32_t cin, int32_t 
  * bias: (cout) fp32 or NULL.
  * flags: SEGM_CONV_FWD_ACCUMULATE adds the result to what `y` already holds (the 48-channel blocks of a wider layer
  * accumulate in place); SEGM_CONV_FWD_CHAIN (cout % 48 == 0 only) selects the kernel whose K parts are pipelined
- * through LDS instead of reduced at every output row - same results up to the order of fp32 additions.
+ * through LDS instead of reduced at every output row - same results up to the order of fp32 additions;
+ * SEGM_CONV_FWD_PITCH48 (with CHAIN only) lays its LDS rows out without padding (a bank-conflict experiment).
  * ------------------------------------------------------------------------------------------------ */
-enum segm_conv_fwd_flags { SEGM_CONV_FWD_ACCUMULATE = 1, SEGM_CONV_FWD_CHAIN = 2 };
+enum segm_conv_fwd_flags { SEGM_CONV_FWD_ACCUMULATE = 1, SEGM_CONV_FWD_CHAIN = 2, SEGM_CONV_FWD_PITCH48 = 4 };
 
 typedef struct segm_conv3d_fwd_args {
     int32_t batch, cin, cout, depth, height, width;

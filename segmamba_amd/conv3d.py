@@ -80,7 +80,7 @@ def _hip_fwd_ok(x, w) -> bool:
         ops_raw.conv3d_k3_fwd_supported(x[:, :_BLOCK], w.shape[0])
 
 
-def _fwd_hip(x, w, pad, bias=None, chain=False):
+def _fwd_hip(x, w, pad, bias=None, chain=False, pitch48=False):
     """segm_conv3d_k3_fwd per 48-channel input block (the kernel keeps one block's weights in registers).  With
     Cout % 48 == 0 the later blocks accumulate into the first block's output in place; `chain` picks the kernel whose K
     parts are pipelined (csrc/conv3d_fwd.hip, variant 1)."""
@@ -91,7 +91,8 @@ def _fwd_hip(x, w, pad, bias=None, chain=False):
     for i, ib in enumerate(_blocks(w.shape[1])):
         wp = ops_raw.pack_conv3d_weight(w[:, ib], x.dtype)
         if inplace:
-            out = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None, out=out, accumulate=i > 0, chain=chain)
+            out = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None, out=out, accumulate=i > 0, chain=chain,
+                                        pitch48=pitch48)
         else:
             y = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None)
             out = y if out is None else out + y
@@ -134,8 +135,8 @@ def _dgrad_as_fwd_blocked(dy, w, x, pad):
     return _fwd_blocked(dy, _flipT(w), pad)
 
 
-def _dgrad_hip(dy, w, x, pad, chain=False):
-    return _fwd_hip(dy, _flipT(w), pad, None, chain)
+def _dgrad_hip(dy, w, x, pad, chain=False, pitch48=False):
+    return _fwd_hip(dy, _flipT(w), pad, None, chain, pitch48)
 
 
 def _wgrad_native(x, dy, w, pad):
@@ -190,6 +191,7 @@ class _ConvSame(torch.autograd.Function):
             cands.append(lambda: _fwd_hip(x, w, pad, bias))        # bias fused into the kernel's epilogue
         if chain:
             cands.append(lambda: _fwd_hip(x, w, pad, bias, True))
+            cands.append(lambda: _fwd_hip(x, w, pad, bias, True, True))      # unpadded LDS rows (not yet measured)
         return _pick(key, cands)
 
     @staticmethod
@@ -209,6 +211,7 @@ class _ConvSame(torch.autograd.Function):
             chain = hip and _hip_chain_ok(w.transpose(0, 1))
             if chain:
                 cands.append(lambda: _dgrad_hip(dy, w, x, pad, True))
+                cands.append(lambda: _dgrad_hip(dy, w, x, pad, True, True))
             dx = _pick(("dgrad", tuple(x.shape), tuple(w.shape), x.dtype, hip, chain), cands)
         if ctx.needs_input_grad[1]:
             cands = [lambda: _wgrad_native(x, dy, w, pad)]

@@ -242,7 +242,7 @@ struct CopyLane {
 };
 struct RowRegs { u32x4 a, c; };  // 8 x values of channels 2 tcp / 2 tcp + 1 (halo wave: one value each, in a[0] / c[0])
 
-template <typename T>
+template <typename T, int CP = kFwCP>
 __device__ __forceinline__ CopyLane copy_lane(const ConvFwdDev& P, int wslot, int lane, int x0) {
     CopyLane L;
     int tcp, x, pos;
@@ -266,7 +266,7 @@ __device__ __forceinline__ CopyLane copy_lane(const ConvFwdDev& P, int wslot, in
     const int64_t xs = inside ? x : 0;
     L.goff0 = (uint32_t)(((int64_t)(L.live0 ? 2 * tcp : 0) * P.x_sc + xs) * (int64_t)sizeof(T));
     L.goff1 = (uint32_t)(((int64_t)(L.live1 ? 2 * tcp + 1 : 0) * P.x_sc + xs) * (int64_t)sizeof(T));
-    L.loff = (uint32_t)((pos * kFwCP + 2 * tcp) * (int)sizeof(T));
+    L.loff = (uint32_t)((pos * CP + 2 * tcp) * (int)sizeof(T));
     return L;
 }
 // uniform base of row (b, zz, yy); null when the row lies outside the volume (a zero row)
@@ -288,7 +288,7 @@ __device__ __forceinline__ void row_fetch(RowRegs& r, const char* rb, const Copy
         r.c[0] = *reinterpret_cast<const uint16_t*>(rb + L.goff1);
     }
 }
-template <typename T>
+template <typename T, int CP = kFwCP>
 __device__ __forceinline__ void row_park(const RowRegs& r, char* ring_row, const CopyLane& L, bool halo_wave) {
     char* dst = ring_row + L.loff;
     if (!halo_wave) {
@@ -297,7 +297,7 @@ __device__ __forceinline__ void row_park(const RowRegs& r, char* ring_row, const
         for (int i = 0; i < 4; ++i) { a[i] = L.live0 ? a[i] : 0u; c[i] = L.live1 ? c[i] : 0u; }
 #pragma unroll
         for (int e = 0; e < 8; ++e)                       // {channel 2 tcp, channel 2 tcp + 1} at x position e
-            *reinterpret_cast<uint32_t*>(dst + e * kFwCP * (int)sizeof(T)) =
+            *reinterpret_cast<uint32_t*>(dst + e * CP * (int)sizeof(T)) =
                 __builtin_amdgcn_perm(c[e >> 1], a[e >> 1], (e & 1) ? 0x07060302u : 0x05040100u);
     } else if (L.has) {
         const uint32_t lo = L.live0 ? r.a[0] : 0u, hi = L.live1 ? r.c[0] : 0u;
@@ -445,35 +445,35 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 }
 
 // ------------------------------------------------------------------------------------------------------
-// 48 output channels per workgroup, K parts chained in time (SEGM_CONV_FWD_CHAIN).  An experiment that LOST on MI355X -
-// 0.94 ms against 0.80 ms at 48 -> 48 @128^3 x 2, slower on every SegMamba shape (profiles/r01_conv_chain_ab.log) - and
-// is therefore opt-in; kept because it is the parity-tested starting point for the next attempt.
+// 48 output channels per workgroup, K parts chained in time (SEGM_CONV_FWD_CHAIN).
 // The kernel above adds its four K parts through LDS once per output row: six waves write, two waves read, sum,
-// convert and store while the other six wait at the barrier, and with ~240 VGPRs per wave at two waves per SIMD there
-// is room for one A fragment pair in flight, so every chunk's MFMAs start with an exposed LDS read.  Here the same
-// four K parts form a pipeline instead:
-//   * 4 waves (one per SIMD, up to 512 registers each), wave p = K part p for all four x tiles and three co tiles:
-//     33 stationary weight fragments, 12 accumulator tiles, and the A fragments of the next chunk (4) read ahead;
+// convert and store while the other six wait at the barrier (two barriers per row).  Here the same four K parts form a
+// pipeline instead:
 //   * at step s part p works on output row s - p: it starts from the partial sums part p - 1 left for that row one step
 //     earlier (double-buffered LDS hand-off, float4 per lane and tile), adds its own chunks and either hands the
 //     tiles on or - part 3 - adds the bias, converts and stores.  All waves do the same amount of MFMA work between
 //     two barriers, one barrier per step, three drain steps per work item;
 //   * the skew makes each tap plane's ring run at its own row offset (the K parts are in (kz, ky, kx, ci) order:
 //     plane 0 is read by parts 0 - 1, plane 1 by parts 1 - 2, plane 2 by parts 2 - 3): during step s the incoming rows
-//     are s + 2 (plane 0), s (plane 1) and s - 1 (plane 2); four slots per plane as before.
+//     are s + 2 (plane 0), s (plane 1) and s - 1 (plane 2); four slots per plane as before;
+//   * the A fragments of the next chunk are read while the current chunk's MFMAs run.
 // LDS: 88.7 KB ring + 2 x 36.9 KB hand-off = 162 432 B of the 163 840 B a workgroup may declare.
-// Why it lost: with ONE wave per SIMD nothing overlaps that wave's ~680 non-MFMA instructions per step (hand-off, staging,
-// address arithmetic, AGPR moves) with its 132 MFMAs; the step costs ~8 600 cycles against 2 250 of MFMA.  The hand-off
-// pipeline itself (no epilogue phase, one barrier) should go back onto the eight-wave layout.
+// Measured (profiles/r01_conv_chain_ab.log): 0.70 ms against 0.83 ms at 48 -> 48 @128^3 x 2, ahead on the 128^3 / 64^3
+// layers, 4 % behind at 32^3 (drain steps); the dispatcher times both per shape.  A first version with ONE wave per SIMD
+// (4 waves x 4 x tiles, 512 registers each) lost - 0.94 ms: nothing overlapped that wave's ~680 non-MFMA instructions
+// per step with its 132 MFMAs.
 // ------------------------------------------------------------------------------------------------------
-// XT = x tiles per wave: 4 -> four waves (one per SIMD, A fragments double-buffered), 2 -> eight waves = 4 K parts x 2 x pairs
-// (two per SIMD, the layout of the kernel above with the hand-off pipeline in place of its reduce + epilogue phase).
-template <typename T, bool ACC, int XT>
-__global__ void __launch_bounds__(1024 / XT, XT == 2 ? 2 : 1) conv3d_k3_fwd48_chain_kernel(ConvFwdDev P) {
+// Eight waves = 4 K parts x 2 x pairs (two per SIMD, the layout of the kernel above with the hand-off pipeline in place of its
+// reduce + epilogue phase).  CP = ci pitch of a ring position in elements: 56 as above, or 48 (no padding) - by the LDS
+// bank model of MI355X_MICROARCH.md (ds_read_b128: four groups of 16 lanes over 64 banks) the unpadded rows make the A
+// fragment reads conflict-free where the padded ones are 2-way (tools/lds_conflicts.py); SEGM_CONV_FWD_PITCH48.
+template <typename T, bool ACC, int CP>
+__global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDev P) {
     typedef typename Mfma16<T>::v8 frag8;
-    constexpr int XP = 4 / XT;                            // waves per K part
-    constexpr int NBUF = 2;                               // A fragment buffers: the next chunk is read ahead of its use
-    __shared__ __attribute__((aligned(16))) T xs[3][4][kFwSlot];
+    constexpr int XT = 2;                                 // x tiles per wave
+    constexpr int XP = 2;                                 // waves per K part
+    constexpr int kSlot = kFwXP * CP;                     // elements per ring row
+    __shared__ __attribute__((aligned(16))) T xs[3][4][kSlot];
     __shared__ __attribute__((aligned(16))) f32x4 hand[2][3][XP][3 * XT][64];     // [buffer][link p -> p + 1][x part][co tile * XT + x tile][lane]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(1024 / XT, XT == 2 ? 2 : 1) conv3d_k3_fwd48_ch
         const int kk = live ? k : 0;
         const int tap = kk / kFwCi, ci0 = kk - tap * kFwCi;
         const int tz = tap / 9, ty = (tap - tz * 9) / 3, tx = tap - tz * 9 - ty * 3;
-        aoff[c] = (tz * 4 * kFwSlot + (xp * XT * 16 + i16 + tx) * kFwCP + ci0) | (ty << 28);
+        aoff[c] = (tz * 4 * kSlot + (xp * XT * 16 + i16 + tx) * CP + ci0) | (ty << 28);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int co = cob * 48 + t * 16 + i16;
@@ -513,40 +513,26 @@ __global__ void __launch_bounds__(1024 / XT, XT == 2 ? 2 : 1) conv3d_k3_fwd48_ch
 #pragma unroll
     for (int t = 0; t < 3; ++t) bias[t] = P.bias ? P.bias[cob * 48 + t * 16 + i16] : 0.f;
 
-    // ---- row staging: plane q's incoming row during step s is s + {2, 0, -1}[q].  Four waves: three slots each; eight
-    //      waves: slot A = plane 0 (waves 0 - 3) / plane 1 (waves 4 - 7), slot B = plane 2 (waves 0 - 3) -----------------------------
-    constexpr int NS = XT == 4 ? 3 : 2;                   // staging slots per wave
+    // ---- row staging: plane q's incoming row during step s is s + {2, 0, -1}[q]: slot A = plane 0 (waves 0 - 3) / plane 1
+    //      (waves 4 - 7), slot B = plane 2 (waves 0 - 3) -------------------------------------------------------------------------
     const int wslot = wave & 3;
-    const bool halo_wave = wslot == 3;
-    const CopyLane cl = copy_lane<T>(P, wslot, lane, x0);
+    const bool halo_wave = wslot == 3, second = wave < 4;
+    const int plane_a = wave >> 2, soff_a = plane_a == 0 ? 2 : 0;
+    const CopyLane cl = copy_lane<T, CP>(P, wslot, lane, x0);
     char* ring = reinterpret_cast<char*>(&xs[0][0][0]);
-    int spl[NS], soff[NS];                                // plane and row offset of this wave's slots (-1: no slot)
-    if (XT == 4) {
-#pragma unroll
-        for (int q = 0; q < NS; ++q) spl[q] = q;
-    } else {
-        spl[0] = wave >> 2;
-        spl[NS - 1] = wave < 4 ? 2 : -1;
-    }
-#pragma unroll
-    for (int q = 0; q < NS; ++q) soff[q] = spl[q] == 0 ? 2 : (spl[q] == 1 ? 0 : -1);
-    auto fetch = [&](RowRegs (&r)[NS], int base, bool skewed) {
-#pragma unroll
-        for (int q = 0; q < NS; ++q)
-            if (spl[q] >= 0) row_fetch<T>(r[q], row_base<T>(P, b, z + spl[q] - 1, base + (skewed ? soff[q] : 0)), cl, halo_wave);
+    auto fetch = [&](RowRegs (&r)[2], int base, bool skewed) {
+        row_fetch<T>(r[0], row_base<T>(P, b, z + plane_a - 1, base + (skewed ? soff_a : 0)), cl, halo_wave);
+        if (second) row_fetch<T>(r[1], row_base<T>(P, b, z + 1, base + (skewed ? -1 : 0)), cl, halo_wave);
     };
-    auto park = [&](const RowRegs (&r)[NS], int base, bool skewed) {
-#pragma unroll
-        for (int q = 0; q < NS; ++q)
-            if (spl[q] >= 0) {
-                const int yy = base + (skewed ? soff[q] : 0);
-                row_park<T>(r[q], ring + (spl[q] * 4 + ((yy + 8) & 3)) * kFwSlot * (int)sizeof(T), cl, halo_wave);
-            }
+    auto park = [&](const RowRegs (&r)[2], int base, bool skewed) {
+        const int ya = base + (skewed ? soff_a : 0), yb = base + (skewed ? -1 : 0);
+        row_park<T, CP>(r[0], ring + (plane_a * 4 + ((ya + 8) & 3)) * kSlot * (int)sizeof(T), cl, halo_wave);
+        if (second) row_park<T, CP>(r[1], ring + (2 * 4 + ((yb + 8) & 3)) * kSlot * (int)sizeof(T), cl, halo_wave);
     };
 
     if (y1 <= y0) return;
     {   // prologue: rows y0 - 1, y0, y0 + 1 of every plane (planes 1 and 2 re-park theirs on schedule; same slot, same data)
-        RowRegs r[NS];
+        RowRegs r[2];
 #pragma unroll
         for (int d = -1; d <= 1; ++d) {
             fetch(r, y0 + d, false);
@@ -560,13 +546,13 @@ __global__ void __launch_bounds__(1024 / XT, XT == 2 ? 2 : 1) conv3d_k3_fwd48_ch
         // the partial sums of the previous K part for this row, then the first chunk's A fragments: issued before the
         // global fetches so that their latency is covered by the address arithmetic
         f32x4 acc[3][XT];
-        frag8 a[NBUF][XT];
+        frag8 a[2][XT];
         const T* pl = &xs[0][0][0];
         auto load_a = [&](frag8 (&dst)[XT], int c) {
             const int slot = (row + (aoff[c] >> 28) + 7) & 3;              // input row = row + ky - 1
-            const T* ap = pl + slot * kFwSlot + (aoff[c] & 0x0fffffff);
+            const T* ap = pl + slot * kSlot + (aoff[c] & 0x0fffffff);
 #pragma unroll
-            for (int u = 0; u < XT; ++u) dst[u] = *reinterpret_cast<const frag8*>(ap + u * 16 * kFwCP);
+            for (int u = 0; u < XT; ++u) dst[u] = *reinterpret_cast<const frag8*>(ap + u * 16 * CP);
         };
         if (active) {
             if (part == 0) {
@@ -580,25 +566,21 @@ __global__ void __launch_bounds__(1024 / XT, XT == 2 ? 2 : 1) conv3d_k3_fwd48_ch
 #pragma unroll
                     for (int u = 0; u < XT; ++u) acc[t][u] = hand[(s + 1) & 1][part - 1][xp][t * XT + u][lane];
             }
-            if (NBUF == 2) load_a(a[0], 0);
+            load_a(a[0], 0);
         }
-        RowRegs r[NS];
+        RowRegs r[2];
         fetch(r, s, true);                                // in flight during this step's MFMAs
         SEGM_SCHED_FENCE();
         if (active) {
 #pragma unroll
             for (int c = 0; c < kF48Chunks; ++c) {
-                if (NBUF == 2) {
-                    if (c + 1 < kF48Chunks) load_a(a[(c + 1) & 1], c + 1);     // one chunk (12 MFMAs) ahead of its use
-                    SEGM_SCHED_FENCE();
-                } else {
-                    load_a(a[0], c);
-                }
+                if (c + 1 < kF48Chunks) load_a(a[(c + 1) & 1], c + 1);     // one chunk (6 MFMAs) ahead of its use
+                SEGM_SCHED_FENCE();
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int u = 0; u < XT; ++u) acc[t][u] = Mfma16<T>::run(a[NBUF == 2 ? (c & 1) : 0][u], wf[t][c], acc[t][u]);
-                if (NBUF == 2) SEGM_SCHED_FENCE();
+                    for (int u = 0; u < XT; ++u) acc[t][u] = Mfma16<T>::run(a[c & 1][u], wf[t][c], acc[t][u]);
+                SEGM_SCHED_FENCE();
             }
             if (part < 3) {
 #pragma unroll
@@ -630,23 +612,26 @@ __global__ void __launch_bounds__(1024 / XT, XT == 2 ? 2 : 1) conv3d_k3_fwd48_ch
 }
 
 struct FwPlan { int nxb, ysplit, rows_per_part, nitems; };
-static FwPlan fwd_plan(int batch, int cout, int d, int h, int w) {
+static FwPlan fwd_plan(int batch, int cout, int d, int h, int w, bool chain = false) {
     FwPlan p;
     p.nxb = (w + kFwXB - 1) / kFwXB;
-    const int64_t wgs = (int64_t)batch * d * p.nxb * ((cout + kFwCo - 1) / kFwCo);
-    int split = 1;                                        // cut y when there are too few workgroups for 256 CUs
-    while (wgs * split < 512 && h / (split * 2) >= 8) split *= 2;
+    // cut y when there are too few workgroups for 256 CUs.  The chained kernel pays three drain steps per cut and runs one
+    // workgroup per CU, so it stops at one workgroup per CU; the other kernels aim for two rounds.
+    const int64_t wgs = (int64_t)batch * d * p.nxb * (chain ? (cout + 47) / 48 : (cout + kFwCo - 1) / kFwCo);
+    const int64_t target = chain ? 256 : 512;
+    int split = 1;
+    while (wgs * split < target && h / (split * 2) >= 8) split *= 2;
     p.ysplit = split;
     p.rows_per_part = (h + split - 1) / split;
     p.nitems = batch * d * p.nxb * split;
     return p;
 }
 
-template <int CHAIN>                                    // 0: reduce-per-row kernel, 2 / 4: chained kernel with that many x tiles per wave
+template <int CHAIN>                                    // 0: reduce-per-row kernel; else the chained kernel with that ci pitch
 static void launch48(const ConvFwdDev& P, dim3 grid, bool f16, bool acc, hipStream_t stream) {
 #define SEGM_L48(T, A)                                                                                          \
     do {                                                                                                        \
-        if (CHAIN) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, A, CHAIN ? CHAIN : 2>), grid, dim3(1024 / (CHAIN ? CHAIN : 2)), 0, stream, P); \
+        if (CHAIN) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, A, CHAIN ? CHAIN : kFwCP>), grid, dim3(512), 0, stream, P); \
         else hipLaunchKernelGGL((conv3d_k3_fwd48_kernel<T, A>), grid, dim3(kF48Threads), 0, stream, P);         \
     } while (0)
     if (f16) { if (acc) SEGM_L48(f16_t, true); else SEGM_L48(f16_t, false); }
@@ -665,8 +650,9 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     if (a->cin < 1 || a->cin > kFwCi || a->cout <= 0 || a->cout % 16 != 0) return SEGM_E_SHAPE;
     if (a->width % 8 != 0) return SEGM_E_SHAPE;
     if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
-    if (a->flags & ~(SEGM_CONV_FWD_ACCUMULATE | SEGM_CONV_FWD_CHAIN)) return SEGM_E_SHAPE;
+    if (a->flags & ~(SEGM_CONV_FWD_ACCUMULATE | SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_PITCH48)) return SEGM_E_SHAPE;
     if ((a->flags & SEGM_CONV_FWD_CHAIN) && a->cout % 48 != 0) return SEGM_E_SHAPE;
+    if ((a->flags & SEGM_CONV_FWD_PITCH48) && !(a->flags & SEGM_CONV_FWD_CHAIN)) return SEGM_E_SHAPE;
     const int64_t st[8] = {a->x_stride_b, a->x_stride_c, a->x_stride_z, a->x_stride_y,
                            a->y_stride_b, a->y_stride_c, a->y_stride_z, a->y_stride_y};
     for (int64_t s : st)
@@ -680,7 +666,7 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     P.wp = a->w_packed;
     P.bias = a->bias;
     P.B = a->batch; P.D = a->depth; P.H = a->height; P.W = a->width; P.cout = a->cout; P.cin = a->cin;
-    const FwPlan pl = fwd_plan(a->batch, a->cout, a->depth, a->height, a->width);
+    const FwPlan pl = fwd_plan(a->batch, a->cout, a->depth, a->height, a->width, (a->flags & SEGM_CONV_FWD_CHAIN) != 0);
     P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part;
     hipStream_t stream = (hipStream_t)a->stream;
     const bool f16 = a->dtype == SEGM_F16;
@@ -689,9 +675,8 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     const bool off32 = ((int64_t)47 * a->x_stride_c + a->width) * 2 < ((int64_t)1 << 32);
     if ((a->flags & SEGM_CONV_FWD_CHAIN) && !off32) return SEGM_E_SHAPE;
     if (a->flags & SEGM_CONV_FWD_CHAIN) {
-        const char* w4 = getenv("SEGM_CONV_CHAIN_WAVES");             // "4": the one-wave-per-SIMD variant (A/B timing)
-        if (w4 && w4[0] == '4') launch48<4>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
-        else launch48<2>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
+        if (a->flags & SEGM_CONV_FWD_PITCH48) launch48<48>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
+        else launch48<kFwCP>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
         return (int)hipGetLastError();
     }
     if (a->cout % 48 == 0 && off32 && (acc || !getenv("SEGM_CONV_FWD_KZ_SPLIT"))) {     // the env switch forces the 32 + 16 kernels (A/B timing)

@@ -267,7 +267,7 @@ def test_conv3d_k3_fwd_emulated(emu, shape):
 
 
 @pytest.mark.parametrize("shape", [(1, 48, 2, 2, 16), (1, 48, 1, 16, 8), (1, 96, 1, 3, 72), (2, 48, 1, 2, 8)])
-def test_conv3d_k3_fwd_chained_k_parts_emulated(emu, shape, monkeypatch):
+def test_conv3d_k3_fwd_chained_k_parts_emulated(emu, shape):
     """the pipelined variant (SEGM_CONV_FWD_CHAIN): K parts skewed in time, per-plane ring offsets, double-buffered
     hand-off, drain steps, y split; on the first shape also in-place accumulation of a second 48-channel input block
     (SEGM_CONV_FWD_ACCUMULATE) with both 48-channel kernels."""
@@ -278,12 +278,10 @@ def test_conv3d_k3_fwd_chained_k_parts_emulated(emu, shape, monkeypatch):
     bias = torch.randn(cout, generator=g)
     ref0 = torch.nn.functional.conv3d(x[:, :48].float(), w[:, :48].float(), bias, 1, 1)
     tol = 1e-2 * max(1.0, float(ref0.abs().max()))
-    y = ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:, :48]), bias, chain=True)      # eight waves
+    y = ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:, :48]), bias, chain=True)
     assert (y.float() - ref0).abs().max() <= tol
-    if shape == (1, 96, 1, 3, 72):
-        monkeypatch.setenv("SEGM_CONV_CHAIN_WAVES", "4")                                                    # one wave per SIMD
-        y4 = ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:, :48]), bias, chain=True)
-        assert (y4.float() - ref0).abs().max() <= tol
+    y48 = ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:, :48]), bias, chain=True, pitch48=True)
+    assert torch.equal(y48, y)                                                                               # same sums, other LDS layout
     if shape != (1, 48, 2, 2, 16):
         return
     ref = torch.nn.functional.conv3d(x.float(), w.float(), bias, 1, 1)
@@ -295,6 +293,8 @@ def test_conv3d_k3_fwd_chained_k_parts_emulated(emu, shape, monkeypatch):
     assert (y3.float() - ref).abs().max() <= 2 * tol
     with pytest.raises(RuntimeError):
         ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:32, :48]), None, chain=True)      # Cout % 48 != 0
+    with pytest.raises(RuntimeError):
+        ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:, :48]), None, pitch48=True)      # needs chain
 
 
 def test_conv3d_k3_dgrad_as_forward_emulated(emu):

@@ -417,6 +417,7 @@ def test_conv3d_k3_fwd_chained_k_parts(hip, shape):
     y = ops_raw.conv3d_k3_fwd(hip, x[:, :48], w0, bias, chain=True)
     assert (y.float() - ref0).abs().max() <= tol
     assert torch.equal(ops_raw.conv3d_k3_fwd(hip, x[:, :48], w0, bias, chain=True), y)          # deterministic
+    assert torch.equal(ops_raw.conv3d_k3_fwd(hip, x[:, :48], w0, bias, chain=True, pitch48=True), y)   # other LDS layout, same sums
     yd = ops_raw.conv3d_k3_fwd(hip, x[:, :48], w0, bias)
     assert (y.float() - yd.float()).abs().max() <= tol                                           # same sums, other order
     for chain in (True, False):
