@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 // pipeline instead:
 //   * at step s part p works on output row s - p: it starts from the partial sums part p - 1 left for that row one step
 //     earlier (double-buffered LDS hand-off, float4 per lane and tile), adds its own chunks and either hands the
-//     tiles on or - part 3 - adds the bias, converts and stores.  All waves do the same amount of MFMA work between
+//     tiles on or - part 3 - converts and stores (part 0 starts from the bias).  All waves do the same MFMA work between
 //     two barriers, one barrier per step, three drain steps per work item;
 //   * the skew makes each tap plane's ring run at its own row offset (the K parts are in (kz, ky, kx, ci) order:
 //     plane 0 is read by parts 0 - 1, plane 1 by parts 1 - 2, plane 2 by parts 2 - 3): during step s the incoming rows
@@ -555,11 +555,11 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
             for (int u = 0; u < XT; ++u) dst[u] = *reinterpret_cast<const frag8*>(ap + u * 16 * CP);
         };
         if (active) {
-            if (part == 0) {
+            if (part == 0) {                              // the chain starts from the bias (a lane's four results share a co)
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int u = 0; u < XT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int u = 0; u < XT; ++u) acc[t][u] = f32x4{bias[t], bias[t], bias[t], bias[t]};
             } else {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
                     for (int t = 0; t < 3; ++t) {
                         float v[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = acc[t][u][q] + bias[t];
+                        for (int q = 0; q < 4; ++q) v[q] = acc[t][u][q];
                         const int co = cob * 48 + t * 16 + i16;
                         T* dst = reinterpret_cast<T*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
                                       (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + xg;
