@@ -63,18 +63,17 @@ struct ConvFwdDev {
 // of a wider layer)
 template <typename T, bool ACC>
 __device__ __forceinline__ void store4(T* dst, const float (&v)[4]) {
-    T o[4];
-    if (ACC) {
-        u32x2 old = *reinterpret_cast<const u32x2*>(dst);
-        memcpy(o, &old, 8);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(v[q] + to_f32(o[q]));
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(v[q]);
-    }
     u32x2 pk;
-    memcpy(&pk, o, 8);
+    if (ACC) {
+        const u32x2 old = *reinterpret_cast<const u32x2*>(dst);
+        T o[4];
+        memcpy(o, &old, 8);
+        pk[0] = pack2<T>(v[0] + to_f32(o[0]), v[1] + to_f32(o[1]));
+        pk[1] = pack2<T>(v[2] + to_f32(o[2]), v[3] + to_f32(o[3]));
+    } else {
+        pk[0] = pack2<T>(v[0], v[1]);
+        pk[1] = pack2<T>(v[2], v[3]);
+    }
     *reinterpret_cast<u32x2*>(dst) = pk;
 }
 

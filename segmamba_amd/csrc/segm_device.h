@@ -53,6 +53,13 @@ typedef __bf16 bf16_t;
 
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+// two fp32 -> one dword of two 16-bit elements (a in the low half): a single v_cvt_pk_* where the target has one
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, t2));
+}
 
 // ---- v_mfma_f32_16x16x32 for the two 16-bit element types (conv3d_fwd.hip, conv3d_wgrad.hip) -----------------------
 typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
