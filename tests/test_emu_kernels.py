@@ -420,3 +420,28 @@ def test_cross_entropy_emulated(emu, shape, dtype):
     assert abs(float(loss_sum) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
     tol = 1e-6 if dtype == torch.float32 else (1e-3 if dtype == torch.float16 else 8e-3)
     assert dlogits.dtype == dtype and (dlogits.double() - ref_in.grad).abs().max() <= tol
+
+
+def test_conv_dispatcher_library_routes_on_emulated_kernels(emu, monkeypatch):
+    """conv3d.py's library candidates (forward / data gradient; reduce-per-row, chained, chained with unpadded LDS rows;
+    96 input channels = two blocks accumulated in place) produce the convolution, through the emulated kernels."""
+    from segmamba_amd import conv3d as C3, lib as L
+    monkeypatch.setattr(L, "get_lib", lambda: emu)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(1, 96, 1, 2, 8, generator=g).bfloat16()
+    w = (0.1 * torch.randn(48, 96, 3, 3, 3, generator=g)).bfloat16()
+    bias = torch.randn(48, generator=g).bfloat16()
+    dy = torch.randn(1, 48, 1, 2, 8, generator=g).bfloat16()
+    xr = x.float().requires_grad_()
+    ref = torch.nn.functional.conv3d(xr, w.float(), bias.float(), 1, 1)
+    ref.backward(dy.float())
+    assert C3._hip_fwd_ok(x, w) and C3._hip_chain_ok(w)
+    for chain, p48 in ((False, False), (True, False), (True, True)):
+        y = C3._fwd_hip(x, w, 1, bias, chain, p48)
+        assert (y.float() - ref.detach()).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max()))
+    w2 = w[:, :48].contiguous()                            # data gradient: 48 -> 48 (flipped weights: Cout' = 48)
+    x2 = x[:, :48].float().requires_grad_()
+    torch.nn.functional.conv3d(x2, w2.float(), None, 1, 1).backward(dy.float())
+    for chain, p48 in ((False, False), (True, True)):
+        dx = C3._dgrad_hip(dy, w2, x[:, :48], 1, chain, p48)
+        assert (dx.float() - x2.grad).abs().max() <= 2e-2 * max(1.0, float(x2.grad.abs().max()))
