@@ -391,6 +391,51 @@ typedef struct segm_cross_entropy_args {
 int segm_cross_entropy(const segm_cross_entropy_args* args);
 int32_t segm_cross_entropy_partials(int32_t batch, int64_t spatial);
 
+/* ------------------------------------------------------------------------------------------------
+ * Single-token decode steps (the native ops behind `Mamba.step`, reference mamba_simple.py:356-401).
+ *
+ * segm_causal_conv1d_update replaces causal_conv1d_cuda.causal_conv1d_update(x, conv_state, weight, bias?, silu)
+ *   (reference causal-conv1d/csrc/causal_conv1d.cpp:270-330; Python causal_conv1d_interface.py:68-82):
+ *   conv_state <- roll(conv_state, -1) with x in the last slot; out = act(sum_w conv_state * weight + bias).
+ *   x, out (batch, dim), conv_state (batch, dim, width) of `dtype`, element strides; weight (dim, width), bias (dim) fp32.
+ *
+ * segm_selective_state_update replaces selective_state_update(state, x, dt, A, B, C, D?, z?, dt_bias?, dt_softplus)
+ *   (reference mamba/mamba_ssm/ops/triton/selective_state_update.py:99-155, a Triton kernel):
+ *   dt' = softplus(dt + dt_bias); state <- state exp(dt' A) + dt' B x; out = <state, C> + D x; out *= silu(z).
+ *   state (batch, dim, dstate) of `state_dtype` (updated in place); x, dt, z, out (batch, dim) and B, C (batch, dstate) of
+ *   `dtype`; A (dim, dstate), D, dt_bias (dim) fp32.  1 <= dstate <= 256.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_conv1d_update_args {
+    int32_t batch, dim, width, silu;
+    int32_t dtype, reserved;
+    const void* x;      int64_t x_stride_b, x_stride_d;
+    void* conv_state;   int64_t state_stride_b, state_stride_d, state_stride_w;
+    void* out;          int64_t out_stride_b, out_stride_d;
+    const float* weight;
+    const float* bias;        /* or NULL */
+    void* stream;
+} segm_conv1d_update_args;
+
+int segm_causal_conv1d_update(const segm_conv1d_update_args* args);
+
+typedef struct segm_state_update_args {
+    int32_t batch, dim, dstate, dt_softplus;
+    int32_t dtype, state_dtype;
+    void* state;        int64_t state_stride_b, state_stride_d, state_stride_n;
+    const void* x;      int64_t x_stride_b, x_stride_d;
+    const void* dt;     int64_t dt_stride_b, dt_stride_d;
+    const void* z;      int64_t z_stride_b, z_stride_d;      /* z NULL = no gate */
+    void* out;          int64_t out_stride_b, out_stride_d;
+    const void* B;      int64_t B_stride_b, B_stride_n;
+    const void* C;      int64_t C_stride_b, C_stride_n;
+    const float* A;
+    const float* D;           /* or NULL */
+    const float* dt_bias;     /* or NULL */
+    void* stream;
+} segm_state_update_args;
+
+int segm_selective_state_update(const segm_state_update_args* args);
+
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);
 const char* segm_status_string(int status);

@@ -167,6 +167,77 @@ def mamba_v3_forward_ref(hidden_states, p, nslices):
 
 
 # --------------------------------------------------------------------------------------
+# single-token decode
+# --------------------------------------------------------------------------------------
+def causal_conv1d_update_ref(x, conv_state, weight, bias=None, activation=None):
+    """causal-conv1d/causal_conv1d/causal_conv1d_interface.py:84-104.  x (batch, dim); conv_state (batch, dim, width),
+    updated in place; weight (dim, width); bias (dim)."""
+    dtype_in = x.dtype
+    conv_state.copy_(torch.roll(conv_state, shifts=-1, dims=-1))
+    conv_state[:, :, -1] = x
+    out = torch.sum(conv_state * weight, dim=-1)
+    if bias is not None:
+        out = out + bias
+    return (out if activation is None else F.silu(out)).to(dtype=dtype_in)
+
+
+def selective_state_update_ref(state, x, dt, A, B, C, D=None, z=None, dt_bias=None, dt_softplus=False):
+    """mamba/mamba_ssm/ops/triton/selective_state_update.py:157-192.  state (batch, dim, dstate), updated in place."""
+    if dt_bias is not None:
+        dt = dt + dt_bias
+    dt = F.softplus(dt) if dt_softplus else dt
+    dA = torch.exp(dt[:, :, None] * A)
+    dB = dt[:, :, None] * B[:, None, :]
+    state.copy_(state * dA + dB * x[:, :, None])
+    out = torch.einsum("bdn,bn->bd", state.to(C.dtype), C)
+    if D is not None:
+        out = out + (x * D).to(out.dtype)
+    return (out if z is None else out * F.silu(z)).to(x.dtype)
+
+
+def mamba_step_ref(hidden_states, p, conv_state, ssm_state):
+    """mamba/mamba_ssm/modules/mamba_simple.py:356-401 (`Mamba.step`): one token through the forward-direction
+    parameters; hidden_states (batch, 1, d_model); the two states are updated in place."""
+    d_state = p["A_log"].shape[1]
+    dt_rank = p["dt_proj.weight"].shape[1]
+    xz = F.linear(hidden_states.squeeze(1), p["in_proj.weight"], p.get("in_proj.bias"))
+    x, z = xz.chunk(2, dim=-1)
+    x = causal_conv1d_update_ref(x, conv_state, p["conv1d.weight"].squeeze(1), p["conv1d.bias"], "silu")
+    x_db = F.linear(x, p["x_proj.weight"])
+    dt, B, C = torch.split(x_db, [dt_rank, d_state, d_state], dim=-1)
+    dt = F.linear(dt, p["dt_proj.weight"])
+    A = -torch.exp(p["A_log"].float())
+    y = selective_state_update_ref(ssm_state, x, dt, A, B, C, p["D"], z=z, dt_bias=p["dt_proj.bias"], dt_softplus=True)
+    return F.linear(y, p["out_proj.weight"], p.get("out_proj.bias")).unsqueeze(1)
+
+
+def mamba_prefill_ref(hidden_states, p, conv_state, ssm_state):
+    """mamba/mamba_ssm/modules/mamba_simple.py:196-208, 265-355: `Mamba.forward` with `inference_params` at
+    seqlen_offset 0 - the uni-directional branch on the forward-direction parameters, leaving the last d_conv inputs
+    of the convolution in conv_state and the final SSM state in ssm_state."""
+    batch, L, _ = hidden_states.shape
+    d_state = p["A_log"].shape[1]
+    dt_rank = p["dt_proj.weight"].shape[1]
+    d_conv = p["conv1d.weight"].shape[-1]
+    xz = (p["in_proj.weight"] @ hidden_states.reshape(batch * L, -1).t()).reshape(-1, batch, L).permute(1, 0, 2)
+    if p.get("in_proj.bias") is not None:
+        xz = xz + p["in_proj.bias"].to(xz.dtype)[:, None]
+    x, z = xz.chunk(2, dim=1)
+    conv_state.copy_(x[:, :, -d_conv:])
+    x = causal_conv1d_ref(x, p["conv1d.weight"].squeeze(1), p["conv1d.bias"], "silu")
+    x_dbl = F.linear(x.permute(0, 2, 1).reshape(batch * L, -1), p["x_proj.weight"])
+    dt, B, C = torch.split(x_dbl, [dt_rank, d_state, d_state], dim=-1)
+    dt = (p["dt_proj.weight"] @ dt.t()).reshape(-1, batch, L).permute(1, 0, 2)
+    B = B.reshape(batch, L, d_state).permute(0, 2, 1).contiguous()
+    C = C.reshape(batch, L, d_state).permute(0, 2, 1).contiguous()
+    A = -torch.exp(p["A_log"].float())
+    y, last = selective_scan_ref(x, dt, A, B, C, p["D"].float(), z=z, delta_bias=p["dt_proj.bias"].float(),
+                                 delta_softplus=True, return_last_state=True)
+    ssm_state.copy_(last)
+    return F.linear(y.permute(0, 2, 1), p["out_proj.weight"], p.get("out_proj.bias"))
+
+
+# --------------------------------------------------------------------------------------
 # closed-form backward of the scan (Appendix A of SURVEY.md), fp64, used as an independent check
 # --------------------------------------------------------------------------------------
 def selective_scan_bwd_closed_form(u, delta, A, B, C, D, z, delta_bias, dout, delta_softplus=True):

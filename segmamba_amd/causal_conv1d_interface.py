@@ -54,9 +54,13 @@ def causal_conv1d_fn(x, weight, bias=None, activation=None):
 
 
 def causal_conv1d_update(x, conv_state, weight, bias=None, activation=None):
-    """Single-token decode step (reference causal_conv1d_interface.py:68-82).
+    """Single-token decode step (reference causal_conv1d_interface.py:68-82; native op causal_conv1d.cpp:270-330).
 
-    Not on SegMamba's path (the model never passes `inference_params`); the name exists
-    because `mamba_simple.py:14` imports it.  Calling it is an error rather than a silent slow path.
+    x: (batch, dim)    conv_state: (batch, dim, width), updated in place    weight: (dim, width)    bias: (dim,)
+    out: (batch, dim)
     """
-    raise NotImplementedError("causal_conv1d_update (autoregressive decode) is outside the SegMamba hot path")
+    if activation not in [None, "silu", "swish"]:
+        raise NotImplementedError("activation must be None, silu, or swish")
+    w32 = weight.float().contiguous()
+    b32 = bias.float().contiguous() if bias is not None else None
+    return ops_raw.conv1d_update(L.get_lib(), x, conv_state, w32, b32, activation in ["silu", "swish"])

@@ -150,6 +150,32 @@ class CrossEntropyArgs(C.Structure):
     ]
 
 
+class Conv1dUpdateArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("dim", C.c_int32), ("width", C.c_int32), ("silu", C.c_int32),
+        ("dtype", C.c_int32), ("reserved", C.c_int32),
+        ("x", C.c_void_p), ("x_stride_b", C.c_int64), ("x_stride_d", C.c_int64),
+        ("conv_state", C.c_void_p), ("state_stride_b", C.c_int64), ("state_stride_d", C.c_int64), ("state_stride_w", C.c_int64),
+        ("out", C.c_void_p), ("out_stride_b", C.c_int64), ("out_stride_d", C.c_int64),
+        ("weight", C.c_void_p), ("bias", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
+class StateUpdateArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("dim", C.c_int32), ("dstate", C.c_int32), ("dt_softplus", C.c_int32),
+        ("dtype", C.c_int32), ("state_dtype", C.c_int32),
+        ("state", C.c_void_p), ("state_stride_b", C.c_int64), ("state_stride_d", C.c_int64), ("state_stride_n", C.c_int64),
+        ("x", C.c_void_p), ("x_stride_b", C.c_int64), ("x_stride_d", C.c_int64),
+        ("dt", C.c_void_p), ("dt_stride_b", C.c_int64), ("dt_stride_d", C.c_int64),
+        ("z", C.c_void_p), ("z_stride_b", C.c_int64), ("z_stride_d", C.c_int64),
+        ("out", C.c_void_p), ("out_stride_b", C.c_int64), ("out_stride_d", C.c_int64),
+        ("B", C.c_void_p), ("B_stride_b", C.c_int64), ("B_stride_n", C.c_int64),
+        ("C", C.c_void_p), ("C_stride_b", C.c_int64), ("C_stride_n", C.c_int64),
+        ("A", C.c_void_p), ("D", C.c_void_p), ("dt_bias", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
 class TransposeArgs(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("dtype", C.c_int32),
@@ -165,6 +191,7 @@ EXPORTS = (
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add",
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
+    "segm_causal_conv1d_update", "segm_selective_state_update",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -206,6 +233,8 @@ class SegmLib:
         sig("segm_sgd_clip_step_workspace_bytes", [C.c_int32, C.c_void_p], C.c_size_t)
         sig("segm_cross_entropy", [C.POINTER(CrossEntropyArgs)], C.c_int)
         sig("segm_cross_entropy_partials", [C.c_int32, C.c_int64], C.c_int32)
+        sig("segm_causal_conv1d_update", [C.POINTER(Conv1dUpdateArgs)], C.c_int)
+        sig("segm_selective_state_update", [C.POINTER(StateUpdateArgs)], C.c_int)
         sig("segm_abi_version", [], C.c_int)
         sig("segm_status_string", [C.c_int], C.c_char_p)
 

@@ -134,7 +134,7 @@ class Mamba(nn.Module):
     def forward(self, hidden_states, inference_params=None):
         """hidden_states: (B, L, D) -> (B, L, D)"""
         if inference_params is not None:
-            raise NotImplementedError("autoregressive decoding is outside the SegMamba hot path (SURVEY.md §2.1)")
+            return self._forward_with_cache(hidden_states, inference_params)
         batch, seqlen, _ = hidden_states.shape
         if seqlen % self.nslices != 0:
             raise RuntimeError(f"sequence length {seqlen} must be divisible by nslices {self.nslices}")
@@ -144,8 +144,66 @@ class Mamba(nn.Module):
         out_s = self._direction(xz, "_s", L.TIME_INTERLEAVED, self.nslices)
         return linear_cl(out + out_b + out_s, self.out_proj.weight, self.out_proj.bias)
 
+    # ---- autoregressive decoding (reference :196-201, :265-310, :356-436).  SegMamba never takes this path; with
+    # `inference_params` the reference runs its uni-directional branch on the forward-direction parameters only. -------------
+    def _forward_with_cache(self, hidden_states, inference_params):
+        from .causal_conv1d_interface import causal_conv1d_fn
+        from .selective_scan_interface import selective_scan_fn
+        batch, seqlen, _ = hidden_states.shape
+        conv_state, ssm_state = self._get_states_from_cache(inference_params, batch)
+        if inference_params.seqlen_offset > 0:
+            out, _, _ = self.step(hidden_states, conv_state, ssm_state)              # the states are updated in place
+            return out
+        xz = linear_cl(hidden_states, self.in_proj.weight, self.in_proj.bias).transpose(1, 2)     # (B, 2*d_inner, L)
+        A = -torch.exp(self.A_log.float())
+        x, z = xz.chunk(2, dim=1)
+        conv_state.copy_(x[:, :, -self.d_conv:])                                      # reference :315
+        x = causal_conv1d_fn(x, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.activation)
+        x_dbl = self.x_proj(x.transpose(1, 2).reshape(batch * seqlen, self.d_inner))
+        dt, Bm, Cm = torch.split(x_dbl, [self.dt_rank, self.d_state, self.d_state], dim=-1)
+        dt = (self.dt_proj.weight @ dt.t()).reshape(self.d_inner, batch, seqlen).transpose(0, 1)
+        Bm = Bm.reshape(batch, seqlen, self.d_state).transpose(1, 2).contiguous()
+        Cm = Cm.reshape(batch, seqlen, self.d_state).transpose(1, 2).contiguous()
+        y, last_state = selective_scan_fn(x, dt, A, Bm, Cm, self.D.float(), z=z, delta_bias=self.dt_proj.bias.float(),
+                                          delta_softplus=True, return_last_state=True)
+        ssm_state.copy_(last_state)
+        return self.out_proj(y.transpose(1, 2))
+
     def step(self, hidden_states, conv_state, ssm_state):
-        raise NotImplementedError("autoregressive decoding is outside the SegMamba hot path (SURVEY.md §2.1)")
+        """One token: hidden_states (B, 1, d_model); conv_state (B, d_inner, d_conv) and ssm_state (B, d_inner, d_state) are
+        updated in place.  Reference :356-401."""
+        from .causal_conv1d_interface import causal_conv1d_update
+        from .selective_state_update import selective_state_update
+        assert hidden_states.shape[1] == 1, "Only support decoding with 1 token at a time for now"
+        xz = self.in_proj(hidden_states.squeeze(1))                                   # (B, 2*d_inner)
+        x, z = xz.chunk(2, dim=-1)
+        x = causal_conv1d_update(x, conv_state, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.activation)
+        x_db = self.x_proj(x)
+        dt, Bm, Cm = torch.split(x_db, [self.dt_rank, self.d_state, self.d_state], dim=-1)
+        dt = torch.nn.functional.linear(dt, self.dt_proj.weight)                      # the bias is added by the kernel
+        A = -torch.exp(self.A_log.float())
+        y = selective_state_update(ssm_state, x, dt, A, Bm, Cm, self.D, z=z, dt_bias=self.dt_proj.bias, dt_softplus=True)
+        out = self.out_proj(y)
+        return out.unsqueeze(1), conv_state, ssm_state
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
-        raise NotImplementedError("autoregressive decoding is outside the SegMamba hot path (SURVEY.md §2.1)")
+        """Reference :403-416."""
+        device = self.out_proj.weight.device
+        conv_dtype = self.conv1d.weight.dtype if dtype is None else dtype
+        conv_state = torch.zeros(batch_size, self.d_model * self.expand, self.d_conv, device=device, dtype=conv_dtype)
+        ssm_dtype = self.dt_proj.weight.dtype if dtype is None else dtype
+        ssm_state = torch.zeros(batch_size, self.d_model * self.expand, self.d_state, device=device, dtype=ssm_dtype)
+        return conv_state, ssm_state
+
+    def _get_states_from_cache(self, inference_params, batch_size, initialize_states=False):
+        """Reference :418-445."""
+        assert self.layer_idx is not None
+        if self.layer_idx not in inference_params.key_value_memory_dict:
+            conv_state, ssm_state = self.allocate_inference_cache(batch_size, 0)
+            inference_params.key_value_memory_dict[self.layer_idx] = (conv_state, ssm_state)
+        else:
+            conv_state, ssm_state = inference_params.key_value_memory_dict[self.layer_idx]
+            if initialize_states:
+                conv_state.zero_()
+                ssm_state.zero_()
+        return conv_state, ssm_state

@@ -508,3 +508,57 @@ def cross_entropy(lib: L.SegmLib, logits: torch.Tensor, labels: torch.Tensor, ig
     lib.check(lib.dll.segm_cross_entropy(a), "cross_entropy")
     tot = parts.sum(1)
     return tot[0], tot[1], dlogits
+
+
+# ---------------------------------------------------------------------------------------------------------
+# single-token decode steps
+# ---------------------------------------------------------------------------------------------------------
+def conv1d_update(lib: L.SegmLib, x, conv_state, weight, bias=None, silu=False):
+    """x (B, D), conv_state (B, D, W) updated in place, weight (D, W) / bias (D) fp32 -> out (B, D) of x's dtype."""
+    if x.dim() != 2 or conv_state.dim() != 3 or tuple(conv_state.shape[:2]) != tuple(x.shape) or conv_state.dtype != x.dtype:
+        raise RuntimeError("conv1d_update: x (B, D) and conv_state (B, D, W) of one dtype")
+    B, D = x.shape
+    W = conv_state.shape[2]
+    if tuple(weight.shape) != (D, W) or weight.dtype != torch.float32 or not weight.is_contiguous():
+        raise RuntimeError("conv1d_update: weight must be a contiguous fp32 (D, W) tensor")
+    if bias is not None and (tuple(bias.shape) != (D,) or bias.dtype != torch.float32 or not bias.is_contiguous()):
+        raise RuntimeError("conv1d_update: bias must be a contiguous fp32 (D) tensor")
+    out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    a = L.Conv1dUpdateArgs()
+    a.batch, a.dim, a.width, a.silu, a.dtype = B, D, W, int(bool(silu)), L.dtype_code(x)
+    a.x, a.x_stride_b, a.x_stride_d = x.data_ptr(), x.stride(0), x.stride(1)
+    a.conv_state = conv_state.data_ptr()
+    a.state_stride_b, a.state_stride_d, a.state_stride_w = conv_state.stride()
+    a.out, a.out_stride_b, a.out_stride_d = out.data_ptr(), out.stride(0), out.stride(1)
+    a.weight, a.bias, a.stream = weight.data_ptr(), L.fptr(bias), L.stream_handle(x)
+    lib.check(lib.dll.segm_causal_conv1d_update(a), "causal_conv1d_update")
+    return out
+
+
+def state_update(lib: L.SegmLib, state, x, dt, A, Bm, Cm, D=None, z=None, dt_bias=None, dt_softplus=False):
+    """state (B, D, N) updated in place; x, dt, z (B, D); Bm, Cm (B, N); A (D, N), D, dt_bias (D) fp32 -> out (B, D)."""
+    if state.dim() != 3 or x.dim() != 2 or tuple(state.shape[:2]) != tuple(x.shape):
+        raise RuntimeError("state_update: state (B, D, N), x (B, D)")
+    B, Dm, N = state.shape
+    for name, t, shape in (("dt", dt, (B, Dm)), ("B", Bm, (B, N)), ("C", Cm, (B, N))) + ((("z", z, (B, Dm)),) if z is not None else ()):
+        if tuple(t.shape) != shape or t.dtype != x.dtype:
+            raise RuntimeError(f"state_update: {name} must be {shape} of x's dtype")
+    for name, t, shape in (("A", A, (Dm, N)),) + ((("D", D, (Dm,)),) if D is not None else ()) + \
+            ((("dt_bias", dt_bias, (Dm,)),) if dt_bias is not None else ()):
+        if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError(f"state_update: {name} must be a contiguous fp32 {shape} tensor")
+    out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    a = L.StateUpdateArgs()
+    a.batch, a.dim, a.dstate, a.dt_softplus = B, Dm, N, int(bool(dt_softplus))
+    a.dtype, a.state_dtype = L.dtype_code(x), L.dtype_code(state)
+    a.state = state.data_ptr()
+    a.state_stride_b, a.state_stride_d, a.state_stride_n = state.stride()
+    for name, t in (("x", x), ("dt", dt), ("out", out)):
+        setattr(a, name, t.data_ptr()); setattr(a, name + "_stride_b", t.stride(0)); setattr(a, name + "_stride_d", t.stride(1))
+    if z is not None:
+        a.z, a.z_stride_b, a.z_stride_d = z.data_ptr(), z.stride(0), z.stride(1)
+    a.B, a.B_stride_b, a.B_stride_n = Bm.data_ptr(), Bm.stride(0), Bm.stride(1)
+    a.C, a.C_stride_b, a.C_stride_n = Cm.data_ptr(), Cm.stride(0), Cm.stride(1)
+    a.A, a.D, a.dt_bias, a.stream = A.data_ptr(), L.fptr(D), L.fptr(dt_bias), L.stream_handle(x)
+    lib.check(lib.dll.segm_selective_state_update(a), "selective_state_update")
+    return out

@@ -445,3 +445,67 @@ def test_conv_dispatcher_library_routes_on_emulated_kernels(emu, monkeypatch):
     for chain, p48 in ((False, False), (True, True)):
         dx = C3._dgrad_hip(dy, w2, x[:, :48], 1, chain, p48)
         assert (dx.float() - x2.grad).abs().max() <= 2e-2 * max(1.0, float(x2.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype,state_dtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32), (torch.float16, torch.float16)])
+def test_decode_step_kernels_emulated(emu, dtype, state_dtype):
+    """segm_causal_conv1d_update / segm_selective_state_update against the golden fixture of the reference's *_ref functions
+    (fp32) and against the oracle on strided, lower-precision inputs."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mamba_decode.npz"))
+    f = {k: torch.from_numpy(z[k]) for k in z.files}
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    # conv update: x as a strided half of a wider tensor, as Mamba.step passes it
+    xz = torch.cat([f["cu.x"], f["cu.x"] + 1], dim=1).to(dtype)
+    x = xz[:, :f["cu.x"].shape[1]]
+    cs = f["cu.state_in"].to(dtype).clone()
+    cs_ref = cs.float().clone()
+    want = ref_ops.causal_conv1d_update_ref(x.float(), cs_ref, f["cu.weight"], f["cu.bias"], "silu")
+    got = ops_raw.conv1d_update(emu, x, cs, f["cu.weight"], f["cu.bias"], True)
+    assert got.dtype == dtype and (got.float() - want).abs().max() <= tol * max(1.0, float(want.abs().max()))
+    assert torch.equal(cs.float(), cs_ref.to(dtype).float())
+    if dtype == torch.float32:
+        assert (got - f["cu.out"]).abs().max() <= 2e-5 and (cs - f["cu.state_out"]).abs().max() == 0
+    # state update
+    st = f["su.state_in"].to(state_dtype).clone()
+    st_ref = st.clone()
+    args = [f[k].to(dtype) for k in ("su.x", "su.dt")]
+    Bm, Cm, zz = f["su.B"].to(dtype), f["su.C"].to(dtype), f["su.z"].to(dtype)
+    want = ref_ops.selective_state_update_ref(st_ref, args[0].float(), args[1].float(), f["su.A"], Bm.float(), Cm.float(), f["su.D"],
+                                              z=zz.float(), dt_bias=f["su.dt_bias"], dt_softplus=True)
+    got = ops_raw.state_update(emu, st, args[0], args[1], f["su.A"], Bm, Cm, f["su.D"], zz, f["su.dt_bias"], True)
+    assert (got.float() - want).abs().max() <= tol * max(1.0, float(want.abs().max()))
+    assert (st.float() - st_ref.float()).abs().max() <= (2e-5 if state_dtype == torch.float32 else 2e-2) * max(1.0, float(st_ref.abs().max()))
+    if dtype == torch.float32:
+        assert (got - f["su.out"]).abs().max() <= 2e-5 * max(1.0, float(f["su.out"].abs().max()))
+        assert (st - f["su.state_out"]).abs().max() <= 2e-5 * max(1.0, float(f["su.state_out"].abs().max()))
+    with pytest.raises(RuntimeError):
+        ops_raw.conv1d_update(emu, x, torch.zeros(3, 10, 5, dtype=dtype), torch.zeros(10, 5), None, True)     # width 5
+
+
+def test_mamba_decode_host_path_on_emulated_kernels(emu, monkeypatch):
+    """`Mamba.forward(h, inference_params)` (prefill at seqlen_offset 0, then `step` per token) through the product's host
+    code with the kernels emulated == the reference Mamba's own run (tests/golden/make_golden_decode.py)."""
+    import types
+    monkeypatch.setattr(L, "_lib", emu)
+    from mamba_ssm import Mamba
+    f = H.load_golden("mamba_decode.npz")
+    m = Mamba(d_model=12, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=4, layer_idx=0)
+    m.load_state_dict({k[len("param."):]: v for k, v in f.items() if k.startswith("param.")})
+    h, L0 = f["h"], int(f["L0"])
+    params = types.SimpleNamespace(key_value_memory_dict={}, seqlen_offset=0)
+    with torch.no_grad():
+        out = m(h[:, :L0], inference_params=params)
+        conv, ssm = params.key_value_memory_dict[0]
+        H.assert_close(out, f["out_prefill"], 1e-4, 1e-5, "prefill out")
+        H.assert_close(conv, f["conv_state_prefill"], 1e-5, 1e-6, "prefill conv_state")
+        H.assert_close(ssm, f["ssm_state_prefill"], 1e-4, 1e-5, "prefill ssm_state")
+        outs = []
+        for t in range(L0, h.shape[1]):
+            params.seqlen_offset = t
+            outs.append(m(h[:, t:t + 1], inference_params=params))
+    H.assert_close(torch.cat(outs, 1), f["out_steps"], 1e-4, 1e-5, "step outs")
+    H.assert_close(conv, f["conv_state_final"], 1e-5, 1e-6, "final conv_state")
+    H.assert_close(ssm, f["ssm_state_final"], 1e-4, 1e-5, "final ssm_state")
+    c2, s2 = m.allocate_inference_cache(3, 0)
+    assert c2.shape == (3, 24, 4) and s2.shape == (3, 24, 16) and c2.dtype == torch.float32

@@ -96,3 +96,27 @@ def test_slice_interleave_roundtrip():
         ref = torch.stack(x.chunk(ns, dim=-1), dim=-1).flatten(-2)
         assert torch.equal(y, ref)
         assert torch.equal(ref_ops.slice_deinterleave(y, ns), x)
+
+
+def test_decode_oracle_matches_reference(golden_dir):
+    """the decode restatements (update ops, Mamba.step, prefill with inference_params) against the reference's own run."""
+    f = _load(golden_dir, "mamba_decode.npz")
+    cs = f["cu.state_in"].clone()
+    _close(ref_ops.causal_conv1d_update_ref(f["cu.x"], cs, f["cu.weight"], f["cu.bias"], "silu"), f["cu.out"])
+    _close(cs, f["cu.state_out"])
+    st = f["su.state_in"].clone()
+    out = ref_ops.selective_state_update_ref(st, f["su.x"], f["su.dt"], f["su.A"], f["su.B"], f["su.C"], f["su.D"], z=f["su.z"],
+                                             dt_bias=f["su.dt_bias"], dt_softplus=True)
+    _close(out, f["su.out"])
+    _close(st, f["su.state_out"])
+    p = {k[len("param."):]: v for k, v in f.items() if k.startswith("param.")}
+    h, L0 = f["h"], int(f["L0"])
+    conv = torch.zeros_like(f["conv_state_final"])
+    ssm = torch.zeros_like(f["ssm_state_final"])
+    _close(ref_ops.mamba_prefill_ref(h[:, :L0], p, conv, ssm), f["out_prefill"])
+    _close(conv, f["conv_state_prefill"])
+    _close(ssm, f["ssm_state_prefill"])
+    outs = [ref_ops.mamba_step_ref(h[:, t:t + 1], p, conv, ssm) for t in range(L0, h.shape[1])]
+    _close(torch.cat(outs, 1), f["out_steps"])
+    _close(conv, f["conv_state_final"])
+    _close(ssm, f["ssm_state_final"])
