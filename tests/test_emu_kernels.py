@@ -509,3 +509,32 @@ def test_mamba_decode_host_path_on_emulated_kernels(emu, monkeypatch):
     H.assert_close(ssm, f["ssm_state_final"], 1e-4, 1e-5, "final ssm_state")
     c2, s2 = m.allocate_inference_cache(3, 0)
     assert c2.shape == (3, 24, 4) and s2.shape == (3, 24, 16) and c2.dtype == torch.float32
+
+
+def test_randomised_conv3d_forward_sweep_emulated(emu):
+    """fixed-seed random shapes through every forward-convolution kernel: narrow / full input blocks, 16 / 32 / 48 / 96 output
+    channels, widths that end inside an x block, heights that force a y split, strided channel slices, all three 48-channel
+    kernel variants and in-place accumulation."""
+    rng = np.random.default_rng(1234)
+    for case in range(10):
+        B = int(rng.integers(1, 3))
+        cin = int(rng.choice([3, 17, 48, 48, 48]))
+        cout = int(rng.choice([16, 32, 48, 48, 96]))
+        D, H_ = int(rng.integers(1, 4)), int(rng.choice([1, 2, 5, 17]))
+        W = int(rng.choice([8, 16, 24, 72]))
+        g = torch.Generator().manual_seed(100 + case)
+        full = torch.randn(B, cin + 5, D, H_, W, generator=g).bfloat16()
+        x = full[:, 2:2 + cin]                                             # a strided channel slice
+        w = (0.2 * torch.randn(cout, cin, 3, 3, 3, generator=g)).bfloat16()
+        bias = torch.randn(cout, generator=g)
+        ref = torch.nn.functional.conv3d(x.float(), w.float(), bias, 1, 1)
+        tol = 1e-2 * max(1.0, float(ref.abs().max()))
+        wp = ops_raw.pack_conv3d_weight(w)
+        variants = [dict()] + ([dict(chain=True), dict(chain=True, pitch48=True)] if cout % 48 == 0 else [])
+        for kw in variants:
+            y = ops_raw.conv3d_k3_fwd(emu, x, wp, bias, **kw)
+            assert (y.float() - ref).abs().max() <= tol, (case, kw, tuple(x.shape), cout)
+            if cout % 48 == 0:
+                y2 = ops_raw.conv3d_k3_fwd(emu, x, wp, None, out=y.clone(), accumulate=True, **kw)
+                want = y.float() + (ref - bias.view(1, -1, 1, 1, 1))
+                assert (y2.float() - want).abs().max() <= 2 * tol, (case, kw, "accumulate")
