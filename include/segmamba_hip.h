@@ -46,8 +46,8 @@ enum segm_status {
     SEGM_OK = 0,
     SEGM_E_NULL = -1,        /* a required pointer is NULL                                            */
     SEGM_E_SHAPE = -2,       /* non-positive size, dim % n_groups != 0, L % nslices != 0, ...        */
-    SEGM_E_DSTATE = -3,      /* dstate outside [1, 16]  (reference limit is 256, selective_scan.cpp:247;
-                                SegMamba uses 16)                                                      */
+    SEGM_E_DSTATE = -3,      /* dstate outside [1, 16] for the scan (reference limit is 256,
+                                selective_scan.cpp:247; SegMamba uses 16), [1, 256] for the decode step   */
     SEGM_E_DTYPE = -4,       /* unknown dtype code                                                    */
     SEGM_E_WIDTH = -5,       /* conv width outside [2, 4]  (reference causal_conv1d.cpp:157)          */
     SEGM_E_WORKSPACE = -6,   /* workspace pointer NULL or too small                                   */

@@ -25,7 +25,7 @@ TIME_FORWARD, TIME_REVERSED, TIME_INTERLEAVED = 0, 1, 2
 _DTYPES = {torch.float32: SEGM_F32, torch.float16: SEGM_F16, torch.bfloat16: SEGM_BF16}
 
 _STATUS = {
-    -1: "a required pointer is NULL", -2: "bad shape / stride", -3: "dstate must be in [1, 16]",
+    -1: "a required pointer is NULL", -2: "bad shape / stride", -3: "dstate out of range ([1, 16] for the scan, [1, 256] for the decode step)",
     -4: "unsupported dtype", -5: "conv width must be in [2, 4]", -6: "workspace missing or too small",
     -7: "unknown time order",
 }
