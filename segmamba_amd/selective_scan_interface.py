@@ -93,8 +93,29 @@ class SelectiveScanFn(torch.autograd.Function):
 def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
                       return_last_state=False):
     """if return_last_state is True, returns (out, last_state); last_state has shape (batch, dim, dstate)
-    and its gradient is not considered in the backward pass (reference :76-83)."""
-    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+    and its gradient is not considered in the backward pass (reference :76-83).
+
+    The kernels keep at most 16 states per lane (SegMamba's d_state); wider state spaces (the reference accepts up to
+    256, selective_scan.cpp:247) run as a sum over 16-state blocks - the scan is linear in (B, C) blocks - with the skip
+    term in the first block and the gate applied to the sum."""
+    dstate = A.shape[-1]
+    if dstate <= 16:
+        return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+    if dstate > 256:
+        raise RuntimeError("selective_scan only supports state dimension <= 256")        # reference selective_scan.cpp:247
+    y, lasts = None, []
+    for n0 in range(0, dstate, 16):
+        blk = slice(n0, min(n0 + 16, dstate))
+        r = SelectiveScanFn.apply(u, delta, A[:, blk], B[..., blk, :], C[..., blk, :], D if n0 == 0 else None, None,
+                                  delta_bias, delta_softplus, return_last_state)
+        if return_last_state:
+            r, last = r
+            lasts.append(last)
+        y = r.float() if y is None else y + r.float()
+    if z is not None:
+        y = y * torch.nn.functional.silu(z.float())
+    y = y.to(u.dtype)
+    return (y, torch.cat(lasts, dim=-1)) if return_last_state else y
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -538,3 +538,31 @@ def test_randomised_conv3d_forward_sweep_emulated(emu):
                 y2 = ops_raw.conv3d_k3_fwd(emu, x, wp, None, out=y.clone(), accumulate=True, **kw)
                 want = y.float() + (ref - bias.view(1, -1, 1, 1, 1))
                 assert (y2.float() - want).abs().max() <= 2 * tol, (case, kw, "accumulate")
+
+
+@pytest.mark.parametrize("dstate,groups", [(40, 1), (32, 2)])
+def test_selective_scan_fn_wide_state_on_emulated_kernels(emu, monkeypatch, dstate, groups):
+    """dstate > 16 (the reference takes up to 256): blocks of 16 states summed by the host wrapper, against the oracle's
+    selective_scan_ref - output, last state and every gradient."""
+    monkeypatch.setattr(L, "_lib", emu)
+    from mamba_ssm.ops.selective_scan_interface import selective_scan_fn
+    g = torch.Generator().manual_seed(dstate)
+    Bsz, D, Lq = 1, 4, 24
+    shape_bc = (Bsz, groups, dstate, Lq) if groups > 1 else (Bsz, dstate, Lq)
+    t = {"u": torch.randn(Bsz, D, Lq, generator=g), "delta": 0.5 * torch.rand(Bsz, D, Lq, generator=g),
+         "A": -0.5 * torch.rand(D, dstate, generator=g) - 0.05, "B": torch.randn(shape_bc, generator=g),
+         "C": torch.randn(shape_bc, generator=g), "D": torch.randn(D, generator=g), "z": torch.randn(Bsz, D, Lq, generator=g),
+         "delta_bias": 0.5 * torch.rand(D, generator=g)}
+    dout = torch.randn(Bsz, D, Lq, generator=g)
+    res = {}
+    for name, fn in (("hip", selective_scan_fn), ("ref", ref_ops.selective_scan_ref)):
+        leaves = {k: v.clone().requires_grad_() for k, v in t.items()}
+        out, last = fn(leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves["D"], z=leaves["z"],
+                       delta_bias=leaves["delta_bias"], delta_softplus=True, return_last_state=True)
+        out.backward(dout)
+        res[name] = (out.detach(), last.detach(), {k: v.grad for k, v in leaves.items()})
+    H.assert_close(res["hip"][0], res["ref"][0], 1e-4, 1e-4, "out")
+    H.assert_close(res["hip"][1], res["ref"][1], 1e-4, 1e-4, "last_state")
+    for k in t:
+        r = res["ref"][2][k]
+        H.assert_close(res["hip"][2][k], r, 1e-3, 1e-3 * max(1.0, float(r.abs().max())), "d" + k)
