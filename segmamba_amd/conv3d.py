@@ -36,15 +36,19 @@ _cache: Dict[tuple, int] = {}
 _TUNE = os.environ.get("SEGM_CONV_AUTOTUNE", "1") == "1"
 
 
-def _time(fn: Callable[[], torch.Tensor]) -> float:
+def _time(fn: Callable[[], torch.Tensor], reps: int = 3) -> float:
+    """median of `reps` timed calls after one warm-up call (close candidates differ by a few per cent)"""
     fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1)
+    times = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1))
+    return sorted(times)[len(times) // 2]
 
 
 def _pick(key: tuple, cands: List[Callable[[], torch.Tensor]]) -> torch.Tensor:
