@@ -222,9 +222,11 @@ size_t segm_conv3d_k3_wgrad_workspace_bytes(int32_t batch, int32_t cin, int32_t 
  * flags: SEGM_CONV_FWD_ACCUMULATE adds the result to what `y` already holds (the 48-channel blocks of a wider layer
  * accumulate in place); SEGM_CONV_FWD_CHAIN (cout % 48 == 0 only) selects the kernel whose K parts are pipelined
  * through LDS instead of reduced at every output row - same results up to the order of fp32 additions;
- * SEGM_CONV_FWD_PITCH48 (with CHAIN only) lays its LDS rows out without padding (a bank-conflict experiment).
+ * SEGM_CONV_FWD_PITCH48 (with CHAIN only) lays its LDS rows out without padding (a bank-conflict experiment);
+ * SEGM_CONV_FWD_CHAIN32 (alone or with ACCUMULATE) is the chained kernel on 32-wide x blocks, two workgroups per CU.
  * ------------------------------------------------------------------------------------------------ */
-enum segm_conv_fwd_flags { SEGM_CONV_FWD_ACCUMULATE = 1, SEGM_CONV_FWD_CHAIN = 2, SEGM_CONV_FWD_PITCH48 = 4 };
+enum segm_conv_fwd_flags { SEGM_CONV_FWD_ACCUMULATE = 1, SEGM_CONV_FWD_CHAIN = 2, SEGM_CONV_FWD_PITCH48 = 4,
+                           SEGM_CONV_FWD_CHAIN32 = 8 };
 
 typedef struct segm_conv3d_fwd_args {
     int32_t batch, cin, cout, depth, height, width;

@@ -84,7 +84,7 @@ def _hip_fwd_ok(x, w) -> bool:
         ops_raw.conv3d_k3_fwd_supported(x[:, :_BLOCK], w.shape[0])
 
 
-def _fwd_hip(x, w, pad, bias=None, chain=False, pitch48=False):
+def _fwd_hip(x, w, pad, bias=None, chain=False, pitch48=False, chain32=False):
     """segm_conv3d_k3_fwd per 48-channel input block (the kernel keeps one block's weights in registers).  With
     Cout % 48 == 0 the later blocks accumulate into the first block's output in place; `chain` picks the kernel whose K
     parts are pipelined (csrc/conv3d_fwd.hip, variant 1)."""
@@ -96,7 +96,7 @@ def _fwd_hip(x, w, pad, bias=None, chain=False, pitch48=False):
         wp = ops_raw.pack_conv3d_weight(w[:, ib], x.dtype)
         if inplace:
             out = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None, out=out, accumulate=i > 0, chain=chain,
-                                        pitch48=pitch48)
+                                        pitch48=pitch48, chain32=chain32)
         else:
             y = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None)
             out = y if out is None else out + y
@@ -139,8 +139,8 @@ def _dgrad_as_fwd_blocked(dy, w, x, pad):
     return _fwd_blocked(dy, _flipT(w), pad)
 
 
-def _dgrad_hip(dy, w, x, pad, chain=False, pitch48=False):
-    return _fwd_hip(dy, _flipT(w), pad, None, chain, pitch48)
+def _dgrad_hip(dy, w, x, pad, chain=False, pitch48=False, chain32=False):
+    return _fwd_hip(dy, _flipT(w), pad, None, chain, pitch48, chain32)
 
 
 def _wgrad_native(x, dy, w, pad):
@@ -196,6 +196,7 @@ class _ConvSame(torch.autograd.Function):
         if chain:
             cands.append(lambda: _fwd_hip(x, w, pad, bias, True))
             cands.append(lambda: _fwd_hip(x, w, pad, bias, True, True))      # unpadded LDS rows (not yet measured)
+            cands.append(lambda: _fwd_hip(x, w, pad, bias, False, False, True))      # 32-wide x blocks (not yet measured)
         return _pick(key, cands)
 
     @staticmethod
@@ -216,6 +217,7 @@ class _ConvSame(torch.autograd.Function):
             if chain:
                 cands.append(lambda: _dgrad_hip(dy, w, x, pad, True))
                 cands.append(lambda: _dgrad_hip(dy, w, x, pad, True, True))
+                cands.append(lambda: _dgrad_hip(dy, w, x, pad, False, False, True))
             dx = _pick(("dgrad", tuple(x.shape), tuple(w.shape), x.dtype, hip, chain), cands)
         if ctx.needs_input_grad[1]:
             cands = [lambda: _wgrad_native(x, dy, w, pad)]

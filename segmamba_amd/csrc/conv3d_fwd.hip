@@ -287,10 +287,11 @@ __device__ __forceinline__ void row_fetch(RowRegs& r, const char* rb, const Copy
         r.c[0] = *reinterpret_cast<const uint16_t*>(rb + L.goff1);
     }
 }
-template <typename T, int CP = kFwCP>
+template <typename T, int CP = kFwCP, bool GUARD = false>   // GUARD: granule waves may hold lanes without a task
 __device__ __forceinline__ void row_park(const RowRegs& r, char* ring_row, const CopyLane& L, bool halo_wave) {
     char* dst = ring_row + L.loff;
     if (!halo_wave) {
+        if (GUARD && !L.has) return;
         u32x4 a = r.a, c = r.c;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { a[i] = L.live0 ? a[i] : 0u; c[i] = L.live1 ? c[i] : 0u; }
@@ -610,14 +611,208 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The chained kernel on 32-wide x blocks (SEGM_CONV_FWD_CHAIN32): four waves = the four K parts, one pair of x tiles, unpadded
+// LDS rows.  Ring 12 x 34 x 48 x 2 B = 39.2 KB + hand-off 36.9 KB = 76 KB, so TWO workgroups share a CU: the same eight
+// waves per CU as above, but in two independent barrier domains - one workgroup's hand-off / staging / barrier phases can
+// overlap the other's MFMA phase instead of all eight waves walking through the phases in lockstep.  (Written after the GPU
+// budget of round 1 was spent: parity-tested on the emulator, not yet timed; the dispatcher times it per shape.)
+// Staging per step: wave p < 3 moves plane p's 96 granule tasks (two slots: 64 + 32 lanes), wave 3 - the storing wave - the
+// 48 halo tasks of each of the three planes.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kC32XB = 32;                        // x positions per workgroup
+constexpr int kC32XP = kC32XB + 2;                // ring positions per row
+constexpr int kC32CP = 48;                        // ci pitch (elements): unpadded
+
+template <typename T>
+__device__ __forceinline__ CopyLane copy_lane32(const ConvFwdDev& P, bool halo, int j, int x0) {
+    CopyLane L;
+    int tcp, x, pos;
+    if (!halo) {
+        const int gr = j / 24;
+        tcp = j - gr * 24;
+        L.has = j < 4 * 24;
+        if (!L.has) tcp = 0;
+        x = x0 + 8 * (L.has ? gr : 0);
+        pos = 1 + 8 * (L.has ? gr : 0);
+    } else {
+        const int side = j >= 24 ? 1 : 0;
+        tcp = j - side * 24;
+        L.has = j < 48;
+        if (!L.has) tcp = 0;
+        x = side ? x0 + kC32XB : x0 - 1;
+        pos = side ? kC32XB + 1 : 0;
+    }
+    const bool inside = L.has && x >= 0 && x < P.W;
+    L.live0 = inside && 2 * tcp < P.cin;
+    L.live1 = inside && 2 * tcp + 1 < P.cin;
+    const int64_t xs = inside ? x : 0;
+    L.goff0 = (uint32_t)(((int64_t)(L.live0 ? 2 * tcp : 0) * P.x_sc + xs) * (int64_t)sizeof(T));
+    L.goff1 = (uint32_t)(((int64_t)(L.live1 ? 2 * tcp + 1 : 0) * P.x_sc + xs) * (int64_t)sizeof(T));
+    L.loff = (uint32_t)((pos * kC32CP + 2 * tcp) * (int)sizeof(T));
+    return L;
+}
+
+template <typename T, bool ACC>
+__global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwdDev P) {
+    typedef typename Mfma16<T>::v8 frag8;
+    constexpr int XT = 2, CP = kC32CP;
+    constexpr int kSlot = kC32XP * CP;                    // elements per ring row
+    __shared__ __attribute__((aligned(16))) T xs[3][4][kSlot];
+    __shared__ __attribute__((aligned(16))) f32x4 hand[2][3][3 * XT][64];         // [buffer][link p -> p + 1][co tile * XT + x tile][lane]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int part = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int cob = blockIdx.y;                           // block of 48 output channels
+    int item = blockIdx.x;
+    const int ypart = item % P.ysplit;  item /= P.ysplit;
+    const int xb = item % P.nxb;        item /= P.nxb;
+    const int z = item % P.D, b = item / P.D;
+    const int y0 = ypart * P.rows_per_part;
+    const int y1 = (y0 + P.rows_per_part < P.H) ? y0 + P.rows_per_part : P.H;
+    const int x0 = xb * kC32XB;
+    const int c_begin = part == 0 ? 0 : 11 + 10 * (part - 1);     // first chunk of this K part
+    const int c_count = part == 0 ? 11 : 10;
+
+    // ---- stationary weights and the matching A fragment offsets (x tile 0) ---------------------------------------------------
+    frag8 wf[3][kF48Chunks];
+    int32_t aoff[kF48Chunks];                             // LDS element offset without the row slot; ky in bits 28..29
+#pragma unroll
+    for (int c = 0; c < kF48Chunks; ++c) {
+        const int k = 32 * (c_begin + c) + 8 * g;
+        const bool live = c < c_count && k < kF48K;
+        const int kk = live ? k : 0;
+        const int tap = kk / kFwCi, ci0 = kk - tap * kFwCi;
+        const int tz = tap / 9, ty = (tap - tz * 9) / 3, tx = tap - tz * 9 - ty * 3;
+        aoff[c] = (tz * 4 * kSlot + (i16 + tx) * CP + ci0) | (ty << 28);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int co = cob * 48 + t * 16 + i16;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(P.wp) + (int64_t)co * kF48K + kk);
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            wf[t][c] = __builtin_bit_cast(frag8, live ? w : zero);
+        }
+    }
+    float bias[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bias[t] = P.bias ? P.bias[cob * 48 + t * 16 + i16] : 0.f;
+
+    // ---- row staging: plane q's incoming row during step s is s + {2, 0, -1}[q] -----------------------------------------------
+    // waves 0 - 2: slots 0 / 1 = granule tasks lane / 64 + lane of plane `part`; wave 3: slots 0 - 2 = halo tasks of planes 0 - 2
+    const bool halo_wave = part == 3;
+    const CopyLane cl0 = copy_lane32<T>(P, halo_wave, lane, x0);
+    const CopyLane cl1 = copy_lane32<T>(P, halo_wave, halo_wave ? lane : 64 + lane, x0);
+    char* ring = reinterpret_cast<char*>(&xs[0][0][0]);
+    auto srow = [&](int pl, int base, bool skewed) { return base + (skewed ? (pl == 0 ? 2 : (pl == 1 ? 0 : -1)) : 0); };
+    auto fetch = [&](RowRegs (&r)[3], int base, bool skewed) {
+        if (!halo_wave) {
+            const char* rb = row_base<T>(P, b, z + part - 1, srow(part, base, skewed));
+            row_fetch<T>(r[0], rb, cl0, false);
+            row_fetch<T>(r[1], rb, cl1, false);
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) row_fetch<T>(r[pl], row_base<T>(P, b, z + pl - 1, srow(pl, base, skewed)), cl0, true);
+        }
+    };
+    auto park = [&](const RowRegs (&r)[3], int base, bool skewed) {
+        if (!halo_wave) {
+            char* row = ring + (part * 4 + ((srow(part, base, skewed) + 8) & 3)) * kSlot * (int)sizeof(T);
+            row_park<T, CP, true>(r[0], row, cl0, false);
+            row_park<T, CP, true>(r[1], row, cl1, false);
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                row_park<T, CP>(r[pl], ring + (pl * 4 + ((srow(pl, base, skewed) + 8) & 3)) * kSlot * (int)sizeof(T), cl0, true);
+        }
+    };
+
+    if (y1 <= y0) return;
+    {   // prologue: rows y0 - 1, y0, y0 + 1 of every plane (planes 1 and 2 re-park theirs on schedule; same slot, same data)
+        RowRegs r[3];
+#pragma unroll
+        for (int d = -1; d <= 1; ++d) {
+            fetch(r, y0 + d, false);
+            park(r, y0 + d, false);
+        }
+    }
+    __syncthreads();
+    for (int s = y0; s < y1 + 3; ++s) {
+        const int row = s - part;                         // this part's output row
+        const bool active = row >= y0 && row < y1;
+        f32x4 acc[3][XT];
+        frag8 a[2][XT];
+        const T* pl = &xs[0][0][0];
+        auto load_a = [&](frag8 (&dst)[XT], int c) {
+            const int slot = (row + (aoff[c] >> 28) + 7) & 3;              // input row = row + ky - 1
+            const T* ap = pl + slot * kSlot + (aoff[c] & 0x0fffffff);
+#pragma unroll
+            for (int u = 0; u < XT; ++u) dst[u] = *reinterpret_cast<const frag8*>(ap + u * 16 * CP);
+        };
+        if (active) {
+            if (part == 0) {                              // the chain starts from the bias (a lane's four results share a co)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int u = 0; u < XT; ++u) acc[t][u] = f32x4{bias[t], bias[t], bias[t], bias[t]};
+            } else {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int u = 0; u < XT; ++u) acc[t][u] = hand[(s + 1) & 1][part - 1][t * XT + u][lane];
+            }
+            load_a(a[0], 0);
+        }
+        RowRegs r[3];
+        fetch(r, s, true);                                // in flight during this step's MFMAs
+        SEGM_SCHED_FENCE();
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < kF48Chunks; ++c) {
+                if (c + 1 < kF48Chunks) load_a(a[(c + 1) & 1], c + 1);     // one chunk (6 MFMAs) ahead of its use
+                SEGM_SCHED_FENCE();
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int u = 0; u < XT; ++u) acc[t][u] = Mfma16<T>::run(a[c & 1][u], wf[t][c], acc[t][u]);
+                SEGM_SCHED_FENCE();
+            }
+            if (part < 3) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int u = 0; u < XT; ++u) hand[s & 1][part][t * XT + u][lane] = acc[t][u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < XT; ++u) {
+                    const int xg = x0 + u * 16 + 4 * g;   // this lane's 4 output positions
+                    if (xg >= P.W) continue;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = acc[t][u][q];
+                        const int co = cob * 48 + t * 16 + i16;
+                        T* dst = reinterpret_cast<T*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
+                                      (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + xg;
+                        store4<T, ACC>(dst, v);
+                    }
+                }
+            }
+        }
+        SEGM_SCHED_FENCE();
+        park(r, s, true);
+        __syncthreads();                                  // incoming rows and the hand-off tiles are in LDS
+    }
+}
+
 struct FwPlan { int nxb, ysplit, rows_per_part, nitems; };
-static FwPlan fwd_plan(int batch, int cout, int d, int h, int w, bool chain = false) {
+static FwPlan fwd_plan(int batch, int cout, int d, int h, int w, bool chain = false, int xb = kFwXB) {
     FwPlan p;
-    p.nxb = (w + kFwXB - 1) / kFwXB;
-    // cut y when there are too few workgroups for 256 CUs.  The chained kernel pays three drain steps per cut and runs one
-    // workgroup per CU, so it stops at one workgroup per CU; the other kernels aim for two rounds.
+    p.nxb = (w + xb - 1) / xb;
+    // cut y when there are too few workgroups for 256 CUs.  The chained kernels pay three drain steps per cut, so they stop
+    // at one workgroup per slot (one per CU for 64-wide x blocks, two for 32-wide ones); the other kernels aim for two rounds.
     const int64_t wgs = (int64_t)batch * d * p.nxb * (chain ? (cout + 47) / 48 : (cout + kFwCo - 1) / kFwCo);
-    const int64_t target = chain ? 256 : 512;
+    const int64_t target = chain ? (xb == kFwXB ? 256 : 512) : 512;
     int split = 1;
     while (wgs * split < target && h / (split * 2) >= 8) split *= 2;
     p.ysplit = split;
@@ -649,8 +844,9 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     if (a->cin < 1 || a->cin > kFwCi || a->cout <= 0 || a->cout % 16 != 0) return SEGM_E_SHAPE;
     if (a->width % 8 != 0) return SEGM_E_SHAPE;
     if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
-    if (a->flags & ~(SEGM_CONV_FWD_ACCUMULATE | SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_PITCH48)) return SEGM_E_SHAPE;
-    if ((a->flags & SEGM_CONV_FWD_CHAIN) && a->cout % 48 != 0) return SEGM_E_SHAPE;
+    if (a->flags & ~(SEGM_CONV_FWD_ACCUMULATE | SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_PITCH48 | SEGM_CONV_FWD_CHAIN32)) return SEGM_E_SHAPE;
+    if ((a->flags & (SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_CHAIN32)) && a->cout % 48 != 0) return SEGM_E_SHAPE;
+    if ((a->flags & SEGM_CONV_FWD_CHAIN32) && (a->flags & (SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_PITCH48))) return SEGM_E_SHAPE;
     if ((a->flags & SEGM_CONV_FWD_PITCH48) && !(a->flags & SEGM_CONV_FWD_CHAIN)) return SEGM_E_SHAPE;
     const int64_t st[8] = {a->x_stride_b, a->x_stride_c, a->x_stride_z, a->x_stride_y,
                            a->y_stride_b, a->y_stride_c, a->y_stride_z, a->y_stride_y};
@@ -665,14 +861,24 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     P.wp = a->w_packed;
     P.bias = a->bias;
     P.B = a->batch; P.D = a->depth; P.H = a->height; P.W = a->width; P.cout = a->cout; P.cin = a->cin;
-    const FwPlan pl = fwd_plan(a->batch, a->cout, a->depth, a->height, a->width, (a->flags & SEGM_CONV_FWD_CHAIN) != 0);
+    const bool chain32 = (a->flags & SEGM_CONV_FWD_CHAIN32) != 0;
+    const FwPlan pl = fwd_plan(a->batch, a->cout, a->depth, a->height, a->width, (a->flags & (SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_CHAIN32)) != 0,
+                               chain32 ? kC32XB : kFwXB);
     P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part;
     hipStream_t stream = (hipStream_t)a->stream;
     const bool f16 = a->dtype == SEGM_F16;
     const bool acc = (a->flags & SEGM_CONV_FWD_ACCUMULATE) != 0;
     // the 48-channel kernels address a row as [uniform base + 32-bit lane offset]: 48 channel strides must fit
     const bool off32 = ((int64_t)47 * a->x_stride_c + a->width) * 2 < ((int64_t)1 << 32);
-    if ((a->flags & SEGM_CONV_FWD_CHAIN) && !off32) return SEGM_E_SHAPE;
+    if ((a->flags & (SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_CHAIN32)) && !off32) return SEGM_E_SHAPE;
+    if (chain32) {
+        const dim3 grid(pl.nitems, a->cout / 48);
+#define SEGM_L32(T, A) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, A>), grid, dim3(256), 0, stream, P)
+        if (f16) { if (acc) SEGM_L32(f16_t, true); else SEGM_L32(f16_t, false); }
+        else { if (acc) SEGM_L32(bf16_t, true); else SEGM_L32(bf16_t, false); }
+#undef SEGM_L32
+        return (int)hipGetLastError();
+    }
     if (a->flags & SEGM_CONV_FWD_CHAIN) {
         if (a->flags & SEGM_CONV_FWD_PITCH48) launch48<48>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
         else launch48<kFwCP>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);

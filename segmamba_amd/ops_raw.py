@@ -282,22 +282,25 @@ def conv3d_k3_fwd_supported(x: torch.Tensor, cout: int) -> bool:
     return x.stride(4) == 1 and not any(x.stride(i) % 8 for i in range(4)) and x.data_ptr() % 16 == 0
 
 
-CONV_FWD_ACCUMULATE, CONV_FWD_CHAIN, CONV_FWD_PITCH48 = 1, 2, 4            # segm_conv_fwd_flags
+CONV_FWD_ACCUMULATE, CONV_FWD_CHAIN, CONV_FWD_PITCH48, CONV_FWD_CHAIN32 = 1, 2, 4, 8     # segm_conv_fwd_flags
 
 
 def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None, accumulate: bool = False, chain: bool = False,
-                  pitch48: bool = False) -> torch.Tensor:
+                  pitch48: bool = False, chain32: bool = False) -> torch.Tensor:
     """y (B, Cout, D, H, W) = conv3d(x, w, bias, stride 1, padding 1); x (B, <= 48, D, H, W) bf16 / fp16, w_packed from
     pack_conv3d_weight().  `out` + `accumulate`: add to an existing result (the next 48-channel block of a wider
-    layer; Cout % 48 == 0).  `chain`: the pipelined-K-parts kernel (Cout % 48 == 0); `pitch48`: its unpadded LDS layout."""
+    layer; Cout % 48 == 0).  `chain`: the pipelined-K-parts kernel (Cout % 48 == 0); `pitch48`: its unpadded LDS layout; `chain32`: the
+    same pipeline on 32-wide x blocks, two workgroups per CU (exclusive with `chain`)."""
     cout = w_packed.shape[0]
     if not conv3d_k3_fwd_supported(x, cout):
         raise RuntimeError("conv3d_k3_fwd: unsupported shape / dtype / layout")
     if tuple(w_packed.shape[1:]) != (3, 3, 3, 48) or w_packed.dtype != x.dtype or not w_packed.is_contiguous():
         raise RuntimeError("conv3d_k3_fwd: w_packed must be a contiguous (Cout, 3, 3, 3, 48) tensor of x's dtype")
-    if (accumulate or chain) and cout % 48:
+    if (accumulate or chain or chain32) and cout % 48:
         raise RuntimeError("conv3d_k3_fwd: accumulate / chain need Cout % 48 == 0")
+    if chain32 and (chain or pitch48):
+        raise RuntimeError("conv3d_k3_fwd: chain32 excludes chain / pitch48")
     B, _, D, H, W = x.shape
     if out is None:
         if accumulate:
@@ -315,7 +318,8 @@ def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias:
     a.dtype = L.dtype_code(x)
     if pitch48 and not chain:
         raise RuntimeError("conv3d_k3_fwd: pitch48 is a variant of the chained kernel")
-    a.flags = (CONV_FWD_ACCUMULATE if accumulate else 0) | (CONV_FWD_CHAIN if chain else 0) | (CONV_FWD_PITCH48 if pitch48 else 0)
+    a.flags = (CONV_FWD_ACCUMULATE if accumulate else 0) | (CONV_FWD_CHAIN if chain else 0) | (CONV_FWD_PITCH48 if pitch48 else 0) | \
+        (CONV_FWD_CHAIN32 if chain32 else 0)
     a.x, a.y, a.w_packed = x.data_ptr(), y.data_ptr(), w_packed.data_ptr()
     a.x_stride_b, a.x_stride_c, a.x_stride_z, a.x_stride_y = x.stride()[:4]
     a.y_stride_b, a.y_stride_c, a.y_stride_z, a.y_stride_y = y.stride()[:4]

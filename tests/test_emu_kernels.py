@@ -282,6 +282,8 @@ def test_conv3d_k3_fwd_chained_k_parts_emulated(emu, shape):
     assert (y.float() - ref0).abs().max() <= tol
     y48 = ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:, :48]), bias, chain=True, pitch48=True)
     assert torch.equal(y48, y)                                                                               # same sums, other LDS layout
+    y32 = ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:, :48]), bias, chain32=True)
+    assert torch.equal(y32, y)                                                                               # same sums, 32-wide x blocks
     if shape != (1, 48, 2, 2, 16):
         return
     ref = torch.nn.functional.conv3d(x.float(), w.float(), bias, 1, 1)
@@ -436,14 +438,14 @@ def test_conv_dispatcher_library_routes_on_emulated_kernels(emu, monkeypatch):
     ref = torch.nn.functional.conv3d(xr, w.float(), bias.float(), 1, 1)
     ref.backward(dy.float())
     assert C3._hip_fwd_ok(x, w) and C3._hip_chain_ok(w)
-    for chain, p48 in ((False, False), (True, False), (True, True)):
-        y = C3._fwd_hip(x, w, 1, bias, chain, p48)
+    for chain, p48, c32 in ((False, False, False), (True, False, False), (True, True, False), (False, False, True)):
+        y = C3._fwd_hip(x, w, 1, bias, chain, p48, c32)
         assert (y.float() - ref.detach()).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max()))
     w2 = w[:, :48].contiguous()                            # data gradient: 48 -> 48 (flipped weights: Cout' = 48)
     x2 = x[:, :48].float().requires_grad_()
     torch.nn.functional.conv3d(x2, w2.float(), None, 1, 1).backward(dy.float())
-    for chain, p48 in ((False, False), (True, True)):
-        dx = C3._dgrad_hip(dy, w2, x[:, :48], 1, chain, p48)
+    for chain, p48, c32 in ((False, False, False), (True, True, False), (False, False, True)):
+        dx = C3._dgrad_hip(dy, w2, x[:, :48], 1, chain, p48, c32)
         assert (dx.float() - x2.grad).abs().max() <= 2e-2 * max(1.0, float(x2.grad.abs().max()))
 
 
@@ -530,7 +532,7 @@ def test_randomised_conv3d_forward_sweep_emulated(emu):
         ref = torch.nn.functional.conv3d(x.float(), w.float(), bias, 1, 1)
         tol = 1e-2 * max(1.0, float(ref.abs().max()))
         wp = ops_raw.pack_conv3d_weight(w)
-        variants = [dict()] + ([dict(chain=True), dict(chain=True, pitch48=True)] if cout % 48 == 0 else [])
+        variants = [dict()] + ([dict(chain=True), dict(chain=True, pitch48=True), dict(chain32=True)] if cout % 48 == 0 else [])
         for kw in variants:
             y = ops_raw.conv3d_k3_fwd(emu, x, wp, bias, **kw)
             assert (y.float() - ref).abs().max() <= tol, (case, kw, tuple(x.shape), cout)

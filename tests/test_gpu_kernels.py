@@ -418,11 +418,12 @@ def test_conv3d_k3_fwd_chained_k_parts(hip, shape):
     assert (y.float() - ref0).abs().max() <= tol
     assert torch.equal(ops_raw.conv3d_k3_fwd(hip, x[:, :48], w0, bias, chain=True), y)          # deterministic
     assert torch.equal(ops_raw.conv3d_k3_fwd(hip, x[:, :48], w0, bias, chain=True, pitch48=True), y)   # other LDS layout, same sums
+    assert torch.equal(ops_raw.conv3d_k3_fwd(hip, x[:, :48], w0, bias, chain32=True), y)               # 32-wide x blocks, same sums
     yd = ops_raw.conv3d_k3_fwd(hip, x[:, :48], w0, bias)
     assert (y.float() - yd.float()).abs().max() <= tol                                           # same sums, other order
-    for chain in (True, False):
+    for kw in (dict(chain=True), dict(), dict(chain32=True)):
         acc = yd.clone()
-        ops_raw.conv3d_k3_fwd(hip, x[:, 48:], w1, None, out=acc, accumulate=True, chain=chain)
+        ops_raw.conv3d_k3_fwd(hip, x[:, 48:], w1, None, out=acc, accumulate=True, **kw)
         assert (acc.float() - ref).abs().max() <= 2 * tol
 
 
