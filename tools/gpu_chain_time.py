@@ -26,16 +26,20 @@ for (B, cin, cout, S) in [(2, 48, 48, 128), (2, 48, 48, 64), (2, 96, 96, 64), (2
     w = (0.05 * torch.randn(cout, cin, 3, 3, 3, device=dev)).bfloat16()
     wps = [ops_raw.pack_conv3d_weight(w[:, i:i + 48]) for i in range(0, cin, 48)]
 
-    def run(chain):
+    def run(**kw):
         out = None
         for i, wp in enumerate(wps):
-            out = ops_raw.conv3d_k3_fwd(hip, x[:, 48 * i:48 * i + 48], wp, None, out=out, accumulate=i > 0, chain=chain)
+            out = ops_raw.conv3d_k3_fwd(hip, x[:, 48 * i:48 * i + 48], wp, None, out=out, accumulate=i > 0, **kw)
         return out
     try:
-        t0, t1 = timeit(lambda: run(False)), timeit(lambda: run(True))
-        d = (run(False).float() - run(True).float()).abs().max().item()
         fl = 2.0 * B * S ** 3 * cin * cout * 27
-        print(f"conv fwd {cin}->{cout} @{S}^3 B={B}: default {t0:.3f} ms ({fl / t0 / 1e9:.0f} TF/s)  chain {t1:.3f} ms ({fl / t1 / 1e9:.0f} TF/s)  maxdiff {d:.3g}", flush=True)
+        base = run()
+        line = f"conv fwd {cin}->{cout} @{S}^3 B={B}:"
+        for name, kw in (("reduce", {}), ("chain", dict(chain=True)), ("chain48", dict(chain=True, pitch48=True)), ("chain32", dict(chain32=True))):
+            t = timeit(lambda: run(**kw))
+            d = (run(**kw).float() - base.float()).abs().max().item()
+            line += f"  {name} {t:.3f} ms ({fl / t / 1e9:.0f} TF/s, maxdiff {d:.2g})"
+        print(line, flush=True)
     except RuntimeError as e:
         print(f"conv fwd {cin}->{cout} @{S}^3: {e}", flush=True)
 
