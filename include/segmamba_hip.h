@@ -438,6 +438,27 @@ typedef struct segm_state_update_args {
 
 int segm_selective_state_update(const segm_state_update_args* args);
 
+/* ------------------------------------------------------------------------------------------------
+ * Row-streaming projection  y[m, :] = x[m, :] W^T + bias  for tall activations (rows >> k, n).
+ * Replaces the `nn.Linear` calls of the Mamba block on (batch * length, channels) activations - in_proj, x_proj,
+ * out_proj - and their data gradients (reference mamba_simple.py:204-208, 264; selective_scan_interface.py:185-205,
+ * 247-275), which the reference hands to cuBLAS.  x (rows, k) and y (rows, n) with element row strides (views into wider
+ * tensors are fine), w (n, k) contiguous - the nn.Linear layout - all of one 16-bit dtype; bias (n) fp32 or NULL.
+ * k a multiple of 8, at most 192; n a multiple of 4; x rows 16-byte aligned, y rows 8-byte aligned.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_linear_args {
+    int64_t rows;
+    int32_t k, n;
+    int32_t dtype, reserved;
+    const void* x;      int64_t x_stride_row;
+    const void* w;
+    const float* bias;
+    void* y;            int64_t y_stride_row;
+    void* stream;
+} segm_linear_args;
+
+int segm_linear_rows(const segm_linear_args* args);
+
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);
 const char* segm_status_string(int status);

@@ -1,0 +1,154 @@
+// Row-streaming projection  y[m, :] = x[m, :] W^T + bias  for tall activations (C ABI: segm_linear_rows).
+//
+// Replaces the `nn.Linear` / `F.linear` calls of the Mamba block on (batch * length) x channels activations - in_proj,
+// x_proj, out_proj and their data gradients (reference mamba/mamba_ssm/modules/mamba_simple.py:204-208, 264;
+// selective_scan_interface.py:185-205, 247-275) - which the reference hands to cuBLAS.  With M = B L up to 524 288 rows and
+// K, N between 48 and 384 these are streaming operators: 9.7 GFLOP against 250 MB at stage 0.  The BLAS library runs them at
+// ~1 TB/s (profiles/r01_bench_step_kernels_v11.txt: 13 launches of 225 us where the traffic needs ~45 us).
+//
+//   * W (N x K, at most 192 x 192 per block of output columns) is STATIONARY in registers as MFMA A-operand fragments;
+//   * a wave walks 16-row tiles of x: each lane loads its B-operand fragments straight from global memory (16 bytes of
+//     one row per fragment), the next tile's loads are in flight during the current tile's MFMAs;
+//   * D = W x^T, so a lane ends up with four consecutive output columns of one row: 8-byte stores, no LDS anywhere.
+// v_mfma_f32_16x16x32: A[i][k]: lane l holds A[i = l & 15][8 (l >> 4) .. +7]; B[k][j]: lane l holds B[8 (l >> 4) .. +7][j = l & 15];
+// D[row = 4 (l >> 4) + r][col = l & 15].  Here i = output column n, j = row m.
+#include <string.h>
+
+#include "segm_device.h"
+
+namespace segm {
+
+typedef float lin_f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t lin_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t lin_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kLinWaves = 4;
+constexpr int kLinTilesPerWave = 8;          // 16-row tiles a wave walks (amortises the weight fragment loads)
+
+struct LinDev {
+    const char* x;  int64_t ldx;             // element stride between rows
+    const char* w;
+    const float* bias;
+    char* y;        int64_t ldy;
+    int64_t rows;
+    int32_t k, n;
+};
+
+// KC = 32-wide chunks of K held per wave; NT = 16-column tiles of W per wave (at most 24 fragments = 96 VGPRs, which
+// leaves room for two to three waves per SIMD - the kernel lives on memory-level parallelism)
+constexpr int lin_tiles(int kc) { return kc <= 2 ? 12 : (kc == 3 ? 8 : (kc == 4 ? 6 : 4)); }
+template <typename T, int KC>
+__global__ void __launch_bounds__(kLinWaves * 64) linear_rows_kernel(LinDev P) {
+    typedef typename Mfma16<T>::v8 frag8;
+    constexpr int NT = lin_tiles(KC);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.y * NT * 16;
+    int nt_live = (P.n - n0 + 15) / 16;
+    nt_live = nt_live > NT ? NT : nt_live;
+    const T* W = reinterpret_cast<const T*>(P.w);
+
+    frag8 wf[NT][KC];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + 16 * t + i16;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int k = 32 * c + 8 * g;
+            const bool live = t < nt_live && n < P.n && k < P.k;
+            const lin_u32x4 v = *reinterpret_cast<const lin_u32x4*>(W + (int64_t)(live ? n : 0) * P.k + (live ? k : 0));
+            const lin_u32x4 zero = {0u, 0u, 0u, 0u};
+            wf[t][c] = __builtin_bit_cast(frag8, live ? v : zero);
+        }
+    }
+
+    const int64_t ntiles = (P.rows + 15) / 16;
+    const int64_t first = ((int64_t)blockIdx.x * kLinWaves + wave) * kLinTilesPerWave;
+    auto load_x = [&](frag8 (&dst)[KC], int64_t tile) {
+        int64_t m = tile * 16 + i16;
+        m = m < P.rows ? m : P.rows - 1;                     // rows past the end are read from the last row and never stored
+        const T* row = reinterpret_cast<const T*>(P.x) + m * P.ldx;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int k = 32 * c + 8 * g;
+            const lin_u32x4 v = *reinterpret_cast<const lin_u32x4*>(row + (k < P.k ? k : 0));
+            const lin_u32x4 zero = {0u, 0u, 0u, 0u};
+            dst[c] = __builtin_bit_cast(frag8, k < P.k ? v : zero);
+        }
+    };
+    auto compute = [&](const frag8 (&xf)[KC], int64_t tile) {
+        const int64_t m = tile * 16 + i16;
+        const bool row_ok = tile < ntiles && m < P.rows;
+        T* yrow = reinterpret_cast<T*>(P.y) + (row_ok ? m : 0) * P.ldy + n0 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < nt_live) {                               // uniform
+                const int nb = n0 + 16 * t + 4 * g;          // this lane's four output columns of tile t
+                const bool col_ok = nb < P.n;
+                lin_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (P.bias) acc = *reinterpret_cast<const lin_f32x4*>(P.bias + (col_ok ? nb : 0));
+#pragma unroll
+                for (int c = 0; c < KC; ++c) acc = Mfma16<T>::run(wf[t][c], xf[c], acc);
+                if (row_ok && col_ok) {
+                    lin_u32x2 pk;
+                    pk[0] = pack2<T>(acc[0], acc[1]);
+                    pk[1] = pack2<T>(acc[2], acc[3]);
+                    *reinterpret_cast<lin_u32x2*>(yrow + 16 * t) = pk;
+                }
+            }
+        }
+    };
+    if (first >= ntiles) return;
+    auto clampt = [&](int64_t t) { return t < ntiles ? t : ntiles - 1; };
+    frag8 xa[KC], xb[KC];
+    load_x(xa, first);
+    for (int i = 0; i < kLinTilesPerWave; i += 2) {          // two tiles per trip: the buffers swap roles without copies
+        load_x(xb, clampt(first + i + 1));                   // in flight during this tile's MFMAs
+        SEGM_SCHED_FENCE();
+        compute(xa, first + i);
+        SEGM_SCHED_FENCE();
+        load_x(xa, clampt(first + i + 2));
+        SEGM_SCHED_FENCE();
+        compute(xb, first + i + 1);
+        SEGM_SCHED_FENCE();
+    }
+}
+
+template <typename T>
+static int launch_linear(const LinDev& P, hipStream_t st) {
+    const int kc = (P.k + 31) / 32;
+    const int nt = lin_tiles(kc <= 2 ? 2 : kc);
+    const int64_t ntiles = (P.rows + 15) / 16;
+    const int64_t gx = (ntiles + kLinWaves * kLinTilesPerWave - 1) / (kLinWaves * kLinTilesPerWave);
+    if (gx >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;
+    const dim3 grid((unsigned)gx, (unsigned)((P.n + nt * 16 - 1) / (nt * 16)));
+    const dim3 block(kLinWaves * 64);
+    if (kc <= 2) hipLaunchKernelGGL((linear_rows_kernel<T, 2>), grid, block, 0, st, P);
+    else if (kc == 3) hipLaunchKernelGGL((linear_rows_kernel<T, 3>), grid, block, 0, st, P);
+    else if (kc == 4) hipLaunchKernelGGL((linear_rows_kernel<T, 4>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((linear_rows_kernel<T, 6>), grid, block, 0, st, P);
+    return (int)hipGetLastError();
+}
+
+}  // namespace segm
+
+using namespace segm;
+
+extern "C" int segm_linear_rows(const segm_linear_args* a) {
+    if (!a) return SEGM_E_NULL;
+    if (a->rows <= 0 || a->k <= 0 || a->n <= 0) return SEGM_E_SHAPE;
+    if (a->k % 8 != 0 || a->k > 192 || a->n % 4 != 0) return SEGM_E_SHAPE;
+    if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
+    if (!a->x || !a->w || !a->y) return SEGM_E_NULL;
+    if (a->x_stride_row % 8 != 0 || a->x_stride_row < a->k || a->y_stride_row % 4 != 0 || a->y_stride_row < a->n) return SEGM_E_SHAPE;
+    if (((uintptr_t)a->x & 15) || ((uintptr_t)a->w & 15) || ((uintptr_t)a->y & 7) || (a->bias && ((uintptr_t)a->bias & 15)))
+        return SEGM_E_SHAPE;
+    LinDev P;
+    P.x = (const char*)a->x; P.ldx = a->x_stride_row;
+    P.w = (const char*)a->w; P.bias = a->bias;
+    P.y = (char*)a->y; P.ldy = a->y_stride_row;
+    P.rows = a->rows; P.k = a->k; P.n = a->n;
+    hipStream_t st = (hipStream_t)a->stream;
+    return a->dtype == SEGM_F16 ? launch_linear<f16_t>(P, st) : launch_linear<bf16_t>(P, st);
+}

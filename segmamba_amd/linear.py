@@ -13,12 +13,32 @@ they are *called* matter on MI355X (profiles/r01_bench_step_kernels_v5.txt, tool
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
 _SLAB = 4096          # rows of K per partial product
 _MIN_K = 32768        # below this one GEMM is fine
 _FORCE_SPLIT = False  # tests: exercise the split path on CPU tensors too
+# The library's row-streaming projection kernel (csrc/linear.hip) for tall activations.  Written after the GPU budget of
+# round 1 was spent - parity-tested on the emulator, never timed - so it is opt-in until it has been measured.
+_ROWS_HIP = os.environ.get("SEGM_LINEAR_HIP", "0") == "1"
+_ROWS_MIN = 32768     # rows below which the BLAS call stays
+
+
+def _on_device(t: torch.Tensor) -> bool:
+    return t.is_cuda
+
+
+def _rows_hip(x2: torch.Tensor, w: torch.Tensor, b):
+    """x2 (rows, K) @ w (N, K)^T + b through segm_linear_rows, or None when the shape / layout is not the kernel's."""
+    if not (_ROWS_HIP and _on_device(x2) and x2.shape[0] >= _ROWS_MIN):
+        return None
+    from . import lib as L, ops_raw
+    if not ops_raw.linear_rows_supported(x2, w):
+        return None
+    return ops_raw.linear_rows(L.get_lib(), x2, w, b)
 
 
 def _split(K: int) -> int:
@@ -64,7 +84,8 @@ class _LinearCL(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        return F.linear(x, w, b)
+        y = _rows_hip(x.reshape(-1, x.shape[-1]), w, b)
+        return F.linear(x, w, b) if y is None else y.reshape(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
@@ -72,7 +93,8 @@ class _LinearCL(torch.autograd.Function):
         dx = dw = db = None
         dy2 = dy.reshape(-1, dy.shape[-1])
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ w).reshape(x.shape)
+            dx = _rows_hip(dy2, w.t().contiguous(), None)
+            dx = (dy2 @ w if dx is None else dx).reshape(x.shape)
         if ctx.needs_input_grad[1]:
             dw = tn_matmul(dy2, x.reshape(-1, x.shape[-1])).to(w.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -566,3 +566,38 @@ def state_update(lib: L.SegmLib, state, x, dt, A, Bm, Cm, D=None, z=None, dt_bia
     a.A, a.D, a.dt_bias, a.stream = A.data_ptr(), L.fptr(D), L.fptr(dt_bias), L.stream_handle(x)
     lib.check(lib.dll.segm_selective_state_update(a), "selective_state_update")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# row-streaming projection (tall activations)
+# ---------------------------------------------------------------------------------------------------------
+def linear_rows_supported(x2: torch.Tensor, w: torch.Tensor, n_out: Optional[int] = None) -> bool:
+    """x2 (rows, K) view with unit column stride, w (N, K)."""
+    if x2.dim() != 2 or w.dim() != 2 or x2.dtype not in (torch.bfloat16, torch.float16) or w.dtype != x2.dtype:
+        return False
+    K, N = x2.shape[1], w.shape[0]
+    return w.shape[1] == K and K % 8 == 0 and K <= 192 and N % 4 == 0 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and \
+        x2.data_ptr() % 16 == 0 and x2.shape[0] > 0
+
+
+def linear_rows(lib: L.SegmLib, x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y (rows, N) = x2 (rows, K) @ w (N, K)^T + bias; `out` may be a column slice of a wider row-major tensor."""
+    if not linear_rows_supported(x2, w):
+        raise RuntimeError("linear_rows: x (rows, K <= 192, K % 8 == 0) with unit column stride and 16-byte rows, w (N % 4 == 0, K), bf16 / fp16")
+    M, K = x2.shape
+    N = w.shape[0]
+    w = w.contiguous()
+    y = torch.empty(M, N, dtype=x2.dtype, device=x2.device) if out is None else out
+    if tuple(y.shape) != (M, N) or y.dtype != x2.dtype or y.stride(1) != 1 or y.stride(0) % 4 or y.data_ptr() % 8:
+        raise RuntimeError("linear_rows: `out` must be (rows, N) of x's dtype, unit column stride, 8-byte rows")
+    if bias is not None:
+        bias = bias.float().contiguous()
+    a = L.LinearArgs()
+    a.rows, a.k, a.n, a.dtype = M, K, N, L.dtype_code(x2)
+    a.x, a.x_stride_row = x2.data_ptr(), x2.stride(0)
+    a.w, a.bias = w.data_ptr(), L.fptr(bias)
+    a.y, a.y_stride_row = y.data_ptr(), y.stride(0)
+    a.stream = L.stream_handle(x2)
+    lib.check(lib.dll.segm_linear_rows(a), "linear_rows")
+    return y

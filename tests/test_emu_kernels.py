@@ -568,3 +568,51 @@ def test_selective_scan_fn_wide_state_on_emulated_kernels(emu, monkeypatch, dsta
     for k in t:
         r = res["ref"][2][k]
         H.assert_close(res["hip"][2][k], r, 1e-3, 1e-3 * max(1.0, float(r.abs().max())), "d" + k)
+
+
+@pytest.mark.parametrize("M,K,N,dtype,bias", [(100, 48, 192, torch.bfloat16, False), (37, 96, 48, torch.bfloat16, True),
+                                              (200, 192, 100, torch.float16, True), (16, 128, 388, torch.bfloat16, False),
+                                              (33, 40, 36, torch.bfloat16, True)])
+def test_linear_rows_emulated(emu, M, K, N, dtype, bias):
+    """row-streaming projection: every K-chunk count (K <= 64 / 96 / 128 / 192), ragged row and column tails, several column
+    blocks, strided input rows (a column slice of a wider tensor) and output rows (written into a wider tensor)."""
+    g = torch.Generator().manual_seed(M + K + N)
+    xw = torch.randn(M, K + 16, generator=g).to(dtype)
+    x = xw[:, 8:8 + K]                                       # 16-byte aligned column slice
+    w = (0.2 * torch.randn(N, K, generator=g)).to(dtype)
+    b = torch.randn(N, generator=g) if bias else None
+    ref = torch.nn.functional.linear(x.float(), w.float(), b)
+    yw = torch.full((M, N + 8), 7.0).to(dtype)
+    y = ops_raw.linear_rows(emu, x, w, b, out=yw[:, 4:4 + N])
+    tol = (1e-2 if dtype == torch.bfloat16 else 2e-3) * max(1.0, float(ref.abs().max()))
+    assert (y.float() - ref).abs().max() <= tol
+    assert (yw[:, :4] == 7).all() and (yw[:, 4 + N:] == 7).all()          # nothing outside the slice is touched
+    y2 = ops_raw.linear_rows(emu, x.contiguous(), w, b)
+    assert torch.equal(y2, yw[:, 4:4 + N])
+    assert not ops_raw.linear_rows_supported(x.float(), w.float()) and not ops_raw.linear_rows_supported(xw[:, 1:1 + K], w)
+
+
+def test_linear_cl_library_route_on_emulated_kernels(emu, monkeypatch):
+    """linear.linear_cl with the row-streaming kernel switched in (SEGM_LINEAR_HIP): forward and data gradient through the
+    library, weight gradient through the split-K path - against F.linear autograd."""
+    from segmamba_amd import linear as LN, lib as Lm, ops_raw as OR
+    monkeypatch.setattr(Lm, "_lib", emu)
+    monkeypatch.setattr(LN, "_ROWS_HIP", True)
+    monkeypatch.setattr(LN, "_ROWS_MIN", 1)
+    calls = []
+    real = OR.linear_rows
+    monkeypatch.setattr(OR, "linear_rows", lambda *a, **k: (calls.append(a[1].shape), real(*a, **k))[1])
+    monkeypatch.setattr(LN, "_on_device", lambda t: True)                             # the route is taken for CUDA tensors only
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 20, 48, generator=g).bfloat16().requires_grad_()
+    w = (0.2 * torch.randn(96, 48, generator=g)).bfloat16().requires_grad_()
+    dy = torch.randn(2, 20, 96, generator=g).bfloat16()
+    y = LN._LinearCL.apply(x, w, None)
+    gx, gw = torch.autograd.grad(y, (x, w), dy)
+    monkeypatch.undo()
+    x2, w2 = x.detach().float().requires_grad_(), w.detach().float().requires_grad_()
+    y2 = torch.nn.functional.linear(x2, w2)
+    gx2, gw2 = torch.autograd.grad(y2, (x2, w2), dy.float())
+    assert len(calls) == 2 and calls[0] == (40, 48) and calls[1] == (40, 96)         # forward and data gradient
+    for got, want in ((y, y2), (gx, gx2), (gw, gw2)):
+        assert (got.float() - want).abs().max() <= 2e-2 * max(1.0, float(want.abs().max()))
