@@ -445,11 +445,13 @@ int segm_selective_state_update(const segm_state_update_args* args);
  * 247-275), which the reference hands to cuBLAS.  x (rows, k) and y (rows, n) with element row strides (views into wider
  * tensors are fine), w (n, k) contiguous - the nn.Linear layout - all of one 16-bit dtype; bias (n) fp32 or NULL.
  * k a multiple of 8, at most 192; n a multiple of 4; x rows 16-byte aligned, y rows 8-byte aligned.
+ * accumulate != 0: y += x W^T (+ bias), e.g. `torch.addmm(dconv, dx_dbl, x_proj_weight)` of the reference's backward
+ * (selective_scan_interface.py:276).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct segm_linear_args {
     int64_t rows;
     int32_t k, n;
-    int32_t dtype, reserved;
+    int32_t dtype, accumulate;
     const void* x;      int64_t x_stride_row;
     const void* w;
     const float* bias;

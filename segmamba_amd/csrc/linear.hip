@@ -32,6 +32,7 @@ struct LinDev {
     char* y;        int64_t ldy;
     int64_t rows;
     int32_t k, n;
+    int32_t accumulate;                      // y += x W^T (+ bias) instead of y =
 };
 
 // KC = 32-wide chunks of K held per wave; NT = 16-column tiles of W per wave (at most 24 fragments = 96 VGPRs, which
@@ -91,6 +92,13 @@ __global__ void __launch_bounds__(kLinWaves * 64) linear_rows_kernel(LinDev P) {
 #pragma unroll
                 for (int c = 0; c < KC; ++c) acc = Mfma16<T>::run(wf[t][c], xf[c], acc);
                 if (row_ok && col_ok) {
+                    if (P.accumulate) {                      // uniform
+                        const lin_u32x2 old = *reinterpret_cast<const lin_u32x2*>(yrow + 16 * t);
+                        T o[4];
+                        memcpy(o, &old, 8);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q] += to_f32(o[q]);
+                    }
                     lin_u32x2 pk;
                     pk[0] = pack2<T>(acc[0], acc[1]);
                     pk[1] = pack2<T>(acc[2], acc[3]);
@@ -149,6 +157,7 @@ extern "C" int segm_linear_rows(const segm_linear_args* a) {
     P.w = (const char*)a->w; P.bias = a->bias;
     P.y = (char*)a->y; P.ldy = a->y_stride_row;
     P.rows = a->rows; P.k = a->k; P.n = a->n;
+    P.accumulate = a->accumulate != 0;
     hipStream_t st = (hipStream_t)a->stream;
     return a->dtype == SEGM_F16 ? launch_linear<f16_t>(P, st) : launch_linear<bf16_t>(P, st);
 }

@@ -178,7 +178,7 @@ class StateUpdateArgs(C.Structure):
 
 class LinearArgs(C.Structure):
     _fields_ = [
-        ("rows", C.c_int64), ("k", C.c_int32), ("n", C.c_int32), ("dtype", C.c_int32), ("reserved", C.c_int32),
+        ("rows", C.c_int64), ("k", C.c_int32), ("n", C.c_int32), ("dtype", C.c_int32), ("accumulate", C.c_int32),
         ("x", C.c_void_p), ("x_stride_row", C.c_int64), ("w", C.c_void_p), ("bias", C.c_void_p),
         ("y", C.c_void_p), ("y_stride_row", C.c_int64), ("stream", C.c_void_p),
     ]

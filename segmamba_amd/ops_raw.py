@@ -581,8 +581,9 @@ def linear_rows_supported(x2: torch.Tensor, w: torch.Tensor, n_out: Optional[int
 
 
 def linear_rows(lib: L.SegmLib, x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y (rows, N) = x2 (rows, K) @ w (N, K)^T + bias; `out` may be a column slice of a wider row-major tensor."""
+                out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """y (rows, N) = x2 (rows, K) @ w (N, K)^T + bias; `out` may be a column slice of a wider row-major tensor;
+    `accumulate` adds to what `out` holds."""
     if not linear_rows_supported(x2, w):
         raise RuntimeError("linear_rows: x (rows, K <= 192, K % 8 == 0) with unit column stride and 16-byte rows, w (N % 4 == 0, K), bf16 / fp16")
     M, K = x2.shape
@@ -594,7 +595,9 @@ def linear_rows(lib: L.SegmLib, x2: torch.Tensor, w: torch.Tensor, bias: Optiona
     if bias is not None:
         bias = bias.float().contiguous()
     a = L.LinearArgs()
-    a.rows, a.k, a.n, a.dtype = M, K, N, L.dtype_code(x2)
+    if accumulate and out is None:
+        raise RuntimeError("linear_rows: accumulate needs `out`")
+    a.rows, a.k, a.n, a.dtype, a.accumulate = M, K, N, L.dtype_code(x2), int(bool(accumulate))
     a.x, a.x_stride_row = x2.data_ptr(), x2.stride(0)
     a.w, a.bias = w.data_ptr(), L.fptr(bias)
     a.y, a.y_stride_row = y.data_ptr(), y.stride(0)

@@ -155,8 +155,11 @@ class MambaInnerCore(torch.autograd.Function):
         x, z = xz.split(dim, dim=cdim)
         conv_out = ops_raw.conv1d_fwd(lib, x, w32, cb32, True, channel_last=channel_last, time_order=time_order,
                                       nslices=nslices)
-        x_dbl, delta, Bv, Cv = _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last,
-                                        B_proj_bias, C_proj_bias)
+        if _rows_route(conv_out, channel_last) and B_proj_bias is None and C_proj_bias is None:
+            x_dbl, delta, Bv, Cv = _project_rows(conv_out, x_proj_weight, delta_proj_weight, R, N)
+        else:
+            x_dbl, delta, Bv, Cv = _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last,
+                                            B_proj_bias, C_proj_bias)
         # the un-gated y and the state checkpoints are only what the backward starts from: inference skips both stores
         train = any(ctx.needs_input_grad)
         r = ops_raw.scan_fwd(lib, conv_out, delta, A32, Bv, Cv, D32, z, db32, delta_softplus,
@@ -190,8 +193,12 @@ class MambaInnerCore(torch.autograd.Function):
         # recompute conv output and delta (checkpoint_lvl 1)
         conv_out = ops_raw.conv1d_fwd(lib, x, w32, cb32, True, channel_last=channel_last, time_order=time_order,
                                       nslices=nslices)
-        _, delta, Bv, Cv = _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last,
-                                    B_proj_bias, C_proj_bias, x_dbl=x_dbl)
+        rows_route = x_dbl.shape[1] != R + 2 * N           # the forward kept x_dbl padded: library projection route
+        if rows_route:
+            _, delta, Bv, Cv = _project_rows(conv_out, x_proj_weight, delta_proj_weight, R, N, x_dbl=x_dbl)
+        else:
+            _, delta, Bv, Cv = _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last,
+                                        B_proj_bias, C_proj_bias, x_dbl=x_dbl)
         dxz = torch.empty_like(xz, memory_format=torch.contiguous_format)
         dx, dz = dxz.split(dim, dim=cdim)                 # dx / dz written in place (reference :244-245)
         g = ops_raw.scan_bwd(lib, conv_out, delta, A32, Bv, Cv, D32, z, db32, dout, out, ckpt, delta_softplus,
@@ -211,14 +218,26 @@ class MambaInnerCore(torch.autograd.Function):
             conv2 = conv_out.permute(0, 2, 1).reshape(batch * seqlen, dim)
             dconv2 = dconv_out.permute(0, 2, 1).reshape(batch * seqlen, dim)
         dx_dbl = torch.empty_like(x_dbl)
-        dx_dbl[:, R:R + N] = dB2
-        dx_dbl[:, R + N:] = dC2
         dB_proj_bias = dB2.sum(0).to(B_proj_bias.dtype) if has_Bb else None
         dC_proj_bias = dC2.sum(0).to(C_proj_bias.dtype) if has_Cb else None
         ddelta_proj_weight = tn_matmul(ddelta2, x_dbl[:, :R])                   # (d, R)    reference :272
-        dx_dbl[:, :R] = ddelta2 @ delta_proj_weight                             # (bl, R)   reference :273
-        dx_proj_weight = tn_matmul(dx_dbl, conv2)                              # (R+2N, d) reference :275
-        dconv2 = torch.addmm(dconv2, dx_dbl, x_proj_weight)                     # (bl, d)   reference :276
+        if rows_route:
+            P, P8, R4 = R + 2 * N, x_dbl.shape[1], -(-R // 4) * 4
+            # (bl, R) = ddelta2 @ dt_proj_weight (reference :273), written - with zero padding columns - before dB lands
+            ops_raw.linear_rows(lib, ddelta2, _pad_rows(delta_proj_weight.t(), R4), out=dx_dbl[:, :R4])
+            dx_dbl[:, R:R + N] = dB2
+            dx_dbl[:, R + N:P] = dC2
+            if P8 > P:
+                dx_dbl[:, P:] = 0
+            dx_proj_weight = tn_matmul(dx_dbl[:, :P], conv2)                    # (R+2N, d) reference :275
+            wx_t = _pad_rows(x_proj_weight, P8).t().contiguous()                # (d, P8)
+            dconv2 = ops_raw.linear_rows(lib, dx_dbl, wx_t, out=dconv2, accumulate=True)        # reference :276
+        else:
+            dx_dbl[:, R:R + N] = dB2
+            dx_dbl[:, R + N:] = dC2
+            dx_dbl[:, :R] = ddelta2 @ delta_proj_weight                         # (bl, R)   reference :273
+            dx_proj_weight = tn_matmul(dx_dbl, conv2)                          # (R+2N, d) reference :275
+            dconv2 = torch.addmm(dconv2, dx_dbl, x_proj_weight)                 # (bl, d)   reference :276
         dconv_full = dconv2.reshape(batch, seqlen, dim)
         if not channel_last:
             dconv_full = dconv_full.permute(0, 2, 1)                             # strided (b, d, l) view
@@ -231,6 +250,41 @@ class MambaInnerCore(torch.autograd.Function):
                 g["dD"].to(D.dtype) if D is not None else None,
                 g["ddelta_bias"].to(delta_bias.dtype) if delta_bias is not None else None,
                 dB_proj_bias, dC_proj_bias, None, None, None, None)
+
+
+def _rows_route(conv_out, channel_last) -> bool:
+    """The library's row-streaming projection kernel (csrc/linear.hip) for x_proj / dt_proj and their data gradients: opt-in
+    (SEGM_LINEAR_HIP=1, see linear.py), channel-last 16-bit activations with enough rows only."""
+    from . import linear as LN
+    return bool(LN._ROWS_HIP and channel_last and LN._on_device(conv_out) and conv_out.dtype in (torch.bfloat16, torch.float16)
+                and conv_out.shape[0] * conv_out.shape[1] >= LN._ROWS_MIN and conv_out.shape[2] % 8 == 0
+                and conv_out.shape[2] <= 192 and conv_out.is_contiguous())
+
+
+def _pad_rows(w, rows):
+    """w (r, c) -> (rows, c) with zero rows appended"""
+    if w.shape[0] == rows:
+        return w.contiguous()
+    out = w.new_zeros(rows, w.shape[1])
+    out[:w.shape[0]] = w
+    return out
+
+
+def _project_rows(conv_out, x_proj_weight, delta_proj_weight, R, N, x_dbl=None):
+    """`_project` for channel-last activations through segm_linear_rows.  x_dbl is kept with its columns padded to a
+    multiple of 8 (R + 2N = 35 -> 40; the extra columns are zero) so that it can be both an output and - its first
+    8-column group, against a zero-padded dt_proj weight - an input of the kernel."""
+    lib = L.get_lib()
+    batch, seqlen, dim = conv_out.shape
+    P = R + 2 * N
+    P8, R8 = -(-P // 8) * 8, -(-R // 8) * 8
+    if x_dbl is None:
+        x_dbl = ops_raw.linear_rows(lib, conv_out.reshape(batch * seqlen, dim), _pad_rows(x_proj_weight, P8))
+    wdt = delta_proj_weight.new_zeros(dim, R8)
+    wdt[:, :R] = delta_proj_weight
+    delta = ops_raw.linear_rows(lib, x_dbl[:, :R8], wdt).reshape(batch, seqlen, dim)
+    v3 = x_dbl.view(batch, seqlen, P8)
+    return x_dbl, delta, v3[:, :, R:R + N], v3[:, :, R + N:P]
 
 
 def _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last, B_proj_bias, C_proj_bias, x_dbl=None):

@@ -589,6 +589,9 @@ def test_linear_rows_emulated(emu, M, K, N, dtype, bias):
     assert (yw[:, :4] == 7).all() and (yw[:, 4 + N:] == 7).all()          # nothing outside the slice is touched
     y2 = ops_raw.linear_rows(emu, x.contiguous(), w, b)
     assert torch.equal(y2, yw[:, 4:4 + N])
+    y3 = ops_raw.linear_rows(emu, x, w, None, out=y2.clone(), accumulate=True)                  # y3 = y2 + x W^T
+    want = y2.float() + torch.nn.functional.linear(x.float(), w.float())
+    assert (y3.float() - want).abs().max() <= 2 * tol
     assert not ops_raw.linear_rows_supported(x.float(), w.float()) and not ops_raw.linear_rows_supported(xw[:, 1:1 + K], w)
 
 
@@ -616,3 +619,38 @@ def test_linear_cl_library_route_on_emulated_kernels(emu, monkeypatch):
     assert len(calls) == 2 and calls[0] == (40, 48) and calls[1] == (40, 96)         # forward and data gradient
     for got, want in ((y, y2), (gx, gx2), (gw, gw2)):
         assert (got.float() - want).abs().max() <= 2e-2 * max(1.0, float(want.abs().max()))
+
+
+def test_mamba_block_with_library_projections_on_emulated_kernels(emu, monkeypatch):
+    """SEGM_LINEAR_HIP route: in / out / x / dt projections and their data gradients through segm_linear_rows (padded x_dbl,
+    accumulate into dconv) == the BLAS route, on a bf16 Mamba(v3) block: output, input gradient, all 23 parameter gradients."""
+    from segmamba_amd import linear as LN
+    monkeypatch.setattr(L, "_lib", emu)
+    from mamba_ssm import Mamba
+    from tests.golden.make_golden import named_fill
+    m = Mamba(d_model=16, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=4)
+    m.load_state_dict(named_fill(m.state_dict()))
+    m = m.bfloat16()
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randn(2, 24, 16, generator=g).bfloat16()
+    dy = torch.randn(2, 24, 16, generator=g).bfloat16()
+    res, calls = [], []
+    real = ops_raw.linear_rows
+    monkeypatch.setattr(ops_raw, "linear_rows", lambda *a, **k: (calls.append((tuple(a[1].shape), tuple(a[2].shape))), real(*a, **k))[1])
+    for route in (False, True):
+        monkeypatch.setattr(LN, "_ROWS_HIP", route)
+        monkeypatch.setattr(LN, "_ROWS_MIN", 1)
+        monkeypatch.setattr(LN, "_on_device", lambda t: True)
+        assert not calls                                   # nothing goes through the kernel while the route is off
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_()
+        y = m(x)
+        y.backward(dy)
+        res.append((y.detach().float(), x.grad.float(), {k: p.grad.float().clone() for k, p in m.named_parameters()}))
+    # per direction: x_proj, dt_proj (forward), dt_proj again (recompute), ddelta @ W_dt, dx_dbl @ W_x; plus in / out proj x 2
+    assert len(calls) == 3 * 5 + 4, len(calls)
+    (y0, gx0, gp0), (y1, gx1, gp1) = res
+    assert (y1 - y0).abs().max() <= 3e-2 * max(1.0, float(y0.abs().max()))
+    assert (gx1 - gx0).abs().max() <= 3e-2 * max(1.0, float(gx0.abs().max()))
+    for k in gp0:
+        assert (gp1[k] - gp0[k]).abs().max() <= 5e-2 * max(1e-2, float(gp0[k].abs().max())), k
