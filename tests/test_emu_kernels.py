@@ -654,3 +654,24 @@ def test_mamba_block_with_library_projections_on_emulated_kernels(emu, monkeypat
     assert (gx1 - gx0).abs().max() <= 3e-2 * max(1.0, float(gx0.abs().max()))
     for k in gp0:
         assert (gp1[k] - gp0[k]).abs().max() <= 5e-2 * max(1e-2, float(gp0[k].abs().max())), k
+
+
+def test_conv_same_autograd_with_every_library_candidate_on_emulated_kernels(emu, monkeypatch):
+    """conv3d._ConvSame (forward, data gradient, weight gradient, bias gradient) with each of the dispatcher's library
+    candidates forced in turn - the CPU twin of tests/test_gpu_kernels.py::test_conv3d_same_autograd_with_library_kernels."""
+    from segmamba_amd import conv3d as C3
+    monkeypatch.setattr(L, "_lib", emu)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 48, 2, 4, 16, generator=g).bfloat16().requires_grad_()
+    w = (0.05 * torch.randn(48, 48, 3, 3, 3, generator=g)).bfloat16().requires_grad_()
+    bias = torch.randn(48, generator=g).bfloat16().requires_grad_()
+    dy = torch.randn(1, 48, 2, 4, 16, generator=g).bfloat16()
+    x2, w2, b2 = (t.detach().float().requires_grad_() for t in (x, w, bias))
+    want = torch.autograd.grad(torch.nn.functional.conv3d(x2, w2, b2, 1, 1), (x2, w2, b2), dy.float())
+    y_want = torch.nn.functional.conv3d(x2, w2, b2, 1, 1).detach()
+    for idx in (-1, -2, -3, -4):                           # chain32, chained + unpadded rows, chained, reduce-per-row
+        monkeypatch.setattr(C3, "_pick", lambda key, cands, idx=idx: cands[max(idx, -len(cands))]())
+        y = C3._ConvSame.apply(x, w, bias)
+        got = torch.autograd.grad(y, (x, w, bias), dy)
+        for a, b in zip((y,) + got, (y_want,) + want):
+            assert (a.float() - b).abs().max() <= 2e-2 * max(1.0, float(b.abs().max())), idx
