@@ -234,7 +234,8 @@ class _ConvSame(torch.autograd.Function):
 
 def conv3d_same(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
     """Conv3d(kernel k odd, stride 1, padding k//2).  Follows autocast like `F.conv3d` does."""
-    if not x.is_cuda:
+    from . import lib as L
+    if not L.on_device(x):
         return F.conv3d(x, weight, bias, 1, weight.shape[2] // 2)
     if torch.is_autocast_enabled():
         dt = torch.get_autocast_dtype("cuda")

@@ -55,7 +55,8 @@ def instance_norm_act(x: torch.Tensor, act: str = "none", slope: float = 0.01, e
     """
     if act not in ("none", "relu", "leaky_relu"):
         raise ValueError(f"unknown activation {act!r}")
-    if x.is_cuda:
+    from . import lib as L
+    if L.on_device(x):
         return _InstNormAct.apply(x, residual, act, slope, eps)
     y = F.instance_norm(x, eps=eps)
     if residual is not None:

@@ -46,7 +46,8 @@ def volume_to_tokens_layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torc
     Like autocast's LayerNorm the statistics are fp32; the result is returned in x's dtype."""
     B, C = x.shape[:2]
     x3 = x.reshape(B, C, -1)
-    if x.is_cuda:
+    from . import lib as L
+    if L.on_device(x):
         from . import ops_raw
         x3 = x3.contiguous()
         if ops_raw.layernorm_tokens_supported(x3):
@@ -56,7 +57,8 @@ def volume_to_tokens_layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torc
 
 def transpose_add(x: torch.Tensor, add: torch.Tensor | None = None) -> torch.Tensor:
     """x (B, R, C) -> (B, C, R) contiguous, plus `add` (B, C, R) if given."""
-    if not x.is_cuda:
+    from . import lib as L
+    if not L.on_device(x):
         y = x.transpose(1, 2)
         return (y + add) if add is not None else y.contiguous()
     if add is not None and add.dtype != x.dtype:

@@ -299,6 +299,12 @@ def bc_view(t: torch.Tensor, channel_last: bool) -> SegmBC:
     return SegmBC(t.data_ptr(), s[0], s[1], s[3], s[2])
 
 
+def on_device(t: torch.Tensor) -> bool:
+    """Whether `t` takes the library's kernels (CUDA tensors do).  Host modules ask this instead of `t.is_cuda` so that the
+    CPU tests can send CPU tensors through the emulated kernels; the product never patches it."""
+    return t.is_cuda
+
+
 def stream_handle(t: torch.Tensor) -> Optional[int]:
     if t.is_cuda:
         return torch.cuda.current_stream(t.device).cuda_stream

@@ -28,7 +28,8 @@ _ROWS_MIN = 32768     # rows below which the BLAS call stays
 
 
 def _on_device(t: torch.Tensor) -> bool:
-    return t.is_cuda
+    from . import lib as L
+    return L.on_device(t)
 
 
 def _rows_hip(x2: torch.Tensor, w: torch.Tensor, b):
@@ -55,7 +56,7 @@ def tn_matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a^T b for tall operands a (K, M), b (K, N), K >> M, N; fp32 result.  Row slices / column slices of larger
     matrices are fine (only views are taken)."""
     K = a.shape[0]
-    s = _split(K) if (a.is_cuda or _FORCE_SPLIT) else 1
+    s = _split(K) if (_on_device(a) or _FORCE_SPLIT) else 1
     if s == 1:
         return (a.t() @ b).float()
     part = torch.bmm(a.unflatten(0, (s, K // s)).transpose(1, 2), b.unflatten(0, (s, K // s)))      # (s, M, N)
@@ -65,7 +66,7 @@ def tn_matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 def nt_matmul_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """sum over the batch of a[i] b[i]^T for wide operands a (B, M, K), b (B, N, K) with unit stride along K; fp32."""
     B, M, K = a.shape
-    s = _split(K) if (a.is_cuda or _FORCE_SPLIT) else 1
+    s = _split(K) if (_on_device(a) or _FORCE_SPLIT) else 1
     if s == 1 or a.stride(2) != 1 or b.stride(2) != 1:
         return torch.matmul(a, b.transpose(1, 2)).sum(0, dtype=torch.float32)
     acc = None

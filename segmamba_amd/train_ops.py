@@ -33,7 +33,8 @@ class _CrossEntropy(torch.autograd.Function):
 def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
     """Mean cross entropy over the class axis (dim 1); fp32 scalar.  Under autocast the logits are used in the dtype they
     arrive in (the kernel computes in fp32 either way), which skips ATen's fp32 copy of the logits."""
-    if not logits.is_cuda:
+    from . import lib as L
+    if not L.on_device(logits):
         return F.cross_entropy(logits.float(), labels, ignore_index=ignore_index)
     from . import ops_raw
     if not ops_raw.cross_entropy_supported(logits, labels):
@@ -84,7 +85,8 @@ class FusedClipSGD(torch.optim.Optimizer):
         if not allp:
             return loss
         max_norm = float(self.max_norm) if self.max_norm else 0.0
-        if allp[0].is_cuda:
+        from . import lib as L
+        if L.on_device(allp[0]):
             self._step_hip(groups, allp, max_norm)
         else:
             self._step_aten(groups, allp, max_norm)
