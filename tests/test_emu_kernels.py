@@ -675,3 +675,45 @@ def test_conv_same_autograd_with_every_library_candidate_on_emulated_kernels(emu
         got = torch.autograd.grad(y, (x, w, bias), dy)
         for a, b in zip((y,) + got, (y_want,) + want):
             assert (a.float() - b).abs().max() <= 2e-2 * max(1.0, float(b.abs().max())), idx
+
+
+def test_segmamba_forward_golden_through_library_routes_on_emulated_kernels(emu, monkeypatch):
+    """The whole network in fp32 with the library's routes switched on for CPU tensors (InstanceNorm, transpose + LayerNorm,
+    transposes, conv1d, scans - the MFMA convolutions are 16-bit only and stay on ATen here) against the reference SegMamba's
+    own forward (vendored MONAI blocks + reference Mamba on its ref ops): the CPU twin of the GPU golden test."""
+    monkeypatch.setattr(L, "_lib", emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    from model_segmamba.segmamba import SegMamba
+    from tests.golden.make_golden import named_fill
+    f = H.load_golden("segmamba_tiny.npz")
+    m = SegMamba(in_chans=4, out_chans=4, depths=[1, 1, 1, 1], feat_size=[48, 8, 16, 32], hidden_size=32)
+    sd = named_fill(m.state_dict())
+    assert len(sd) == int(f["nkeys"])
+    m.load_state_dict(sd)
+    m = m.eval()
+    x = torch.rand(1, 4, 32, 32, 32, generator=torch.Generator().manual_seed(int(f["x_seed"])))
+    with torch.no_grad():
+        y = m(x)
+    H.assert_close(y[:, :, ::2, ::2, ::2], f["y_sub"], 2e-3, 2e-3, "y_sub")
+    assert abs(float(y.mean()) - float(f["y_mean"])) < 1e-3 and abs(float(y.std()) - float(f["y_std"])) < 1e-3
+
+
+def test_segmamba_bf16_forward_with_library_convolutions_on_emulated_kernels(emu, monkeypatch):
+    """As above in bf16 and with the dispatcher's last forward candidate (the chained MFMA kernel on 32-wide x blocks) forced
+    for every 3x3x3 convolution it applies to: close to the reference's fp32 forward at bf16 precision."""
+    from segmamba_amd import conv3d as C3
+    monkeypatch.setattr(L, "_lib", emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    routed = []
+    monkeypatch.setattr(C3, "_pick", lambda key, cands: (routed.append(len(cands)), cands[-1]())[1])
+    from model_segmamba.segmamba import SegMamba
+    from tests.golden.make_golden import named_fill
+    f = H.load_golden("segmamba_tiny.npz")
+    m = SegMamba(in_chans=4, out_chans=4, depths=[1, 1, 1, 1], feat_size=[48, 8, 16, 32], hidden_size=32)
+    m.load_state_dict(named_fill(m.state_dict()))
+    m = m.bfloat16().eval()
+    x = torch.rand(1, 4, 32, 32, 32, generator=torch.Generator().manual_seed(int(f["x_seed"])))
+    with torch.no_grad():
+        y = m(x.bfloat16()).float()
+    assert max(routed) >= 5                                # native, reduce-per-row, chained, chained unpadded, chained 32-wide
+    H.assert_close(y[:, :, ::2, ::2, ::2], f["y_sub"], 6e-2, 6e-2, "y_sub (bf16)")
