@@ -72,7 +72,8 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
             model, device_ids=[local_rank] if device.type == "cuda" else None,
             find_unused_parameters=os.environ.get("SEGM_DDP_FIND_UNUSED", "0") == "1",
             gradient_as_bucket_view=True, bucket_cap_mb=64)
-    fused = device.type == "cuda" and os.environ.get("SEGM_FUSED_TRAIN_OPS", "1") != "0"
+    from . import lib as L
+    fused = L.on_device(next(model.parameters())) and os.environ.get("SEGM_FUSED_TRAIN_OPS", "1") != "0"
     if fused:
         # clip_grad_norm_(12) + SGD step as two passes of the library's multi-tensor kernels, cross entropy with its
         # gradient as one (csrc/trainstep.hip); SEGM_FUSED_TRAIN_OPS=0 restores the ATen calls of the reference loop

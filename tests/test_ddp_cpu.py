@@ -22,9 +22,19 @@ def _batch(rank):
     return torch.rand(2, 4, 8, 8, 8, generator=g), torch.randint(0, 4, (2, 8, 8, 8), generator=g)
 
 
-def _worker(rank, world, port, out):
+def _use_emulated_library():
+    """route CPU tensors through the library's kernels on the CPU emulation of HIP (test infrastructure, tests/emu)"""
+    from segmamba_amd import lib as L
+    from tests import emu_util
+    L._lib = emu_util.emu_lib()
+    L.on_device = lambda t: True
+
+
+def _worker(rank, world, port, out, library=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if library:
+        _use_emulated_library()
     from segmamba_amd.trainer import build_training_state, train_step
     st = build_training_state(torch.device("cpu"), distributed=True, model=_tiny_model())
     img, lab = _batch(rank)
@@ -57,3 +67,35 @@ def test_two_process_ddp_matches_single_process():
         train_step(st, img, lab)
     for a, b in zip(out[0][1], st.model.parameters()):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_two_process_ddp_with_library_loss_and_optimizer(monkeypatch):
+    """The same lock-step check with the library's cross entropy and clip + SGD kernels (emulated) under DDP: gradients are
+    views into DDP's buckets (gradient_as_bucket_view), not necessarily 16-byte aligned - the multi-tensor kernels read them
+    where they are."""
+    from tests import emu_util
+    if not emu_util.emu_available():
+        pytest.skip("no host clang for the emulation build")
+    emu_util.build_emu()                                   # before the workers race to build it
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out, True), nprocs=2, join=True)
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.equal(a, b), "ranks diverged"
+    from segmamba_amd import lib as L
+    from segmamba_amd.trainer import build_training_state, train_step
+    from segmamba_amd.train_ops import FusedClipSGD
+    st = build_training_state(torch.device("cpu"), distributed=False, model=_tiny_model())      # ATen loss / SGD, one process
+    assert not isinstance(st.optimizer, FusedClipSGD)
+    img = torch.cat([_batch(0)[0], _batch(1)[0]])
+    lab = torch.cat([_batch(0)[1], _batch(1)[1]])
+    for _ in range(2):
+        train_step(st, img, lab)
+    for a, b in zip(out[0][1], st.model.parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+    monkeypatch.setattr(L, "_lib", emu_util.emu_lib())
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    assert isinstance(build_training_state(torch.device("cpu"), model=_tiny_model()).optimizer, FusedClipSGD)
