@@ -214,3 +214,64 @@ def test_fused_clip_sgd_host_logic_matches_torch_sgd():
     opt_c.load_state_dict(opt_b.state_dict())              # checkpoints interchange with torch.optim.SGD
     bufs = [opt_c.state[p]["momentum_buffer"] for p in net_a.parameters()]
     assert all((b - opt_b.state[p]["momentum_buffer"]).abs().max() == 0 for b, p in zip(bufs, net_b.parameters()))
+
+
+def test_argument_errors_of_the_newer_entry_points_without_gpu(built_lib):
+    """every entry point validates its arguments on the host and returns a SEGM_E_* code before touching the device"""
+    from segmamba_amd import lib
+    l = lib.SegmLib(built_lib)
+    d = l.dll
+    buf = (ctypes.c_char * 256)()
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) & ~15
+
+    a = lib.Conv3dFwdArgs()
+    a.batch, a.cin, a.cout, a.depth, a.height, a.width, a.dtype = 1, 48, 32, 2, 2, 8, lib.SEGM_BF16
+    a.x = a.y = a.w_packed = p16
+    a.x_stride_b = a.x_stride_c = a.x_stride_z = a.x_stride_y = 8
+    a.y_stride_b = a.y_stride_c = a.y_stride_z = a.y_stride_y = 8
+    for flags in (2, 8, 1 | 2, 4, 2 | 8, 64):              # chain / chain32 / accumulate need cout % 48 == 0; pitch48 needs chain; unknown bit
+        a.flags = flags
+        assert d.segm_conv3d_k3_fwd(a) == -2, flags
+    a.flags, a.dtype = 0, lib.SEGM_F32
+    assert d.segm_conv3d_k3_fwd(a) == -4                   # 16-bit only
+
+    s = lib.SgdArgs()
+    assert d.segm_sgd_clip_step(s) == 0                    # no tensors: nothing to do
+    s.ntensors = 1
+    assert d.segm_sgd_clip_step(s) == -1                   # NULL lists
+    ne = (ctypes.c_int64 * 1)(100)
+    ptrs = (ctypes.c_void_p * 1)(p16)
+    s.params = s.grads = s.momenta = ctypes.cast(ptrs, ctypes.c_void_p)
+    s.numel = ctypes.cast(ne, ctypes.c_void_p)
+    assert d.segm_sgd_clip_step(s) == -6                   # workspace missing
+    assert d.segm_sgd_clip_step_workspace_bytes(1, ctypes.cast(ne, ctypes.c_void_p)) == (1 + 4) * 4
+
+    c = lib.CrossEntropyArgs()
+    c.batch, c.classes, c.dtype, c.spatial = 1, 17, lib.SEGM_F32, 8
+    assert d.segm_cross_entropy(c) == -2                   # at most 16 classes
+    c.classes = 4
+    assert d.segm_cross_entropy(c) == -1                   # NULL tensors
+    assert d.segm_cross_entropy_partials(2, 1000) == (2000 + 255) // 256
+
+    u = lib.Conv1dUpdateArgs()
+    u.batch, u.dim, u.width, u.dtype = 1, 8, 5, lib.SEGM_F32
+    assert d.segm_causal_conv1d_update(u) == -5            # width outside [2, 4]
+    t = lib.StateUpdateArgs()
+    t.batch, t.dim, t.dstate, t.dtype, t.state_dtype = 1, 8, 257, lib.SEGM_F32, lib.SEGM_F32
+    assert d.segm_selective_state_update(t) == -3          # dstate above the reference's 256
+    t.dstate, t.state_dtype = 16, 9
+    assert d.segm_selective_state_update(t) == -4
+
+    g = lib.LinearArgs()
+    g.rows, g.k, g.n, g.dtype = 64, 200, 48, lib.SEGM_BF16
+    assert d.segm_linear_rows(g) == -2                     # k <= 192
+    g.k, g.n = 48, 50
+    assert d.segm_linear_rows(g) == -2                     # n % 4
+    g.n, g.dtype = 48, lib.SEGM_F32
+    assert d.segm_linear_rows(g) == -4
+    g.dtype = lib.SEGM_BF16
+    assert d.segm_linear_rows(g) == -1                     # NULL tensors
+    g.x = g.w = g.y = p16
+    g.x_stride_row, g.y_stride_row = 40, 48
+    assert d.segm_linear_rows(g) == -2                     # x rows shorter than k
