@@ -661,6 +661,7 @@ def test_conv_same_autograd_with_every_library_candidate_on_emulated_kernels(emu
     candidates forced in turn - the CPU twin of tests/test_gpu_kernels.py::test_conv3d_same_autograd_with_library_kernels."""
     from segmamba_amd import conv3d as C3
     monkeypatch.setattr(L, "_lib", emu)
+    monkeypatch.setenv("SEGM_CONV_FWD_UNTIMED", "1")
     g = torch.Generator().manual_seed(4)
     x = torch.randn(1, 48, 2, 4, 16, generator=g).bfloat16().requires_grad_()
     w = (0.05 * torch.randn(48, 48, 3, 3, 3, generator=g)).bfloat16().requires_grad_()
@@ -704,6 +705,7 @@ def test_segmamba_bf16_forward_with_library_convolutions_on_emulated_kernels(emu
     from segmamba_amd import conv3d as C3
     monkeypatch.setattr(L, "_lib", emu)
     monkeypatch.setattr(L, "on_device", lambda t: True)
+    monkeypatch.setenv("SEGM_CONV_FWD_UNTIMED", "1")
     routed = []
     monkeypatch.setattr(C3, "_pick", lambda key, cands: (routed.append(len(cands)), cands[-1]())[1])
     from model_segmamba.segmamba import SegMamba

@@ -287,9 +287,9 @@ def test_conv3d_same_autograd_with_mfma_wgrad(hip, monkeypatch):
     x = torch.randn(1, 48, 8, 16, 32, device=DEV, generator=g).bfloat16().requires_grad_()
     w = (0.05 * torch.randn(48, 48, 3, 3, 3, device=DEV, generator=g)).bfloat16().requires_grad_()
     dy = torch.randn(1, 48, 8, 16, 32, device=DEV, generator=g).bfloat16()
-    # library candidates: forward / data gradient [.., reduce-per-row, chained, chained unpadded, chained 32-wide] -> the chained kernel;
-    # weight gradient [.., MFMA kernel] -> the last one.  (The two newest forward variants: tests/test_zz_gpu_unmeasured.py.)
-    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-3 if key[0] != "wgrad" and len(cands) >= 5 else -1]())
+    # the last candidates: the chained forward kernel (forward / data gradient) and the MFMA weight-gradient kernel
+    # (the two untimed forward variants are candidates only with SEGM_CONV_FWD_UNTIMED=1: tests/test_zz_gpu_unmeasured.py)
+    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
     y = C3.conv3d_same(x, w)
     gx, gw = torch.autograd.grad(y, (x, w), dy)
     x2, w2 = x.detach().float().requires_grad_(), w.detach().float().requires_grad_()
@@ -435,9 +435,9 @@ def test_conv3d_same_autograd_with_library_kernels(hip, monkeypatch):
     w = (0.05 * torch.randn(48, 48, 3, 3, 3, device=DEV, generator=g)).bfloat16().requires_grad_()
     bias = torch.randn(48, device=DEV, generator=g).bfloat16().requires_grad_()
     dy = torch.randn(2, 48, 8, 16, 32, device=DEV, generator=g).bfloat16()
-    # library candidates: forward / data gradient [.., reduce-per-row, chained, chained unpadded, chained 32-wide] -> the chained kernel;
-    # weight gradient [.., MFMA kernel] -> the last one.  (The two newest forward variants: tests/test_zz_gpu_unmeasured.py.)
-    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-3 if key[0] != "wgrad" and len(cands) >= 5 else -1]())
+    # the last candidates: the chained forward kernel (forward / data gradient) and the MFMA weight-gradient kernel
+    # (the two untimed forward variants are candidates only with SEGM_CONV_FWD_UNTIMED=1: tests/test_zz_gpu_unmeasured.py)
+    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
     y = C3.conv3d_same(x, w, bias)
     gx, gw, gb = torch.autograd.grad(y, (x, w, bias), dy)
     x2, w2, b2 = (t.detach().float().requires_grad_() for t in (x, w, bias))

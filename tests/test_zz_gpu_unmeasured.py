@@ -42,6 +42,7 @@ def test_conv3d_k3_fwd_newer_chained_variants(hip, shape):
 def test_conv3d_same_autograd_with_newer_library_candidates(hip, monkeypatch, idx):
     """the dispatcher with its last (chained, 32-wide) / second-to-last (chained, unpadded rows) forward candidates forced in"""
     from segmamba_amd import conv3d as C3
+    monkeypatch.setenv("SEGM_CONV_FWD_UNTIMED", "1")
     g = torch.Generator(device=DEV).manual_seed(4)
     x = torch.randn(2, 48, 8, 16, 32, device=DEV, generator=g).bfloat16().requires_grad_()
     w = (0.05 * torch.randn(48, 48, 3, 3, 3, device=DEV, generator=g)).bfloat16().requires_grad_()

@@ -8,8 +8,11 @@ kernels running on the CPU emulation of HIP (tests/emu) - against the same step 
 
 Slow (about ten minutes on 8 cores): an integration check for the build container, where there is no GPU; not part of the
 pytest suite.  The Mamba operators have no CPU path, so all three runs use the (oracle-checked) emulated scan kernels."""
+import os
 import sys
 import time
+
+os.environ.setdefault("SEGM_CONV_FWD_UNTIMED", "1")     # every forward-convolution variant is a candidate here
 
 sys.path.insert(0, ".")
 import torch  # noqa: E402

@@ -31,5 +31,5 @@ for M, K, N in [(524288, 48, 192), (524288, 96, 48), (524288, 96, 40), (524288, 
     print(f"linear {M}x{K} -> {N}: BLAS {t_blas*1e3:.0f} us ({gb/t_blas*1e3:.0f} GB/s)  segm_linear_rows {t_hip*1e3:.0f} us ({gb/t_hip*1e3:.0f} GB/s)", flush=True)
 PY
 cat gpurun_out/r2_linear.log
-SEGM_CONV_VERBOSE=1 timeout 150 python bench.py 2>&1 | grep -v "amdgpu.ids\|MIOpen" > gpurun_out/r2_bench.log
+SEGM_CONV_FWD_UNTIMED=1 SEGM_CONV_VERBOSE=1 timeout 150 python bench.py 2>&1 | grep -v "amdgpu.ids\|MIOpen" > gpurun_out/r2_bench.log
 grep -c autotune gpurun_out/r2_bench.log; tail -1 gpurun_out/r2_bench.log | cut -c1-400
