@@ -719,3 +719,75 @@ def test_segmamba_bf16_forward_with_library_convolutions_on_emulated_kernels(emu
         y = m(x.bfloat16()).float()
     assert max(routed) >= 5                                # native, reduce-per-row, chained, chained unpadded, chained 32-wide
     H.assert_close(y[:, :, ::2, ::2, ::2], f["y_sub"], 6e-2, 6e-2, "y_sub (bf16)")
+
+
+def test_randomised_norm_layout_wgrad_sweep_emulated(emu):
+    """fixed-seed random shapes through the stem's other kernels: InstanceNorm (+ residual) (+ activation) forward and backward,
+    transpose (+ add), transpose + LayerNorm forward and backward, and the MFMA weight gradient."""
+    rng = np.random.default_rng(77)
+    F = torch.nn.functional
+    for case in range(24):
+        g = torch.Generator().manual_seed(500 + case)
+        dtype = [torch.float32, torch.bfloat16, torch.float16][case % 3]
+        tol = {torch.float32: 2e-5, torch.bfloat16: 3e-2, torch.float16: 4e-3}[dtype]
+        # ---- InstanceNorm ------------------------------------------------------------------------------------------
+        B, Cc = int(rng.integers(1, 3)), int(rng.integers(1, 7))
+        sp = tuple(int(v) for v in rng.integers(1, 9, size=3))
+        if int(np.prod(sp)) < 2:
+            sp = (2, 1, 1)
+        act = ["none", "relu", "leaky_relu"][int(rng.integers(0, 3))]
+        use_res = bool(rng.integers(0, 2))
+        x = (2 * torch.randn(B, Cc, *sp, generator=g) + 0.5).to(dtype)
+        res = torch.randn(B, Cc, *sp, generator=g).to(dtype) if use_res else None
+        dy = torch.randn(B, Cc, *sp, generator=g).to(dtype)
+        xr = x.double().requires_grad_()
+        rr = res.double().requires_grad_() if use_res else None
+        pre = F.instance_norm(xr, eps=1e-5) + (rr if use_res else 0)
+        ref = {"none": lambda v: v, "relu": F.relu, "leaky_relu": lambda v: F.leaky_relu(v, 0.01)}[act](pre)
+        grads = torch.autograd.grad(ref, (xr, rr) if use_res else (xr,), dy.double())
+        ref = ref.detach()
+        y, mean, rstd = ops_raw.instnorm_fwd(emu, x, res, act)
+        assert (y.double() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max())), ("instnorm fwd", case)
+        dx, dres = ops_raw.instnorm_bwd(emu, x, dy, mean, rstd, y if (act != "none" and use_res) else None, act, want_dresidual=use_res)
+        # elements that sit exactly at an activation kink after rounding may differ: compare in the bulk
+        bad = ((dx.double() - grads[0]).abs() > 4 * tol * max(1.0, float(grads[0].abs().max()))).float().mean()
+        assert bad <= (0.0 if dtype == torch.float32 else 0.02), ("instnorm bwd dx", case, float(bad))
+        if use_res:
+            bad = ((dres.double() - grads[1]).abs() > 4 * tol * max(1.0, float(grads[1].abs().max()))).float().mean()
+            assert bad <= (0.0 if dtype == torch.float32 else 0.02), ("instnorm bwd dres", case)
+        # ---- transpose (+ add) -------------------------------------------------------------------------------------
+        R, Ct = int(rng.integers(1, 150)), int(rng.integers(1, 150))
+        xt = torch.randn(B, R, Ct, generator=g).to(dtype)
+        add = torch.randn(B, Ct, R, generator=g).to(dtype) if use_res else None
+        want = xt.transpose(1, 2).float() + (add.float() if use_res else 0)
+        got = ops_raw.transpose_add(emu, xt, add)
+        assert (got.float() - want).abs().max() <= tol * max(1.0, float(want.abs().max())), ("transpose", case)
+        # ---- transpose + LayerNorm ---------------------------------------------------------------------------------
+        n = 4 if dtype == torch.float32 else 8
+        Cl, S = n * int(rng.integers(1, 13)), n * int(rng.integers(1, 30))
+        xl = (1.5 * torch.randn(B, Cl, S, generator=g) + 0.3).to(dtype)
+        gamma, beta = torch.randn(Cl, generator=g), torch.randn(Cl, generator=g)
+        dyl = torch.randn(B, S, Cl, generator=g).to(dtype)
+        xlr, gr, br = xl.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+        refl = F.layer_norm(xlr.transpose(1, 2), (Cl,), gr, br, 1e-5)
+        gx, gg, gb = torch.autograd.grad(refl, (xlr, gr, br), dyl.double())
+        refl = refl.detach()
+        yl, m2, r2 = ops_raw.layernorm_tokens_fwd(emu, xl, gamma, beta, 1e-5)
+        assert (yl.double() - refl).abs().max() <= 2 * tol * max(1.0, float(refl.abs().max())), ("layernorm fwd", case)
+        dxl, dg, db = ops_raw.layernorm_tokens_bwd(emu, xl, dyl, m2, r2, gamma)
+        assert (dxl.double() - gx).abs().max() <= 2 * tol * max(1.0, float(gx.abs().max())), ("layernorm dx", case)
+        assert (dg.double() - gg).abs().max() <= max(tol, 2e-3) * max(1.0, float(gg.abs().max())), ("layernorm dgamma", case)
+        assert (db.double() - gb).abs().max() <= max(tol, 2e-3) * max(1.0, float(gb.abs().max())), ("layernorm dbeta", case)
+    # ---- MFMA weight gradient ---------------------------------------------------------------------------------------
+    for case in range(8):
+        g = torch.Generator().manual_seed(900 + case)
+        B = int(rng.integers(1, 3))
+        cin = int(rng.choice([4, 30, 48, 96]))
+        cout = int(rng.choice([48, 96]))
+        D, H_, W = int(rng.integers(1, 4)), int(rng.integers(1, 6)), int(rng.choice([8, 16, 40, 72]))
+        dt = torch.bfloat16 if case % 2 == 0 else torch.float16
+        xw = torch.randn(B, cin, D, H_, W, generator=g).to(dt)
+        dyw = torch.randn(B, cout, D, H_, W, generator=g).to(dt)
+        dw = ops_raw.conv3d_k3_wgrad(emu, xw, dyw, torch.float32)
+        ref_dw = _wgrad_reference(xw, dyw)
+        assert dw.shape == ref_dw.shape and (dw - ref_dw).abs().max() <= 1e-5 * ref_dw.abs().max() + 1e-3, ("wgrad", case, cin, cout, D, H_, W)
