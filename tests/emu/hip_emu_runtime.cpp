@@ -5,6 +5,12 @@
 #if !defined(__x86_64__)
 #error "the HIP emulation's fiber switch is written for x86-64"
 #endif
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPEMU_ASAN 1
+extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
+#endif
+#endif
 
 thread_local uint3_emu threadIdx;
 thread_local uint3_emu blockIdx;
@@ -55,6 +61,9 @@ pthread_barrier_t g_block_bar;
     abort();                                  // a finished lane is never resumed
 }
 void fiber_reset(Fiber& f) {
+#ifdef HIPEMU_ASAN
+    __asan_unpoison_memory_region(f.stack, kStack);   // tools/emu_asan_check.sh: a reused stack carries no stale redzones
+#endif
     // the slot holding the entry address is 16-byte aligned, so the entry function starts with the ABI's stack alignment
     uintptr_t top = (reinterpret_cast<uintptr_t>(f.stack) + kStack - 64) & ~uintptr_t(15);
     void** slot = reinterpret_cast<void**>(top);

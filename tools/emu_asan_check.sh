@@ -1,0 +1,57 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE: the kernel sources on the CPU emulation of HIP, built with AddressSanitizer - `static __shared__`
+# arrays become instrumented globals, so out-of-bounds LDS indexing (and wild global pointers into ASan-owned memory) is
+# reported.  Runs a few small problems through the newer kernels.   bash tools/emu_asan_check.sh
+set -e
+cd "$(dirname "$0")/.."
+CLANG=/opt/rocm/lib/llvm/bin/clang++
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+OUT=build/emu_asan
+mkdir -p $OUT
+FLAGS="-O1 -g -fsanitize=address -fno-omit-frame-pointer -std=c++17 -fPIC -pthread -Itests/emu -Wno-unused-value -DSEGM_EMU=1"
+OBJS=""
+for f in segmamba_amd/csrc/*.hip tests/emu/hip_emu_runtime.cpp; do
+  o=$OUT/$(basename $f).o
+  $CLANG $FLAGS '-DSEGM_PIN_F32(x)=' '-DSEGM_SCHED_FENCE()=' '-DSEGM_PIN_F2(x)=' '-DSEGM_WAVE_LDS_SYNC()=hipemu::sync_wave()' -x c++ -c $f -o $o &
+  OBJS="$OBJS $o"
+done
+wait
+$CLANG -shared -pthread -fsanitize=address -shared-libasan $OBJS -o $OUT/libsegmamba_emu_asan.so
+LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1 python - <<'PY'
+import sys; sys.path.insert(0, ".")
+import torch
+from segmamba_amd import lib as L, ops_raw
+emu = L.SegmLib("build/emu_asan/libsegmamba_emu_asan.so")
+g = torch.Generator().manual_seed(0)
+x = torch.randn(1, 96, 2, 3, 40, generator=g).bfloat16(); w = (0.1 * torch.randn(48, 96, 3, 3, 3, generator=g)).bfloat16()
+ref = torch.nn.functional.conv3d(x.float(), w.float(), None, 1, 1)
+for kw in (dict(), dict(chain=True), dict(chain=True, pitch48=True), dict(chain32=True)):
+    y = ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:, :48]), None, **kw)
+    ops_raw.conv3d_k3_fwd(emu, x[:, 48:], ops_raw.pack_conv3d_weight(w[:, 48:]), None, out=y, accumulate=True, **kw)
+    assert (y.float() - ref).abs().max() <= 3e-2 * float(ref.abs().max()), kw
+    print("conv fwd", kw, "ok", flush=True)
+xn = torch.randn(1, 4, 2, 3, 16, generator=g).bfloat16(); wn = (0.1 * torch.randn(32, 4, 3, 3, 3, generator=g)).bfloat16()
+ops_raw.conv3d_k3_fwd(emu, xn, ops_raw.pack_conv3d_weight(wn)); print("conv fwd 12-wave kernel ok", flush=True)
+dy = torch.randn(1, 48, 2, 3, 40, generator=g).bfloat16()
+ops_raw.conv3d_k3_wgrad(emu, x[:, :48].contiguous(), dy, torch.float32); print("wgrad ok", flush=True)
+a = torch.randn(70, 96, generator=g).bfloat16(); wl = torch.randn(52, 96, generator=g).bfloat16()
+ops_raw.linear_rows(emu, a, wl, torch.randn(52)); print("linear_rows ok", flush=True)
+ps = [torch.randn(n) for n in (5, 16385, 0, 100)]; gs = [torch.randn(n) for n in (5, 16385, 0, 100)]; ms = [torch.zeros(n) for n in (5, 16385, 0, 100)]
+ops_raw.sgd_clip_step(emu, ps, gs, ms, 0.01, 0.9, 1e-4, True, 1.0); print("sgd ok", flush=True)
+lg = torch.randn(2, 4, 50, generator=g).bfloat16(); lb = torch.randint(0, 4, (2, 50), generator=g)
+ops_raw.cross_entropy(emu, lg, lb); print("cross entropy ok", flush=True)
+cs = torch.randn(2, 8, 4); ops_raw.conv1d_update(emu, torch.randn(2, 8), cs, torch.randn(8, 4), None, True)
+st = torch.randn(2, 8, 16); ops_raw.state_update(emu, st, torch.randn(2, 8), torch.randn(2, 8), -torch.rand(8, 16), torch.randn(2, 16), torch.randn(2, 16))
+print("decode ok", flush=True)
+xi = torch.randn(2, 3, 5, 6, 7, generator=g).bfloat16()
+y, m, r = ops_raw.instnorm_fwd(emu, xi, None, "relu"); ops_raw.instnorm_bwd(emu, xi, xi, m, r, None, "relu"); print("instnorm ok", flush=True)
+xl = torch.randn(2, 48, 40, generator=g).bfloat16()
+yl, m2, r2 = ops_raw.layernorm_tokens_fwd(emu, xl, torch.ones(48), torch.zeros(48)); ops_raw.layernorm_tokens_bwd(emu, xl, yl, m2, r2, torch.ones(48)); print("layernorm ok", flush=True)
+ops_raw.transpose_add(emu, torch.randn(2, 70, 33, generator=g).bfloat16()); print("transpose ok", flush=True)
+from tests import helpers as H
+c = H.scan_case(2, 96, 16, 64, dtype=torch.bfloat16, seed=1)
+H.run_scan(emu, c, "cpu", True, L.TIME_INTERLEAVED, 8); print("scan (regular-shape kernels) ok", flush=True)
+c = H.scan_case(1, 40, 12, 50, dtype=torch.float32, seed=2)
+H.run_scan(emu, c, "cpu", False, L.TIME_REVERSED, 1); print("scan (general kernels) ok", flush=True)
+print("AddressSanitizer run finished without reports")
+PY
