@@ -497,7 +497,9 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
     for (int c = 0; c < kF48Chunks; ++c) {
         const int k = 32 * (c_begin + c) + 8 * g;
         const bool live = c < c_count && k < kF48K;
-        const int kk = live ? k : 0;
+        // a dead chunk (zero weights) still issues its LDS reads: aim them at rows this part reads anyway, not at tap 0 of
+        // plane 0, whose slot another wave may be refilling in this step
+        const int kk = live ? k : 32 * c_begin + 8 * g;
         const int tap = kk / kFwCi, ci0 = kk - tap * kFwCi;
         const int tz = tap / 9, ty = (tap - tz * 9) / 3, tx = tap - tz * 9 - ty * 3;
         aoff[c] = (tz * 4 * kSlot + (xp * XT * 16 + i16 + tx) * CP + ci0) | (ty << 28);
@@ -681,7 +683,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
     for (int c = 0; c < kF48Chunks; ++c) {
         const int k = 32 * (c_begin + c) + 8 * g;
         const bool live = c < c_count && k < kF48K;
-        const int kk = live ? k : 0;
+        // a dead chunk (zero weights) still issues its LDS reads: aim them at rows this part reads anyway, not at tap 0 of
+        // plane 0, whose slot another wave may be refilling in this step
+        const int kk = live ? k : 32 * c_begin + 8 * g;
         const int tap = kk / kFwCi, ci0 = kk - tap * kFwCi;
         const int tz = tap / 9, ty = (tap - tz * 9) / 3, tx = tap - tz * 9 - ty * 3;
         aoff[c] = (tz * 4 * kSlot + (i16 + tx) * CP + ci0) | (ty << 28);

@@ -1,0 +1,53 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE: the kernel sources on the CPU emulation of HIP, built with ThreadSanitizer.  Every wave is an OS thread
+# and every `__syncthreads()` a pthread barrier, so an LDS location written by one wave and read by another without a barrier
+# in between is reported as a data race - a check of the kernels' barrier placement (lanes of one wave are fibers of one
+# thread: intra-wave ordering is not checked).  Found one so far: a zero-weight chunk of the chained convolution kernel
+# reading a ring slot that was being refilled (harmless numerically, fixed).     bash tools/emu_tsan_check.sh
+set -e
+cd "$(dirname "$0")/.."
+CLANG=/opt/rocm/lib/llvm/bin/clang++
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so | head -1)
+OUT=build/emu_tsan
+mkdir -p $OUT
+FLAGS="-O1 -g -fsanitize=thread -std=c++17 -fPIC -pthread -Itests/emu -Wno-unused-value -DSEGM_EMU=1"
+OBJS=""
+for f in segmamba_amd/csrc/*.hip tests/emu/hip_emu_runtime.cpp; do
+  o=$OUT/$(basename $f).o
+  $CLANG $FLAGS '-DSEGM_PIN_F32(x)=' '-DSEGM_SCHED_FENCE()=' '-DSEGM_PIN_F2(x)=' '-DSEGM_WAVE_LDS_SYNC()=hipemu::sync_wave()' -x c++ -c $f -o $o &
+  OBJS="$OBJS $o"
+done
+wait
+$CLANG -shared -pthread -fsanitize=thread -shared-libsan $OBJS -o $OUT/libsegmamba_emu_tsan.so
+LD_PRELOAD=$RT TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=7" python - 2> $OUT/tsan.log <<'PY'
+import sys; sys.path.insert(0, ".")
+import torch
+from segmamba_amd import lib as L, ops_raw
+from tests import helpers as H
+emu = L.SegmLib("build/emu_tsan/libsegmamba_emu_tsan.so")
+g = torch.Generator().manual_seed(0)
+x = torch.randn(1, 96, 2, 5, 40, generator=g).bfloat16(); w = (0.1 * torch.randn(48, 96, 3, 3, 3, generator=g)).bfloat16()
+for kw in (dict(), dict(chain=True), dict(chain=True, pitch48=True), dict(chain32=True)):
+    y = ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:, :48]), None, **kw)
+    ops_raw.conv3d_k3_fwd(emu, x[:, 48:], ops_raw.pack_conv3d_weight(w[:, 48:]), None, out=y, accumulate=True, **kw)
+xn = torch.randn(1, 4, 2, 3, 16, generator=g).bfloat16(); wn = (0.1 * torch.randn(32, 4, 3, 3, 3, generator=g)).bfloat16()
+ops_raw.conv3d_k3_fwd(emu, xn, ops_raw.pack_conv3d_weight(wn))
+ops_raw.conv3d_k3_wgrad(emu, x[:, :48].contiguous(), torch.randn(1, 48, 2, 5, 40, generator=g).bfloat16(), torch.float32)
+ops_raw.linear_rows(emu, torch.randn(70, 96, generator=g).bfloat16(), torch.randn(52, 96, generator=g).bfloat16(), torch.randn(52))
+ps = [torch.randn(n) for n in (5, 16385, 0, 100)]; gs = [torch.randn(n) for n in (5, 16385, 0, 100)]; ms = [torch.zeros(n) for n in (5, 16385, 0, 100)]
+ops_raw.sgd_clip_step(emu, ps, gs, ms, 0.01, 0.9, 1e-4, True, 1.0)
+ops_raw.cross_entropy(emu, torch.randn(2, 4, 700, generator=g).bfloat16(), torch.randint(0, 4, (2, 700), generator=g))
+xi = torch.randn(2, 3, 9, 10, 11, generator=g).bfloat16()
+y, m, r = ops_raw.instnorm_fwd(emu, xi, xi, "relu"); ops_raw.instnorm_bwd(emu, xi, xi, m, r, y, "relu", want_dresidual=True)
+xl = torch.randn(2, 48, 200, generator=g).bfloat16()
+yl, m2, r2 = ops_raw.layernorm_tokens_fwd(emu, xl, torch.ones(48), torch.zeros(48)); ops_raw.layernorm_tokens_bwd(emu, xl, yl, m2, r2, torch.ones(48))
+ops_raw.transpose_add(emu, torch.randn(2, 70, 133, generator=g).bfloat16())
+H.run_scan(emu, H.scan_case(2, 96, 16, 128, dtype=torch.bfloat16, seed=1), "cpu", True, L.TIME_INTERLEAVED, 8)
+H.run_scan(emu, H.scan_case(1, 40, 12, 100, dtype=torch.float32, seed=2), "cpu", False, L.TIME_REVERSED, 1)
+xc = torch.randn(2, 100, 24, generator=g).bfloat16()
+o = ops_raw.conv1d_fwd(emu, xc, torch.randn(24, 4), torch.randn(24), True, channel_last=True)
+ops_raw.conv1d_bwd(emu, xc, torch.randn(24, 4), torch.randn(24), o, True, channel_last=True)
+PY
+N=$(grep -c "WARNING: ThreadSanitizer" $OUT/tsan.log || true)
+echo "ThreadSanitizer reports: $N"
+if [ "$N" != "0" ]; then grep "SUMMARY" $OUT/tsan.log | sort | uniq -c | head; exit 1; fi
