@@ -1,14 +1,15 @@
 #!/bin/bash
-# TEST INFRASTRUCTURE: the kernel sources on the CPU emulation of HIP, built with AddressSanitizer - `static __shared__`
+# TEST INFRASTRUCTURE: the kernel sources on the CPU emulation of HIP, built with AddressSanitizer + UBSan - `static __shared__`
 # arrays become instrumented globals, so out-of-bounds LDS indexing (and wild global pointers into ASan-owned memory) is
-# reported.  Runs a few small problems through the newer kernels.   bash tools/emu_asan_check.sh
+# reported; UBSan adds misaligned vector accesses (a 16-byte LDS or global access off its alignment faults on the GPU) and
+# integer overflow in the index arithmetic.  Runs small problems through every kernel family.   bash tools/emu_asan_check.sh
 set -e
 cd "$(dirname "$0")/.."
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 OUT=build/emu_asan
 mkdir -p $OUT
-FLAGS="-O1 -g -fsanitize=address -fno-omit-frame-pointer -std=c++17 -fPIC -pthread -Itests/emu -Wno-unused-value -DSEGM_EMU=1"
+FLAGS="-O1 -g -fsanitize=address,undefined,alignment -fno-sanitize-recover=undefined,alignment -fno-omit-frame-pointer -std=c++17 -fPIC -pthread -Itests/emu -Wno-unused-value -DSEGM_EMU=1"
 OBJS=""
 for f in segmamba_amd/csrc/*.hip tests/emu/hip_emu_runtime.cpp; do
   o=$OUT/$(basename $f).o
@@ -16,7 +17,7 @@ for f in segmamba_amd/csrc/*.hip tests/emu/hip_emu_runtime.cpp; do
   OBJS="$OBJS $o"
 done
 wait
-$CLANG -shared -pthread -fsanitize=address -shared-libasan $OBJS -o $OUT/libsegmamba_emu_asan.so
+$CLANG -shared -pthread -fsanitize=address,undefined -shared-libasan $OBJS -o $OUT/libsegmamba_emu_asan.so
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1 python - <<'PY'
 import sys; sys.path.insert(0, ".")
 import torch
