@@ -32,7 +32,9 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+// `__shared__` arrays live in one named section so that the runtime can fill LDS with a NaN pattern before every block
+// (HIPEMU_POISON_LDS=1): on the GPU LDS holds whatever the previous workgroup left, and 0 x NaN = NaN.
+#define __shared__ static __attribute__((section("hipemu_lds")))
 
 struct dim3 {
     unsigned x, y, z;

@@ -30,6 +30,9 @@ asm(".text\n"
     "  ret\n"
     ".size hipemu_switch,.-hipemu_switch\n");
 
+extern "C" char __start_hipemu_lds[] __attribute__((weak));
+extern "C" char __stop_hipemu_lds[] __attribute__((weak));
+
 namespace hipemu {
 std::vector<unsigned char>* g_wave_big = nullptr;
 thread_local unsigned t_linear = 0;
@@ -53,6 +56,7 @@ struct Wave {
 };
 thread_local Wave t_wave;
 pthread_barrier_t g_block_bar;
+const bool g_poison_lds = getenv("HIPEMU_POISON_LDS") != nullptr;
 
 [[noreturn]] void fiber_entry() {
     t_wave.body->run();
@@ -101,6 +105,10 @@ void* wave_main(void* p) {
         for (unsigned by = 0; by < a->grid.y; ++by)
             for (unsigned bx = 0; bx < a->grid.x; ++bx) {
                 blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz;
+                if (g_poison_lds) {                 // every wave waits until wave 0 has filled LDS with NaN patterns
+                    if (a->wave == 0 && __start_hipemu_lds) memset(__start_hipemu_lds, 0xff, __stop_hipemu_lds - __start_hipemu_lds);
+                    pthread_barrier_wait(&g_block_bar);
+                }
                 for (Fiber& f : lanes) fiber_reset(f);
                 for (;;) {
                     unsigned live = 0, at_block = 0;
