@@ -7,18 +7,22 @@
 Step = one training step of BASELINE config 2/3: SegMamba(4 -> 4, depths [2,2,2,2], widths [48,96,192,384]) on a
 synthetic BraTS batch of 2 volumes of 128x128x128x4 per GPU, bf16 autocast, cross-entropy loss, backward, gradient
 clip 12, SGD(lr 1e-2, momentum 0.99, nesterov, wd 3e-5) step - the loop body of the reference trainer
-(light_training/trainer.py:445-470, 3_train.py:51-66).  N > 1: DistributedDataParallel over RCCL
-(find_unused_parameters=True as trainer.py:354-357), batch per GPU fixed (weak scaling).
+(light_training/trainer.py:445-470, 3_train.py:51-66).  N > 1: one process per GPU, DistributedDataParallel over RCCL
+(the reference's wrapper, trainer.py:353-357, with find_unused_parameters=False, gradient_as_bucket_view=True and 64 MB
+buckets - stated in `config.ddp`), batch per GPU fixed (weak scaling).  `--gpus N` without a torchrun environment
+re-executes itself through `python -m torch.distributed.run --nproc-per-node N` (as the reference's launch.py:89-108
+does with torchrun); under torchrun WORLD_SIZE must equal --gpus.
 
 Rank 0 prints ONE JSON line.  `value` = volumes / s over all GPUs.  `roofline` = the selective-scan forward at
 SegMamba's largest stage (B=2, D=96, N=16, L=64^3, same dtype as the step): algorithmic bytes (SURVEY.md §8d:
 e*B*L*(5D+2N)) / its measured duration (HIP events on the launch stream), against 8 TB/s HBM; the backward is reported
 next to it.  `traffic` = HBM-side bytes of one forward launch from rocprofv3 PMC counters (FETCH_SIZE + WRITE_SIZE,
-separate passes, calibrated on kernels with known byte counts: profiles/r01_scan_pmc_hbm_traffic.txt) - a constant
-measured once per shape, since counters cannot be read from inside the timed process.  It is ~2x the algorithmic
-bytes by construction: the chunked scan reads u / delta / B twice (aggregate + apply passes) and, in training mode,
-writes the fp32 state checkpoints the backward starts from (as many bytes as out + out_z).  `cpu_baseline` = the CPU oracle (a port of the reference's pure-PyTorch selective_scan_ref) timed on this
-box's host cores on a bounded sample of the same operator.
+separate passes, calibrated on kernels with known byte counts), read from profiles/scan_traffic.json - the file
+tools/gpu_pmc_traffic.sh regenerates together with the commit it was measured at (counters cannot be read from inside
+the timed process); null when the file does not cover the dtype.  `cpu_baseline` = the CPU oracle timed on this box's
+host cores on bounded samples: the C port (oracle/scan_ref.c, OpenMP) of the scan at the roofline shape, the PyTorch port
+of the reference's selective_scan_ref (a Python loop over time, as the reference's CPU path is) and the whole network
+on that path.
 """
 from __future__ import annotations
 
@@ -40,10 +44,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per forward launch at the roofline shape, bf16 (tools/gpu_pmc_scan.sh ->
-# profiles/r01_scan_pmc_hbm_traffic.txt; reads scaled by the 2-byte-row calibration 100.66 MB / 67.47 MB):
-#   agg 167.3 MB*1.49 + 12.8 MB, carry 11.8 + 12.0 MB, apply 276.7 MB*1.49 + 394.1 MB
-SCAN_FWD_TRAFFIC_BF16 = int((167.27 * 1.49 + 12.75 + 11.76 + 12.0 + 276.67 * 1.49 + 394.08) * 2 ** 20)
+
+
+def scan_traffic(dtype_name):
+    """HBM-side bytes per forward launch at the roofline shape from the committed PMC summary (tools/gpu_pmc_traffic.sh)."""
+    path = os.path.join(ROOT, "profiles", "scan_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        e = rec.get(dtype_name)
+        if e:
+            return {"bytes": int(e["bytes"]), "measured_at": rec.get("commit"), "date": rec.get("date"),
+                    "method": rec.get("method")}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def parse():
@@ -55,7 +70,25 @@ def parse():
     p.add_argument("--batch", type=int, default=2, help="volumes per GPU")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-baseline-full", action="store_true", help="add the whole-network 64^3 / 32^3 fwd+bwd CPU legs (~80 s)")
+    p.add_argument("--cpu-dry-run", action="store_true",
+                   help="plumbing check without a GPU: gloo, CPU tensors, a tiny SegMamba on the CPU emulation of the kernels "
+                        "(tests/emu); the printed value is NOT a measurement")
     return p.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    (one process per GPU; reference light_training/launch.py:89-108)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def time_gpu(fn, iters, warmup=3):
@@ -72,9 +105,16 @@ def time_gpu(fn, iters, warmup=3):
     return e0.elapsed_time(e1) / iters
 
 
+def algorithmic_bytes_scan(batch, dim, L, N, esize, G=1, backward=False):
+    """standalone selective scan, real A, variable B / C, with z, D, delta_bias.
+    fwd = e B L (5D + 2GN)  [read u, delta, z, B, C; write out, out_z];  bwd = B L (e (8D + 2GN) + 8GN)."""
+    if backward:
+        return batch * L * (esize * (8 * dim + 2 * G * N) + 8 * G * N)
+    return esize * batch * L * (5 * dim + 2 * G * N)
+
+
 def scan_roofline(dtype, device):
     from segmamba_amd import lib as L, ops_raw
-    from oracle.ref_ops import algorithmic_bytes_scan
     hip = L.get_lib()
     B, D, N, Lq = 2, 96, 16, 64 ** 3
     g = torch.Generator(device=device).manual_seed(0)
@@ -99,13 +139,23 @@ def scan_roofline(dtype, device):
     bytes_f = algorithmic_bytes_scan(B, D, Lq, N, es)
     bytes_b = algorithmic_bytes_scan(B, D, Lq, N, es, backward=True)
     gf, gb = bytes_f / ms_f * 1e-6, bytes_b / ms_b * 1e-6
+    tr = scan_traffic({torch.bfloat16: "bf16", torch.float32: "fp32", torch.float16: "fp16"}[dtype])
+    # The kernels are bound by VALU issue, not by HBM: one v_exp_f32 (quarter rate) per step and state
+    # per pass plus the packed multiply-adds of the recurrence.  `valu` prices the same launch against that ceiling:
+    # VALU cycles per (batch, channel, step) element the algorithm needs (tools/probe_valu2.hip rates: transcendental 8,
+    # plain fp32 op 2 cycles per wave-instruction on a SIMD) / the cycles the launch took per element.
+    cyc_needed = 2 * N * (8 + 3 * 2) + N * 2 + 60             # two passes x N x (exp + 3 plain) + y fma + softplus / silu / casts
+    elems_per_simd = B * D * Lq / 64 / 1024                    # wave-steps per SIMD (256 CUs x 4 SIMDs)
+    cyc_taken = ms_f * 1e-3 * 2.4e9 / elems_per_simd
     return {
         "bound": "hbm", "kernel": "selective_scan_fwd (scan_fwd_agg + scan_carry + scan_fwd_apply)",
         "shape": {"B": B, "D": D, "N": N, "L": Lq, "layout": "channel-last", "chunk": f["chunk"]},
         "achieved": round(gf, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gf / HBM_PEAK_GBPS, 4),
         "ms": round(ms_f, 4), "algorithmic_bytes": bytes_f,
-        "traffic": SCAN_FWD_TRAFFIC_BF16 if dtype == torch.bfloat16 else None,
-        "note": "VALU-issue bound (one v_exp_f32 per step and state per pass, two passes): DESIGN.md section 4",
+        "traffic": tr["bytes"] if tr else None, "traffic_source": tr,
+        "valu": {"bound": "valu-issue", "cycles_needed_per_wave_step": cyc_needed,
+                 "cycles_taken_per_wave_step_at_2.4GHz": round(cyc_taken, 1), "frac": round(cyc_needed / cyc_taken, 4)},
+        "note": "the true bound is VALU issue (v_exp_f32 per step and state, two passes), not HBM: read `frac` with `valu.frac`",
         "backward": {"achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4), "ms": round(ms_b, 4),
                      "algorithmic_bytes": bytes_b},
     }
@@ -128,44 +178,117 @@ def inference_rate(state, device, size):
             "published_reference": {"cases_per_s": 1.51, "hardware": "not stated (reference README table 5)"}}
 
 
-def cpu_baseline():
-    """The oracle's selective_scan_ref (fp32, pure PyTorch - a port of the reference's CPU path) on the host cores."""
-    from oracle import ref_ops
-    B, D, N, Lq = 2, 96, 16, 16384          # ~15 s of host work on the GPU box (7 s at L = 8192)
+def cpu_baseline(full=False):
+    """The reference's CPU path on this box's host cores, bounded samples:
+      value            the C port of the scan (oracle/scan_ref.c, fp64 arithmetic, OpenMP) at the roofline shape, forward
+      scan_fwd_bwd     the same, forward + backward
+      torch_ref        the PyTorch port of selective_scan_ref (a Python loop over time - what the reference's own CPU path is),
+                       forward and forward + backward at L = 2048 (cost is linear in L)
+      segmamba         the whole network on that path: forward at 32^3; with --cpu-baseline-full also forward at 64^3
+                       (BASELINE config 0) and forward + backward at 32^3 (another ~80 s of host time; one such run is kept
+                       in profiles/)."""
+    from oracle import ref_ops, scan_ref
+    from oracle.segmamba_cpu import cpu_reference_segmamba
+    out = {}
+    B, D, N, Lq = 2, 96, 16, 64 ** 3
     g = torch.Generator().manual_seed(0)
-    u, z = torch.randn(B, D, Lq, generator=g), torch.randn(B, D, Lq, generator=g)
-    delta = 0.5 * torch.rand(B, D, Lq, generator=g)
+    mk = lambda L_: dict(u=torch.randn(B, D, L_, generator=g), z=torch.randn(B, D, L_, generator=g),
+                         delta=0.5 * torch.rand(B, D, L_, generator=g), Bm=torch.randn(B, N, L_, generator=g),
+                         Cm=torch.randn(B, N, L_, generator=g), g=torch.randn(B, D, L_, generator=g))
     A = -0.5 * torch.rand(D, N, generator=g)
-    Bm, Cm = torch.randn(B, N, Lq, generator=g), torch.randn(B, N, Lq, generator=g)
     Dv, db = torch.randn(D, generator=g), 0.5 * torch.rand(D, generator=g)
+    c = mk(Lq)
+    args = (c["u"], c["delta"], A, c["Bm"], c["Cm"], Dv, c["z"], db)
+    scan_ref.scan_fwd(*[a[..., :1024].contiguous() if a.dim() == 3 else a for a in args], delta_softplus=True)   # load / warm
+    t0 = time.time()
+    scan_ref.scan_fwd(*args, delta_softplus=True)
+    tf = time.time() - t0
+    t0 = time.time()
+    scan_ref.scan_bwd(*args, c["g"], delta_softplus=True)
+    tb = time.time() - t0
+    bf, bb = algorithmic_bytes_scan(B, D, Lq, N, 4), algorithmic_bytes_scan(B, D, Lq, N, 4, backward=True)
+    out.update({"value": round(bf / tf * 1e-9, 3), "unit": "GB/s", "cores": scan_ref.threads(), "kind": "port",
+                "seconds": round(tf, 2),
+                "sample": f"C port of selective_scan_ref (oracle/scan_ref.c, OpenMP, fp64), forward, fp32 I/O, B={B} D={D} N={N} "
+                          f"L={Lq} (the whole roofline shape), same algorithmic-bytes formula",
+                "scan_fwd_bwd": {"value": round((bf + bb) / (tf + tb) * 1e-9, 3), "unit": "GB/s", "seconds": round(tf + tb, 2)}})
+    # the reference's own CPU path is a Python loop over time: L = 2048
+    Ls = 2048
+    c = mk(Ls)
+    leaves = [c["u"].requires_grad_(), c["delta"].requires_grad_()]
+    t0 = time.time()
+    y = ref_ops.selective_scan_ref(leaves[0], leaves[1], A, c["Bm"], c["Cm"], Dv, z=c["z"], delta_bias=db, delta_softplus=True)
+    t1 = time.time()
+    y.backward(c["g"])
+    t2 = time.time()
+    out["torch_ref"] = {"sample": f"PyTorch port of selective_scan_ref, fp32, B={B} D={D} N={N} L={Ls}",
+                        "cores": torch.get_num_threads(), "fwd_seconds": round(t1 - t0, 2), "fwd_bwd_seconds": round(t2 - t0, 2),
+                        "fwd_GBps": round(algorithmic_bytes_scan(B, D, Ls, N, 4) / (t1 - t0) * 1e-9, 5),
+                        "seconds_per_stage0_scan_extrapolated": round((t2 - t0) * Lq / Ls, 1)}
+    torch.manual_seed(0)
+    net = cpu_reference_segmamba(in_chans=4, out_chans=4, depths=[2, 2, 2, 2], feat_size=[48, 96, 192, 384])
+    x64, x32 = torch.rand(1, 4, 64, 64, 64), torch.rand(1, 4, 32, 32, 32)
     t0 = time.time()
     with torch.no_grad():
-        ref_ops.selective_scan_ref(u, delta, A, Bm, Cm, Dv, z=z, delta_bias=db, delta_softplus=True)
-    dt = time.time() - t0
-    nbytes = ref_ops.algorithmic_bytes_scan(B, D, Lq, N, 4)
-    return {"value": round(nbytes / dt * 1e-9, 4), "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
-            "seconds": round(dt, 2),
-            "sample": f"oracle selective_scan_ref forward, fp32, B={B} D={D} N={N} L={Lq} (1/16 of the roofline shape's L; "
-                      "cost is linear in L), same algorithmic-bytes formula"}
+        net(x32)
+    t32f = time.time() - t0
+    out["segmamba"] = {"sample": "SegMamba(4->4,[2,2,2,2],[48,96,192,384]) on the pure-PyTorch reference path (oracle modules), fp32",
+                       "fwd_32cube_seconds": round(t32f, 2), "volumes_per_s_fwd_32cube": round(1.0 / t32f, 4)}
+    if full:
+        t0 = time.time()
+        with torch.no_grad():
+            net(x64)
+        t64 = time.time() - t0
+        t0 = time.time()
+        torch.nn.functional.cross_entropy(net(x32), torch.randint(0, 4, (1, 32, 32, 32))).backward()
+        t32 = time.time() - t0
+        out["segmamba"].update({"fwd_64cube_seconds": round(t64, 2), "fwd_bwd_32cube_seconds": round(t32, 2),
+                                "volumes_per_s_fwd_64cube": round(1.0 / t64, 4),
+                                "volumes_per_s_fwd_bwd_32cube": round(1.0 / t32, 4)})
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} processes; "
+                 f"run `python bench.py --gpus {world}` or let bench.py launch itself (no torchrun)")
     distributed = world > 1 or os.environ.get("SEGM_FORCE_DDP") == "1"     # the latter: exercise the DDP path on one GPU
+    dry = args.cpu_dry_run
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if dry:
+        # plumbing check only (launch, rendezvous, DDP wrap, barrier / max-over-ranks timing, the JSON line): CPU tensors go
+        # through the CPU emulation build of the kernel sources (test infrastructure, tests/emu)
+        from segmamba_amd import lib as SL
+        from tests import emu_util
+        SL._lib = emu_util.emu_lib()
+        SL.on_device = lambda t: True
+        device = torch.device("cpu")
+        sync = lambda: None
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend="gloo" if dry else "nccl", init_method="env://", rank=rank, world_size=world)
 
-    from segmamba_amd.trainer import SyntheticBraTS, build_training_state, train_step
-    state = build_training_state(device, distributed, local_rank)
+    from segmamba_amd.trainer import DDP_SETTINGS, SyntheticBraTS, build_training_state, train_step
+    model = None
+    if dry:
+        from segmamba_amd.segmamba import SegMamba
+        torch.manual_seed(0)
+        model = SegMamba(in_chans=4, out_chans=4, depths=[1, 1, 1, 1], feat_size=[48, 16, 16, 32], hidden_size=32)
+        args.size, args.batch = 32, 1
+    state = build_training_state(device, distributed, local_rank, model=model)
     data = SyntheticBraTS(args.batch, args.size, device, seed=42 + rank)      # trainer.py:331 seeds 42 + rank
 
     def step():
@@ -176,13 +299,13 @@ def main():
         step()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -191,24 +314,31 @@ def main():
 
     if rank == 0:
         vols = world * args.batch * args.steps
+        ddp = None
+        if distributed:
+            ddp = dict(DDP_SETTINGS)
+            ddp["backend"] = "gloo (cpu dry run)" if dry else "nccl = RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
         out = {
             "metric": f"volumes/sec fwd+bwd+step, SegMamba {args.size}^3x4 (whole job; divide by n_gpus for per-GPU)",
             "value": round(vols / elapsed, 4), "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"SegMamba(4->4,[2,2,2,2],[48,96,192,384]) train step, {args.batch}x4x{args.size}^3 per GPU, "
-                                   "bf16 autocast, CE loss, clip 12, SGD nesterov",
-                       "volumes_per_gpu": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}",
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp32 (cpu dry run)" if dry else "bf16",
+            "data": "synthetic" if not dry else "synthetic; CPU DRY RUN on emulated kernels with a tiny model - not a measurement",
+            "config": {"workload": (f"SegMamba(4->4,[2,2,2,2],[48,96,192,384]) train step, {args.batch}x4x{args.size}^3 per GPU, "
+                                    "bf16 autocast, CE loss, clip 12, SGD nesterov") if not dry else
+                                   "tiny SegMamba, 1x4x32^3 per process, plumbing only",
+                       "volumes_per_gpu": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}", "ddp": ddp,
                        "loss": round(float(loss), 5)},
         }
-        if not args.no_roofline:
+        if not args.no_roofline and not dry:
             out["inference"] = inference_rate(state, device, args.size)
             out["roofline"] = scan_roofline(torch.bfloat16, device)
             out["roofline_fp32"] = scan_roofline(torch.float32, device)
-        if not args.no_cpu_baseline and world == 1:       # the host-core baseline is reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline()
+        if not args.no_cpu_baseline and world == 1 and not dry:       # the host-core baseline is reported at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)
         print(json.dumps(out), flush=True)
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
 
 

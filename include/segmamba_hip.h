@@ -372,7 +372,8 @@ size_t segm_sgd_clip_step_workspace_bytes(int32_t ntensors, const int64_t* numel
  * Replaces `nn.CrossEntropyLoss()(pred, label)` and its backward (reference 3_train.py:48,57-66).
  *
  *   loss_v = logsumexp_c(x[b, :, s]) - x[b, label, s] ;  dlogits[b, c, s] = softmax_c(x)[c] - [c == label]
- *   voxels whose label == ignore_index contribute neither loss nor gradient.
+ *   voxels whose label == ignore_index contribute neither loss nor gradient.  Any other label outside [0, classes) is a
+ *   caller error (ATen raises a device-side assertion): it turns the loss sum and that voxel's gradient into NaN.
  *
  * logits, dlogits: (batch, classes, spatial) contiguous, one dtype (fp32 / fp16 / bf16; arithmetic in fp32); labels
  * (batch, spatial) int64; classes <= 16.  loss_partial / count_partial: fp32 arrays of segm_cross_entropy_partials()

@@ -18,7 +18,7 @@ Every quantity below is mathematically the same convolution, only routed to a di
   wgrad  dW = conv_bwd_weight(x, dy)          or  per input/output channel block
                                               or  segm_conv3d_k3_wgrad, the library's own MFMA kernel
 
-The first time a (kind, shape, dtype) is seen each candidate is timed once on the real tensors and the fastest is
+The first time a (kind, shapes, dtype, device, strides) is seen each candidate is timed once on the real tensors and the fastest is
 cached (what MIOpen's own "find" does, one level up).  On the SegMamba shapes the library's kernels win every layer
 with W >= 32 (profiles/r01_conv_autotune_v2.log); the 16^3 / 8^3 bottleneck layers stay on MIOpen.
 SEGM_CONV_AUTOTUNE=0 always takes the first candidate (the plain library call); SEGM_CONV_VERBOSE=1 prints the timings.
@@ -51,6 +51,12 @@ def _time(fn: Callable[[], torch.Tensor], reps: int = 3) -> float:
     return sorted(times)[len(times) // 2]
 
 
+def _key(kind, x, w, *flags) -> tuple:
+    """cache key of one routing decision: everything a candidate's speed (or applicability) depends on - shapes, dtype,
+    the device, and the operand strides (NCDHW vs channels-last views take different MIOpen solvers)"""
+    return (kind, tuple(x.shape), tuple(w.shape), x.dtype, x.device.index, tuple(x.stride()), tuple(w.stride())) + flags
+
+
 def _pick(key: tuple, cands: List[Callable[[], torch.Tensor]]) -> torch.Tensor:
     if len(cands) == 1 or not _TUNE or not torch.cuda.is_available():
         return cands[0]()
@@ -60,7 +66,12 @@ def _pick(key: tuple, cands: List[Callable[[], torch.Tensor]]) -> torch.Tensor:
         for c in cands:
             try:
                 times.append(_time(c))
-            except RuntimeError:
+            except RuntimeError as e:
+                # only "this candidate does not take this shape" is a score (the library's status -2 / -4, MIOpen's
+                # "no solver"); a HIP launch failure or an out-of-memory error must surface, not be timed as infinity
+                msg = str(e)
+                if "HIP error" in msg or "out of memory" in msg:
+                    raise
                 times.append(float("inf"))
         i = min(range(len(cands)), key=lambda j: times[j])
         _cache[key] = i
@@ -190,7 +201,7 @@ class _ConvSame(torch.autograd.Function):
         ctx.has_bias = bias is not None
         hip = _hip_fwd_ok(x, w)
         chain = hip and _hip_chain_ok(w)
-        key = ("fwd", tuple(x.shape), tuple(w.shape), x.dtype, hip, chain, _hip_untimed_ok())
+        key = _key("fwd", x, w, hip, chain, _hip_untimed_ok())
 
         def with_bias(y):
             return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
@@ -227,7 +238,7 @@ class _ConvSame(torch.autograd.Function):
                 if _hip_untimed_ok():
                     cands.append(lambda: _dgrad_hip(dy, w, x, pad, True, True))
                     cands.append(lambda: _dgrad_hip(dy, w, x, pad, False, False, True))
-            dx = _pick(("dgrad", tuple(x.shape), tuple(w.shape), x.dtype, hip, chain, _hip_untimed_ok()), cands)
+            dx = _pick(_key("dgrad", dy, w, hip, chain, _hip_untimed_ok()), cands)
         if ctx.needs_input_grad[1]:
             cands = [lambda: _wgrad_native(x, dy, w, pad)]
             if blockable:
@@ -235,7 +246,7 @@ class _ConvSame(torch.autograd.Function):
             mfma = _mfma_wgrad_ok(x, dy, w)
             if mfma:
                 cands.append(lambda: _wgrad_mfma(x, dy, w, pad))
-            dw = _pick(("wgrad", tuple(x.shape), tuple(w.shape), x.dtype, mfma), cands)
+            dw = _pick(_key("wgrad", x, w, mfma), cands)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3, 4), dtype=torch.float32).to(dy.dtype)
         return dx, dw, db

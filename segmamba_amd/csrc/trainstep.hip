@@ -190,7 +190,10 @@ __global__ void __launch_bounds__(kCeBlock) cross_entropy_kernel(CeDev P) {
             }
         }
         const bool valid = lab != P.ignore_index;
-        const float inv = 1.f / se;
+        // a label outside [0, classes) that is not ignore_index is a caller error (ATen asserts on the device); here it
+        // poisons the loss and this voxel's gradient with NaN instead of passing as "x[label] = 0": wrong labels stay loud
+        const bool oob = valid && (lab < 0 || lab >= (int64_t)P.classes);
+        const float inv = oob ? __builtin_nanf("") : 1.f / se;
 #pragma unroll
         for (int c = 0; c < kCeMaxC; ++c) {
             if (c < P.classes) {
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(kCeBlock) cross_entropy_kernel(CeDev P) {
             }
         }
         if (valid) {
-            loss = fast_log(se) - xl;          // logsumexp - x[label]
+            loss = oob ? __builtin_nanf("") : fast_log(se) - xl;          // logsumexp - x[label]
             cnt = 1.f;
         }
     }

@@ -96,8 +96,9 @@ def _fill_scan_args(a: L.ScanFwdArgs, u, delta, A, B, C, D, z, delta_bias, delta
 
 def scan_fwd(lib: L.SegmLib, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *,
              channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, need_out=True,
-             need_ckpt=False, need_last_state=False):
-    """-> dict(out, out_z, ckpt, last_state, chunk).  `out` is the un-gated y (None unless need_out or z is None)."""
+             need_ckpt=False, need_last_state=False, ckpt_buf=None):
+    """-> dict(out, out_z, ckpt, last_state, chunk).  `out` is the un-gated y (None unless need_out or z is None).
+    `ckpt_buf`: a caller-owned fp32 buffer of segm_selective_scan_ckpt_bytes() for the checkpoints."""
     a = L.ScanFwdArgs()
     batch, seqlen, dim, dstate, groups, B4, C4 = _fill_scan_args(
         a, u, delta, A, B, C, D, z, delta_bias, delta_softplus, channel_last, time_order, nslices, chunk)
@@ -110,7 +111,13 @@ def scan_fwd(lib: L.SegmLib, u, delta, A, B, C, D=None, z=None, delta_bias=None,
     ckpt = None
     if need_ckpt:
         nbytes = lib.dll.segm_selective_scan_ckpt_bytes(batch, dim, dstate, seqlen)
-        ckpt = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        if ckpt_buf is not None:
+            if ckpt_buf.dtype != torch.float32 or not ckpt_buf.is_contiguous() or ckpt_buf.numel() < nbytes // 4 or \
+                    ckpt_buf.device != dev:
+                raise RuntimeError("scan_fwd: ckpt_buf must be a contiguous fp32 tensor of segm_selective_scan_ckpt_bytes()")
+            ckpt = ckpt_buf
+        else:
+            ckpt = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     last_state = torch.empty(batch, dim, dstate, dtype=torch.float32, device=dev) if need_last_state else None
     ws_bytes = lib.dll.segm_selective_scan_fwd_workspace_bytes(batch, dim, dstate, seqlen, chunk)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -604,3 +611,39 @@ def linear_rows(lib: L.SegmLib, x2: torch.Tensor, w: torch.Tensor, bias: Optiona
     a.stream = L.stream_handle(x2)
     lib.check(lib.dll.segm_linear_rows(a), "linear_rows")
     return y
+
+
+# ---------------------------------------------------------------------------------------------------------
+# device guard
+# ---------------------------------------------------------------------------------------------------------
+# The reference's native ops run under a CUDAGuard on their first tensor's device (selective_scan.cpp:326-327,
+# causal_conv1d.cpp:178-179): a kernel launch goes to the CURRENT device, whatever device the pointers and the stream
+# belong to.  Every launching wrapper above therefore runs with the device of its first CUDA tensor current (a model on
+# cuda:1 while the process's current device is cuda:0 must work); nothing happens - one integer compare - when it already is.
+def _first_cuda_tensor(args):
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            if a.is_cuda:
+                return a
+        elif isinstance(a, (list, tuple)) and a and isinstance(a[0], torch.Tensor) and a[0].is_cuda:
+            return a[0]
+    return None
+
+
+def _device_guard(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def guarded(lib, *args, **kw):
+        t = _first_cuda_tensor(args)
+        if t is not None and t.device.index != torch.cuda.current_device():
+            with torch.cuda.device(t.device):
+                return fn(lib, *args, **kw)
+        return fn(lib, *args, **kw)
+    return guarded
+
+
+for _name in ("scan_fwd", "scan_bwd", "conv1d_fwd", "conv1d_bwd", "conv3d_k3_wgrad", "conv3d_k3_fwd", "instnorm_fwd",
+              "instnorm_bwd", "transpose_add", "layernorm_tokens_fwd", "layernorm_tokens_bwd", "sgd_clip_step", "cross_entropy",
+              "conv1d_update", "state_update", "linear_rows"):
+    globals()[_name] = _device_guard(globals()[_name])

@@ -133,7 +133,7 @@ class MambaInnerCore(torch.autograd.Function):
     @staticmethod
     @_custom_fwd
     def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
-                B_proj_bias, C_proj_bias, delta_softplus, channel_last, time_order, nslices):
+                B_proj_bias, C_proj_bias, delta_softplus, channel_last, time_order, nslices, train=True):
         lib = L.get_lib()
         if torch.is_autocast_enabled():
             act_dtype = torch.get_autocast_dtype("cuda")
@@ -160,8 +160,8 @@ class MambaInnerCore(torch.autograd.Function):
         else:
             x_dbl, delta, Bv, Cv = _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last,
                                             B_proj_bias, C_proj_bias)
-        # the un-gated y and the state checkpoints are only what the backward starts from: inference skips both stores
-        train = any(ctx.needs_input_grad)
+        # the un-gated y and the state checkpoints are only what the backward starts from: inference skips both stores.
+        # `train` is decided by the caller (_inner): ctx.needs_input_grad stays True for parameters under no_grad().
         r = ops_raw.scan_fwd(lib, conv_out, delta, A32, Bv, Cv, D32, z, db32, delta_softplus,
                              channel_last=channel_last, time_order=time_order, nslices=nslices,
                              need_out=train, need_ckpt=train)
@@ -249,7 +249,7 @@ class MambaInnerCore(torch.autograd.Function):
                 ddelta_proj_weight.to(delta_proj_weight.dtype), g["dA"].to(A.dtype),
                 g["dD"].to(D.dtype) if D is not None else None,
                 g["ddelta_bias"].to(delta_bias.dtype) if delta_bias is not None else None,
-                dB_proj_bias, dC_proj_bias, None, None, None, None)
+                dB_proj_bias, dC_proj_bias, None, None, None, None, None)
 
 
 def _rows_route(conv_out, channel_last) -> bool:
@@ -316,8 +316,13 @@ def _inner(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, 
     if B is not None or C is not None:
         raise RuntimeError("constant B / C is not supported: B and C must be None (input-dependent), "
                            "the only case on the SegMamba path")
+    # inference (no_grad, or nothing requires a gradient): the forward skips the stores only a backward would read.
+    # is_grad_enabled() is always False inside Function.forward, so the decision is taken here.
+    train = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D,
+                                                    delta_bias, B_proj_bias, C_proj_bias))
     return MambaInnerCore.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
-                                B_proj_bias, C_proj_bias, delta_softplus, channel_last, time_order, nslices)
+                                B_proj_bias, C_proj_bias, delta_softplus, channel_last, time_order, nslices, train)
 
 
 def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,

@@ -44,6 +44,12 @@ class SyntheticBraTS:
         return item
 
 
+# what build_training_state passes to DistributedDataParallel (bench.py prints it in `config.ddp`).  The reference passes
+# find_unused_parameters=True and the defaults otherwise (light_training/trainer.py:353-357).
+DDP_SETTINGS = {"find_unused_parameters": os.environ.get("SEGM_DDP_FIND_UNUSED", "0") == "1", "gradient_as_bucket_view": True,
+                "bucket_cap_mb": 64}
+
+
 @dataclass
 class TrainingState:
     model: nn.Module
@@ -70,8 +76,7 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
         # restores the reference's flag.
         model = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[local_rank] if device.type == "cuda" else None,
-            find_unused_parameters=os.environ.get("SEGM_DDP_FIND_UNUSED", "0") == "1",
-            gradient_as_bucket_view=True, bucket_cap_mb=64)
+            **DDP_SETTINGS)
     from . import lib as L
     fused = L.on_device(next(model.parameters())) and os.environ.get("SEGM_FUSED_TRAIN_OPS", "1") != "0"
     if fused:

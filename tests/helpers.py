@@ -37,12 +37,38 @@ def iperm(x, order, ns):
     return x
 
 
+# Every comparison appends one JSON line {what, max_abs_err, ref_max, worst (= max err / allowed, <= 1 passes), rtol, atol}
+# to $SEGM_PARITY_LOG (default gpurun_out/parity_log.jsonl when that directory exists), so that a GPU run leaves a record of
+# the margin to the tolerance, not only pass / fail.
+def _parity_log_path():
+    p = os.environ.get("SEGM_PARITY_LOG")
+    if p:
+        return p
+    d = os.path.join(os.path.dirname(GOLDEN.rstrip("/")), "..", "gpurun_out")
+    return os.path.join(d, "parity_log.jsonl") if os.path.isdir(d) else None
+
+
+def _parity_log(rec):
+    p = _parity_log_path()
+    if p:
+        import json
+        try:
+            with open(p, "a") as f:
+                f.write(json.dumps(rec) + "\n")
+        except OSError:
+            pass
+
+
 def assert_close(a, b, rtol, atol, what=""):
-    a = a.detach().float().cpu()
-    b = b.detach().float().cpu()
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     err = (a - b).abs()
     tol = atol + rtol * b.abs()
+    worst = float((err / tol).max()) if err.numel() else 0.0
+    _parity_log({"what": what, "max_abs_err": float(err.max()) if err.numel() else 0.0,
+                 "ref_max": float(b.abs().max()) if b.numel() else 0.0, "worst": worst, "rtol": rtol, "atol": atol,
+                 "dev": "cuda" if torch.cuda.is_available() else "cpu-emu"})
     bad = err > tol
     assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; "
                            f"max abs err {err.max().item():.3e} (rtol {rtol}, atol {atol}, ref max {b.abs().max().item():.3e})")
@@ -134,29 +160,43 @@ def run_scan(lib, c, device, channel_last, order=L.TIME_FORWARD, ns=1, chunk=0, 
     return res
 
 
+def north_star_tol(dtype):
+    """BASELINE.json north_star: "within 1e-3 fp32 / 1e-2 bf16" of selective_scan_ref on identical inputs (fp16: 5e-3).
+    Tighter than the reference's own test tolerances (mamba/tests/ops/test_selective_scan.py:45-51: 6e-4 + 2e-3 fp32,
+    3e-2 + 5e-2 bf16, with x2 ... x10 on the gradients)."""
+    return {torch.float32: 1e-3, torch.float16: 5e-3, torch.bfloat16: 1e-2}[dtype]
+
+
 def scan_tolerances(dtype):
-    """reference tolerances, mamba/tests/ops/test_selective_scan.py:45-51,137-149"""
-    rtol, atol = (6e-4, 2e-3) if dtype == torch.float32 else (3e-3, 5e-3)
-    if dtype == torch.bfloat16:
-        rtol, atol = 3e-2, 5e-2
-    rtolw, atolw = max(1e-3, rtol), max(1e-3, atol)
-    return rtol, atol, rtolw, atolw
+    """(rtol, atol) for element-wise quantities = the north-star bound for both; kept for callers of the old name."""
+    t = north_star_tol(dtype)
+    return t, t, t, t
 
 
 def check_scan(res, ref, dtype, what=""):
-    rtol, atol, rtolw, atolw = scan_tolerances(dtype)
-    assert_close(res["out"], ref["out"], rtol, atol, what + " out")
-    assert_close(res["last_state"], ref["last_state"], rtol, atol, what + " last_state")
+    """|err| <= tol * |ref| + tol * S per element, tol = the north-star bound of the dtype.  S = 1 for the per-element
+    outputs (out, last state, du, ddelta, dz, dB, dC - values of order 1 ... 10 on the test distributions) and
+    S = max |ref| for the reductions over batch x time (dA, dD, ddelta_bias), whose magnitude grows with the sequence
+    length (fp32 accumulation order differs from the oracle's)."""
+    t = north_star_tol(dtype)
+
+    def red(k):
+        return t * max(1.0, float(ref[k].abs().max()))
+
+    assert_close(res["out"], ref["out"], t, t, what + " out")
+    if res.get("last_state") is not None and ref.get("last_state") is not None:
+        assert_close(res["last_state"], ref["last_state"], t, t, what + " last_state")
     if "du" not in res:
         return
-    assert_close(res["du"], ref["du"], rtol * 2, atol * 2, what + " du")
-    assert_close(res["ddelta"], ref["ddelta"], rtol * 5, atol * 10, what + " ddelta")
-    assert_close(res["dA"], ref["dA"], rtolw, atolw * 5, what + " dA")
-    assert_close(res["dB"], ref["dB"], rtol, atol, what + " dB")
-    assert_close(res["dC"], ref["dC"], rtol, atol, what + " dC")
+    assert_close(res["du"], ref["du"], t, t, what + " du")
+    assert_close(res["ddelta"], ref["ddelta"], t, t, what + " ddelta")
+    assert_close(res["dA"], ref["dA"], t, red("dA"), what + " dA")
+    if ref.get("dB") is not None:
+        assert_close(res["dB"], ref["dB"], t, t, what + " dB")
+        assert_close(res["dC"], ref["dC"], t, t, what + " dC")
     if ref.get("dD") is not None:
-        assert_close(res["dD"], ref["dD"], rtolw, atolw, what + " dD")
+        assert_close(res["dD"], ref["dD"], t, red("dD"), what + " dD")
     if ref.get("dz") is not None:
-        assert_close(res["dz"], ref["dz"], rtolw, atolw, what + " dz")
+        assert_close(res["dz"], ref["dz"], t, t, what + " dz")
     if ref.get("ddelta_bias") is not None:
-        assert_close(res["ddelta_bias"], ref["ddelta_bias"], rtolw, atolw, what + " ddelta_bias")
+        assert_close(res["ddelta_bias"], ref["ddelta_bias"], t, red("ddelta_bias"), what + " ddelta_bias")

@@ -99,3 +99,67 @@ def test_two_process_ddp_with_library_loss_and_optimizer(monkeypatch):
     monkeypatch.setattr(L, "_lib", emu_util.emu_lib())
     monkeypatch.setattr(L, "on_device", lambda t: True)
     assert isinstance(build_training_state(torch.device("cpu"), model=_tiny_model()).optimizer, FusedClipSGD)
+
+
+def _segmamba_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _use_emulated_library()
+    from segmamba_amd.segmamba import SegMamba
+    from segmamba_amd.trainer import build_training_state, train_step
+    torch.manual_seed(0)
+    net = SegMamba(in_chans=4, out_chans=4, depths=[1, 1, 1, 1], feat_size=[48, 16, 16, 32], hidden_size=32)
+    st = build_training_state(torch.device("cpu"), distributed=True, model=net)
+    g = torch.Generator().manual_seed(42 + rank)
+    img, lab = torch.rand(1, 4, 32, 32, 32, generator=g), torch.randint(0, 4, (1, 32, 32, 32), generator=g)
+    losses = [float(train_step(st, img, lab)) for _ in range(2)]
+    out[rank] = (losses, [p.detach().clone() for p in st.model.module.parameters()],
+                 [None if p.grad is None else bool(torch.isfinite(p.grad).all()) for p in st.model.module.parameters()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_ddp_with_the_real_segmamba_on_emulated_kernels():
+    """The REAL network under DDP: SegMamba with its custom autograd Functions (MambaInnerCore, the conv dispatcher, fused norms)
+    on the library's kernels (CPU emulation), gradients as views into DDP's buckets (gradient_as_bucket_view), the library's
+    loss and clip + SGD kernels.  Every parameter must receive a gradient on both ranks (find_unused_parameters=False is only
+    legal then) and the ranks must stay bit-identical after two steps."""
+    from tests import emu_util
+    if not emu_util.emu_available():
+        pytest.skip("no host clang for the emulation build")
+    emu_util.build_emu()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_segmamba_worker, args=(2, port, out), nprocs=2, join=True)
+    assert all(f is True for f in out[0][2]) and all(f is True for f in out[1][2]), "a parameter got no (finite) gradient"
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.equal(a, b), "ranks diverged"
+    assert out[0][0] != out[1][0]                           # different data per rank (seed 42 + rank), same weights
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` (no torchrun) must start two ranks and report n_gpus = 2; under a launcher whose world size
+    differs from --gpus it must refuse.  CPU dry run: gloo, emulated kernels, tiny model."""
+    import json
+    import subprocess
+    import sys
+    from tests import emu_util
+    if not emu_util.emu_available():
+        pytest.skip("no host clang for the emulation build")
+    emu_util.build_emu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-dry-run", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]                 # rank 0 prints ONE line
+    rec = json.loads(line[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["ddp"]["bucket_cap_mb"] == 64
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-dry-run", "--steps", "1", "--warmup", "0"],
+                        capture_output=True, text=True, timeout=600, env=env2, cwd=root)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in r2.stderr

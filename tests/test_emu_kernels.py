@@ -422,6 +422,11 @@ def test_cross_entropy_emulated(emu, shape, dtype):
     assert abs(float(loss_sum) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
     tol = 1e-6 if dtype == torch.float32 else (1e-3 if dtype == torch.float16 else 8e-3)
     assert dlogits.dtype == dtype and (dlogits.double() - ref_in.grad).abs().max() <= tol
+    # a label outside [0, C) that is not ignore_index must not pass silently (ATen asserts): the loss becomes NaN
+    bad = labels.clone()
+    bad.view(-1)[1] = shape[1]
+    loss_bad, _, d_bad = ops_raw.cross_entropy(emu, logits, bad)
+    assert torch.isnan(loss_bad) and torch.isnan(d_bad.float()).any()
 
 
 def test_conv_dispatcher_library_routes_on_emulated_kernels(emu, monkeypatch):

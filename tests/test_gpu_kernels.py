@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP kernels (through the C ABI of libsegmamba_hip.so) against the CPU oracle and against the
-golden fixtures produced by the reference.  Tolerances are the reference's own (see helpers.scan_tolerances) which are
-at or below the north-star bounds for fp32 (1e-3) / bf16 (1e-2 relative)."""
+golden fixtures produced by the reference.  Scan tolerances are BASELINE.json's north-star bounds (helpers.check_scan:
+|err| <= tol |ref| + tol with tol = 1e-3 fp32 / 1e-2 bf16 - tighter than the reference's own test tolerances); every
+comparison logs its margin (helpers.assert_close -> gpurun_out/parity_log.jsonl).  The sizes BASELINE.json names are in
+tests/test_gpu_at_size.py (fp64 C oracle)."""
 import numpy as np
 import pytest
 import torch

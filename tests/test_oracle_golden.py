@@ -120,3 +120,42 @@ def test_decode_oracle_matches_reference(golden_dir):
     _close(torch.cat(outs, 1), f["out_steps"])
     _close(conv, f["conv_state_final"])
     _close(ssm, f["ssm_state_final"])
+
+
+# ---- the fp64 C oracle (oracle/scan_ref.c): the checker of the at-size GPU tests, pinned to the same fixtures --------------
+@pytest.mark.parametrize("L", [64, 256])
+@pytest.mark.parametrize("G", [1, 2])
+def test_c_oracle_matches_reference(golden_dir, L, G):
+    from oracle import scan_ref
+    f = _load(golden_dir, f"scan_L{L}_G{G}.npz")
+    args = (f["u"], f["delta"], f["A"], f["B"], f["C"], f["D"], f["z"], f["delta_bias"])
+    r = scan_ref.scan_fwd(*args, delta_softplus=True)
+    _close(r["out"].float(), f["out"])
+    _close(r["last_state"].float(), f["last_state"])
+    g = scan_ref.scan_bwd(*args, f["g"], delta_softplus=True)
+    for k in ("du", "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias"):
+        _close(g[k].float(), f[k], tol=2e-5)
+
+
+def test_c_oracle_matches_pytorch_oracle_on_ragged_optional_cases():
+    """lengths that are not multiples of the C oracle's recompute block, no z / D / bias, no softplus"""
+    from oracle import scan_ref
+    from tests import helpers as H
+    for seqlen, has_z, has_D, has_bias, softplus in [(2049, True, True, True, True), (37, False, True, False, False),
+                                                      (4100, True, False, True, True)]:
+        c = H.scan_case(1, 6, 5, seqlen, seed=seqlen, has_z=has_z, has_D=has_D, has_bias=has_bias)
+        ref = H.scan_oracle(c, softplus=softplus)
+        args = (c["u"], c["delta"], c["A"], c["B"], c["C"], c["D"], c["z"], c["delta_bias"])
+        r = scan_ref.scan_fwd(*args, delta_softplus=softplus)
+        _close(r["out"].float(), ref["out"])
+        g = scan_ref.scan_bwd(*args, c["g"], delta_softplus=softplus)
+        for k in g:
+            _close(g[k].float(), ref[k], tol=1e-4)
+
+
+@pytest.mark.parametrize("width", [2, 3, 4])
+def test_c_oracle_conv1d_matches_reference(golden_dir, width):
+    from oracle import scan_ref
+    f = _load(golden_dir, f"conv1d_w{width}.npz")
+    _close(scan_ref.conv1d_fwd(f["x"], f["weight"], f["bias"], True).float(), f["out"])
+    _close(scan_ref.conv1d_fwd(f["x"], f["weight"], None, False).float(), f["out_nobias_noact"])

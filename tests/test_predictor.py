@@ -70,3 +70,20 @@ def test_predictor_on_device_full_brats_case():
     assert y.shape == (1, 4, 138, 176, 144) and y.device.type == "cuda" and torch.isfinite(y).all()
     y_flip = pred.maybe_mirror_and_predict(torch.flip(x, (3,)), model, device=dev)
     assert (torch.flip(y_flip, (3,)) - y).abs().max() <= 2e-2 * float(y.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_sliding_window_and_mirror_tta_match_reference_on_the_gpu(name):
+    """the reference-generated fixtures again, with the volume, the window batches, the blending accumulator and the mirrored
+    predictions resident on the GPU (the setting the predictor is written for)"""
+    shape, roi, swb, ov, mode, axes = CASES[name]
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(sum(shape))).cuda()
+    net = toy_net(shape[1], 3).cuda()
+    inferer = P.SlidingWindowInferer(roi_size=roi, sw_batch_size=swb, overlap=ov, mode=mode)
+    with torch.no_grad():
+        win = inferer(x, net)
+    assert win.is_cuda
+    assert np.allclose(win.cpu().numpy(), GOLD[name + "_window"], atol=5e-6)
+    tta = P.Predictor(window_infer=inferer, mirror_axes=axes).maybe_mirror_and_predict(x, net)
+    assert tta.is_cuda and np.allclose(tta.cpu().numpy(), GOLD[name + "_tta"], atol=5e-6)
