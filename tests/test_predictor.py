@@ -84,6 +84,13 @@ def test_sliding_window_and_mirror_tta_match_reference_on_the_gpu(name):
     with torch.no_grad():
         win = inferer(x, net)
     assert win.is_cuda
-    assert np.allclose(win.cpu().numpy(), GOLD[name + "_window"], atol=5e-6)
+    # the toy network's convolutions run on MIOpen here and on ATen's CPU kernels in the fixture: fp32 round-off of a different
+    # summation order (per mirrored input a different solver may be picked), bounded relative to the output's magnitude
+    def err(got, key):
+        ref = GOLD[key]
+        return float(np.abs(got.cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max()))
+    e_win = err(win, name + "_window")
+    assert e_win <= 2e-5, f"window prediction: relative error {e_win:.3e}"
     tta = P.Predictor(window_infer=inferer, mirror_axes=axes).maybe_mirror_and_predict(x, net)
-    assert tta.is_cuda and np.allclose(tta.cpu().numpy(), GOLD[name + "_tta"], atol=5e-6)
+    e_tta = err(tta, name + "_tta")
+    assert tta.is_cuda and e_tta <= 2e-5, f"mirror TTA: relative error {e_tta:.3e}"

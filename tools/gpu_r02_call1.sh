@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 rm -f gpurun_out/parity_log.jsonl
 timeout 120 ./build/probe_valu2 > gpurun_out/r02_probe_valu2.log 2>&1; tail -50 gpurun_out/r02_probe_valu2.log
-timeout 900 python -m pytest tests -m gpu -q -x --durations=15 > gpurun_out/r02_gpu_tests.log 2>&1; tail -40 gpurun_out/r02_gpu_tests.log
+timeout 900 python -m pytest tests -m gpu -q --durations=15 > gpurun_out/r02_gpu_tests.log 2>&1; tail -40 gpurun_out/r02_gpu_tests.log
 timeout 90 python - > gpurun_out/r02_linear.log 2>&1 <<'PY'
 import sys; sys.path.insert(0, ".")
 import torch
