@@ -199,8 +199,19 @@ __global__ void __launch_bounds__(kCarrySegs * 64) reduce_partials_kernel(const 
     const int d = blockIdx.x * 64 + lane, k = blockIdx.y;
     const bool valid = d < dim;
     float acc = 0.f;
-    if (valid)
-        for (int64_t r = seg; r < nrows; r += kCarrySegs) acc += part[(r * K + k) * dim + d];
+    if (valid) {
+        // eight rows in flight per lane, added in row order (the sum is the same as a plain loop's, bit for bit)
+        constexpr int U = 8;
+        int64_t r = seg;
+        for (; r + (U - 1) * kCarrySegs < nrows; r += U * kCarrySegs) {
+            float v[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) v[i] = part[((r + i * kCarrySegs) * K + k) * dim + d];
+#pragma unroll
+            for (int i = 0; i < U; ++i) acc += v[i];
+        }
+        for (; r < nrows; r += kCarrySegs) acc += part[(r * K + k) * dim + d];
+    }
     s_acc[seg][lane] = acc;
     __syncthreads();
     if (seg == 0 && valid) {

@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(256) clear_bc_kernel(float* p, int64_t sb, int
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
-struct BwdWs { size_t sd, e, carry, part, total; };
+struct BwdWs { size_t sd, e, carry, part, seg, total; };
 static BwdWs bwd_ws_layout(int batch, int dim, int nstate, int64_t L, int chunk) {
     const int64_t nch = (L + chunk - 1) / chunk;
     BwdWs w;
@@ -383,7 +383,8 @@ static BwdWs bwd_ws_layout(int batch, int dim, int nstate, int64_t L, int chunk)
     w.e = align256((size_t)batch * nch * dim * sizeof(float));
     w.carry = w.e + align256((size_t)batch * nch * nstate * dim * sizeof(float));
     w.part = w.carry + align256((size_t)batch * nch * nstate * dim * sizeof(float));
-    w.total = w.part + align256((size_t)batch * nch * (nstate + 2) * dim * sizeof(float));
+    w.seg = w.part + align256((size_t)batch * nch * (nstate + 2) * dim * sizeof(float));
+    w.total = w.seg + scan_carry_scratch_bytes(batch, dim, nstate, nch);
     return w;
 }
 
@@ -393,7 +394,7 @@ static int launch_bwd_rw(const ScanDev& P, hipStream_t stream) {
     const Geom& gm = P.gm;
     const unsigned nblocks = (unsigned)((gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL((scan_bwd_agg_kernel<T, NS, TS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
-    launch_scan_carry(P, true, P.agg_sd, P.agg_h, P.carry, stream);
+    launch_scan_carry(P, true, P.agg_sd, P.agg_h, P.carry, P.carry_seg, stream);
     hipLaunchKernelGGL((scan_bwd_main_kernel<T, NS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
     return (int)hipGetLastError();
 }
@@ -470,6 +471,7 @@ extern "C" int segm_selective_scan_bwd(const segm_scan_bwd_args* b) {
         P.agg_h = (float*)(wsb + ws.e) + (size_t)g * a->batch * nch * N * Dg;
         P.carry = (float*)(wsb + ws.carry) + (size_t)g * a->batch * nch * N * Dg;
         P.part = (float*)(wsb + ws.part) + (size_t)g * a->batch * nch * (N + 2) * Dg;
+        P.carry_seg = (float*)(wsb + ws.seg) + (size_t)g * a->batch * ((nch + kCarrySeg - 1) / kCarrySeg) * (N + 1) * Dg;
         P.dout = seq_at(b->dout, d0, es); P.du = seq_at(b->du, d0, es);
         P.ddelta = seq_at(b->ddelta, d0, es); P.dz = seq_at(b->dz, d0, es);
         P.dB = (float*)b->dB.ptr + (int64_t)g * b->dB.stride_g;
@@ -485,7 +487,7 @@ extern "C" int segm_selective_scan_bwd(const segm_scan_bwd_args* b) {
         }
         if (use_fast_bwd() && scan_bwd_fast_shape(P)) {     // regular shapes (every SegMamba stage): scan_bwd_fast.hip
             launch_scan_bwd_fast(P, a->dtype, false, stream);
-            launch_scan_carry(P, true, P.agg_sd, P.agg_h, P.carry, stream);
+            launch_scan_carry(P, true, P.agg_sd, P.agg_h, P.carry, P.carry_seg, stream);
             launch_scan_bwd_fast(P, a->dtype, true, stream);
             rc = (int)hipGetLastError();
         } else if (a->dtype == SEGM_F32) rc = launch_bwd_ns<float>(P, stream);

@@ -4,7 +4,8 @@
 
 namespace segm {
 
-constexpr int kCarrySegs = 16;        // waves per workgroup of the carry kernel, each owning 1/16 of the chunks
+constexpr int kCarrySegs = 16;        // waves per workgroup of the partial-sum reduction kernel (conv1d.hip)
+constexpr int kCarrySeg = 64;         // chunks per segment of the carry kernels (held in registers by one wave)
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Device-side argument block of the scan kernels: one B/C group, channel offset already applied.
@@ -21,6 +22,7 @@ struct ScanDev {
     float* agg_sd;                         // [batch][nchunks][dim]          sum of delta over the chunk
     float* agg_h;                          // [batch][nchunks][nstate][dim]  chunk end state from a zero start
     float* carry;                          // [batch][nchunks][nstate][dim]  state entering the chunk
+    float* carry_seg;                      // [batch][nseg][nstate + 1][dim] scratch of the carry kernels (segment composites)
     float* ckpt;                           // [batch][nck][nstate][dim]      state entering step 16*k (or null)
     int32_t nck;
     float* last_state;                     // (batch, dim, nstate) or null
@@ -138,7 +140,8 @@ bool scan_fast_shape(const ScanDev& P);                        // scan_fwd_fast.
 void launch_scan_fwd_fast(const ScanDev& P, int dtype, bool apply, hipStream_t stream);
 bool scan_bwd_fast_shape(const ScanDev& P);                    // scan_bwd_fast.hip
 void launch_scan_bwd_fast(const ScanDev& P, int dtype, bool main, hipStream_t stream);
-void launch_scan_carry(const ScanDev& P, bool reverse, const float* agg_sd, const float* agg_h, float* carry,
+void launch_scan_carry(const ScanDev& P, bool reverse, const float* agg_sd, const float* agg_h, float* carry, float* seg,
                        hipStream_t stream);
+size_t scan_carry_scratch_bytes(int batch, int dim, int nstate, int64_t nchunks);
 
 }  // namespace segm

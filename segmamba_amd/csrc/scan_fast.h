@@ -112,6 +112,23 @@ __device__ __forceinline__ void fast_stage_park(const float (&v)[FastStage<RW>::
     for (int i = 0; i < FastStage<RW>::EPL; ++i) lds_item[st.lds0 + i * st.ldsinc] = v[i];
 }
 
+// acc += x[lane 4 (l / 4) + K of this lane's quad] * y.  B_t / C_t sit in LDS as fp32 rows of 16; ONE ds_read_b128 per matrix
+// and step hands lane l the four values 4 (l % 4) .. + 3, so every quad of lanes holds the whole row and state n = 4 K + i is
+// register i of quad lane K: a DPP operand (quad_perm:[K,K,K,K]) of a v_fmac_f32 instead of a 64-byte broadcast read per lane
+// (8 VGPRs for B_t and C_t instead of 32).  Inline asm: the compiler's DPP combiner gives up once it has packed the two
+// multiply-adds of a state pair.  (profiles/r02_proto_scan_v5.log)
+template <int K> __device__ __forceinline__ void fmac_quad(float& acc, float x, float y) {
+#ifdef SEGM_EMU
+    acc = fmaf(__shfl(x, (int)((threadIdx.x & 63u) & ~3u) + K), y, acc);
+#else
+    static_assert(K >= 0 && K < 4, "quad lane");
+    if (K == 0) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y));
+    if (K == 1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y));
+    if (K == 2) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y));
+    if (K == 3) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y));
+#endif
+}
+
 // U of sub-tile s computed directly (the backward walks the sub-tiles downwards)
 __device__ __forceinline__ int32_t fast_U_of(const TimeMap& tm, int32_t s) {
     if (tm.ns > 1) {

@@ -121,88 +121,97 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_kernel(ScanDev P) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// K2: compose chunk aggregates into the state entering every chunk.  One thread per (batch, channel, state),
-// 16 waves per workgroup each owning 1/16 of the chunks: local fold, 16-entry LDS fold, re-walk.
-// REVERSE walks the chunks from last to first (backward pass: the adjoint state entering from the right).
+// K2: compose chunk aggregates into the state entering every chunk (REVERSE: chunks from last to first - the backward
+// pass's adjoint entering from the right).  A latency problem, not a bandwidth one: per (batch, channel, state) a chain of
+// one fma per chunk behind two loads.  Two launches of single-wave workgroups (lane = channel), one per
+// (batch, channel tile, state, segment of kCarrySeg chunks), each holding its whole segment in registers behind ONE batch of
+// loads:  A) fold the segment from a zero start -> (sum of delta, end state);  B) fold the composites of the segments
+// before this one (again one batch), then walk the segment's chunks from that state, storing the state entering each.
+// (Round 1's kernel walked 64 chunks per wave twice behind 16-deep single-buffered loads: 47 us at 1024 chunks.)
 // ------------------------------------------------------------------------------------------------------
-template <bool REVERSE>
-__global__ void __launch_bounds__(kCarrySegs * 64) scan_carry_kernel(ScanDev P, const float* __restrict__ agg_sd,
-                                                                     const float* __restrict__ agg_h,
-                                                                     float* __restrict__ carry) {
-    constexpr int TILE = 16;            // chunks whose aggregates are fetched together (independent loads), then folded
-    __shared__ float s_p[kCarrySegs][64];
-    __shared__ float s_h[kCarrySegs][64];
-    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+template <bool REVERSE, bool PHASE_B>
+__global__ void __launch_bounds__(64) scan_carry_kernel(ScanDev P, const float* __restrict__ agg_sd,
+                                                        const float* __restrict__ agg_h, float* __restrict__ carry,
+                                                        float* __restrict__ seg) {
+    const int lane = threadIdx.x;
     const Geom& gm = P.gm;
-    const int d = blockIdx.x * 64 + lane, n = blockIdx.y, b = blockIdx.z;
+    const int nstate = gm.nstate, nch = gm.nchunks;
+    const int nseg = (nch + kCarrySeg - 1) / kCarrySeg;
+    const int d = blockIdx.x * 64 + lane, b = blockIdx.z;
+    const int n = blockIdx.y % nstate, sg = blockIdx.y / nstate;
     const bool valid = d < gm.dim;
     const int dd = valid ? d : 0;
-    const int nstate = gm.nstate;
-    const int nch = gm.nchunks;
-    const int per = (nch + kCarrySegs - 1) / kCarrySegs;
-    const int q0 = seg * per;
-    const int q1 = (q0 + per < nch) ? q0 + per : nch;
     const float A2 = valid ? P.A[(int64_t)d * nstate + n] * kLog2e : 0.f;
     const float* sd_base = agg_sd + (int64_t)b * nch * gm.dim + dd;
     const float* h_base = agg_h + ((int64_t)b * nch * nstate + n) * gm.dim + dd;
     const int64_t h_stride = (int64_t)nstate * gm.dim;
+    // segment composites: [batch][segment][nstate + 1][dim], row nstate = sum of delta
+    float* seg_b = seg + (int64_t)b * nseg * (nstate + 1) * gm.dim + dd;
+    const int64_t seg_stride = (int64_t)(nstate + 1) * gm.dim;
 
-    float acc = 0.f, sds = 0.f;
-    for (int qb = q0; qb < q1; qb += TILE) {
-        float pv[TILE], hv[TILE];
-#pragma unroll
-        for (int i = 0; i < TILE; ++i) {
-            const int q = qb + i;
-            const bool in = q < q1;
-            const int c = in ? (REVERSE ? nch - 1 - q : q) : 0;
-            const float sd = sd_base[(int64_t)c * gm.dim];
-            const float hh = h_base[(int64_t)c * h_stride];
-            sds += in ? sd : 0.f;
-            pv[i] = in ? fast_exp2(A2 * sd) : 1.f;
-            hv[i] = in ? hh : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < TILE; ++i) acc = fmaf(pv[i], acc, hv[i]);
-    }
-    s_p[seg][lane] = fast_exp2(A2 * sds);
-    s_h[seg][lane] = acc;
-    __syncthreads();
     float cin = 0.f;
-    for (int s = 0; s < seg; ++s) cin = fmaf(s_p[s][lane], cin, s_h[s][lane]);
-    for (int qb = q0; qb < q1; qb += TILE) {
-        float pv[TILE], hv[TILE];
+    float psd[kCarrySeg], ph[kCarrySeg];                          // PHASE_B: composites of the earlier segments
+    if (PHASE_B) {
 #pragma unroll
-        for (int i = 0; i < TILE; ++i) {
-            const int q = qb + i;
-            const bool in = q < q1;
-            const int c = in ? (REVERSE ? nch - 1 - q : q) : 0;
-            const float sd = sd_base[(int64_t)c * gm.dim];
-            const float hh = h_base[(int64_t)c * h_stride];
-            pv[i] = in ? fast_exp2(A2 * sd) : 1.f;
-            hv[i] = in ? hh : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < TILE; ++i) {
-            const int q = qb + i;
-            if (valid && q < q1) {
-                const int c = REVERSE ? nch - 1 - q : q;
-                carry[(((int64_t)b * nch + c) * nstate + n) * gm.dim + d] = cin;
-            }
-            cin = fmaf(pv[i], cin, hv[i]);
+        for (int i = 0; i < kCarrySeg; ++i) {
+            const int s = i < sg ? i : 0;
+            psd[i] = seg_b[(int64_t)s * seg_stride + (int64_t)nstate * gm.dim];
+            ph[i] = seg_b[(int64_t)s * seg_stride + (int64_t)n * gm.dim];
         }
     }
-    if (!REVERSE && P.last_state && valid && q0 < nch && q1 == nch)
+    float sd[kCarrySeg], hh[kCarrySeg];
+    const int q0 = sg * kCarrySeg;
+#pragma unroll
+    for (int i = 0; i < kCarrySeg; ++i) {
+        const int q = q0 + i < nch ? q0 + i : nch - 1;            // clamped: a re-read, masked below
+        const int c = REVERSE ? nch - 1 - q : q;
+        sd[i] = sd_base[(int64_t)c * gm.dim];
+        hh[i] = h_base[(int64_t)c * h_stride];
+    }
+    if (PHASE_B) {
+#pragma unroll
+        for (int i = 0; i < kCarrySeg; ++i)
+            if (i < sg) cin = fmaf(fast_exp2(A2 * psd[i]), cin, ph[i]);
+        for (int s = kCarrySeg; s < sg; ++s)                       // more than kCarrySeg^2 chunks: the remaining composites, in order
+            cin = fmaf(fast_exp2(A2 * seg_b[(int64_t)s * seg_stride + (int64_t)nstate * gm.dim]), cin,
+                       seg_b[(int64_t)s * seg_stride + (int64_t)n * gm.dim]);
+    }
+    float sds = 0.f;
+#pragma unroll
+    for (int i = 0; i < kCarrySeg; ++i) {
+        const int q = q0 + i;
+        if (q < nch) {
+            const int c = REVERSE ? nch - 1 - q : q;
+            if (PHASE_B && valid) carry[(((int64_t)b * nch + c) * nstate + n) * gm.dim + d] = cin;
+            cin = fmaf(fast_exp2(A2 * sd[i]), cin, hh[i]);
+            sds += sd[i];
+        }
+    }
+    if (!PHASE_B && valid) {
+        seg_b[(int64_t)sg * seg_stride + (int64_t)n * gm.dim] = cin;
+        if (n == 0) seg_b[(int64_t)sg * seg_stride + (int64_t)nstate * gm.dim] = sds;
+    }
+    if (PHASE_B && !REVERSE && P.last_state && valid && sg == nseg - 1)
         P.last_state[(int64_t)b * P.last_state_sb + (int64_t)d * nstate + n] = cin;
 }
 
-void launch_scan_carry(const ScanDev& P, bool reverse, const float* agg_sd, const float* agg_h, float* carry,
+size_t scan_carry_scratch_bytes(int batch, int dim, int nstate, int64_t nchunks) {
+    const int64_t nseg = (nchunks + kCarrySeg - 1) / kCarrySeg;
+    return align256((size_t)batch * nseg * (nstate + 1) * dim * sizeof(float));
+}
+
+void launch_scan_carry(const ScanDev& P, bool reverse, const float* agg_sd, const float* agg_h, float* carry, float* seg,
                        hipStream_t stream) {
     const Geom& gm = P.gm;
-    dim3 cgrid((gm.dim + 63) / 64, gm.nstate, gm.batch);
-    if (reverse)
-        hipLaunchKernelGGL((scan_carry_kernel<true>), cgrid, dim3(kCarrySegs * 64), 0, stream, P, agg_sd, agg_h, carry);
-    else
-        hipLaunchKernelGGL((scan_carry_kernel<false>), cgrid, dim3(kCarrySegs * 64), 0, stream, P, agg_sd, agg_h, carry);
+    const int nseg = (gm.nchunks + kCarrySeg - 1) / kCarrySeg;
+    dim3 cgrid((gm.dim + 63) / 64, gm.nstate * nseg, gm.batch);
+    if (reverse) {
+        if (nseg > 1) hipLaunchKernelGGL((scan_carry_kernel<true, false>), cgrid, dim3(64), 0, stream, P, agg_sd, agg_h, carry, seg);
+        hipLaunchKernelGGL((scan_carry_kernel<true, true>), cgrid, dim3(64), 0, stream, P, agg_sd, agg_h, carry, seg);
+    } else {
+        if (nseg > 1) hipLaunchKernelGGL((scan_carry_kernel<false, false>), cgrid, dim3(64), 0, stream, P, agg_sd, agg_h, carry, seg);
+        hipLaunchKernelGGL((scan_carry_kernel<false, true>), cgrid, dim3(64), 0, stream, P, agg_sd, agg_h, carry, seg);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -377,14 +386,15 @@ int32_t default_chunk(int32_t batch, int32_t dim, int64_t L) {
     return chunk;
 }
 
-struct FwdWs { size_t sd, h, carry, total; };
+struct FwdWs { size_t sd, h, carry, seg, total; };
 static FwdWs fwd_ws_layout(int batch, int dim, int nstate, int64_t L, int chunk) {
     const int64_t nch = (L + chunk - 1) / chunk;
     FwdWs w;
     w.sd = 0;
     w.h = align256((size_t)batch * nch * dim * sizeof(float));
     w.carry = w.h + align256((size_t)batch * nch * nstate * dim * sizeof(float));
-    w.total = w.carry + align256((size_t)batch * nch * nstate * dim * sizeof(float));
+    w.seg = w.carry + align256((size_t)batch * nch * nstate * dim * sizeof(float));
+    w.total = w.seg + scan_carry_scratch_bytes(batch, dim, nstate, nch);
     return w;
 }
 
@@ -407,7 +417,7 @@ static int launch_fwd_rw(const ScanDev& P, hipStream_t stream) {
     const Geom& gm = P.gm;
     const unsigned nblocks = (unsigned)((gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL((scan_fwd_agg_kernel<T, NS, TS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
-    launch_scan_carry(P, false, P.agg_sd, P.agg_h, P.carry, stream);
+    launch_scan_carry(P, false, P.agg_sd, P.agg_h, P.carry, P.carry_seg, stream);
     if (apply_subtile() == 4)
         hipLaunchKernelGGL((scan_fwd_apply_kernel<T, NS, 4, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
     else
@@ -563,11 +573,12 @@ extern "C" int segm_selective_scan_fwd(const segm_scan_fwd_args* a) {
         P.agg_sd = (float*)(wsb + ws.sd) + (size_t)g * a->batch * nch * Dg;
         P.agg_h = (float*)(wsb + ws.h) + (size_t)g * a->batch * nch * N * Dg;
         P.carry = (float*)(wsb + ws.carry) + (size_t)g * a->batch * nch * N * Dg;
+        P.carry_seg = (float*)(wsb + ws.seg) + (size_t)g * a->batch * ((nch + kCarrySeg - 1) / kCarrySeg) * (N + 1) * Dg;
         P.last_state = a->last_state ? a->last_state + (int64_t)g * Dg * N : nullptr;
         P.last_state_sb = (int64_t)a->dim * N;
         if (use_fast_path() && scan_fast_shape(P)) {       // regular shapes (every SegMamba stage): scan_fwd_fast.hip
             launch_scan_fwd_fast(P, a->dtype, false, stream);
-            launch_scan_carry(P, false, P.agg_sd, P.agg_h, P.carry, stream);
+            launch_scan_carry(P, false, P.agg_sd, P.agg_h, P.carry, P.carry_seg, stream);
             launch_scan_fwd_fast(P, a->dtype, true, stream);
             rc = (int)hipGetLastError();
         } else if (a->dtype == SEGM_F32) rc = launch_fwd_ns<float>(P, stream);

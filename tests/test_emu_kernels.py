@@ -40,6 +40,16 @@ def test_scan_forward_backward_emulated(emu, dim, dstate, seqlen, chunk, channel
     H.check_scan(res, ref, torch.float32, f"emu D={dim} L={seqlen}")
 
 
+@pytest.mark.parametrize("seqlen,order,ns", [(16 * 70, L.TIME_FORWARD, 1), (16 * 130, L.TIME_REVERSED, 1), (16 * 72, L.TIME_INTERLEAVED, 8)])
+def test_scan_many_chunks_carry_segments_emulated(emu, seqlen, order, ns):
+    """more chunks than one carry segment holds (64): the two-launch carry composition (segment composites, then the walk
+    from the composed state), forward and - in the backward pass - reversed, with a partly filled last segment"""
+    c = H.scan_case(1, 16, 16, seqlen, seed=seqlen)
+    ref = H.scan_oracle(c, order, ns)
+    res = H.run_scan(emu, c, "cpu", True, order, ns, chunk=16)
+    H.check_scan(res, ref, torch.float32, f"emu many chunks L={seqlen}")
+
+
 def test_scan_bf16_and_no_gate_emulated(emu):
     c = H.scan_case(1, 32, 16, 64, dtype=torch.bfloat16)
     H.check_scan(H.run_scan(emu, c, "cpu", True, chunk=32), H.scan_oracle(c), torch.bfloat16, "emu bf16")
