@@ -16,6 +16,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import os
+
 import torch
 
 from . import lib as L
@@ -134,10 +136,12 @@ def scan_bwd(lib: L.SegmLib, u, delta, A, B, C, D, z, delta_bias, dout, out, ckp
     (e.g. halves of one dxz buffer, reference selective_scan_interface.py:244-245); dB / dC are fp32 and have
     the layout and rank of B / C."""
     a = L.ScanBwdArgs()
+    if chunk and os.environ.get("SEGM_BWD_CHUNK"):        # experiments only: the backward's own chunking (the checkpoints are per 16 steps, not per chunk)
+        chunk = int(os.environ["SEGM_BWD_CHUNK"])
     batch, seqlen, dim, dstate, groups, B4, C4 = _fill_scan_args(
         a.f, u, delta, A, B, C, D, z, delta_bias, delta_softplus, channel_last, time_order, nslices, chunk)
     if chunk == 0:
-        raise RuntimeError("scan_bwd needs the chunk length the forward used")
+        raise RuntimeError("scan_bwd needs a chunk length (the forward's, or segm_selective_scan_bwd_default_chunk)")
     if ckpt is None:
         raise RuntimeError("scan_bwd needs the forward checkpoints (run the forward with need_ckpt=True)")
     if z is not None and out is None:
