@@ -1,7 +1,9 @@
 """Projection GEMMs of the hot path (1x1x1 convolutions, patch convolutions, Mamba in/out/x/dt projections).
 
-These stay on the BLAS library (rocBLAS / hipBLASLt through torch - plain library GEMMs), but two things about how
-they are *called* matter on MI355X (profiles/r01_bench_step_kernels_v5.txt, tools/gpu_torch_prof.py):
+Tall 16-bit activations with at most 192 channels (the Mamba projections of stages 0 / 1) go through the library's
+row-streaming MFMA kernel (csrc/linear.hip: 1.0 - 2.0x the BLAS call on every such shape, profiles/r02_linear.log);
+everything else stays on the BLAS library (rocBLAS / hipBLASLt through torch - plain library GEMMs), where two things
+about how they are *called* matter on MI355X (profiles/r01_bench_step_kernels_v5.txt, tools/gpu_torch_prof.py):
 
   * weight gradients are  dW = dY^T X  with a reduction over K = B*D*H*W rows (up to 4.2 M) and only 3 .. 192 output
     rows / columns.  The library runs such a shape as ONE small tile looping over all of K (1.3 - 5 ms each, ~40 ms
@@ -21,9 +23,9 @@ import torch.nn.functional as F
 _SLAB = 4096          # rows of K per partial product
 _MIN_K = 32768        # below this one GEMM is fine
 _FORCE_SPLIT = False  # tests: exercise the split path on CPU tensors too
-# The library's row-streaming projection kernel (csrc/linear.hip) for tall activations.  Written after the GPU budget of
-# round 1 was spent - parity-tested on the emulator, never timed - so it is opt-in until it has been measured.
-_ROWS_HIP = os.environ.get("SEGM_LINEAR_HIP", "0") == "1"
+# The library's row-streaming projection kernel (csrc/linear.hip) for tall activations: 3.4 - 4.9 TB/s against 1.4 - 2.9 TB/s
+# for the BLAS calls at stage 0, 1.7 - 2.4 against 1.2 - 2.3 at stage 1 (profiles/r02_linear.log).  SEGM_LINEAR_HIP=0 -> BLAS.
+_ROWS_HIP = os.environ.get("SEGM_LINEAR_HIP", "1") == "1"
 _ROWS_MIN = 32768     # rows below which the BLAS call stays
 
 

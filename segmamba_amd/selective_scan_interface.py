@@ -19,6 +19,8 @@ seqlen)) and error behaviour.  What changes underneath:
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -118,6 +120,9 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
     return (y, torch.cat(lasts, dim=-1)) if return_last_state else y
 
 
+_RECOMPUTE = os.environ.get("SEGM_RECOMPUTE", "0") == "1"     # reference trade: recompute conv output / delta in backward
+
+
 # ---------------------------------------------------------------------------------------------------------
 # fused inner pipeline: conv1d+SiLU -> x_proj -> dt_proj -> selective scan (gated by silu(z))
 # ---------------------------------------------------------------------------------------------------------
@@ -126,8 +131,10 @@ class MambaInnerCore(torch.autograd.Function):
 
     xz is (batch, 2*dim, seqlen) when `channel_last` is False (the reference layout) and
     (batch, seqlen, 2*dim) when True; the result has the layout of one half of xz.  `time_order` /
-    `nslices` select the logical direction (lib.TIME_*).  Activations recomputed in backward: the conv output
-    and delta (reference checkpoint_lvl=1, :161,218-219,238-241).
+    `nslices` select the logical direction (lib.TIME_*).  The reference recomputes the conv output and delta in backward
+    (checkpoint_lvl=1, :161,218-219,238-241) to save memory on 16 - 80 GB devices; an MI355X has 288 GB, so by default they
+    are KEPT (2 x 100 MB per direction at stage 0 of a 2 x 128^3 step, 1.6 GB for the whole network) and the backward starts
+    without the conv1d / dt_proj launches.  SEGM_RECOMPUTE=1 restores the reference's trade.
     """
 
     @staticmethod
@@ -165,10 +172,12 @@ class MambaInnerCore(torch.autograd.Function):
         r = ops_raw.scan_fwd(lib, conv_out, delta, A32, Bv, Cv, D32, z, db32, delta_softplus,
                              channel_last=channel_last, time_order=time_order, nslices=nslices,
                              need_out=train, need_ckpt=train)
+        keep = train and not _RECOMPUTE
         ctx.cfg = (bool(delta_softplus), bool(channel_last), int(time_order), int(nslices), r["chunk"], R, N,
-                   B_proj_bias is not None, C_proj_bias is not None)
+                   B_proj_bias is not None, C_proj_bias is not None, keep)
         ctx.save_for_backward(xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, A, D,
-                              delta_bias, B_proj_bias, C_proj_bias, r["out"], r["ckpt"])
+                              delta_bias, B_proj_bias, C_proj_bias, r["out"], r["ckpt"],
+                              conv_out if keep else None, delta if keep else None)
         return r["out_z"]
 
     @staticmethod
@@ -176,8 +185,8 @@ class MambaInnerCore(torch.autograd.Function):
     def backward(ctx, dout):
         lib = L.get_lib()
         (xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, A, D, delta_bias,
-         B_proj_bias, C_proj_bias, out, ckpt) = ctx.saved_tensors
-        delta_softplus, channel_last, time_order, nslices, chunk, R, N, has_Bb, has_Cb = ctx.cfg
+         B_proj_bias, C_proj_bias, out, ckpt, conv_out, delta) = ctx.saved_tensors
+        delta_softplus, channel_last, time_order, nslices, chunk, R, N, has_Bb, has_Cb, keep = ctx.cfg
         cdim = 2 if channel_last else 1
         dim = xz.shape[cdim] // 2
         batch = xz.shape[0]
@@ -190,15 +199,17 @@ class MambaInnerCore(torch.autograd.Function):
         x, z = xz.split(dim, dim=cdim)
         if (dout.stride(1) if channel_last else dout.stride(2)) != 1 and dout.stride(cdim) != 1:
             dout = dout.contiguous()
-        # recompute conv output and delta (checkpoint_lvl 1)
-        conv_out = ops_raw.conv1d_fwd(lib, x, w32, cb32, True, channel_last=channel_last, time_order=time_order,
-                                      nslices=nslices)
         rows_route = x_dbl.shape[1] != R + 2 * N           # the forward kept x_dbl padded: library projection route
-        if rows_route:
-            _, delta, Bv, Cv = _project_rows(conv_out, x_proj_weight, delta_proj_weight, R, N, x_dbl=x_dbl)
-        else:
-            _, delta, Bv, Cv = _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last,
-                                        B_proj_bias, C_proj_bias, x_dbl=x_dbl)
+        if keep:                                           # conv output and delta kept by the forward: B / C are views of x_dbl
+            Bv, Cv = _bc_views(x_dbl, batch, seqlen, R, N, channel_last, B_proj_bias, C_proj_bias)
+        else:                                              # recompute them (checkpoint_lvl 1)
+            conv_out = ops_raw.conv1d_fwd(lib, x, w32, cb32, True, channel_last=channel_last, time_order=time_order,
+                                          nslices=nslices)
+            if rows_route:
+                _, delta, Bv, Cv = _project_rows(conv_out, x_proj_weight, delta_proj_weight, R, N, x_dbl=x_dbl)
+            else:
+                _, delta, Bv, Cv = _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last,
+                                            B_proj_bias, C_proj_bias, x_dbl=x_dbl)
         dxz = torch.empty_like(xz, memory_format=torch.contiguous_format)
         dx, dz = dxz.split(dim, dim=cdim)                 # dx / dz written in place (reference :244-245)
         g = ops_raw.scan_bwd(lib, conv_out, delta, A32, Bv, Cv, D32, z, db32, dout, out, ckpt, delta_softplus,
@@ -250,6 +261,19 @@ class MambaInnerCore(torch.autograd.Function):
                 g["dD"].to(D.dtype) if D is not None else None,
                 g["ddelta_bias"].to(delta_bias.dtype) if delta_bias is not None else None,
                 dB_proj_bias, dC_proj_bias, None, None, None, None, None)
+
+
+def _bc_views(x_dbl, batch, seqlen, R, N, channel_last, B_proj_bias, C_proj_bias):
+    """B_t / C_t as the scan expects them: strided views of x_dbl (b*l, R + 2N [+ padding])"""
+    v3 = x_dbl.view(batch, seqlen, x_dbl.shape[1])
+    Bv, Cv = v3[:, :, R:R + N], v3[:, :, R + N:R + 2 * N]
+    if not channel_last:
+        Bv, Cv = Bv.permute(0, 2, 1), Cv.permute(0, 2, 1)
+    if B_proj_bias is not None:
+        Bv = Bv + (B_proj_bias.to(Bv.dtype) if channel_last else B_proj_bias.to(Bv.dtype)[:, None])
+    if C_proj_bias is not None:
+        Cv = Cv + (C_proj_bias.to(Cv.dtype) if channel_last else C_proj_bias.to(Cv.dtype)[:, None])
+    return Bv, Cv
 
 
 def _rows_route(conv_out, channel_last) -> bool:

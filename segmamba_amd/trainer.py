@@ -7,7 +7,9 @@ Mirrors the body of the reference loop - `Trainer.train_epoch` (light_training/t
 
 with the reference hyper-parameters (3_train.py:51-52: SGD lr 1e-2, weight decay 3e-5, momentum 0.99, nesterov;
 lr_scheduler.py:36 poly 0.9).  Differences, all deliberate:
-  * autocast dtype is bf16 (the north star's dtype; the reference's default fp16 + GradScaler is not needed for bf16);
+  * autocast dtype is bf16 by default (the north star's dtype).  `amp="fp16"` (or SEGM_AMP=fp16) runs the loop the reference
+    actually runs - fp16 autocast with a GradScaler: scale(loss).backward(), unscale_, clip, scaler.step, scaler.update
+    (light_training/trainer.py:65-67, 461-466) - through the same kernels (all instantiated for fp16);
   * data come from a device-side synthetic generator instead of the 18-process batchgenerators pipeline
     (trainer.py:154-162), which is out of scope (SURVEY.md §2.1);
   * multi-GPU is the same plain DDP (trainer.py:353-357) over RCCL; one process per GPU,
@@ -27,7 +29,12 @@ from .segmamba import SegMamba
 class SyntheticBraTS:
     """Random 4-modality volumes + 4-class label maps generated on the device (per-rank seed as trainer.py:331)."""
 
-    def __init__(self, batch: int, size: int, device, seed: int = 42, pool: int = 2):
+    def __init__(self, batch: int, size: int, device, seed: int = 42, pool: int = 2, augment: bool = False):
+        # augment: run the reference's training transforms on the device (segmamba_amd/augment.py) on every batch handed out
+        self.augmenter = None
+        if augment:
+            from .augment import DeviceAugmenter
+            self.augmenter = DeviceAugmenter(device, seed=seed)
         g = torch.Generator(device=device).manual_seed(seed)
         self.items = []
         for _ in range(pool):
@@ -41,6 +48,8 @@ class SyntheticBraTS:
     def next(self):
         item = self.items[self.i % len(self.items)]
         self.i += 1
+        if self.augmenter is not None:
+            item = self.augmenter(*item)
         return item
 
 
@@ -59,10 +68,14 @@ class TrainingState:
     autocast_dtype: torch.dtype = torch.bfloat16
     clip: float = 12.0
     step: int = 0
+    scaler: object = None          # torch.amp.GradScaler when autocast_dtype is fp16 (reference trainer.py:65-67)
 
 
 def build_training_state(device, distributed: bool = False, local_rank: int = 0, max_steps: int = 250 * 1000,
-                         model: nn.Module | None = None) -> TrainingState:
+                         model: nn.Module | None = None, amp: str | None = None) -> TrainingState:
+    amp = (amp or os.environ.get("SEGM_AMP", "bf16")).lower()
+    if amp not in ("bf16", "fp16"):
+        raise ValueError(f"amp must be 'bf16' or 'fp16', got {amp!r}")
     if model is None:
         model = SegMamba(in_chans=4, out_chans=4, depths=[2, 2, 2, 2], feat_size=[48, 96, 192, 384])
     model = model.to(device)
@@ -89,19 +102,33 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
         opt = torch.optim.SGD(model.parameters(), lr=1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
         loss_fn = nn.CrossEntropyLoss()
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: (1 - min(s, max_steps - 1) / max_steps) ** 0.9)
-    return TrainingState(model=model, optimizer=opt, scheduler=sched, loss_fn=loss_fn)
+    st = TrainingState(model=model, optimizer=opt, scheduler=sched, loss_fn=loss_fn)
+    if amp == "fp16":
+        st.autocast_dtype = torch.float16
+        st.scaler = torch.amp.GradScaler(device.type)     # the reference's GradScaler() defaults: 2^16, x2 / 2000 steps, x0.5 on inf
+    return st
 
 
 def train_step(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
     for p in st.model.parameters():
         p.grad = None                                              # trainer.py:445
-    with torch.autocast(image.device.type, dtype=st.autocast_dtype, enabled=image.device.type == "cuda"):
+    with torch.autocast(image.device.type, dtype=st.autocast_dtype,
+                        enabled=image.device.type == "cuda" or st.scaler is not None):
         pred = st.model(image)
         loss = st.loss_fn(pred, label)                             # 3_train.py:62
-    loss.backward()
-    if getattr(st.optimizer, "max_norm", None) is None:
-        torch.nn.utils.clip_grad_norm_(st.model.parameters(), st.clip)  # trainer.py:464
-    st.optimizer.step()                                            # FusedClipSGD clips inside step()
+    fused_clip = getattr(st.optimizer, "max_norm", None) is not None    # FusedClipSGD clips inside step()
+    if st.scaler is None:
+        loss.backward()
+        if not fused_clip:
+            torch.nn.utils.clip_grad_norm_(st.model.parameters(), st.clip)  # trainer.py:464
+        st.optimizer.step()
+    else:                                                          # trainer.py:461-466
+        st.scaler.scale(loss).backward()
+        st.scaler.unscale_(st.optimizer)                           # true-scale gradients before the clip
+        if not fused_clip:
+            torch.nn.utils.clip_grad_norm_(st.model.parameters(), st.clip)
+        st.scaler.step(st.optimizer)                               # skipped when a gradient is inf / nan
+        st.scaler.update()
     st.scheduler.step()
     st.step += 1
     return loss.detach()

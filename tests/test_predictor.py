@@ -91,6 +91,6 @@ def test_sliding_window_and_mirror_tta_match_reference_on_the_gpu(name):
         return float(np.abs(got.cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max()))
     e_win = err(win, name + "_window")
     assert e_win <= 2e-5, f"window prediction: relative error {e_win:.3e}"
-    tta = P.Predictor(window_infer=inferer, mirror_axes=axes).maybe_mirror_and_predict(x, net)
+    tta = P.Predictor(window_infer=inferer, mirror_axes=axes).maybe_mirror_and_predict(x, net, device=torch.device("cuda"))
     e_tta = err(tta, name + "_tta")
     assert tta.is_cuda and e_tta <= 2e-5, f"mirror TTA: relative error {e_tta:.3e}"

@@ -1,0 +1,93 @@
+"""Host-side pieces of the training loop that need no GPU: the reference's fp16 + GradScaler step and the device-side
+augmentation feeder."""
+import torch
+import torch.nn as nn
+
+from segmamba_amd.augment import DeviceAugmenter
+from segmamba_amd.trainer import SyntheticBraTS, build_training_state, train_step
+
+
+def _tiny():
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Conv3d(4, 8, 3, padding=1), nn.InstanceNorm3d(8), nn.LeakyReLU(0.01), nn.Conv3d(8, 4, 1))
+
+
+def test_fp16_gradscaler_step_follows_the_reference_loop():
+    """amp='fp16': scale(loss).backward -> unscale_ -> clip -> scaler.step -> scaler.update (light_training/trainer.py:461-466).
+    On CPU tensors (torch's CPU autocast / GradScaler): the parameters move, the scale is the GradScaler default, and a step whose
+    gradients overflow is skipped with the scale halved."""
+    st = build_training_state(torch.device("cpu"), model=_tiny(), amp="fp16")
+    assert st.autocast_dtype == torch.float16 and st.scaler is not None and st.scaler.get_scale() == 65536.0
+    g = torch.Generator().manual_seed(1)
+    img, lab = torch.rand(1, 4, 8, 8, 8, generator=g), torch.randint(0, 4, (1, 8, 8, 8), generator=g)
+    before = [p.detach().clone() for p in st.model.parameters()]
+    loss = train_step(st, img, lab)
+    assert torch.isfinite(loss)
+    assert any((a - b.detach()).abs().max() > 0 for a, b in zip(before, st.model.parameters()))
+    assert st.step == 1 and st.scaler.get_scale() == 65536.0
+    # an overflowing step: inf in the input -> non-finite gradients -> optimizer step skipped, scale halved
+    before = [p.detach().clone() for p in st.model.parameters()]
+    bad = img.clone()
+    bad[0, 0, 0, 0, 0] = float("inf")
+    train_step(st, bad, lab)
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, st.model.parameters()))
+    assert st.scaler.get_scale() == 32768.0
+
+
+def test_bf16_is_the_default_and_has_no_scaler():
+    st = build_training_state(torch.device("cpu"), model=_tiny())
+    assert st.autocast_dtype == torch.bfloat16 and st.scaler is None
+
+
+class _OnlyMirror(DeviceAugmenter):
+    def _coin(self, p, *shape):                            # every p = 0.5 decision is "yes" (the mirrors), every other one "no"
+        return torch.full(shape, p == 0.5, dtype=torch.bool)
+
+
+def test_augmenter_mirrors_image_and_label_together():
+    g = torch.Generator().manual_seed(0)
+    lab = torch.randint(0, 4, (2, 6, 5, 4), generator=g)
+    img = torch.stack([lab.float(), lab.float() * 2, torch.rand(2, 6, 5, 4, generator=g), torch.zeros(2, 6, 5, 4)], 1)
+    x, y = _OnlyMirror("cpu")(img, lab)
+    assert torch.equal(y, lab.flip(1, 2, 3)) and torch.equal(x, img.flip(2, 3, 4))
+    assert torch.equal(x[:, 0], y.float())                 # still aligned
+
+
+def test_augmenter_is_reproducible_and_keeps_shapes_and_classes():
+    g = torch.Generator().manual_seed(3)
+    img, lab = torch.rand(2, 4, 12, 12, 12, generator=g), torch.randint(0, 4, (2, 12, 12, 12), generator=g)
+    outs = []
+    for _ in range(2):
+        aug = DeviceAugmenter("cpu", seed=7)
+        outs.append([aug(img, lab) for _ in range(12)])     # 12 draws: every transform fires at least once at these odds
+    for (x0, y0), (x1, y1) in zip(*outs):
+        assert torch.equal(x0, x1) and torch.equal(y0, y1)
+        assert x0.shape == img.shape and y0.shape == lab.shape and y0.dtype == lab.dtype and x0.dtype == img.dtype
+        assert torch.isfinite(x0).all() and int(y0.min()) >= 0 and int(y0.max()) <= 3
+    assert any(not torch.equal(x, img) for x, _ in outs[0])
+
+
+def test_intensity_transforms_follow_their_published_definitions():
+    aug = DeviceAugmenter("cpu", seed=0, spatial=False)
+    x = torch.rand(3, 2, 8, 8, 8, generator=torch.Generator().manual_seed(5)) * 3 - 1
+    # gamma with retained statistics: per-channel mean and std unchanged wherever it was applied
+    class G(DeviceAugmenter):
+        def _coin(self, p, *shape):
+            return torch.ones(shape, dtype=torch.bool)
+    y = G("cpu", seed=1, spatial=False)._gamma(x, 0.3, invert=False)
+    assert torch.allclose(y.mean((2, 3, 4)), x.mean((2, 3, 4)), atol=1e-5)
+    assert torch.allclose(y.std((2, 3, 4)), x.std((2, 3, 4)), rtol=1e-4)
+    yi = G("cpu", seed=1, spatial=False)._gamma(x, 0.1, invert=True)
+    assert torch.allclose(yi.mean((2, 3, 4)), x.mean((2, 3, 4)), atol=1e-5)
+    # blur of a constant volume is the constant; low-res simulation keeps the value range
+    c = torch.full((1, 2, 8, 8, 8), 2.5)
+    assert torch.allclose(G("cpu", seed=2, spatial=False)._blur(c), c, atol=1e-6)
+    lo = G("cpu", seed=3, spatial=False)._low_res(x)
+    assert float(lo.min()) >= float(x.min()) - 1e-6 and float(lo.max()) <= float(x.max()) + 1e-6
+    assert aug is not None
+
+
+def test_synthetic_feeder_with_augmentation():
+    data = SyntheticBraTS(1, 8, torch.device("cpu"), seed=42, augment=True)
+    a, b = data.next(), data.next()
+    assert a[0].shape == (1, 4, 8, 8, 8) and a[1].shape == (1, 8, 8, 8) and b[0].shape == a[0].shape
