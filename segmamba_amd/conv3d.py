@@ -122,10 +122,11 @@ def _hip_chain_ok(w) -> bool:
 
 
 def _hip_untimed_ok() -> bool:
-    """Two further variants of the chained kernel - unpadded LDS rows, 32-wide x blocks with two workgroups per CU - were
-    written after the GPU budget of round 1 was spent: parity-tested on the emulator, never run on an MI355X.  They join the
-    candidates only on request (SEGM_CONV_FWD_UNTIMED=1) until they have been."""
-    return os.environ.get("SEGM_CONV_FWD_UNTIMED", "0") == "1"
+    """Two further variants of the chained kernel - unpadded LDS rows, 32-wide x blocks with two workgroups per CU.  Measured in
+    round 2 (profiles/r02_bench_variants.log): the 32-wide variant wins every 32^3 / 16^3 layer (96 -> 96 @32^3 0.15 -> 0.11 ms,
+    192 -> 192 @32^3 0.43 -> 0.27 ms, 384 -> 384 @16^3 0.41 -> 0.31 ms, where MIOpen was the previous winner) and the step drops from
+    79.2 to 77.9 ms, so both are candidates by default; SEGM_CONV_FWD_UNTIMED=0 removes them."""
+    return os.environ.get("SEGM_CONV_FWD_UNTIMED", "1") == "1"
 
 
 def _fwd_blocked(x, w, pad):

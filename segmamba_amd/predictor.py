@@ -149,7 +149,8 @@ class Predictor:
             ordered = sorted(axes)
             for k in range(1, len(ordered) + 1):
                 combos += list(itertools.combinations(ordered, k))
-        with torch.no_grad(), torch.autocast("cuda", dtype=self.autocast_dtype, enabled=device.type == "cuda"):
+        with torch.no_grad(), torch.autocast("cuda", dtype=self.autocast_dtype,
+                                             enabled=device.type == "cuda" and self.autocast_dtype != torch.float32):
             total = None
             for c in combos:
                 dims = tuple(a + 2 for a in c)

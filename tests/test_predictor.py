@@ -93,4 +93,8 @@ def test_sliding_window_and_mirror_tta_match_reference_on_the_gpu(name):
     assert e_win <= 2e-5, f"window prediction: relative error {e_win:.3e}"
     tta = P.Predictor(window_infer=inferer, mirror_axes=axes).maybe_mirror_and_predict(x, net, device=torch.device("cuda"))
     e_tta = err(tta, name + "_tta")
-    assert tta.is_cuda and e_tta <= 2e-5, f"mirror TTA: relative error {e_tta:.3e}"
+    # on the GPU the Predictor runs the network under 16-bit autocast, as the reference does (prediction.py:124): bf16 rounding
+    assert tta.is_cuda and e_tta <= 2e-2, f"mirror TTA: relative error {e_tta:.3e}"
+    fp32 = P.Predictor(window_infer=inferer, mirror_axes=axes, autocast_dtype=torch.float32)
+    e32 = err(fp32.maybe_mirror_and_predict(x, net, device=torch.device("cuda")), name + "_tta")
+    assert e32 <= 2e-5, f"mirror TTA without autocast: relative error {e32:.3e}"
