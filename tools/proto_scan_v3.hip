@@ -31,7 +31,7 @@ struct Args {
     int T, dim;
 };
 
-template <int PD, bool AGG, int MINB, int ABL = 0> __global__ void __launch_bounds__(256, MINB) scan_v3(Args P) {
+template <int PD, bool AGG, int MINB, int ABL = 0, bool FUSE = false> __global__ void __launch_bounds__(256, MINB) scan_v3(Args P) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int item = blockIdx.x * 4 + wave;
@@ -51,6 +51,9 @@ template <int PD, bool AGG, int MINB, int ABL = 0> __global__ void __launch_boun
     uint16_t* yp = P.out + row0 * P.st + d;
     const CAS f32x16* Bp = (const CAS f32x16*)(uintptr_t)(P.BC + row0 * 32);
     const int st = (int)P.st;
+    float hx[3] = {0.f, 0.f, 0.f};
+    const float cw4[4] = {P.A[d * 16 + 0] * 0.1f, P.A[d * 16 + 1] * 0.1f, P.A[d * 16 + 2] * 0.1f, P.A[d * 16 + 3] * 0.1f};
+    const float cbias = P.A[d * 16 + 4] * 0.01f;
     uint32_t ub[PD], db[PD], zb[PD];
 #pragma unroll
     for (int j = 0; j < PD; ++j) { ub[j] = up[j * st]; db[j] = dp[j * st]; if (!AGG) zb[j] = zp[j * st]; }
@@ -80,7 +83,13 @@ template <int PD, bool AGG, int MINB, int ABL = 0> __global__ void __launch_boun
             const f32x16 bw = bs[j & 1];
             f32x16 cw = bs[j & 1];
             if (!AGG) cw = cs[j & 1];
-            const float uu = bf(ub[j]);
+            float uu = bf(ub[j]);
+            if (FUSE) {                                    // the "conv1d fused into the scan launch" variant: 4 taps + bias + SiLU per step
+                const float xc = uu;
+                float o = cw4[3] * xc + cw4[2] * hx[0] + cw4[1] * hx[1] + cw4[0] * hx[2] + cbias;
+                hx[2] = hx[1]; hx[1] = hx[0]; hx[0] = xc;
+                uu = o * __builtin_amdgcn_rcpf(1.f + fexp2(-o * 1.4426950408889634f));
+            }
             float dl = bf(db[j]);
             float zz = 0.f;
             if (!AGG) zz = bf(zb[j]);
@@ -136,13 +145,13 @@ template <int PD, bool AGG, int MINB, int ABL = 0> __global__ void __launch_boun
     }
 }
 
-template <int PD, bool AGG, int MINB, int ABL = 0> static float run(const Args& P, int64_t rows, int reps) {
+template <int PD, bool AGG, int MINB, int ABL = 0, bool FUSE = false> static float run(const Args& P, int64_t rows, int reps) {
     const int nblk = (int)(rows / P.T / 4);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((scan_v3<PD, AGG, MINB, ABL>), dim3(nblk), dim3(256), 0, 0, P);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((scan_v3<PD, AGG, MINB, ABL, FUSE>), dim3(nblk), dim3(256), 0, 0, P);
     (void)hipEventRecord(e0, 0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((scan_v3<PD, AGG, MINB, ABL>), dim3(nblk), dim3(256), 0, 0, P);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((scan_v3<PD, AGG, MINB, ABL, FUSE>), dim3(nblk), dim3(256), 0, 0, P);
     (void)hipEventRecord(e1, 0);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
@@ -195,6 +204,8 @@ int main(int argc, char** argv) {
             case 11: r = run<4, false, 2, 1>(P, rows, 20); nm = "apply PD4 no vmem"; break;
             case 12: r = run<4, false, 2, 2>(P, rows, 20); nm = "apply PD4 no smem"; break;
             case 13: r = run<4, false, 2, 3>(P, rows, 20); nm = "apply PD4 valu only"; break;
+            case 20: r = run<4, true, 2, 0, true>(P, rows, 20); nm = "aggregate PD4 + conv1d/SiLU"; break;
+            case 21: r = run<4, false, 2, 0, true>(P, rows, 20); nm = "apply PD4 + conv1d/SiLU"; break;
             default: break;
         }
         CHK(hipDeviceSynchronize());
