@@ -18,7 +18,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libsegmamba_hip.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+LIB_PATH = os.environ.get("SEGM_LIB_OUT") or os.path.join(_HERE, LIB_NAME)     # SEGM_LIB_OUT: a variant built for an A/B run
 
 SEGM_F32, SEGM_F16, SEGM_BF16 = 0, 1, 2
 TIME_FORWARD, TIME_REVERSED, TIME_INTERLEAVED = 0, 1, 2
