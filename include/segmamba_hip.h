@@ -462,6 +462,30 @@ typedef struct segm_linear_args {
 
 int segm_linear_rows(const segm_linear_args* args);
 
+/* ------------------------------------------------------------------------------------------------
+ * Channel-first 1x1x1 convolution  y[b, co, s] = sum_ci w[co, ci] x[b, ci, s] + bias[co]  on (batch, channels, voxels)
+ * activations whose voxels are contiguous (NCDHW, or channel slices of it).  Replaces the `Conv3d(kernel_size=1)` calls of
+ * the conv stem that the reference hands to cuDNN: the residual branch `conv3` of MONAI's UnetResBlock
+ * (monai/networks/blocks/dynunet_block.py:72-96), UnetOutBlock (:247-263), GSC.proj3 / proj4 and MlpChannel.fc1 / fc2
+ * (model_segmamba/segmamba.py:78-131) - and, with the transposed weight, their data gradients.
+ * x, w, y of one 16-bit dtype; w (cout, w_stride) row-major with w_stride >= cin a multiple of 8 and zero padding columns;
+ * bias (cout) fp32 or NULL; cin, cout <= 96; spatial (voxels per channel) a multiple of 64; element strides of batch and
+ * channel: multiples of 8 for x (16-byte aligned rows), of 4 for y.  accumulate != 0: y += ... (the second half of a
+ * concatenated input, `conv3(cat(up, skip))` = conv3a(up) + conv3b(skip)).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_pointwise_args {
+    int32_t batch, cin, cout;
+    int32_t dtype, accumulate;
+    int64_t spatial;
+    const void* x;      int64_t x_stride_b, x_stride_c;
+    const void* w;      int32_t w_stride;
+    const float* bias;
+    void* y;            int64_t y_stride_b, y_stride_c;
+    void* stream;
+} segm_pointwise_args;
+
+int segm_pointwise_cf(const segm_pointwise_args* args);
+
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);
 const char* segm_status_string(int status);

@@ -184,6 +184,16 @@ class LinearArgs(C.Structure):
     ]
 
 
+class PointwiseArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("dtype", C.c_int32), ("accumulate", C.c_int32),
+        ("spatial", C.c_int64),
+        ("x", C.c_void_p), ("x_stride_b", C.c_int64), ("x_stride_c", C.c_int64),
+        ("w", C.c_void_p), ("w_stride", C.c_int32), ("bias", C.c_void_p),
+        ("y", C.c_void_p), ("y_stride_b", C.c_int64), ("y_stride_c", C.c_int64), ("stream", C.c_void_p),
+    ]
+
+
 class TransposeArgs(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("dtype", C.c_int32),
@@ -199,7 +209,7 @@ EXPORTS = (
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add",
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
-    "segm_causal_conv1d_update", "segm_selective_state_update", "segm_linear_rows",
+    "segm_causal_conv1d_update", "segm_selective_state_update", "segm_linear_rows", "segm_pointwise_cf",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -244,6 +254,7 @@ class SegmLib:
         sig("segm_causal_conv1d_update", [C.POINTER(Conv1dUpdateArgs)], C.c_int)
         sig("segm_selective_state_update", [C.POINTER(StateUpdateArgs)], C.c_int)
         sig("segm_linear_rows", [C.POINTER(LinearArgs)], C.c_int)
+        sig("segm_pointwise_cf", [C.POINTER(PointwiseArgs)], C.c_int)
         sig("segm_abi_version", [], C.c_int)
         sig("segm_status_string", [C.c_int], C.c_char_p)
 

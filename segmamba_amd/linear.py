@@ -27,6 +27,10 @@ _FORCE_SPLIT = False  # tests: exercise the split path on CPU tensors too
 # for the BLAS calls at stage 0, 1.7 - 2.4 against 1.2 - 2.3 at stage 1 (profiles/r02_linear.log).  SEGM_LINEAR_HIP=0 -> BLAS.
 _ROWS_HIP = os.environ.get("SEGM_LINEAR_HIP", "1") == "1"
 _ROWS_MIN = 32768     # rows below which the BLAS call stays
+# Channel-first 1x1x1 convolutions (csrc/pointwise.hip): the BLAS route runs y[b] = W x[b] on strided views at ~1.6 TB/s and
+# adds the bias in a further pass; SEGM_POINTWISE_HIP=0 restores it.
+_PW_HIP = os.environ.get("SEGM_POINTWISE_HIP", "1") == "1"
+_PW_MIN = 32768       # voxels per channel below which the BLAS call stays
 
 
 def _on_device(t: torch.Tensor) -> bool:
@@ -105,6 +109,16 @@ class _LinearCL(torch.autograd.Function):
         return dx, dw, db
 
 
+def _pw_hip(w: torch.Tensor, x: torch.Tensor, b):
+    """w (M, K) times every x[b] (K, S) (+ bias) through segm_pointwise_cf, or None when the shape / layout is not the kernel's"""
+    if not (_PW_HIP and _on_device(x) and x.shape[2] >= _PW_MIN and x.stride(2) == 1 and w.shape[1] <= 96):
+        return None
+    from . import lib as L, ops_raw
+    if not ops_raw.pointwise_cf_supported(x, w.shape[0]) or w.dtype != x.dtype:
+        return None
+    return ops_raw.pointwise_cf(L.get_lib(), x, w, b)
+
+
 def _bmm_w(w: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """w (M, K) times every x[b] (K, S) -> (B, M, S) contiguous.  (torch.matmul would fold the batch into the rows of
     a transposed product, which costs a transposing copy of x and returns a channel-last result.)"""
@@ -118,9 +132,11 @@ class _Pointwise(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        y = _bmm_w(w, x)
-        if b is not None:
-            y += b.view(1, -1, 1)
+        y = _pw_hip(w, x, b)                                # bias in the kernel's accumulator initialisation
+        if y is None:
+            y = _bmm_w(w, x)
+            if b is not None:
+                y += b.view(1, -1, 1)
         return y
 
     @staticmethod
@@ -130,7 +146,9 @@ class _Pointwise(torch.autograd.Function):
         if dy.stride(2) != 1 and dy.stride(1) != 1:
             dy = dy.contiguous()
         if ctx.needs_input_grad[0]:
-            dx = _bmm_w(w.t(), dy)
+            dx = _pw_hip(w.t(), dy, None)
+            if dx is None:
+                dx = _bmm_w(w.t(), dy)
         if ctx.needs_input_grad[1]:
             if x.stride(2) == 1 and dy.stride(2) == 1:
                 dw = nt_matmul_rows(dy, x).to(w.dtype)

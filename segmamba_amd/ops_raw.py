@@ -617,6 +617,43 @@ def linear_rows(lib: L.SegmLib, x2: torch.Tensor, w: torch.Tensor, bias: Optiona
     return y
 
 
+def pointwise_cf_supported(x3: torch.Tensor, cout: int) -> bool:
+    """x3 (B, Cin <= 96, S) 16-bit with contiguous voxels, S % 64 == 0, 16-byte aligned channel rows; Cout <= 96"""
+    return bool(x3.dim() == 3 and x3.dtype in (torch.bfloat16, torch.float16) and x3.shape[1] <= 96 and cout <= 96
+                and x3.shape[2] % 64 == 0 and x3.stride(2) == 1 and x3.stride(0) % 8 == 0 and x3.stride(1) % 8 == 0
+                and x3.data_ptr() % 16 == 0)
+
+
+def pointwise_cf(lib: L.SegmLib, x3: torch.Tensor, w2: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """y (B, Cout, S) = w2 (Cout, Cin) @ x3[b] (Cin, S) + bias, channel-first in and out (a 1x1x1 convolution on NCDHW
+    activations flattened over their voxels, or on channel slices of them).  `out` + `accumulate`: y += ... ."""
+    B, Cin, S = x3.shape
+    Cout = w2.shape[0]
+    if not pointwise_cf_supported(x3, Cout) or w2.shape[1] != Cin or w2.dtype != x3.dtype:
+        raise RuntimeError("pointwise_cf: x (B, Cin <= 96, S % 64 == 0) 16-bit with contiguous 16-byte aligned voxel rows, "
+                           "w (Cout <= 96, Cin) of the same dtype")
+    if Cin % 8:                                            # pad the weight rows to a multiple of 8 (zero columns)
+        w2 = torch.nn.functional.pad(w2, (0, 8 - Cin % 8))
+    w2 = w2.contiguous()
+    y = torch.empty(B, Cout, S, dtype=x3.dtype, device=x3.device) if out is None else out
+    if tuple(y.shape) != (B, Cout, S) or y.dtype != x3.dtype or y.stride(2) != 1 or y.stride(0) % 4 or y.stride(1) % 4 \
+            or y.data_ptr() % 8:
+        raise RuntimeError("pointwise_cf: `out` must be (B, Cout, S) of x's dtype with contiguous 8-byte aligned voxel rows")
+    if accumulate and out is None:
+        raise RuntimeError("pointwise_cf: accumulate needs `out`")
+    if bias is not None:
+        bias = bias.float().contiguous()
+    a = L.PointwiseArgs()
+    a.batch, a.cin, a.cout, a.dtype, a.accumulate, a.spatial = B, Cin, Cout, L.dtype_code(x3), int(bool(accumulate)), S
+    a.x, a.x_stride_b, a.x_stride_c = x3.data_ptr(), x3.stride(0), x3.stride(1)
+    a.w, a.w_stride, a.bias = w2.data_ptr(), w2.shape[1], L.fptr(bias)
+    a.y, a.y_stride_b, a.y_stride_c = y.data_ptr(), y.stride(0), y.stride(1)
+    a.stream = L.stream_handle(x3)
+    lib.check(lib.dll.segm_pointwise_cf(a), "pointwise_cf")
+    return y
+
+
 # ---------------------------------------------------------------------------------------------------------
 # device guard
 # ---------------------------------------------------------------------------------------------------------
@@ -649,5 +686,5 @@ def _device_guard(fn):
 
 for _name in ("scan_fwd", "scan_bwd", "conv1d_fwd", "conv1d_bwd", "conv3d_k3_wgrad", "conv3d_k3_fwd", "instnorm_fwd",
               "instnorm_bwd", "transpose_add", "layernorm_tokens_fwd", "layernorm_tokens_bwd", "sgd_clip_step", "cross_entropy",
-              "conv1d_update", "state_update", "linear_rows"):
+              "conv1d_update", "state_update", "linear_rows", "pointwise_cf"):
     globals()[_name] = _device_guard(globals()[_name])

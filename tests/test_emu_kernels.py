@@ -810,3 +810,51 @@ def test_randomised_norm_layout_wgrad_sweep_emulated(emu):
         dw = ops_raw.conv3d_k3_wgrad(emu, xw, dyw, torch.float32)
         ref_dw = _wgrad_reference(xw, dyw)
         assert dw.shape == ref_dw.shape and (dw - ref_dw).abs().max() <= 1e-5 * ref_dw.abs().max() + 1e-3, ("wgrad", case, cin, cout, D, H_, W)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,S,dtype,bias,view", [(2, 48, 48, 128, torch.bfloat16, True, False), (1, 4, 48, 64, torch.bfloat16, False, False),
+                                                        (2, 48, 4, 192, torch.float16, True, False), (1, 96, 48, 64, torch.bfloat16, True, True),
+                                                        (1, 40, 96, 128, torch.bfloat16, False, False)])
+def test_pointwise_cf_emulated(emu, B, Cin, Cout, S, dtype, bias, view):
+    """segm_pointwise_cf (channel-first 1x1x1 convolution: LDS transpose of the voxel strips, stationary weights, bias in the
+    accumulator) against fp32 matmul on the same 16-bit operands; narrow / ragged channel counts, a channel-slice view of a wider
+    tensor as input, accumulation into an existing result"""
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout)
+    full = torch.randn(B, Cin + (16 if view else 0), S, generator=g).to(dtype)
+    x = full[:, 8:8 + Cin] if view else full
+    w = (0.2 * torch.randn(Cout, Cin, generator=g)).to(dtype)
+    b = torch.randn(Cout, generator=g) if bias else None
+    assert ops_raw.pointwise_cf_supported(x, Cout)
+    y = ops_raw.pointwise_cf(emu, x, w, b)
+    ref = torch.einsum("oc,bcs->bos", w.float(), x.float()) + (b.view(1, -1, 1) if bias else 0)
+    assert y.shape == (B, Cout, S) and y.dtype == dtype
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert (y.float() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    y2 = ops_raw.pointwise_cf(emu, x, w, None, out=y.clone(), accumulate=True)
+    ref2 = y.float() + torch.einsum("oc,bcs->bos", w.float(), x.float())
+    assert (y2.float() - ref2).abs().max() <= tol * max(1.0, float(ref2.abs().max()))
+    with pytest.raises(RuntimeError):
+        ops_raw.pointwise_cf(emu, x[:, :, :S - 8], w)                      # voxels not a multiple of 64
+
+
+def test_pointwise_autograd_route_on_emulated_kernels(emu, monkeypatch):
+    """linear.pointwise (the 1x1x1 convolutions of the conv stem) with the library kernel switched in: forward with the bias
+    fused and the data gradient through segm_pointwise_cf == the BLAS route, output and all three gradients"""
+    from segmamba_amd import linear as LN
+    monkeypatch.setattr(L, "_lib", emu)
+    monkeypatch.setattr(LN, "_on_device", lambda t: True)
+    monkeypatch.setattr(LN, "_PW_MIN", 1)
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(2, 48, 4, 4, 8, generator=g).bfloat16()
+    w0 = (0.2 * torch.randn(96, 48, generator=g)).bfloat16()
+    b0 = torch.randn(96, generator=g).bfloat16()
+    dy = torch.randn(2, 96, 4, 4, 8, generator=g).bfloat16()
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(LN, "_PW_HIP", on)
+        x, w, b = x0.clone().requires_grad_(), w0.clone().requires_grad_(), b0.clone().requires_grad_()
+        y = LN.pointwise(x, w, b)
+        y.backward(dy)
+        res.append([t.float() for t in (y.detach(), x.grad, w.grad, b.grad)])
+    for a, c in zip(*res):
+        assert (a - c).abs().max() <= 3e-2 * max(1.0, float(a.abs().max()))

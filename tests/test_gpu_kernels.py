@@ -566,3 +566,41 @@ def test_cross_entropy_matches_torch(hip, shape, dtype):
     scale = float(ref_in.grad.abs().max())
     tol = 1e-6 if dtype == torch.float32 else (2e-3 if dtype == torch.float16 else 1e-2)
     assert (logits.grad.double() - ref_in.grad).abs().max() <= tol * scale
+
+
+@pytest.mark.parametrize("B,Cin,Cout,S,dtype,bias", [(2, 48, 48, 64 ** 3, torch.bfloat16, True), (2, 4, 48, 64 ** 3, torch.bfloat16, False),
+                                                   (2, 48, 4, 32 ** 3, torch.float16, True), (1, 96, 48, 32 ** 3, torch.bfloat16, True),
+                                                   (2, 96, 96, 16 ** 3 * 8, torch.bfloat16, False)])
+def test_pointwise_cf_matches_matmul(B, Cin, Cout, S, dtype, bias):
+    """segm_pointwise_cf (1x1x1 convolution on channel-first activations) against an fp32 matmul of the same 16-bit operands, a
+    channel-slice view as input, accumulation; and the autograd route of linear.pointwise against the BLAS route"""
+    from segmamba_amd import linear as LN
+    hip = L.get_lib()
+    g = torch.Generator(device=DEV).manual_seed(Cin * 100 + Cout)
+    full = torch.randn(B, Cin + 16, S, device=DEV, generator=g).to(dtype)
+    x = full[:, 8:8 + Cin]
+    w = (0.2 * torch.randn(Cout, Cin, device=DEV, generator=g)).to(dtype)
+    b = torch.randn(Cout, device=DEV, generator=g) if bias else None
+    y = ops_raw.pointwise_cf(hip, x, w, b)
+    ref = torch.einsum("oc,bcs->bos", w.float(), x.float()) + (b.view(1, -1, 1) if bias else 0)
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    assert (y.float() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    y2 = ops_raw.pointwise_cf(hip, x, w, None, out=y.clone(), accumulate=True)
+    ref2 = y.float() + torch.einsum("oc,bcs->bos", w.float(), x.float())
+    assert (y2.float() - ref2).abs().max() <= tol * max(1.0, float(ref2.abs().max()))
+    if S % 64 == 0 and Cin >= 8:
+        res = []
+        dy = torch.randn(B, Cout, S, device=DEV, generator=g).to(dtype)
+        for on in (False, True):
+            old = LN._PW_HIP
+            LN._PW_HIP = on
+            try:
+                xa, wa = x.clone().requires_grad_(), w.clone().requires_grad_()
+                ba = b.to(dtype).clone().requires_grad_() if bias else None
+                out = LN.pointwise(xa.view(B, Cin, S, 1, 1), wa, ba).view(B, Cout, S)
+                out.backward(dy)
+                res.append([t.float() for t in (out.detach(), xa.grad, wa.grad)])
+            finally:
+                LN._PW_HIP = old
+        for a, c in zip(*res):
+            assert (a - c).abs().max() <= 3e-2 * max(1.0, float(a.abs().max()))
