@@ -486,6 +486,27 @@ typedef struct segm_pointwise_args {
 
 int segm_pointwise_cf(const segm_pointwise_args* args);
 
+/* ------------------------------------------------------------------------------------------------
+ * The encoder's stem convolution: Conv3d(kernel 7, stride 2, padding 3) on at most 4 input channels
+ * (model_segmamba/segmamba.py:141; cuDNN in the reference), forward.
+ * x4: the input channel-LAST with exactly 4 channels, (batch, din, hin, win, 4) contiguous (missing channels zero) - one
+ * transposing copy of the small input, made by the caller; w_packed: (cout, 7, 7, 8, 4) contiguous = weight[co][ci][kz][ky][kx]
+ * at [co][kz][ky][kx][ci], kx slot 7 and missing channels zero; bias (cout) fp32 or NULL; y (batch, cout, din/2, hin/2, win/2)
+ * contiguous.  One 16-bit dtype; cout <= 48; din, hin even; win a multiple of 32.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_stem_args {
+    int32_t batch, cout;
+    int32_t din, hin, win;
+    int32_t dtype;
+    const void* x4;
+    const void* w_packed;
+    const float* bias;
+    void* y;
+    void* stream;
+} segm_stem_args;
+
+int segm_stem_conv_fwd(const segm_stem_args* args);
+
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);
 const char* segm_status_string(int status);

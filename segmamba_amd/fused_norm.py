@@ -16,6 +16,8 @@ backward counterparts: 41 ms of a 283 ms training step, profiles/r01_bench_step_
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -81,6 +83,41 @@ def pointwise_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor |
     """
     cout, cin = weight.shape[0], weight.shape[1]
     return linear.pointwise(x, weight.reshape(cout, cin), bias)
+
+
+class _StemConv(torch.autograd.Function):
+    """Conv3d(kernel 7, stride 2, padding 3) of the encoder's stem (model_segmamba/segmamba.py:141): forward through
+    segm_stem_conv_fwd (an implicit GEMM; MIOpen's im2col route took 1.37 ms for the 2 x 4 x 128^3 input), backward through
+    ATen's convolution_backward on the same 16-bit operands (weight / bias gradients; the data gradient only if the input asks)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from . import lib as L, ops_raw
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return ops_raw.stem_conv_fwd(L.get_lib(), x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
+        dx, dw, db = torch.ops.aten.convolution_backward(dy.contiguous(), x, w, [w.shape[0]] if ctx.has_bias else None, [2, 2, 2],
+                                                         [3, 3, 3], [1, 1, 1], False, [0, 0, 0], 1, mask)
+        return dx, dw, db
+
+
+_STEM_HIP = os.environ.get("SEGM_STEM_HIP", "1") == "1"
+
+
+def stem_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """The 7^3 stride-2 stem convolution; follows autocast like F.conv3d.  Library kernel for 16-bit activations on the device
+    (SEGM_STEM_HIP=0: the MIOpen call), F.conv3d otherwise."""
+    from . import lib as L, ops_raw
+    if _STEM_HIP and L.on_device(x) and ops_raw.stem_conv_supported(x, weight):
+        dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
+        if dt in (torch.bfloat16, torch.float16):
+            return _StemConv.apply(x.to(dt), weight.to(dt), bias.to(dt) if bias is not None else None)
+    return F.conv3d(x, weight, bias, stride=2, padding=3)
 
 
 def patch_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, k: int) -> torch.Tensor:

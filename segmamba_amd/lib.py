@@ -194,6 +194,13 @@ class PointwiseArgs(C.Structure):
     ]
 
 
+class StemArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("cout", C.c_int32), ("din", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32), ("dtype", C.c_int32),
+        ("x4", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
 class TransposeArgs(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("dtype", C.c_int32),
@@ -209,7 +216,7 @@ EXPORTS = (
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add",
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
-    "segm_causal_conv1d_update", "segm_selective_state_update", "segm_linear_rows", "segm_pointwise_cf",
+    "segm_causal_conv1d_update", "segm_selective_state_update", "segm_linear_rows", "segm_pointwise_cf", "segm_stem_conv_fwd",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -255,6 +262,7 @@ class SegmLib:
         sig("segm_selective_state_update", [C.POINTER(StateUpdateArgs)], C.c_int)
         sig("segm_linear_rows", [C.POINTER(LinearArgs)], C.c_int)
         sig("segm_pointwise_cf", [C.POINTER(PointwiseArgs)], C.c_int)
+        sig("segm_stem_conv_fwd", [C.POINTER(StemArgs)], C.c_int)
         sig("segm_abi_version", [], C.c_int)
         sig("segm_status_string", [C.c_int], C.c_char_p)
 

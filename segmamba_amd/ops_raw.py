@@ -654,6 +654,41 @@ def pointwise_cf(lib: L.SegmLib, x3: torch.Tensor, w2: torch.Tensor, bias: Optio
     return y
 
 
+def stem_conv_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """x (B, Cin <= 4, D, H, W) with D, H even and W % 32 == 0; weight (Cout <= 48, Cin, 7, 7, 7); a wave's 8 output tiles are
+    TX along x (the largest of 8, 4, 2, 1 dividing W / 32) times 8 / TX rows, which must divide H / 2"""
+    if not (x.dim() == 5 and weight.dim() == 5 and tuple(weight.shape[2:]) == (7, 7, 7) and weight.shape[1] == x.shape[1]
+            and x.shape[1] <= 4 and weight.shape[0] <= 48 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[4] % 32 == 0):
+        return False
+    xt, hout = x.shape[4] // 32, x.shape[3] // 2
+    return any(xt % tx == 0 and hout % (8 // tx) == 0 for tx in (8, 4, 2, 1))
+
+
+def pack_stem_weight(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """(Cout, Cin <= 4, 7, 7, 7) -> (Cout, 7, 7, 8, 4): [co][kz][ky][kx slot][ci], slot 7 and missing channels zero"""
+    w = weight.permute(0, 2, 3, 4, 1)                                  # co, kz, ky, kx, ci
+    w = torch.nn.functional.pad(w, (0, 4 - w.shape[-1], 0, 1))
+    return w.contiguous().to(dtype)
+
+
+def stem_conv_fwd(lib: L.SegmLib, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = conv3d(x, weight, bias, stride 2, padding 3) for the 7^3 stem (x, weight of one 16-bit dtype) -> (B, Cout, D/2, H/2, W/2)"""
+    if not stem_conv_supported(x, weight) or x.dtype not in (torch.bfloat16, torch.float16) or weight.dtype != x.dtype:
+        raise RuntimeError("stem_conv_fwd: x (B, Cin <= 4, D even, H even, W % 32 == 0) and weight (Cout <= 48, Cin, 7, 7, 7) of one 16-bit dtype")
+    B, Cin, D, H, W = x.shape
+    x4 = torch.nn.functional.pad(x.permute(0, 2, 3, 4, 1), (0, 4 - Cin)).contiguous()
+    wp = pack_stem_weight(weight, x.dtype)
+    y = torch.empty(B, weight.shape[0], D // 2, H // 2, W // 2, dtype=x.dtype, device=x.device)
+    if bias is not None:
+        bias = bias.float().contiguous()
+    a = L.StemArgs()
+    a.batch, a.cout, a.din, a.hin, a.win, a.dtype = B, weight.shape[0], D, H, W, L.dtype_code(x)
+    a.x4, a.w_packed, a.bias, a.y = x4.data_ptr(), wp.data_ptr(), L.fptr(bias), y.data_ptr()
+    a.stream = L.stream_handle(x)
+    lib.check(lib.dll.segm_stem_conv_fwd(a), "stem_conv_fwd")
+    return y
+
+
 # ---------------------------------------------------------------------------------------------------------
 # device guard
 # ---------------------------------------------------------------------------------------------------------
@@ -686,5 +721,5 @@ def _device_guard(fn):
 
 for _name in ("scan_fwd", "scan_bwd", "conv1d_fwd", "conv1d_bwd", "conv3d_k3_wgrad", "conv3d_k3_fwd", "instnorm_fwd",
               "instnorm_bwd", "transpose_add", "layernorm_tokens_fwd", "layernorm_tokens_bwd", "sgd_clip_step", "cross_entropy",
-              "conv1d_update", "state_update", "linear_rows", "pointwise_cf"):
+              "conv1d_update", "state_update", "linear_rows", "pointwise_cf", "stem_conv_fwd"):
     globals()[_name] = _device_guard(globals()[_name])

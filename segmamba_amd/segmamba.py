@@ -125,7 +125,8 @@ class MambaEncoder(nn.Module):
         outs = []
         for i in range(4):
             if i == 0:
-                x = self.downsample_layers[0](x)
+                stem = self.downsample_layers[0][0]
+                x = fused_norm.stem_conv3d(x, stem.weight, stem.bias)
             else:                                           # InstanceNorm -> conv k2 s2 (a GEMM on 2x2x2 patches)
                 norm, conv = self.downsample_layers[i][0], self.downsample_layers[i][1]
                 x = fused_norm.instance_norm_act(x, act="none", eps=norm.eps)

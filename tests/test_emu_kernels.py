@@ -858,3 +858,22 @@ def test_pointwise_autograd_route_on_emulated_kernels(emu, monkeypatch):
         res.append([t.float() for t in (y.detach(), x.grad, w.grad, b.grad)])
     for a, c in zip(*res):
         assert (a - c).abs().max() <= 3e-2 * max(1.0, float(a.abs().max()))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,D,H,W,dtype,bias", [(1, 4, 48, 4, 16, 32, torch.bfloat16, True), (2, 1, 16, 2, 8, 64, torch.bfloat16, False),
+                                                       (1, 3, 32, 6, 16, 32, torch.float16, True), (1, 4, 48, 2, 4, 128, torch.bfloat16, False),
+                                                       (1, 2, 16, 2, 2, 256, torch.bfloat16, True)])
+def test_stem_conv_fwd_emulated(emu, B, Cin, Cout, D, H, W, dtype, bias):
+    """segm_stem_conv_fwd (7^3, stride 2, padding 3: implicit GEMM with K = (kz, ky, kx slot, ci), channel-last-4 input, packed
+    weights) against torch's conv3d in fp32 on the same 16-bit operands: every tile-block shape (TX x TY), fewer than 4 input
+    channels, fewer than 48 output channels, volumes smaller than the kernel (all padding cases)"""
+    g = torch.Generator().manual_seed(B + Cin + Cout + D)
+    x = torch.randn(B, Cin, D, H, W, generator=g).to(dtype)
+    w = (0.05 * torch.randn(Cout, Cin, 7, 7, 7, generator=g)).to(dtype)
+    b = torch.randn(Cout, generator=g) if bias else None
+    assert ops_raw.stem_conv_supported(x, w)
+    y = ops_raw.stem_conv_fwd(emu, x, w, b)
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), b, stride=2, padding=3)
+    assert y.shape == ref.shape and y.dtype == dtype
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert (y.float() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))

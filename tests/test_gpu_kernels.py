@@ -604,3 +604,26 @@ def test_pointwise_cf_matches_matmul(B, Cin, Cout, S, dtype, bias):
                 LN._PW_HIP = old
         for a, c in zip(*res):
             assert (a - c).abs().max() <= 3e-2 * max(1.0, float(a.abs().max()))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,size,dtype", [(2, 4, 48, 128, torch.bfloat16), (1, 1, 48, 64, torch.float16), (1, 4, 32, 32, torch.bfloat16)])
+def test_stem_conv_matches_conv3d(B, Cin, Cout, size, dtype):
+    """segm_stem_conv_fwd (7^3 stride 2 padding 3) against conv3d in fp32 on the same 16-bit operands, at the BASELINE input size;
+    and fused_norm.stem_conv3d's autograd (weight / bias gradients through ATen) against F.conv3d's"""
+    from segmamba_amd import fused_norm as FN
+    hip = L.get_lib()
+    g = torch.Generator(device=DEV).manual_seed(size + Cin)
+    x = torch.rand(B, Cin, size, size, size, device=DEV, generator=g).to(dtype)
+    w = (0.05 * torch.randn(Cout, Cin, 7, 7, 7, device=DEV, generator=g)).to(dtype)
+    b = torch.randn(Cout, device=DEV, generator=g)
+    y = ops_raw.stem_conv_fwd(hip, x, w, b)
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), b, stride=2, padding=3)
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    assert (y.float() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    wa, ba = w.clone().requires_grad_(), b.to(dtype).clone().requires_grad_()
+    wb, bb = w.clone().requires_grad_(), b.to(dtype).clone().requires_grad_()
+    dy = torch.randn_like(y)
+    FN.stem_conv3d(x, wa, ba).backward(dy)
+    torch.nn.functional.conv3d(x, wb, bb, stride=2, padding=3).backward(dy)
+    assert (wa.grad.float() - wb.grad.float()).abs().max() <= 3e-2 * max(1.0, float(wb.grad.float().abs().max()))
+    assert (ba.grad.float() - bb.grad.float()).abs().max() <= 3e-2 * max(1.0, float(bb.grad.float().abs().max()))
