@@ -140,13 +140,14 @@ def scan_roofline(dtype, device):
     bytes_b = algorithmic_bytes_scan(B, D, Lq, N, es, backward=True)
     gf, gb = bytes_f / ms_f * 1e-6, bytes_b / ms_b * 1e-6
     tr = scan_traffic({torch.bfloat16: "bf16", torch.float32: "fp32", torch.float16: "fp16"}[dtype])
-    # The kernels are bound by VALU issue, not by HBM: one v_exp_f32 (quarter rate) per step and state
-    # per pass plus the packed multiply-adds of the recurrence.  `valu` prices the same launch against that ceiling:
-    # VALU cycles per (batch, channel, step) element the algorithm needs (tools/probe_valu2.hip rates: transcendental 8,
-    # plain fp32 op 2 cycles per wave-instruction on a SIMD) / the cycles the launch took per element.
-    cyc_needed = 2 * N * (8 + 3 * 2) + N * 2 + 60             # two passes x N x (exp + 3 plain) + y fma + softplus / silu / casts
+    # The kernels are bound by VALU issue, not by HBM (profiles/r02_scan_proto_notes.md): one v_exp_f32 per
+    # step and state per pass plus the packed multiply-adds of the recurrence.  `valu` prices the same launch against that ceiling
+    # with the issue rates MEASURED on this MI355X (profiles/r02_probe_valu2.log: v_exp_f32 8.3, packed fp32 2.25 per lane-op, plain
+    # 2.7 cycles per wave-instruction on a SIMD with enough resident waves; 2.1 GHz under this load): cycles per
+    # (batch, channel, step) element the algorithm needs / the cycles the launch took per element.
+    cyc_needed = round(N * (8.3 + 3 * 2.25) + 50 + N * (8.3 + 4 * 2.25) + 80)      # aggregate pass + apply pass
     elems_per_simd = B * D * Lq / 64 / 1024                    # wave-steps per SIMD (256 CUs x 4 SIMDs)
-    cyc_taken = ms_f * 1e-3 * 2.4e9 / elems_per_simd
+    cyc_taken = ms_f * 1e-3 * 2.1e9 / elems_per_simd
     return {
         "bound": "hbm", "kernel": "selective_scan_fwd (scan_fwd_agg + scan_carry + scan_fwd_apply)",
         "shape": {"B": B, "D": D, "N": N, "L": Lq, "layout": "channel-last", "chunk": f["chunk"]},
@@ -154,7 +155,8 @@ def scan_roofline(dtype, device):
         "ms": round(ms_f, 4), "algorithmic_bytes": bytes_f,
         "traffic": tr["bytes"] if tr else None, "traffic_source": tr,
         "valu": {"bound": "valu-issue", "cycles_needed_per_wave_step": cyc_needed,
-                 "cycles_taken_per_wave_step_at_2.4GHz": round(cyc_taken, 1), "frac": round(cyc_needed / cyc_taken, 4)},
+                 "cycles_taken_per_wave_step_at_2.1GHz": round(cyc_taken, 1), "frac": round(cyc_needed / cyc_taken, 4),
+                 "busy_cycles_per_wave_step_SQ_counters": {"aggregate": 304, "apply": 402, "source": "profiles/r02_scan_pmc_bwd2.txt"}},
         "note": "the true bound is VALU issue (v_exp_f32 per step and state, two passes), not HBM: read `frac` with `valu.frac`",
         "backward": {"achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4), "ms": round(ms_b, 4),
                      "algorithmic_bytes": bytes_b},

@@ -11,9 +11,9 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last third of the trace = the two timed steps (warm-up and autotuning come first); normalise per step by counting CE kernels
 names = [r["Kernel_Name"] for r in rows]
-ce = [i for i, n in enumerate(names) if "cross_entropy" in n]
+ce = [i for i, n in enumerate(names) if "sgd_coef" in n]     # one launch per optimizer step (the last phase of a training step)
 steps = len(ce)
-start = ce[-3] + 1 if steps >= 3 else 0           # after the CE of the third-last step: exactly two steps follow
+start = ce[-3] + 1 if steps >= 3 else 0           # after the third-last step's coefficient kernel: two whole steps follow (shifted by the update launches)
 sel = rows[start:]
 nsteps = 2 if steps >= 3 else max(steps, 1)
 def owner(n):
