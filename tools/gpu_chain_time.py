@@ -1,6 +1,6 @@
 """A/B timings on the GPU box: conv3d forward default vs chained-K-parts kernel, fused clip+SGD / cross entropy vs ATen."""
 import os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from segmamba_amd import lib as L, ops_raw, train_ops
 
