@@ -54,5 +54,11 @@ c = H.scan_case(2, 96, 16, 64, dtype=torch.bfloat16, seed=1)
 H.run_scan(emu, c, "cpu", True, L.TIME_INTERLEAVED, 8); print("scan (regular-shape kernels) ok", flush=True)
 c = H.scan_case(1, 40, 12, 50, dtype=torch.float32, seed=2)
 H.run_scan(emu, c, "cpu", False, L.TIME_REVERSED, 1); print("scan (general kernels) ok", flush=True)
+c = H.scan_case(1, 16, 16, 16 * 70, dtype=torch.float32, seed=3)
+H.run_scan(emu, c, "cpu", True, L.TIME_REVERSED, 1, chunk=16); print("scan with several carry segments ok", flush=True)
+xp = torch.randn(2, 56, 128, generator=g).bfloat16()[:, 8:48]; wpw = (0.1 * torch.randn(52, 40, generator=g)).bfloat16()
+ops_raw.pointwise_cf(emu, xp, wpw, torch.randn(52)); print("pointwise_cf ok", flush=True)
+xs = torch.randn(1, 3, 2, 8, 64, generator=g).bfloat16(); ws = (0.1 * torch.randn(20, 3, 7, 7, 7, generator=g)).bfloat16()
+ops_raw.stem_conv_fwd(emu, xs, ws, torch.randn(20)); print("stem_conv_fwd ok", flush=True)
 print("AddressSanitizer run finished without reports")
 PY
