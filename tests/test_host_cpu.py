@@ -275,3 +275,30 @@ def test_argument_errors_of_the_newer_entry_points_without_gpu(built_lib):
     g.x = g.w = g.y = p16
     g.x_stride_row, g.y_stride_row = 40, 48
     assert d.segm_linear_rows(g) == -2                     # x rows shorter than k
+
+    q = lib.PointwiseArgs()
+    q.batch, q.cin, q.cout, q.dtype, q.spatial, q.w_stride = 1, 48, 48, lib.SEGM_BF16, 100, 48
+    assert d.segm_pointwise_cf(q) == -2                    # voxels not a multiple of 64
+    q.spatial, q.cin, q.w_stride = 128, 100, 104
+    assert d.segm_pointwise_cf(q) == -2                    # cin <= 96
+    q.cin, q.w_stride = 48, 44
+    assert d.segm_pointwise_cf(q) == -2                    # weight rows shorter than cin / not a multiple of 8
+    q.w_stride, q.dtype = 48, lib.SEGM_F32
+    assert d.segm_pointwise_cf(q) == -4
+    q.dtype = lib.SEGM_BF16
+    assert d.segm_pointwise_cf(q) == -1                    # NULL tensors
+    q.x = q.w = q.y = p16
+    q.x_stride_b, q.x_stride_c, q.y_stride_b, q.y_stride_c = 48 * 128, 130, 48 * 128, 128
+    assert d.segm_pointwise_cf(q) == -2                    # channel rows of x not 16-byte aligned
+
+    m = lib.StemArgs()
+    m.batch, m.cout, m.din, m.hin, m.win, m.dtype = 1, 48, 4, 4, 48, lib.SEGM_BF16
+    assert d.segm_stem_conv_fwd(m) == -2                   # width not a multiple of 32
+    m.win, m.cout = 64, 64
+    assert d.segm_stem_conv_fwd(m) == -2                   # cout <= 48
+    m.cout, m.hin = 48, 6
+    assert d.segm_stem_conv_fwd(m) == -2                   # 8 tiles = TX x TY must tile the output rows (wout 32: TY 4, hout 3)
+    m.hin, m.dtype = 8, lib.SEGM_F32
+    assert d.segm_stem_conv_fwd(m) == -4
+    m.dtype = lib.SEGM_BF16
+    assert d.segm_stem_conv_fwd(m) == -1                   # NULL tensors
