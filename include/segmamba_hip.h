@@ -507,6 +507,25 @@ typedef struct segm_stem_args {
 
 int segm_stem_conv_fwd(const segm_stem_args* args);
 
+/* Weight gradient of the same convolution (the reference: cuDNN's backward-filter through autograd).
+ * x4 as above; dy (batch, cout, din/2, hin/2, win/2) contiguous, same 16-bit dtype; dw_packed: fp32 (7, 7, cout16, 32) with
+ * cout16 = cout rounded up to 16: [kz][ky][co][kx slot * 4 + ci] (slot 7 / missing channels / co >= cout are padding);
+ * workspace: segm_stem_conv_wgrad_workspace_bytes() of per-slab partials, added in a fixed order (deterministic).
+ * win in {64, 128, 256}. */
+typedef struct segm_stem_wgrad_args {
+    int32_t batch, cout;
+    int32_t din, hin, win;
+    int32_t dtype;
+    const void* x4;
+    const void* dy;
+    float* dw_packed;
+    void* workspace;    size_t workspace_bytes;
+    void* stream;
+} segm_stem_wgrad_args;
+
+size_t segm_stem_conv_wgrad_workspace_bytes(int32_t batch, int32_t cout, int32_t din, int32_t hin);
+int segm_stem_conv_wgrad(const segm_stem_wgrad_args* args);
+
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);
 const char* segm_status_string(int status);

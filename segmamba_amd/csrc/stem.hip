@@ -149,6 +149,131 @@ static int launch_stem(StemDev& P, hipStream_t st) {
     return launch_stem_tx<T, 1>(P, st);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// weight gradient of the stem convolution  (C ABI: segm_stem_conv_wgrad)
+// ------------------------------------------------------------------------------------------------------
+// dW[co][kz][ky][slot][ci] = sum over (b, z, y, x) dy[b][co][z][y][x] * x4[b][2 z + kz - 3][2 y + ky - 3][2 x + slot - 3][ci]
+// MIOpen builds the 1.4 GB column matrix again (3.0 ms, profiles/r02_stem_bwd.log).  Here every output row (b, z, y) is a
+// correlation along x on MFMA with the contraction over the row's voxels:
+//   A[i = co][k = x]          a lane holds 8 consecutive x of one channel of dy: 16 contiguous bytes, loaded ONCE per row and kept
+//                             for the 7 ky taps a wave owns (kz is the wave's, from the grid);
+//   B[k = x][j = (slot, ci)]  the input row (2 z + kz - 3, 2 y + ky - 3), channel-last-4, staged into a wave-private LDS
+//                             strip (one 16-byte load per lane) and gathered at stride 2 positions: 8 ds_read_u16 per fragment;
+//   acc[ky][co tile][j tile]  7 x 3 x 2 tiles = 168 registers, written once per wave as a partial [slab][kz][ky][co][32];
+// a second launch adds the slabs in a fixed order (deterministic, no atomics).
+constexpr int kStemRowsPerWave = 64;
+
+struct StemWgDev {
+    const char* x4;                          // (B, Din, Hin, Win, 4)
+    const char* dy;                          // (B, cout, Dout, Hout, Wout)
+    float* part;                             // [slabs][7 kz][7 ky][cout16][32]
+    int32_t batch, cout, cout16;
+    int32_t din, hin, win, dout, hout, wout;
+    int64_t rows;                            // batch * dout * hout
+    int32_t slabs;
+};
+
+template <typename T, int NT, int KS>        // NT = 16-channel tiles of cout, KS = 32-voxel steps per output row
+__global__ void __launch_bounds__(kStemWaves * 64) stem_conv_wgrad_kernel(StemWgDev P) {
+    typedef typename Mfma16<T>::v8 frag8;
+    constexpr int WIN = KS * 64;                                  // input row length (positions)
+    constexpr int STRIP = (WIN + 8) * 4;                          // elements: 4 + 4 padding positions around the row (16-byte aligned stores)
+    __shared__ __attribute__((aligned(16))) T s_row[kStemWaves][STRIP];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int slab = blockIdx.x * kStemWaves + wave;
+    const int kz = blockIdx.y;
+    if (slab >= P.slabs) return;
+    T* strip = &s_row[wave][0];
+    // padding positions -4 .. -1 and WIN .. WIN + 3 stay zero for the whole kernel
+    if (lane < 16) strip[lane] = from_f32<T>(0.f);
+    else if (lane < 32) strip[(4 + WIN) * 4 + lane - 16] = from_f32<T>(0.f);
+
+    st_f32x4 acc[kStemK][NT][2];
+#pragma unroll
+    for (int ky = 0; ky < kStemK; ++ky)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) { acc[ky][mt][0] = st_f32x4{0.f, 0.f, 0.f, 0.f}; acc[ky][mt][1] = st_f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const T* X = reinterpret_cast<const T*>(P.x4);
+    const T* DY = reinterpret_cast<const T*>(P.dy);
+    const int64_t row_el = (int64_t)P.win * 4, plane_el = (int64_t)P.hin * row_el, vol_el = (int64_t)P.din * plane_el;
+    const int64_t oplane = (int64_t)P.hout * P.wout, ovol = (int64_t)P.dout * oplane;
+    // the lane's gather offsets: column j = i16 -> slot 4 jt + i16 / 4, channel i16 % 4; voxel x = 32 ks + 8 g + e
+    const int ci = i16 & 3, sl = i16 >> 2;
+
+    const int64_t r0 = (int64_t)slab * kStemRowsPerWave;
+    for (int rr = 0; rr < kStemRowsPerWave; ++rr) {
+        const int64_t row = r0 + rr;
+        if (row >= P.rows) break;                                // uniform
+        const int y = (int)(row % P.hout);
+        const int z = (int)((row / P.hout) % P.dout);
+        const int b = (int)(row / ((int64_t)P.hout * P.dout));
+        const int iz = 2 * z + kz - 3;
+        if (iz < 0 || iz >= P.din) continue;                     // uniform: a padding plane contributes nothing
+        frag8 af[NT][KS];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            const int co = 16 * mt + i16;
+            const T* dp = DY + ((int64_t)b * P.cout + (co < P.cout ? co : 0)) * ovol + (int64_t)z * oplane + (int64_t)y * P.wout;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const st_u32x4 zero = {0u, 0u, 0u, 0u};
+                const st_u32x4 v = *reinterpret_cast<const st_u32x4*>(dp + 32 * ks + 8 * g);
+                af[mt][ks] = __builtin_bit_cast(frag8, co < P.cout ? v : zero);
+            }
+        }
+#pragma unroll
+        for (int ky = 0; ky < kStemK; ++ky) {
+            const int iy = 2 * y + ky - 3;
+            if (iy < 0 || iy >= P.hin) continue;                 // uniform
+            const T* rowp = X + (int64_t)b * vol_el + (int64_t)iz * plane_el + (int64_t)iy * row_el;
+            SEGM_WAVE_LDS_SYNC();                                // the previous row's gathers are done
+#pragma unroll
+            for (int q = 0; q < (KS + 1) / 2; ++q)               // 64 lanes x 16 bytes = 128 positions per load
+                if ((q * 64 + lane) * 8 < WIN * 4)
+                    *reinterpret_cast<st_u32x4*>(strip + 16 + (q * 64 + lane) * 8) = *reinterpret_cast<const st_u32x4*>(rowp + (q * 64 + lane) * 8);
+            SEGM_WAVE_LDS_SYNC();
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    // B fragment: x4row[2 (32 ks + 8 g + e) + (4 jt + sl) - 3][ci], e = 0 .. 7   (strip index = position + 4)
+                    const T* gp = strip + (2 * (32 * ks + 8 * g) + 4 * jt + sl + 1) * 4 + ci;
+                    T e8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) e8[e] = gp[e * 8];
+                    frag8 bf;
+                    memcpy(&bf, e8, 16);
+#pragma unroll
+                    for (int mt = 0; mt < NT; ++mt) acc[ky][mt][jt] = Mfma16<T>::run(af[mt][ks], bf, acc[ky][mt][jt]);
+                }
+            }
+        }
+    }
+    // partial: D[co = 16 mt + 4 g + r][j = 16 jt + i16]
+    float* pp = P.part + (((int64_t)slab * kStemK + kz) * kStemK) * P.cout16 * 32;
+#pragma unroll
+    for (int ky = 0; ky < kStemK; ++ky)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pp[((int64_t)ky * P.cout16 + 16 * mt + 4 * g + r) * 32 + 16 * jt + i16] = acc[ky][mt][jt][r];
+}
+
+// dwp[n] = sum over slabs of part[slab][n], slabs added in order
+__global__ void __launch_bounds__(256) stem_wgrad_reduce_kernel(const float* __restrict__ part, int slabs, int64_t n, float* __restrict__ dwp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int s = 0; s < slabs; ++s) acc += part[(int64_t)s * n + i];
+    dwp[i] = acc;
+}
+
 }  // namespace segm
 
 using namespace segm;
@@ -168,4 +293,47 @@ extern "C" int segm_stem_conv_fwd(const segm_stem_args* a) {
     P.dout = a->din / 2; P.hout = a->hin / 2; P.wout = a->win / 2;
     hipStream_t st = (hipStream_t)a->stream;
     return a->dtype == SEGM_F16 ? launch_stem<f16_t>(P, st) : launch_stem<bf16_t>(P, st);
+}
+
+extern "C" size_t segm_stem_conv_wgrad_workspace_bytes(int32_t batch, int32_t cout, int32_t din, int32_t hin) {
+    if (batch <= 0 || cout <= 0 || din <= 0 || hin <= 0) return 0;
+    const int64_t rows = (int64_t)batch * (din / 2) * (hin / 2);
+    const int64_t slabs = (rows + kStemRowsPerWave - 1) / kStemRowsPerWave;
+    return (size_t)slabs * kStemK * kStemK * ((cout + 15) / 16 * 16) * 32 * sizeof(float);
+}
+
+extern "C" int segm_stem_conv_wgrad(const segm_stem_wgrad_args* a) {
+    if (!a) return SEGM_E_NULL;
+    if (a->batch <= 0 || a->cout <= 0 || a->cout > 48 || a->din <= 0 || a->hin <= 0 || a->win <= 0) return SEGM_E_SHAPE;
+    if (a->din % 2 || a->hin % 2 || (a->win != 64 && a->win != 128 && a->win != 256)) return SEGM_E_SHAPE;   // rows of 1, 2 or 4 k-steps
+    if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
+    if (!a->x4 || !a->dy || !a->dw_packed) return SEGM_E_NULL;
+    if (((uintptr_t)a->x4 & 15) || ((uintptr_t)a->dy & 15)) return SEGM_E_SHAPE;
+    const size_t need = segm_stem_conv_wgrad_workspace_bytes(a->batch, a->cout, a->din, a->hin);
+    if (!a->workspace || a->workspace_bytes < need) return SEGM_E_WORKSPACE;
+    StemWgDev P;
+    P.x4 = (const char*)a->x4; P.dy = (const char*)a->dy; P.part = (float*)a->workspace;
+    P.batch = a->batch; P.cout = a->cout; P.cout16 = (a->cout + 15) / 16 * 16;
+    P.din = a->din; P.hin = a->hin; P.win = a->win;
+    P.dout = a->din / 2; P.hout = a->hin / 2; P.wout = a->win / 2;
+    P.rows = (int64_t)P.batch * P.dout * P.hout;
+    P.slabs = (int32_t)((P.rows + kStemRowsPerWave - 1) / kStemRowsPerWave);
+    hipStream_t st = (hipStream_t)a->stream;
+    const dim3 grid((unsigned)((P.slabs + kStemWaves - 1) / kStemWaves), kStemK), block(kStemWaves * 64);
+    const int nt = P.cout16 / 16, ks = a->win / 64;
+#define SEGM_STEM_WG(TT)                                                                                                   \
+    if (nt == 1 && ks == 1) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 1, 1>), grid, block, 0, st, P);                  \
+    else if (nt == 2 && ks == 1) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 2, 1>), grid, block, 0, st, P);             \
+    else if (nt == 3 && ks == 1) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 3, 1>), grid, block, 0, st, P);             \
+    else if (nt == 1 && ks == 2) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 1, 2>), grid, block, 0, st, P);             \
+    else if (nt == 2 && ks == 2) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 2, 2>), grid, block, 0, st, P);             \
+    else if (nt == 3 && ks == 2) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 3, 2>), grid, block, 0, st, P);             \
+    else if (nt == 1) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 1, 4>), grid, block, 0, st, P);                        \
+    else if (nt == 2) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 2, 4>), grid, block, 0, st, P);                        \
+    else hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 3, 4>), grid, block, 0, st, P);
+    if (a->dtype == SEGM_F16) { SEGM_STEM_WG(f16_t) } else { SEGM_STEM_WG(bf16_t) }
+#undef SEGM_STEM_WG
+    const int64_t n = (int64_t)kStemK * kStemK * P.cout16 * 32;
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P.part, P.slabs, n, a->dw_packed);
+    return (int)hipGetLastError();
 }

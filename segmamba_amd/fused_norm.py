@@ -87,25 +87,36 @@ def pointwise_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor |
 
 class _StemConv(torch.autograd.Function):
     """Conv3d(kernel 7, stride 2, padding 3) of the encoder's stem (model_segmamba/segmamba.py:141): forward through
-    segm_stem_conv_fwd (an implicit GEMM; MIOpen's im2col route took 1.37 ms for the 2 x 4 x 128^3 input), backward through
-    ATen's convolution_backward on the same 16-bit operands (weight / bias gradients; the data gradient only if the input asks)."""
+    segm_stem_conv_fwd (an implicit GEMM; MIOpen's im2col route took 1.37 ms for the 2 x 4 x 128^3 input), weight gradient
+    through segm_stem_conv_wgrad on the channel-last-4 copy of the input the forward made (MIOpen: 3.0 ms), bias gradient a
+    sum.  The network input needs no gradient; when it does ask for one (or the width is not one the kernel takes) ATen's
+    convolution_backward runs on the same 16-bit operands."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         from . import lib as L, ops_raw
-        ctx.save_for_backward(x, w)
+        x4 = ops_raw.stem_channel_last4(x)
+        ctx.use_hip = (_STEM_WGRAD_HIP and not ctx.needs_input_grad[0] and ops_raw.stem_wgrad_supported(x4, w.shape[0]))
+        ctx.save_for_backward(x4 if ctx.use_hip else x, w)
         ctx.has_bias = b is not None
-        return ops_raw.stem_conv_fwd(L.get_lib(), x, w, b)
+        return ops_raw.stem_conv_fwd(L.get_lib(), x, w, b, x4=x4)
 
     @staticmethod
     def backward(ctx, dy):
+        from . import lib as L, ops_raw
         x, w = ctx.saved_tensors
+        if ctx.use_hip:
+            dy = dy.contiguous()
+            dw = ops_raw.stem_conv_wgrad(L.get_lib(), x, dy, w.shape[1]).to(w.dtype) if ctx.needs_input_grad[1] else None
+            db = dy.sum(dim=(0, 2, 3, 4), dtype=torch.float32).to(dy.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            return None, dw, db
         mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
         dx, dw, db = torch.ops.aten.convolution_backward(dy.contiguous(), x, w, [w.shape[0]] if ctx.has_bias else None, [2, 2, 2],
                                                          [3, 3, 3], [1, 1, 1], False, [0, 0, 0], 1, mask)
         return dx, dw, db
 
 
+_STEM_WGRAD_HIP = os.environ.get("SEGM_STEM_WGRAD_HIP", "1") == "1"
 _STEM_HIP = os.environ.get("SEGM_STEM_HIP", "1") == "1"
 
 

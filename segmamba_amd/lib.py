@@ -201,6 +201,14 @@ class StemArgs(C.Structure):
     ]
 
 
+class StemWgradArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("cout", C.c_int32), ("din", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32), ("dtype", C.c_int32),
+        ("x4", C.c_void_p), ("dy", C.c_void_p), ("dw_packed", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+    ]
+
+
 class TransposeArgs(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("dtype", C.c_int32),
@@ -217,6 +225,7 @@ EXPORTS = (
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
     "segm_causal_conv1d_update", "segm_selective_state_update", "segm_linear_rows", "segm_pointwise_cf", "segm_stem_conv_fwd",
+    "segm_stem_conv_wgrad", "segm_stem_conv_wgrad_workspace_bytes",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -263,6 +272,8 @@ class SegmLib:
         sig("segm_linear_rows", [C.POINTER(LinearArgs)], C.c_int)
         sig("segm_pointwise_cf", [C.POINTER(PointwiseArgs)], C.c_int)
         sig("segm_stem_conv_fwd", [C.POINTER(StemArgs)], C.c_int)
+        sig("segm_stem_conv_wgrad", [C.POINTER(StemWgradArgs)], C.c_int)
+        sig("segm_stem_conv_wgrad_workspace_bytes", [C.c_int32] * 4, C.c_size_t)
         sig("segm_abi_version", [], C.c_int)
         sig("segm_status_string", [C.c_int], C.c_char_p)
 

@@ -671,12 +671,19 @@ def pack_stem_weight(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return w.contiguous().to(dtype)
 
 
-def stem_conv_fwd(lib: L.SegmLib, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+def stem_channel_last4(x: torch.Tensor) -> torch.Tensor:
+    """(B, Cin <= 4, D, H, W) -> (B, D, H, W, 4) contiguous, missing channels zero: the input layout of both stem kernels"""
+    return torch.nn.functional.pad(x.permute(0, 2, 3, 4, 1), (0, 4 - x.shape[1])).contiguous()
+
+
+def stem_conv_fwd(lib: L.SegmLib, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                  x4: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = conv3d(x, weight, bias, stride 2, padding 3) for the 7^3 stem (x, weight of one 16-bit dtype) -> (B, Cout, D/2, H/2, W/2)"""
     if not stem_conv_supported(x, weight) or x.dtype not in (torch.bfloat16, torch.float16) or weight.dtype != x.dtype:
         raise RuntimeError("stem_conv_fwd: x (B, Cin <= 4, D even, H even, W % 32 == 0) and weight (Cout <= 48, Cin, 7, 7, 7) of one 16-bit dtype")
     B, Cin, D, H, W = x.shape
-    x4 = torch.nn.functional.pad(x.permute(0, 2, 3, 4, 1), (0, 4 - Cin)).contiguous()
+    if x4 is None:
+        x4 = stem_channel_last4(x)
     wp = pack_stem_weight(weight, x.dtype)
     y = torch.empty(B, weight.shape[0], D // 2, H // 2, W // 2, dtype=x.dtype, device=x.device)
     if bias is not None:
@@ -687,6 +694,34 @@ def stem_conv_fwd(lib: L.SegmLib, x: torch.Tensor, weight: torch.Tensor, bias: O
     a.stream = L.stream_handle(x)
     lib.check(lib.dll.segm_stem_conv_fwd(a), "stem_conv_fwd")
     return y
+
+
+def stem_wgrad_supported(x4: torch.Tensor, cout: int) -> bool:
+    """x4 (B, D, H, W, 4) with D, H even and W in {64, 128, 256}; cout <= 48"""
+    return x4.dim() == 5 and x4.shape[4] == 4 and x4.shape[1] % 2 == 0 and x4.shape[2] % 2 == 0 and x4.shape[3] in (64, 128, 256) and cout <= 48
+
+
+def stem_conv_wgrad(lib: L.SegmLib, x4: torch.Tensor, dy: torch.Tensor, cin: int) -> torch.Tensor:
+    """dW (Cout, cin, 7, 7, 7) fp32 of conv3d(x, W, stride 2, padding 3) from the channel-last-4 input x4 (B, D, H, W, 4) and
+    dy (B, Cout, D/2, H/2, W/2), one 16-bit dtype"""
+    B, D, H, W, _ = x4.shape
+    cout = dy.shape[1]
+    if (not stem_wgrad_supported(x4, cout) or x4.dtype not in (torch.bfloat16, torch.float16) or dy.dtype != x4.dtype
+            or tuple(dy.shape) != (B, cout, D // 2, H // 2, W // 2) or not 1 <= cin <= 4):
+        raise RuntimeError("stem_conv_wgrad: x4 (B, D even, H even, W in {64, 128, 256}, 4) and dy (B, Cout <= 48, D/2, H/2, W/2) of one 16-bit dtype")
+    x4, dy = x4.contiguous(), dy.contiguous()
+    cout16 = (cout + 15) // 16 * 16
+    dwp = torch.empty(7, 7, cout16, 8, 4, dtype=torch.float32, device=x4.device)
+    nbytes = lib.dll.segm_stem_conv_wgrad_workspace_bytes(B, cout, D, H)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x4.device)
+    a = L.StemWgradArgs()
+    a.batch, a.cout, a.din, a.hin, a.win, a.dtype = B, cout, D, H, W, L.dtype_code(x4)
+    a.x4, a.dy, a.dw_packed = x4.data_ptr(), dy.data_ptr(), dwp.data_ptr()
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    a.stream = L.stream_handle(x4)
+    lib.check(lib.dll.segm_stem_conv_wgrad(a), "stem_conv_wgrad")
+    # [kz][ky][co][kx slot][ci] -> (co, ci, kz, ky, kx)
+    return dwp[:, :, :cout, :7, :cin].permute(2, 4, 0, 1, 3).contiguous()
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -721,5 +756,5 @@ def _device_guard(fn):
 
 for _name in ("scan_fwd", "scan_bwd", "conv1d_fwd", "conv1d_bwd", "conv3d_k3_wgrad", "conv3d_k3_fwd", "instnorm_fwd",
               "instnorm_bwd", "transpose_add", "layernorm_tokens_fwd", "layernorm_tokens_bwd", "sgd_clip_step", "cross_entropy",
-              "conv1d_update", "state_update", "linear_rows", "pointwise_cf", "stem_conv_fwd"):
+              "conv1d_update", "state_update", "linear_rows", "pointwise_cf", "stem_conv_fwd", "stem_conv_wgrad"):
     globals()[_name] = _device_guard(globals()[_name])

@@ -877,3 +877,23 @@ def test_stem_conv_fwd_emulated(emu, B, Cin, Cout, D, H, W, dtype, bias):
     assert y.shape == ref.shape and y.dtype == dtype
     tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
     assert (y.float() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,D,H,W,dtype", [(1, 4, 48, 4, 8, 64, torch.bfloat16), (2, 1, 16, 2, 4, 128, torch.bfloat16),
+                                                  (1, 3, 32, 6, 6, 64, torch.float16), (1, 2, 40, 2, 2, 256, torch.bfloat16)])
+def test_stem_conv_wgrad_emulated(emu, B, Cin, Cout, D, H, W, dtype):
+    """segm_stem_conv_wgrad (per output row a correlation along x on MFMA: A = dy row, B = stride-2 gathers of the staged
+    channel-last-4 input row, per-slab partials added in order) against autograd of torch's conv3d in fp32 on the same 16-bit
+    operands: 1, 2 and 4 k-steps per row, fewer than 4 input channels, channel counts that are not multiples of 16, volumes
+    with every (kz, ky) tap touching the padding"""
+    g = torch.Generator().manual_seed(B + Cin + Cout + D)
+    x = torch.randn(B, Cin, D, H, W, generator=g).to(dtype)
+    dy = torch.randn(B, Cout, D // 2, H // 2, W // 2, generator=g).to(dtype)
+    x4 = ops_raw.stem_channel_last4(x)
+    assert ops_raw.stem_wgrad_supported(x4, Cout)
+    dw = ops_raw.stem_conv_wgrad(emu, x4, dy, Cin)
+    w = torch.zeros(Cout, Cin, 7, 7, 7, requires_grad=True)
+    torch.nn.functional.conv3d(x.float(), w, None, stride=2, padding=3).backward(dy.float())
+    assert dw.shape == w.grad.shape and dw.dtype == torch.float32
+    assert (dw - w.grad).abs().max() <= 1e-3 * max(1.0, float(w.grad.abs().max()))
+    assert torch.equal(dw, ops_raw.stem_conv_wgrad(emu, x4, dy, Cin))                        # fixed summation order

@@ -609,7 +609,7 @@ def test_pointwise_cf_matches_matmul(B, Cin, Cout, S, dtype, bias):
 @pytest.mark.parametrize("B,Cin,Cout,size,dtype", [(2, 4, 48, 128, torch.bfloat16), (1, 1, 48, 64, torch.float16), (1, 4, 32, 32, torch.bfloat16)])
 def test_stem_conv_matches_conv3d(B, Cin, Cout, size, dtype):
     """segm_stem_conv_fwd (7^3 stride 2 padding 3) against conv3d in fp32 on the same 16-bit operands, at the BASELINE input size;
-    and fused_norm.stem_conv3d's autograd (weight / bias gradients through ATen) against F.conv3d's"""
+    and fused_norm.stem_conv3d's autograd (weight gradient through segm_stem_conv_wgrad for W in {64, 128, 256}, ATen otherwise) against F.conv3d's"""
     from segmamba_amd import fused_norm as FN
     hip = L.get_lib()
     g = torch.Generator(device=DEV).manual_seed(size + Cin)
@@ -627,3 +627,19 @@ def test_stem_conv_matches_conv3d(B, Cin, Cout, size, dtype):
     torch.nn.functional.conv3d(x, wb, bb, stride=2, padding=3).backward(dy)
     assert (wa.grad.float() - wb.grad.float()).abs().max() <= 3e-2 * max(1.0, float(wb.grad.float().abs().max()))
     assert (ba.grad.float() - bb.grad.float()).abs().max() <= 3e-2 * max(1.0, float(bb.grad.float().abs().max()))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,size,dtype", [(2, 4, 48, 128, torch.bfloat16), (1, 3, 40, 64, torch.float16)])
+def test_stem_conv_wgrad_matches_autograd(B, Cin, Cout, size, dtype):
+    """segm_stem_conv_wgrad at the BASELINE input size against the fp32 weight gradient of conv3d on the same 16-bit operands
+    (fp32 accumulation over 524 288 voxels: 1e-3 of the largest entry), and bitwise repeatable"""
+    hip = L.get_lib()
+    g = torch.Generator(device=DEV).manual_seed(size + Cout)
+    x = torch.rand(B, Cin, size, size, size, device=DEV, generator=g).to(dtype)
+    dy = torch.randn(B, Cout, size // 2, size // 2, size // 2, device=DEV, generator=g).to(dtype)
+    x4 = ops_raw.stem_channel_last4(x)
+    dw = ops_raw.stem_conv_wgrad(hip, x4, dy, Cin)
+    w = torch.zeros(Cout, Cin, 7, 7, 7, device=DEV, requires_grad=True)
+    torch.nn.functional.conv3d(x.float(), w, None, stride=2, padding=3).backward(dy.float())
+    assert (dw - w.grad).abs().max() <= 1e-3 * float(w.grad.abs().max())
+    assert torch.equal(dw, ops_raw.stem_conv_wgrad(hip, x4, dy, Cin))

@@ -302,3 +302,18 @@ def test_argument_errors_of_the_newer_entry_points_without_gpu(built_lib):
     assert d.segm_stem_conv_fwd(m) == -4
     m.dtype = lib.SEGM_BF16
     assert d.segm_stem_conv_fwd(m) == -1                   # NULL tensors
+
+    g = lib.StemWgradArgs()
+    g.batch, g.cout, g.din, g.hin, g.win, g.dtype = 1, 48, 4, 4, 96, lib.SEGM_BF16
+    assert d.segm_stem_conv_wgrad(g) == -2                 # rows of 1, 2 or 4 k-steps: width 64, 128 or 256
+    g.win, g.din = 64, 3
+    assert d.segm_stem_conv_wgrad(g) == -2                 # even extents
+    g.din, g.dtype = 4, lib.SEGM_F32
+    assert d.segm_stem_conv_wgrad(g) == -4
+    g.dtype = lib.SEGM_BF16
+    assert d.segm_stem_conv_wgrad(g) == -1                 # NULL tensors
+    g.x4 = g.dy = g.dw_packed = p16
+    need = d.segm_stem_conv_wgrad_workspace_bytes(1, 48, 4, 4)
+    assert need == 1 * 7 * 7 * 48 * 32 * 4                 # 4 output rows: one slab of partials
+    g.workspace, g.workspace_bytes = p16, need - 1
+    assert d.segm_stem_conv_wgrad(g) == -6                 # workspace too small
