@@ -223,7 +223,9 @@ class _ConvSame(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         pad = w.shape[2] // 2
-        dy = dy.contiguous()
+        from . import ops_raw
+        if not ops_raw.channel_dense(dy):                # the kernels take strides; a padded channel stride is not copied
+            dy = dy.contiguous()
         dx = dw = db = None
         blockable = max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0
         if ctx.needs_input_grad[0]:

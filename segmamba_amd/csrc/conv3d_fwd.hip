@@ -61,6 +61,20 @@ struct ConvFwdDev {
 
 // four consecutive outputs of one lane: convert and store, optionally on top of what y holds (a later 48-channel block
 // of a wider layer)
+// Workgroups are handed to the 8 XCDs round robin (workgroup i -> XCD i % 8), each XCD with its own L2.  Work items that are
+// neighbours in z read the same input rows (every row is staged by the three planes around it), so consecutive items should
+// meet in ONE L2: XCD k takes the k-th contiguous eighth of the item range.  Without this every row is fetched from HBM /
+// Infinity Cache by three different L2s.
+__device__ __forceinline__ int xcd_item(int bid, int nitems) {
+#ifdef SEGM_NO_XCD_MAP
+    return bid;
+#else
+    const int per = nitems >> 3;
+    if ((nitems & 7) != 0 || per == 0) return bid;
+    return (bid & 7) * per + (bid >> 3);
+#endif
+}
+
 template <typename T, bool ACC>
 __device__ __forceinline__ void store4(T* dst, const float (&v)[4]) {
     u32x2 pk;
@@ -87,7 +101,7 @@ __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P)
     const int kz = wave >> 2, xt = wave & 3;
     const int i16 = lane & 15, g = lane >> 4;
     const int cob = blockIdx.y + P.cob0;
-    int item = blockIdx.x;
+    int item = xcd_item(blockIdx.x, gridDim.x);
     const int ypart = item % P.ysplit;  item /= P.ysplit;
     const int xb = item % P.nxb;        item /= P.nxb;
     const int z = item % P.D, b = item / P.D;
@@ -252,10 +266,12 @@ __device__ __forceinline__ CopyLane copy_lane(const ConvFwdDev& P, int wslot, in
         pos = 1 + 8 * gr;
         L.has = true;
     } else {
-        const int side = lane >= 24 ? 1 : 0;
-        tcp = lane - side * 24;
-        L.has = lane < 48;
-        if (!L.has) tcp = 0;
+        // lanes 48 - 63 repeat the tasks of lanes 0 - 15 (same address, same value): no lane-divergent branch around the
+        // park, so every path through a step waits for its loads before the output stores are issued
+        const int l48 = lane >= 48 ? lane - 48 : lane;
+        const int side = l48 >= 24 ? 1 : 0;
+        tcp = l48 - side * 24;
+        L.has = true;
         x = side ? x0 + kFwXB : x0 - 1;
         pos = side ? kFwXB + 1 : 0;
     }
@@ -328,7 +344,7 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
     const int part = wave >> 1, xp = wave & 1;            // K part, pair of x tiles (x0 + 32 xp .. + 31)
     const int i16 = lane & 15, g = lane >> 4;
     const int cob = blockIdx.y;                           // block of 48 output channels
-    int item = blockIdx.x;
+    int item = xcd_item(blockIdx.x, gridDim.x);
     const int ypart = item % P.ysplit;  item /= P.ysplit;
     const int xb = item % P.nxb;        item /= P.nxb;
     const int z = item % P.D, b = item / P.D;
@@ -480,7 +496,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
     const int part = wave / XP, xp = wave % XP;
     const int i16 = lane & 15, g = lane >> 4;
     const int cob = blockIdx.y;                           // block of 48 output channels
-    int item = blockIdx.x;
+    int item = xcd_item(blockIdx.x, gridDim.x);
     const int ypart = item % P.ysplit;  item /= P.ysplit;
     const int xb = item % P.nxb;        item /= P.nxb;
     const int z = item % P.D, b = item / P.D;
@@ -517,7 +533,9 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
 
     // ---- row staging: plane q's incoming row during step s is s + {2, 0, -1}[q]: slot A = plane 0 (waves 0 - 3) / plane 1
     //      (waves 4 - 7), slot B = plane 2 (waves 0 - 3) -------------------------------------------------------------------------
-    const int wslot = wave & 3;
+    // the halo task goes to waves 0 and 4 (K parts 0 and 2), never to the storing part: a halo wave's fetch is followed by
+    // a wait that would also cover the output stores it issued one step earlier
+    const int wslot = ((wave & 3) + 3) & 3;
     const bool halo_wave = wslot == 3, second = wave < 4;
     const int plane_a = wave >> 2, soff_a = plane_a == 0 ? 2 : 0;
     const CopyLane cl = copy_lane<T, CP>(P, wslot, lane, x0);
@@ -589,26 +607,30 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
                     for (int u = 0; u < XT; ++u) hand[s & 1][part][xp][t * XT + u][lane] = acc[t][u];
-            } else {
-#pragma unroll
-                for (int u = 0; u < XT; ++u) {
-                    const int xg = x0 + (xp * XT + u) * 16 + 4 * g;        // this lane's 4 output positions
-                    if (xg >= P.W) continue;
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        float v[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = acc[t][u][q];
-                        const int co = cob * 48 + t * 16 + i16;
-                        T* dst = reinterpret_cast<T*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
-                                      (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + xg;
-                        store4<T, ACC>(dst, v);
-                    }
-                }
             }
         }
         SEGM_SCHED_FENCE();
         park(r, s, true);
+        // the last K part stores AFTER the rows are parked: vmcnt counts loads and stores in order, so a park behind the stores
+        // would wait for their write acknowledgements (a memory round trip on the critical path of every step); here the
+        // stores drain during the next step
+        if (active && part == 3) {
+#pragma unroll
+            for (int u = 0; u < XT; ++u) {
+                const int xg = x0 + (xp * XT + u) * 16 + 4 * g;            // this lane's 4 output positions
+                if (xg >= P.W) continue;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = acc[t][u][q];
+                    const int co = cob * 48 + t * 16 + i16;
+                    T* dst = reinterpret_cast<T*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
+                                  (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + xg;
+                    store4<T, ACC>(dst, v);
+                }
+            }
+        }
         __syncthreads();                                  // incoming rows and the hand-off tiles are in LDS
     }
 }
@@ -666,7 +688,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
     const int part = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g = lane >> 4;
     const int cob = blockIdx.y;                           // block of 48 output channels
-    int item = blockIdx.x;
+    int item = xcd_item(blockIdx.x, gridDim.x);
     const int ypart = item % P.ysplit;  item /= P.ysplit;
     const int xb = item % P.nxb;        item /= P.nxb;
     const int z = item % P.D, b = item / P.D;

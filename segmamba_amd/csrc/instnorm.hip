@@ -27,6 +27,7 @@ struct NormDev {
     float* mean; float* rstd;
     float2* part;
     int64_t S;
+    int64_t xs, dys;       // elements between consecutive instances of x / dy (a conv output with a padded channel stride); S when dense
     int64_t slab;          // elements per slab (multiple of 8 * 256)
     int32_t nsplit;
     int32_t act;           // 0 none, 1 relu, 2 leaky relu
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(kBlock) inorm_fwd_stats_kernel(NormDev P) {
     using Pk = Pack<T, VEC>;
     __shared__ float2 lds[kWavesPerBlock];
     const int split = blockIdx.x, inst = blockIdx.y;
-    const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.S;
+    const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.xs;
     int64_t e0, e1;
     slab_range(P, split, e0, e1);
     float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(kBlock) inorm_fwd_apply_kernel(NormDev P) {
     const float2 st = merge_stats(P, inst, lds);
     const float mean = st.x, rstd = st.y;
     if (split == 0 && threadIdx.x == 0) { P.mean[inst] = mean; P.rstd[inst] = rstd; }
-    const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.S;
+    const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.xs;
     const T* res = P.res ? reinterpret_cast<const T*>(P.res) + (int64_t)inst * P.S : nullptr;
     T* y = reinterpret_cast<T*>(P.y) + (int64_t)inst * P.S;
     const float slope = P.act == 1 ? 0.f : P.slope;
@@ -176,8 +177,8 @@ __global__ void __launch_bounds__(kBlock) inorm_bwd_stats_kernel(NormDev P) {
     __shared__ float2 lds[kWavesPerBlock];
     const int split = blockIdx.x, inst = blockIdx.y;
     const int64_t base = (int64_t)inst * P.S;
-    const T* x = reinterpret_cast<const T*>(P.x) + base;
-    const T* dy = reinterpret_cast<const T*>(P.dy) + base;
+    const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.xs;
+    const T* dy = reinterpret_cast<const T*>(P.dy) + (int64_t)inst * P.dys;
     const T* ym = P.ymask ? reinterpret_cast<const T*>(P.ymask) + base : nullptr;
     T* dres = P.dres ? reinterpret_cast<T*>(P.dres) + base : nullptr;
     const float mean = P.mean[inst], rstd = P.rstd[inst];
@@ -232,8 +233,8 @@ __global__ void __launch_bounds__(kBlock) inorm_bwd_apply_kernel(NormDev P) {
     __syncthreads();
     const float mg = lds[0].x, mgx = lds[0].y;
     const int64_t base = (int64_t)inst * P.S;
-    const T* x = reinterpret_cast<const T*>(P.x) + base;
-    const T* dy = reinterpret_cast<const T*>(P.dy) + base;
+    const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.xs;
+    const T* dy = reinterpret_cast<const T*>(P.dy) + (int64_t)inst * P.dys;
     const T* ym = P.ymask ? reinterpret_cast<const T*>(P.ymask) + base : nullptr;
     const T* gsrc = P.dres ? reinterpret_cast<const T*>(P.dres) + base : nullptr;     // g parked by the stats pass
     T* dx = reinterpret_cast<T*>(P.dx) + base;
@@ -331,8 +332,11 @@ extern "C" int segm_instnorm_fwd(const segm_instnorm_fwd_args* a) {
     P.x = a->x; P.res = a->residual; P.y = a->y; P.mean = a->mean; P.rstd = a->rstd;
     P.part = (float2*)a->workspace;
     P.S = a->spatial; P.act = a->act; P.slope = a->slope; P.eps = a->eps;
+    if (a->x_instance_stride != 0 && a->x_instance_stride < a->spatial) return SEGM_E_SHAPE;
+    P.xs = a->x_instance_stride ? a->x_instance_stride : a->spatial;
+    P.dys = a->spatial;
     const int vn = vec_width(a->dtype);
-    const bool vec = a->spatial % vn == 0 && aligned16(a->x) && aligned16(a->y) && (!a->residual || aligned16(a->residual));
+    const bool vec = a->spatial % vn == 0 && P.xs % vn == 0 && aligned16(a->x) && aligned16(a->y) && (!a->residual || aligned16(a->residual));
     norm_plan(a->instances, a->spatial, vn, P.nsplit, P.slab);
     hipStream_t st = (hipStream_t)a->stream;
     if (a->dtype == SEGM_F32) return launch_norm_fwd<float>(P, a->instances, vec, st);
@@ -351,8 +355,12 @@ extern "C" int segm_instnorm_bwd(const segm_instnorm_bwd_args* a) {
     P.mean = (float*)a->mean; P.rstd = (float*)a->rstd;
     P.part = (float2*)a->workspace;
     P.S = a->spatial; P.act = a->act; P.slope = a->slope; P.eps = 0.f;
+    if ((a->x_instance_stride != 0 && a->x_instance_stride < a->spatial) || (a->dy_instance_stride != 0 && a->dy_instance_stride < a->spatial))
+        return SEGM_E_SHAPE;
+    P.xs = a->x_instance_stride ? a->x_instance_stride : a->spatial;
+    P.dys = a->dy_instance_stride ? a->dy_instance_stride : a->spatial;
     const int vn = vec_width(a->dtype);
-    const bool vec = a->spatial % vn == 0 && aligned16(a->x) && aligned16(a->dy) && aligned16(a->dx) &&
+    const bool vec = a->spatial % vn == 0 && P.xs % vn == 0 && P.dys % vn == 0 && aligned16(a->x) && aligned16(a->dy) && aligned16(a->dx) &&
                      (!P.ymask || aligned16(P.ymask)) && (!a->dresidual || aligned16(a->dresidual));
     norm_plan(a->instances, a->spatial, vn, P.nsplit, P.slab);
     hipStream_t st = (hipStream_t)a->stream;

@@ -30,7 +30,8 @@ class _InstNormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, act, slope, eps):
         from . import lib as L, ops_raw
-        x = x.contiguous()
+        if not ops_raw.channel_dense(x):                 # a convolution output with a padded channel stride is taken as it is
+            x = x.contiguous()
         if residual is not None:
             residual = residual.to(x.dtype).contiguous()
         y, mean, rstd = ops_raw.instnorm_fwd(L.get_lib(), x, residual, act, slope, eps)

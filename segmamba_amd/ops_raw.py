@@ -316,7 +316,7 @@ def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias:
     if out is None:
         if accumulate:
             raise RuntimeError("conv3d_k3_fwd: accumulate needs `out`")
-        y = torch.empty(B, cout, D, H, W, dtype=x.dtype, device=x.device)
+        y = volume_empty(B, cout, (D, H, W), x.dtype, x.device)
     else:
         y = out
         if tuple(y.shape) != (B, cout, D, H, W) or y.dtype != x.dtype or y.device != x.device or y.stride(4) != 1 or \
@@ -346,9 +346,48 @@ def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias:
 ACT_CODES = {"none": 0, "relu": 1, "leaky_relu": 2}
 
 
+# ---------------------------------------------------------------------------------------------------------
+# volumes with a padded channel stride
+# ---------------------------------------------------------------------------------------------------------
+# A dense (B, C, 128, 128, 128) 16-bit volume has a channel stride of exactly 4 MiB: the C lines a convolution writes for one
+# output row (one per channel, same z / y / x) all fall into the same L2 set and the same memory channel.  Measured on MI355X
+# (profiles/r02_conv_stride_pad.log): the 48 -> 48 3x3x3 kernel takes 0.669 ms on dense tensors, 0.586 ms with 64 elements of
+# padding per channel of the OUTPUT and 0.530 ms with input and output padded; the 1x1x1 kernel 0.284 -> 0.247 ms; 64^3 volumes
+# (0.5 MiB) do not care.  The convolution kernels therefore allocate such outputs with `volume_empty`; their consumers take the
+# strides (convolutions, the instance-norm kernels) or see an ordinary strided tensor (ATen).
+_VOLUME_PAD = 192                 # elements: 384 bytes = three 128-byte lines
+_VOLUME_PAD_ON = os.environ.get("SEGM_VOLUME_PAD", "1") == "1"
+
+
+def volume_empty(B: int, C: int, spatial, dtype: torch.dtype, device) -> torch.Tensor:
+    """(B, C, *spatial) tensor, dense inside a channel; the channel stride is padded by _VOLUME_PAD elements when the dense one
+    would be a multiple of 1 MiB (and C >= 16: with a handful of channels nothing aliases)."""
+    S = 1
+    for d in spatial:
+        S *= int(d)
+    nbytes = S * torch.empty(0, dtype=dtype).element_size()
+    if not (_VOLUME_PAD_ON and C >= 16 and nbytes >= (1 << 20) and nbytes % (1 << 20) == 0):
+        return torch.empty(B, C, *spatial, dtype=dtype, device=device)
+    buf = torch.empty(B, C, S + _VOLUME_PAD, dtype=dtype, device=device)
+    return buf[:, :, :S].view(B, C, *spatial)
+
+
+def channel_dense(x: torch.Tensor) -> bool:
+    """(B, C, *spatial) with dense channels (contiguous spatial dims) and batch stride = C * channel stride: what the kernels
+    that take a channel / instance stride accept (a contiguous tensor, or one from volume_empty)."""
+    if x.dim() < 3:
+        return False
+    s = 1
+    for i in range(x.dim() - 1, 1, -1):
+        if x.shape[i] != 1 and x.stride(i) != s:
+            return False
+        s *= x.shape[i]
+    return x.stride(1) >= s and x.stride(0) == x.shape[1] * x.stride(1)
+
+
 def _norm_geom(x):
-    if x.dim() < 3 or not x.is_contiguous():
-        raise RuntimeError("instnorm: x must be a contiguous (B, C, *spatial) tensor")
+    if x.dim() < 3 or not channel_dense(x):
+        raise RuntimeError("instnorm: x must be a (B, C, *spatial) tensor with dense channels (contiguous, or a padded channel stride)")
     inst = x.shape[0] * x.shape[1]
     return inst, x.numel() // inst
 
@@ -361,7 +400,8 @@ def instnorm_fwd(lib: L.SegmLib, x, residual=None, act="none", slope=0.01, eps=1
     a = L.InstNormFwdArgs()
     a.instances, a.dtype, a.act, a.spatial = inst, L.dtype_code(x), ACT_CODES[act], S
     a.slope, a.eps = float(slope), float(eps)
-    y = torch.empty_like(x)
+    a.x_instance_stride = x.stride(1)
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     mean = torch.empty(inst, dtype=torch.float32, device=x.device)
     rstd = torch.empty(inst, dtype=torch.float32, device=x.device)
     ws_bytes = lib.dll.segm_instnorm_workspace_bytes(inst, S)
@@ -378,12 +418,14 @@ def instnorm_bwd(lib: L.SegmLib, x, dy, mean, rstd, y=None, act="none", slope=0.
     inst, S = _norm_geom(x)
     if dy.shape != x.shape or dy.dtype != x.dtype:
         raise RuntimeError("instnorm: dy must match x")
-    dy = dy.contiguous()
+    if not channel_dense(dy):
+        dy = dy.contiguous()
     a = L.InstNormBwdArgs()
     a.instances, a.dtype, a.act, a.spatial = inst, L.dtype_code(x), ACT_CODES[act], S
     a.slope = float(slope)
-    dx = torch.empty_like(x)
-    dres = torch.empty_like(x) if want_dresidual else None
+    a.x_instance_stride, a.dy_instance_stride = x.stride(1), dy.stride(1)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dresidual else None
     ws_bytes = lib.dll.segm_instnorm_workspace_bytes(inst, S)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     a.x, a.dy, a.y = x.data_ptr(), dy.data_ptr(), (y.data_ptr() if y is not None else None)
@@ -636,7 +678,7 @@ def pointwise_cf(lib: L.SegmLib, x3: torch.Tensor, w2: torch.Tensor, bias: Optio
     if Cin % 8:                                            # pad the weight rows to a multiple of 8 (zero columns)
         w2 = torch.nn.functional.pad(w2, (0, 8 - Cin % 8))
     w2 = w2.contiguous()
-    y = torch.empty(B, Cout, S, dtype=x3.dtype, device=x3.device) if out is None else out
+    y = volume_empty(B, Cout, (S,), x3.dtype, x3.device) if out is None else out
     if tuple(y.shape) != (B, Cout, S) or y.dtype != x3.dtype or y.stride(2) != 1 or y.stride(0) % 4 or y.stride(1) % 4 \
             or y.data_ptr() % 8:
         raise RuntimeError("pointwise_cf: `out` must be (B, Cout, S) of x's dtype with contiguous 8-byte aligned voxel rows")

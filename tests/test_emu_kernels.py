@@ -206,6 +206,75 @@ def test_instance_norm_act_emulated(emu, shape, act, with_res, dtype):
         assert (dres.double() - ref_g[1]).abs().max() < tol
 
 
+def _channel_padded(t, pad):
+    """the same values in a buffer whose channel stride is padded by `pad` elements (what ops_raw.volume_empty hands out)"""
+    B, C = t.shape[:2]
+    S = t[0, 0].numel()
+    buf = torch.full((B, C, S + pad), float("nan"), dtype=t.dtype)
+    v = buf[:, :, :S].view(t.shape)
+    v.copy_(t)
+    return v
+
+
+@pytest.mark.parametrize("shape,act,with_res,dtype,padx,pady", [
+    ((2, 3, 4, 8, 16), "leaky_relu", True, torch.bfloat16, 192, 64),     # vector path on both padded operands
+    ((1, 2, 16, 32, 48), "relu", False, torch.float32, 64, 0),           # several slabs, dy dense
+    ((2, 2, 3, 5, 7), "leaky_relu", True, torch.float32, 3, 5),          # odd strides: the scalar path
+])
+def test_instance_norm_padded_channel_stride_emulated(emu, shape, act, with_res, dtype, padx, pady):
+    """x (forward, backward) and dy (backward) with a padded channel stride - conv outputs of the 128^3 level - give bit-identical
+    results to the dense tensors; the padding is never read (it holds NaN)"""
+    g = torch.Generator().manual_seed(sum(shape) + padx)
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(dtype)
+    res = torch.randn(shape, generator=g).to(dtype) if with_res else None
+    gy = torch.randn(shape, generator=g).to(dtype)
+    y0, mean0, rstd0 = ops_raw.instnorm_fwd(emu, x, res, act, 0.01, 1e-5)
+    ym = y0 if (with_res and act != "none") else None
+    dx0, dres0 = ops_raw.instnorm_bwd(emu, x, gy, mean0, rstd0, ym, act, 0.01, want_dresidual=with_res)
+    xp, gp = _channel_padded(x, padx), (_channel_padded(gy, pady) if pady else gy)
+    assert ops_raw.channel_dense(xp) and not xp.is_contiguous()
+    y1, mean1, rstd1 = ops_raw.instnorm_fwd(emu, xp, res, act, 0.01, 1e-5)
+    assert y1.is_contiguous() and torch.equal(y1, y0) and torch.equal(mean1, mean0) and torch.equal(rstd1, rstd0)
+    dx1, dres1 = ops_raw.instnorm_bwd(emu, xp, gp, mean1, rstd1, ym, act, 0.01, want_dresidual=with_res)
+    assert dx1.is_contiguous() and torch.equal(dx1, dx0)
+    if with_res:
+        assert torch.equal(dres1, dres0)
+
+
+def test_conv3d_chain_padded_channel_stride_emulated(emu):
+    """the 3x3x3 kernels (all variants) and the 1x1x1 kernel on input / output volumes with a padded channel stride"""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 48, 3, 6, 64, generator=g).bfloat16()
+    w = (0.05 * torch.randn(48, 48, 3, 3, 3, generator=g)).bfloat16()
+    wp = ops_raw.pack_conv3d_weight(w)
+    xp = _channel_padded(x, 192)
+    for kw in ({}, dict(chain=True), dict(chain=True, pitch48=True), dict(chain32=True)):
+        ref = ops_raw.conv3d_k3_fwd(emu, x, wp, None, **kw)
+        out = _channel_padded(torch.zeros_like(ref), 64)
+        ops_raw.conv3d_k3_fwd(emu, xp, wp, None, out=out, **kw)
+        assert torch.equal(out, ref), kw
+    w2 = (0.1 * torch.randn(32, 48, generator=g)).bfloat16()
+    ref = ops_raw.pointwise_cf(emu, x.flatten(2), w2, None)
+    out = _channel_padded(torch.zeros_like(ref), 64)
+    ops_raw.pointwise_cf(emu, xp.flatten(2), w2, None, out=out)
+    assert torch.equal(out, ref)
+
+
+def test_volume_empty_pads_power_of_two_channel_strides():
+    """ops_raw.volume_empty: a 128^3 16-bit volume with >= 16 channels gets a padded channel stride (4 MiB strides alias in L2 /
+    memory channels), everything else is an ordinary contiguous tensor; channel_dense recognises both"""
+    v = ops_raw.volume_empty(1, 16, (128, 128, 128), torch.bfloat16, "cpu")
+    assert v.shape == (1, 16, 128, 128, 128) and v.stride(1) == 128 ** 3 + 192 and v.stride(0) == 16 * v.stride(1)
+    assert v.stride()[2:] == (128 * 128, 128, 1) and ops_raw.channel_dense(v) and not v.is_contiguous()
+    assert v.flatten(2).data_ptr() == v.data_ptr()                                   # flattening the voxels stays a view
+    for args in ((1, 4, (128, 128, 128), torch.bfloat16), (1, 48, (64, 64, 64), torch.bfloat16), (2, 48, (96, 96, 96), torch.float16)):
+        t = ops_raw.volume_empty(*args, "cpu")
+        assert t.is_contiguous() and ops_raw.channel_dense(t)
+    assert ops_raw.volume_empty(1, 16, (64, 64, 64), torch.float32, "cpu").stride(1) == 64 ** 3 + 192     # 1 MiB fp32 channels
+    assert not ops_raw.channel_dense(torch.zeros(2, 4, 6, 8).permute(0, 2, 1, 3))
+    assert not ops_raw.channel_dense(torch.zeros(2, 8, 6, 8)[:, :3])                 # batch stride != channels * channel stride
+
+
 @pytest.mark.parametrize("shape,dtype,with_add", [((2, 48, 200), torch.bfloat16, True), ((1, 130, 72), torch.float32, False),
                                                   ((1, 7, 13), torch.float32, True), ((2, 64, 64), torch.float16, False)])
 def test_transpose_add_emulated(emu, shape, dtype, with_add):
