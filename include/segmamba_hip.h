@@ -265,9 +265,9 @@ typedef struct segm_instnorm_fwd_args {
     void* workspace;          /* segm_instnorm_workspace_bytes() */
     size_t workspace_bytes;
     void* stream;
-    int64_t x_instance_stride;   /* elements between consecutive (b, c) instances of x; 0 = spatial (dense).  The 3x3x3 / 1x1x1 kernels
-                                  * write 128^3 volumes with a padded channel stride (a 4 MiB stride puts all channels of a row
-                                  * into one L2 set / memory channel); residual and y are dense */
+    /* elements between consecutive (b, c) instances of x / residual / y; 0 = spatial (dense).  128^3 volumes are kept with a
+     * padded channel stride (a 4 MiB stride puts all channels of a row into one L2 set / memory channel) */
+    int64_t x_instance_stride, residual_instance_stride, y_instance_stride;
 } segm_instnorm_fwd_args;
 
 typedef struct segm_instnorm_bwd_args {
@@ -284,8 +284,7 @@ typedef struct segm_instnorm_bwd_args {
     void* workspace;
     size_t workspace_bytes;
     void* stream;
-    int64_t x_instance_stride;   /* as in the forward; 0 = spatial */
-    int64_t dy_instance_stride;  /* likewise for dy (the data gradient of a convolution); y, dx, dresidual are dense */
+    int64_t x_instance_stride, dy_instance_stride, y_instance_stride, dx_instance_stride, dresidual_instance_stride;   /* as above */
 } segm_instnorm_bwd_args;
 
 int segm_instnorm_fwd(const segm_instnorm_fwd_args* args);

@@ -27,7 +27,8 @@ struct NormDev {
     float* mean; float* rstd;
     float2* part;
     int64_t S;
-    int64_t xs, dys;       // elements between consecutive instances of x / dy (a conv output with a padded channel stride); S when dense
+    int64_t xs, rs, ys, dys, dxs, drs;   // elements between consecutive instances of x, residual, y (ymask), dy, dx, dres: S when
+                                         // dense, larger for volumes with a padded channel stride (ops_raw.volume_empty)
     int64_t slab;          // elements per slab (multiple of 8 * 256)
     int32_t nsplit;
     int32_t act;           // 0 none, 1 relu, 2 leaky relu
@@ -128,8 +129,8 @@ __global__ void __launch_bounds__(kBlock) inorm_fwd_apply_kernel(NormDev P) {
     const float mean = st.x, rstd = st.y;
     if (split == 0 && threadIdx.x == 0) { P.mean[inst] = mean; P.rstd[inst] = rstd; }
     const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.xs;
-    const T* res = P.res ? reinterpret_cast<const T*>(P.res) + (int64_t)inst * P.S : nullptr;
-    T* y = reinterpret_cast<T*>(P.y) + (int64_t)inst * P.S;
+    const T* res = P.res ? reinterpret_cast<const T*>(P.res) + (int64_t)inst * P.rs : nullptr;
+    T* y = reinterpret_cast<T*>(P.y) + (int64_t)inst * P.ys;
     const float slope = P.act == 1 ? 0.f : P.slope;
     const float shift = -mean * rstd;
     int64_t e0, e1;
@@ -176,11 +177,10 @@ __global__ void __launch_bounds__(kBlock) inorm_bwd_stats_kernel(NormDev P) {
     using Pk = Pack<T, VEC>;
     __shared__ float2 lds[kWavesPerBlock];
     const int split = blockIdx.x, inst = blockIdx.y;
-    const int64_t base = (int64_t)inst * P.S;
     const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.xs;
     const T* dy = reinterpret_cast<const T*>(P.dy) + (int64_t)inst * P.dys;
-    const T* ym = P.ymask ? reinterpret_cast<const T*>(P.ymask) + base : nullptr;
-    T* dres = P.dres ? reinterpret_cast<T*>(P.dres) + base : nullptr;
+    const T* ym = P.ymask ? reinterpret_cast<const T*>(P.ymask) + (int64_t)inst * P.ys : nullptr;
+    T* dres = P.dres ? reinterpret_cast<T*>(P.dres) + (int64_t)inst * P.drs : nullptr;
     const float mean = P.mean[inst], rstd = P.rstd[inst];
     const float shift = -mean * rstd;
     const float slope = P.act == 1 ? 0.f : P.slope;
@@ -232,12 +232,11 @@ __global__ void __launch_bounds__(kBlock) inorm_bwd_apply_kernel(NormDev P) {
     }
     __syncthreads();
     const float mg = lds[0].x, mgx = lds[0].y;
-    const int64_t base = (int64_t)inst * P.S;
     const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.xs;
     const T* dy = reinterpret_cast<const T*>(P.dy) + (int64_t)inst * P.dys;
-    const T* ym = P.ymask ? reinterpret_cast<const T*>(P.ymask) + base : nullptr;
-    const T* gsrc = P.dres ? reinterpret_cast<const T*>(P.dres) + base : nullptr;     // g parked by the stats pass
-    T* dx = reinterpret_cast<T*>(P.dx) + base;
+    const T* ym = P.ymask ? reinterpret_cast<const T*>(P.ymask) + (int64_t)inst * P.ys : nullptr;
+    const T* gsrc = P.dres ? reinterpret_cast<const T*>(P.dres) + (int64_t)inst * P.drs : nullptr;     // g parked by the stats pass
+    T* dx = reinterpret_cast<T*>(P.dx) + (int64_t)inst * P.dxs;
     const float mean = P.mean[inst], rstd = P.rstd[inst];
     const float shift = -mean * rstd;
     const float slope = P.act == 1 ? 0.f : P.slope;
@@ -276,6 +275,11 @@ static void norm_plan(int instances, int64_t S, int vecn, int& nsplit, int64_t& 
 }
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+// an instance stride argument: 0 = dense (the spatial size); never smaller than the spatial size
+static bool norm_stride(int64_t given, int64_t spatial, int64_t& out) {
+    out = given ? given : spatial;
+    return out >= spatial;
+}
 
 template <typename T>
 static int launch_norm_fwd(NormDev& P, int instances, bool vec, hipStream_t st) {
@@ -332,11 +336,11 @@ extern "C" int segm_instnorm_fwd(const segm_instnorm_fwd_args* a) {
     P.x = a->x; P.res = a->residual; P.y = a->y; P.mean = a->mean; P.rstd = a->rstd;
     P.part = (float2*)a->workspace;
     P.S = a->spatial; P.act = a->act; P.slope = a->slope; P.eps = a->eps;
-    if (a->x_instance_stride != 0 && a->x_instance_stride < a->spatial) return SEGM_E_SHAPE;
-    P.xs = a->x_instance_stride ? a->x_instance_stride : a->spatial;
-    P.dys = a->spatial;
+    if (!norm_stride(a->x_instance_stride, a->spatial, P.xs) || !norm_stride(a->residual_instance_stride, a->spatial, P.rs) ||
+        !norm_stride(a->y_instance_stride, a->spatial, P.ys))
+        return SEGM_E_SHAPE;
     const int vn = vec_width(a->dtype);
-    const bool vec = a->spatial % vn == 0 && P.xs % vn == 0 && aligned16(a->x) && aligned16(a->y) && (!a->residual || aligned16(a->residual));
+    const bool vec = a->spatial % vn == 0 && P.xs % vn == 0 && P.rs % vn == 0 && P.ys % vn == 0 && aligned16(a->x) && aligned16(a->y) && (!a->residual || aligned16(a->residual));
     norm_plan(a->instances, a->spatial, vn, P.nsplit, P.slab);
     hipStream_t st = (hipStream_t)a->stream;
     if (a->dtype == SEGM_F32) return launch_norm_fwd<float>(P, a->instances, vec, st);
@@ -355,12 +359,13 @@ extern "C" int segm_instnorm_bwd(const segm_instnorm_bwd_args* a) {
     P.mean = (float*)a->mean; P.rstd = (float*)a->rstd;
     P.part = (float2*)a->workspace;
     P.S = a->spatial; P.act = a->act; P.slope = a->slope; P.eps = 0.f;
-    if ((a->x_instance_stride != 0 && a->x_instance_stride < a->spatial) || (a->dy_instance_stride != 0 && a->dy_instance_stride < a->spatial))
+    if (!norm_stride(a->x_instance_stride, a->spatial, P.xs) || !norm_stride(a->dy_instance_stride, a->spatial, P.dys) ||
+        !norm_stride(a->y_instance_stride, a->spatial, P.ys) || !norm_stride(a->dx_instance_stride, a->spatial, P.dxs) ||
+        !norm_stride(a->dresidual_instance_stride, a->spatial, P.drs))
         return SEGM_E_SHAPE;
-    P.xs = a->x_instance_stride ? a->x_instance_stride : a->spatial;
-    P.dys = a->dy_instance_stride ? a->dy_instance_stride : a->spatial;
     const int vn = vec_width(a->dtype);
-    const bool vec = a->spatial % vn == 0 && P.xs % vn == 0 && P.dys % vn == 0 && aligned16(a->x) && aligned16(a->dy) && aligned16(a->dx) &&
+    const bool vec = a->spatial % vn == 0 && P.xs % vn == 0 && P.dys % vn == 0 && P.ys % vn == 0 && P.dxs % vn == 0 && P.drs % vn == 0 &&
+                     aligned16(a->x) && aligned16(a->dy) && aligned16(a->dx) &&
                      (!P.ymask || aligned16(P.ymask)) && (!a->dresidual || aligned16(a->dresidual));
     norm_plan(a->instances, a->spatial, vn, P.nsplit, P.slab);
     hipStream_t st = (hipStream_t)a->stream;

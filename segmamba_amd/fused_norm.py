@@ -33,7 +33,9 @@ class _InstNormAct(torch.autograd.Function):
         if not ops_raw.channel_dense(x):                 # a convolution output with a padded channel stride is taken as it is
             x = x.contiguous()
         if residual is not None:
-            residual = residual.to(x.dtype).contiguous()
+            residual = residual.to(x.dtype)
+            if not ops_raw.channel_dense(residual):
+                residual = residual.contiguous()
         y, mean, rstd = ops_raw.instnorm_fwd(L.get_lib(), x, residual, act, slope, eps)
         need_y = residual is not None and act != "none"
         ctx.save_for_backward(x, mean, rstd, y if need_y else None)

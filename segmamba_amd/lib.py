@@ -109,7 +109,7 @@ class InstNormFwdArgs(C.Structure):
         ("spatial", C.c_int64), ("slope", C.c_float), ("eps", C.c_float),
         ("x", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
-        ("x_instance_stride", C.c_int64),
+        ("x_instance_stride", C.c_int64), ("residual_instance_stride", C.c_int64), ("y_instance_stride", C.c_int64),
     ]
 
 
@@ -120,7 +120,8 @@ class InstNormBwdArgs(C.Structure):
         ("x", C.c_void_p), ("dy", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
         ("dx", C.c_void_p), ("dresidual", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
-        ("x_instance_stride", C.c_int64), ("dy_instance_stride", C.c_int64),
+        ("x_instance_stride", C.c_int64), ("dy_instance_stride", C.c_int64), ("y_instance_stride", C.c_int64),
+        ("dx_instance_stride", C.c_int64), ("dresidual_instance_stride", C.c_int64),
     ]
 
 

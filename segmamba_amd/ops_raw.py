@@ -357,6 +357,7 @@ ACT_CODES = {"none": 0, "relu": 1, "leaky_relu": 2}
 # strides (convolutions, the instance-norm kernels) or see an ordinary strided tensor (ATen).
 _VOLUME_PAD = 192                 # elements: 384 bytes = three 128-byte lines
 _VOLUME_PAD_ON = os.environ.get("SEGM_VOLUME_PAD", "1") == "1"
+_VOLUME_PAD_QUANTUM = 1 << 20     # channel sizes (bytes) that are multiples of this get the padding (tests lower it)
 
 
 def volume_empty(B: int, C: int, spatial, dtype: torch.dtype, device) -> torch.Tensor:
@@ -366,7 +367,7 @@ def volume_empty(B: int, C: int, spatial, dtype: torch.dtype, device) -> torch.T
     for d in spatial:
         S *= int(d)
     nbytes = S * torch.empty(0, dtype=dtype).element_size()
-    if not (_VOLUME_PAD_ON and C >= 16 and nbytes >= (1 << 20) and nbytes % (1 << 20) == 0):
+    if not (_VOLUME_PAD_ON and C >= 16 and nbytes >= _VOLUME_PAD_QUANTUM and nbytes % _VOLUME_PAD_QUANTUM == 0):
         return torch.empty(B, C, *spatial, dtype=dtype, device=device)
     buf = torch.empty(B, C, S + _VOLUME_PAD, dtype=dtype, device=device)
     return buf[:, :, :S].view(B, C, *spatial)
@@ -395,13 +396,14 @@ def _norm_geom(x):
 def instnorm_fwd(lib: L.SegmLib, x, residual=None, act="none", slope=0.01, eps=1e-5):
     """-> (y, mean, rstd): y = act(IN(x) + residual); mean / rstd fp32 (B * C)."""
     inst, S = _norm_geom(x)
-    if residual is not None and (residual.shape != x.shape or residual.dtype != x.dtype or not residual.is_contiguous()):
-        raise RuntimeError("instnorm: residual must match x (shape, dtype, contiguous)")
+    if residual is not None and (residual.shape != x.shape or residual.dtype != x.dtype or not channel_dense(residual)):
+        raise RuntimeError("instnorm: residual must match x (shape, dtype, dense channels)")
     a = L.InstNormFwdArgs()
     a.instances, a.dtype, a.act, a.spatial = inst, L.dtype_code(x), ACT_CODES[act], S
     a.slope, a.eps = float(slope), float(eps)
-    a.x_instance_stride = x.stride(1)
-    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    y = volume_empty(x.shape[0], x.shape[1], x.shape[2:], x.dtype, x.device)
+    a.x_instance_stride, a.y_instance_stride = x.stride(1), y.stride(1)
+    a.residual_instance_stride = residual.stride(1) if residual is not None else 0
     mean = torch.empty(inst, dtype=torch.float32, device=x.device)
     rstd = torch.empty(inst, dtype=torch.float32, device=x.device)
     ws_bytes = lib.dll.segm_instnorm_workspace_bytes(inst, S)
@@ -423,9 +425,13 @@ def instnorm_bwd(lib: L.SegmLib, x, dy, mean, rstd, y=None, act="none", slope=0.
     a = L.InstNormBwdArgs()
     a.instances, a.dtype, a.act, a.spatial = inst, L.dtype_code(x), ACT_CODES[act], S
     a.slope = float(slope)
-    a.x_instance_stride, a.dy_instance_stride = x.stride(1), dy.stride(1)
-    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-    dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dresidual else None
+    if y is not None and (y.shape != x.shape or y.dtype != x.dtype or not channel_dense(y)):
+        raise RuntimeError("instnorm: y must match x (shape, dtype, dense channels)")
+    dx = volume_empty(x.shape[0], x.shape[1], x.shape[2:], x.dtype, x.device)
+    dres = volume_empty(x.shape[0], x.shape[1], x.shape[2:], x.dtype, x.device) if want_dresidual else None
+    a.x_instance_stride, a.dy_instance_stride, a.dx_instance_stride = x.stride(1), dy.stride(1), dx.stride(1)
+    a.y_instance_stride = y.stride(1) if y is not None else 0
+    a.dresidual_instance_stride = dres.stride(1) if dres is not None else 0
     ws_bytes = lib.dll.segm_instnorm_workspace_bytes(inst, S)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     a.x, a.dy, a.y = x.data_ptr(), dy.data_ptr(), (y.data_ptr() if y is not None else None)

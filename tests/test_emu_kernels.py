@@ -222,8 +222,8 @@ def _channel_padded(t, pad):
     ((2, 2, 3, 5, 7), "leaky_relu", True, torch.float32, 3, 5),          # odd strides: the scalar path
 ])
 def test_instance_norm_padded_channel_stride_emulated(emu, shape, act, with_res, dtype, padx, pady):
-    """x (forward, backward) and dy (backward) with a padded channel stride - conv outputs of the 128^3 level - give bit-identical
-    results to the dense tensors; the padding is never read (it holds NaN)"""
+    """x, the residual, the saved y and dy with (different) padded channel strides - the volumes of the 128^3 level - give
+    bit-identical results to the dense tensors; the padding is never read (it holds NaN)"""
     g = torch.Generator().manual_seed(sum(shape) + padx)
     x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(dtype)
     res = torch.randn(shape, generator=g).to(dtype) if with_res else None
@@ -232,11 +232,13 @@ def test_instance_norm_padded_channel_stride_emulated(emu, shape, act, with_res,
     ym = y0 if (with_res and act != "none") else None
     dx0, dres0 = ops_raw.instnorm_bwd(emu, x, gy, mean0, rstd0, ym, act, 0.01, want_dresidual=with_res)
     xp, gp = _channel_padded(x, padx), (_channel_padded(gy, pady) if pady else gy)
+    rp = _channel_padded(res, pady + 8) if with_res else None
     assert ops_raw.channel_dense(xp) and not xp.is_contiguous()
-    y1, mean1, rstd1 = ops_raw.instnorm_fwd(emu, xp, res, act, 0.01, 1e-5)
-    assert y1.is_contiguous() and torch.equal(y1, y0) and torch.equal(mean1, mean0) and torch.equal(rstd1, rstd0)
-    dx1, dres1 = ops_raw.instnorm_bwd(emu, xp, gp, mean1, rstd1, ym, act, 0.01, want_dresidual=with_res)
-    assert dx1.is_contiguous() and torch.equal(dx1, dx0)
+    y1, mean1, rstd1 = ops_raw.instnorm_fwd(emu, xp, rp, act, 0.01, 1e-5)
+    assert torch.equal(y1, y0) and torch.equal(mean1, mean0) and torch.equal(rstd1, rstd0)
+    ymp = _channel_padded(ym, padx + 16) if ym is not None else None
+    dx1, dres1 = ops_raw.instnorm_bwd(emu, xp, gp, mean1, rstd1, ymp, act, 0.01, want_dresidual=with_res)
+    assert torch.equal(dx1, dx0)
     if with_res:
         assert torch.equal(dres1, dres0)
 
@@ -258,6 +260,33 @@ def test_conv3d_chain_padded_channel_stride_emulated(emu):
     out = _channel_padded(torch.zeros_like(ref), 64)
     ops_raw.pointwise_cf(emu, xp.flatten(2), w2, None, out=out)
     assert torch.equal(out, ref)
+
+
+def test_unet_res_block_on_padded_volumes_emulated(emu, monkeypatch):
+    """A UnetResBlock (3x3x3 conv -> IN -> LeakyReLU -> 3x3x3 conv -> IN, 1x1x1 conv -> IN skip, add, LeakyReLU) forward and
+    backward through the library with every volume allocated by volume_empty PADDED (quantum lowered so that the small test
+    volumes qualify, as the 128^3 level does at full size) against the same block on dense volumes: bit-identical"""
+    from segmamba_amd import lib as L, unet_blocks as UB, conv3d as C3
+    monkeypatch.setattr(L, "get_lib", lambda: emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())     # the library's candidates (forward, dgrad, wgrad)
+    torch.manual_seed(3)
+    blk = UB.UnetResBlock(96, 48).bfloat16()
+    g = torch.Generator().manual_seed(9)
+    xa = torch.randn(1, 48, 2, 4, 64, generator=g).bfloat16()
+    xb = torch.randn(1, 48, 2, 4, 64, generator=g).bfloat16()
+    dy = torch.randn(1, 48, 2, 4, 64, generator=g).bfloat16()
+    res = []
+    for quantum in (1 << 20, 1024):                       # 2 * 4 * 64 * 2 B = 1024-byte channels
+        monkeypatch.setattr(ops_raw, "_VOLUME_PAD_QUANTUM", quantum)
+        a, b = xa.clone().requires_grad_(), xb.clone().requires_grad_()
+        blk.zero_grad()
+        y = blk((a, b))
+        assert y.is_contiguous() == (quantum != 1024)
+        y.backward(dy)
+        res.append([y.detach().clone(), a.grad.clone(), b.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
+    for u, v in zip(*res):
+        assert torch.equal(u.contiguous(), v.contiguous())
 
 
 def test_volume_empty_pads_power_of_two_channel_strides():
