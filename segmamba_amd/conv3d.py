@@ -176,12 +176,13 @@ def _wgrad_blocked(x, dy, w, pad):
     return dw
 
 
-def _wgrad_mfma(x, dy, w, pad):
-    """segm_conv3d_k3_wgrad: the hand-written MFMA weight-gradient kernel (csrc/conv3d_wgrad.hip)."""
+def _wgrad_mfma(x, dy, w, pad, out_dtype=None):
+    """segm_conv3d_k3_wgrad: the hand-written MFMA weight-gradient kernel (csrc/conv3d_wgrad.hip); the result in the dtype
+    of the master weight (fp32 under autocast: the kernel's accumulators, not rounded)."""
     from . import lib as L, ops_raw
     if not ops_raw.conv3d_k3_wgrad_supported(x, dy):
         x = x.contiguous()                       # e.g. the permuted (channel-last) outputs of the Mamba encoder
-    return ops_raw.conv3d_k3_wgrad(L.get_lib(), x, dy, w.dtype)
+    return ops_raw.conv3d_k3_wgrad(L.get_lib(), x, dy, out_dtype or w.dtype)
 
 
 def _mfma_wgrad_ok(x, dy, w) -> bool:
@@ -197,9 +198,10 @@ class _ConvSame(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias):
+        from .linear import _masters
+        w, bias = _masters(ctx, x, w, bias)              # fp32 masters -> the step's 16-bit copies; gradients go back in fp32
         pad = w.shape[2] // 2
         ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
         hip = _hip_fwd_ok(x, w)
         chain = hip and _hip_chain_ok(w)
         key = _key("fwd", x, w, hip, chain, _hip_untimed_ok())
@@ -248,10 +250,10 @@ class _ConvSame(torch.autograd.Function):
                 cands.append(lambda: _wgrad_blocked(x, dy, w, pad))
             mfma = _mfma_wgrad_ok(x, dy, w)
             if mfma:
-                cands.append(lambda: _wgrad_mfma(x, dy, w, pad))
-            dw = _pick(_key("wgrad", x, w, mfma), cands)
+                cands.append(lambda: _wgrad_mfma(x, dy, w, pad, ctx.w_dtype))
+            dw = _pick(_key("wgrad", x, w, mfma, ctx.w_dtype), cands).to(ctx.w_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2, 3, 4), dtype=torch.float32).to(dy.dtype)
+            db = dy.sum((0, 2, 3, 4), dtype=torch.float32).to(ctx.b_dtype)
         return dx, dw, db
 
 
@@ -261,11 +263,7 @@ def conv3d_same(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
     if not L.on_device(x):
         return F.conv3d(x, weight, bias, 1, weight.shape[2] // 2)
     if torch.is_autocast_enabled():
-        dt = torch.get_autocast_dtype("cuda")
-        x, weight = x.to(dt), weight.to(dt)
-        bias = bias.to(dt) if bias is not None else None
-    elif weight.dtype != x.dtype:
-        weight = weight.to(x.dtype)
+        x = x.to(torch.get_autocast_dtype("cuda"))       # the weights stay masters: _ConvSame makes its own copies
     return _ConvSame.apply(x, weight, bias)
 
 

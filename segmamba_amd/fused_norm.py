@@ -98,10 +98,11 @@ class _StemConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         from . import lib as L, ops_raw
+        from .linear import _masters
+        w, b = _masters(ctx, x, w, b)                    # fp32 masters -> the step's 16-bit copies; gradients go back in fp32
         x4 = ops_raw.stem_channel_last4(x)
         ctx.use_hip = (_STEM_WGRAD_HIP and not ctx.needs_input_grad[0] and ops_raw.stem_wgrad_supported(x4, w.shape[0]))
         ctx.save_for_backward(x4 if ctx.use_hip else x, w)
-        ctx.has_bias = b is not None
         return ops_raw.stem_conv_fwd(L.get_lib(), x, w, b, x4=x4)
 
     @staticmethod
@@ -110,13 +111,13 @@ class _StemConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         if ctx.use_hip:
             dy = dy.contiguous()
-            dw = ops_raw.stem_conv_wgrad(L.get_lib(), x, dy, w.shape[1]).to(w.dtype) if ctx.needs_input_grad[1] else None
-            db = dy.sum(dim=(0, 2, 3, 4), dtype=torch.float32).to(dy.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            dw = ops_raw.stem_conv_wgrad(L.get_lib(), x, dy, w.shape[1]).to(ctx.w_dtype) if ctx.needs_input_grad[1] else None
+            db = dy.sum(dim=(0, 2, 3, 4), dtype=torch.float32).to(ctx.b_dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
             return None, dw, db
         mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
         dx, dw, db = torch.ops.aten.convolution_backward(dy.contiguous(), x, w, [w.shape[0]] if ctx.has_bias else None, [2, 2, 2],
                                                          [3, 3, 3], [1, 1, 1], False, [0, 0, 0], 1, mask)
-        return dx, dw, db
+        return dx, (dw.to(ctx.w_dtype) if dw is not None else None), (db.to(ctx.b_dtype) if db is not None else None)
 
 
 _STEM_WGRAD_HIP = os.environ.get("SEGM_STEM_WGRAD_HIP", "1") == "1"
@@ -130,7 +131,7 @@ def stem_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
     if _STEM_HIP and L.on_device(x) and ops_raw.stem_conv_supported(x, weight):
         dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
         if dt in (torch.bfloat16, torch.float16):
-            return _StemConv.apply(x.to(dt), weight.to(dt), bias.to(dt) if bias is not None else None)
+            return _StemConv.apply(x.to(dt), weight, bias)             # the weights stay masters
     return F.conv3d(x, weight, bias, stride=2, padding=3)
 
 

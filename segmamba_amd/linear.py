@@ -84,13 +84,22 @@ def nt_matmul_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return acc
 
 
+def _masters(ctx, x, w, b):
+    """the weight / bias of a Function in x's dtype (param_bank.low_precision: the step's 16-bit copy, no autograd edge); the
+    Function returns their gradients in the dtype they came in (fp32 masters: straight from the fp32 accumulators)"""
+    from .param_bank import low_precision
+    ctx.w_dtype, ctx.b_dtype = w.dtype, (b.dtype if b is not None else None)
+    ctx.has_bias = b is not None
+    return low_precision(w, x.dtype), low_precision(b, x.dtype)
+
+
 class _LinearCL(torch.autograd.Function):
-    """y = x W^T + b on a channel-last x (..., Cin); tensors already in the compute dtype."""
+    """y = x W^T + b on a channel-last x (..., Cin) already in the compute dtype; w, b in any dtype (fp32 masters under autocast)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
+        w, b = _masters(ctx, x, w, b)
         ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
         y = _rows_hip(x.reshape(-1, x.shape[-1]), w, b)
         return F.linear(x, w, b) if y is None else y.reshape(*x.shape[:-1], w.shape[0])
 
@@ -103,9 +112,9 @@ class _LinearCL(torch.autograd.Function):
             dx = _rows_hip(dy2, w.t().contiguous(), None)
             dx = (dy2 @ w if dx is None else dx).reshape(x.shape)
         if ctx.needs_input_grad[1]:
-            dw = tn_matmul(dy2, x.reshape(-1, x.shape[-1])).to(w.dtype)
+            dw = tn_matmul(dy2, x.reshape(-1, x.shape[-1])).to(ctx.w_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0, dtype=torch.float32).to(dy.dtype)
+            db = dy2.sum(0, dtype=torch.float32).to(ctx.b_dtype)
         return dx, dw, db
 
 
@@ -130,8 +139,8 @@ class _Pointwise(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
+        w, b = _masters(ctx, x, w, b)
         ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
         y = _pw_hip(w, x, b)                                # bias in the kernel's accumulator initialisation
         if y is None:
             y = _bmm_w(w, x)
@@ -151,16 +160,16 @@ class _Pointwise(torch.autograd.Function):
                 dx = _bmm_w(w.t(), dy)
         if ctx.needs_input_grad[1]:
             if x.stride(2) == 1 and dy.stride(2) == 1:
-                dw = nt_matmul_rows(dy, x).to(w.dtype)
+                dw = nt_matmul_rows(dy, x).to(ctx.w_dtype)
             else:                                                          # channel-last operands: (B*S, C) matrices
                 xs, dys = x.transpose(1, 2), dy.transpose(1, 2)
                 if x.stride(1) != 1:
                     xs = xs.contiguous()
                 if dy.stride(1) != 1:
                     dys = dys.contiguous()
-                dw = sum(tn_matmul(dys[i], xs[i]) for i in range(x.shape[0])).to(w.dtype)
+                dw = sum(tn_matmul(dys[i], xs[i]) for i in range(x.shape[0])).to(ctx.w_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2), dtype=torch.float32).to(dy.dtype)
+            db = dy.sum((0, 2), dtype=torch.float32).to(ctx.b_dtype)
         return dx, dw, db
 
 
@@ -169,7 +178,7 @@ def _compute_dtype(x, *ws):
         dt = torch.get_autocast_dtype("cuda")
     else:
         dt = x.dtype
-    return (x.to(dt),) + tuple(w.to(dt) if w is not None else None for w in ws)
+    return (x.to(dt),) + ws                                 # the weights stay masters: the Functions make their own copies
 
 
 def linear_cl(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:

@@ -144,8 +144,9 @@ class MambaInnerCore(torch.autograd.Function):
         lib = L.get_lib()
         if torch.is_autocast_enabled():
             act_dtype = torch.get_autocast_dtype("cuda")
-            x_proj_weight = x_proj_weight.to(dtype=act_dtype)
-            delta_proj_weight = delta_proj_weight.to(dtype=act_dtype)
+            from .param_bank import low_precision
+            x_proj_weight = low_precision(x_proj_weight, act_dtype)
+            delta_proj_weight = low_precision(delta_proj_weight, act_dtype)
         cdim = 2 if channel_last else 1
         if (xz.stride(1) if channel_last else xz.stride(2)) != 1 and xz.stride(cdim) != 1:
             xz = xz.contiguous()

@@ -69,6 +69,7 @@ class TrainingState:
     clip: float = 12.0
     step: int = 0
     scaler: object = None          # torch.amp.GradScaler when autocast_dtype is fp16 (reference trainer.py:65-67)
+    bank: object = None            # param_bank.ParamBank: the step's 16-bit parameter copies, one launch per group
 
 
 def build_training_state(device, distributed: bool = False, local_rank: int = 0, max_steps: int = 250 * 1000,
@@ -81,6 +82,13 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
     model = model.to(device)
     if os.environ.get("SEGM_CHANNELS_LAST_3D", "0") == "1":     # experiment switch: NDHWC activations / weights
         model = model.to(memory_format=torch.channels_last_3d)
+    from . import lib as L
+    bank = None
+    if L.on_device(next(model.parameters())) and os.environ.get("SEGM_PARAM_BANK", "1") == "1":
+        # the autocast copies of the weights (and the fp32 copies of their gradients) in one launch per top-level module
+        # instead of one per parameter (param_bank.py); built before DDP looks at the parameters
+        from .param_bank import ParamBank
+        bank = ParamBank(model, torch.float16 if amp == "fp16" else torch.bfloat16)
     if distributed:
         # The reference passes find_unused_parameters=True (trainer.py:354-357); every SegMamba parameter takes part in
         # every step (DDP itself reports "did not find any unused parameters"), so the extra per-step graph traversal
@@ -90,7 +98,6 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
         model = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[local_rank] if device.type == "cuda" else None,
             **DDP_SETTINGS)
-    from . import lib as L
     fused = L.on_device(next(model.parameters())) and os.environ.get("SEGM_FUSED_TRAIN_OPS", "1") != "0"
     if fused:
         # clip_grad_norm_(12) + SGD step as two passes of the library's multi-tensor kernels, cross entropy with its
@@ -102,7 +109,7 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
         opt = torch.optim.SGD(model.parameters(), lr=1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
         loss_fn = nn.CrossEntropyLoss()
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: (1 - min(s, max_steps - 1) / max_steps) ** 0.9)
-    st = TrainingState(model=model, optimizer=opt, scheduler=sched, loss_fn=loss_fn)
+    st = TrainingState(model=model, optimizer=opt, scheduler=sched, loss_fn=loss_fn, bank=bank)
     if amp == "fp16":
         st.autocast_dtype = torch.float16
         st.scaler = torch.amp.GradScaler(device.type)     # the reference's GradScaler() defaults: 2^16, x2 / 2000 steps, x0.5 on inf
@@ -110,6 +117,13 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
 
 
 def train_step(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    if st.bank is None:
+        return _train_step(st, image, label)
+    with st.bank.step():                                           # forward and backward see one set of 16-bit parameter copies
+        return _train_step(st, image, label)
+
+
+def _train_step(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
     for p in st.model.parameters():
         p.grad = None                                              # trainer.py:445
     with torch.autocast(image.device.type, dtype=st.autocast_dtype,

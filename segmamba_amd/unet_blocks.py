@@ -72,13 +72,14 @@ class ConvOnly(nn.Sequential):
     def forward(self, x) -> torch.Tensor:
         """`x` may be a tuple of tensors standing for their channel concatenation (never materialised)."""
         if isinstance(x, (tuple, list)):
+            weight = self.conv.weight                    # sliced per part: the Functions copy the slices they are given
             if self._same and self.conv.bias is None:
-                return conv3d_same_cat(tuple(x), self.conv.weight)
+                return conv3d_same_cat(tuple(x), weight)
             if self._pointwise:
                 out, c0 = None, 0
                 for part in x:
                     c = part.shape[1]
-                    y = fused_norm.pointwise_conv3d(part, self.conv.weight[:, c0:c0 + c],
+                    y = fused_norm.pointwise_conv3d(part, weight[:, c0:c0 + c],
                                                     self.conv.bias if c0 == 0 else None)
                     out = y if out is None else out + y
                     c0 += c

@@ -91,3 +91,70 @@ def test_synthetic_feeder_with_augmentation():
     data = SyntheticBraTS(1, 8, torch.device("cpu"), seed=42, augment=True)
     a, b = data.next(), data.next()
     assert a[0].shape == (1, 4, 8, 8, 8) and a[1].shape == (1, 8, 8, 8) and b[0].shape == a[0].shape
+
+
+def test_param_bank_hands_out_views_of_one_converted_buffer():
+    """param_bank.ParamBank: the parameters become views of one flat fp32 buffer (state_dict unchanged); inside `bank.step()`
+    `low_precision` returns pieces of ONE 16-bit buffer converted on entry - for a parameter and for any view of it (reshaped,
+    transposed, channel-sliced weights) - without an autograd edge; outside it is a plain cast; after an in-place parameter
+    update the next step sees the new values"""
+    from segmamba_amd.param_bank import ParamBank, low_precision
+    torch.manual_seed(0)
+    m = nn.Sequential(nn.Linear(5, 3), nn.Conv3d(4, 6, 3))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    bank = ParamBank(m, torch.bfloat16)
+    assert list(m.state_dict()) == list(before) and all(torch.equal(m.state_dict()[k], v) for k, v in before.items())
+    w = m[1].weight                                            # NOT the first parameter of the flat buffer
+    assert w.is_leaf and w.requires_grad and w.data_ptr() == bank.flat32.data_ptr() + 4 * (16 + 8)
+    plain = low_precision(w, torch.bfloat16)
+    assert plain.dtype == torch.bfloat16 and not plain.requires_grad
+    assert not bank.flat16.data_ptr() <= plain.data_ptr() < bank.flat16.data_ptr() + 2 * bank.flat16.numel()
+    with bank.step():
+        a = low_precision(w, torch.bfloat16)
+        assert a.data_ptr() == bank.flat16.data_ptr() + 2 * (16 + 8) and not a.requires_grad and torch.equal(a, w.detach().bfloat16())
+        for view in (w.reshape(6, -1), w.reshape(6, -1).t(), w[:, 1:3], w[2:4, :, 1]):
+            v = low_precision(view, torch.bfloat16)
+            assert torch.equal(v, view.detach().bfloat16())
+            assert bank.flat16.data_ptr() <= v.data_ptr() < bank.flat16.data_ptr() + 2 * bank.flat16.numel()       # no copy
+        f = low_precision(w.flip(2), torch.bfloat16)                     # not a view of the parameter: a plain cast
+        assert torch.equal(f, w.detach().flip(2).bfloat16())
+        assert torch.equal(low_precision(m[0].bias, torch.bfloat16), m[0].bias.detach().bfloat16())
+        assert low_precision(w, torch.float16).dtype == torch.float16    # not the bank's dtype: a plain cast
+        assert low_precision(None, torch.bfloat16) is None
+    with torch.no_grad():
+        w.mul_(2.0)
+    stale = low_precision(w, torch.bfloat16)                                         # stale copies are not handed out
+    assert not bank.flat16.data_ptr() <= stale.data_ptr() < bank.flat16.data_ptr() + 2 * bank.flat16.numel()
+    with bank.step():
+        assert torch.equal(low_precision(w, torch.bfloat16), w.detach().bfloat16())
+
+
+def test_functions_take_fp32_masters_and_return_fp32_gradients():
+    """linear.linear_cl / linear.pointwise Functions with fp32 weights and 16-bit activations (what autocast hands them): the
+    output equals the per-parameter-cast route and the weight / bias gradients come back in fp32 (no cast-back launch), with and
+    without the bank"""
+    from segmamba_amd import linear as LN
+    from segmamba_amd.param_bank import ParamBank
+    g = torch.Generator().manual_seed(4)
+    lin = nn.Linear(16, 8)
+    x = torch.randn(2, 40, 16, generator=g).bfloat16()
+    dy = torch.randn(2, 40, 8, generator=g).bfloat16()
+    ref_w = lin.weight.detach().bfloat16().float().requires_grad_()
+    ref_b = lin.bias.detach().bfloat16().float().requires_grad_()
+    ref = torch.nn.functional.linear(x.float(), ref_w, ref_b)
+    ref.backward(dy.float())
+    bank = ParamBank(lin, torch.bfloat16)
+    for use_bank in (False, True):
+        lin.zero_grad()
+        if use_bank:
+            with bank.step():
+                y = LN._LinearCL.apply(x, lin.weight, lin.bias)
+                y.backward(dy)
+        else:
+            y = LN._LinearCL.apply(x, lin.weight, lin.bias)
+            y.backward(dy)
+        assert y.dtype == torch.bfloat16 and (y.float() - ref).abs().max() <= 2e-2 * float(ref.abs().max())
+        assert lin.weight.grad.dtype == torch.float32 and lin.bias.grad.dtype == torch.float32
+        # (a short contraction like this one is a single 16-bit GEMM; the split-K route of tall operands keeps fp32 partial sums)
+        assert (lin.weight.grad - ref_w.grad).abs().max() <= 1e-2 * float(ref_w.grad.abs().max())
+        assert (lin.bias.grad - ref_b.grad).abs().max() <= 1e-4 * float(ref_b.grad.abs().max())     # fp32 reduction
