@@ -530,6 +530,34 @@ typedef struct segm_stem_wgrad_args {
 size_t segm_stem_conv_wgrad_workspace_bytes(int32_t batch, int32_t cout, int32_t din, int32_t hin);
 int segm_stem_conv_wgrad(const segm_stem_wgrad_args* args);
 
+/* ------------------------------------------------------------------------------------------------
+ * Weight gradients of the projections: out (m, n) fp32 = sum_k a[k][.] b[k][.] over a long k (tokens / voxels).
+ * The reference gets them from autograd -> cuBLAS: dW of in_proj / out_proj / x_proj / dt_proj
+ * (mamba/mamba_ssm/modules/mamba_simple.py:204-208,264; ops/selective_scan_interface.py:272-276) and of the 1x1x1
+ * convolutions (monai/networks/blocks/dynunet_block.py:72-96,247-263).
+ *   SEGM_WGEMM_TN  a (k, m), b (k, n) row-major, row strides a_stride_row / b_stride_row (elements; any alignment: rows that are
+ *                  not 16-byte aligned take 2-byte loads); batch strides ignored; m, n <= 1024
+ *   SEGM_WGEMM_NT  a (batch, m, k), b (batch, n, k), unit stride along k, k % 32 == 0, strides % 8 == 0, 16-byte aligned;
+ *                  out = sum over the batch of a[i] b[i]^T; m, n <= 96
+ * 16-bit operands, fp32 accumulation, per-wave partial sums in the workspace added in a fixed order (bitwise repeatable).
+ * ------------------------------------------------------------------------------------------------ */
+enum segm_wgemm_layout { SEGM_WGEMM_TN = 0, SEGM_WGEMM_NT = 1 };
+
+typedef struct segm_wgrad_gemm_args {
+    int32_t layout, dtype;
+    int32_t m, n;
+    int64_t k;
+    int32_t batch, reserved;
+    const void* a;  int64_t a_stride_row, a_stride_batch;
+    const void* b;  int64_t b_stride_row, b_stride_batch;
+    float* out;
+    void* workspace;    size_t workspace_bytes;
+    void* stream;
+} segm_wgrad_gemm_args;
+
+size_t segm_wgrad_gemm_workspace_bytes(int32_t layout, int32_t m, int32_t n, int64_t k, int32_t batch);
+int segm_wgrad_gemm(const segm_wgrad_gemm_args* args);
+
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);
 const char* segm_status_string(int status);

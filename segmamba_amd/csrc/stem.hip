@@ -265,14 +265,8 @@ __global__ void __launch_bounds__(kStemWaves * 64) stem_conv_wgrad_kernel(StemWg
                     pp[((int64_t)ky * P.cout16 + 16 * mt + 4 * g + r) * 32 + 16 * jt + i16] = acc[ky][mt][jt][r];
 }
 
-// dwp[n] = sum over slabs of part[slab][n], slabs added in order
-__global__ void __launch_bounds__(256) stem_wgrad_reduce_kernel(const float* __restrict__ part, int slabs, int64_t n, float* __restrict__ dwp) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float acc = 0.f;
-    for (int s = 0; s < slabs; ++s) acc += part[(int64_t)s * n + i];
-    dwp[i] = acc;
-}
+// dwp[n] = sum over slabs of part[slab][n], slabs added in a fixed order (wgrad_gemm.hip)
+void launch_partial_sum(const float* part, int parts, int64_t n, float* out, hipStream_t stream);
 
 }  // namespace segm
 
@@ -334,6 +328,6 @@ extern "C" int segm_stem_conv_wgrad(const segm_stem_wgrad_args* a) {
     if (a->dtype == SEGM_F16) { SEGM_STEM_WG(f16_t) } else { SEGM_STEM_WG(bf16_t) }
 #undef SEGM_STEM_WG
     const int64_t n = (int64_t)kStemK * kStemK * P.cout16 * 32;
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P.part, P.slabs, n, a->dw_packed);
+    launch_partial_sum(P.part, P.slabs, n, a->dw_packed, st);
     return (int)hipGetLastError();
 }

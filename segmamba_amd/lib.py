@@ -212,6 +212,16 @@ class StemWgradArgs(C.Structure):
     ]
 
 
+class WgradGemmArgs(C.Structure):
+    _fields_ = [
+        ("layout", C.c_int32), ("dtype", C.c_int32), ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int64),
+        ("batch", C.c_int32), ("reserved", C.c_int32),
+        ("a", C.c_void_p), ("a_stride_row", C.c_int64), ("a_stride_batch", C.c_int64),
+        ("b", C.c_void_p), ("b_stride_row", C.c_int64), ("b_stride_batch", C.c_int64),
+        ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+    ]
+
+
 class TransposeArgs(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("dtype", C.c_int32),
@@ -228,7 +238,7 @@ EXPORTS = (
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
     "segm_causal_conv1d_update", "segm_selective_state_update", "segm_linear_rows", "segm_pointwise_cf", "segm_stem_conv_fwd",
-    "segm_stem_conv_wgrad", "segm_stem_conv_wgrad_workspace_bytes",
+    "segm_stem_conv_wgrad", "segm_stem_conv_wgrad_workspace_bytes", "segm_wgrad_gemm", "segm_wgrad_gemm_workspace_bytes",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -277,6 +287,8 @@ class SegmLib:
         sig("segm_stem_conv_fwd", [C.POINTER(StemArgs)], C.c_int)
         sig("segm_stem_conv_wgrad", [C.POINTER(StemWgradArgs)], C.c_int)
         sig("segm_stem_conv_wgrad_workspace_bytes", [C.c_int32] * 4, C.c_size_t)
+        sig("segm_wgrad_gemm", [C.POINTER(WgradGemmArgs)], C.c_int)
+        sig("segm_wgrad_gemm_workspace_bytes", [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32], C.c_size_t)
         sig("segm_abi_version", [], C.c_int)
         sig("segm_status_string", [C.c_int], C.c_char_p)
 

@@ -31,6 +31,12 @@ _ROWS_MIN = 32768     # rows below which the BLAS call stays
 # adds the bias in a further pass; SEGM_POINTWISE_HIP=0 restores it.
 _PW_HIP = os.environ.get("SEGM_POINTWISE_HIP", "1") == "1"
 _PW_MIN = 32768       # voxels per channel below which the BLAS call stays
+# The weight gradients of the 1x1x1 convolutions on channel-first volumes through csrc/wgrad_gemm.hip (layout NT: 135 - 270 us
+# against 205 - 310 us for slab-batched BLAS GEMMs + a sum at 128^3, profiles/r02_wgrad_gemm_time.log); SEGM_WGRAD_GEMM_HIP=0
+# restores those.  The token-major layout (TN: the Mamba projections) stays on the BLAS slabs, which stream at 3 - 3.9 TB/s
+# where the library's LDS-gather kernel reaches 1.1 - 2.6; SEGM_WGRAD_GEMM_TN=1 switches it on (measurements, tests).
+_WG_HIP = os.environ.get("SEGM_WGRAD_GEMM_HIP", "1") == "1"
+_WG_TN = os.environ.get("SEGM_WGRAD_GEMM_TN", "0") == "1"
 
 
 def _on_device(t: torch.Tensor) -> bool:
@@ -62,6 +68,10 @@ def tn_matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a^T b for tall operands a (K, M), b (K, N), K >> M, N; fp32 result.  Row slices / column slices of larger
     matrices are fine (only views are taken)."""
     K = a.shape[0]
+    if _WG_HIP and _WG_TN and K >= _MIN_K and _on_device(a):
+        from . import lib as L, ops_raw
+        if ops_raw.wgrad_gemm_tn_supported(a, b):
+            return ops_raw.wgrad_gemm(L.get_lib(), a, b, ops_raw.WGEMM_TN)
     s = _split(K) if (_on_device(a) or _FORCE_SPLIT) else 1
     if s == 1:
         return (a.t() @ b).float()
@@ -72,6 +82,10 @@ def tn_matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 def nt_matmul_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """sum over the batch of a[i] b[i]^T for wide operands a (B, M, K), b (B, N, K) with unit stride along K; fp32."""
     B, M, K = a.shape
+    if _WG_HIP and K >= _MIN_K and _on_device(a):
+        from . import lib as L, ops_raw
+        if ops_raw.wgrad_gemm_nt_supported(a, b):
+            return ops_raw.wgrad_gemm(L.get_lib(), a, b, ops_raw.WGEMM_NT)
     s = _split(K) if (_on_device(a) or _FORCE_SPLIT) else 1
     if s == 1 or a.stride(2) != 1 or b.stride(2) != 1:
         return torch.matmul(a, b.transpose(1, 2)).sum(0, dtype=torch.float32)

@@ -772,6 +772,50 @@ def stem_conv_wgrad(lib: L.SegmLib, x4: torch.Tensor, dy: torch.Tensor, cin: int
     return dwp[:, :, :cout, :7, :cin].permute(2, 4, 0, 1, 3).contiguous()
 
 
+WGEMM_TN, WGEMM_NT = 0, 1
+
+
+def wgrad_gemm_tn_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """a (K, M), b (K, N): 16-bit, same dtype, unit column stride, M, N <= 1024"""
+    return bool(a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.dtype == b.dtype
+                and a.dtype in (torch.bfloat16, torch.float16) and a.stride(1) == 1 and b.stride(1) == 1
+                and a.shape[1] <= 1024 and b.shape[1] <= 1024 and a.stride(0) >= a.shape[1] and b.stride(0) >= b.shape[1])
+
+
+def wgrad_gemm_nt_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """a (B, M, K), b (B, N, K): 16-bit, same dtype, unit stride along K, K % 32 == 0, M, N <= 96, 16-byte aligned rows"""
+    return bool(a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.shape[2] == b.shape[2] and a.dtype == b.dtype
+                and a.dtype in (torch.bfloat16, torch.float16) and a.stride(2) == 1 and b.stride(2) == 1 and a.shape[2] % 32 == 0
+                and a.shape[1] <= 96 and b.shape[1] <= 96 and not any(t.stride(i) % 8 for t in (a, b) for i in (0, 1))
+                and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
+def wgrad_gemm(lib: L.SegmLib, a: torch.Tensor, b: torch.Tensor, layout: int) -> torch.Tensor:
+    """fp32 (M, N): a^T b for a (K, M), b (K, N) (WGEMM_TN), or sum_i a[i] b[i]^T for a (B, M, K), b (B, N, K) (WGEMM_NT)"""
+    if layout == WGEMM_TN:
+        if not wgrad_gemm_tn_supported(a, b):
+            raise RuntimeError("wgrad_gemm TN: a (K, M), b (K, N) 16-bit with unit column stride, M, N <= 1024")
+        K, M = a.shape
+        N, batch = b.shape[1], 1
+        strides = (a.stride(0), 0, b.stride(0), 0)
+    else:
+        if not wgrad_gemm_nt_supported(a, b):
+            raise RuntimeError("wgrad_gemm NT: a (B, M, K), b (B, N, K) 16-bit, unit stride along K % 32 == 0, M, N <= 96, 16-byte aligned rows")
+        batch, M, K = a.shape
+        N = b.shape[1]
+        strides = (a.stride(1), a.stride(0), b.stride(1), b.stride(0))
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    nbytes = lib.dll.segm_wgrad_gemm_workspace_bytes(layout, M, N, K, batch)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+    g = L.WgradGemmArgs()
+    g.layout, g.dtype, g.m, g.n, g.k, g.batch = layout, L.dtype_code(a), M, N, K, batch
+    g.a, g.a_stride_row, g.a_stride_batch = a.data_ptr(), strides[0], strides[1]
+    g.b, g.b_stride_row, g.b_stride_batch = b.data_ptr(), strides[2], strides[3]
+    g.out, g.workspace, g.workspace_bytes, g.stream = out.data_ptr(), ws.data_ptr(), nbytes, L.stream_handle(a)
+    lib.check(lib.dll.segm_wgrad_gemm(g), "wgrad_gemm")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 # device guard
 # ---------------------------------------------------------------------------------------------------------
@@ -804,5 +848,5 @@ def _device_guard(fn):
 
 for _name in ("scan_fwd", "scan_bwd", "conv1d_fwd", "conv1d_bwd", "conv3d_k3_wgrad", "conv3d_k3_fwd", "instnorm_fwd",
               "instnorm_bwd", "transpose_add", "layernorm_tokens_fwd", "layernorm_tokens_bwd", "sgd_clip_step", "cross_entropy",
-              "conv1d_update", "state_update", "linear_rows", "pointwise_cf", "stem_conv_fwd", "stem_conv_wgrad"):
+              "conv1d_update", "state_update", "linear_rows", "pointwise_cf", "stem_conv_fwd", "stem_conv_wgrad", "wgrad_gemm"):
     globals()[_name] = _device_guard(globals()[_name])

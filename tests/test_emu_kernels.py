@@ -995,3 +995,72 @@ def test_stem_conv_wgrad_emulated(emu, B, Cin, Cout, D, H, W, dtype):
     assert dw.shape == w.grad.shape and dw.dtype == torch.float32
     assert (dw - w.grad).abs().max() <= 1e-3 * max(1.0, float(w.grad.abs().max()))
     assert torch.equal(dw, ops_raw.stem_conv_wgrad(emu, x4, dy, Cin))                        # fixed summation order
+
+
+@pytest.mark.parametrize("K,M,N,dtype,lda,ldb", [
+    (4096, 192, 48, torch.bfloat16, None, None),        # in_proj at stage 0: three column blocks of a, aligned rows
+    (1000, 35, 96, torch.bfloat16, None, None),         # x_proj: 35-column rows (2-byte loads for a), k tail (1000 = 31 * 32 + 8)
+    (640, 96, 3, torch.float16, None, 35),              # dt_proj: b = the first 3 columns of the 35-column x_dbl
+    (2048, 72, 200, torch.bfloat16, 80, 208),           # padded row strides, column blocks of b (96 + 96 + 8), m tail tile
+    (96, 8, 8, torch.bfloat16, None, None),             # fewer chunks than waves
+])
+def test_wgrad_gemm_tn_emulated(emu, K, M, N, dtype, lda, ldb):
+    """segm_wgrad_gemm, layout TN (a^T b for token-major operands: the Mamba projections' weight gradients): LDS-staged 32-row
+    tiles, fragments gathered column-wise, per-wave partials added in order - against the fp32 product of the same 16-bit
+    operands; bitwise repeatable"""
+    g = torch.Generator().manual_seed(K + M + N)
+    A = torch.randn(K, lda or M, generator=g).to(dtype)
+    B = torch.randn(K, ldb or N, generator=g).to(dtype)
+    a, b = A[:, :M], B[:, :N]
+    assert ops_raw.wgrad_gemm_tn_supported(a, b)
+    out = ops_raw.wgrad_gemm(emu, a, b, ops_raw.WGEMM_TN)
+    ref = a.float().t() @ b.float()
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    assert (out - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(out, ops_raw.wgrad_gemm(emu, a, b, ops_raw.WGEMM_TN))
+
+
+@pytest.mark.parametrize("Bn,M,N,K,dtype", [(2, 48, 48, 2048, torch.bfloat16), (1, 4, 48, 512, torch.bfloat16), (2, 48, 4, 256, torch.float16),
+                                           (1, 96, 96, 1024, torch.bfloat16), (3, 40, 20, 96, torch.bfloat16)])
+def test_wgrad_gemm_nt_emulated(emu, Bn, M, N, K, dtype):
+    """segm_wgrad_gemm, layout NT (sum over the batch of a[i] b[i]^T for channel-first volumes: the 1x1x1 convolutions' weight
+    gradients): operand fragments straight from memory; channel slices of wider tensors as operands"""
+    g = torch.Generator().manual_seed(Bn + M + N + K)
+    A = torch.randn(Bn, M + 8, K, generator=g).to(dtype)
+    Bm = torch.randn(Bn, N, K, generator=g).to(dtype)
+    a = A[:, 8:]                                                            # a channel slice: batch stride != M * K
+    assert ops_raw.wgrad_gemm_nt_supported(a, Bm)
+    out = ops_raw.wgrad_gemm(emu, a, Bm, ops_raw.WGEMM_NT)
+    ref = torch.einsum("bmk,bnk->mn", a.float(), Bm.float())
+    assert out.shape == ref.shape and (out - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(out, ops_raw.wgrad_gemm(emu, a, Bm, ops_raw.WGEMM_NT))
+
+
+def test_pointwise_weight_gradient_takes_the_library_gemm(emu, monkeypatch):
+    """linear.pointwise's backward on channel-first activations: dW through segm_wgrad_gemm (layout NT) when the voxel count
+    reaches the split threshold (lowered here), dx through segm_pointwise_cf - against autograd of the fp32 expression"""
+    from segmamba_amd import lib as L, linear as LN
+    monkeypatch.setattr(L, "get_lib", lambda: emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    monkeypatch.setattr(LN, "_MIN_K", 64)
+    monkeypatch.setattr(LN, "_PW_MIN", 64)
+    calls = []
+    real = ops_raw.wgrad_gemm
+    monkeypatch.setattr(ops_raw, "wgrad_gemm", lambda *a, **k: (calls.append(a[3]), real(*a, **k))[1])
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 48, 4, 4, 8, generator=g).bfloat16().requires_grad_()
+    w = (0.2 * torch.randn(32, 48, generator=g)).requires_grad_()             # an fp32 master weight
+    b = torch.randn(32, generator=g).requires_grad_()
+    dy = torch.randn(2, 32, 4, 4, 8, generator=g).bfloat16()
+    y = LN.pointwise(x, w, b)
+    y.backward(dy)
+    assert calls == [ops_raw.WGEMM_NT]
+    xr = x.detach().float().requires_grad_()
+    wr = w.detach().bfloat16().float().requires_grad_()
+    br = b.detach().bfloat16().float().requires_grad_()
+    ref = torch.einsum("oc,bcdhw->bodhw", wr, xr) + br.view(1, -1, 1, 1, 1)
+    ref.backward(dy.float())
+    assert (y.float() - ref).abs().max() <= 2e-2 * float(ref.abs().max())
+    assert w.grad.dtype == torch.float32 and (w.grad - wr.grad).abs().max() <= 1e-4 * float(wr.grad.abs().max())
+    assert b.grad.dtype == torch.float32 and (b.grad - br.grad).abs().max() <= 1e-4 * float(br.grad.abs().max())
+    assert (x.grad.float() - xr.grad).abs().max() <= 2e-2 * float(xr.grad.abs().max())

@@ -643,3 +643,31 @@ def test_stem_conv_wgrad_matches_autograd(B, Cin, Cout, size, dtype):
     torch.nn.functional.conv3d(x.float(), w, None, stride=2, padding=3).backward(dy.float())
     assert (dw - w.grad).abs().max() <= 1e-3 * float(w.grad.abs().max())
     assert torch.equal(dw, ops_raw.stem_conv_wgrad(hip, x4, dy, Cin))
+
+
+@pytest.mark.parametrize("K,M,N,lda,ldb", [(524288, 192, 48, 192, 48), (524288, 35, 96, 35, 96), (65536, 192, 6, 192, 38), (70001, 100, 130, 104, 136)])
+def test_wgrad_gemm_tn_matches_fp32_product(K, M, N, lda, ldb):
+    """segm_wgrad_gemm (TN) at the stage-0 / stage-1 token counts against the fp64-accumulated product of the same bf16 operands
+    (K up to 524 288 terms per entry: 1e-3 of the largest entry), bitwise repeatable"""
+    hip = L.get_lib()
+    g = torch.Generator(device=DEV).manual_seed(K % 1000 + M)
+    a = torch.randn(K, lda, device=DEV, generator=g).bfloat16()[:, :M]
+    b = torch.randn(K, ldb, device=DEV, generator=g).bfloat16()[:, :N]
+    out = ops_raw.wgrad_gemm(hip, a, b, ops_raw.WGEMM_TN)
+    ref = (a.double().t() @ b.double()).float()
+    assert (out - ref).abs().max() <= 1e-3 * float(ref.abs().max())
+    assert torch.equal(out, ops_raw.wgrad_gemm(hip, a, b, ops_raw.WGEMM_TN))
+
+
+@pytest.mark.parametrize("Bn,M,N,K", [(2, 48, 48, 128 ** 3), (2, 4, 48, 128 ** 3), (2, 96, 96, 64 ** 3)])
+def test_wgrad_gemm_nt_matches_fp32_product(Bn, M, N, K):
+    """segm_wgrad_gemm (NT) on channel-first volumes of the BASELINE size (padded channel stride as the convolutions write them)"""
+    hip = L.get_lib()
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    a = ops_raw.volume_empty(Bn, M, (K,), torch.bfloat16, DEV)
+    a.copy_(torch.randn(Bn, M, K, device=DEV, generator=g))
+    b = torch.randn(Bn, N, K, device=DEV, generator=g).bfloat16()
+    out = ops_raw.wgrad_gemm(hip, a, b, ops_raw.WGEMM_NT)
+    ref = torch.einsum("bmk,bnk->mn", a.double(), b.double()).float()
+    assert (out - ref).abs().max() <= 1e-3 * float(ref.abs().max())
+    assert torch.equal(out, ops_raw.wgrad_gemm(hip, a, b, ops_raw.WGEMM_NT))

@@ -303,6 +303,26 @@ def test_argument_errors_of_the_newer_entry_points_without_gpu(built_lib):
     m.dtype = lib.SEGM_BF16
     assert d.segm_stem_conv_fwd(m) == -1                   # NULL tensors
 
+    q = lib.WgradGemmArgs()
+    q.layout, q.dtype, q.m, q.n, q.k, q.batch = 2, lib.SEGM_BF16, 48, 48, 4096, 1
+    assert d.segm_wgrad_gemm(q) == -2                      # unknown layout
+    q.layout, q.m = 1, 128
+    assert d.segm_wgrad_gemm(q) == -2                      # NT: m, n <= 96
+    q.m, q.k = 48, 4100
+    assert d.segm_wgrad_gemm(q) == -2                      # NT: k % 32 == 0
+    q.k, q.dtype = 4096, lib.SEGM_F32
+    assert d.segm_wgrad_gemm(q) == -4
+    q.dtype, q.layout = lib.SEGM_BF16, 0
+    q.a_stride_row, q.b_stride_row = 40, 48
+    assert d.segm_wgrad_gemm(q) == -2                      # TN: a row shorter than m
+    q.a_stride_row = 48
+    assert d.segm_wgrad_gemm(q) == -1                      # NULL tensors
+    q.a = q.b = q.out = p16
+    need = d.segm_wgrad_gemm_workspace_bytes(0, 48, 48, 4096, 1)
+    assert need > 0 and need % (48 * 48 * 4) == 0          # whole per-wave partials
+    q.workspace, q.workspace_bytes = p16, need - 1
+    assert d.segm_wgrad_gemm(q) == -6                      # workspace too small
+
     g = lib.StemWgradArgs()
     g.batch, g.cout, g.din, g.hin, g.win, g.dtype = 1, 48, 4, 4, 96, lib.SEGM_BF16
     assert d.segm_stem_conv_wgrad(g) == -2                 # rows of 1, 2 or 4 k-steps: width 64, 128 or 256
