@@ -61,20 +61,6 @@ struct ConvFwdDev {
 
 // four consecutive outputs of one lane: convert and store, optionally on top of what y holds (a later 48-channel block
 // of a wider layer)
-// Workgroups are handed to the 8 XCDs round robin (workgroup i -> XCD i % 8), each XCD with its own L2.  Work items that are
-// neighbours in z read the same input rows (every row is staged by the three planes around it), so consecutive items should
-// meet in ONE L2: XCD k takes the k-th contiguous eighth of the item range.  Without this every row is fetched from HBM /
-// Infinity Cache by three different L2s.
-__device__ __forceinline__ int xcd_item(int bid, int nitems) {
-#ifdef SEGM_NO_XCD_MAP
-    return bid;
-#else
-    const int per = nitems >> 3;
-    if ((nitems & 7) != 0 || per == 0) return bid;
-    return (bid & 7) * per + (bid >> 3);
-#endif
-}
-
 template <typename T, bool ACC>
 __device__ __forceinline__ void store4(T* dst, const float (&v)[4]) {
     u32x2 pk;

@@ -27,7 +27,7 @@
 //               read plus two halo dwords with v_alignbyte.  Zero padding in x / y / z is materialised as zero rows /
 //               columns in LDS, so the inner loop has no masks.  Row pitch 88 elements (44 dwords): the 16 lanes of a
 //               fragment read hit 16 distinct 4-bank groups.
-//   grid      = (work items, 3 kz x co blocks of 48, ci blocks of 48); every workgroup writes its 9 x 48 x 48 partial
+//   grid      = (co blocks of 48 x work items x 3 kz in an XCD-aware order, ci blocks of 48); every workgroup writes its 9 x 48 x 48 partial
 //               taps; a second kernel sums the work items in a fixed order (deterministic, no atomics) and converts
 //               to the weight dtype.
 // v_mfma_f32_16x16x32_bf16 operand layout (cdna_hip_programming.md §3): lane l holds A[i = l & 15][k = 8 (l >> 4) .. +7],
@@ -73,8 +73,13 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
     const int tid = threadIdx.x, lane = tid & 63;
     const int ky = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: row / tap arithmetic stays on the SALU
     const int i16 = lane & 15, g = lane >> 4;
-    const int kz = blockIdx.y % 3, cob = blockIdx.y / 3, cib = blockIdx.z;
-    int item = blockIdx.x;
+    // blockIdx.x runs over (co block, item, kz) with kz fastest, re-ordered so that every XCD owns a contiguous range: the three
+    // tap planes of an item read the same dY rows, items that are neighbours in z the same X rows - one L2 fetches them once
+    // (before: the kz planes were grid rows, dispatched thousands of workgroups apart: X and dY came from HBM three times)
+    const int vid = xcd_item(blockIdx.x, gridDim.x);
+    const int kz = vid % 3, cib = blockIdx.y;
+    const int item_id = (vid / 3) % P.nitems, cob = vid / (3 * P.nitems);
+    int item = item_id;
     const int ypart = item % P.ysplit;  item /= P.ysplit;
     const int xb = item % P.nxb;        item /= P.nxb;
     const int z = item % P.D, b = item / P.D;
@@ -194,7 +199,7 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
         }
     }
     // partial block: part[((cob * ncib + cib) * nitems + item)][tap = kz*9 + ky*3 + kx][co (32)][ci (48)]
-    float* out = P.part + ((((int64_t)cob * P.ncib + cib) * P.nitems + blockIdx.x) * 27) * (kWgCo * kWgBlock);
+    float* out = P.part + ((((int64_t)cob * P.ncib + cib) * P.nitems + item_id) * 27) * (kWgCo * kWgBlock);
 #pragma unroll
     for (int ct = 0; ct < NCO; ++ct)
 #pragma unroll
@@ -290,7 +295,7 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
     P.ncob = (a->cout + kWgCo - 1) / kWgCo; P.ncib = (a->cin + kWgBlock - 1) / kWgBlock;
     hipStream_t stream = (hipStream_t)a->stream;
     {
-        const dim3 grid(P.nitems, P.ncob * 3, P.ncib);
+        const dim3 grid(P.nitems * 3 * P.ncob, P.ncib);
         if (a->dtype == SEGM_F16) {
             if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 2>), grid, dim3(kWgThreads), 0, stream, P);
             else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 1>), grid, dim3(kWgThreads), 0, stream, P);

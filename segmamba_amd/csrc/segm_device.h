@@ -61,6 +61,21 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, t2));
 }
 
+// ---- XCD-aware work item order (conv3d_fwd.hip, conv3d_wgrad.hip) -----------------------------------------------------
+// Workgroups are handed to the 8 XCDs round robin (workgroup i -> XCD i % 8), each XCD with its own L2.  Work items that are
+// neighbours in z read the same input rows (the convolution kernels stage every row for the three planes around it), so
+// consecutive items should meet in ONE L2: XCD k takes the k-th contiguous eighth of the item range.  Without this every row is fetched from HBM /
+// Infinity Cache by three different L2s.
+__device__ __forceinline__ int xcd_item(int bid, int nitems) {
+#ifdef SEGM_NO_XCD_MAP
+    return bid;
+#else
+    const int per = nitems >> 3;
+    if ((nitems & 7) != 0 || per == 0) return bid;
+    return (bid & 7) * per + (bid >> 3);
+#endif
+}
+
 // ---- v_mfma_f32_16x16x32 for the two 16-bit element types (conv3d_fwd.hip, conv3d_wgrad.hip) -----------------------
 typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Mfma16;
