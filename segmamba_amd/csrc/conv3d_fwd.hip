@@ -56,7 +56,7 @@ struct ConvFwdDev {
     const void* wp;                                       // packed weights [cout][27 * 48], k = ((kz*3 + ky)*3 + kx)*48 + ci
     const float* bias;                                    // (cout) or null
     int32_t B, D, H, W, cout, cob0, cin;
-    int32_t nxb, ysplit, rows_per_part;
+    int32_t nxb, ysplit, rows_per_part, ncob;
 };
 
 // four consecutive outputs of one lane: convert and store, optionally on top of what y holds (a later 48-channel block
@@ -329,8 +329,11 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int part = wave >> 1, xp = wave & 1;            // K part, pair of x tiles (x0 + 32 xp .. + 31)
     const int i16 = lane & 15, g = lane >> 4;
-    const int cob = blockIdx.y;                           // block of 48 output channels
-    int item = xcd_item(blockIdx.x, gridDim.x);
+    // blockIdx.x runs over (item, block of 48 output channels) with the channel block fastest, XCD-aware: the co blocks of an
+    // item stage the same input rows and meet in one L2 (as grid rows they ran thousands of workgroups apart)
+    const int vid = xcd_item(blockIdx.x, gridDim.x);
+    const int cob = vid % P.ncob;
+    int item = vid / P.ncob;
     const int ypart = item % P.ysplit;  item /= P.ysplit;
     const int xb = item % P.nxb;        item /= P.nxb;
     const int z = item % P.D, b = item / P.D;
@@ -481,8 +484,11 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int part = wave / XP, xp = wave % XP;
     const int i16 = lane & 15, g = lane >> 4;
-    const int cob = blockIdx.y;                           // block of 48 output channels
-    int item = xcd_item(blockIdx.x, gridDim.x);
+    // blockIdx.x runs over (item, block of 48 output channels) with the channel block fastest, XCD-aware: the co blocks of an
+    // item stage the same input rows and meet in one L2 (as grid rows they ran thousands of workgroups apart)
+    const int vid = xcd_item(blockIdx.x, gridDim.x);
+    const int cob = vid % P.ncob;
+    int item = vid / P.ncob;
     const int ypart = item % P.ysplit;  item /= P.ysplit;
     const int xb = item % P.nxb;        item /= P.nxb;
     const int z = item % P.D, b = item / P.D;
@@ -673,8 +679,11 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
     const int tid = threadIdx.x, lane = tid & 63;
     const int part = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g = lane >> 4;
-    const int cob = blockIdx.y;                           // block of 48 output channels
-    int item = xcd_item(blockIdx.x, gridDim.x);
+    // blockIdx.x runs over (item, block of 48 output channels) with the channel block fastest, XCD-aware: the co blocks of an
+    // item stage the same input rows and meet in one L2 (as grid rows they ran thousands of workgroups apart)
+    const int vid = xcd_item(blockIdx.x, gridDim.x);
+    const int cob = vid % P.ncob;
+    int item = vid / P.ncob;
     const int ypart = item % P.ysplit;  item /= P.ysplit;
     const int xb = item % P.nxb;        item /= P.nxb;
     const int z = item % P.D, b = item / P.D;
@@ -876,7 +885,7 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     const bool chain32 = (a->flags & SEGM_CONV_FWD_CHAIN32) != 0;
     const FwPlan pl = fwd_plan(a->batch, a->cout, a->depth, a->height, a->width, (a->flags & (SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_CHAIN32)) != 0,
                                chain32 ? kC32XB : kFwXB);
-    P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part;
+    P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part; P.ncob = a->cout / 48 > 0 ? a->cout / 48 : 1;
     hipStream_t stream = (hipStream_t)a->stream;
     const bool f16 = a->dtype == SEGM_F16;
     const bool acc = (a->flags & SEGM_CONV_FWD_ACCUMULATE) != 0;
@@ -884,7 +893,7 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     const bool off32 = ((int64_t)47 * a->x_stride_c + a->width) * 2 < ((int64_t)1 << 32);
     if ((a->flags & (SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_CHAIN32)) && !off32) return SEGM_E_SHAPE;
     if (chain32) {
-        const dim3 grid(pl.nitems, a->cout / 48);
+        const dim3 grid(pl.nitems * (a->cout / 48));
 #define SEGM_L32(T, A) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, A>), grid, dim3(256), 0, stream, P)
         if (f16) { if (acc) SEGM_L32(f16_t, true); else SEGM_L32(f16_t, false); }
         else { if (acc) SEGM_L32(bf16_t, true); else SEGM_L32(bf16_t, false); }
@@ -892,12 +901,12 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
         return (int)hipGetLastError();
     }
     if (a->flags & SEGM_CONV_FWD_CHAIN) {
-        if (a->flags & SEGM_CONV_FWD_PITCH48) launch48<48>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
-        else launch48<kFwCP>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
+        if (a->flags & SEGM_CONV_FWD_PITCH48) launch48<48>(P, dim3(pl.nitems * (a->cout / 48)), f16, acc, stream);
+        else launch48<kFwCP>(P, dim3(pl.nitems * (a->cout / 48)), f16, acc, stream);
         return (int)hipGetLastError();
     }
     if (a->cout % 48 == 0 && off32 && (acc || !getenv("SEGM_CONV_FWD_KZ_SPLIT"))) {     // the env switch forces the 32 + 16 kernels (A/B timing)
-        launch48<0>(P, dim3(pl.nitems, a->cout / 48), f16, acc, stream);
+        launch48<0>(P, dim3(pl.nitems * (a->cout / 48)), f16, acc, stream);
         return (int)hipGetLastError();
     }
     if (acc) return SEGM_E_SHAPE;                         // in-place accumulation is a feature of the 48-channel kernels
