@@ -507,6 +507,11 @@ typedef struct segm_stem_args {
     const float* bias;
     void* y;
     void* stream;
+    /* 0 / 0 = the stem proper (kernel 7, stride 2).  3 / 1: the first 3x3x3 stride-1 padding-1 convolution of the conv stem on
+     * the same few input channels (UnetResBlock conv1 of `encoder1`, model_segmamba/segmamba.py:236-244): w_packed (cout, 3, 3, 8, 4),
+     * y (batch, cout, din, hin, win), win a multiple of 16. */
+    int32_t kernel_size, stride;
+    int64_t y_channel_stride;   /* elements between channels of y (batch stride = cout x that); 0 = dense */
 } segm_stem_args;
 
 int segm_stem_conv_fwd(const segm_stem_args* args);
@@ -525,9 +530,14 @@ typedef struct segm_stem_wgrad_args {
     float* dw_packed;
     void* workspace;    size_t workspace_bytes;
     void* stream;
+    /* 0 / 0 = kernel 7, stride 2.  3 / 1: the 3x3x3 stride-1 layer (see segm_stem_args): dw_packed fp32 (3, 3, cout16, 16) =
+     * [kz][ky][co][kx slot (4) * 4 + ci], workspace from segm_stem_conv_wgrad_workspace_bytes2; win in {32, 64, 128}. */
+    int32_t kernel_size, stride;
+    int64_t dy_channel_stride;  /* elements between channels of dy; 0 = dense */
 } segm_stem_wgrad_args;
 
 size_t segm_stem_conv_wgrad_workspace_bytes(int32_t batch, int32_t cout, int32_t din, int32_t hin);
+size_t segm_stem_conv_wgrad_workspace_bytes2(int32_t batch, int32_t cout, int32_t din, int32_t hin, int32_t kernel_size, int32_t stride);
 int segm_stem_conv_wgrad(const segm_stem_wgrad_args* args);
 
 /* ------------------------------------------------------------------------------------------------

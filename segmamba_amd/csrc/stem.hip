@@ -26,13 +26,14 @@ typedef uint32_t st_u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kStemWaves = 4;
 constexpr int kStemTiles = 8;                // 16-voxel tiles per wave
-constexpr int kStemK = 7;
+constexpr int kStemK = 7;                    // the stem proper; the same kernels run the 3^3 stride-1 first layer (KSZ = 3, STR = 1)
 
 struct StemDev {
     const char* x4;                          // (B, Din, Hin, Win, 4) contiguous
     const char* wp;                          // (cout, 7, 7, 8, 4) contiguous
     const float* bias;
-    char* y;                                 // (B, cout, Dout, Hout, Wout) contiguous
+    char* y;                                 // (B, cout, Dout, Hout, Wout), dense inside a channel
+    int64_t y_sc;                            // elements between channels (batch stride = cout * y_sc)
     int32_t batch, cout;
     int32_t din, hin, win, dout, hout, wout;
     int64_t blocks;                          // wave blocks: batch * dout * (hout / TY) * (wout / 16 / TX), TX * TY = kStemTiles
@@ -40,10 +41,11 @@ struct StemDev {
 
 // A wave owns a block of TX x TY = 8 tiles: TX 16-voxel tiles along x on each of TY consecutive output rows (TX = min(8, tiles
 // per row)), so its tiles differ only by compile-time offsets from one (batch, z, y0, x0).
-template <typename T, int NT, int TX>
+template <typename T, int NT, int TX, int KSZ, int STR>     // KSZ^3 taps, stride STR, padding KSZ / 2
 __global__ void __launch_bounds__(kStemWaves * 64, 2) stem_conv_fwd_kernel(StemDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     constexpr int TY = kStemTiles / TX;
+    constexpr int PAD = KSZ / 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, g = lane >> 4;
@@ -68,27 +70,27 @@ __global__ void __launch_bounds__(kStemWaves * 64, 2) stem_conv_fwd_kernel(StemD
     const int64_t row_el = (int64_t)P.win * 4, plane_el = (int64_t)P.hin * row_el, vol_el = (int64_t)P.din * plane_el;
 
 #pragma unroll 1
-    for (int kz = 0; kz < kStemK; ++kz) {
+    for (int kz = 0; kz < KSZ; ++kz) {
 #pragma unroll 1
-        for (int ky = 0; ky < kStemK; ++ky) {
+        for (int ky = 0; ky < KSZ; ++ky) {
             frag8 wf[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = 16 * nt + i16;
                 const st_u32x4 zero = {0u, 0u, 0u, 0u};
-                const st_u32x4 v = *reinterpret_cast<const st_u32x4*>(W + (((int64_t)(co < P.cout ? co : 0) * kStemK + kz) * kStemK + ky) * 32 + 8 * g);
+                const st_u32x4 v = *reinterpret_cast<const st_u32x4*>(W + (((int64_t)(co < P.cout ? co : 0) * KSZ + kz) * KSZ + ky) * 32 + 8 * g);
                 wf[nt] = __builtin_bit_cast(frag8, co < P.cout ? v : zero);
             }
-            const int iz = 2 * z0 + kz - 3;                                          // wave-uniform
+            const int iz = STR * z0 + kz - PAD;                                          // wave-uniform
             const bool z_ok = iz >= 0 && iz < P.din;
             const T* planep = X + (int64_t)b0 * vol_el + (int64_t)(z_ok ? iz : 0) * plane_el;
 #pragma unroll
             for (int t = 0; t < kStemTiles; ++t) {
-                const int iy = 2 * (y0 + t / TX) + ky - 3;
+                const int iy = STR * (y0 + t / TX) + ky - PAD;
                 const bool row_ok = z_ok && iy >= 0 && iy < P.hin;
-                const int ix = 2 * (x0 + 16 * (t % TX) + i16) + 2 * g - 3;           // first of the lane's two input columns
+                const int ix = STR * (x0 + 16 * (t % TX) + i16) + 2 * g - PAD;           // first of the lane's two input columns
                 const T* rowp = planep + (int64_t)(row_ok ? iy : 0) * row_el;
-                const bool ok0 = row_ok && ix >= 0 && ix < P.win, ok1 = row_ok && ix + 1 >= 0 && ix + 1 < P.win && !(g == 3);   // slot 7 = no tap
+                const bool ok0 = row_ok && ix >= 0 && ix < P.win && 2 * g < KSZ, ok1 = row_ok && ix + 1 >= 0 && ix + 1 < P.win && 2 * g + 1 < KSZ;   // slots >= KSZ: no tap
                 const st_u32x2 z2 = {0u, 0u};
                 const st_u32x2 v0 = *reinterpret_cast<const st_u32x2*>(rowp + (int64_t)(ok0 ? ix : 0) * 4);
                 const st_u32x2 v1 = *reinterpret_cast<const st_u32x2*>(rowp + (int64_t)(ok1 ? ix + 1 : 0) * 4);
@@ -101,7 +103,7 @@ __global__ void __launch_bounds__(kStemWaves * 64, 2) stem_conv_fwd_kernel(StemD
         }
     }
     T* Y = reinterpret_cast<T*>(P.y);
-    const int64_t oplane = (int64_t)P.hout * P.wout, ovol = (int64_t)P.dout * oplane;
+    const int64_t oplane = (int64_t)P.hout * P.wout, ovol = P.y_sc;
 #pragma unroll
     for (int t = 0; t < kStemTiles; ++t) {
 #pragma unroll
@@ -118,15 +120,15 @@ __global__ void __launch_bounds__(kStemWaves * 64, 2) stem_conv_fwd_kernel(StemD
     }
 }
 
-template <typename T, int TX>
+template <typename T, int TX, int KSZ, int STR>
 static int launch_stem_tx(const StemDev& P, hipStream_t st) {
     const int64_t gx = (P.blocks + kStemWaves - 1) / kStemWaves;
     if (gx >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;
     const dim3 grid((unsigned)gx), block(kStemWaves * 64);
     const int nt = (P.cout + 15) / 16;
-    if (nt == 1) hipLaunchKernelGGL((stem_conv_fwd_kernel<T, 1, TX>), grid, block, 0, st, P);
-    else if (nt == 2) hipLaunchKernelGGL((stem_conv_fwd_kernel<T, 2, TX>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((stem_conv_fwd_kernel<T, 3, TX>), grid, block, 0, st, P);
+    if (nt == 1) hipLaunchKernelGGL((stem_conv_fwd_kernel<T, 1, TX, KSZ, STR>), grid, block, 0, st, P);
+    else if (nt == 2) hipLaunchKernelGGL((stem_conv_fwd_kernel<T, 2, TX, KSZ, STR>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((stem_conv_fwd_kernel<T, 3, TX, KSZ, STR>), grid, block, 0, st, P);
     return (int)hipGetLastError();
 }
 
@@ -138,15 +140,15 @@ static int stem_tx(int wout, int hout) {
     return 0;
 }
 
-template <typename T>
+template <typename T, int KSZ, int STR>
 static int launch_stem(StemDev& P, hipStream_t st) {
     const int tx = stem_tx(P.wout, P.hout);
     if (!tx) return SEGM_E_SHAPE;
     P.blocks = (int64_t)P.batch * P.dout * (P.hout / (kStemTiles / tx)) * (P.wout / (16 * tx));
-    if (tx == 8) return launch_stem_tx<T, 8>(P, st);
-    if (tx == 4) return launch_stem_tx<T, 4>(P, st);
-    if (tx == 2) return launch_stem_tx<T, 2>(P, st);
-    return launch_stem_tx<T, 1>(P, st);
+    if (tx == 8) return launch_stem_tx<T, 8, KSZ, STR>(P, st);
+    if (tx == 4) return launch_stem_tx<T, 4, KSZ, STR>(P, st);
+    if (tx == 2) return launch_stem_tx<T, 2, KSZ, STR>(P, st);
+    return launch_stem_tx<T, 1, KSZ, STR>(P, st);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -165,18 +167,22 @@ constexpr int kStemRowsPerWave = 64;
 
 struct StemWgDev {
     const char* x4;                          // (B, Din, Hin, Win, 4)
-    const char* dy;                          // (B, cout, Dout, Hout, Wout)
-    float* part;                             // [slabs][7 kz][7 ky][cout16][32]
+    const char* dy;                          // (B, cout, Dout, Hout, Wout), dense inside a channel
+    int64_t dy_sc;                           // elements between channels of dy (batch stride = cout * dy_sc)
+    float* part;                             // [slabs][KSZ kz][KSZ ky][cout16][16 NJ]
     int32_t batch, cout, cout16;
     int32_t din, hin, win, dout, hout, wout;
     int64_t rows;                            // batch * dout * hout
     int32_t slabs;
 };
 
-template <typename T, int NT, int KS>        // NT = 16-channel tiles of cout, KS = 32-voxel steps per output row
+// NT = 16-channel tiles of cout, KS = 32-voxel steps per output row, KSZ^3 taps, stride STR, padding KSZ / 2
+template <typename T, int NT, int KS, int KSZ, int STR>
 __global__ void __launch_bounds__(kStemWaves * 64) stem_conv_wgrad_kernel(StemWgDev P) {
     typedef typename Mfma16<T>::v8 frag8;
-    constexpr int WIN = KS * 64;                                  // input row length (positions)
+    constexpr int PAD = KSZ / 2;
+    constexpr int NJ = KSZ > 4 ? 2 : 1;                           // 16-column tiles of (kx slot, ci): slots 0 - 3 / 4 - 7
+    constexpr int WIN = KS * 32 * STR;                            // input row length (positions)
     constexpr int STRIP = (WIN + 8) * 4;                          // elements: 4 + 4 padding positions around the row (16-byte aligned stores)
     __shared__ __attribute__((aligned(16))) T s_row[kStemWaves][STRIP];
     const int lane = threadIdx.x & 63;
@@ -190,16 +196,18 @@ __global__ void __launch_bounds__(kStemWaves * 64) stem_conv_wgrad_kernel(StemWg
     if (lane < 16) strip[lane] = from_f32<T>(0.f);
     else if (lane < 32) strip[(4 + WIN) * 4 + lane - 16] = from_f32<T>(0.f);
 
-    st_f32x4 acc[kStemK][NT][2];
+    st_f32x4 acc[KSZ][NT][NJ];
 #pragma unroll
-    for (int ky = 0; ky < kStemK; ++ky)
+    for (int ky = 0; ky < KSZ; ++ky)
 #pragma unroll
-        for (int mt = 0; mt < NT; ++mt) { acc[ky][mt][0] = st_f32x4{0.f, 0.f, 0.f, 0.f}; acc[ky][mt][1] = st_f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) acc[ky][mt][jt] = st_f32x4{0.f, 0.f, 0.f, 0.f};
 
     const T* X = reinterpret_cast<const T*>(P.x4);
     const T* DY = reinterpret_cast<const T*>(P.dy);
     const int64_t row_el = (int64_t)P.win * 4, plane_el = (int64_t)P.hin * row_el, vol_el = (int64_t)P.din * plane_el;
-    const int64_t oplane = (int64_t)P.hout * P.wout, ovol = (int64_t)P.dout * oplane;
+    const int64_t oplane = (int64_t)P.hout * P.wout, ovol = P.dy_sc;
     // the lane's gather offsets: column j = i16 -> slot 4 jt + i16 / 4, channel i16 % 4; voxel x = 32 ks + 8 g + e
     const int ci = i16 & 3, sl = i16 >> 2;
 
@@ -210,7 +218,7 @@ __global__ void __launch_bounds__(kStemWaves * 64) stem_conv_wgrad_kernel(StemWg
         const int y = (int)(row % P.hout);
         const int z = (int)((row / P.hout) % P.dout);
         const int b = (int)(row / ((int64_t)P.hout * P.dout));
-        const int iz = 2 * z + kz - 3;
+        const int iz = STR * z + kz - PAD;
         if (iz < 0 || iz >= P.din) continue;                     // uniform: a padding plane contributes nothing
         frag8 af[NT][KS];
 #pragma unroll
@@ -225,25 +233,25 @@ __global__ void __launch_bounds__(kStemWaves * 64) stem_conv_wgrad_kernel(StemWg
             }
         }
 #pragma unroll
-        for (int ky = 0; ky < kStemK; ++ky) {
-            const int iy = 2 * y + ky - 3;
+        for (int ky = 0; ky < KSZ; ++ky) {
+            const int iy = STR * y + ky - PAD;
             if (iy < 0 || iy >= P.hin) continue;                 // uniform
             const T* rowp = X + (int64_t)b * vol_el + (int64_t)iz * plane_el + (int64_t)iy * row_el;
             SEGM_WAVE_LDS_SYNC();                                // the previous row's gathers are done
 #pragma unroll
-            for (int q = 0; q < (KS + 1) / 2; ++q)               // 64 lanes x 16 bytes = 128 positions per load
+            for (int q = 0; q < (WIN + 127) / 128; ++q)          // 64 lanes x 16 bytes = 128 positions per load
                 if ((q * 64 + lane) * 8 < WIN * 4)
                     *reinterpret_cast<st_u32x4*>(strip + 16 + (q * 64 + lane) * 8) = *reinterpret_cast<const st_u32x4*>(rowp + (q * 64 + lane) * 8);
             SEGM_WAVE_LDS_SYNC();
 #pragma unroll
-            for (int jt = 0; jt < 2; ++jt) {
+            for (int jt = 0; jt < NJ; ++jt) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    // B fragment: x4row[2 (32 ks + 8 g + e) + (4 jt + sl) - 3][ci], e = 0 .. 7   (strip index = position + 4)
-                    const T* gp = strip + (2 * (32 * ks + 8 * g) + 4 * jt + sl + 1) * 4 + ci;
+                    // B fragment: x4row[STR (32 ks + 8 g + e) + (4 jt + sl) - PAD][ci], e = 0 .. 7   (strip index = position + 4)
+                    const T* gp = strip + (STR * (32 * ks + 8 * g) + 4 * jt + sl + 4 - PAD) * 4 + ci;
                     T e8[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) e8[e] = gp[e * 8];
+                    for (int e = 0; e < 8; ++e) e8[e] = gp[e * STR * 4];
                     frag8 bf;
                     memcpy(&bf, e8, 16);
 #pragma unroll
@@ -253,16 +261,16 @@ __global__ void __launch_bounds__(kStemWaves * 64) stem_conv_wgrad_kernel(StemWg
         }
     }
     // partial: D[co = 16 mt + 4 g + r][j = 16 jt + i16]
-    float* pp = P.part + (((int64_t)slab * kStemK + kz) * kStemK) * P.cout16 * 32;
+    float* pp = P.part + (((int64_t)slab * KSZ + kz) * KSZ) * P.cout16 * (16 * NJ);
 #pragma unroll
-    for (int ky = 0; ky < kStemK; ++ky)
+    for (int ky = 0; ky < KSZ; ++ky)
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
+            for (int jt = 0; jt < NJ; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    pp[((int64_t)ky * P.cout16 + 16 * mt + 4 * g + r) * 32 + 16 * jt + i16] = acc[ky][mt][jt][r];
+                    pp[((int64_t)ky * P.cout16 + 16 * mt + 4 * g + r) * (16 * NJ) + 16 * jt + i16] = acc[ky][mt][jt][r];
 }
 
 // dwp[n] = sum over slabs of part[slab][n], slabs added in a fixed order (wgrad_gemm.hip)
@@ -272,11 +280,19 @@ void launch_partial_sum(const float* part, int parts, int64_t n, float* out, hip
 
 using namespace segm;
 
+// (kernel size, stride) of a call: 0 / 0 = the stem proper
+static bool stem_geometry(int32_t ksz, int32_t str, int& k, int& s) {
+    k = ksz ? ksz : 7; s = str ? str : 2;
+    return (k == 7 && s == 2) || (k == 3 && s == 1);
+}
+
 extern "C" int segm_stem_conv_fwd(const segm_stem_args* a) {
     if (!a) return SEGM_E_NULL;
+    int ksz, str;
+    if (!stem_geometry(a->kernel_size, a->stride, ksz, str)) return SEGM_E_SHAPE;
     if (a->batch <= 0 || a->cout <= 0 || a->cout > 48 || a->din <= 0 || a->hin <= 0 || a->win <= 0) return SEGM_E_SHAPE;
-    if (a->din % 2 || a->hin % 2 || a->win % 32) return SEGM_E_SHAPE;             // even extents, output rows in 16-voxel tiles
-    if (!stem_tx(a->win / 2, a->hin / 2)) return SEGM_E_SHAPE;                       // 8 tiles = TX along x times TY rows
+    if (a->din % str || a->hin % str || (a->win / str) % 16 || a->win % str) return SEGM_E_SHAPE;      // output rows in 16-voxel tiles
+    if (!stem_tx(a->win / str, a->hin / str)) return SEGM_E_SHAPE;                   // 8 tiles = TX along x times TY rows
     if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
     if (!a->x4 || !a->w_packed || !a->y) return SEGM_E_NULL;
     if (((uintptr_t)a->x4 & 7) || ((uintptr_t)a->w_packed & 15) || ((uintptr_t)a->y & 7)) return SEGM_E_SHAPE;
@@ -284,50 +300,72 @@ extern "C" int segm_stem_conv_fwd(const segm_stem_args* a) {
     P.x4 = (const char*)a->x4; P.wp = (const char*)a->w_packed; P.bias = a->bias; P.y = (char*)a->y;
     P.batch = a->batch; P.cout = a->cout;
     P.din = a->din; P.hin = a->hin; P.win = a->win;
-    P.dout = a->din / 2; P.hout = a->hin / 2; P.wout = a->win / 2;
+    P.dout = a->din / str; P.hout = a->hin / str; P.wout = a->win / str;
+    const int64_t dense = (int64_t)P.dout * P.hout * P.wout;
+    P.y_sc = a->y_channel_stride ? a->y_channel_stride : dense;
+    if (P.y_sc < dense || P.y_sc % 4) return SEGM_E_SHAPE;
     hipStream_t st = (hipStream_t)a->stream;
-    return a->dtype == SEGM_F16 ? launch_stem<f16_t>(P, st) : launch_stem<bf16_t>(P, st);
+    if (ksz == 7) return a->dtype == SEGM_F16 ? launch_stem<f16_t, 7, 2>(P, st) : launch_stem<bf16_t, 7, 2>(P, st);
+    return a->dtype == SEGM_F16 ? launch_stem<f16_t, 3, 1>(P, st) : launch_stem<bf16_t, 3, 1>(P, st);
+}
+
+extern "C" size_t segm_stem_conv_wgrad_workspace_bytes2(int32_t batch, int32_t cout, int32_t din, int32_t hin, int32_t kernel_size, int32_t stride) {
+    int ksz, str;
+    if (batch <= 0 || cout <= 0 || din <= 0 || hin <= 0 || !stem_geometry(kernel_size, stride, ksz, str)) return 0;
+    const int64_t rows = (int64_t)batch * (din / str) * (hin / str);
+    const int64_t slabs = (rows + kStemRowsPerWave - 1) / kStemRowsPerWave;
+    return (size_t)slabs * ksz * ksz * ((cout + 15) / 16 * 16) * (ksz > 4 ? 32 : 16) * sizeof(float);
 }
 
 extern "C" size_t segm_stem_conv_wgrad_workspace_bytes(int32_t batch, int32_t cout, int32_t din, int32_t hin) {
-    if (batch <= 0 || cout <= 0 || din <= 0 || hin <= 0) return 0;
-    const int64_t rows = (int64_t)batch * (din / 2) * (hin / 2);
-    const int64_t slabs = (rows + kStemRowsPerWave - 1) / kStemRowsPerWave;
-    return (size_t)slabs * kStemK * kStemK * ((cout + 15) / 16 * 16) * 32 * sizeof(float);
+    return segm_stem_conv_wgrad_workspace_bytes2(batch, cout, din, hin, 7, 2);
+}
+
+template <typename T, int KSZ, int STR>
+static void launch_stem_wgrad(const StemWgDev& P, int nt, int ks, dim3 grid, dim3 block, hipStream_t st) {
+#define SEGM_STEM_WG(NN)                                                                                              \
+    do {                                                                                                              \
+        if (ks == 1) hipLaunchKernelGGL((stem_conv_wgrad_kernel<T, NN, 1, KSZ, STR>), grid, block, 0, st, P);          \
+        else if (ks == 2) hipLaunchKernelGGL((stem_conv_wgrad_kernel<T, NN, 2, KSZ, STR>), grid, block, 0, st, P);     \
+        else hipLaunchKernelGGL((stem_conv_wgrad_kernel<T, NN, 4, KSZ, STR>), grid, block, 0, st, P);                  \
+    } while (0)
+    if (nt == 1) SEGM_STEM_WG(1); else if (nt == 2) SEGM_STEM_WG(2); else SEGM_STEM_WG(3);
+#undef SEGM_STEM_WG
 }
 
 extern "C" int segm_stem_conv_wgrad(const segm_stem_wgrad_args* a) {
     if (!a) return SEGM_E_NULL;
+    int ksz, str;
+    if (!stem_geometry(a->kernel_size, a->stride, ksz, str)) return SEGM_E_SHAPE;
     if (a->batch <= 0 || a->cout <= 0 || a->cout > 48 || a->din <= 0 || a->hin <= 0 || a->win <= 0) return SEGM_E_SHAPE;
-    if (a->din % 2 || a->hin % 2 || (a->win != 64 && a->win != 128 && a->win != 256)) return SEGM_E_SHAPE;   // rows of 1, 2 or 4 k-steps
+    const int wout = a->win / str;
+    if (a->din % str || a->hin % str || a->win % str || (wout != 32 && wout != 64 && wout != 128)) return SEGM_E_SHAPE;   // rows of 1, 2 or 4 k-steps
     if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
     if (!a->x4 || !a->dy || !a->dw_packed) return SEGM_E_NULL;
     if (((uintptr_t)a->x4 & 15) || ((uintptr_t)a->dy & 15)) return SEGM_E_SHAPE;
-    const size_t need = segm_stem_conv_wgrad_workspace_bytes(a->batch, a->cout, a->din, a->hin);
+    const size_t need = segm_stem_conv_wgrad_workspace_bytes2(a->batch, a->cout, a->din, a->hin, ksz, str);
     if (!a->workspace || a->workspace_bytes < need) return SEGM_E_WORKSPACE;
     StemWgDev P;
     P.x4 = (const char*)a->x4; P.dy = (const char*)a->dy; P.part = (float*)a->workspace;
     P.batch = a->batch; P.cout = a->cout; P.cout16 = (a->cout + 15) / 16 * 16;
     P.din = a->din; P.hin = a->hin; P.win = a->win;
-    P.dout = a->din / 2; P.hout = a->hin / 2; P.wout = a->win / 2;
+    P.dout = a->din / str; P.hout = a->hin / str; P.wout = wout;
+    const int64_t dense = (int64_t)P.dout * P.hout * P.wout;
+    P.dy_sc = a->dy_channel_stride ? a->dy_channel_stride : dense;
+    if (P.dy_sc < dense || P.dy_sc % 8) return SEGM_E_SHAPE;
     P.rows = (int64_t)P.batch * P.dout * P.hout;
     P.slabs = (int32_t)((P.rows + kStemRowsPerWave - 1) / kStemRowsPerWave);
     hipStream_t st = (hipStream_t)a->stream;
-    const dim3 grid((unsigned)((P.slabs + kStemWaves - 1) / kStemWaves), kStemK), block(kStemWaves * 64);
-    const int nt = P.cout16 / 16, ks = a->win / 64;
-#define SEGM_STEM_WG(TT)                                                                                                   \
-    if (nt == 1 && ks == 1) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 1, 1>), grid, block, 0, st, P);                  \
-    else if (nt == 2 && ks == 1) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 2, 1>), grid, block, 0, st, P);             \
-    else if (nt == 3 && ks == 1) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 3, 1>), grid, block, 0, st, P);             \
-    else if (nt == 1 && ks == 2) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 1, 2>), grid, block, 0, st, P);             \
-    else if (nt == 2 && ks == 2) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 2, 2>), grid, block, 0, st, P);             \
-    else if (nt == 3 && ks == 2) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 3, 2>), grid, block, 0, st, P);             \
-    else if (nt == 1) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 1, 4>), grid, block, 0, st, P);                        \
-    else if (nt == 2) hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 2, 4>), grid, block, 0, st, P);                        \
-    else hipLaunchKernelGGL((stem_conv_wgrad_kernel<TT, 3, 4>), grid, block, 0, st, P);
-    if (a->dtype == SEGM_F16) { SEGM_STEM_WG(f16_t) } else { SEGM_STEM_WG(bf16_t) }
-#undef SEGM_STEM_WG
-    const int64_t n = (int64_t)kStemK * kStemK * P.cout16 * 32;
+    const dim3 grid((unsigned)((P.slabs + kStemWaves - 1) / kStemWaves), ksz), block(kStemWaves * 64);
+    const int nt = P.cout16 / 16, ks = wout / 32;
+    if (ksz == 7) {
+        if (a->dtype == SEGM_F16) launch_stem_wgrad<f16_t, 7, 2>(P, nt, ks, grid, block, st);
+        else launch_stem_wgrad<bf16_t, 7, 2>(P, nt, ks, grid, block, st);
+    } else {
+        if (a->dtype == SEGM_F16) launch_stem_wgrad<f16_t, 3, 1>(P, nt, ks, grid, block, st);
+        else launch_stem_wgrad<bf16_t, 3, 1>(P, nt, ks, grid, block, st);
+    }
+    const int64_t n = (int64_t)ksz * ksz * P.cout16 * (ksz > 4 ? 32 : 16);
     launch_partial_sum(P.part, P.slabs, n, a->dw_packed, st);
     return (int)hipGetLastError();
 }

@@ -89,19 +89,22 @@ def pointwise_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor |
 
 
 class _StemConv(torch.autograd.Function):
-    """Conv3d(kernel 7, stride 2, padding 3) of the encoder's stem (model_segmamba/segmamba.py:141): forward through
-    segm_stem_conv_fwd (an implicit GEMM; MIOpen's im2col route took 1.37 ms for the 2 x 4 x 128^3 input), weight gradient
-    through segm_stem_conv_wgrad on the channel-last-4 copy of the input the forward made (MIOpen: 3.0 ms), bias gradient a
-    sum.  The network input needs no gradient; when it does ask for one (or the width is not one the kernel takes) ATen's
-    convolution_backward runs on the same 16-bit operands."""
+    """A convolution on at most 4 input channels through the thin-input kernels (csrc/stem.hip): Conv3d(kernel 7, stride 2,
+    padding 3) of the encoder's stem (model_segmamba/segmamba.py:141) and Conv3d(kernel 3, stride 1, padding 1) of `encoder1`'s
+    first layer (:236-244, monai dynunet_block.py:72-80) - the geometry follows the weight's shape.  Forward: segm_stem_conv_fwd
+    (an implicit GEMM; MIOpen's im2col route took 1.37 ms for the stem on the 2 x 4 x 128^3 input, the 48-channel 3x3x3 kernel
+    0.6 ms for the 3^3 layer with 44 of its 48 input channels zero); weight gradient: segm_stem_conv_wgrad on the channel-last-4
+    copy of the input the forward made (MIOpen: 3.0 ms for the stem); bias gradient: a sum.  The network input needs no gradient;
+    when it does ask for one (or the width is not one the kernel takes) ATen's convolution_backward runs on the same operands."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         from . import lib as L, ops_raw
         from .linear import _masters
         w, b = _masters(ctx, x, w, b)                    # fp32 masters -> the step's 16-bit copies; gradients go back in fp32
+        ctx.k, ctx.s = ops_raw._stem_geometry(w)
         x4 = ops_raw.stem_channel_last4(x)
-        ctx.use_hip = (_STEM_WGRAD_HIP and not ctx.needs_input_grad[0] and ops_raw.stem_wgrad_supported(x4, w.shape[0]))
+        ctx.use_hip = (_STEM_WGRAD_HIP and not ctx.needs_input_grad[0] and ops_raw.stem_wgrad_supported(x4, w.shape[0], ctx.k))
         ctx.save_for_backward(x4 if ctx.use_hip else x, w)
         return ops_raw.stem_conv_fwd(L.get_lib(), x, w, b, x4=x4)
 
@@ -110,18 +113,32 @@ class _StemConv(torch.autograd.Function):
         from . import lib as L, ops_raw
         x, w = ctx.saved_tensors
         if ctx.use_hip:
-            dy = dy.contiguous()
-            dw = ops_raw.stem_conv_wgrad(L.get_lib(), x, dy, w.shape[1]).to(ctx.w_dtype) if ctx.needs_input_grad[1] else None
+            dw = ops_raw.stem_conv_wgrad(L.get_lib(), x, dy, w.shape[1], ctx.k).to(ctx.w_dtype) if ctx.needs_input_grad[1] else None
             db = dy.sum(dim=(0, 2, 3, 4), dtype=torch.float32).to(ctx.b_dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
             return None, dw, db
         mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
-        dx, dw, db = torch.ops.aten.convolution_backward(dy.contiguous(), x, w, [w.shape[0]] if ctx.has_bias else None, [2, 2, 2],
-                                                         [3, 3, 3], [1, 1, 1], False, [0, 0, 0], 1, mask)
+        dx, dw, db = torch.ops.aten.convolution_backward(dy.contiguous(), x, w, [w.shape[0]] if ctx.has_bias else None, [ctx.s] * 3,
+                                                         [ctx.k // 2] * 3, [1, 1, 1], False, [0, 0, 0], 1, mask)
         return dx, (dw.to(ctx.w_dtype) if dw is not None else None), (db.to(ctx.b_dtype) if db is not None else None)
 
 
 _STEM_WGRAD_HIP = os.environ.get("SEGM_STEM_WGRAD_HIP", "1") == "1"
 _STEM_HIP = os.environ.get("SEGM_STEM_HIP", "1") == "1"
+
+
+def thin_conv3d_same(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor | None:
+    """Conv3d(kernel 3, stride 1, padding 1) on at most 4 input channels through the thin-input kernels, or None when the call is
+    not theirs (SEGM_THIN_CONV_HIP=0, CPU tensors, a 32-bit compute dtype, an input that needs its gradient, other shapes)"""
+    from . import lib as L, ops_raw
+    if not (_THIN_HIP and L.on_device(x) and weight.shape[1] <= 4 and not x.requires_grad and ops_raw.stem_conv_supported(x, weight)):
+        return None
+    dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
+    if dt not in (torch.bfloat16, torch.float16):
+        return None
+    return _StemConv.apply(x.to(dt), weight, bias)
+
+
+_THIN_HIP = os.environ.get("SEGM_THIN_CONV_HIP", "1") == "1"
 
 
 def stem_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:

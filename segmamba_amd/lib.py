@@ -201,6 +201,7 @@ class StemArgs(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("cout", C.c_int32), ("din", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32), ("dtype", C.c_int32),
         ("x4", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("stream", C.c_void_p),
+        ("kernel_size", C.c_int32), ("stride", C.c_int32), ("y_channel_stride", C.c_int64),
     ]
 
 
@@ -209,6 +210,7 @@ class StemWgradArgs(C.Structure):
         ("batch", C.c_int32), ("cout", C.c_int32), ("din", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32), ("dtype", C.c_int32),
         ("x4", C.c_void_p), ("dy", C.c_void_p), ("dw_packed", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+        ("kernel_size", C.c_int32), ("stride", C.c_int32), ("dy_channel_stride", C.c_int64),
     ]
 
 
@@ -238,7 +240,7 @@ EXPORTS = (
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
     "segm_causal_conv1d_update", "segm_selective_state_update", "segm_linear_rows", "segm_pointwise_cf", "segm_stem_conv_fwd",
-    "segm_stem_conv_wgrad", "segm_stem_conv_wgrad_workspace_bytes", "segm_wgrad_gemm", "segm_wgrad_gemm_workspace_bytes",
+    "segm_stem_conv_wgrad", "segm_stem_conv_wgrad_workspace_bytes", "segm_stem_conv_wgrad_workspace_bytes2", "segm_wgrad_gemm", "segm_wgrad_gemm_workspace_bytes",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -287,6 +289,7 @@ class SegmLib:
         sig("segm_stem_conv_fwd", [C.POINTER(StemArgs)], C.c_int)
         sig("segm_stem_conv_wgrad", [C.POINTER(StemWgradArgs)], C.c_int)
         sig("segm_stem_conv_wgrad_workspace_bytes", [C.c_int32] * 4, C.c_size_t)
+        sig("segm_stem_conv_wgrad_workspace_bytes2", [C.c_int32] * 6, C.c_size_t)
         sig("segm_wgrad_gemm", [C.POINTER(WgradGemmArgs)], C.c_int)
         sig("segm_wgrad_gemm_workspace_bytes", [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32], C.c_size_t)
         sig("segm_abi_version", [], C.c_int)

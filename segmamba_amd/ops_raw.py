@@ -702,74 +702,97 @@ def pointwise_cf(lib: L.SegmLib, x3: torch.Tensor, w2: torch.Tensor, bias: Optio
     return y
 
 
+def _stem_geometry(weight: torch.Tensor):
+    """(kernel size, stride) the thin-input kernels run a weight of this shape with: 7^3 -> stride 2 (the stem), 3^3 -> stride 1"""
+    k = tuple(weight.shape[2:])
+    return (7, 2) if k == (7, 7, 7) else ((3, 1) if k == (3, 3, 3) else (0, 0))
+
+
 def stem_conv_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
-    """x (B, Cin <= 4, D, H, W) with D, H even and W % 32 == 0; weight (Cout <= 48, Cin, 7, 7, 7); a wave's 8 output tiles are
-    TX along x (the largest of 8, 4, 2, 1 dividing W / 32) times 8 / TX rows, which must divide H / 2"""
-    if not (x.dim() == 5 and weight.dim() == 5 and tuple(weight.shape[2:]) == (7, 7, 7) and weight.shape[1] == x.shape[1]
-            and x.shape[1] <= 4 and weight.shape[0] <= 48 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[4] % 32 == 0):
+    """x (B, Cin <= 4, D, H, W); weight (Cout <= 48, Cin, 7, 7, 7) (stride 2, padding 3: D, H even, W % 32 == 0) or
+    (Cout <= 48, Cin, 3, 3, 3) (stride 1, padding 1: W % 16 == 0); a wave's 8 output tiles are TX along x (the largest of 8, 4, 2, 1
+    dividing Wout / 16) times 8 / TX rows, which must divide Hout"""
+    if not (x.dim() == 5 and weight.dim() == 5 and weight.shape[1] == x.shape[1] and x.shape[1] <= 4 and weight.shape[0] <= 48):
         return False
-    xt, hout = x.shape[4] // 32, x.shape[3] // 2
+    k, s = _stem_geometry(weight)
+    if not k or x.shape[2] % s or x.shape[3] % s or x.shape[4] % (16 * s):
+        return False
+    xt, hout = x.shape[4] // (16 * s), x.shape[3] // s
     return any(xt % tx == 0 and hout % (8 // tx) == 0 for tx in (8, 4, 2, 1))
 
 
 def pack_stem_weight(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """(Cout, Cin <= 4, 7, 7, 7) -> (Cout, 7, 7, 8, 4): [co][kz][ky][kx slot][ci], slot 7 and missing channels zero"""
+    """(Cout, Cin <= 4, k, k, k) -> (Cout, k, k, 8, 4): [co][kz][ky][kx slot][ci], slots >= k and missing channels zero"""
     w = weight.permute(0, 2, 3, 4, 1)                                  # co, kz, ky, kx, ci
-    w = torch.nn.functional.pad(w, (0, 4 - w.shape[-1], 0, 1))
+    w = torch.nn.functional.pad(w, (0, 4 - w.shape[-1], 0, 8 - w.shape[-2]))
     return w.contiguous().to(dtype)
 
 
 def stem_channel_last4(x: torch.Tensor) -> torch.Tensor:
-    """(B, Cin <= 4, D, H, W) -> (B, D, H, W, 4) contiguous, missing channels zero: the input layout of both stem kernels"""
+    """(B, Cin <= 4, D, H, W) -> (B, D, H, W, 4) contiguous, missing channels zero: the input layout of the thin-input kernels"""
     return torch.nn.functional.pad(x.permute(0, 2, 3, 4, 1), (0, 4 - x.shape[1])).contiguous()
 
 
 def stem_conv_fwd(lib: L.SegmLib, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                   x4: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = conv3d(x, weight, bias, stride 2, padding 3) for the 7^3 stem (x, weight of one 16-bit dtype) -> (B, Cout, D/2, H/2, W/2)"""
+    """y = conv3d(x, weight, bias, stride 2, padding 3) for the 7^3 stem, conv3d(x, weight, bias, stride 1, padding 1) for a 3^3
+    weight (x, weight of one 16-bit dtype, at most 4 input channels) -> (B, Cout, D / s, H / s, W / s)"""
     if not stem_conv_supported(x, weight) or x.dtype not in (torch.bfloat16, torch.float16) or weight.dtype != x.dtype:
-        raise RuntimeError("stem_conv_fwd: x (B, Cin <= 4, D even, H even, W % 32 == 0) and weight (Cout <= 48, Cin, 7, 7, 7) of one 16-bit dtype")
+        raise RuntimeError("stem_conv_fwd: x (B, Cin <= 4, D, H, W) and weight (Cout <= 48, Cin, 7, 7, 7) [stride 2: D, H even, W % 32 == 0] "
+                           "or (Cout <= 48, Cin, 3, 3, 3) [stride 1: W % 16 == 0] of one 16-bit dtype")
     B, Cin, D, H, W = x.shape
+    k, s = _stem_geometry(weight)
     if x4 is None:
         x4 = stem_channel_last4(x)
     wp = pack_stem_weight(weight, x.dtype)
-    y = torch.empty(B, weight.shape[0], D // 2, H // 2, W // 2, dtype=x.dtype, device=x.device)
+    y = volume_empty(B, weight.shape[0], (D // s, H // s, W // s), x.dtype, x.device)
     if bias is not None:
         bias = bias.float().contiguous()
     a = L.StemArgs()
     a.batch, a.cout, a.din, a.hin, a.win, a.dtype = B, weight.shape[0], D, H, W, L.dtype_code(x)
     a.x4, a.w_packed, a.bias, a.y = x4.data_ptr(), wp.data_ptr(), L.fptr(bias), y.data_ptr()
+    a.kernel_size, a.stride, a.y_channel_stride = k, s, y.stride(1)
     a.stream = L.stream_handle(x)
     lib.check(lib.dll.segm_stem_conv_fwd(a), "stem_conv_fwd")
     return y
 
 
-def stem_wgrad_supported(x4: torch.Tensor, cout: int) -> bool:
-    """x4 (B, D, H, W, 4) with D, H even and W in {64, 128, 256}; cout <= 48"""
-    return x4.dim() == 5 and x4.shape[4] == 4 and x4.shape[1] % 2 == 0 and x4.shape[2] % 2 == 0 and x4.shape[3] in (64, 128, 256) and cout <= 48
+def stem_wgrad_supported(x4: torch.Tensor, cout: int, kernel_size: int = 7) -> bool:
+    """x4 (B, D, H, W, 4); kernel 7 (stride 2): D, H even and W in {64, 128, 256}; kernel 3 (stride 1): W in {32, 64, 128}; cout <= 48"""
+    if not (x4.dim() == 5 and x4.shape[4] == 4 and cout <= 48):
+        return False
+    if kernel_size == 7:
+        return x4.shape[1] % 2 == 0 and x4.shape[2] % 2 == 0 and x4.shape[3] in (64, 128, 256)
+    return kernel_size == 3 and x4.shape[3] in (32, 64, 128)
 
 
-def stem_conv_wgrad(lib: L.SegmLib, x4: torch.Tensor, dy: torch.Tensor, cin: int) -> torch.Tensor:
-    """dW (Cout, cin, 7, 7, 7) fp32 of conv3d(x, W, stride 2, padding 3) from the channel-last-4 input x4 (B, D, H, W, 4) and
-    dy (B, Cout, D/2, H/2, W/2), one 16-bit dtype"""
+def stem_conv_wgrad(lib: L.SegmLib, x4: torch.Tensor, dy: torch.Tensor, cin: int, kernel_size: int = 7) -> torch.Tensor:
+    """dW (Cout, cin, k, k, k) fp32 of conv3d(x, W, stride 2, padding 3) [k = 7] or conv3d(x, W, stride 1, padding 1) [k = 3] from the
+    channel-last-4 input x4 (B, D, H, W, 4) and dy (B, Cout, D / s, H / s, W / s) (dense channels), one 16-bit dtype"""
     B, D, H, W, _ = x4.shape
     cout = dy.shape[1]
-    if (not stem_wgrad_supported(x4, cout) or x4.dtype not in (torch.bfloat16, torch.float16) or dy.dtype != x4.dtype
-            or tuple(dy.shape) != (B, cout, D // 2, H // 2, W // 2) or not 1 <= cin <= 4):
-        raise RuntimeError("stem_conv_wgrad: x4 (B, D even, H even, W in {64, 128, 256}, 4) and dy (B, Cout <= 48, D/2, H/2, W/2) of one 16-bit dtype")
-    x4, dy = x4.contiguous(), dy.contiguous()
+    s = 2 if kernel_size == 7 else 1
+    if (not stem_wgrad_supported(x4, cout, kernel_size) or x4.dtype not in (torch.bfloat16, torch.float16) or dy.dtype != x4.dtype
+            or tuple(dy.shape) != (B, cout, D // s, H // s, W // s) or not 1 <= cin <= 4):
+        raise RuntimeError("stem_conv_wgrad: x4 (B, D, H, W, 4) and dy (B, Cout <= 48, D / s, H / s, W / s) of one 16-bit dtype; "
+                           "kernel 7: D, H even, W in {64, 128, 256}; kernel 3: W in {32, 64, 128}")
+    x4 = x4.contiguous()
+    if not channel_dense(dy) or dy.stride(1) % 8:
+        dy = dy.contiguous()
     cout16 = (cout + 15) // 16 * 16
-    dwp = torch.empty(7, 7, cout16, 8, 4, dtype=torch.float32, device=x4.device)
-    nbytes = lib.dll.segm_stem_conv_wgrad_workspace_bytes(B, cout, D, H)
+    slots = 8 if kernel_size == 7 else 4
+    dwp = torch.empty(kernel_size, kernel_size, cout16, slots, 4, dtype=torch.float32, device=x4.device)
+    nbytes = lib.dll.segm_stem_conv_wgrad_workspace_bytes2(B, cout, D, H, kernel_size, s)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x4.device)
     a = L.StemWgradArgs()
     a.batch, a.cout, a.din, a.hin, a.win, a.dtype = B, cout, D, H, W, L.dtype_code(x4)
     a.x4, a.dy, a.dw_packed = x4.data_ptr(), dy.data_ptr(), dwp.data_ptr()
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    a.kernel_size, a.stride, a.dy_channel_stride = kernel_size, s, dy.stride(1)
     a.stream = L.stream_handle(x4)
     lib.check(lib.dll.segm_stem_conv_wgrad(a), "stem_conv_wgrad")
     # [kz][ky][co][kx slot][ci] -> (co, ci, kz, ky, kx)
-    return dwp[:, :, :cout, :7, :cin].permute(2, 4, 0, 1, 3).contiguous()
+    return dwp[:, :, :cout, :kernel_size, :cin].permute(2, 4, 0, 1, 3).contiguous()
 
 
 WGEMM_TN, WGEMM_NT = 0, 1

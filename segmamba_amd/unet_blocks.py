@@ -88,6 +88,10 @@ class ConvOnly(nn.Sequential):
         if self._pointwise:
             return fused_norm.pointwise_conv3d(x, self.conv.weight, self.conv.bias)
         if self._same:
+            if self.conv.weight.shape[1] <= 4:           # the network's first layer: 4 input channels, not 48 with 44 zero ones
+                y = fused_norm.thin_conv3d_same(x, self.conv.weight, self.conv.bias)
+                if y is not None:
+                    return y
             return conv3d_same(x, self.conv.weight, self.conv.bias)
         if self._patch and all(s % self._k == 0 for s in x.shape[2:]):
             if self._transposed:

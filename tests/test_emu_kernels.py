@@ -289,6 +289,33 @@ def test_unet_res_block_on_padded_volumes_emulated(emu, monkeypatch):
         assert torch.equal(u.contiguous(), v.contiguous())
 
 
+def test_first_layer_takes_the_thin_input_kernels_emulated(emu, monkeypatch):
+    """encoder1's UnetResBlock(4 -> 48) under bf16: conv1 through the thin-input kernels (forward + weight gradient) against
+    the same block with the 48-channel kernels (SEGM_THIN_CONV_HIP=0 route): output and every parameter gradient agree"""
+    from segmamba_amd import lib as L, unet_blocks as UB, conv3d as C3, fused_norm as FN
+    monkeypatch.setattr(L, "get_lib", lambda: emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
+    torch.manual_seed(5)
+    blk = UB.UnetResBlock(4, 48)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 4, 2, 8, 64, generator=g).bfloat16()
+    dy = torch.randn(1, 48, 2, 8, 64, generator=g).bfloat16()
+    calls = []
+    real = ops_raw.stem_conv_fwd
+    monkeypatch.setattr(ops_raw, "stem_conv_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    res = []
+    for thin in (True, False):
+        monkeypatch.setattr(FN, "_THIN_HIP", thin)
+        blk.zero_grad()
+        y = blk(x)
+        y.backward(dy)
+        res.append([y.detach().float()] + [p.grad.clone() for p in blk.parameters()])
+    assert len(calls) == 1                                # only the thin route calls it
+    for u, v in zip(*res):
+        assert u.dtype == v.dtype and (u - v).abs().max() <= 2e-2 * max(1.0, float(v.abs().max()))
+
+
 def test_volume_empty_pads_power_of_two_channel_strides():
     """ops_raw.volume_empty: a 128^3 16-bit volume with >= 16 channels gets a padded channel stride (4 MiB strides alias in L2 /
     memory channels), everything else is an ordinary contiguous tensor; channel_dense recognises both"""
@@ -975,6 +1002,30 @@ def test_stem_conv_fwd_emulated(emu, B, Cin, Cout, D, H, W, dtype, bias):
     assert y.shape == ref.shape and y.dtype == dtype
     tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
     assert (y.float() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+
+
+def test_thin_input_conv3_emulated(emu):
+    """the same two kernels as the 3x3x3 stride-1 padding-1 convolution on <= 4 input channels (UnetResBlock conv1 of encoder1):
+    forward (with a padded output channel stride) and weight gradient (with a padded dy channel stride) against conv3d / autograd
+    in fp32 on the same 16-bit operands"""
+    g = torch.Generator().manual_seed(11)
+    for (B, Cin, Cout, D, H, W, dtype) in ((1, 4, 48, 3, 8, 32, torch.bfloat16), (2, 1, 16, 2, 4, 64, torch.float16), (1, 3, 40, 2, 2, 128, torch.bfloat16)):
+        x = torch.randn(B, Cin, D, H, W, generator=g).to(dtype)
+        w = (0.1 * torch.randn(Cout, Cin, 3, 3, 3, generator=g)).to(dtype)
+        b = torch.randn(Cout, generator=g)
+        assert ops_raw.stem_conv_supported(x, w)
+        y = ops_raw.stem_conv_fwd(emu, x, w, b)
+        wr = w.float().requires_grad_()
+        ref = torch.nn.functional.conv3d(x.float(), wr, b, stride=1, padding=1)
+        assert y.shape == ref.shape and (y.float() - ref).abs().max() <= (2e-2 if dtype == torch.bfloat16 else 4e-3) * max(1.0, float(ref.abs().max()))
+        dy = torch.randn(ref.shape, generator=g).to(dtype)
+        ref.backward(dy.float())
+        x4 = ops_raw.stem_channel_last4(x)
+        assert ops_raw.stem_wgrad_supported(x4, Cout, 3)
+        dw = ops_raw.stem_conv_wgrad(emu, x4, dy, Cin, 3)
+        assert dw.shape == wr.grad.shape and (dw - wr.grad).abs().max() <= 1e-3 * max(1.0, float(wr.grad.abs().max()))
+        dyp = _channel_padded(dy, 64)                                         # dy as the instance-norm backward writes it at 128^3
+        assert torch.equal(dw, ops_raw.stem_conv_wgrad(emu, x4, dyp, Cin, 3))
 
 
 @pytest.mark.parametrize("B,Cin,Cout,D,H,W,dtype", [(1, 4, 48, 4, 8, 64, torch.bfloat16), (2, 1, 16, 2, 4, 128, torch.bfloat16),

@@ -671,3 +671,22 @@ def test_wgrad_gemm_nt_matches_fp32_product(Bn, M, N, K):
     ref = torch.einsum("bmk,bnk->mn", a.double(), b.double()).float()
     assert (out - ref).abs().max() <= 1e-3 * float(ref.abs().max())
     assert torch.equal(out, ops_raw.wgrad_gemm(hip, a, b, ops_raw.WGEMM_NT))
+
+
+def test_thin_input_conv3_matches_conv3d_at_size():
+    """the thin-input kernels as the 3x3x3 stride-1 first layer (4 -> 48 at 2 x 128^3, the BASELINE input): forward against conv3d and
+    weight gradient against autograd, fp32 on the same bf16 operands; the output comes with the padded channel stride of 128^3 volumes"""
+    hip = L.get_lib()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.rand(2, 4, 128, 128, 128, device=DEV, generator=g).bfloat16()
+    w = (0.1 * torch.randn(48, 4, 3, 3, 3, device=DEV, generator=g)).bfloat16()
+    y = ops_raw.stem_conv_fwd(hip, x, w, None)
+    assert not y.is_contiguous() and ops_raw.channel_dense(y)
+    wr = w.float().requires_grad_()
+    ref = torch.nn.functional.conv3d(x.float(), wr, None, stride=1, padding=1)
+    assert (y.float() - ref).abs().max() <= 1e-2 * max(1.0, float(ref.abs().max()))
+    dy = ops_raw.volume_empty(2, 48, (128, 128, 128), torch.bfloat16, DEV)
+    dy.copy_(torch.randn(2, 48, 128, 128, 128, device=DEV, generator=g))
+    ref.backward(dy.float())
+    dw = ops_raw.stem_conv_wgrad(hip, ops_raw.stem_channel_last4(x), dy, 4, 3)
+    assert (dw - wr.grad).abs().max() <= 1e-3 * float(wr.grad.abs().max())
