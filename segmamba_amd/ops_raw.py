@@ -362,12 +362,14 @@ _VOLUME_PAD_QUANTUM = 1 << 20     # channel sizes (bytes) that are multiples of 
 
 def volume_empty(B: int, C: int, spatial, dtype: torch.dtype, device) -> torch.Tensor:
     """(B, C, *spatial) tensor, dense inside a channel; the channel stride is padded by _VOLUME_PAD elements when the dense one
-    would be a multiple of 1 MiB (and C >= 16: with a handful of channels nothing aliases)."""
+    would be a multiple of 1 MiB (C >= 16: with a handful of channels nothing aliases; 16-bit dtypes only: fp32 volumes go to
+    vendor kernels that would copy a strided input)."""
     S = 1
     for d in spatial:
         S *= int(d)
     nbytes = S * torch.empty(0, dtype=dtype).element_size()
-    if not (_VOLUME_PAD_ON and C >= 16 and nbytes >= _VOLUME_PAD_QUANTUM and nbytes % _VOLUME_PAD_QUANTUM == 0):
+    if not (_VOLUME_PAD_ON and C >= 16 and dtype in (torch.bfloat16, torch.float16) and nbytes >= _VOLUME_PAD_QUANTUM
+            and nbytes % _VOLUME_PAD_QUANTUM == 0):
         return torch.empty(B, C, *spatial, dtype=dtype, device=device)
     buf = torch.empty(B, C, S + _VOLUME_PAD, dtype=dtype, device=device)
     return buf[:, :, :S].view(B, C, *spatial)

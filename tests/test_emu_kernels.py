@@ -326,7 +326,8 @@ def test_volume_empty_pads_power_of_two_channel_strides():
     for args in ((1, 4, (128, 128, 128), torch.bfloat16), (1, 48, (64, 64, 64), torch.bfloat16), (2, 48, (96, 96, 96), torch.float16)):
         t = ops_raw.volume_empty(*args, "cpu")
         assert t.is_contiguous() and ops_raw.channel_dense(t)
-    assert ops_raw.volume_empty(1, 16, (64, 64, 64), torch.float32, "cpu").stride(1) == 64 ** 3 + 192     # 1 MiB fp32 channels
+    assert ops_raw.volume_empty(1, 16, (128, 128, 128), torch.float16, "cpu").stride(1) == 128 ** 3 + 192
+    assert ops_raw.volume_empty(1, 16, (64, 64, 64), torch.float32, "cpu").is_contiguous()               # 16-bit dtypes only
     assert not ops_raw.channel_dense(torch.zeros(2, 4, 6, 8).permute(0, 2, 1, 3))
     assert not ops_raw.channel_dense(torch.zeros(2, 8, 6, 8)[:, :3])                 # batch stride != channels * channel stride
 
