@@ -34,6 +34,7 @@ import torch.nn.functional as F
 _BLOCK = 48                      # channel block of the library's kernels (and of MIOpen's fast 3-D bf16 solvers)
 _cache: Dict[tuple, int] = {}
 _TUNE = os.environ.get("SEGM_CONV_AUTOTUNE", "1") == "1"
+_CAT_FUSED = os.environ.get("SEGM_CONV_CAT_FUSED", "1") == "1"      # cat(up, skip) convolutions as one node, parts added in place
 
 
 def _time(fn: Callable[[], torch.Tensor], reps: int = 3) -> float:
@@ -95,19 +96,20 @@ def _hip_fwd_ok(x, w) -> bool:
         ops_raw.conv3d_k3_fwd_supported(x[:, :_BLOCK], w.shape[0])
 
 
-def _fwd_hip(x, w, pad, bias=None, chain=False, pitch48=False, chain32=False):
+def _fwd_hip(x, w, pad, bias=None, chain=False, pitch48=False, chain32=False, into=None):
     """segm_conv3d_k3_fwd per 48-channel input block (the kernel keeps one block's weights in registers).  With
     Cout % 48 == 0 the later blocks accumulate into the first block's output in place; `chain` picks the kernel whose K
-    parts are pipelined (csrc/conv3d_fwd.hip, variant 1)."""
+    parts are pipelined (csrc/conv3d_fwd.hip, variant 1).  `into`: an existing result every block is added to (the next part
+    of a concatenated input; Cout % 48 == 0, no bias)."""
     from . import lib as L, ops_raw
     hip = L.get_lib()
     inplace = w.shape[0] % _BLOCK == 0
-    out = None
+    out = into
     for i, ib in enumerate(_blocks(w.shape[1])):
         wp = ops_raw.pack_conv3d_weight(w[:, ib], x.dtype)
         if inplace:
-            out = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None, out=out, accumulate=i > 0, chain=chain,
-                                        pitch48=pitch48, chain32=chain32)
+            out = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None, out=out, accumulate=i > 0 or into is not None,
+                                        chain=chain, pitch48=pitch48, chain32=chain32)
         else:
             y = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None)
             out = y if out is None else out + y
@@ -193,32 +195,69 @@ def _mfma_wgrad_ok(x, dy, w) -> bool:
         x.shape[0] == dy.shape[0]
 
 
+_HIP_VARIANTS = ((False, False, False), (True, False, False), (True, True, False), (False, False, True))   # (chain, pitch48, chain32)
+
+
+def _fwd_candidates(x, w, bias, pad):
+    """-> (key, candidates, variant per candidate): the mathematically identical routings of one forward convolution; variant =
+    the library kernel's (chain, pitch48, chain32) flags, None for the vendor routes"""
+    hip = _hip_fwd_ok(x, w)
+    chain = hip and _hip_chain_ok(w)
+    key = _key("fwd", x, w, hip, chain, _hip_untimed_ok())
+
+    def with_bias(y):
+        return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
+
+    cands, variants = [lambda: F.conv3d(x, w, bias, 1, pad)], [None]
+    if max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0:
+        cands.append(lambda: with_bias(_fwd_blocked(x, w, pad)))
+        variants.append(None)
+    n = (1 if hip else 0) + (1 if chain else 0) + (2 if chain and _hip_untimed_ok() else 0)
+    for v in _HIP_VARIANTS[:n]:                          # bias fused into the kernel's epilogue
+        cands.append(lambda v=v: _fwd_hip(x, w, pad, bias, *v))
+        variants.append(v)
+    return key, cands, variants
+
+
+def _tuned_variant(key, cands, variants):
+    """the library-kernel variant the tuner has already picked for this key, or None (not tuned yet / a vendor route won)"""
+    if len(cands) == 1 or not _TUNE or not torch.cuda.is_available():
+        return None
+    i = _cache.get(key)
+    return variants[i] if i is not None else None
+
+
+def _dgrad(dy, w, x, pad):
+    cands = [lambda: _dgrad_native(dy, w, x, pad), lambda: _dgrad_as_fwd(dy, w, x, pad)]
+    if max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0:
+        cands.append(lambda: _dgrad_as_fwd_blocked(dy, w, x, pad))
+    hip = _hip_fwd_ok(dy, w.transpose(0, 1))
+    chain = hip and _hip_chain_ok(w.transpose(0, 1))
+    n = (1 if hip else 0) + (1 if chain else 0) + (2 if chain and _hip_untimed_ok() else 0)
+    for v in _HIP_VARIANTS[:n]:
+        cands.append(lambda v=v: _dgrad_hip(dy, w, x, pad, *v))
+    return _pick(_key("dgrad", dy, w, hip, chain, _hip_untimed_ok()), cands)
+
+
+def _wgrad(x, dy, w, pad, w_dtype):
+    cands = [lambda: _wgrad_native(x, dy, w, pad)]
+    if max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0:
+        cands.append(lambda: _wgrad_blocked(x, dy, w, pad))
+    mfma = _mfma_wgrad_ok(x, dy, w)
+    if mfma:
+        cands.append(lambda: _wgrad_mfma(x, dy, w, pad, w_dtype))
+    return _pick(_key("wgrad", x, w, mfma, w_dtype), cands).to(w_dtype)
+
+
 class _ConvSame(torch.autograd.Function):
-    """stride-1 "same" convolution, odd kernel; tensors already in the compute dtype."""
+    """stride-1 "same" convolution, odd kernel; x already in the compute dtype, w / bias in any dtype (fp32 masters under autocast)."""
 
     @staticmethod
     def forward(ctx, x, w, bias):
         from .linear import _masters
         w, bias = _masters(ctx, x, w, bias)              # fp32 masters -> the step's 16-bit copies; gradients go back in fp32
-        pad = w.shape[2] // 2
         ctx.save_for_backward(x, w)
-        hip = _hip_fwd_ok(x, w)
-        chain = hip and _hip_chain_ok(w)
-        key = _key("fwd", x, w, hip, chain, _hip_untimed_ok())
-
-        def with_bias(y):
-            return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
-
-        cands = [lambda: F.conv3d(x, w, bias, 1, pad)]
-        if max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0:
-            cands.append(lambda: with_bias(_fwd_blocked(x, w, pad)))
-        if hip:
-            cands.append(lambda: _fwd_hip(x, w, pad, bias))        # bias fused into the kernel's epilogue
-        if chain:
-            cands.append(lambda: _fwd_hip(x, w, pad, bias, True))
-            if _hip_untimed_ok():
-                cands.append(lambda: _fwd_hip(x, w, pad, bias, True, True))              # unpadded LDS rows
-                cands.append(lambda: _fwd_hip(x, w, pad, bias, False, False, True))      # 32-wide x blocks
+        key, cands, _ = _fwd_candidates(x, w, bias, w.shape[2] // 2)
         return _pick(key, cands)
 
     @staticmethod
@@ -229,32 +268,59 @@ class _ConvSame(torch.autograd.Function):
         if not ops_raw.channel_dense(dy):                # the kernels take strides; a padded channel stride is not copied
             dy = dy.contiguous()
         dx = dw = db = None
-        blockable = max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0
         if ctx.needs_input_grad[0]:
-            cands = [lambda: _dgrad_native(dy, w, x, pad), lambda: _dgrad_as_fwd(dy, w, x, pad)]
-            if blockable:
-                cands.append(lambda: _dgrad_as_fwd_blocked(dy, w, x, pad))
-            hip = _hip_fwd_ok(dy, w.transpose(0, 1))
-            if hip:
-                cands.append(lambda: _dgrad_hip(dy, w, x, pad))
-            chain = hip and _hip_chain_ok(w.transpose(0, 1))
-            if chain:
-                cands.append(lambda: _dgrad_hip(dy, w, x, pad, True))
-                if _hip_untimed_ok():
-                    cands.append(lambda: _dgrad_hip(dy, w, x, pad, True, True))
-                    cands.append(lambda: _dgrad_hip(dy, w, x, pad, False, False, True))
-            dx = _pick(_key("dgrad", dy, w, hip, chain, _hip_untimed_ok()), cands)
+            dx = _dgrad(dy, w, x, pad)
         if ctx.needs_input_grad[1]:
-            cands = [lambda: _wgrad_native(x, dy, w, pad)]
-            if blockable:
-                cands.append(lambda: _wgrad_blocked(x, dy, w, pad))
-            mfma = _mfma_wgrad_ok(x, dy, w)
-            if mfma:
-                cands.append(lambda: _wgrad_mfma(x, dy, w, pad, ctx.w_dtype))
-            dw = _pick(_key("wgrad", x, w, mfma, ctx.w_dtype), cands).to(ctx.w_dtype)
+            dw = _wgrad(x, dy, w, pad, ctx.w_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3, 4), dtype=torch.float32).to(ctx.b_dtype)
         return dx, dw, db
+
+
+class _ConvSameCat(torch.autograd.Function):
+    """conv3d_same(cat(xs, 1), w) without the concatenation AND without the adds: the convolution is linear in its input
+    channels; the first part is a plain convolution with w[:, :c0], every later part is added in place by the library kernel the
+    tuner picked for its shape (`accumulate`) - or, when a vendor route won for that shape, through an ordinary add.  One node
+    for the whole layer: the weight gradient is assembled by one cat instead of autograd's zero-fill + copy + add per slice."""
+
+    @staticmethod
+    def forward(ctx, w, *xs):
+        from .param_bank import low_precision
+        ctx.w_dtype = w.dtype
+        w = low_precision(w, xs[0].dtype)
+        pad = w.shape[2] // 2
+        ctx.save_for_backward(w, *xs)
+        out, c0 = None, 0
+        for x in xs:
+            wi = w[:, c0:c0 + x.shape[1]]
+            c0 += x.shape[1]
+            key, cands, variants = _fwd_candidates(x, wi, None, pad)
+            if out is None:
+                out = _pick(key, cands)
+                continue
+            v = _tuned_variant(key, cands, variants) if wi.shape[0] % _BLOCK == 0 else None
+            if v is not None:
+                out = _fwd_hip(x, wi, pad, None, *v, into=out)
+            else:                                        # not tuned yet (this call does it) or a vendor route won
+                out = out + _pick(key, cands)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, *xs = ctx.saved_tensors
+        pad = w.shape[2] // 2
+        from . import ops_raw
+        if not ops_raw.channel_dense(dy):
+            dy = dy.contiguous()
+        dxs, dws, c0 = [], [], 0
+        for i, x in enumerate(xs):
+            wi = w[:, c0:c0 + x.shape[1]]
+            c0 += x.shape[1]
+            dxs.append(_dgrad(dy, wi, x, pad) if ctx.needs_input_grad[1 + i] else None)
+            if ctx.needs_input_grad[0]:
+                dws.append(_wgrad(x, dy, wi, pad, ctx.w_dtype))
+        dw = torch.cat(dws, dim=1) if ctx.needs_input_grad[0] else None
+        return (dw, *dxs)
 
 
 def conv3d_same(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
@@ -271,6 +337,13 @@ def conv3d_same_cat(xs: Tuple[torch.Tensor, ...], weight: torch.Tensor) -> torch
     """conv3d_same(torch.cat(xs, 1), weight) without materialising the concatenation: the convolution is linear in
     its input channels, so it is the sum of convolutions of the parts with the matching weight slices.  (The UNETR
     decoder convolves cat(upsampled, skip), unetr_block.py:82-84; MIOpen's 96 -> 48 @128^3 solver is the 600 ms one.)"""
+    from . import lib as L
+    if _CAT_FUSED and len(xs) > 1 and all(L.on_device(x) for x in xs):
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype("cuda")
+            xs = tuple(x.to(dt) for x in xs)
+        if all(x.dtype == xs[0].dtype for x in xs):
+            return _ConvSameCat.apply(weight, *xs)
     out, c0 = None, 0
     for x in xs:
         c = x.shape[1]

@@ -132,14 +132,15 @@ class _LinearCL(torch.autograd.Function):
         return dx, dw, db
 
 
-def _pw_hip(w: torch.Tensor, x: torch.Tensor, b):
-    """w (M, K) times every x[b] (K, S) (+ bias) through segm_pointwise_cf, or None when the shape / layout is not the kernel's"""
+def _pw_hip(w: torch.Tensor, x: torch.Tensor, b, into=None):
+    """w (M, K) times every x[b] (K, S) (+ bias) through segm_pointwise_cf, or None when the shape / layout is not the kernel's;
+    `into`: an existing (B, M, S) result the product is added to"""
     if not (_PW_HIP and _on_device(x) and x.shape[2] >= _PW_MIN and x.stride(2) == 1 and w.shape[1] <= 96):
         return None
     from . import lib as L, ops_raw
     if not ops_raw.pointwise_cf_supported(x, w.shape[0]) or w.dtype != x.dtype:
         return None
-    return ops_raw.pointwise_cf(L.get_lib(), x, w, b)
+    return ops_raw.pointwise_cf(L.get_lib(), x, w, b, out=into, accumulate=into is not None)
 
 
 def _bmm_w(w: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
@@ -185,6 +186,62 @@ class _Pointwise(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2), dtype=torch.float32).to(ctx.b_dtype)
         return dx, dw, db
+
+
+class _PointwiseCat(torch.autograd.Function):
+    """_Pointwise on the channel concatenation of xs without materialising it and without the adds: y = W[:, :c0] x0 + b, every
+    later part added in place by the kernel (`accumulate`); one node, the weight gradient assembled by one cat."""
+
+    @staticmethod
+    def forward(ctx, w, b, *xs):
+        w, b = _masters(ctx, xs[0], w, b)
+        ctx.save_for_backward(w, *xs)
+        out, c0 = None, 0
+        for x in xs:
+            wi = w[:, c0:c0 + x.shape[1]]
+            c0 += x.shape[1]
+            if out is None:
+                out = _pw_hip(wi, x, b)
+                if out is None:
+                    out = _bmm_w(wi, x)
+                    if b is not None:
+                        out += b.view(1, -1, 1)
+            else:
+                y = _pw_hip(wi, x, None, into=out)
+                out = y if y is not None else out + _bmm_w(wi, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, *xs = ctx.saved_tensors
+        if dy.stride(2) != 1:
+            dy = dy.contiguous()
+        dxs, dws, c0 = [], [], 0
+        for i, x in enumerate(xs):
+            wi = w[:, c0:c0 + x.shape[1]]
+            c0 += x.shape[1]
+            dx = None
+            if ctx.needs_input_grad[2 + i]:
+                dx = _pw_hip(wi.t(), dy, None)
+                if dx is None:
+                    dx = _bmm_w(wi.t(), dy)
+            dxs.append(dx)
+            if ctx.needs_input_grad[0]:
+                dws.append(nt_matmul_rows(dy, x))
+        dw = torch.cat(dws, dim=1).to(ctx.w_dtype) if ctx.needs_input_grad[0] else None
+        db = dy.sum((0, 2), dtype=torch.float32).to(ctx.b_dtype) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        return (dw, db, *dxs)
+
+
+def pointwise_cat(xs, weight2d: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """pointwise(torch.cat(xs, 1), weight2d, bias) for channel-first parts (B, Ci, *spatial) -> (B, Cout, *spatial), or None when
+    a part is not channel-first with contiguous voxels (the caller then sums per-part results)"""
+    dt = _compute_dtype(xs[0])[0].dtype
+    flat = [x.to(dt).flatten(2) for x in xs]
+    if any(f.stride(2) != 1 for f in flat):
+        return None
+    y = _PointwiseCat.apply(weight2d, bias, *flat)
+    return y.reshape(xs[0].shape[0], weight2d.shape[0], *xs[0].shape[2:])
 
 
 def _compute_dtype(x, *ws):

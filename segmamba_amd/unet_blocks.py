@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import fused_norm
-from .conv3d import conv3d_same, conv3d_same_cat
+from .conv3d import _CAT_FUSED, conv3d_same, conv3d_same_cat
 
 
 def _same_padding(kernel_size: int, stride: int) -> int:
@@ -76,6 +76,11 @@ class ConvOnly(nn.Sequential):
             if self._same and self.conv.bias is None:
                 return conv3d_same_cat(tuple(x), weight)
             if self._pointwise:
+                from . import lib as L, linear
+                if _CAT_FUSED and all(L.on_device(part) for part in x):      # one node, the parts added in place
+                    out = linear.pointwise_cat(tuple(x), weight.reshape(weight.shape[0], weight.shape[1]), self.conv.bias)
+                    if out is not None:
+                        return out
                 out, c0 = None, 0
                 for part in x:
                     c = part.shape[1]

@@ -1116,3 +1116,70 @@ def test_pointwise_weight_gradient_takes_the_library_gemm(emu, monkeypatch):
     assert w.grad.dtype == torch.float32 and (w.grad - wr.grad).abs().max() <= 1e-4 * float(wr.grad.abs().max())
     assert b.grad.dtype == torch.float32 and (b.grad - br.grad).abs().max() <= 1e-4 * float(br.grad.abs().max())
     assert (x.grad.float() - xr.grad).abs().max() <= 2e-2 * float(xr.grad.abs().max())
+
+
+def test_concatenated_input_convolution_is_one_node_with_in_place_parts(emu, monkeypatch):
+    """conv3d_same_cat((a, b), w) - the decoder's conv1 on cat(upsampled, skip) - as ONE autograd node: the second part is
+    added in place by the library kernel (every variant), gradients of both parts and of the whole weight, against autograd of
+    conv3d on the materialised concatenation in fp32; and the route with an ordinary add (variant not tuned yet) gives the same"""
+    from segmamba_amd import lib as L, conv3d as C3
+    monkeypatch.setattr(L, "get_lib", lambda: emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
+    g = torch.Generator().manual_seed(8)
+    a = torch.randn(1, 48, 2, 3, 64, generator=g).bfloat16().requires_grad_()
+    b = torch.randn(1, 48, 2, 3, 64, generator=g).bfloat16().requires_grad_()
+    w = (0.05 * torch.randn(48, 96, 3, 3, 3, generator=g)).requires_grad_()             # fp32 master
+    dy = torch.randn(1, 48, 2, 3, 64, generator=g).bfloat16()
+    ar, br = a.detach().float().requires_grad_(), b.detach().float().requires_grad_()
+    wr = w.detach().bfloat16().float().requires_grad_()
+    ref = torch.nn.functional.conv3d(torch.cat((ar, br), 1), wr, None, 1, 1)
+    ref.backward(dy.float())
+    outs = []
+    for variant in (None,) + C3._HIP_VARIANTS:
+        monkeypatch.setattr(C3, "_tuned_variant", lambda key, cands, variants, v=variant: v)
+        for t in (a, b, w):
+            t.grad = None
+        y = C3.conv3d_same_cat((a, b), w)
+        assert type(y.grad_fn).__name__ == "_ConvSameCatBackward"
+        y.backward(dy)
+        assert (y.float() - ref).abs().max() <= 2e-2 * float(ref.abs().max()), variant
+        assert (a.grad.float() - ar.grad).abs().max() <= 2e-2 * float(ar.grad.abs().max())
+        assert (b.grad.float() - br.grad).abs().max() <= 2e-2 * float(br.grad.abs().max())
+        assert w.grad.dtype == torch.float32 and (w.grad - wr.grad).abs().max() <= 1e-3 * float(wr.grad.abs().max())
+        outs.append(y.detach().float())
+    for o in outs[1:]:
+        assert (o - outs[0]).abs().max() <= 2e-2 * float(outs[0].abs().max())         # in place (fp32 sum, one rounding) vs add (two)
+    monkeypatch.setattr(C3, "_CAT_FUSED", False)
+    assert type(C3.conv3d_same_cat((a, b), w).grad_fn).__name__ == "AddBackward0"
+
+
+def test_concatenated_input_pointwise_is_one_node_with_in_place_parts(emu, monkeypatch):
+    """linear.pointwise_cat: the decoder's 1x1x1 residual convolution on cat(upsampled, skip) as one node, second part added in
+    place by segm_pointwise_cf, against autograd of the fp32 expression on the materialised concatenation"""
+    from segmamba_amd import lib as L, linear as LN
+    monkeypatch.setattr(L, "get_lib", lambda: emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    monkeypatch.setattr(LN, "_PW_MIN", 64)
+    monkeypatch.setattr(LN, "_MIN_K", 64)
+    g = torch.Generator().manual_seed(12)
+    a = torch.randn(2, 48, 2, 4, 16, generator=g).bfloat16().requires_grad_()
+    b = torch.randn(2, 48, 2, 4, 16, generator=g).bfloat16().requires_grad_()
+    w = (0.1 * torch.randn(48, 96, generator=g)).requires_grad_()
+    bias = torch.randn(48, generator=g).requires_grad_()
+    dy = torch.randn(2, 48, 2, 4, 16, generator=g).bfloat16()
+    calls = []
+    real = ops_raw.pointwise_cf
+    monkeypatch.setattr(ops_raw, "pointwise_cf", lambda *args, **kw: (calls.append(bool(kw.get("accumulate"))), real(*args, **kw))[1])
+    y = LN.pointwise_cat((a, b), w, bias)
+    assert calls == [False, True] and type(y.grad_fn.next_functions[0][0]).__name__ == "_PointwiseCatBackward"   # behind the reshape
+    y.backward(dy)
+    ar, br = a.detach().float().requires_grad_(), b.detach().float().requires_grad_()
+    wr, biasr = w.detach().bfloat16().float().requires_grad_(), bias.detach().bfloat16().float().requires_grad_()
+    ref = torch.einsum("oc,bcdhw->bodhw", wr, torch.cat((ar, br), 1)) + biasr.view(1, -1, 1, 1, 1)
+    ref.backward(dy.float())
+    assert (y.float() - ref).abs().max() <= 2e-2 * float(ref.abs().max())
+    assert (a.grad.float() - ar.grad).abs().max() <= 2e-2 * float(ar.grad.abs().max())
+    assert (b.grad.float() - br.grad).abs().max() <= 2e-2 * float(br.grad.abs().max())
+    assert w.grad.dtype == torch.float32 and (w.grad - wr.grad).abs().max() <= 1e-3 * float(wr.grad.abs().max())
+    assert (bias.grad - biasr.grad).abs().max() <= 1e-4 * float(biasr.grad.abs().max())
