@@ -23,7 +23,8 @@ import torch
 import torch.nn as nn
 
 from . import fused_norm
-from .conv3d import _CAT_FUSED, conv3d_same, conv3d_same_cat
+from . import conv3d as _conv3d
+from .conv3d import conv3d_same, conv3d_same_cat
 
 
 def _same_padding(kernel_size: int, stride: int) -> int:
@@ -77,7 +78,7 @@ class ConvOnly(nn.Sequential):
                 return conv3d_same_cat(tuple(x), weight)
             if self._pointwise:
                 from . import lib as L, linear
-                if _CAT_FUSED and all(L.on_device(part) for part in x):      # one node, the parts added in place
+                if _conv3d._CAT_FUSED and all(L.on_device(part) for part in x):      # one node, the parts added in place
                     out = linear.pointwise_cat(tuple(x), weight.reshape(weight.shape[0], weight.shape[1]), self.conv.bias)
                     if out is not None:
                         return out

@@ -1126,6 +1126,7 @@ def test_concatenated_input_convolution_is_one_node_with_in_place_parts(emu, mon
     monkeypatch.setattr(L, "get_lib", lambda: emu)
     monkeypatch.setattr(L, "on_device", lambda t: True)
     monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
+    monkeypatch.setattr(C3, "_CAT_FUSED", True)
     g = torch.Generator().manual_seed(8)
     a = torch.randn(1, 48, 2, 3, 64, generator=g).bfloat16().requires_grad_()
     b = torch.randn(1, 48, 2, 3, 64, generator=g).bfloat16().requires_grad_()
@@ -1183,3 +1184,42 @@ def test_concatenated_input_pointwise_is_one_node_with_in_place_parts(emu, monke
     assert (b.grad.float() - br.grad).abs().max() <= 2e-2 * float(br.grad.abs().max())
     assert w.grad.dtype == torch.float32 and (w.grad - wr.grad).abs().max() <= 1e-3 * float(wr.grad.abs().max())
     assert (bias.grad - biasr.grad).abs().max() <= 1e-4 * float(biasr.grad.abs().max())
+
+
+def test_decoder_block_with_fused_concatenation_emulated(emu, monkeypatch):
+    """UnetResBlock(96 -> 48) on a (upsampled, skip) pair with SEGM_CONV_CAT_FUSED on (both cat convolutions as single nodes, parts
+    added in place) and with the default route (per-part convolutions + adds), both against the block in fp32 on the same bf16
+    inputs / weights.  bf16 rounding moves a few pre-activations across the LeakyReLU kink (single gradient entries change by
+    O(1)), so the comparison is in the Frobenius norm: both routes sit ~4 % from the fp32 gradients, the fused one no further"""
+    import torch.nn.functional as F
+    from segmamba_amd import lib as L, unet_blocks as UB, conv3d as C3, linear as LN
+    monkeypatch.setattr(L, "get_lib", lambda: emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
+    monkeypatch.setattr(C3, "_tuned_variant", lambda key, cands, variants: variants[-1])
+    monkeypatch.setattr(LN, "_PW_MIN", 64)
+    torch.manual_seed(3)
+    blk = UB.UnetResBlock(96, 48)
+    g = torch.Generator().manual_seed(9)
+    xa = torch.randn(1, 48, 2, 4, 64, generator=g).bfloat16()
+    xb = torch.randn(1, 48, 2, 4, 64, generator=g).bfloat16()
+    dy = torch.randn(1, 48, 2, 4, 64, generator=g).bfloat16()
+    w1, w2, w3 = (m.conv.weight.detach().bfloat16().float().requires_grad_() for m in (blk.conv1, blk.conv2, blk.conv3))
+    ar, br = xa.float().requires_grad_(), xb.float().requires_grad_()
+    x = torch.cat((ar, br), 1)
+    o = F.instance_norm(F.conv3d(F.leaky_relu(F.instance_norm(F.conv3d(x, w1, None, 1, 1)), 0.01), w2, None, 1, 1))
+    yr = F.leaky_relu(o + F.instance_norm(F.conv3d(x, w3)), 0.01)
+    yr.backward(dy.float())
+    refs = [yr.detach(), ar.grad, br.grad, w1.grad, w2.grad, w3.grad]
+    errs = []
+    for fused in (False, True):
+        monkeypatch.setattr(C3, "_CAT_FUSED", fused)
+        a, b = xa.clone().requires_grad_(), xb.clone().requires_grad_()
+        blk.zero_grad()
+        y = blk((a, b))
+        y.backward(dy)
+        got = [y.detach().float(), a.grad.float(), b.grad.float(), blk.conv1.conv.weight.grad, blk.conv2.conv.weight.grad, blk.conv3.conv.weight.grad]
+        errs.append([float((u - r).norm() / r.norm()) for u, r in zip(got, refs)])
+    for e0, e1 in zip(*errs):
+        assert e1 <= 8e-2 and e1 <= 1.25 * e0 + 1e-3, errs
+    assert errs[1][0] <= 1e-2                                   # the forward output itself: bf16 rounding only
