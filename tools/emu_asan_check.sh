@@ -60,5 +60,21 @@ xp = torch.randn(2, 56, 128, generator=g).bfloat16()[:, 8:48]; wpw = (0.1 * torc
 ops_raw.pointwise_cf(emu, xp, wpw, torch.randn(52)); print("pointwise_cf ok", flush=True)
 xs = torch.randn(1, 3, 2, 8, 64, generator=g).bfloat16(); ws = (0.1 * torch.randn(20, 3, 7, 7, 7, generator=g)).bfloat16()
 ops_raw.stem_conv_fwd(emu, xs, ws, torch.randn(20)); print("stem_conv_fwd ok", flush=True)
+dys = torch.randn(1, 20, 1, 4, 32, generator=g).bfloat16()
+ops_raw.stem_conv_wgrad(emu, ops_raw.stem_channel_last4(xs), dys, 3); print("stem_conv_wgrad (7^3) ok", flush=True)
+x3 = torch.randn(1, 4, 2, 8, 32, generator=g).bfloat16(); w3 = (0.1 * torch.randn(48, 4, 3, 3, 3, generator=g)).bfloat16()
+ops_raw.stem_conv_fwd(emu, x3, w3, None)
+dy3 = torch.zeros(1, 48, 2 * 8 * 32 + 64, dtype=torch.bfloat16)[:, :, :2 * 8 * 32].view(1, 48, 2, 8, 32)         # padded channel stride
+ops_raw.stem_conv_wgrad(emu, ops_raw.stem_channel_last4(x3), dy3, 4, 3); print("thin-input 3^3 forward / wgrad ok", flush=True)
+ta = torch.randn(1000, 35, generator=g).bfloat16(); tb = torch.randn(1000, 104, generator=g).bfloat16()[:, :100]
+ops_raw.wgrad_gemm(emu, ta, tb, ops_raw.WGEMM_TN)
+ta = torch.randn(300, 72, generator=g).bfloat16(); tb = torch.randn(300, 200, generator=g).bfloat16()
+ops_raw.wgrad_gemm(emu, ta, tb, ops_raw.WGEMM_TN); print("wgrad_gemm TN ok", flush=True)
+na = torch.randn(2, 48, 96, generator=g).bfloat16()[:, 8:]; nb = torch.randn(2, 20, 96, generator=g).bfloat16()
+ops_raw.wgrad_gemm(emu, na, nb, ops_raw.WGEMM_NT); print("wgrad_gemm NT ok", flush=True)
+xq = torch.full((2, 3, 5 * 6 * 8 + 24), float("nan"), dtype=torch.bfloat16)[:, :, :240].view(2, 3, 5, 6, 8)       # padded instances
+xq.copy_(torch.randn(2, 3, 5, 6, 8, generator=g))
+yq, mq, rq = ops_raw.instnorm_fwd(emu, xq, None, "leaky_relu"); ops_raw.instnorm_bwd(emu, xq, xq, mq, rq, None, "leaky_relu")
+print("instnorm on padded instances ok", flush=True)
 print("AddressSanitizer run finished without reports")
 PY
