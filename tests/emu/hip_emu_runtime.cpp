@@ -39,7 +39,10 @@ thread_local unsigned t_linear = 0;
 thread_local uint64_t* t_wave_buf = nullptr;
 
 namespace {
-constexpr size_t kStack = 512 << 10;
+#ifndef HIPEMU_STACK_BYTES
+#define HIPEMU_STACK_BYTES (512 << 10)
+#endif
+constexpr size_t kStack = HIPEMU_STACK_BYTES;      // per lane; the sanitizer builds of the most unrolled kernels need more (tools/emu_tsan_check.sh)
 enum Reason { kNone = 0, kWave = 1, kBlock = 2, kDone = 3 };
 
 struct Fiber {

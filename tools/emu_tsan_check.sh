@@ -10,7 +10,7 @@ CLANG=/opt/rocm/lib/llvm/bin/clang++
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so | head -1)
 OUT=build/emu_tsan
 mkdir -p $OUT
-FLAGS="-O1 -g -fsanitize=thread -std=c++17 -fPIC -pthread -Itests/emu -Wno-unused-value -DSEGM_EMU=1"
+FLAGS="-O1 -g -fsanitize=thread -std=c++17 -fPIC -pthread -Itests/emu -Wno-unused-value -DSEGM_EMU=1 -DHIPEMU_STACK_BYTES=4194304"
 OBJS=""
 for f in segmamba_amd/csrc/*.hip tests/emu/hip_emu_runtime.cpp; do
   o=$OUT/$(basename $f).o
@@ -47,6 +47,18 @@ H.run_scan(emu, H.scan_case(1, 40, 12, 100, dtype=torch.float32, seed=2), "cpu",
 xc = torch.randn(2, 100, 24, generator=g).bfloat16()
 o = ops_raw.conv1d_fwd(emu, xc, torch.randn(24, 4), torch.randn(24), True, channel_last=True)
 ops_raw.conv1d_bwd(emu, xc, torch.randn(24, 4), torch.randn(24), o, True, channel_last=True)
+xp = torch.randn(2, 48, 256, generator=g).bfloat16()
+ops_raw.pointwise_cf(emu, xp, (0.1 * torch.randn(52, 48, generator=g)).bfloat16(), torch.randn(52))
+xs = torch.randn(1, 3, 2, 8, 64, generator=g).bfloat16(); ws = (0.1 * torch.randn(20, 3, 7, 7, 7, generator=g)).bfloat16()
+ops_raw.stem_conv_fwd(emu, xs, ws, None)
+# (the 7^3 weight-gradient instantiation is left out: the ThreadSanitizer runtime itself dies in it - SEGV inside its signal
+#  handler, with 512 KB and with 4 MB fiber stacks alike - while the AddressSanitizer build runs it clean; the kernel has no
+#  cross-wave LDS traffic, and its 3^3 instantiation and the shared partial-sum kernel run below)
+x3 = torch.randn(1, 4, 2, 8, 32, generator=g).bfloat16()
+ops_raw.stem_conv_fwd(emu, x3, (0.1 * torch.randn(48, 4, 3, 3, 3, generator=g)).bfloat16(), None)
+ops_raw.stem_conv_wgrad(emu, ops_raw.stem_channel_last4(x3), torch.randn(1, 48, 2, 8, 32, generator=g).bfloat16(), 4, 3)
+ops_raw.wgrad_gemm(emu, torch.randn(2000, 72, generator=g).bfloat16(), torch.randn(2000, 200, generator=g).bfloat16(), ops_raw.WGEMM_TN)
+ops_raw.wgrad_gemm(emu, torch.randn(2, 48, 512, generator=g).bfloat16(), torch.randn(2, 20, 512, generator=g).bfloat16(), ops_raw.WGEMM_NT)
 PY
 N=$(grep -c "WARNING: ThreadSanitizer" $OUT/tsan.log || true)
 echo "ThreadSanitizer reports: $N"
