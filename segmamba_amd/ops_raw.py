@@ -385,7 +385,18 @@ def channel_dense(x: torch.Tensor) -> bool:
         if x.shape[i] != 1 and x.stride(i) != s:
             return False
         s *= x.shape[i]
-    return x.stride(1) >= s and x.stride(0) == x.shape[1] * x.stride(1)
+    if x.shape[1] == 1:                                   # one channel: the batch stride is the instance stride
+        return x.shape[0] == 1 or x.stride(0) >= s
+    return x.stride(1) >= s and (x.shape[0] == 1 or x.stride(0) == x.shape[1] * x.stride(1))
+
+
+def instance_stride(x: torch.Tensor) -> int:
+    """elements between consecutive (b, c) instances of a channel_dense tensor (strides of size-1 dimensions mean nothing)"""
+    if x.shape[1] > 1:
+        return x.stride(1)
+    if x.shape[0] > 1:
+        return x.stride(0)
+    return x[0, 0].numel()
 
 
 def _norm_geom(x):
@@ -404,8 +415,8 @@ def instnorm_fwd(lib: L.SegmLib, x, residual=None, act="none", slope=0.01, eps=1
     a.instances, a.dtype, a.act, a.spatial = inst, L.dtype_code(x), ACT_CODES[act], S
     a.slope, a.eps = float(slope), float(eps)
     y = volume_empty(x.shape[0], x.shape[1], x.shape[2:], x.dtype, x.device)
-    a.x_instance_stride, a.y_instance_stride = x.stride(1), y.stride(1)
-    a.residual_instance_stride = residual.stride(1) if residual is not None else 0
+    a.x_instance_stride, a.y_instance_stride = instance_stride(x), instance_stride(y)
+    a.residual_instance_stride = instance_stride(residual) if residual is not None else 0
     mean = torch.empty(inst, dtype=torch.float32, device=x.device)
     rstd = torch.empty(inst, dtype=torch.float32, device=x.device)
     ws_bytes = lib.dll.segm_instnorm_workspace_bytes(inst, S)
@@ -431,9 +442,9 @@ def instnorm_bwd(lib: L.SegmLib, x, dy, mean, rstd, y=None, act="none", slope=0.
         raise RuntimeError("instnorm: y must match x (shape, dtype, dense channels)")
     dx = volume_empty(x.shape[0], x.shape[1], x.shape[2:], x.dtype, x.device)
     dres = volume_empty(x.shape[0], x.shape[1], x.shape[2:], x.dtype, x.device) if want_dresidual else None
-    a.x_instance_stride, a.dy_instance_stride, a.dx_instance_stride = x.stride(1), dy.stride(1), dx.stride(1)
-    a.y_instance_stride = y.stride(1) if y is not None else 0
-    a.dresidual_instance_stride = dres.stride(1) if dres is not None else 0
+    a.x_instance_stride, a.dy_instance_stride, a.dx_instance_stride = instance_stride(x), instance_stride(dy), instance_stride(dx)
+    a.y_instance_stride = instance_stride(y) if y is not None else 0
+    a.dresidual_instance_stride = instance_stride(dres) if dres is not None else 0
     ws_bytes = lib.dll.segm_instnorm_workspace_bytes(inst, S)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     a.x, a.dy, a.y = x.data_ptr(), dy.data_ptr(), (y.data_ptr() if y is not None else None)

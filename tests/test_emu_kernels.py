@@ -328,6 +328,8 @@ def test_volume_empty_pads_power_of_two_channel_strides():
         assert t.is_contiguous() and ops_raw.channel_dense(t)
     assert ops_raw.volume_empty(1, 16, (128, 128, 128), torch.float16, "cpu").stride(1) == 128 ** 3 + 192
     assert ops_raw.volume_empty(1, 16, (64, 64, 64), torch.float32, "cpu").is_contiguous()               # 16-bit dtypes only
+    one = torch.zeros(2, 1, 6 * 8 + 5)[:, :, :48].view(2, 1, 6, 8)                    # one channel: the batch stride is the instance stride
+    assert ops_raw.channel_dense(one) and ops_raw.instance_stride(one) == 53 and ops_raw.instance_stride(v) == v.stride(1)
     assert not ops_raw.channel_dense(torch.zeros(2, 4, 6, 8).permute(0, 2, 1, 3))
     assert not ops_raw.channel_dense(torch.zeros(2, 8, 6, 8)[:, :3])                 # batch stride != channels * channel stride
 

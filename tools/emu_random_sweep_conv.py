@@ -1,0 +1,127 @@
+"""Randomised sweep of the round-2 conv-stem kernels on the CPU emulation against fp32 torch (test infrastructure).
+    python tools/emu_random_sweep_conv.py [ncases] [seed]
+segm_wgrad_gemm (TN / NT), segm_pointwise_cf (+ accumulate), the thin-input kernels (7^3 stride 2 and 3^3 stride 1, forward and
+weight gradient) and the instance-norm kernels on padded instances: random shapes, strides, dtypes; prints the failing
+configuration and exits non-zero on the first mismatch."""
+import os, random, sys
+import torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.emu_util import emu_lib
+from segmamba_amd import ops_raw
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+emu = emu_lib()
+
+
+def padded(t, pad):
+    """same values, channel (dim 1) stride padded by `pad` elements, padding NaN"""
+    if pad == 0:
+        return t
+    B, C = t.shape[:2]
+    S = t[0, 0].numel()
+    buf = torch.full((B, C, S + pad), float("nan"), dtype=t.dtype)
+    v = buf[:, :, :S].view(t.shape)
+    v.copy_(t)
+    return v
+
+
+def close(got, ref, tol, what):
+    err = float((got.float() - ref).abs().max())
+    lim = tol * max(1.0, float(ref.abs().max()))
+    if not err <= lim:
+        raise AssertionError(f"{what}: max error {err} > {lim}")
+
+
+for case in range(n):
+    g = torch.Generator().manual_seed(5000 + case)
+    dtype = rng.choice([torch.bfloat16, torch.bfloat16, torch.float16])
+    tol16 = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    kind = rng.choice(["tn", "nt", "pointwise", "thin7", "thin3", "instnorm"])
+    cfg = dict(kind=kind, dtype=str(dtype))
+    try:
+        if kind == "tn":
+            K, M, N = rng.choice([33, 96, 500, 1024, 2050]), rng.choice([3, 8, 35, 48, 64, 65, 100, 192]), rng.choice([3, 6, 38, 96, 97, 130, 200])
+            lda, ldb = M + rng.choice([0, 0, 1, 5, 8]), N + rng.choice([0, 0, 3, 8])
+            cfg.update(K=K, M=M, N=N, lda=lda, ldb=ldb)
+            a = torch.randn(K, lda, generator=g).to(dtype)[:, :M]
+            b = torch.randn(K, ldb, generator=g).to(dtype)[:, :N]
+            close(ops_raw.wgrad_gemm(emu, a, b, ops_raw.WGEMM_TN), a.float().t() @ b.float(), 1e-4, "wgrad_gemm TN")
+        elif kind == "nt":
+            Bn, M, N, K = rng.choice([1, 2, 3]), rng.choice([1, 4, 16, 40, 48, 50, 96]), rng.choice([2, 4, 20, 48, 80, 96]), 32 * rng.choice([1, 2, 5, 16, 33])
+            off = rng.choice([0, 8])
+            cfg.update(B=Bn, M=M, N=N, K=K, off=off)
+            a = torch.randn(Bn, M + off, K, generator=g).to(dtype)[:, off:]
+            b = torch.randn(Bn, N, K, generator=g).to(dtype)
+            close(ops_raw.wgrad_gemm(emu, a, b, ops_raw.WGEMM_NT), torch.einsum("bmk,bnk->mn", a.float(), b.float()), 1e-4, "wgrad_gemm NT")
+        elif kind == "pointwise":
+            Bn, Cin, Cout, S = rng.choice([1, 2]), rng.choice([4, 8, 24, 40, 48, 96]), rng.choice([4, 16, 33, 48, 96]), 64 * rng.choice([1, 2, 5])
+            padx, pady, bias, acc = rng.choice([0, 64, 192]), rng.choice([0, 64]), rng.random() < 0.5, rng.random() < 0.4
+            cfg.update(B=Bn, Cin=Cin, Cout=Cout, S=S, padx=padx, pady=pady, bias=bias, acc=acc)
+            x = padded(torch.randn(Bn, Cin, S, generator=g).to(dtype), padx)
+            w = (0.2 * torch.randn(Cout, Cin, generator=g)).to(dtype)
+            bv = torch.randn(Cout, generator=g) if bias else None
+            ref = torch.einsum("oc,bcs->bos", w.float(), x.float()) + (bv.view(1, -1, 1) if bias else 0)
+            out = None
+            if acc:
+                y0 = torch.randn(Bn, Cout, S, generator=g).to(dtype)
+                out = padded(y0.clone(), pady)
+                ref = ref + y0.float()
+            elif pady:
+                out = padded(torch.zeros(Bn, Cout, S, dtype=dtype), pady)
+            y = ops_raw.pointwise_cf(emu, x, w, bv, out=out, accumulate=acc)
+            close(y, ref, tol16, "pointwise_cf")
+        elif kind in ("thin7", "thin3"):
+            k, s = (7, 2) if kind == "thin7" else (3, 1)
+            Bn, Cin, Cout = rng.choice([1, 2]), rng.choice([1, 2, 3, 4]), rng.choice([8, 16, 20, 32, 48])
+            D, H = s * rng.choice([1, 2, 3]), s * rng.choice([1, 2, 4, 8])
+            W = rng.choice([64, 128] if k == 7 else [32, 64, 128])
+            x = torch.randn(Bn, Cin, D, H, W, generator=g).to(dtype)
+            w = (0.1 * torch.randn(Cout, Cin, k, k, k, generator=g)).to(dtype)
+            cfg.update(B=Bn, Cin=Cin, Cout=Cout, D=D, H=H, W=W)
+            if not ops_raw.stem_conv_supported(x, w):
+                print(f"skip {case:3d} {cfg}")
+                continue
+            bv = torch.randn(Cout, generator=g) if rng.random() < 0.5 else None
+            wr = w.float().requires_grad_()
+            ref = F.conv3d(x.float(), wr, bv, stride=s, padding=k // 2)
+            close(ops_raw.stem_conv_fwd(emu, x, w, bv), ref.detach(), tol16, "stem_conv_fwd")
+            dy = torch.randn(ref.shape, generator=g).to(dtype)
+            ref.backward(dy.float())
+            x4 = ops_raw.stem_channel_last4(x)
+            if ops_raw.stem_wgrad_supported(x4, Cout, k):
+                pad = rng.choice([0, 64])
+                cfg.update(dy_pad=pad)
+                close(ops_raw.stem_conv_wgrad(emu, x4, padded(dy, pad), Cin, k), wr.grad, 1e-3, "stem_conv_wgrad")
+        else:
+            shape = (rng.choice([1, 2]), rng.choice([1, 3, 5]), rng.choice([2, 3, 4]), rng.choice([4, 5, 8]), rng.choice([7, 8, 16, 24]))
+            act, with_res = rng.choice(["none", "relu", "leaky_relu"]), rng.random() < 0.5
+            dt = rng.choice([dtype, torch.float32])
+            pads = [rng.choice([0, 8, 24, 5]) for _ in range(4)]
+            cfg.update(shape=shape, act=act, res=with_res, dt=str(dt), pads=pads)
+            x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(dt)
+            res = torch.randn(shape, generator=g).to(dt) if with_res else None
+            gy = torch.randn(shape, generator=g).to(dt)
+            y0, m0, r0 = ops_raw.instnorm_fwd(emu, x, res, act, 0.01, 1e-5)
+            ym = y0 if (with_res and act != "none") else None
+            dx0, dr0 = ops_raw.instnorm_bwd(emu, x, gy, m0, r0, ym, act, 0.01, want_dresidual=with_res)
+            xp, rp, gp = padded(x, pads[0]), (padded(res, pads[1]) if with_res else None), padded(gy, pads[2])
+            y1, m1, r1 = ops_raw.instnorm_fwd(emu, xp, rp, act, 0.01, 1e-5)
+            ymp = padded(ym, pads[3]) if ym is not None else None
+            dx1, dr1 = ops_raw.instnorm_bwd(emu, xp, gp, m1, r1, ymp, act, 0.01, want_dresidual=with_res)
+            if all(p % 8 == 0 for p in pads):             # same (vector) path as the dense tensors: bit-identical
+                if not (torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(dx0, dx1) and (not with_res or torch.equal(dr0, dr1))):
+                    raise AssertionError("instnorm: padded instances differ from dense ones")
+            else:                                         # odd strides take the scalar path: another summation order
+                t = 1e-5 if dt == torch.float32 else 3e-2
+                close(y1, y0.float(), t, "instnorm_fwd padded vs dense")
+                close(dx1, dx0.float(), 20 * t, "instnorm_bwd padded vs dense")
+            pre = F.instance_norm(x.float(), eps=1e-5) + (res.float() if with_res else 0)
+            ref = pre if act == "none" else (F.relu(pre) if act == "relu" else F.leaky_relu(pre, 0.01))
+            close(y1, ref, 1e-4 if dt == torch.float32 else 3e-2, "instnorm_fwd")
+    except Exception as e:                                   # noqa: BLE001 - report the configuration, then fail
+        print("FAILED", cfg, "\n", repr(e)[:600])
+        sys.exit(1)
+    print(f"ok {case:3d} {cfg}", flush=True)
+print("all", n, "cases agree")
