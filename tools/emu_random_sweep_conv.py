@@ -38,7 +38,7 @@ for case in range(n):
     g = torch.Generator().manual_seed(5000 + case)
     dtype = rng.choice([torch.bfloat16, torch.bfloat16, torch.float16])
     tol16 = 2e-2 if dtype == torch.bfloat16 else 4e-3
-    kind = rng.choice(["tn", "nt", "pointwise", "thin7", "thin3", "instnorm"])
+    kind = rng.choice(["tn", "nt", "pointwise", "thin7", "thin3", "instnorm", "conv3", "conv3", "wgrad3"])
     cfg = dict(kind=kind, dtype=str(dtype))
     try:
         if kind == "tn":
@@ -94,6 +94,39 @@ for case in range(n):
                 pad = rng.choice([0, 64])
                 cfg.update(dy_pad=pad)
                 close(ops_raw.stem_conv_wgrad(emu, x4, padded(dy, pad), Cin, k), wr.grad, 1e-3, "stem_conv_wgrad")
+        elif kind == "conv3":
+            # 3x3x3 forward: every kernel variant, XCD-mapped and unmapped grids (the item count is a multiple of 8 or not), 1 - 3
+            # blocks of 48 output channels folded into the item order, narrow first blocks, padded channel strides, accumulation
+            Bn, cin, cout = rng.choice([1, 2, 3]), rng.choice([4, 16, 48, 48, 96]), rng.choice([16, 32, 48, 48, 96, 144])
+            if cin > 48 and cout % 48:                   # later input blocks accumulate in place: a feature of the 48-channel kernels
+                cout = 48
+            D, H, W = rng.choice([1, 2, 3, 4, 8]), rng.choice([1, 3, 8, 9, 16]), rng.choice([8, 16, 40, 64, 72])
+            padx, pady = rng.choice([0, 64]), rng.choice([0, 64])
+            variants = [dict()] + ([dict(chain=True), dict(chain=True, pitch48=True), dict(chain32=True)] if cout % 48 == 0 else [])
+            kw = rng.choice(variants)
+            cfg.update(B=Bn, cin=cin, cout=cout, D=D, H=H, W=W, padx=padx, pady=pady, kw=kw)
+            x = padded(torch.randn(Bn, cin, D, H, W, generator=g).to(dtype), padx)
+            w = (0.05 * torch.randn(cout, cin, 3, 3, 3, generator=g)).to(dtype)
+            bv = torch.randn(cout, generator=g) if rng.random() < 0.5 else None
+            ref = F.conv3d(x.float(), w.float(), bv, 1, 1)
+            out = None
+            for i, c0 in enumerate(range(0, cin, 48)):
+                blk = slice(c0, min(c0 + 48, cin))
+                if i == 0 and pady:
+                    out = padded(torch.zeros(Bn, cout, D, H, W, dtype=dtype), pady)
+                out = ops_raw.conv3d_k3_fwd(emu, x[:, blk], ops_raw.pack_conv3d_weight(w[:, blk], dtype), bv if i == 0 else None, out=out,
+                                            accumulate=i > 0, **kw)
+            close(out, ref, tol16 * 1.5, "conv3d_k3_fwd")
+        elif kind == "wgrad3":
+            Bn, cin, cout = rng.choice([1, 2]), rng.choice([4, 48, 96]), rng.choice([48, 96])
+            D, H, W = rng.choice([1, 2, 4, 8]), rng.choice([2, 8, 9]), rng.choice([8, 16, 40, 64])
+            padx, pady = rng.choice([0, 64]), rng.choice([0, 64])
+            cfg.update(B=Bn, cin=cin, cout=cout, D=D, H=H, W=W, padx=padx, pady=pady)
+            x = padded(torch.randn(Bn, cin, D, H, W, generator=g).to(dtype), padx)
+            dy = padded(torch.randn(Bn, cout, D, H, W, generator=g).to(dtype), pady)
+            wr = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+            F.conv3d(x.float(), wr, None, 1, 1).backward(dy.float())
+            close(ops_raw.conv3d_k3_wgrad(emu, x, dy, torch.float32), wr.grad, 1e-3, "conv3d_k3_wgrad")
         else:
             shape = (rng.choice([1, 2]), rng.choice([1, 3, 5]), rng.choice([2, 3, 4]), rng.choice([4, 5, 8]), rng.choice([7, 8, 16, 24]))
             act, with_res = rng.choice(["none", "relu", "leaky_relu"]), rng.random() < 0.5
