@@ -16,6 +16,9 @@ from segmamba_amd import ops_raw
 from oracle import ref_ops
 
 pytestmark = pytest.mark.skipif(not emu_util.emu_available(), reason="ROCm host clang not present")
+# the fp32 references of this file are torch CPU convolutions: oneDNN's weight gradient of strided 3-D convolutions returns
+# garbage for some shapes on this PyTorch build (tools/emu_random_sweep_conv.py found one), the native path does not
+torch.backends.mkldnn.enabled = False
 
 
 @pytest.fixture(scope="module")

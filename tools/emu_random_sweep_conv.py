@@ -10,6 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.emu_util import emu_lib
 from segmamba_amd import ops_raw
 
+# oneDNN's fp32 weight gradient of strided 3-D convolutions returns garbage for some shapes on this PyTorch build (found by this
+# sweep: 2 x 1 x 6 x 8 x 64 -> 48, kernel 7, stride 2: the whole kz = 5 plane, against fp64 and against the native path): the
+# references here run without it
+torch.backends.mkldnn.enabled = False
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 emu = emu_lib()
