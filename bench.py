@@ -330,7 +330,10 @@ def main():
                                     "bf16 autocast, CE loss, clip 12, SGD nesterov") if not dry else
                                    "tiny SegMamba, 1x4x32^3 per process, plumbing only",
                        "volumes_per_gpu": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}", "ddp": ddp,
-                       "loss": round(float(loss), 5)},
+                       "loss": round(float(loss), 5),
+                       # host-side arrangements that do not change the arithmetic: the step's 16-bit parameter copies in one launch
+                       # (param_bank.py), 128^3 volumes with a padded channel stride (ops_raw.volume_empty)
+                       "param_bank": state.bank is not None, "volume_pad": os.environ.get("SEGM_VOLUME_PAD", "1") == "1"},
         }
         if not args.no_roofline and not dry:
             out["inference"] = inference_rate(state, device, args.size)
