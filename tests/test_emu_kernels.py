@@ -1228,3 +1228,31 @@ def test_decoder_block_with_fused_concatenation_emulated(emu, monkeypatch):
     for e0, e1 in zip(*errs):
         assert e1 <= 8e-2 and e1 <= 1.25 * e0 + 1e-3, errs
     assert errs[1][0] <= 1e-2                                   # the forward output itself: bf16 rounding only
+
+
+def test_every_routing_candidate_of_the_conv_dispatcher_runs_and_agrees(emu, monkeypatch):
+    """conv3d.py's tuner runs EVERY candidate of a key once (timing) before it picks: here each candidate of the forward, the data
+    gradient and the weight gradient of a 96 -> 48 layer is executed (vendor routes on the CPU, library routes on the emulator) and
+    compared with the first one - what the GPU's first step does, minus the clock"""
+    from segmamba_amd import lib as L, conv3d as C3
+    monkeypatch.setattr(L, "get_lib", lambda: emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    seen = {}
+
+    def run_all(key, cands):
+        outs = [c() for c in cands]
+        seen[key[0]] = len(cands)
+        for o in outs[1:]:
+            assert o.shape == outs[0].shape
+            assert (o.float() - outs[0].float()).abs().max() <= 3e-2 * max(1.0, float(outs[0].float().abs().max())), key[0]
+        return outs[-1]
+
+    monkeypatch.setattr(C3, "_pick", run_all)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 96, 2, 4, 16, generator=g).bfloat16().requires_grad_()
+    w = (0.05 * torch.randn(48, 96, 3, 3, 3, generator=g)).requires_grad_()                 # fp32 master
+    b = torch.randn(48, generator=g).requires_grad_()
+    y = C3.conv3d_same(x, w, b)
+    y.backward(torch.randn(y.shape, generator=g).bfloat16())
+    assert seen == {"fwd": 6, "dgrad": 7, "wgrad": 3}, seen       # vendor, blocked, four library variants (+ dgrad-as-forward)
+    assert w.grad.dtype == torch.float32 and b.grad.dtype == torch.float32 and x.grad.dtype == torch.bfloat16
