@@ -70,6 +70,8 @@ def parse():
     p.add_argument("--batch", type=int, default=2, help="volumes per GPU")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-configs", action="store_true", help="skip the BASELINE config 1 / config 4 measurements")
+    p.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a captured HIP graph")
     p.add_argument("--cpu-baseline-full", action="store_true", help="add the whole-network 64^3 / 32^3 fwd+bwd CPU legs (~80 s)")
     p.add_argument("--cpu-dry-run", action="store_true",
                    help="plumbing check without a GPU: gloo, CPU tensors, a tiny SegMamba on the CPU emulation of the kernels "
@@ -149,7 +151,7 @@ def scan_roofline(dtype, device):
     elems_per_simd = B * D * Lq / 64 / 1024                    # wave-steps per SIMD (256 CUs x 4 SIMDs)
     cyc_taken = ms_f * 1e-3 * 2.1e9 / elems_per_simd
     return {
-        "bound": "hbm", "kernel": "selective_scan_fwd (scan_fwd_agg + scan_carry + scan_fwd_apply)",
+        "bound": "valu", "priced_against": "hbm", "kernel": "selective_scan_fwd (scan_fwd_agg + scan_carry + scan_fwd_apply)",
         "shape": {"B": B, "D": D, "N": N, "L": Lq, "layout": "channel-last", "chunk": f["chunk"]},
         "achieved": round(gf, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gf / HBM_PEAK_GBPS, 4),
         "ms": round(ms_f, 4), "algorithmic_bytes": bytes_f,
@@ -157,10 +159,85 @@ def scan_roofline(dtype, device):
         "valu": {"bound": "valu-issue", "cycles_needed_per_wave_step": cyc_needed,
                  "cycles_taken_per_wave_step_at_2.1GHz": round(cyc_taken, 1), "frac": round(cyc_needed / cyc_taken, 4),
                  "busy_cycles_per_wave_step_SQ_counters": {"aggregate": 304, "apply": 402, "source": "profiles/r02_scan_pmc_bwd2.txt"}},
-        "note": "the true bound is VALU issue (v_exp_f32 per step and state, two passes), not HBM: read `frac` with `valu.frac`",
+        "note": "bound = what limits the kernel: VALU issue (one v_exp_f32 per step and state in each of the two passes). "
+                "achieved / peak / frac price it against the HBM roofline BASELINE.json's metric names (algorithmic bytes / time "
+                "vs 8 TB/s); valu.frac prices the same launch against the measured VALU issue ceiling",
         "backward": {"achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4), "ms": round(ms_b, 4),
                      "algorithmic_bytes": bytes_b},
     }
+
+
+def config1_mamba_block(device):
+    """BASELINE config 1: one Mamba(d_model=384, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=64) block, forward and
+    forward + backward on randn(2, 64^3, 384) under bf16 autocast.  Per direction the scan moves
+    e B L (5D + 2N) bytes forward and B L (e (8D + 2N) + 8N) backward (D = 768)."""
+    from segmamba_amd.mamba_simple import Mamba
+    torch.manual_seed(0)
+    B, Lq, dm, N = 2, 64 ** 3, 384, 16
+    m = Mamba(d_model=dm, d_state=N, d_conv=4, expand=2, bimamba_type="v3", nslices=64).to(device)
+    x = torch.randn(B, Lq, dm, device=device, generator=torch.Generator(device=device).manual_seed(0))
+    g = torch.randn(B, Lq, dm, device=device, generator=torch.Generator(device=device).manual_seed(1)).to(torch.bfloat16)
+
+    def fwd():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return m(x)
+
+    def fwd_bwd():
+        for p in m.parameters():
+            p.grad = None
+        xx = x.detach().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(xx)
+        y.backward(g)
+    ms_f = time_gpu(fwd, 5, warmup=2)
+    ms_fb = time_gpu(fwd_bwd, 5, warmup=2)
+    D = 2 * dm
+    bf = 3 * algorithmic_bytes_scan(B, D, Lq, N, 2)
+    bb = 3 * algorithmic_bytes_scan(B, D, Lq, N, 2, backward=True)
+    return {"workload": "Mamba(d_model=384,d_state=16,v3,nslices=64) on (2, 262144, 384), bf16 autocast, three directions",
+            "fwd_ms": round(ms_f, 3), "fwd_bwd_ms": round(ms_fb, 3),
+            "scan_algorithmic_bytes": {"fwd": bf, "bwd": bb},
+            "whole_block_vs_scan_bytes_GBps": {"fwd": round(bf / ms_f * 1e-6, 1), "fwd_bwd": round((bf + bb) / ms_fb * 1e-6, 1)},
+            "note": "the block also runs in_proj / conv1d / x_proj / dt_proj / out_proj; GB/s = scan bytes over whole-block time"}
+
+
+def config4_long_scan(device):
+    """BASELINE config 4: the standalone scan forward and backward at B=1, D=96, N=16, L = 2^21 (what the stem yields for a
+    256^3 volume) and L = 2^24 (the figure BASELINE.json quotes), bf16 and fp32 I/O, channel-last rows."""
+    from segmamba_amd import lib as L, ops_raw
+    hip = L.get_lib()
+    out = {}
+    for Lq in (1 << 21, 1 << 24):
+        for dtype, name in ((torch.bfloat16, "bf16"), (torch.float32, "fp32")):
+            B, D, N = 1, 96, 16
+            g = torch.Generator(device=device).manual_seed(0)
+            rn = lambda *s: torch.randn(*s, device=device, generator=g).to(dtype)
+            u, z, dout = rn(B, Lq, D), rn(B, Lq, D), rn(B, Lq, D)
+            delta = (0.5 * torch.rand(B, Lq, D, device=device, generator=g)).to(dtype)
+            A = -0.5 * torch.rand(D, N, device=device, generator=g)
+            Bm, Cm = rn(B, Lq, N), rn(B, Lq, N)
+            Dv = torch.randn(D, device=device, generator=g)
+            db = 0.5 * torch.rand(D, device=device, generator=g)
+
+            def fwd():
+                return ops_raw.scan_fwd(hip, u, delta, A, Bm, Cm, Dv, z, db, True, channel_last=True, need_out=True, need_ckpt=True)
+            f = fwd()
+
+            def bwd():
+                return ops_raw.scan_bwd(hip, u, delta, A, Bm, Cm, Dv, z, db, dout, f["out"], f["ckpt"], True, channel_last=True,
+                                        chunk=f["chunk"])
+            it = 6 if Lq < (1 << 23) else 3
+            ms_f, ms_b = time_gpu(fwd, it, warmup=1), time_gpu(bwd, it, warmup=1)
+            es = u.element_size()
+            bf, bb = algorithmic_bytes_scan(B, D, Lq, N, es), algorithmic_bytes_scan(B, D, Lq, N, es, backward=True)
+            out[f"L{Lq}_{name}"] = {"fwd_ms": round(ms_f, 3), "bwd_ms": round(ms_b, 3),
+                                    "fwd_GBps": round(bf / ms_f * 1e-6, 1), "bwd_GBps": round(bb / ms_b * 1e-6, 1),
+                                    "fwd_frac": round(bf / ms_f * 1e-6 / HBM_PEAK_GBPS, 4),
+                                    "bwd_frac": round(bb / ms_b * 1e-6 / HBM_PEAK_GBPS, 4), "chunk": f["chunk"]}
+            del u, z, dout, delta, Bm, Cm, f
+            torch.cuda.empty_cache()
+    out["shape"] = {"B": 1, "D": 96, "N": 16, "layout": "channel-last", "peak_GBps": HBM_PEAK_GBPS}
+    return out
 
 
 def inference_rate(state, device, size):
@@ -297,6 +374,22 @@ def main():
         image, label = data.next()
         return train_step(state, image, label)
 
+    # The forward + backward bracket as ONE captured HIP graph (trainer.GraphedStep); the batch is copied into the graph's
+    # static input buffers every step, the all-reduce / optimizer / scheduler run eagerly behind the replay.  The capture
+    # warm-up runs the bracket without an optimizer step, so it is not part of --warmup.
+    graph_note = "off (--no-graph / SEGM_GRAPH=0)"
+    if state.flat and not dry and not args.no_graph and os.environ.get("SEGM_GRAPH", "1") == "1":
+        from segmamba_amd.trainer import GraphedStep
+        try:
+            GraphedStep(state, *data.next())
+            graph_note = "hipGraph replay of forward + backward"
+        except Exception as e:                              # noqa: BLE001 - any capture failure: eager launches, reason reported
+            state.graphed = None
+            torch.cuda.synchronize()
+            graph_note = f"capture failed, eager launches: {type(e).__name__}: {str(e)[:200]}"
+    elif not state.flat:
+        graph_note = "off (no flat-gradient state: torch DDP wrapper, fp16 GradScaler loop or CPU dry run)"
+
     for _ in range(args.warmup):
         step()
     if distributed:
@@ -309,36 +402,60 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
+    allreduce_ms = None
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
+        elapsed = max(float(x.item()) for x in every)                # MAX over ranks
+        if state.flat and not dry:                                   # the exchange step on its own: one all-reduce of the flat gradients
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dist.all_reduce(state.bank.flat_grad)
+            torch.cuda.synchronize()
+            e0.record()
+            dist.all_reduce(state.bank.flat_grad)
+            e1.record()
+            e1.synchronize()
+            allreduce_ms = round(e0.elapsed_time(e1), 3)
 
     if rank == 0:
         vols = world * args.batch * args.steps
         ddp = None
         if distributed:
-            ddp = dict(DDP_SETTINGS)
+            ddp = {"mode": "flat: one all-reduce of the flat fp32 gradient array per step, no wrapper"} if state.flat else dict(DDP_SETTINGS, mode="torch DistributedDataParallel")
             ddp["backend"] = "gloo (cpu dry run)" if dry else "nccl = RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+            ddp["rank_ms_per_step"] = {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)}
+            if state.flat:
+                ddp["gradient_bytes"] = int(state.bank.flat_grad.numel()) * 4
+                ddp["allreduce_ms"] = allreduce_ms
+        amp_name = {torch.bfloat16: "bf16", torch.float16: "fp16"}.get(state.autocast_dtype, str(state.autocast_dtype))
         out = {
             "metric": f"volumes/sec fwd+bwd+step, SegMamba {args.size}^3x4 (whole job; divide by n_gpus for per-GPU)",
             "value": round(vols / elapsed, 4), "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "fp32 (cpu dry run)" if dry else "bf16",
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp32 (cpu dry run)" if dry else amp_name,
             "data": "synthetic" if not dry else "synthetic; CPU DRY RUN on emulated kernels with a tiny model - not a measurement",
             "config": {"workload": (f"SegMamba(4->4,[2,2,2,2],[48,96,192,384]) train step, {args.batch}x4x{args.size}^3 per GPU, "
-                                    "bf16 autocast, CE loss, clip 12, SGD nesterov") if not dry else
+                                    f"{amp_name} autocast, CE loss, clip 12, SGD nesterov") if not dry else
                                    "tiny SegMamba, 1x4x32^3 per process, plumbing only",
                        "volumes_per_gpu": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}", "ddp": ddp,
                        "loss": round(float(loss), 5),
                        # host-side arrangements that do not change the arithmetic: the step's 16-bit parameter copies in one launch
                        # (param_bank.py), 128^3 volumes with a padded channel stride (ops_raw.volume_empty)
-                       "param_bank": state.bank is not None, "volume_pad": os.environ.get("SEGM_VOLUME_PAD", "1") == "1"},
+                       "param_bank": state.bank is not None, "volume_pad": os.environ.get("SEGM_VOLUME_PAD", "1") == "1",
+                       "flat_gradients": state.flat, "launch": graph_note},
         }
         if not args.no_roofline and not dry:
             out["inference"] = inference_rate(state, device, args.size)
             out["roofline"] = scan_roofline(torch.bfloat16, device)
             out["roofline_fp32"] = scan_roofline(torch.float32, device)
+            if not args.no_configs and world == 1:
+                del state, data
+                torch.cuda.empty_cache()
+                out["config1"] = config1_mamba_block(device)
+                out["config4"] = config4_long_scan(device)
         if not args.no_cpu_baseline and world == 1 and not dry:       # the host-core baseline is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)
         print(json.dumps(out), flush=True)

@@ -29,10 +29,11 @@ import torch.nn.functional as F
 def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
                        return_last_state=False, compute_dtype=torch.float32):
     """mamba/mamba_ssm/ops/selective_scan_interface.py:86-152 (`selective_scan_ref`),
-    real `A`, input-dependent `B`/`C` (the only case on the SegMamba path).
+    real `A`; `B` / `C` input-dependent (the SegMamba path) or constant per channel (:104-110, :122-133 - the
+    `is_variable_B/C = False` rows of the reference's test matrix).
 
     u, delta, z : (batch, dim, L)            A : (dim, N)      D, delta_bias : (dim,)
-    B, C        : (batch, N, L) or (batch, G, N, L) with dim % G == 0
+    B, C        : (batch, N, L) or (batch, G, N, L) with dim % G == 0, or constant (dim, N)
     Returns out (batch, dim, L) in u.dtype [, last_state (batch, dim, N) in compute_dtype].
 
     h_t = exp(delta_t * A) * h_{t-1} + delta_t * u_t * B_t ; y_t = <C_t, h_t> + D*u_t ; out = y * silu(z)
@@ -43,8 +44,6 @@ def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
     """
     if A.is_complex():
         raise NotImplementedError("complex A is not on the SegMamba path (SURVEY.md §2.1)")
-    if B.dim() < 3 or C.dim() < 3:
-        raise NotImplementedError("constant B/C is not on the SegMamba path (SURVEY.md §2.1)")
     dtype_in = u.dtype
     cd = compute_dtype
     u_ = u.to(cd)
@@ -56,15 +55,16 @@ def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
     batch, dim, L = u_.shape
     N = A.shape[1]
     A_ = A.to(cd)
-    Bm = B.to(cd)
-    Cm = C.to(cd)
-    if Bm.dim() == 3:
-        Bm = Bm[:, None]
-    if Cm.dim() == 3:
-        Cm = Cm[:, None]
-    # (batch, G, N, L) -> (batch, dim, N, L) by repeating each group over its dim//G channels
-    Bm = Bm.repeat_interleave(dim // Bm.shape[1], dim=1)
-    Cm = Cm.repeat_interleave(dim // Cm.shape[1], dim=1)
+    def per_channel(M):
+        M = M.to(cd)
+        if M.dim() == 2:                                   # constant (dim, N): the same row at every step (:122-123, :131-132)
+            return M[None, :, :, None].expand(batch, dim, N, L)
+        if M.dim() == 3:
+            M = M[:, None]
+        # (batch, G, N, L) -> (batch, dim, N, L) by repeating each group over its dim//G channels
+        return M.repeat_interleave(dim // M.shape[1], dim=1)
+    Bm = per_channel(B)
+    Cm = per_channel(C)
 
     h = u_.new_zeros((batch, dim, N))
     ys = []
@@ -123,6 +123,53 @@ def mamba_inner_no_out_proj_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, d
     Cm = x_dbl[:, -N:].reshape(batch, L, N).permute(0, 2, 1).contiguous()
     return selective_scan_ref(xc, delta, A, Bm, Cm, D, z=z, delta_bias=delta_bias,
                               delta_softplus=delta_softplus)
+
+
+def _inner_scan_inputs(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, B_proj_bias, C_proj_bias):
+    """the shared front of `mamba_inner_ref` / `bimamba_inner_ref` (:642-667 = :679-704): conv1d + SiLU, x_proj, dt_proj and
+    the B / C the scan sees - columns of x_dbl where they are input-dependent (None), the given (dim, N) constants otherwise"""
+    L = xz.shape[-1]
+    R = delta_proj_weight.shape[1]
+    N = A.shape[-1]
+    x, z = xz.chunk(2, dim=1)
+    xc = causal_conv1d_ref(x, conv1d_weight.reshape(conv1d_weight.shape[0], -1), conv1d_bias, "silu")
+    batch, dim, _ = xc.shape
+    x_dbl = F.linear(xc.permute(0, 2, 1).reshape(batch * L, dim), x_proj_weight)
+    delta = (delta_proj_weight @ x_dbl[:, :R].t()).reshape(dim, batch, L).permute(1, 0, 2)
+    if B is None:
+        B = x_dbl[:, R:R + N]
+        if B_proj_bias is not None:
+            B = B + B_proj_bias.to(B.dtype)
+        B = B.reshape(batch, L, N).permute(0, 2, 1).contiguous()
+    if C is None:
+        C = x_dbl[:, -N:]
+        if C_proj_bias is not None:
+            C = C + C_proj_bias.to(C.dtype)
+        C = C.reshape(batch, L, N).permute(0, 2, 1).contiguous()
+    return xc, z, delta, B, C
+
+
+def mamba_inner_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                    A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
+    """mamba/mamba_ssm/ops/selective_scan_interface.py:636-670 (`mamba_inner_ref`): real A, B / C None (input-dependent) or
+    constant (dim, N).  xz (batch, 2*dim, L) -> (batch, L, out_features)."""
+    xc, z, delta, B, C = _inner_scan_inputs(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C,
+                                            B_proj_bias, C_proj_bias)
+    y = selective_scan_ref(xc, delta, A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=True)
+    return F.linear(y.permute(0, 2, 1), out_proj_weight, out_proj_bias)
+
+
+def bimamba_inner_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                      A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                      delta_softplus=True):
+    """mamba/mamba_ssm/ops/selective_scan_interface.py:673-709 (`bimamba_inner_ref`): the forward scan with A plus a scan of
+    the time-reversed conv output / delta / B / C / z with A_b (every other weight shared), flipped back and added."""
+    xc, z, delta, B, C = _inner_scan_inputs(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C,
+                                            B_proj_bias, C_proj_bias)
+    y = selective_scan_ref(xc, delta, A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=True)
+    y_b = selective_scan_ref(xc.flip([-1]), delta.flip([-1]), A_b, B.flip([-1]), C.flip([-1]), D, z.flip([-1]),
+                             delta_bias, delta_softplus=True)
+    return F.linear((y + y_b.flip([-1])).permute(0, 2, 1), out_proj_weight, out_proj_bias)
 
 
 # --------------------------------------------------------------------------------------

@@ -9,7 +9,8 @@ The chain, in the reference's order and with its parameters (train_augment.py:30
 third-party dependency that is NOT in the reference tree (setup: pip `batchgenerators`, unpinned); what each transform does
 is restated from its published implementation:
 
-  SpatialTransform         rotation about x / y / z by U(-30 deg, 30 deg) with p 0.2, isotropic scale U(0.7, 1.4) with p 0.2,
+  SpatialTransform         rotation about x / y / z by U(-30 deg, 30 deg) with p 0.2, isotropic scale with p 0.2 drawn two-sided - U(0.7, 1) or U(1, 1.4)
+                           with equal odds, batchgenerators' rule for a range straddling 1 -
                            about the patch centre, zero padding; image cubic spline / label linear in the reference ->
                            trilinear / nearest here (grid_sample has no 3-D cubic mode); labels outside the volume become 0
                            (RemoveLabelTransform(-1, 0), :57)
@@ -62,7 +63,7 @@ class DeviceAugmenter:
         if not bool((rot | scl).any()):
             return x, y
         a = self._u(-math.pi / 6, math.pi / 6, B, 3) * rot[:, None]
-        s = torch.where(scl, self._u(0.7, 1.4, B), torch.ones(B, device=self.device))
+        s = torch.where(scl, self._two_sided(0.7, 1.4, B), torch.ones(B, device=self.device))
         cx, sx, cy, sy, cz, sz = a[:, 0].cos(), a[:, 0].sin(), a[:, 1].cos(), a[:, 1].sin(), a[:, 2].cos(), a[:, 2].sin()
         one, zero = torch.ones_like(cx), torch.zeros_like(cx)
         Rx = torch.stack([one, zero, zero, zero, cx, -sx, zero, sx, cx], 1).view(B, 3, 3)

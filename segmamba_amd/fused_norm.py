@@ -130,6 +130,8 @@ def thin_conv3d_same(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor |
     """Conv3d(kernel 3, stride 1, padding 1) on at most 4 input channels through the thin-input kernels, or None when the call is
     not theirs (SEGM_THIN_CONV_HIP=0, CPU tensors, a 32-bit compute dtype, an input that needs its gradient, other shapes)"""
     from . import lib as L, ops_raw
+    if tuple(weight.shape[2:]) != (3, 3, 3):             # the thin kernels infer (kernel, stride) from the weight: 7^3 would run stride 2
+        return None
     if not (_THIN_HIP and L.on_device(x) and weight.shape[1] <= 4 and not x.requires_grad and ops_raw.stem_conv_supported(x, weight)):
         return None
     dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
@@ -145,6 +147,8 @@ def stem_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
     """The 7^3 stride-2 stem convolution; follows autocast like F.conv3d.  Library kernel for 16-bit activations on the device
     (SEGM_STEM_HIP=0: the MIOpen call), F.conv3d otherwise."""
     from . import lib as L, ops_raw
+    if tuple(weight.shape[2:]) != (7, 7, 7):
+        raise RuntimeError(f"stem_conv3d: a 7x7x7 stride-2 convolution is expected, got a kernel of {tuple(weight.shape[2:])}")
     if _STEM_HIP and L.on_device(x) and ops_raw.stem_conv_supported(x, weight):
         dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
         if dt in (torch.bfloat16, torch.float16):

@@ -46,14 +46,44 @@ class ParamBank:
         self.flat32 = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat16 = torch.zeros(total, dtype=dtype, device=dev)
         self.views16: Dict[int, torch.Tensor] = {}
+        self.offsets: Dict[int, int] = {}
         with torch.no_grad():
             for p, o in zip(params, offs):
                 v = self.flat32[o:o + p.numel()].view(p.shape)
                 v.copy_(p.data)
                 p.data = v
                 self.views16[id(p)] = self.flat16[o:o + p.numel()].view(p.shape)
+                self.offsets[id(p)] = o
         self.params = params                                   # keeps the ids alive
         self.fresh = False
+        self.flat_grad: Optional[torch.Tensor] = None
+
+    def attach_flat_grads(self) -> torch.Tensor:
+        """`p.grad` of every parameter becomes a window of ONE flat fp32 buffer laid out like `flat32` (what DDP's
+        `gradient_as_bucket_view` does per bucket): autograd accumulates in place, so the addresses never change - a captured
+        step (trainer.GraphedStep) replays into them, a data-parallel run all-reduces the single buffer, and the optimizer
+        walks three flat arrays instead of 286 tensors.  Zero it (`flat_grad.zero_()`) where the loop set `p.grad = None`."""
+        if self.flat_grad is None:
+            self.flat_grad = torch.zeros_like(self.flat32)
+        for p in self.params:
+            o = self.offsets[id(p)]
+            p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        return self.flat_grad
+
+    def grads_attached(self) -> bool:
+        """every parameter's gradient still is its window of `flat_grad` (nobody set `p.grad = None` or swapped it)"""
+        if self.flat_grad is None:
+            return False
+        base = self.flat_grad.data_ptr()
+        return all(p.grad is not None and p.grad.data_ptr() == base + 4 * self.offsets[id(p)] for p in self.params)
+
+    def owns(self, p: torch.Tensor) -> bool:
+        """`p.data` still is the window of `flat32` the bank gave it.  Anything that re-points the storage after the bank was
+        built - `model.to(memory_format=...)`, `.to(dtype / device)`, `load_state_dict(assign=True)` - makes the 16-bit twin
+        stale for that parameter; `lookup` then declines and the caller casts the live weight instead."""
+        o = self.offsets.get(id(p))
+        return (o is not None and p.dtype == torch.float32 and p.device == self.flat32.device and
+                p.data_ptr() == self.flat32.data_ptr() + 4 * o and p.is_contiguous())
 
     def refresh(self) -> None:
         with torch.no_grad():
@@ -63,7 +93,7 @@ class ParamBank:
     def lookup(self, w: torch.Tensor) -> Optional[torch.Tensor]:
         base = w._base if w._is_view() else w
         v = self.views16.get(id(base))
-        if v is None or not self.fresh:
+        if v is None or not self.fresh or not self.owns(base):
             return None
         if w is base:
             return v

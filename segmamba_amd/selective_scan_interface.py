@@ -101,6 +101,8 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
     256, selective_scan.cpp:247) run as a sum over 16-state blocks - the scan is linear in (B, C) blocks - with the skip
     term in the first block and the gate applied to the sum."""
     dstate = A.shape[-1]
+    if B.dim() == 2 or C.dim() == 2:
+        return _scan_constant_bc(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
     if dstate <= 16:
         return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
     if dstate > 256:
@@ -114,6 +116,38 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
             r, last = r
             lasts.append(last)
         y = r.float() if y is None else y + r.float()
+    if z is not None:
+        y = y * torch.nn.functional.silu(z.float())
+    y = y.to(u.dtype)
+    return (y, torch.cat(lasts, dim=-1)) if return_last_state else y
+
+
+def _scan_constant_bc(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state):
+    """Constant (per-channel) B and / or C - (dim, dstate) instead of input-dependent (batch, [groups,] dstate, seqlen); reference
+    selective_scan_interface.py:104-110,122-133 and selective_scan_fwd_kernel.cuh:223-233.  Not on the SegMamba path, so no kernel
+    variant: the scan is a sum over states of single-state scans, a constant B[d, n] scales that state's input channel-wise
+    (u B[d, n] against an all-ones B_t), a constant C[d, n] scales its output; the skip term and the gate are applied to the
+    sum.  Everything around the kernel calls is ordinary autograd, so B / C receive their (dim, dstate) gradients."""
+    if A.is_complex():
+        raise RuntimeError("complex A is not supported (not on the SegMamba path)")
+    batch, dim, L = u.shape
+    dstate = A.shape[-1]
+    ones = u.new_ones(batch, 1, L)
+    y, lasts = None, []
+    for n in range(dstate):
+        un = u if B.dim() > 2 else (u.float() * B[:, n].float()[None, :, None]).to(u.dtype)
+        Bn = B[..., n:n + 1, :] if B.dim() > 2 else ones
+        Cn = C[..., n:n + 1, :] if C.dim() > 2 else ones
+        r = SelectiveScanFn.apply(un, delta, A[:, n:n + 1], Bn, Cn, None, None, delta_bias, delta_softplus, return_last_state)
+        if return_last_state:
+            r, last = r
+            lasts.append(last)
+        r = r.float()
+        if C.dim() == 2:
+            r = r * C[:, n].float()[None, :, None]
+        y = r if y is None else y + r
+    if D is not None:
+        y = y + u.float() * D.float()[None, :, None]
     if z is not None:
         y = y * torch.nn.functional.silu(z.float())
     y = y.to(u.dtype)
@@ -339,8 +373,8 @@ def _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last, B_p
 def _inner(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias,
            B_proj_bias, C_proj_bias, delta_softplus, channel_last=False, time_order=L.TIME_FORWARD, nslices=1):
     if B is not None or C is not None:
-        raise RuntimeError("constant B / C is not supported: B and C must be None (input-dependent), "
-                           "the only case on the SegMamba path")
+        return _inner_constant_bc(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias,
+                                  B_proj_bias, C_proj_bias, delta_softplus, channel_last, time_order, nslices)
     # inference (no_grad, or nothing requires a gradient): the forward skips the stores only a backward would read.
     # is_grad_enabled() is always False inside Function.forward, so the decision is taken here.
     train = torch.is_grad_enabled() and any(
@@ -348,6 +382,35 @@ def _inner(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, 
                                                     delta_bias, B_proj_bias, C_proj_bias))
     return MambaInnerCore.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
                                 B_proj_bias, C_proj_bias, delta_softplus, channel_last, time_order, nslices, train)
+
+
+def _inner_constant_bc(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias,
+                       B_proj_bias, C_proj_bias, delta_softplus, channel_last, time_order, nslices):
+    """The inner pipeline with a constant (dim, dstate) B and / or C (reference :170-213 with `is_variable_B/C` False): x_proj
+    then has dt_rank + dstate * (number of input-dependent matrices) rows.  Off the SegMamba path: composed from the public ops
+    (causal_conv1d_fn, the projections, selective_scan_fn), differentiated by autograd, reference layout only."""
+    if channel_last or time_order != L.TIME_FORWARD:
+        raise RuntimeError("constant B / C is implemented for the reference (batch, dim, seqlen) layout in forward time order")
+    from .causal_conv1d_interface import causal_conv1d_fn
+    dim = xz.shape[1] // 2
+    batch, seqlen = xz.shape[0], xz.shape[2]
+    R = delta_proj_weight.shape[1]
+    N = A.shape[-1]
+    x, z = xz.split(dim, dim=1)
+    conv_out = causal_conv1d_fn(x, conv1d_weight.reshape(dim, -1), conv1d_bias, "silu")
+    x_dbl = F.linear(conv_out.permute(0, 2, 1).reshape(batch * seqlen, dim), x_proj_weight.to(conv_out.dtype))
+    delta = (delta_proj_weight.to(x_dbl.dtype) @ x_dbl[:, :R].t()).reshape(dim, batch, seqlen).permute(1, 0, 2).contiguous()
+    if B is None:
+        B = x_dbl[:, R:R + N]
+        if B_proj_bias is not None:
+            B = B + B_proj_bias.to(B.dtype)
+        B = B.reshape(batch, seqlen, N).permute(0, 2, 1).contiguous()
+    if C is None:
+        C = x_dbl[:, -N:]
+        if C_proj_bias is not None:
+            C = C + C_proj_bias.to(C.dtype)
+        C = C.reshape(batch, seqlen, N).permute(0, 2, 1).contiguous()
+    return selective_scan_fn(conv_out, delta, A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=delta_softplus)
 
 
 def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,

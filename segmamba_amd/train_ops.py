@@ -66,6 +66,40 @@ class FusedClipSGD(torch.optim.Optimizer):
                                       dampening=0, maximize=False, foreach=None, differentiable=False, fused=None))
         self.max_norm = max_norm
         self.last_clip = None                 # device tensor {clip coefficient, gradient norm, -, -} of the last step
+        self.bank = None                      # param_bank.ParamBank with flat gradients attached: see use_flat()
+        self._flat_mom = None
+
+    def use_flat(self, bank) -> None:
+        """Step over the bank's three flat arrays (parameters, gradients, momenta) - ONE tensor per launch instead of a table of
+        286 pointers, and nothing for the host to gather per step.  Needs `bank.attach_flat_grads()` and one parameter group
+        holding exactly the bank's parameters; `state[p]["momentum_buffer"]` stays a per-parameter tensor (a window of the flat
+        momentum array), so the state dict still interchanges with torch.optim.SGD."""
+        ps = [p for gr in self.param_groups for p in gr["params"]]
+        if len(self.param_groups) != 1 or len(ps) != len(bank.params) or {id(p) for p in ps} != {id(p) for p in bank.params}:
+            raise RuntimeError("FusedClipSGD.use_flat: one parameter group holding exactly the bank's parameters is required")
+        if bank.flat_grad is None:
+            raise RuntimeError("FusedClipSGD.use_flat: call bank.attach_flat_grads() first")
+        self._flat_mom = torch.zeros_like(bank.flat32)
+        for p in bank.params:
+            o = bank.offsets[id(p)]
+            win = self._flat_mom[o:o + p.numel()].view(p.shape)
+            old = self.state[p].get("momentum_buffer")
+            if old is not None:
+                win.copy_(old)
+            self.state[p]["momentum_buffer"] = win
+        self.bank = bank
+
+    def _flat_ok(self) -> bool:
+        """the flat arrays still are what the parameters, their gradients and their momenta live in"""
+        b = self.bank
+        if b is None or not b.grads_attached():
+            return False
+        mbase = self._flat_mom.data_ptr()
+        for p in b.params:
+            m = self.state[p].get("momentum_buffer")
+            if m is None or m.data_ptr() != mbase + 4 * b.offsets[id(p)] or not b.owns(p):
+                return False
+        return True
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -73,6 +107,16 @@ class FusedClipSGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self.bank is not None:
+            if not self._flat_ok():               # someone re-pointed a parameter / gradient / momentum: per-tensor route
+                self.bank = None
+            else:
+                from . import lib as L, ops_raw
+                gr = self.param_groups[0]
+                self.last_clip = ops_raw.sgd_clip_step(L.get_lib(), [self.bank.flat32], [self.bank.flat_grad], [self._flat_mom],
+                                                       gr["lr"], gr["momentum"], gr["weight_decay"], gr["nesterov"],
+                                                       float(self.max_norm) if self.max_norm else 0.0)
+                return loss
         groups = []
         for gr in self.param_groups:
             ps = [p for p in gr["params"] if p.grad is not None]

@@ -12,8 +12,15 @@ lr_scheduler.py:36 poly 0.9).  Differences, all deliberate:
     (light_training/trainer.py:65-67, 461-466) - through the same kernels (all instantiated for fp16);
   * data come from a device-side synthetic generator instead of the 18-process batchgenerators pipeline
     (trainer.py:154-162), which is out of scope (SURVEY.md §2.1);
-  * multi-GPU is the same plain DDP (trainer.py:353-357) over RCCL; one process per GPU,
-    launched by torchrun - batch per GPU stays 2 (weak scaling), gradients are all-reduced in DDP's buckets.
+  * multi-GPU is data parallel by volume over RCCL, one process per GPU launched by torchrun, batch per GPU 2 (weak scaling).
+    Two forms of the same arithmetic (mean of the ranks' gradients, then one identical update on every rank):
+      ddp="flat" (default on the GPU)  the parameters, their gradients and momenta live in three flat fp32 arrays
+                 (param_bank.py); a step is  [forward + backward]  ->  ONE all-reduce of the flat gradient array
+                 (269.7 MB over xGMI)  ->  clip + SGD over the flat arrays.  The bracket has fixed addresses and no host
+                 decision in it, so it is captured once as a HIP graph (`GraphedStep`) and replayed: ~2000 kernel launches per
+                 step cost the host one `hipGraphLaunch`;
+      ddp="torch"  the reference's wrapper - DistributedDataParallel (trainer.py:353-357), bucketed all-reduce overlapped
+                 with the backward pass, eager launches.
 """
 from __future__ import annotations
 
@@ -70,13 +77,22 @@ class TrainingState:
     step: int = 0
     scaler: object = None          # torch.amp.GradScaler when autocast_dtype is fp16 (reference trainer.py:65-67)
     bank: object = None            # param_bank.ParamBank: the step's 16-bit parameter copies, one launch per group
+    flat: bool = False             # gradients / momenta in flat arrays next to the bank's parameters (attach_flat_grads)
+    world: int = 1                 # ranks averaging their gradients through ONE all-reduce of the flat array (ddp="flat")
+    graphed: object = None         # GraphedStep once the forward + backward bracket has been captured
 
 
 def build_training_state(device, distributed: bool = False, local_rank: int = 0, max_steps: int = 250 * 1000,
-                         model: nn.Module | None = None, amp: str | None = None) -> TrainingState:
+                         model: nn.Module | None = None, amp: str | None = None, ddp: str | None = None,
+                         flat: bool | None = None) -> TrainingState:
+    """ddp: "flat" | "torch" (see the module docstring; default SEGM_DDP, else "flat" where the parameter bank exists).
+    flat: keep gradients / momenta in flat arrays also on one GPU (default: yes with the bank and the fused optimizer)."""
     amp = (amp or os.environ.get("SEGM_AMP", "bf16")).lower()
     if amp not in ("bf16", "fp16"):
         raise ValueError(f"amp must be 'bf16' or 'fp16', got {amp!r}")
+    ddp = (ddp or os.environ.get("SEGM_DDP", "flat")).lower()
+    if ddp not in ("flat", "torch"):
+        raise ValueError(f"ddp must be 'flat' or 'torch', got {ddp!r}")
     if model is None:
         model = SegMamba(in_chans=4, out_chans=4, depths=[2, 2, 2, 2], feat_size=[48, 96, 192, 384])
     model = model.to(device)
@@ -89,6 +105,16 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
         # instead of one per parameter (param_bank.py); built before DDP looks at the parameters
         from .param_bank import ParamBank
         bank = ParamBank(model, torch.float16 if amp == "fp16" else torch.bfloat16)
+    fused_ok = L.on_device(next(model.parameters())) and os.environ.get("SEGM_FUSED_TRAIN_OPS", "1") != "0"
+    if flat is None:
+        flat = os.environ.get("SEGM_FLAT_GRADS", "1") == "1"
+    flat = bool(flat and bank is not None and fused_ok and amp == "bf16")
+    world = 1
+    if distributed and flat and ddp == "flat":
+        import torch.distributed as dist
+        world = dist.get_world_size()
+        dist.broadcast(bank.flat32, 0)                     # what DDP's constructor does: every rank starts from rank 0's weights
+        distributed = False                                # no wrapper: the exchange step is one all-reduce in finish_step()
     if distributed:
         # The reference passes find_unused_parameters=True (trainer.py:354-357); every SegMamba parameter takes part in
         # every step (DDP itself reports "did not find any unused parameters"), so the extra per-step graph traversal
@@ -98,7 +124,7 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
         model = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[local_rank] if device.type == "cuda" else None,
             **DDP_SETTINGS)
-    fused = L.on_device(next(model.parameters())) and os.environ.get("SEGM_FUSED_TRAIN_OPS", "1") != "0"
+    fused = fused_ok
     if fused:
         # clip_grad_norm_(12) + SGD step as two passes of the library's multi-tensor kernels, cross entropy with its
         # gradient as one (csrc/trainstep.hip); SEGM_FUSED_TRAIN_OPS=0 restores the ATen calls of the reference loop
@@ -109,7 +135,11 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
         opt = torch.optim.SGD(model.parameters(), lr=1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
         loss_fn = nn.CrossEntropyLoss()
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: (1 - min(s, max_steps - 1) / max_steps) ** 0.9)
-    st = TrainingState(model=model, optimizer=opt, scheduler=sched, loss_fn=loss_fn, bank=bank)
+    st = TrainingState(model=model, optimizer=opt, scheduler=sched, loss_fn=loss_fn, bank=bank, world=world)
+    if flat and not isinstance(model, torch.nn.parallel.DistributedDataParallel):
+        bank.attach_flat_grads()
+        opt.use_flat(bank)
+        st.flat = True
     if amp == "fp16":
         st.autocast_dtype = torch.float16
         st.scaler = torch.amp.GradScaler(device.type)     # the reference's GradScaler() defaults: 2^16, x2 / 2000 steps, x0.5 on inf
@@ -117,10 +147,74 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
 
 
 def train_step(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    if st.flat:
+        if st.graphed is not None:
+            return st.graphed(image, label)
+        loss = forward_backward(st, image, label)
+        finish_step(st)
+        return loss
     if st.bank is None:
         return _train_step(st, image, label)
     with st.bank.step():                                           # forward and backward see one set of 16-bit parameter copies
         return _train_step(st, image, label)
+
+
+def forward_backward(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    """The bracket of a flat-mode step that a HIP graph can hold: 16-bit parameter copies, zeroed flat gradient array,
+    autocast forward, loss, backward.  With `st.world` ranks the loss is scaled by 1 / world before the backward pass so that
+    the SUM all-reduce in finish_step() leaves the mean gradient (what DDP's bucket division does)."""
+    with st.bank.step():
+        st.bank.flat_grad.zero_()                                  # trainer.py:445 sets every p.grad to None
+        with torch.autocast(image.device.type, dtype=st.autocast_dtype, enabled=image.device.type == "cuda"):
+            pred = st.model(image)
+            loss = st.loss_fn(pred, label)                         # 3_train.py:62
+        (loss / st.world if st.world > 1 else loss).backward()
+    return loss.detach()
+
+
+def finish_step(st: TrainingState) -> None:
+    """exchange + update of a flat-mode step: all-reduce (world > 1), clip 12 + SGD-Nesterov over the flat arrays, poly LR"""
+    if st.world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(st.bank.flat_grad)                          # 269.7 MB fp32 over xGMI, one collective
+    st.optimizer.step()
+    st.scheduler.step()
+    st.step += 1
+
+
+class GraphedStep:
+    """forward_backward() captured once as a HIP graph on static input buffers and replayed per step.
+
+    A training step is ~2000 kernel launches; enqueueing them eagerly costs the host ~60 ms per step back to back
+    (profiles/r02_host_time.log) - as much as the GPU needs to run them.  Everything inside the bracket has fixed shapes,
+    fixed addresses (flat gradient array, bank copies, the caching allocator's private graph pool) and no host-side decision
+    (the convolution routing is frozen after the warm-up steps), so one `hipGraphLaunch` replaces the launches.  The
+    all-reduce, the optimizer (its learning rate is a kernel argument that changes every step) and the scheduler stay eager."""
+
+    def __init__(self, st: TrainingState, image: torch.Tensor, label: torch.Tensor, warmup: int = 3):
+        if not st.flat:
+            raise RuntimeError("GraphedStep needs the flat-gradient training state (build_training_state(flat=True))")
+        self.st = st
+        self.image = image.clone()
+        self.label = label.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                              # lazy initialisation and the routing tuner run here, eagerly
+            for _ in range(max(1, warmup)):
+                forward_backward(st, self.image, self.label)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = forward_backward(st, self.image, self.label)
+        st.graphed = self
+
+    def __call__(self, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+        self.image.copy_(image)
+        self.label.copy_(label)
+        self.graph.replay()
+        finish_step(self.st)
+        return self.loss
 
 
 def _train_step(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:

@@ -30,20 +30,25 @@ def _use_emulated_library():
     L.on_device = lambda t: True
 
 
-def _worker(rank, world, port, out, library=False):
+def _net(st):
+    return st.model.module if hasattr(st.model, "module") else st.model
+
+
+def _worker(rank, world, port, out, library=False, ddp="torch"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if library:
         _use_emulated_library()
     from segmamba_amd.trainer import build_training_state, train_step
-    st = build_training_state(torch.device("cpu"), distributed=True, model=_tiny_model())
+    st = build_training_state(torch.device("cpu"), distributed=True, model=_tiny_model(), ddp=ddp)
+    assert st.flat == (library and ddp == "flat") and st.world == (world if st.flat else 1)
     img, lab = _batch(rank)
     for _ in range(2):
         loss = train_step(st, img, lab)
     # the bench's timing reduction: max over ranks
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    out[rank] = (float(loss), [p.detach().clone() for p in st.model.module.parameters()], float(t))
+    out[rank] = (float(loss), [p.detach().clone() for p in _net(st).parameters()], float(t))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,10 +74,12 @@ def test_two_process_ddp_matches_single_process():
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
 
 
-def test_two_process_ddp_with_library_loss_and_optimizer(monkeypatch):
-    """The same lock-step check with the library's cross entropy and clip + SGD kernels (emulated) under DDP: gradients are
-    views into DDP's buckets (gradient_as_bucket_view), not necessarily 16-byte aligned - the multi-tensor kernels read them
-    where they are."""
+@pytest.mark.parametrize("ddp", ["torch", "flat"])
+def test_two_process_ddp_with_library_loss_and_optimizer(monkeypatch, ddp):
+    """The same lock-step check with the library's cross entropy and clip + SGD kernels (emulated).  ddp="torch": the reference's
+    wrapper - gradients are views into DDP's buckets (gradient_as_bucket_view), not necessarily 16-byte aligned, the multi-tensor
+    kernels read them where they are.  ddp="flat" (the GPU default): no wrapper - every rank scales its loss by 1 / world, ONE
+    all-reduce sums the flat gradient array, the optimizer steps over the three flat arrays."""
     from tests import emu_util
     if not emu_util.emu_available():
         pytest.skip("no host clang for the emulation build")
@@ -82,7 +89,7 @@ def test_two_process_ddp_with_library_loss_and_optimizer(monkeypatch):
         port = s.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, out, True), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, True, ddp), nprocs=2, join=True)
     for a, b in zip(out[0][1], out[1][1]):
         assert torch.equal(a, b), "ranks diverged"
     from segmamba_amd import lib as L
@@ -101,26 +108,28 @@ def test_two_process_ddp_with_library_loss_and_optimizer(monkeypatch):
     assert isinstance(build_training_state(torch.device("cpu"), model=_tiny_model()).optimizer, FusedClipSGD)
 
 
-def _segmamba_worker(rank, world, port, out):
+def _segmamba_worker(rank, world, port, out, ddp="torch"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _use_emulated_library()
     from segmamba_amd.segmamba import SegMamba
     from segmamba_amd.trainer import build_training_state, train_step
-    torch.manual_seed(0)
+    torch.manual_seed(rank if ddp == "flat" else 0)             # flat: different initial weights per rank - rank 0's must win
     net = SegMamba(in_chans=4, out_chans=4, depths=[1, 1, 1, 1], feat_size=[48, 16, 16, 32], hidden_size=32)
-    st = build_training_state(torch.device("cpu"), distributed=True, model=net)
+    st = build_training_state(torch.device("cpu"), distributed=True, model=net, ddp=ddp)
     g = torch.Generator().manual_seed(42 + rank)
     img, lab = torch.rand(1, 4, 32, 32, 32, generator=g), torch.randint(0, 4, (1, 32, 32, 32), generator=g)
     losses = [float(train_step(st, img, lab)) for _ in range(2)]
-    out[rank] = (losses, [p.detach().clone() for p in st.model.module.parameters()],
-                 [None if p.grad is None else bool(torch.isfinite(p.grad).all()) for p in st.model.module.parameters()])
+    out[rank] = (losses, [p.detach().clone() for p in _net(st).parameters()],
+                 [None if p.grad is None else bool(torch.isfinite(p.grad).all()) for p in _net(st).parameters()])
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_process_ddp_with_the_real_segmamba_on_emulated_kernels():
-    """The REAL network under DDP: SegMamba with its custom autograd Functions (MambaInnerCore, the conv dispatcher, fused norms)
+@pytest.mark.parametrize("ddp", ["torch", "flat"])
+def test_two_process_ddp_with_the_real_segmamba_on_emulated_kernels(ddp):
+    """(ddp="flat": the same through the wrapper-free form - flat gradient array, one all-reduce, flat optimizer step.)
+    The REAL network under DDP: SegMamba with its custom autograd Functions (MambaInnerCore, the conv dispatcher, fused norms)
     on the library's kernels (CPU emulation), gradients as views into DDP's buckets (gradient_as_bucket_view), the library's
     loss and clip + SGD kernels.  Every parameter must receive a gradient on both ranks (find_unused_parameters=False is only
     legal then) and the ranks must stay bit-identical after two steps."""
@@ -133,7 +142,7 @@ def test_two_process_ddp_with_the_real_segmamba_on_emulated_kernels():
         port = s.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_segmamba_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_segmamba_worker, args=(2, port, out, ddp), nprocs=2, join=True)
     assert all(f is True for f in out[0][2]) and all(f is True for f in out[1][2]), "a parameter got no (finite) gradient"
     for a, b in zip(out[0][1], out[1][1]):
         assert torch.equal(a, b), "ranks diverged"
@@ -158,7 +167,8 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, r.stdout[-2000:]                 # rank 0 prints ONE line
     rec = json.loads(line[0])
-    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["ddp"]["bucket_cap_mb"] == 64
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["ddp"]["mode"].startswith("flat")
+    assert rec["config"]["ddp"]["rank_ms_per_step"]["max"] >= rec["config"]["ddp"]["rank_ms_per_step"]["min"] > 0
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-dry-run", "--steps", "1", "--warmup", "0"],
                         capture_output=True, text=True, timeout=600, env=env2, cwd=root)

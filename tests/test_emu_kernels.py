@@ -131,6 +131,27 @@ def test_reference_layout_inner_fn_on_emulated_kernels(emu, monkeypatch):
         H.assert_close(t[k].grad, f[gk], 1e-3, 1e-3 * max(1.0, float(f[gk].abs().max())), gk)
 
 
+@pytest.mark.parametrize("vB,vC", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_mamba_inner_fn_matrix_golden_on_emulated_kernels(emu, monkeypatch, vB, vC):
+    """`mamba_inner_fn` (with the output projection) against the reference's `mamba_inner_ref` over the reference test's
+    matrix of input-dependent / constant B and C (mamba/tests/ops/test_selective_scan.py:152-221; fixtures from
+    tests/golden/make_golden_inner_out_proj.py): output and EVERY gradient"""
+    monkeypatch.setattr(L, "_lib", emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    f = H.load_golden(f"inner_fn_vB{vB}_vC{vC}.npz")
+    out, grads = H.run_inner_fn(f, "cpu")
+    H.check_inner_fn(out, grads, f, f"emu inner_fn vB{vB} vC{vC}")
+
+
+def test_bimamba_inner_fn_golden_on_emulated_kernels(emu, monkeypatch):
+    """`bimamba_inner_fn` against the reference's `bimamba_inner_ref` (selective_scan_interface.py:673-709)"""
+    monkeypatch.setattr(L, "_lib", emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    f = H.load_golden("bimamba_inner.npz")
+    out, grads = H.run_inner_fn(f, "cpu", bidirectional=True)
+    H.check_inner_fn(out, grads, f, "emu bimamba_inner_fn")
+
+
 def _wgrad_reference(x, dy):
     w = torch.zeros(dy.shape[1], x.shape[1], 3, 3, 3, requires_grad=True)
     torch.nn.functional.conv3d(x.float(), w, None, 1, 1).backward(dy.float())

@@ -197,9 +197,14 @@ def test_causal_conv1d_reference_matrix(hip, seqlen, width, itype):
             what = f"conv L={seqlen} W={width} {itype} cl={channel_last} silu={silu}"
             H.assert_close(tr(out), ref.to(itype), rtol, atol, what + " out")
             H.assert_close(tr(dx), xr.grad.to(itype), rtol * 3, atol * 3, what + " dx")
-            H.assert_close(dw, wr.grad, 1e-2 if itype != torch.float32 else 1e-3, 2e-1 if itype != torch.float32 else 1e-2, what + " dweight")
+            # weight / bias gradients are fp32 sums of products of the SAME rounded operands on both sides: only the summation
+            # order differs.  16-bit: rtol 1e-2 + 5e-3 max|ref| (<= 1e-2 max|ref|; the reference's 1e-3 compares two
+            # 16-bit pipelines with each other, causal-conv1d/tests/test_causal_conv1d.py:34,73-75)
+            wtol = (1e-3, 1e-3 * max(1.0, float(wr.grad.abs().max()))) if itype == torch.float32 else (1e-2, 5e-3 * float(wr.grad.abs().max()))
+            H.assert_close(dw, wr.grad, wtol[0], wtol[1], what + " dweight")
             if has_bias:
-                H.assert_close(dbias, br.grad, 1e-2 if itype != torch.float32 else 1e-3, 2e-1 if itype != torch.float32 else 1e-2, what + " dbias")
+                btol = (1e-3, 1e-3 * max(1.0, float(br.grad.abs().max()))) if itype == torch.float32 else (1e-2, 5e-3 * float(br.grad.abs().max()))
+                H.assert_close(dbias, br.grad, btol[0], btol[1], what + " dbias")
 
 
 @pytest.mark.parametrize("order,ns", [(L.TIME_REVERSED, 1), (L.TIME_INTERLEAVED, 8), (L.TIME_INTERLEAVED, 64)])

@@ -73,6 +73,35 @@ def test_inner_no_out_proj_oracle_matches_reference(golden_dir):
         _close(t[k].grad, f[gk], tol=2e-4)
 
 
+_INNER = ("xz", "conv_w", "conv_b", "x_proj_w", "dt_proj_w", "out_proj_w", "A", "B", "C", "D", "delta_bias", "A_b")
+
+
+@pytest.mark.parametrize("vB", [0, 1])
+@pytest.mark.parametrize("vC", [0, 1])
+def test_inner_fn_with_out_proj_oracle_matches_reference(golden_dir, vB, vC):
+    """`mamba_inner_ref` with the output projection, B / C input-dependent or constant - the reference test's matrix
+    (mamba/tests/ops/test_selective_scan.py:152-221) - pinned by tests/golden/make_golden_inner_out_proj.py"""
+    f = _load(golden_dir, f"inner_fn_vB{vB}_vC{vC}.npz")
+    t = {k: f[k].clone().requires_grad_() for k in _INNER if k in f}
+    out = ref_ops.mamba_inner_ref(t["xz"], t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"], t["out_proj_w"], None,
+                                  t["A"], t.get("B"), t.get("C"), t["D"], delta_bias=t["delta_bias"], delta_softplus=True)
+    _close(out, f["out"], tol=1e-4)
+    out.backward(f["g"])
+    for k in t:
+        _close(t[k].grad, f["d" + k], tol=5e-4)
+
+
+def test_bimamba_inner_oracle_matches_reference(golden_dir):
+    f = _load(golden_dir, "bimamba_inner.npz")
+    t = {k: f[k].clone().requires_grad_() for k in _INNER if k in f}
+    out = ref_ops.bimamba_inner_ref(t["xz"], t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"], t["out_proj_w"], None,
+                                    t["A"], t["A_b"], None, None, t["D"], delta_bias=t["delta_bias"], delta_softplus=True)
+    _close(out, f["out"], tol=1e-4)
+    out.backward(f["g"])
+    for k in t:
+        _close(t[k].grad, f["d" + k], tol=5e-4)
+
+
 def test_mamba_v3_oracle_matches_reference(golden_dir):
     f = _load(golden_dir, "mamba_v3.npz")
     ns = int(f["nslices"])

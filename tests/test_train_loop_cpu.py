@@ -129,6 +129,62 @@ def test_param_bank_hands_out_views_of_one_converted_buffer():
         assert torch.equal(low_precision(w, torch.bfloat16), w.detach().bfloat16())
 
 
+def test_param_bank_declines_parameters_whose_storage_moved():
+    """anything that re-points `p.data` after the bank was built (model.to(memory_format=...), .to(dtype),
+    load_state_dict(assign=True)) must not be served the stale 16-bit twin: `lookup` checks that the parameter still lives in
+    the flat buffer and `low_precision` falls back to casting the LIVE weight."""
+    from segmamba_amd.param_bank import ParamBank, low_precision
+    torch.manual_seed(0)
+    m = nn.Sequential(nn.Linear(5, 3), nn.Conv3d(4, 6, 3))
+    bank = ParamBank(m, torch.bfloat16)
+    w = m[1].weight
+    with bank.step():
+        assert bank.owns(w) and low_precision(w, torch.bfloat16).data_ptr() == bank.flat16.data_ptr() + 2 * bank.offsets[id(w)]
+    m.to(memory_format=torch.channels_last_3d)                 # re-points the 5-d weight's storage (same Parameter object)
+    with torch.no_grad():
+        w.mul_(3.0)                                            # ... and the optimizer then updates the NEW storage
+    with bank.step():
+        assert not bank.owns(w)
+        got = low_precision(w, torch.bfloat16)
+        assert torch.equal(got, w.detach().bfloat16())          # the live values, not the bank's old copy
+        assert not bank.flat16.data_ptr() <= got.data_ptr() < bank.flat16.data_ptr() + 2 * bank.flat16.numel()
+        assert bank.owns(m[0].weight)                           # untouched parameters are still served from the bank
+    sd = {k: v.clone() * 2 for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, assign=True)                          # new Parameter objects: unknown to the bank -> plain casts
+    with bank.step():
+        assert torch.equal(low_precision(m[0].weight, torch.bfloat16), m[0].weight.detach().bfloat16())
+
+
+def test_flat_gradients_and_flat_optimizer_match_the_per_tensor_route(monkeypatch):
+    """trainer flat mode (bank.attach_flat_grads + FusedClipSGD.use_flat): gradients accumulate into windows of ONE flat array
+    whose addresses never change, the optimizer steps over three flat arrays; two steps equal the per-tensor route bit for bit,
+    the momentum state is still per parameter, and a swapped gradient tensor sends the optimizer back to the per-tensor route."""
+    from tests import emu_util
+    import pytest
+    if not emu_util.emu_available():
+        pytest.skip("no host clang for the emulation build")
+    from segmamba_amd import lib as L
+    monkeypatch.setattr(L, "_lib", emu_util.emu_lib())
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    g = torch.Generator().manual_seed(1)
+    img, lab = torch.rand(1, 4, 8, 8, 8, generator=g), torch.randint(0, 4, (1, 8, 8, 8), generator=g)
+    a = build_training_state(torch.device("cpu"), model=_tiny(), flat=True)
+    b = build_training_state(torch.device("cpu"), model=_tiny(), flat=False)
+    assert a.flat and not b.flat and a.bank.grads_attached()
+    ptrs = [p.grad.data_ptr() for p in a.model.parameters()]
+    for _ in range(2):
+        la, lb = train_step(a, img, lab), train_step(b, img, lab)
+        assert torch.equal(la, lb)
+    assert [p.grad.data_ptr() for p in a.model.parameters()] == ptrs and a.optimizer.bank is a.bank
+    for pa, pb in zip(a.model.parameters(), b.model.parameters()):
+        assert torch.equal(pa, pb) and torch.equal(pa.grad, pb.grad)
+        assert torch.equal(a.optimizer.state[pa]["momentum_buffer"], b.optimizer.state[pb]["momentum_buffer"])
+    p0 = next(a.model.parameters())
+    p0.grad = p0.grad.clone()                                   # someone replaced a gradient tensor
+    a.optimizer.step()
+    assert a.optimizer.bank is None                             # per-tensor route from now on, nothing silently skipped
+
+
 def test_functions_take_fp32_masters_and_return_fp32_gradients():
     """linear.linear_cl / linear.pointwise Functions with fp32 weights and 16-bit activations (what autocast hands them): the
     output equals the per-parameter-cast route and the weight / bias gradients come back in fp32 (no cast-back launch), with and
