@@ -221,7 +221,11 @@ def config4_long_scan(device):
 
             def fwd():
                 return ops_raw.scan_fwd(hip, u, delta, A, Bm, Cm, Dv, z, db, True, channel_last=True, need_out=True, need_ckpt=True)
-            f = fwd()
+            try:
+                f = fwd()
+            except RuntimeError as e:
+                out[f"L{Lq}_{name}"] = {"error": str(e)[:200]}
+                continue
 
             def bwd():
                 return ops_raw.scan_bwd(hip, u, delta, A, Bm, Cm, Dv, z, db, dout, f["out"], f["ckpt"], True, channel_last=True,
@@ -454,8 +458,11 @@ def main():
             if not args.no_configs and world == 1:
                 del state, data
                 torch.cuda.empty_cache()
-                out["config1"] = config1_mamba_block(device)
-                out["config4"] = config4_long_scan(device)
+                for key, fn in (("config1", config1_mamba_block), ("config4", config4_long_scan)):
+                    try:
+                        out[key] = fn(device)
+                    except Exception as e:                  # noqa: BLE001 - the step's number must not be lost to a side measurement
+                        out[key] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         if not args.no_cpu_baseline and world == 1 and not dry:       # the host-core baseline is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)
         print(json.dumps(out), flush=True)

@@ -126,24 +126,6 @@ __device__ __forceinline__ int32_t fast_U_of(const TimeMap& tm, int32_t s) {
 // reduce-scatter over the RW lanes of a work item: on return lane r holds, in v[0], the sum over the item's
 // lanes of the value the lanes had at index (r mod V).  V = min(RW, 32) values per call.
 // ------------------------------------------------------------------------------------------------------
-#ifdef SEGM_EMU
-// portable form (CPU emulation build): wave shuffles
-template <int RW, int V>
-__device__ __forceinline__ void reduce_scatter(float (&v)[V], int r) {
-#pragma unroll
-    for (int m = V / 2; m >= 1; m >>= 1) {
-        const uint32_t mask = (r & m) ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int i = 0; i < m; ++i) {
-            const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[m + i]);
-            const float keep = __uint_as_float((hi & mask) | (lo & ~mask));
-            const float send = __uint_as_float((lo & mask) | (hi & ~mask));
-            v[i] = keep + __shfl_xor(send, m);
-        }
-    }
-    if (RW > V) v[0] += __shfl_xor(v[0], V);               // RW == 64: fold the two 32-lane halves
-}
-#else
 // gfx950 form: no LDS traffic.  A stage with partner lane ^ m keeps v[i] on lanes with bit m clear and v[m + i] on
 // lanes with it set, and adds the partner's copy of the same element.
 //   m = 16  v_permlane16_swap_b32 exchanges the odd 16-lane rows of one register with the even rows of another: after
@@ -196,6 +178,5 @@ __device__ __forceinline__ void reduce_scatter(float (&v)[V], int r) {
     }
     if (RW > V) v[0] += __shfl_xor(v[0], V);               // RW == 64: fold the two 32-lane halves
 }
-#endif
 
 }  // namespace segm

@@ -146,6 +146,43 @@ static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); re
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 #define __builtin_amdgcn_readfirstlane(x) (x)   /* only used on values that are uniform over the wave */
 
+// ---- cross-lane data movement (scan_fast.h reduce_scatter: DPP operands and v_permlane16_swap_b32) ---------------------------
+// __builtin_amdgcn_update_dpp(old, src, dpp_ctrl, row_mask, bank_mask, bound_ctrl): every lane reads `src` of the lane dpp_ctrl
+// selects inside its row of 16; lanes whose row / bank (4 lanes) is masked off keep `old`; a source outside the row gives 0
+// with bound_ctrl and `old` without.  Controls: quad_perm 0x00..0xff, row_shl:n 0x100+n (reads lane + n), row_shr:n 0x110+n
+// (reads lane - n), row_ror:n 0x120+n (reads lane - n mod 16), row_mirror 0x140, row_half_mirror 0x141.
+static inline uint32_t hipemu_update_dpp(uint32_t old, uint32_t src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    const int lane = hipemu::t_linear % 64, row = lane >> 4, i = lane & 15;
+    int s = i;
+    bool valid = true;
+    if (ctrl >= 0 && ctrl <= 0xff) s = (i & ~3) | ((ctrl >> (2 * (i & 3))) & 3);
+    else if (ctrl >= 0x101 && ctrl <= 0x10f) { s = i + (ctrl - 0x100); valid = s <= 15; }
+    else if (ctrl >= 0x111 && ctrl <= 0x11f) { s = i - (ctrl - 0x110); valid = s >= 0; }
+    else if (ctrl >= 0x121 && ctrl <= 0x12f) s = (i - (ctrl - 0x120)) & 15;
+    else if (ctrl == 0x140) s = 15 - i;
+    else if (ctrl == 0x141) s = (i & 8) | (7 - (i & 7));
+    else { fprintf(stderr, "hipemu: dpp_ctrl 0x%x not emulated\n", ctrl); abort(); }
+    const uint32_t got = hipemu::exchange(src, valid ? (row * 16 + s) : lane);
+    const bool enabled = ((row_mask >> row) & 1) && ((bank_mask >> (i >> 2)) & 1);
+    if (!enabled) return old;
+    return valid ? got : (bound_ctrl ? 0u : old);
+}
+#define __builtin_amdgcn_update_dpp hipemu_update_dpp
+// v_permlane16_swap_b32 vdst, vsrc: the odd rows of 16 lanes of vdst trade places with the even rows of vsrc (lanes 16..31 of
+// vdst <-> lanes 0..15 of vsrc, 48..63 <-> 32..47); returns {new vdst, new vsrc}
+typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
+static inline hipemu_u32x2 hipemu_permlane16_swap(uint32_t vdst, uint32_t vsrc, bool, bool) {
+    const int lane = hipemu::t_linear % 64;
+    const bool odd = (lane >> 4) & 1;
+    const uint32_t src_of_partner = hipemu::exchange(vsrc, lane ^ 16);
+    const uint32_t dst_of_partner = hipemu::exchange(vdst, lane ^ 16);
+    hipemu_u32x2 r;
+    r.x = odd ? src_of_partner : vdst;
+    r.y = odd ? vsrc : dst_of_partner;
+    return r;
+}
+#define __builtin_amdgcn_permlane16_swap hipemu_permlane16_swap
+
 // ---- MFMA / funnel-shift emulation (conv3d_wgrad.hip) -------------------------------------------------------------
 static inline uint32_t hipemu_alignbyte(uint32_t hi, uint32_t lo, uint32_t n) {
     uint64_t v = ((uint64_t)hi << 32) | lo;

@@ -223,11 +223,61 @@ def run_inner_fn(f, dev, bidirectional=False):
 def check_inner_fn(out, grads, f, what, rtol=6e-4, atol=2e-3, rtolw=1e-3, atolw=1e-3):
     """the reference test's tolerances (test_selective_scan.py:162-169, fp32: output 6e-4 / 2e-3, weights max of both),
     every gradient compared - the reference asserts only a subset"""
-    # + 2e-6 max|ref|: with the reference test's randn weights the outputs reach 7e5 and single elements are differences of
+    # + 1e-5 max|ref|: with the reference test's randn weights the outputs reach 7e5 and single elements are differences of
     # terms of that size - fp32 round-off of the sum, which a fixed atol of 2e-3 cannot cover (the oracle itself differs from the
     # reference fixture by that much: tests/test_oracle_golden.py compares relative to the output scale)
-    assert_close(out, f["out"], rtol, atol + 2e-6 * float(f["out"].abs().max()), what + " out")
+    assert_close(out, f["out"], rtol, atol + 1e-5 * float(f["out"].abs().max()), what + " out")
     rtolw, atolw = max(rtolw, rtol), max(atolw, atol)
     for k, g in grads.items():
         ref = f["d" + k]
         assert_close(g, ref, rtolw, atolw * max(1.0, float(ref.abs().max()) / 16.0), f"{what} d{k}")
+
+
+# ---- "fp32 arithmetic, bf16 storage": what ANY bf16 pipeline of this network loses to rounding ------------------------------
+class _RoundBF16(torch.autograd.Function):
+    """identity whose value and gradient are rounded to bf16 (and kept in the incoming dtype)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class bf16_storage_simulation:
+    """Context manager for the fp32 route of the product model: every tensor that the bf16 path stores in 16 bits between two
+    kernels - the outputs (and incoming gradients) of the convolutions, the normalisation / activation passes, the token
+    transposes, the projections and the scan - is rounded to bf16, while all arithmetic stays fp32.  The deviation of this
+    model from the plain fp32 one is the rounding noise inherent to bf16 storage in THIS network (InstanceNorm backward passes
+    subtract means from gradients that were rounded before the subtraction: the relative error of a deep layer's gradient is
+    tens of per cent); the library path is held to a small multiple of it."""
+
+    TARGETS = (("segmamba_amd.fused_norm", ("instance_norm_act", "pointwise_conv3d", "stem_conv3d", "patch_conv3d",
+                                            "patch_conv_transpose3d")),
+               ("segmamba_amd.conv3d", ("conv3d_same", "conv3d_same_cat")),
+               ("segmamba_amd.segmamba", ("conv3d_same",)),
+               ("segmamba_amd.unet_blocks", ("conv3d_same", "conv3d_same_cat")),
+               ("segmamba_amd.layout", ("volume_to_tokens_layernorm", "tokens_to_volume_add")),
+               ("segmamba_amd.mamba_simple", ("linear_cl", "_inner")))
+
+    def __enter__(self):
+        import importlib
+        self.saved = []
+        for modname, names in self.TARGETS:
+            mod = importlib.import_module(modname)
+            for n in names:
+                orig = getattr(mod, n)
+                self.saved.append((mod, n, orig))
+
+                def wrapped(*a, _orig=orig, **k):
+                    y = _orig(*a, **k)
+                    return _RoundBF16.apply(y) if torch.is_tensor(y) else y
+                setattr(mod, n, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for mod, n, orig in self.saved:
+            setattr(mod, n, orig)
+        return False
