@@ -106,6 +106,12 @@ typedef struct segm_scan_fwd_args {
 } segm_scan_fwd_args;
 
 int segm_selective_scan_fwd(const segm_scan_fwd_args* args);
+/* `n` forward scans in one call: the three directions of a Mamba(bimamba_type="v3") layer (reference
+ * mamba_simple.py:216-264 issues three selective_scan_cuda.fwd calls per layer, one per parameter set).  When the blocks share
+ * batch / dim / dstate / seqlen / dtype / chunk / stream, have one B / C group and a regular shape, they run as ONE grid with a
+ * direction axis (3 x the waves: the small stages of SegMamba cannot fill 1024 SIMDs with one direction); otherwise one after
+ * the other, exactly as n calls of segm_selective_scan_fwd.  Every block owns its workspace / outputs. */
+int segm_selective_scan_fwd_multi(const segm_scan_fwd_args* args, int32_t n);
 size_t segm_selective_scan_fwd_workspace_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen,
                                                int32_t chunk);
 size_t segm_selective_scan_ckpt_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen);
@@ -139,6 +145,7 @@ typedef struct segm_scan_bwd_args {
 } segm_scan_bwd_args;
 
 int segm_selective_scan_bwd(const segm_scan_bwd_args* args);
+int segm_selective_scan_bwd_multi(const segm_scan_bwd_args* args, int32_t n);   /* see segm_selective_scan_fwd_multi */
 size_t segm_selective_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen,
                                                int32_t chunk);
 

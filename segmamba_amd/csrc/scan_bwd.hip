@@ -394,7 +394,12 @@ static int launch_bwd_rw(const ScanDev& P, hipStream_t stream) {
     const Geom& gm = P.gm;
     const unsigned nblocks = (unsigned)((gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL((scan_bwd_agg_kernel<T, NS, TS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
-    launch_scan_carry(P, true, P.agg_sd, P.agg_h, P.carry, P.carry_seg, stream);
+    {
+        ScanDevN PP;
+        memset(&PP, 0, sizeof(PP));
+        PP.d[0] = P;
+        launch_scan_carry(PP, 1, true, stream);
+    }
     hipLaunchKernelGGL((scan_bwd_main_kernel<T, NS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
     return (int)hipGetLastError();
 }
@@ -430,7 +435,9 @@ extern "C" size_t segm_selective_scan_bwd_workspace_bytes(int32_t batch, int32_t
     return bwd_ws_layout(batch, dim, dstate, seqlen, chunk).total;
 }
 
-extern "C" int segm_selective_scan_bwd(const segm_scan_bwd_args* b) {
+// one backward launch (see scan_fwd.hip's scan_fwd_one): `batched` != null hands back the argument block of a launch the
+// regular-shape kernels take instead of launching (the dB / dC clears, if any, are enqueued either way)
+static int scan_bwd_one(const segm_scan_bwd_args* b, ScanDev* batched) {
     if (!b) return SEGM_E_NULL;
     const segm_scan_fwd_args* a = &b->f;
     int rc = validate_scan_common(a);
@@ -444,15 +451,6 @@ extern "C" int segm_selective_scan_bwd(const segm_scan_bwd_args* b) {
     if (b->dB.stride_t < 0 || b->dB.stride_t >= ((int64_t)1 << 31) || b->dC.stride_t < 0 ||
         b->dC.stride_t >= ((int64_t)1 << 31))
         return SEGM_E_SHAPE;
-    {
-        const segm_seq* all[9] = {&a->u, &a->delta, &a->z, &a->out, &b->dout, &b->du, &b->ddelta, &b->dz, nullptr};
-        const segm_bc* bv[2] = {&a->B, &a->C};
-        rc = validate_spans(all, 8, bv, 2, a->dim, a->dstate, a->seqlen, dtype_size(a->dtype));
-        if (rc != SEGM_OK) return rc;
-        const segm_bc* gv[2] = {&b->dB, &b->dC};                       // fp32
-        rc = validate_spans(nullptr, 0, gv, 2, a->dim, a->dstate, a->seqlen, sizeof(float));
-        if (rc != SEGM_OK) return rc;
-    }
     const int chunk = a->chunk;
     const BwdWs ws = bwd_ws_layout(a->batch, a->dim, a->dstate, a->seqlen, chunk);
     if (!b->workspace || b->workspace_bytes < ws.total) return SEGM_E_WORKSPACE;
@@ -462,6 +460,9 @@ extern "C" int segm_selective_scan_bwd(const segm_scan_bwd_args* b) {
     const int64_t nch = (a->seqlen + chunk - 1) / chunk;
     hipStream_t stream = (hipStream_t)a->stream;
     char* wsb = (char*)b->workspace;
+    const segm_seq* all[8] = {&a->u, &a->delta, &a->z, &a->out, &b->dout, &b->du, &b->ddelta, &b->dz};
+    const segm_bc* bv[2] = {&a->B, &a->C};
+    const segm_bc* gv[2] = {&b->dB, &b->dC};                            // fp32
 
     for (int g = 0; g < G; ++g) {
         const int64_t d0 = (int64_t)g * Dg;
@@ -479,16 +480,30 @@ extern "C" int segm_selective_scan_bwd(const segm_scan_bwd_args* b) {
         P.dC = (float*)b->dC.ptr + (int64_t)g * b->dC.stride_g;
         P.dC_sb = b->dC.stride_b; P.dC_st = b->dC.stride_t; P.dC_sn = b->dC.stride_n;
         P.atomic_bc = P.gm.ndt > 1;
+        const bool fast = use_fast_bwd() && scan_bwd_fast_shape(P, es);
+        const int64_t span = fast ? fast_span_rows(P) : 0;
+        rc = validate_spans(all, 8, bv, 2, a->dim, a->dstate, a->seqlen, es, span);
+        if (rc != SEGM_OK) return rc;
+        rc = validate_spans(nullptr, 0, gv, 2, a->dim, a->dstate, a->seqlen, sizeof(float), span);
+        if (rc != SEGM_OK) return rc;
+        if (batched && (!fast || G != 1)) return SEGM_E_SHAPE;          // the caller falls back to one launch per block
         if (P.atomic_bc) {
             const int64_t total = a->seqlen * N;
             dim3 cg((unsigned)((total + 255) / 256), a->batch);
             hipLaunchKernelGGL(clear_bc_kernel, cg, dim3(256), 0, stream, P.dB, P.dB_sb, P.dB_st, P.dB_sn, (int32_t)a->seqlen, N);
             hipLaunchKernelGGL(clear_bc_kernel, cg, dim3(256), 0, stream, P.dC, P.dC_sb, P.dC_st, P.dC_sn, (int32_t)a->seqlen, N);
         }
-        if (use_fast_bwd() && scan_bwd_fast_shape(P)) {     // regular shapes (every SegMamba stage): scan_bwd_fast.hip
-            launch_scan_bwd_fast(P, a->dtype, false, stream);
-            launch_scan_carry(P, true, P.agg_sd, P.agg_h, P.carry, P.carry_seg, stream);
-            launch_scan_bwd_fast(P, a->dtype, true, stream);
+        if (batched) {
+            *batched = P;
+            return SEGM_OK;
+        }
+        if (fast) {                                        // regular shapes (every SegMamba stage): scan_bwd_fast.hip
+            ScanDevN PP;
+            memset(&PP, 0, sizeof(PP));
+            PP.d[0] = P;
+            launch_scan_bwd_fast(PP, 1, a->dtype, false, stream);
+            launch_scan_carry(PP, 1, true, stream);
+            launch_scan_bwd_fast(PP, 1, a->dtype, true, stream);
             rc = (int)hipGetLastError();
         } else if (a->dtype == SEGM_F32) rc = launch_bwd_ns<float>(P, stream);
         else if (a->dtype == SEGM_F16) rc = launch_bwd_ns<f16_t>(P, stream);
@@ -498,4 +513,36 @@ extern "C" int segm_selective_scan_bwd(const segm_scan_bwd_args* b) {
                                b->dD ? b->dD + d0 : nullptr, b->ddelta_bias ? b->ddelta_bias + d0 : nullptr, stream);
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int segm_selective_scan_bwd(const segm_scan_bwd_args* b) { return scan_bwd_one(b, nullptr); }
+
+extern "C" int segm_selective_scan_bwd_multi(const segm_scan_bwd_args* args, int32_t n) {
+    if (!args || n <= 0) return SEGM_E_NULL;
+    bool batch = n > 1 && n <= kMaxDirs && use_fast_bwd();
+    for (int i = 1; batch && i < n; ++i) batch = scan_same_launch(&args[0].f, &args[i].f);
+    if (batch) {                                           // probe WITHOUT side effects first: all blocks must be regular
+        ScanDevN PP;
+        memset(&PP, 0, sizeof(PP));
+        int rc = SEGM_OK;
+        for (int i = 0; i < n && rc == SEGM_OK; ++i) rc = scan_bwd_one(&args[i], &PP.d[i]);
+        if (rc == SEGM_OK) {
+            const segm_scan_fwd_args* a = &args[0].f;
+            hipStream_t stream = (hipStream_t)a->stream;
+            launch_scan_bwd_fast(PP, n, a->dtype, false, stream);
+            launch_scan_carry(PP, n, true, stream);
+            launch_scan_bwd_fast(PP, n, a->dtype, true, stream);
+            const int64_t nch = (a->seqlen + a->chunk - 1) / a->chunk;
+            for (int i = 0; i < n; ++i)
+                launch_reduce_partials(PP.d[i].part, (int64_t)a->batch * nch, a->dstate + 2, a->dim, args[i].dA, a->dstate,
+                                       args[i].dD, args[i].ddelta_bias, stream);
+            return (int)hipGetLastError();
+        }
+        if (rc != SEGM_E_SHAPE) return rc;                  // (a clear enqueued for an earlier block is repeated below: harmless)
+    }
+    for (int i = 0; i < n; ++i) {
+        const int rc = scan_bwd_one(&args[i], nullptr);
+        if (rc != SEGM_OK) return rc;
+    }
+    return SEGM_OK;
 }

@@ -1,16 +1,23 @@
 // Selective scan backward, the "regular shape" kernels (same algorithm, workspace and checkpoints as scan_bwd.hip's
-// K1 / K3; see scan_fwd_fast.hip for what "regular" means - here additionally B, C, dB, dC must be state-fastest, the
-// channel-last production layout).
+// K1 / K3; see scan_fwd_fast.hip for what "regular" means - here additionally B, C, dB, dC must be state-fastest and the
+// sequence tensors channel-contiguous with 16-byte aligned rows: the channel-last production layout).
 //
-//   * addressing: wave-uniform base + constant per-lane offset, no masks, no per-lane time iterators;
-//   * the state loop handles two states per iteration in packed fp32.  Per (step, state) that is 6 packed
-//     instructions + 1 v_exp instead of 17 scalar ones + 1:
-//         forward   a = exp2(delta A2)            h = a h_prev + (delta u) B
-//         backward  dh = g C + e                  t2 = dh h_prev a          dA += t2 delta     q += dh B
-//                   ddA += t2 A                   dB_c = dh (delta u)       dC_c = g h         e = a dh
-//     (du = D g + delta q and ddelta = ddA + u q are formed once per window from q = sum_n dh B);
-//   * the dB / dC contributions overwrite the registers of a / h as the backward walk frees them, so the pair loop
-//     needs no additional arrays, and are summed over the channels with the LDS-free reduce-scatter of scan_bwd.hip.
+// Round 3 rewrite of the main kernel.  Round 2's version needed 256 VGPRs + 208 AGPRs (one wave per SIMD, a quarter of its
+// instructions v_accvgpr moves, another tenth 64-bit address arithmetic) and fetched every window behind exposed latency:
+// VALU busy 64 % of a launch whose arithmetic is 55 % of the instructions.  This one is built to fit two waves per SIMD:
+//   * addressing through buffer resources (scan_fast.h): a scalar offset per row, no vector address arithmetic;
+//   * the five row streams of the NEXT window (u, delta, dout, z, out: 16 steps x RW channels each) are fetched during the
+//     current window's state loop as 16-byte pieces by all lanes of the wave - two loads per lane and stream instead of 80
+//     two-byte loads - and parked in an LDS tile the next window's prologue reads its 16 steps from; B / C of the next window
+//     likewise (raw, per-lane elements).  Nothing of a window's input is waited for inside the window;
+//   * the adjoint carried between windows and the dA accumulators (16 + 16 floats per lane) are register arrays indexed by the
+//     state-pair loop counter (s_set_gpr_idx), not LDS: the LDS footprint is 16 KB per wave (two workgroups per CU);
+//   * q = <dh, B> and the delta-gradient sums are scalars (two plain fma per step and pair instead of two packed ones on
+//     pair accumulators: 32 registers less);
+//   * the channel sums of dB / dC leave the reduce-scatter straight to memory (the lane that ends with the finished value
+//     stores it): no LDS tile, no flush phase.
+// Per (step, state): forward  a = exp2(delta A2), h = a h_prev + (delta u) B;  backward  dh = g C + e, en = a dh,
+//   t2 = en h_prev, dA += t2 delta, q += dh B, ddelta += t2 A, dB_c = dh (delta u), dC_c = g h - 11 packed half-ops + 1 v_exp.
 #include "scan_fast.h"
 
 namespace segm {
@@ -18,12 +25,13 @@ namespace segm {
 constexpr int kFW = 16;     // window = spacing of the forward checkpoints
 
 // ------------------------------------------------------------------------------------------------------
-// K1 (regular shapes): reverse chunk aggregates
+// K1 (regular shapes): reverse chunk aggregates.  grid.y = direction.
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int RW>
-__global__ void __launch_bounds__(kBlock) scan_bwd_agg_fast_kernel(ScanDev P) {
-    constexpr int G = 64 / RW, EPL = FastStage<RW>::EPL;
+__global__ void __launch_bounds__(kBlock) scan_bwd_agg_fast_kernel(ScanDevN PP) {
+    constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     __shared__ __attribute__((aligned(16))) float s_c[2][kWavesPerBlock][G][kFT * kFS];
+    const ScanDev& P = PP.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
@@ -31,8 +39,7 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_fast_kernel(ScanDev P) {
     const int ub = uniform_batch(it);
     const bool softplus_on = P.delta_softplus != 0;
     const bool has_z = P.z.p != nullptr;
-    const int32_t dT = P.tm.ns > 1 ? P.tm.sA : P.tm.sA + P.tm.sW;
-    const int32_t t_item = fast_item_row(P.tm, it.chunk * gm.chunk);
+    const WaveRows wr = wave_rows(P.tm, gm, it);
 
     f2 A2[kFS / 2], e[kFS / 2];
 #pragma unroll
@@ -41,34 +48,34 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_fast_kernel(ScanDev P) {
         e[n] = f2{0.f, 0.f};
     }
     const float bias = P.delta_bias ? P.delta_bias[it.d] : 0.f;
-    const FastRow dp = fast_row<T>(P.delta, ub, t_item, it.d);
-    const FastRow gp = fast_row<T>(P.dout, ub, t_item, it.d);
-    const FastRow zp = fast_row<T>(has_z ? P.z : P.dout, ub, t_item, it.d);
-    const FastStage<RW> sc = fast_stage<T, RW>(P.Cm, ub, t_item, dT, it.r);
+    const Stream dp = make_stream<T>(P.delta, ub, wr, it.d);
+    const Stream gp = make_stream<T>(P.dout, ub, wr, it.d);
+    const Stream zp = make_stream<T>(has_z ? P.z : P.dout, ub, wr, it.d);
+    const StageStream<RW> sc = make_stage<T, RW>(P.Cm, ub, wr, it.r);
 
     const int nsub = gm.chunk / kFT;
     float nd[kFT], ng[kFT], nz[kFT], nc[EPL];
     {
-        const int32_t U = fast_U_of(P.tm, nsub - 1);
-        fast_fetch<T>(nd, dp, U, dT);
-        fast_fetch<T>(ng, gp, U, dT);
-        fast_fetch<T>(nz, zp, U, dT);
-        fast_stage_fetch<T, RW>(nc, sc, U);
+        const int32_t U = wr.bias + fast_U_of(P.tm, nsub - 1);
+        stream_fetch<T>(nd, dp, U, wr.dT);
+        stream_fetch<T>(ng, gp, U, wr.dT);
+        stream_fetch<T>(nz, zp, U, wr.dT);
+        stage_fetch_buf<T, RW>(nc, sc, U, wr.dT);
     }
     float sumd = 0.f;
     int buf = 0;
     for (int s = nsub - 1; s >= 0; --s) {
         float* lc = &s_c[buf][wave][it.gi][0];
-        fast_stage_park<RW>(nc, sc, lc);
+        stage_park_buf<RW>(nc, sc, lc);
         SEGM_WAVE_LDS_SYNC();
         float cd[kFT], cg[kFT], cz[kFT];
 #pragma unroll
         for (int j = 0; j < kFT; ++j) { cd[j] = nd[j]; cg[j] = ng[j]; cz[j] = nz[j]; }
-        const int32_t Un = fast_U_of(P.tm, s > 0 ? s - 1 : 0);     // prefetch the next (lower) sub-tile
-        fast_fetch<T>(nd, dp, Un, dT);
-        fast_fetch<T>(ng, gp, Un, dT);
-        fast_fetch<T>(nz, zp, Un, dT);
-        fast_stage_fetch<T, RW>(nc, sc, Un);
+        const int32_t Un = wr.bias + fast_U_of(P.tm, s > 0 ? s - 1 : 0);     // prefetch the next (lower) sub-tile
+        stream_fetch<T>(nd, dp, Un, wr.dT);
+        stream_fetch<T>(ng, gp, Un, wr.dT);
+        stream_fetch<T>(nz, zp, Un, wr.dT);
+        stage_fetch_buf<T, RW>(nc, sc, Un, wr.dT);
 #pragma unroll
         for (int jj = 0; jj < kFT; ++jj) {
             const int j = kFT - 1 - jj;
@@ -106,38 +113,67 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_fast_kernel(ScanDev P) {
 // ------------------------------------------------------------------------------------------------------
 // K3 (regular shapes): main backward kernel
 // ------------------------------------------------------------------------------------------------------
-// the 16 rows of a window: two affine halves of 8
-template <typename T>
-__device__ __forceinline__ void win_fetch(float (&dst)[kFW], const FastRow& r, int32_t U0, int32_t U1, int32_t dT) {
-    const char* p0 = r.base + (int64_t)U0 * r.stb;
-    const char* p1 = r.base + (int64_t)U1 * r.stb;
-    const int64_t inc = (int64_t)dT * r.stb;
+// One row stream of a wave as 16-byte pieces: a half window (8 steps x RW channels x G items = 64 channels-rows of 8 steps)
+// is 64 * sizeof(T) / 2 pieces, i.e. sizeof(T) / 2 loads per lane.  Piece pc of a half window: item = pc / (8 PPR),
+// step = (pc % (8 PPR)) / PPR, 16-byte part = pc % PPR, with PPR = RW sizeof(T) / 16 pieces per row.  In LDS a half window is
+// the same pieces in order, i.e. [item][step][RW channels].
+template <typename T, int RW> struct TileStream {
+    static constexpr int NLH = (int)sizeof(T) / 2;        // loads per lane and half window
+    static constexpr int PPR = RW * (int)sizeof(T) / 16;
+    static constexpr int HALF_BYTES = 64 * NLH * 16;      // one half window of one stream in LDS
+    rsrc_t rs;
+    uint32_t voff[NLH];
+    int32_t stb;
+};
+template <typename T, int RW>
+__device__ __forceinline__ TileStream<T, RW> make_tile(const Seq& s, int b_uniform, const TimeMap& tm, const Geom& gm,
+                                                        const WaveRows& w, int32_t chunk0, int dt, int lane) {
+    typedef TileStream<T, RW> TS;
+    TS t;
+    t.stb = (int32_t)(s.st * (int64_t)sizeof(T));
+    t.rs = make_rsrc(s.p + ((int64_t)b_uniform * s.sb + (int64_t)w.row_lo * s.st + (int64_t)dt * RW * s.sd) * (int64_t)sizeof(T));
 #pragma unroll
-    for (int j = 0; j < kFT; ++j) {
-        dst[j] = to_f32(*reinterpret_cast<const T*>(p0 + (int64_t)j * inc + r.loff));
-        dst[kFT + j] = to_f32(*reinterpret_cast<const T*>(p1 + (int64_t)j * inc + r.loff));
+    for (int q = 0; q < TS::NLH; ++q) {
+        const int pc = lane + 64 * q;
+        const int item = pc / (8 * TS::PPR), rem = pc % (8 * TS::PPR), jl = rem / TS::PPR, part = rem % TS::PPR;
+        const int32_t item_row = fast_item_row(tm, (chunk0 + item) * gm.chunk) - w.bias - w.row_lo;     // >= 0
+        const int32_t lane_steps = w.dT < 0 ? (kFT - 1 - jl) * (-w.dT) : jl * w.dT;
+        t.voff[q] = (uint32_t)(item_row + lane_steps) * (uint32_t)t.stb + (uint32_t)part * 16u;
     }
+    return t;
 }
-template <typename T>
-__device__ __forceinline__ void win_store(const float (&src)[kFW], const FastRow& r, int32_t U0, int32_t U1, int32_t dT) {
-    char* p0 = const_cast<char*>(r.base) + (int64_t)U0 * r.stb;
-    char* p1 = const_cast<char*>(r.base) + (int64_t)U1 * r.stb;
-    const int64_t inc = (int64_t)dT * r.stb;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// issue the loads of half window `h` (uniform rows of its first step: `rows`) ...
+template <typename T, int RW, int N>
+__device__ __forceinline__ void tile_issue(u32x4_t (&v)[N], const TileStream<T, RW>& t, int32_t rows, int32_t dT) {
+    const uint32_t s0 = (uint32_t)(rows + (dT < 0 ? (kFT - 1) * dT : 0)) * (uint32_t)t.stb;
 #pragma unroll
-    for (int j = 0; j < kFT; ++j) {
-        *reinterpret_cast<T*>(p0 + (int64_t)j * inc + r.loff) = from_f32<T>(src[j]);
-        *reinterpret_cast<T*>(p1 + (int64_t)j * inc + r.loff) = from_f32<T>(src[kFT + j]);
-    }
+    for (int q = 0; q < N; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(t.rs, t.voff[q], s0, 0);
 }
+// ... and park them: `half` points at the half window's LDS bytes
+template <int N>
+__device__ __forceinline__ void tile_park(const u32x4_t (&v)[N], char* half, int lane) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) *reinterpret_cast<u32x4_t*>(half + (lane + 64 * q) * 16) = v[q];
+}
+template <typename T> __device__ __forceinline__ float lds_elem(const char* p) { return to_f32(*reinterpret_cast<const T*>(p)); }
+
+#ifndef SEGM_BWD_MAIN_WAVES
+#define SEGM_BWD_MAIN_WAVES 2
+#endif
 
 template <typename T, int RW>
-__global__ void __launch_bounds__(kBlock, 1) scan_bwd_main_fast_kernel(ScanDev P) {
-    constexpr int G = 64 / RW, EPL = FastStage<RW>::EPL;
+__global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fast_kernel(ScanDevN PP) {
+    constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     constexpr int V = RW < 32 ? RW : 32;
-    __shared__ __attribute__((aligned(16))) float s_bc[kWavesPerBlock][G][2][kFW * kFS];     // [s][n]: B then C
-    __shared__ __attribute__((aligned(16))) float s_dbc[kWavesPerBlock][G][2][kFW * kFS];    // [j][n]: dB then dC
-    __shared__ f2 s_e[kFS / 2][kBlock];                  // adjoint entering from the right, per thread and state pair
-    __shared__ f2 s_dA[kFS / 2][kBlock];
+    typedef TileStream<T, RW> TS;
+    constexpr int NSTREAM = 5;                             // u, delta, dout, z, out
+    constexpr int STREAM_BYTES = 2 * TS::HALF_BYTES;      // a window of one stream
+    __shared__ __attribute__((aligned(16))) char s_tile[kWavesPerBlock][NSTREAM * STREAM_BYTES];           // next window's rows
+    __shared__ __attribute__((aligned(16))) T s_raw[kWavesPerBlock][G][2][kFW * kFS];                        // next window's B, C (raw)
+    __shared__ __attribute__((aligned(16))) float s_bc[kWavesPerBlock][G][2][kFW * kFS];                     // this window's B, C
+    __shared__ __attribute__((aligned(16))) T s_u[kWavesPerBlock][G][kFW][RW];                               // this window's u (read again when it closes)
+    const ScanDev& P = PP.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
@@ -145,216 +181,296 @@ __global__ void __launch_bounds__(kBlock, 1) scan_bwd_main_fast_kernel(ScanDev P
     const int ub = uniform_batch(it);
     const bool softplus_on = P.delta_softplus != 0;
     const bool has_z = P.z.p != nullptr;
-    const int32_t dT = P.tm.ns > 1 ? P.tm.sA : P.tm.sA + P.tm.sW;
+    const WaveRows wr = wave_rows(P.tm, gm, it);
+    const int32_t chunk0 = __builtin_amdgcn_readfirstlane(it.chunk - it.gi);
+    const int32_t dtile = __builtin_amdgcn_readfirstlane(it.dt);
     const int32_t tau0 = it.chunk * gm.chunk;
-    const int32_t t_item = fast_item_row(P.tm, tau0);
 
     const int64_t crow = (int64_t)it.b * gm.nchunks + it.chunk;
+    float en[kFS], dAn[kFS];                              // adjoint entering from the right / dA sums, per state
 #pragma unroll
-    for (int p = 0; p < kFS / 2; ++p) {
-        s_e[p][threadIdx.x] = f2{P.carry[(crow * kFS + 2 * p) * gm.dim + it.d], P.carry[(crow * kFS + 2 * p + 1) * gm.dim + it.d]};
-        s_dA[p][threadIdx.x] = f2{0.f, 0.f};
+    for (int n = 0; n < kFS; ++n) {
+        en[n] = P.carry[(crow * kFS + n) * gm.dim + it.d];
+        dAn[n] = 0.f;
     }
     const float* Arow = P.A + (int64_t)it.d * kFS;
     const float bias = P.delta_bias ? P.delta_bias[it.d] : 0.f;
     const float Dv = P.D ? P.D[it.d] : 0.f;
     float dD_acc = 0.f, dbias_acc = 0.f;
 
-    const FastRow up = fast_row<T>(P.u, ub, t_item, it.d);
-    const FastRow dp = fast_row<T>(P.delta, ub, t_item, it.d);
-    const FastRow gp = fast_row<T>(P.dout, ub, t_item, it.d);
-    const FastRow zp = fast_row<T>(has_z ? P.z : P.dout, ub, t_item, it.d);
-    const FastRow yp = fast_row<T>(has_z ? P.out : P.dout, ub, t_item, it.d);
-    const FastRow dup = fast_row<T>(P.du, ub, t_item, it.d);
-    const FastRow ddp = fast_row<T>(P.ddelta, ub, t_item, it.d);
-    const FastRow dzp = fast_row<T>(has_z ? P.dz : P.du, ub, t_item, it.d);
-    const FastStage<RW> sb = fast_stage<T, RW>(P.Bm, ub, t_item, dT, it.r);
-    const FastStage<RW> sc = fast_stage<T, RW>(P.Cm, ub, t_item, dT, it.r);
-    // dB / dC flush (state-fastest fp32): lane r writes elements el = r + i RW of each 8-step half: j = el / 16, n = el % 16
-    const int fj = it.r / kFS, fn = it.r % kFS;
-    constexpr int FJ = RW >= kFS ? RW / kFS : 1;          // steps between a lane's consecutive elements
-    char* dBb = reinterpret_cast<char*>(P.dB) + (int64_t)ub * P.dB_sb * 4;
-    char* dCb = reinterpret_cast<char*>(P.dC) + (int64_t)ub * P.dC_sb * 4;
-    const uint32_t dB_loff = (uint32_t)(t_item + fj * dT) * (uint32_t)(P.dB_st * 4) + (uint32_t)fn * (uint32_t)(P.dB_sn * 4);
-    const uint32_t dC_loff = (uint32_t)(t_item + fj * dT) * (uint32_t)(P.dC_st * 4) + (uint32_t)fn * (uint32_t)(P.dC_sn * 4);
+    // inputs: cooperative 16-byte tiles (whole d-tile of the wave's items); outputs: per-lane rows
+    const Seq* in_seq[NSTREAM] = {&P.u, &P.delta, &P.dout, has_z ? &P.z : &P.dout, has_z ? &P.out : &P.dout};
+    TS tiles[NSTREAM];
+#pragma unroll
+    for (int i = 0; i < NSTREAM; ++i) tiles[i] = make_tile<T, RW>(*in_seq[i], ub, P.tm, gm, wr, chunk0, dtile, lane);
+    const Stream dup = make_stream<T>(P.du, ub, wr, it.d);
+    const Stream ddp = make_stream<T>(P.ddelta, ub, wr, it.d);
+    const Stream dzp = make_stream<T>(has_z ? P.dz : P.du, ub, wr, it.d);
+    const StageStream<RW> sb = make_stage<T, RW>(P.Bm, ub, wr, it.r);
+    const StageStream<RW> sc = make_stage<T, RW>(P.Cm, ub, wr, it.r);
+    // dB / dC (fp32, state-fastest): the lane that ends a reduce-scatter with the sum of step j stores element (j, n)
+    const int red_j = RW >= 32 ? (it.r & (kFW - 1)) : it.r;       // RW >= 32: lanes 0..15 finish dB_j, 16..31 dC_j; RW 16: both
+    BC dBv = {reinterpret_cast<char*>(P.dB), P.dB_sb, P.dB_st, P.dB_sn};
+    BC dCv = {reinterpret_cast<char*>(P.dC), P.dC_sb, P.dC_st, P.dC_sn};
+    char* const dBbase = dBv.p + ((int64_t)ub * dBv.sb + (int64_t)wr.row_lo * dBv.st) * 4;     // wave-uniform
+    char* const dCbase = dCv.p + ((int64_t)ub * dCv.sb + (int64_t)wr.row_lo * dCv.st) * 4;
+    const rsrc_t dBr = make_rsrc(dBbase);
+    const rsrc_t dCr = make_rsrc(dCbase);
+    const int32_t dB_stb = (int32_t)(P.dB_st * 4), dC_stb = (int32_t)(P.dC_st * 4);
+    // rows of step j of a window: uniform part  bias + U_{j / 8} + (j % 8) dT, split so that both parts are >= 0
+    const int32_t red_jl = red_j & (kFT - 1);
+    const int32_t red_lane_steps = wr.dT < 0 ? (kFT - 1 - red_jl) * (-wr.dT) : red_jl * wr.dT;
+    const uint32_t dB_voff = (uint32_t)(wr.lane_row + red_lane_steps) * (uint32_t)dB_stb;
+    const uint32_t dC_voff = (uint32_t)(wr.lane_row + red_lane_steps) * (uint32_t)dC_stb;
+    const int32_t dB_snb = (int32_t)(P.dB_sn * 4), dC_snb = (int32_t)(P.dC_sn * 4);
+
+    char* tile = &s_tile[wave][0];
+    // this lane's element of a tile row: [item][step][RW channels]
+    const int32_t elem_off = (it.gi * kFT * RW + it.r) * (int)sizeof(T);
+    T* raw_b = &s_raw[wave][it.gi][0][0];
+    T* raw_c = &s_raw[wave][it.gi][1][0];
+    char* ukeep = reinterpret_cast<char*>(&s_u[wave][it.gi][0][it.r]);
     float* lb = &s_bc[wave][it.gi][0][0];
     float* lc = &s_bc[wave][it.gi][1][0];
-    float* ldb = &s_dbc[wave][it.gi][0][0];
-    float* ldc = &s_dbc[wave][it.gi][1][0];
-    const float* ckbase = P.ckpt + (((int64_t)it.b * P.nck + tau0 / kCkpt) * kFS) * gm.dim + it.d;
+    // checkpoints [batch][nck][16][dim]: buffer based at the wave's lowest chunk
+    const rsrc_t ckr = make_rsrc(P.ckpt + (((int64_t)ub * P.nck + (int64_t)chunk0 * (gm.chunk / kCkpt)) * kFS) * gm.dim);
+    const uint32_t ck_voff = ((uint32_t)(it.gi * (gm.chunk / kCkpt)) * kFS * (uint32_t)gm.dim + (uint32_t)it.d) * 4u;
+    const int32_t ck_state = gm.dim * 4;
 
     const int nwin = gm.chunk / kFW;
-    for (int w = nwin - 1; w >= 0; --w) {
-        const int32_t U0 = fast_U_of(P.tm, 2 * w), U1 = fast_U_of(P.tm, 2 * w + 1);
-        // ---- window data -------------------------------------------------------------------------------------
+    // ---- first window's inputs: fetched and parked up front (the only exposed fetch of the chunk) -----------------------
+    {
+        const int32_t U0 = wr.bias + fast_U_of(P.tm, 2 * (nwin - 1)), U1 = wr.bias + fast_U_of(P.tm, 2 * (nwin - 1) + 1);
+#pragma unroll
+        for (int i = 0; i < NSTREAM; ++i) {
+            u32x4_t v0[TS::NLH], v1[TS::NLH];
+            tile_issue(v0, tiles[i], U0, wr.dT);
+            tile_issue(v1, tiles[i], U1, wr.dT);
+            tile_park(v0, tile + i * STREAM_BYTES, lane);
+            tile_park(v1, tile + i * STREAM_BYTES + TS::HALF_BYTES, lane);
+        }
         float vb0[EPL], vb1[EPL], vc0[EPL], vc1[EPL];
-        fast_stage_fetch<T, RW>(vb0, sb, U0);
-        fast_stage_fetch<T, RW>(vb1, sb, U1);
-        fast_stage_fetch<T, RW>(vc0, sc, U0);
-        fast_stage_fetch<T, RW>(vc1, sc, U1);
-        float wu[kFW], wd[kFW], wg[kFW], wdu[kFW];
-        f2 qs[kFW], ddA[kFW];                             // sum over states of dh B and of t2 A, two partial sums each
-        win_fetch<T>(wu, up, U0, U1, dT);
-        win_fetch<T>(wd, dp, U0, U1, dT);
-        win_fetch<T>(wg, gp, U0, U1, dT);
+        stage_fetch_buf<T, RW>(vb0, sb, U0, wr.dT);
+        stage_fetch_buf<T, RW>(vb1, sb, U1, wr.dT);
+        stage_fetch_buf<T, RW>(vc0, sc, U0, wr.dT);
+        stage_fetch_buf<T, RW>(vc1, sc, U1, wr.dT);
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            raw_b[sb.lds0 + i * sb.ldsinc] = from_f32<T>(vb0[i]);
+            raw_b[kFT * kFS + sb.lds0 + i * sb.ldsinc] = from_f32<T>(vb1[i]);
+            raw_c[sc.lds0 + i * sc.ldsinc] = from_f32<T>(vc0[i]);
+            raw_c[kFT * kFS + sc.lds0 + i * sc.ldsinc] = from_f32<T>(vc1[i]);
+        }
+    }
+    float hp_next;                                        // checkpoint of the next (state, window) of the walk, one state ahead
+    hp_next = BufIO<float>::ld(ckr, ck_voff, (uint32_t)((nwin - 1) * kFS * ck_state));
+
+    for (int w = nwin - 1; w >= 0; --w) {
+        SEGM_WAVE_LDS_SYNC();                             // the tiles of this window are parked (by this wave)
+        // ---- window prologue: the 16 steps of this lane from the tiles, B / C to fp32 -----------------------------------
+        float wd[kFW], wg[kFW], wdu[kFW], q[kFW], ddA[kFW];
         {
-            float wz[kFW], wy[kFW];
-            if (has_z) {
-                win_fetch<T>(wz, zp, U0, U1, dT);
-                win_fetch<T>(wy, yp, U0, U1, dT);
-            }
+            float dzv[kFW];
 #pragma unroll
             for (int j = 0; j < kFW; ++j) {
-                float dl = wd[j] + bias;
+                const int off = (j / kFT) * TS::HALF_BYTES + (j % kFT) * RW * (int)sizeof(T) + elem_off;
+                const float uu = lds_elem<T>(tile + 0 * STREAM_BYTES + off);
+                float dl = lds_elem<T>(tile + 1 * STREAM_BYTES + off) + bias;
                 wd[j] = softplus_on ? softplus20(dl) : dl;
+                wg[j] = lds_elem<T>(tile + 2 * STREAM_BYTES + off);
                 if (has_z) {
-                    const float zz = wz[j], sg = sigmoidf(zz);
-                    wz[j] = wg[j] * wy[j] * sg * fmaf(zz, 1.f - sg, 1.f);       // dz
+                    const float zz = lds_elem<T>(tile + 3 * STREAM_BYTES + off), yy = lds_elem<T>(tile + 4 * STREAM_BYTES + off);
+                    const float sg = sigmoidf(zz);
+                    dzv[j] = wg[j] * yy * sg * fmaf(zz, 1.f - sg, 1.f);
                     wg[j] *= zz * sg;
                 }
-                wdu[j] = wd[j] * wu[j];
-                qs[j] = f2{0.f, 0.f};
-                ddA[j] = f2{0.f, 0.f};
-                dD_acc = fmaf(wg[j], wu[j], dD_acc);
+                wdu[j] = wd[j] * uu;
+                q[j] = 0.f;
+                ddA[j] = 0.f;
+                dD_acc = fmaf(wg[j], uu, dD_acc);
+                // u is needed once more when the window closes (ddelta = ... + u q): kept as raw elements in LDS, not in registers
+                reinterpret_cast<T*>(ukeep)[j * RW] = from_f32<T>(uu);
             }
-            if (has_z) win_store<T>(wz, dzp, U0, U1, dT);
+            if (has_z) {
+                const int32_t U0 = wr.bias + fast_U_of(P.tm, 2 * w), U1 = wr.bias + fast_U_of(P.tm, 2 * w + 1);
+                const uint32_t inc = (uint32_t)(wr.dT * dzp.stb);
+                uint32_t so = (uint32_t)U0 * (uint32_t)dzp.stb;
+#pragma unroll
+                for (int j = 0; j < kFW; ++j) {
+                    if (j == kFT) so = (uint32_t)U1 * (uint32_t)dzp.stb;
+                    BufIO<T>::st(dzp.rs, dzp.voff, so, dzv[j]);
+                    so += inc;
+                }
+            }
         }
-        SEGM_WAVE_LDS_SYNC();                             // the previous window is done with s_bc / s_dbc
-        fast_stage_park<RW>(vb0, sb, lb);
-        fast_stage_park<RW>(vb1, sb, lb + kFT * kFS);
-        fast_stage_park<RW>(vc0, sc, lc);
-        fast_stage_park<RW>(vc1, sc, lc + kFT * kFS);
-        SEGM_WAVE_LDS_SYNC();
+#pragma unroll
+        for (int i = 0; i < 2 * EPL; ++i) {              // raw [16][16] -> fp32, element e = r + i RW of each matrix
+            const int e = it.r + i * RW;
+            lb[e] = to_f32(raw_b[e]);
+            lc[e] = to_f32(raw_c[e]);
+        }
+        SEGM_WAVE_LDS_SYNC();                             // tiles and raw B / C are consumed: the state loop may refill them
 
-        const float* ck = ckbase + (int64_t)w * kFS * gm.dim;      // state entering the window
+        const int32_t Un0 = wr.bias + fast_U_of(P.tm, w > 0 ? 2 * (w - 1) : 0), Un1 = wr.bias + fast_U_of(P.tm, w > 0 ? 2 * (w - 1) + 1 : 1);
+        const int32_t Uw0 = wr.bias + fast_U_of(P.tm, 2 * w), Uw1 = wr.bias + fast_U_of(P.tm, 2 * w + 1);
 #pragma unroll 1
-        for (int p = 0; p < kFS / 2; ++p) {               // runtime loop over state pairs
-            const f2 A2n = f2{Arow[2 * p], Arow[2 * p + 1]} * kLog2e;
-            const f2 An = A2n * 0.6931471805599453f;
-            const f2 hp = {ck[(int64_t)(2 * p) * gm.dim], ck[(int64_t)(2 * p + 1) * gm.dim]};
-            f2 en = s_e[p][threadIdx.x];
-            f2 dAn = s_dA[p][threadIdx.x];
-            f2 a[kFW], h[kFW];
+        for (int n = 0; n < kFS; ++n) {                   // runtime loop over the states
+            // ---- the next window's inputs, a slice per state: streams in n = 0..4, B / C halves in n = 5..8 ---------------
+            u32x4_t pv0[TS::NLH], pv1[TS::NLH];
+            float pbc[EPL];
+            if (n == 0) { tile_issue(pv0, tiles[0], Un0, wr.dT); tile_issue(pv1, tiles[0], Un1, wr.dT); }
+            else if (n == 1) { tile_issue(pv0, tiles[1], Un0, wr.dT); tile_issue(pv1, tiles[1], Un1, wr.dT); }
+            else if (n == 2) { tile_issue(pv0, tiles[2], Un0, wr.dT); tile_issue(pv1, tiles[2], Un1, wr.dT); }
+            else if (n == 3) { tile_issue(pv0, tiles[3], Un0, wr.dT); tile_issue(pv1, tiles[3], Un1, wr.dT); }
+            else if (n == 4) { tile_issue(pv0, tiles[4], Un0, wr.dT); tile_issue(pv1, tiles[4], Un1, wr.dT); }
+            else if (n == 5) stage_fetch_buf<T, RW>(pbc, sb, Un0, wr.dT);
+            else if (n == 6) stage_fetch_buf<T, RW>(pbc, sb, Un1, wr.dT);
+            else if (n == 7) stage_fetch_buf<T, RW>(pbc, sc, Un0, wr.dT);
+            else if (n == 8) stage_fetch_buf<T, RW>(pbc, sc, Un1, wr.dT);
+            const float hp = hp_next;
+            {                                             // checkpoint of the state after this one (next window after the last)
+                const int nn = n + 1 < kFS ? n + 1 : 0;
+                const int wn = n + 1 < kFS ? w : (w > 0 ? w - 1 : 0);
+                hp_next = BufIO<float>::ld(ckr, ck_voff, (uint32_t)((wn * kFS + nn) * ck_state));
+            }
+            const float A2n = Arow[n] * kLog2e;
+            const float An = A2n * 0.6931471805599453f;
+            float e1 = en[n];
+            float dA1 = dAn[n];
+            float a[kFW], h[kFW];
 #pragma unroll
             for (int j = 0; j < kFW; ++j) {
-                const f2 bb = *reinterpret_cast<const f2*>(lb + j * kFS + 2 * p);
-                const f2 da = A2n * wd[j];
-                a[j] = f2{fast_exp2(da.x), fast_exp2(da.y)};
-                h[j] = a[j] * (j ? h[j - 1] : hp) + bb * wdu[j];
+                const float bb = lb[j * kFS + n];
+                a[j] = fast_exp2(A2n * wd[j]);
+                h[j] = fmaf(a[j], j ? h[j - 1] : hp, bb * wdu[j]);
             }
 #pragma unroll
             for (int jj = 0; jj < kFW; ++jj) {
                 const int j = kFW - 1 - jj;
-                const f2 bb = *reinterpret_cast<const f2*>(lb + j * kFS + 2 * p);
-                const f2 cc = *reinterpret_cast<const f2*>(lc + j * kFS + 2 * p);
-                const f2 dh = cc * wg[j] + en;
-                const f2 t2 = dh * (j ? h[j - 1] : hp) * a[j];
-                dAn = t2 * wd[j] + dAn;
-                qs[j] = dh * bb + qs[j];
-                ddA[j] = t2 * An + ddA[j];
-                en = a[j] * dh;
-                a[j] = dh * wdu[j];                        // dB contribution of (j, pair), in a's registers
-                h[j] = h[j] * wg[j];                       // dC contribution, in h's registers
+                const float bb = lb[j * kFS + n];
+                const float cc = lc[j * kFS + n];
+                const float dh = fmaf(cc, wg[j], e1);
+                e1 = a[j] * dh;
+                const float t2 = e1 * (j ? h[j - 1] : hp);
+                dA1 = fmaf(t2, wd[j], dA1);
+                q[j] = fmaf(dh, bb, q[j]);
+                ddA[j] = fmaf(t2, An, ddA[j]);
+                a[j] = dh * wdu[j];                        // dB contribution of (j, n), in a's register
+                h[j] = h[j] * wg[j];                       // dC contribution, in h's register
+                SEGM_PIN_F32(e1);                          // one step at a time: keeps the LDS reads of earlier steps from being hoisted
             }
-            // sum the dB / dC contributions over the channels (lanes) of the work item, one state at a time
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int n = 2 * p + half;
+            en[n] = e1;
+            dAn[n] = dA1;
+            // ---- sum the dB / dC contributions over the channels (lanes) of the work item; the lane that ends with the sum of
+            //      step j stores element (j, n) ----------------------------------------------------------------------------
+            {
+                const uint32_t rowU = (uint32_t)((red_j < kFT ? Uw0 : Uw1) + (wr.dT < 0 ? (kFT - 1) * wr.dT : 0));
+                const uint32_t rowB = rowU * (uint32_t)dB_stb + (uint32_t)(n * dB_snb);
+                const uint32_t rowC = rowU * (uint32_t)dC_stb + (uint32_t)(n * dC_snb);
                 if constexpr (RW >= 32) {
                     float v[2 * kFW];
 #pragma unroll
-                    for (int j = 0; j < kFW; ++j) {
-                        v[j] = half ? a[j].y : a[j].x;
-                        v[kFW + j] = half ? h[j].y : h[j].x;
-                    }
+                    for (int j = 0; j < kFW; ++j) { v[j] = a[j]; v[kFW + j] = h[j]; }
                     reduce_scatter<RW, V>(v, it.r);
-                    if (it.r < 32) {
-                        const int j = it.r & (kFW - 1);   // lanes 0..15 -> dB_j, 16..31 -> dC_j
-                        (it.r < kFW ? ldb : ldc)[j * kFS + n] = v[0];
+                    if (it.r < 32) {                       // lanes 0..15 -> dB_j, 16..31 -> dC_j
+                        if (it.r < kFW) {
+                            if (P.atomic_bc) atomicAdd(reinterpret_cast<float*>(dBbase + (dB_voff + rowB)), v[0]);
+                            else BufIO<float>::st(dBr, dB_voff + rowB, 0u, v[0]);
+                        } else {
+                            if (P.atomic_bc) atomicAdd(reinterpret_cast<float*>(dCbase + (dC_voff + rowC)), v[0]);
+                            else BufIO<float>::st(dCr, dC_voff + rowC, 0u, v[0]);
+                        }
                     }
                 } else {
-                    float vb[kFW], vc[kFW];
-#pragma unroll
-                    for (int j = 0; j < kFW; ++j) { vb[j] = half ? a[j].y : a[j].x; vc[j] = half ? h[j].y : h[j].x; }
-                    reduce_scatter<RW, kFW>(vb, it.r);
-                    reduce_scatter<RW, kFW>(vc, it.r);
-                    ldb[it.r * kFS + n] = vb[0];
-                    ldc[it.r * kFS + n] = vc[0];
+                    reduce_scatter<RW, kFW>(a, it.r);
+                    reduce_scatter<RW, kFW>(h, it.r);
+                    if (P.atomic_bc) {
+                        atomicAdd(reinterpret_cast<float*>(dBbase + (dB_voff + rowB)), a[0]);
+                        atomicAdd(reinterpret_cast<float*>(dCbase + (dC_voff + rowC)), h[0]);
+                    } else {
+                        BufIO<float>::st(dBr, dB_voff + rowB, 0u, a[0]);
+                        BufIO<float>::st(dCr, dC_voff + rowC, 0u, h[0]);
+                    }
                 }
             }
-            s_e[p][threadIdx.x] = en;
-            s_dA[p][threadIdx.x] = dAn;
-        }
-        SEGM_WAVE_LDS_SYNC();                             // the dB / dC tile of every item is complete
-        {
+            // ---- park what this state's slice fetched (it arrived during the arithmetic) ---------------------------------------
+            if (n < NSTREAM) {
+                tile_park(pv0, tile + n * STREAM_BYTES, lane);
+                tile_park(pv1, tile + n * STREAM_BYTES + TS::HALF_BYTES, lane);
+            } else if (n < NSTREAM + 4) {
+                const int k = n - NSTREAM;                 // 0: B first half, 1: B second half, 2: C first half, 3: C second half
+                T* dst = (k < 2 ? raw_b : raw_c) + (k & 1) * kFT * kFS;
+                const StageStream<RW>& ss = k < 2 ? sb : sc;
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int32_t Uh = hh ? U1 : U0;
-                char* pb = dBb + (int64_t)Uh * (P.dB_st * 4);
-                char* pc = dCb + (int64_t)Uh * (P.dC_st * 4);
-#pragma unroll
-                for (int i = 0; i < EPL; ++i) {
-                    const int j = hh * kFT + fj + i * FJ;
-                    float* ob = reinterpret_cast<float*>(pb + (int64_t)(i * FJ * dT) * (P.dB_st * 4) + dB_loff);
-                    float* oc = reinterpret_cast<float*>(pc + (int64_t)(i * FJ * dT) * (P.dC_st * 4) + dC_loff);
-                    const float xb = ldb[j * kFS + fn], xc = ldc[j * kFS + fn];
-                    if (P.atomic_bc) { atomicAdd(ob, xb); atomicAdd(oc, xc); }
-                    else { *ob = xb; *oc = xc; }
-                }
+                for (int i = 0; i < EPL; ++i) dst[ss.lds0 + i * ss.ldsinc] = from_f32<T>(pbc[i]);
             }
         }
         {
             float du[kFW], ddl[kFW];
 #pragma unroll
             for (int j = 0; j < kFW; ++j) {
-                const float q = qs[j].x + qs[j].y;
-                du[j] = fmaf(wd[j], q, Dv * wg[j]);
-                float ddv = fmaf(wu[j], q, ddA[j].x + ddA[j].y);
+                const float uu = to_f32(reinterpret_cast<const T*>(ukeep)[j * RW]);
+                du[j] = fmaf(wd[j], q[j], Dv * wg[j]);
+                float ddv = fmaf(uu, q[j], ddA[j]);
                 ddv *= softplus_on ? 1.f - fast_exp(-wd[j]) : 1.f;       // sigmoid(raw) = 1 - exp(-softplus(raw))
                 dbias_acc += ddv;
                 ddl[j] = ddv;
             }
-            win_store<T>(du, dup, U0, U1, dT);
-            win_store<T>(ddl, ddp, U0, U1, dT);
+            const uint32_t uinc = (uint32_t)(wr.dT * dup.stb), dinc = (uint32_t)(wr.dT * ddp.stb);
+            uint32_t uso = (uint32_t)Uw0 * (uint32_t)dup.stb, dso = (uint32_t)Uw0 * (uint32_t)ddp.stb;
+#pragma unroll
+            for (int j = 0; j < kFW; ++j) {
+                if (j == kFT) { uso = (uint32_t)Uw1 * (uint32_t)dup.stb; dso = (uint32_t)Uw1 * (uint32_t)ddp.stb; }
+                BufIO<T>::st(dup.rs, dup.voff, uso, du[j]);
+                BufIO<T>::st(ddp.rs, ddp.voff, dso, ddl[j]);
+                uso += uinc;
+                dso += dinc;
+            }
         }
     }
     const int64_t row = crow * (kFS + 2);
 #pragma unroll
-    for (int p = 0; p < kFS / 2; ++p) {
-        const f2 dA = s_dA[p][threadIdx.x];
-        P.part[(row + 2 * p) * gm.dim + it.d] = dA.x;
-        P.part[(row + 2 * p + 1) * gm.dim + it.d] = dA.y;
-    }
+    for (int n = 0; n < kFS; ++n) P.part[(row + n) * gm.dim + it.d] = dAn[n];
     P.part[(row + kFS) * gm.dim + it.d] = dD_acc;
     P.part[(row + kFS + 1) * gm.dim + it.d] = dbias_acc;
+    (void)tau0;
 }
 
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
-bool scan_bwd_fast_shape(const ScanDev& P) {
+bool scan_bwd_fast_shape(const ScanDev& P, size_t esize) {
     if (!scan_fast_shape(P)) return false;
     // state-fastest B, C, dB, dC (the channel-last production layout)
-    return P.Bm.sn < P.Bm.st && P.Cm.sn < P.Cm.st && P.dB_sn < P.dB_st && P.dC_sn < P.dC_st;
+    if (!(P.Bm.sn < P.Bm.st && P.Cm.sn < P.Cm.st && P.dB_sn < P.dB_st && P.dC_sn < P.dC_st)) return false;
+    // the input streams are fetched as 16-byte pieces of channel-contiguous rows
+    const Seq* in[5] = {&P.u, &P.delta, &P.dout, &P.z, &P.out};
+    for (const Seq* s : in) {
+        if (!s->p) continue;
+        if (s->sd != 1 || (s->st * (int64_t)esize) % 16 != 0 || (s->sb * (int64_t)esize) % 16 != 0 ||
+            (reinterpret_cast<uintptr_t>(s->p) % 16) != 0)
+            return false;
+    }
+    return ((int64_t)P.gm.rw * (int64_t)esize) % 16 == 0;
 }
 
 template <typename T, int RW>
-static void launch_bwd_fast_rw(const ScanDev& P, bool main, hipStream_t stream) {
-    const unsigned nblocks = (unsigned)((P.gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (main) hipLaunchKernelGGL((scan_bwd_main_fast_kernel<T, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
-    else hipLaunchKernelGGL((scan_bwd_agg_fast_kernel<T, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+static void launch_bwd_fast_rw(const ScanDevN& PP, int ndir, bool main, hipStream_t stream) {
+    const unsigned nblocks = (unsigned)((PP.d[0].gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (main) hipLaunchKernelGGL((scan_bwd_main_fast_kernel<T, RW>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+    else hipLaunchKernelGGL((scan_bwd_agg_fast_kernel<T, RW>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
 }
 template <typename T>
-static void launch_bwd_fast_t(const ScanDev& P, bool main, hipStream_t stream) {
-    if (P.gm.rw == 64) launch_bwd_fast_rw<T, 64>(P, main, stream);
-    else if (P.gm.rw == 32) launch_bwd_fast_rw<T, 32>(P, main, stream);
-    else launch_bwd_fast_rw<T, 16>(P, main, stream);
+static void launch_bwd_fast_t(const ScanDevN& PP, int ndir, bool main, hipStream_t stream) {
+    if (PP.d[0].gm.rw == 64) launch_bwd_fast_rw<T, 64>(PP, ndir, main, stream);
+    else if (PP.d[0].gm.rw == 32) launch_bwd_fast_rw<T, 32>(PP, ndir, main, stream);
+    else launch_bwd_fast_rw<T, 16>(PP, ndir, main, stream);
 }
-// launches K1 (main == false) or K3 (main == true) of the regular-shape backward
-void launch_scan_bwd_fast(const ScanDev& P, int dtype, bool main, hipStream_t stream) {
-    if (dtype == SEGM_F32) launch_bwd_fast_t<float>(P, main, stream);
-    else if (dtype == SEGM_F16) launch_bwd_fast_t<f16_t>(P, main, stream);
-    else launch_bwd_fast_t<bf16_t>(P, main, stream);
+// launches K1 (main == false) or K3 (main == true) of the regular-shape backward for `ndir` blocks of one geometry
+void launch_scan_bwd_fast(const ScanDevN& PP, int ndir, int dtype, bool main, hipStream_t stream) {
+    if (dtype == SEGM_F32) launch_bwd_fast_t<float>(PP, ndir, main, stream);
+    else if (dtype == SEGM_F16) launch_bwd_fast_t<f16_t>(PP, ndir, main, stream);
+    else launch_bwd_fast_t<bf16_t>(PP, ndir, main, stream);
 }
 
 }  // namespace segm

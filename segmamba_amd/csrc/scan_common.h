@@ -35,6 +35,11 @@ struct ScanDev {
     int32_t atomic_bc;                     // more than one d-tile contributes to dB / dC -> accumulate atomically
 };
 
+// up to three launches of ONE geometry (the three directions of a Mamba v3 layer: same shapes, different time order,
+// tensors and parameters) travel in one kernel argument; blockIdx.y picks the block
+constexpr int kMaxDirs = 3;
+struct ScanDevN { ScanDev d[kMaxDirs]; };
+
 // --- staging of the rows shared by all channels (B_t, C_t) ---------------------------------------------
 // Each work item's own RW lanes fetch the TS x NS block of one matrix for the TS consecutive logical steps
 // tau0 .. tau0+TS-1 (`it0` = the item's iterator positioned at tau0) into registers (`stage_fetch`) and
@@ -135,13 +140,16 @@ size_t dtype_size(int dtype);
 void fill_scan_dev(ScanDev& P, const segm_scan_fwd_args* a, int g, int chunk);
 // the kernels' 32-bit offset arithmetic: L <= 2^24, |stride_t| * esize < 2^24, per-batch span of every view < 4 GiB
 int validate_spans(const segm_seq* const* seqs, int nseq, const segm_bc* const* bcs, int nbc, int dim, int dstate,
-                   int64_t L, size_t esize);
+                   int64_t L, size_t esize, int64_t span_rows);
+int64_t fast_span_rows(const ScanDev& P);
+bool scan_same_launch(const segm_scan_fwd_args* a, const segm_scan_fwd_args* b);
 bool scan_fast_shape(const ScanDev& P);                        // scan_fwd_fast.hip: shapes its kernels take
-void launch_scan_fwd_fast(const ScanDev& P, int dtype, bool apply, hipStream_t stream);
-bool scan_bwd_fast_shape(const ScanDev& P);                    // scan_bwd_fast.hip
-void launch_scan_bwd_fast(const ScanDev& P, int dtype, bool main, hipStream_t stream);
-void launch_scan_carry(const ScanDev& P, bool reverse, const float* agg_sd, const float* agg_h, float* carry, float* seg,
-                       hipStream_t stream);
+void launch_scan_fwd_fast(const ScanDevN& PP, int ndir, int dtype, bool apply, hipStream_t stream);
+bool scan_bwd_fast_shape(const ScanDev& P, size_t esize);      // scan_bwd_fast.hip
+void launch_scan_bwd_fast(const ScanDevN& PP, int ndir, int dtype, bool main, hipStream_t stream);
+// carry composition of `ndir` argument blocks of one geometry; forward: agg_* / carry / carry_seg of each block, reverse: the
+// backward's workspace (its agg_* / carry / carry_seg fields hold the reverse aggregates)
+void launch_scan_carry(const ScanDevN& PP, int ndir, bool reverse, hipStream_t stream);
 size_t scan_carry_scratch_bytes(int batch, int dim, int nstate, int64_t nchunks);
 
 }  // namespace segm

@@ -112,6 +112,137 @@ __device__ __forceinline__ void fast_stage_park(const float (&v)[FastStage<RW>::
     for (int i = 0; i < FastStage<RW>::EPL; ++i) lds_item[st.lds0 + i * st.ldsinc] = v[i];
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Buffer-addressed row streams (round 3).  The round-2 kernels formed a 64-bit per-lane address for every 2-byte access
+// (v_lshl_add_u64 / v_mad_u64_u32: ~45 % of the VALU instructions around the recurrence were address arithmetic, in a
+// kernel that is VALU-issue bound).  Here a tensor is a buffer resource whose base is a wave-uniform 64-bit pointer, a lane
+// adds ONE constant 32-bit byte offset and the row of a step is a scalar byte offset:
+//       address = base(batch, lowest row of the wave)  +  voff(lane)  +  soff(sub-tile, step)
+// - no vector instruction takes part in addressing, and a per-batch span beyond 4 GiB (L = 2^24 rows of 96 fp32 channels)
+// is addressable because only the rows ONE wave touches must fit 32 bits (FORWARD / REVERSED; an INTERLEAVED chunk spans the
+// whole sequence).  All parts are non-negative: for a descending order (dT < 0) the uniform part counts down from
+// `bias = chunk - 1` and the lane's anchor is the LOWEST row of its item.
+// ------------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xffffffffu, 0x00020000);   // raw, no range check
+}
+template <typename T> struct BufIO;
+template <> struct BufIO<float> {
+    static __device__ __forceinline__ float ld(rsrc_t r, uint32_t voff, uint32_t soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    }
+    static __device__ __forceinline__ void st(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+    }
+};
+template <> struct BufIO<bf16_t> {
+    static __device__ __forceinline__ float ld(rsrc_t r, uint32_t voff, uint32_t soff) {
+        return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0) << 16);
+    }
+    static __device__ __forceinline__ void st(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, from_f32<bf16_t>(v)), r, voff, soff, 0);
+    }
+};
+template <> struct BufIO<f16_t> {
+    static __device__ __forceinline__ float ld(rsrc_t r, uint32_t voff, uint32_t soff) {
+        return to_f32(__builtin_bit_cast(f16_t, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0)));
+    }
+    static __device__ __forceinline__ void st(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, from_f32<f16_t>(v)), r, voff, soff, 0);
+    }
+};
+
+// what is uniform over a wave for all of its row streams, and the lane's anchor row
+struct WaveRows {
+    int32_t dT;            // rows between consecutive logical steps inside a sub-tile (+1, -1, or L / nslices)
+    int32_t bias;          // dT < 0 ? chunk - 1 : 0    (added to every uniform row offset)
+    int32_t row_lo;        // lowest physical row a lane of this wave touches          (uniform)
+    int32_t lane_row;      // lowest row of this lane's item - row_lo                   (>= 0)
+};
+__device__ __forceinline__ WaveRows wave_rows(const TimeMap& tm, const Geom& gm, const Item& it) {
+    WaveRows w;
+    w.dT = tm.ns > 1 ? tm.sA : tm.sA + tm.sW;
+    w.bias = w.dT < 0 ? gm.chunk - 1 : 0;
+    const int32_t chunk0 = __builtin_amdgcn_readfirstlane(it.chunk - it.gi);      // the wave's items are chunks chunk0 .. chunk0 + g - 1
+    const int32_t a_first = fast_item_row(tm, chunk0 * gm.chunk) - w.bias;
+    const int32_t a_last = fast_item_row(tm, (chunk0 + gm.g - 1) * gm.chunk) - w.bias;
+    w.row_lo = a_first < a_last ? a_first : a_last;
+    w.lane_row = fast_item_row(tm, it.chunk * gm.chunk) - w.bias - w.row_lo;
+    return w;
+}
+// one sequence tensor as a wave sees it
+struct Stream {
+    rsrc_t rs;
+    uint32_t voff;         // lane_row * stride_t + d * stride_d, bytes
+    int32_t stb;           // stride_t in bytes (uniform)
+};
+template <typename T> __device__ __forceinline__ Stream make_stream(const Seq& s, int b_uniform, const WaveRows& w, int d) {
+    Stream r;
+    r.stb = (int32_t)(s.st * (int64_t)sizeof(T));
+    r.rs = make_rsrc(s.p + ((int64_t)b_uniform * s.sb + (int64_t)w.row_lo * s.st) * (int64_t)sizeof(T));
+    r.voff = (uint32_t)w.lane_row * (uint32_t)r.stb + (uint32_t)d * (uint32_t)(s.sd * (int64_t)sizeof(T));
+    return r;
+}
+// the kFT rows of the sub-tile whose first step sits `rows` rows (uniform, >= 0 together with j * dT) above the anchor
+template <typename T>
+__device__ __forceinline__ void stream_fetch(float (&dst)[kFT], const Stream& st, int32_t rows, int32_t dT) {
+    // unsigned arithmetic: every partial term may wrap, the sum is the true offset in [0, 2^32)
+    uint32_t so = (uint32_t)rows * (uint32_t)st.stb;      // running scalar offset: one s_add per row (not a multiply per row)
+    const uint32_t inc = (uint32_t)(dT * st.stb);
+#pragma unroll
+    for (int j = 0; j < kFT; ++j) {
+        dst[j] = BufIO<T>::ld(st.rs, st.voff, so);
+        so += inc;
+    }
+}
+
+// B / C staging through buffer loads: lane r of a work item fetches EPL elements of the kFT x 16 block of a sub-tile;
+// element i sits  i * jrow  steps and  i * ninc  bytes after the lane's first one
+template <int RW> struct StageStream {
+    static constexpr int EPL = kFT * kFS / RW;
+    rsrc_t rs;
+    uint32_t voff;
+    int32_t stb, jrow, ninc, jmax;
+    int32_t lds0, ldsinc;
+};
+template <typename T, int RW>
+__device__ __forceinline__ StageStream<RW> make_stage(const BC& m, int b_uniform, const WaveRows& w, int r) {
+    StageStream<RW> st;
+    st.stb = (int32_t)(m.st * (int64_t)sizeof(T));
+    const int32_t snb = (int32_t)(m.sn * (int64_t)sizeof(T));
+    st.rs = make_rsrc(m.p + ((int64_t)b_uniform * m.sb + (int64_t)w.row_lo * m.st) * (int64_t)sizeof(T));
+    int j0, n0;
+    if (m.st <= m.sn) {                                    // time fastest in memory: e -> (n = e / kFT, s = e % kFT)
+        j0 = r % kFT; n0 = r / kFT;
+        st.jrow = 0; st.ninc = (RW / kFT) * snb; st.jmax = kFT - 1;
+        st.lds0 = j0 * kFS + n0; st.ldsinc = RW / kFT;
+    } else {                                               // state fastest: e -> (s = e / 16, n = e % 16)
+        j0 = r / kFS; n0 = r % kFS;
+        st.jrow = RW >= kFS ? RW / kFS : 1; st.ninc = 0; st.jmax = st.jrow - 1;
+        st.lds0 = j0 * kFS + n0; st.ldsinc = st.jrow * kFS;
+    }
+    const int32_t lane_steps = w.dT < 0 ? (st.jmax - j0) * (-w.dT) : j0 * w.dT;       // >= 0
+    st.voff = (uint32_t)(w.lane_row + lane_steps) * (uint32_t)st.stb + (uint32_t)n0 * (uint32_t)snb;
+    return st;
+}
+template <typename T, int RW>
+__device__ __forceinline__ void stage_fetch_buf(float (&v)[StageStream<RW>::EPL], const StageStream<RW>& st, int32_t rows, int32_t dT) {
+    // uniform rows of element i: rows + i * jrow * dT (+ jmax * dT for a descending order, where the lane part counts upwards)
+    uint32_t so = (uint32_t)(rows + (dT < 0 ? st.jmax * dT : 0)) * (uint32_t)st.stb;
+    const uint32_t inc = (uint32_t)(st.jrow * dT * st.stb + st.ninc);
+#pragma unroll
+    for (int i = 0; i < StageStream<RW>::EPL; ++i) {
+        v[i] = BufIO<T>::ld(st.rs, st.voff, so);
+        so += inc;
+    }
+}
+template <int RW>
+__device__ __forceinline__ void stage_park_buf(const float (&v)[StageStream<RW>::EPL], const StageStream<RW>& st, float* lds_item) {
+#pragma unroll
+    for (int i = 0; i < StageStream<RW>::EPL; ++i) lds_item[st.lds0 + i * st.ldsinc] = v[i];
+}
+
 // U of sub-tile s computed directly (the backward walks the sub-tiles downwards)
 __device__ __forceinline__ int32_t fast_U_of(const TimeMap& tm, int32_t s) {
     if (tm.ns > 1) {

@@ -129,16 +129,23 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_kernel(ScanDev P) {
 // before this one (again one batch), then walk the segment's chunks from that state, storing the state entering each.
 // (Round 1's kernel walked 64 chunks per wave twice behind 16-deep single-buffered loads: 47 us at 1024 chunks.)
 // ------------------------------------------------------------------------------------------------------
+// grid: x = channel tile + (channel tiles) * segment, y = state, z = batch + batch * direction (segments on x: nstate * nseg
+// on y overflowed 65535 for an explicit small chunk on a long sequence).
 template <bool REVERSE, bool PHASE_B>
-__global__ void __launch_bounds__(64) scan_carry_kernel(ScanDev P, const float* __restrict__ agg_sd,
-                                                        const float* __restrict__ agg_h, float* __restrict__ carry,
-                                                        float* __restrict__ seg) {
+__global__ void __launch_bounds__(64) scan_carry_kernel(ScanDevN PP) {
     const int lane = threadIdx.x;
+    const int nbatch = PP.d[0].gm.batch;
+    const ScanDev& P = PP.d[blockIdx.z / nbatch];
+    const float* __restrict__ agg_sd = P.agg_sd;
+    const float* __restrict__ agg_h = P.agg_h;
+    float* __restrict__ carry = P.carry;
+    float* __restrict__ seg = P.carry_seg;
     const Geom& gm = P.gm;
     const int nstate = gm.nstate, nch = gm.nchunks;
     const int nseg = (nch + kCarrySeg - 1) / kCarrySeg;
-    const int d = blockIdx.x * 64 + lane, b = blockIdx.z;
-    const int n = blockIdx.y % nstate, sg = blockIdx.y / nstate;
+    const int ndblk = (gm.dim + 63) / 64;
+    const int d = (blockIdx.x % ndblk) * 64 + lane, b = blockIdx.z % nbatch;
+    const int n = blockIdx.y, sg = blockIdx.x / ndblk;
     const bool valid = d < gm.dim;
     const int dd = valid ? d : 0;
     const float A2 = valid ? P.A[(int64_t)d * nstate + n] * kLog2e : 0.f;
@@ -200,19 +207,19 @@ size_t scan_carry_scratch_bytes(int batch, int dim, int nstate, int64_t nchunks)
     return align256((size_t)batch * nseg * (nstate + 1) * dim * sizeof(float));
 }
 
-void launch_scan_carry(const ScanDev& P, bool reverse, const float* agg_sd, const float* agg_h, float* carry, float* seg,
-                       hipStream_t stream) {
-    const Geom& gm = P.gm;
+void launch_scan_carry(const ScanDevN& PP, int ndir, bool reverse, hipStream_t stream) {
+    const Geom& gm = PP.d[0].gm;
     const int nseg = (gm.nchunks + kCarrySeg - 1) / kCarrySeg;
-    dim3 cgrid((gm.dim + 63) / 64, gm.nstate * nseg, gm.batch);
+    dim3 cgrid(((gm.dim + 63) / 64) * nseg, gm.nstate, gm.batch * ndir);
     if (reverse) {
-        if (nseg > 1) hipLaunchKernelGGL((scan_carry_kernel<true, false>), cgrid, dim3(64), 0, stream, P, agg_sd, agg_h, carry, seg);
-        hipLaunchKernelGGL((scan_carry_kernel<true, true>), cgrid, dim3(64), 0, stream, P, agg_sd, agg_h, carry, seg);
+        if (nseg > 1) hipLaunchKernelGGL((scan_carry_kernel<true, false>), cgrid, dim3(64), 0, stream, PP);
+        hipLaunchKernelGGL((scan_carry_kernel<true, true>), cgrid, dim3(64), 0, stream, PP);
     } else {
-        if (nseg > 1) hipLaunchKernelGGL((scan_carry_kernel<false, false>), cgrid, dim3(64), 0, stream, P, agg_sd, agg_h, carry, seg);
-        hipLaunchKernelGGL((scan_carry_kernel<false, true>), cgrid, dim3(64), 0, stream, P, agg_sd, agg_h, carry, seg);
+        if (nseg > 1) hipLaunchKernelGGL((scan_carry_kernel<false, false>), cgrid, dim3(64), 0, stream, PP);
+        hipLaunchKernelGGL((scan_carry_kernel<false, true>), cgrid, dim3(64), 0, stream, PP);
     }
 }
+static inline ScanDevN one_dir(const ScanDev& P) { ScanDevN PP; memset(&PP, 0, sizeof(PP)); PP.d[0] = P; return PP; }
 
 // ------------------------------------------------------------------------------------------------------
 // K3: apply
@@ -417,7 +424,7 @@ static int launch_fwd_rw(const ScanDev& P, hipStream_t stream) {
     const Geom& gm = P.gm;
     const unsigned nblocks = (unsigned)((gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL((scan_fwd_agg_kernel<T, NS, TS, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
-    launch_scan_carry(P, false, P.agg_sd, P.agg_h, P.carry, P.carry_seg, stream);
+    launch_scan_carry(one_dir(P), 1, false, stream);
     if (apply_subtile() == 4)
         hipLaunchKernelGGL((scan_fwd_apply_kernel<T, NS, 4, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
     else
@@ -460,24 +467,31 @@ int validate_scan_common(const segm_scan_fwd_args* a) {
     return SEGM_OK;
 }
 
+// `span_rows`: the rows whose byte offsets must fit 32 bits together with the channel / state offset - the whole sequence for
+// the general kernels (per-batch base + 32-bit offset) and for an INTERLEAVED order (a chunk visits every slice), the rows of
+// ONE wave (items per wave x chunk) for the regular-shape kernels in FORWARD / REVERSED order, whose buffer base is the wave's
+// lowest row (scan_fast.h): a per-batch span beyond 4 GiB (2^24 rows of 96 fp32 channels) is then addressable.
 int validate_spans(const segm_seq* const* seqs, int nseq, const segm_bc* const* bcs, int nbc, int dim, int dstate,
-                   int64_t L, size_t esize) {
+                   int64_t L, size_t esize, int64_t span_rows) {
     const int64_t es = (int64_t)esize, lim24 = (int64_t)1 << 24, lim32 = (int64_t)1 << 32;
     if (L > lim24) return SEGM_E_SHAPE;                    // time indices 0 .. L-1 must fit 24 bits
+    if (span_rows <= 0 || span_rows > L) span_rows = L;
     for (int i = 0; i < nseq; ++i) {
         const segm_seq* s = seqs[i];
         if (!s || !s->ptr) continue;
         if (s->stride_t < 0 || s->stride_d < 0 || s->stride_t * es >= lim24) return SEGM_E_SHAPE;
-        if (((L - 1) * s->stride_t + (int64_t)(dim - 1) * s->stride_d + 1) * es >= lim32) return SEGM_E_SHAPE;
+        if (((span_rows - 1) * s->stride_t + (int64_t)(dim - 1) * s->stride_d + 1) * es >= lim32) return SEGM_E_SHAPE;
     }
     for (int i = 0; i < nbc; ++i) {
         const segm_bc* m = bcs[i];
         if (!m || !m->ptr) continue;
         if (m->stride_t < 0 || m->stride_n < 0 || m->stride_t * es >= lim24) return SEGM_E_SHAPE;
-        if (((L - 1) * m->stride_t + (int64_t)(dstate - 1) * m->stride_n + 1) * es >= lim32) return SEGM_E_SHAPE;
+        if (((span_rows - 1) * m->stride_t + (int64_t)(dstate - 1) * m->stride_n + 1) * es >= lim32) return SEGM_E_SHAPE;
     }
     return SEGM_OK;
 }
+// rows one wave of the regular-shape kernels touches (0 = the whole sequence)
+int64_t fast_span_rows(const ScanDev& P) { return P.tm.ns > 1 ? 0 : (int64_t)P.gm.g * P.gm.chunk; }
 
 TimeMap make_timemap(int time_order, int nslices, int64_t L) {
     TimeMap tm;
@@ -546,17 +560,13 @@ extern "C" size_t segm_selective_scan_ckpt_bytes(int32_t batch, int32_t dim, int
     return (size_t)batch * nck * dstate * dim * sizeof(float);
 }
 
-extern "C" int segm_selective_scan_fwd(const segm_scan_fwd_args* a) {
+// one forward launch: validation, workspace slices, regular-shape or general kernels.  `PPout` (optional): instead of
+// launching, hand back the argument block of a launch the regular-shape kernels take (n_groups == 1) for a batched launch.
+static int scan_fwd_one(const segm_scan_fwd_args* a, ScanDev* batched) {
     int rc = validate_scan_common(a);
     if (rc != SEGM_OK) return rc;
     if (a->z.ptr && !a->out_z.ptr) return SEGM_E_NULL;
     if (!a->z.ptr && !a->out.ptr) return SEGM_E_NULL;
-    {
-        const segm_seq* sv[5] = {&a->u, &a->delta, &a->z, &a->out, &a->out_z};
-        const segm_bc* bv[2] = {&a->B, &a->C};
-        rc = validate_spans(sv, 5, bv, 2, a->dim, a->dstate, a->seqlen, dtype_size(a->dtype));
-        if (rc != SEGM_OK) return rc;
-    }
     const int chunk = a->chunk > 0 ? a->chunk : default_chunk(a->batch, a->dim, a->seqlen);
     const FwdWs ws = fwd_ws_layout(a->batch, a->dim, a->dstate, a->seqlen, chunk);
     if (!a->workspace || a->workspace_bytes < ws.total) return SEGM_E_WORKSPACE;
@@ -565,6 +575,8 @@ extern "C" int segm_selective_scan_fwd(const segm_scan_fwd_args* a) {
     const int64_t nch = (a->seqlen + chunk - 1) / chunk;
     hipStream_t stream = (hipStream_t)a->stream;
     char* wsb = (char*)a->workspace;
+    const segm_seq* sv[5] = {&a->u, &a->delta, &a->z, &a->out, &a->out_z};
+    const segm_bc* bv[2] = {&a->B, &a->C};
 
     for (int g = 0; g < G; ++g) {
         ScanDev P;
@@ -576,15 +588,61 @@ extern "C" int segm_selective_scan_fwd(const segm_scan_fwd_args* a) {
         P.carry_seg = (float*)(wsb + ws.seg) + (size_t)g * a->batch * ((nch + kCarrySeg - 1) / kCarrySeg) * (N + 1) * Dg;
         P.last_state = a->last_state ? a->last_state + (int64_t)g * Dg * N : nullptr;
         P.last_state_sb = (int64_t)a->dim * N;
-        if (use_fast_path() && scan_fast_shape(P)) {       // regular shapes (every SegMamba stage): scan_fwd_fast.hip
-            launch_scan_fwd_fast(P, a->dtype, false, stream);
-            launch_scan_carry(P, false, P.agg_sd, P.agg_h, P.carry, P.carry_seg, stream);
-            launch_scan_fwd_fast(P, a->dtype, true, stream);
+        const bool fast = use_fast_path() && scan_fast_shape(P);
+        rc = validate_spans(sv, 5, bv, 2, a->dim, a->dstate, a->seqlen, dtype_size(a->dtype), fast ? fast_span_rows(P) : 0);
+        if (rc != SEGM_OK) return rc;
+        if (batched) {
+            if (!fast || G != 1) return SEGM_E_SHAPE;       // the caller falls back to one launch per block
+            *batched = P;
+            return SEGM_OK;
+        }
+        if (fast) {                                        // regular shapes (every SegMamba stage): scan_fwd_fast.hip
+            const ScanDevN PP = one_dir(P);
+            launch_scan_fwd_fast(PP, 1, a->dtype, false, stream);
+            launch_scan_carry(PP, 1, false, stream);
+            launch_scan_fwd_fast(PP, 1, a->dtype, true, stream);
             rc = (int)hipGetLastError();
         } else if (a->dtype == SEGM_F32) rc = launch_fwd_ns<float>(P, stream);
         else if (a->dtype == SEGM_F16) rc = launch_fwd_ns<f16_t>(P, stream);
         else rc = launch_fwd_ns<bf16_t>(P, stream);
         if (rc != 0) return rc;
+    }
+    return SEGM_OK;
+}
+
+extern "C" int segm_selective_scan_fwd(const segm_scan_fwd_args* a) { return scan_fwd_one(a, nullptr); }
+
+namespace segm {
+// true when the launches share geometry, element type and stream, i.e. can be ONE grid with a direction axis
+bool scan_same_launch(const segm_scan_fwd_args* a, const segm_scan_fwd_args* b) {
+    return a->batch == b->batch && a->dim == b->dim && a->dstate == b->dstate && a->n_groups == 1 && b->n_groups == 1 &&
+           a->seqlen == b->seqlen && a->dtype == b->dtype && a->stream == b->stream &&
+           (a->chunk > 0 ? a->chunk : default_chunk(a->batch, a->dim, a->seqlen)) ==
+               (b->chunk > 0 ? b->chunk : default_chunk(b->batch, b->dim, b->seqlen));
+}
+}  // namespace segm
+
+extern "C" int segm_selective_scan_fwd_multi(const segm_scan_fwd_args* args, int32_t n) {
+    if (!args || n <= 0) return SEGM_E_NULL;
+    bool batch = n > 1 && n <= kMaxDirs && use_fast_path();
+    for (int i = 1; batch && i < n; ++i) batch = scan_same_launch(&args[0], &args[i]);
+    ScanDevN PP;
+    memset(&PP, 0, sizeof(PP));
+    for (int i = 0; batch && i < n; ++i) {
+        const int rc = scan_fwd_one(&args[i], &PP.d[i]);
+        if (rc == SEGM_E_SHAPE) batch = false;              // not a regular shape: one launch per block below
+        else if (rc != SEGM_OK) return rc;
+    }
+    if (batch) {
+        hipStream_t stream = (hipStream_t)args[0].stream;
+        launch_scan_fwd_fast(PP, n, args[0].dtype, false, stream);
+        launch_scan_carry(PP, n, false, stream);
+        launch_scan_fwd_fast(PP, n, args[0].dtype, true, stream);
+        return (int)hipGetLastError();
+    }
+    for (int i = 0; i < n; ++i) {
+        const int rc = scan_fwd_one(&args[i], nullptr);
+        if (rc != SEGM_OK) return rc;
     }
     return SEGM_OK;
 }

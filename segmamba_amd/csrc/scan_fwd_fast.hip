@@ -19,12 +19,13 @@
 namespace segm {
 
 // ------------------------------------------------------------------------------------------------------
-// K1 (regular shapes): chunk aggregates
+// K1 (regular shapes): chunk aggregates.  grid.y = direction (up to kMaxDirs launches of identical geometry in one).
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int RW>
-__global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDev P) {
-    constexpr int G = 64 / RW, EPL = FastStage<RW>::EPL;
+__global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) {
+    constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     __shared__ __attribute__((aligned(16))) float s_b[2][kWavesPerBlock][G][kFT * kFS];
+    const ScanDev& P = PP.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDev P) {
     const bool softplus_on = P.delta_softplus != 0;
     FastClock ck;
     ck.init(P.tm);
-    const int32_t t_item = fast_item_row(P.tm, it.chunk * gm.chunk);
+    const WaveRows wr = wave_rows(P.tm, gm, it);
 
     f2 A2[kFS / 2], h[kFS / 2];
 #pragma unroll
@@ -42,30 +43,30 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDev P) {
         h[n] = f2{0.f, 0.f};
     }
     const float bias = P.delta_bias ? P.delta_bias[it.d] : 0.f;
-    const FastRow up = fast_row<T>(P.u, ub, t_item, it.d);
-    const FastRow dp = fast_row<T>(P.delta, ub, t_item, it.d);
-    const FastStage<RW> sb = fast_stage<T, RW>(P.Bm, ub, t_item, ck.dT, it.r);
+    const Stream up = make_stream<T>(P.u, ub, wr, it.d);
+    const Stream dp = make_stream<T>(P.delta, ub, wr, it.d);
+    const StageStream<RW> sb = make_stage<T, RW>(P.Bm, ub, wr, it.r);
 
     float nu[kFT], nd[kFT], nb[EPL];
-    fast_fetch<T>(nu, up, ck.U, ck.dT);
-    fast_fetch<T>(nd, dp, ck.U, ck.dT);
-    fast_stage_fetch<T, RW>(nb, sb, ck.U);
+    stream_fetch<T>(nu, up, wr.bias + ck.U, wr.dT);
+    stream_fetch<T>(nd, dp, wr.bias + ck.U, wr.dT);
+    stage_fetch_buf<T, RW>(nb, sb, wr.bias + ck.U, wr.dT);
 
     float sumd = 0.f;
     int buf = 0;
     const int nsub = gm.chunk / kFT;
     for (int s = 0; s < nsub; ++s) {
         float* lb = &s_b[buf][wave][it.gi][0];
-        fast_stage_park<RW>(nb, sb, lb);
+        stage_park_buf<RW>(nb, sb, lb);
         SEGM_WAVE_LDS_SYNC();
         float cu[kFT], cd[kFT];
 #pragma unroll
         for (int j = 0; j < kFT; ++j) { cu[j] = nu[j]; cd[j] = nd[j]; }
         // prefetch the next sub-tile (after the last one: re-read this one, never past the chunk)
-        const int32_t Un = (s + 1 < nsub) ? ck.next_U() : ck.U;
-        fast_fetch<T>(nu, up, Un, ck.dT);
-        fast_fetch<T>(nd, dp, Un, ck.dT);
-        fast_stage_fetch<T, RW>(nb, sb, Un);
+        const int32_t Un = wr.bias + ((s + 1 < nsub) ? ck.next_U() : ck.U);
+        stream_fetch<T>(nu, up, Un, wr.dT);
+        stream_fetch<T>(nd, dp, Un, wr.dT);
+        stage_fetch_buf<T, RW>(nb, sb, Un, wr.dT);
         ck.advance();
         float4 bq[4];
 #pragma unroll
@@ -112,9 +113,10 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDev P) {
 // K3 (regular shapes): apply
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int RW>
-__global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fast_kernel(ScanDev P) {
-    constexpr int G = 64 / RW, EPL = FastStage<RW>::EPL;
+__global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fast_kernel(ScanDevN PP) {
+    constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     __shared__ __attribute__((aligned(16))) float s_bc[2][kWavesPerBlock][G][2][kFT * kFS];
+    const ScanDev& P = PP.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
@@ -125,7 +127,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
     FastClock ck;
     ck.init(P.tm);
     const int32_t tau0 = it.chunk * gm.chunk;
-    const int32_t t_item = fast_item_row(P.tm, tau0);
+    const WaveRows wr = wave_rows(P.tm, gm, it);
 
     f2 A2[kFS / 2], h[kFS / 2];
     const int64_t crow = (int64_t)it.b * gm.nchunks + it.chunk;
@@ -136,53 +138,57 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
     }
     const float bias = P.delta_bias ? P.delta_bias[it.d] : 0.f;
     const float Dv = P.D ? P.D[it.d] : 0.f;
-    const FastRow up = fast_row<T>(P.u, ub, t_item, it.d);
-    const FastRow dp = fast_row<T>(P.delta, ub, t_item, it.d);
-    const FastRow zp = fast_row<T>(has_z ? P.z : P.u, ub, t_item, it.d);          // without a gate: aliases u, unused
-    const FastRow op = fast_row<T>(has_out ? P.out : P.u, ub, t_item, it.d);
-    const FastRow ozp = fast_row<T>(has_z ? P.out_z : P.u, ub, t_item, it.d);
-    const FastStage<RW> sb = fast_stage<T, RW>(P.Bm, ub, t_item, ck.dT, it.r);
-    const FastStage<RW> sc = fast_stage<T, RW>(P.Cm, ub, t_item, ck.dT, it.r);
-    // checkpoints: state entering step 16 k of the sequence, [batch][nck][16][dim]
-    float* ckp = P.ckpt ? P.ckpt + (((int64_t)it.b * P.nck + tau0 / kCkpt) * kFS) * gm.dim + it.d : nullptr;
+    const Stream up = make_stream<T>(P.u, ub, wr, it.d);
+    const Stream dp = make_stream<T>(P.delta, ub, wr, it.d);
+    const Stream zp = make_stream<T>(has_z ? P.z : P.u, ub, wr, it.d);            // without a gate: aliases u, unused
+    const Stream op = make_stream<T>(has_out ? P.out : P.u, ub, wr, it.d);
+    const Stream ozp = make_stream<T>(has_z ? P.out_z : P.u, ub, wr, it.d);
+    const StageStream<RW> sb = make_stage<T, RW>(P.Bm, ub, wr, it.r);
+    const StageStream<RW> sc = make_stage<T, RW>(P.Cm, ub, wr, it.r);
+    // checkpoints: state entering step 16 k of the sequence, [batch][nck][16][dim]; the wave's window as a buffer
+    // (base = first checkpoint row of the wave's lowest chunk), one scalar offset per checkpoint and state
+    const int32_t chunk0 = __builtin_amdgcn_readfirstlane(it.chunk - it.gi);
+    const rsrc_t ckr = make_rsrc(P.ckpt ? P.ckpt + (((int64_t)ub * P.nck + (int64_t)chunk0 * (gm.chunk / kCkpt)) * kFS) * gm.dim : nullptr);
+    const uint32_t ck_voff = ((uint32_t)(it.gi * (gm.chunk / kCkpt)) * kFS * (uint32_t)gm.dim + (uint32_t)it.d) * 4u;
+    const int32_t ck_state = gm.dim * 4;                  // bytes between consecutive states of one checkpoint
 
     float nu[kFT], nd[kFT], nz[kFT], nb[EPL], nc[EPL];
-    fast_fetch<T>(nu, up, ck.U, ck.dT);
-    fast_fetch<T>(nd, dp, ck.U, ck.dT);
-    fast_fetch<T>(nz, zp, ck.U, ck.dT);
-    fast_stage_fetch<T, RW>(nb, sb, ck.U);
-    fast_stage_fetch<T, RW>(nc, sc, ck.U);
+    stream_fetch<T>(nu, up, wr.bias + ck.U, wr.dT);
+    stream_fetch<T>(nd, dp, wr.bias + ck.U, wr.dT);
+    stream_fetch<T>(nz, zp, wr.bias + ck.U, wr.dT);
+    stage_fetch_buf<T, RW>(nb, sb, wr.bias + ck.U, wr.dT);
+    stage_fetch_buf<T, RW>(nc, sc, wr.bias + ck.U, wr.dT);
 
     int buf = 0;
     const int nsub = gm.chunk / kFT;
     for (int s = 0; s < nsub; ++s) {
         float* lb = &s_bc[buf][wave][it.gi][0][0];
         float* lc = &s_bc[buf][wave][it.gi][1][0];
-        fast_stage_park<RW>(nb, sb, lb);
-        fast_stage_park<RW>(nc, sc, lc);
+        stage_park_buf<RW>(nb, sb, lb);
+        stage_park_buf<RW>(nc, sc, lc);
         SEGM_WAVE_LDS_SYNC();
         float cu[kFT], cd[kFT], cz[kFT];
 #pragma unroll
         for (int j = 0; j < kFT; ++j) { cu[j] = nu[j]; cd[j] = nd[j]; cz[j] = nz[j]; }
-        const int32_t Uc = ck.U;
-        const int32_t Un = (s + 1 < nsub) ? ck.next_U() : ck.U;
-        fast_fetch<T>(nu, up, Un, ck.dT);
-        fast_fetch<T>(nd, dp, Un, ck.dT);
-        fast_fetch<T>(nz, zp, Un, ck.dT);
-        fast_stage_fetch<T, RW>(nb, sb, Un);
-        fast_stage_fetch<T, RW>(nc, sc, Un);
+        const int32_t Uc = wr.bias + ck.U;
+        const int32_t Un = wr.bias + ((s + 1 < nsub) ? ck.next_U() : ck.U);
+        stream_fetch<T>(nu, up, Un, wr.dT);
+        stream_fetch<T>(nd, dp, Un, wr.dT);
+        stream_fetch<T>(nz, zp, Un, wr.dT);
+        stage_fetch_buf<T, RW>(nb, sb, Un, wr.dT);
+        stage_fetch_buf<T, RW>(nc, sc, Un, wr.dT);
         ck.advance();
-        if (ckp && (s & 1) == 0) {                         // kCkpt = 2 sub-tiles
-            float* kp = ckp + (int64_t)(s >> 1) * kFS * gm.dim;
+        if (P.ckpt && (s & 1) == 0) {                      // kCkpt = 2 sub-tiles
+            uint32_t kso = (uint32_t)((s >> 1) * kFS * ck_state);
 #pragma unroll
             for (int n = 0; n < kFS / 2; ++n) {
-                kp[(int64_t)(2 * n) * gm.dim] = h[n].x;
-                kp[(int64_t)(2 * n + 1) * gm.dim] = h[n].y;
+                BufIO<float>::st(ckr, ck_voff, kso, h[n].x);
+                BufIO<float>::st(ckr, ck_voff, kso + (uint32_t)ck_state, h[n].y);
+                kso += 2u * (uint32_t)ck_state;
             }
         }
-        char* orow = const_cast<char*>(op.base) + (int64_t)Uc * op.stb;
-        char* ozrow = const_cast<char*>(ozp.base) + (int64_t)Uc * ozp.stb;
-        const int64_t oinc = (int64_t)ck.dT * op.stb, ozinc = (int64_t)ck.dT * ozp.stb;
+        uint32_t oso = (uint32_t)Uc * (uint32_t)op.stb, ozso = (uint32_t)Uc * (uint32_t)ozp.stb;     // running scalar offsets
+        const uint32_t oinc = (uint32_t)(wr.dT * op.stb), ozinc = (uint32_t)(wr.dT * ozp.stb);
 #pragma unroll
         for (int j = 0; j < kFT; ++j) {
             float dl = cd[j] + bias;
@@ -211,16 +217,19 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
                 yb = c1 * h[2 * q + 1] + yb;
             }
             const float y = (ya.x + yb.x) + (ya.y + yb.y);
-            if (has_out) *reinterpret_cast<T*>(orow + (int64_t)j * oinc + op.loff) = from_f32<T>(y);
+            if (has_out) BufIO<T>::st(op.rs, op.voff, oso, y);
             if (has_z) {
                 const float zz = cz[j];
-                *reinterpret_cast<T*>(ozrow + (int64_t)j * ozinc + ozp.loff) = from_f32<T>(y * zz * sigmoidf(zz));
+                BufIO<T>::st(ozp.rs, ozp.voff, ozso, y * zz * sigmoidf(zz));
             }
+            oso += oinc;
+            ozso += ozinc;
 #pragma unroll
             for (int n = 0; n < kFS / 2; ++n) SEGM_PIN_F2(h[n]);      // keeps the LDS reads of later steps from being hoisted here
         }
         buf ^= 1;
     }
+    (void)tau0;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -236,22 +245,22 @@ bool scan_fast_shape(const ScanDev& P) {
 }
 
 template <typename T, int RW>
-static void launch_fast_rw(const ScanDev& P, bool apply, hipStream_t stream) {
-    const unsigned nblocks = (unsigned)((P.gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (apply) hipLaunchKernelGGL((scan_fwd_apply_fast_kernel<T, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
-    else hipLaunchKernelGGL((scan_fwd_agg_fast_kernel<T, RW>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+static void launch_fast_rw(const ScanDevN& PP, int ndir, bool apply, hipStream_t stream) {
+    const unsigned nblocks = (unsigned)((PP.d[0].gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (apply) hipLaunchKernelGGL((scan_fwd_apply_fast_kernel<T, RW>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+    else hipLaunchKernelGGL((scan_fwd_agg_fast_kernel<T, RW>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
 }
 template <typename T>
-static void launch_fast_t(const ScanDev& P, bool apply, hipStream_t stream) {
-    if (P.gm.rw == 64) launch_fast_rw<T, 64>(P, apply, stream);
-    else if (P.gm.rw == 32) launch_fast_rw<T, 32>(P, apply, stream);
-    else launch_fast_rw<T, 16>(P, apply, stream);
+static void launch_fast_t(const ScanDevN& PP, int ndir, bool apply, hipStream_t stream) {
+    if (PP.d[0].gm.rw == 64) launch_fast_rw<T, 64>(PP, ndir, apply, stream);
+    else if (PP.d[0].gm.rw == 32) launch_fast_rw<T, 32>(PP, ndir, apply, stream);
+    else launch_fast_rw<T, 16>(PP, ndir, apply, stream);
 }
-// launches K1 (apply == false) or K3 (apply == true) of the regular-shape path
-void launch_scan_fwd_fast(const ScanDev& P, int dtype, bool apply, hipStream_t stream) {
-    if (dtype == SEGM_F32) launch_fast_t<float>(P, apply, stream);
-    else if (dtype == SEGM_F16) launch_fast_t<f16_t>(P, apply, stream);
-    else launch_fast_t<bf16_t>(P, apply, stream);
+// launches K1 (apply == false) or K3 (apply == true) of the regular-shape path for `ndir` argument blocks of one geometry
+void launch_scan_fwd_fast(const ScanDevN& PP, int ndir, int dtype, bool apply, hipStream_t stream) {
+    if (dtype == SEGM_F32) launch_fast_t<float>(PP, ndir, apply, stream);
+    else if (dtype == SEGM_F16) launch_fast_t<f16_t>(PP, ndir, apply, stream);
+    else launch_fast_t<bf16_t>(PP, ndir, apply, stream);
 }
 
 }  // namespace segm

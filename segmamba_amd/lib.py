@@ -234,6 +234,7 @@ class TransposeArgs(C.Structure):
 EXPORTS = (
     "segm_selective_scan_fwd", "segm_selective_scan_fwd_workspace_bytes", "segm_selective_scan_ckpt_bytes",
     "segm_selective_scan_default_chunk", "segm_selective_scan_bwd", "segm_selective_scan_bwd_workspace_bytes",
+    "segm_selective_scan_fwd_multi", "segm_selective_scan_bwd_multi",
     "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
     "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes", "segm_conv3d_k3_fwd",
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add",
@@ -261,6 +262,8 @@ class SegmLib:
 
         sig("segm_selective_scan_fwd", [C.POINTER(ScanFwdArgs)], C.c_int)
         sig("segm_selective_scan_bwd", [C.POINTER(ScanBwdArgs)], C.c_int)
+        sig("segm_selective_scan_fwd_multi", [C.POINTER(ScanFwdArgs), C.c_int32], C.c_int)
+        sig("segm_selective_scan_bwd_multi", [C.POINTER(ScanBwdArgs), C.c_int32], C.c_int)
         for n in ("segm_selective_scan_fwd_workspace_bytes", "segm_selective_scan_bwd_workspace_bytes"):
             sig(n, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32], C.c_size_t)
         sig("segm_selective_scan_ckpt_bytes", [C.c_int32, C.c_int32, C.c_int32, C.c_int64], C.c_size_t)

@@ -102,6 +102,31 @@ def scan_fwd(lib: L.SegmLib, u, delta, A, B, C, D=None, z=None, delta_bias=None,
     """-> dict(out, out_z, ckpt, last_state, chunk).  `out` is the un-gated y (None unless need_out or z is None).
     `ckpt_buf`: a caller-owned fp32 buffer of segm_selective_scan_ckpt_bytes() for the checkpoints."""
     a = L.ScanFwdArgs()
+    r = _scan_fwd_prepare(lib, a, u, delta, A, B, C, D, z, delta_bias, delta_softplus, channel_last=channel_last,
+                          time_order=time_order, nslices=nslices, chunk=chunk, need_out=need_out, need_ckpt=need_ckpt,
+                          need_last_state=need_last_state, ckpt_buf=ckpt_buf)
+    lib.check(lib.dll.segm_selective_scan_fwd(a), "selective_scan_fwd")
+    r.pop("_ws")
+    return r
+
+
+def scan_fwd_multi(lib: L.SegmLib, calls):
+    """Several forward scans of ONE geometry (the three directions of a Mamba v3 layer) as one C call: `calls` is a list of
+    keyword dicts for `scan_fwd`; the library runs them as one grid with a direction axis when they are regular-shaped and share
+    batch / dim / dstate / seqlen / dtype / chunk, else one after the other.  -> list of scan_fwd result dicts."""
+    n = len(calls)
+    arr = (L.ScanFwdArgs * n)()
+    rs = [_scan_fwd_prepare(lib, arr[i], **c) for i, c in enumerate(calls)]
+    lib.check(lib.dll.segm_selective_scan_fwd_multi(arr, n), "selective_scan_fwd_multi")
+    for r in rs:
+        r.pop("_ws")
+    return rs
+
+
+def _scan_fwd_prepare(lib, a, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *,
+                      channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, need_out=True,
+                      need_ckpt=False, need_last_state=False, ckpt_buf=None):
+    """fills the argument block `a` and allocates outputs / workspace; -> result dict (+ `_ws`, alive until the launch)"""
     batch, seqlen, dim, dstate, groups, B4, C4 = _fill_scan_args(
         a, u, delta, A, B, C, D, z, delta_bias, delta_softplus, channel_last, time_order, nslices, chunk)
     if chunk == 0:
@@ -126,16 +151,37 @@ def scan_fwd(lib: L.SegmLib, u, delta, A, B, C, D=None, z=None, delta_bias=None,
     a.out, a.out_z = L.seq_view(out, channel_last), L.seq_view(out_z, channel_last)
     a.last_state, a.ckpt = L.fptr(last_state), L.fptr(ckpt)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
-    lib.check(lib.dll.segm_selective_scan_fwd(a), "selective_scan_fwd")
-    return dict(out=out, out_z=out_z, ckpt=ckpt, last_state=last_state, chunk=chunk)
+    return dict(out=out, out_z=out_z, ckpt=ckpt, last_state=last_state, chunk=chunk, _ws=ws)
 
 
 def scan_bwd(lib: L.SegmLib, u, delta, A, B, C, D, z, delta_bias, dout, out, ckpt, delta_softplus, *,
-             channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, du=None, ddelta=None, dz=None):
+             channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, du=None, ddelta=None, dz=None, dB=None, dC=None):
     """-> dict(du, ddelta, dA, dB, dC, dD, ddelta_bias, dz).  du / ddelta / dz may be pre-allocated views
     (e.g. halves of one dxz buffer, reference selective_scan_interface.py:244-245); dB / dC are fp32 and have
     the layout and rank of B / C."""
     a = L.ScanBwdArgs()
+    r = _scan_bwd_prepare(lib, a, u, delta, A, B, C, D, z, delta_bias, dout, out, ckpt, delta_softplus, channel_last=channel_last,
+                          time_order=time_order, nslices=nslices, chunk=chunk, du=du, ddelta=ddelta, dz=dz, dB=dB, dC=dC)
+    lib.check(lib.dll.segm_selective_scan_bwd(a), "selective_scan_bwd")
+    r.pop("_ws")
+    return r
+
+
+def scan_bwd_multi(lib: L.SegmLib, calls):
+    """the backward counterpart of scan_fwd_multi: `calls` = keyword dicts for `scan_bwd`"""
+    n = len(calls)
+    arr = (L.ScanBwdArgs * n)()
+    rs = [_scan_bwd_prepare(lib, arr[i], **c) for i, c in enumerate(calls)]
+    lib.check(lib.dll.segm_selective_scan_bwd_multi(arr, n), "selective_scan_bwd_multi")
+    for r in rs:
+        r.pop("_ws")
+    return rs
+
+
+def _scan_bwd_prepare(lib, a, u, delta, A, B, C, D, z, delta_bias, dout, out, ckpt, delta_softplus, *,
+                      channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, du=None, ddelta=None, dz=None,
+                      dB=None, dC=None):
+    """`dB` / `dC`: optional caller-owned fp32 tensors shaped like B / C (e.g. column windows of the fp32 dx_dbl buffer)"""
     if chunk and os.environ.get("SEGM_BWD_CHUNK"):        # experiments only: the backward's own chunking (the checkpoints are per 16 steps, not per chunk)
         chunk = int(os.environ["SEGM_BWD_CHUNK"])
     batch, seqlen, dim, dstate, groups, B4, C4 = _fill_scan_args(
@@ -156,8 +202,15 @@ def scan_bwd(lib: L.SegmLib, u, delta, A, B, C, D, z, delta_bias, dout, out, ckp
     for name, t in (("du", du), ("ddelta", ddelta), ("dz", dz)):
         _check_seq(name, t, u, u.dtype)
     dA = torch.empty(dim, dstate, dtype=torch.float32, device=dev)
-    dB = torch.empty(B4.shape, dtype=torch.float32, device=dev)
-    dC = torch.empty(C4.shape, dtype=torch.float32, device=dev)
+    own_bc = dB is None
+    if own_bc:
+        dB = torch.empty(B4.shape, dtype=torch.float32, device=dev)
+        dC = torch.empty(C4.shape, dtype=torch.float32, device=dev)
+    else:
+        dB, dC = _bc4(dB, channel_last), _bc4(dC, channel_last)
+        for name, t in (("dB", dB), ("dC", dC)):
+            if tuple(t.shape) != tuple(B4.shape) or t.dtype != torch.float32 or t.device != dev:
+                raise RuntimeError(f"{name} must be an fp32 tensor of B's shape {tuple(B4.shape)} on the same device")
     dD = torch.empty(dim, dtype=torch.float32, device=dev) if D is not None else None
     ddb = torch.empty(dim, dtype=torch.float32, device=dev) if delta_bias is not None else None
     ws_bytes = lib.dll.segm_selective_scan_bwd_workspace_bytes(batch, dim, dstate, seqlen, chunk)
@@ -168,12 +221,11 @@ def scan_bwd(lib: L.SegmLib, u, delta, A, B, C, D, z, delta_bias, dout, out, ckp
     a.dB, a.dC = L.bc_view(dB, channel_last), L.bc_view(dC, channel_last)
     a.dA, a.dD, a.ddelta_bias = dA.data_ptr(), L.fptr(dD), L.fptr(ddb)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
-    lib.check(lib.dll.segm_selective_scan_bwd(a), "selective_scan_bwd")
     if B.dim() == 3:
         dB = dB.squeeze(2 if channel_last else 1)
     if C.dim() == 3:
         dC = dC.squeeze(2 if channel_last else 1)
-    return dict(du=du, ddelta=ddelta, dA=dA, dB=dB, dC=dC, dD=dD, ddelta_bias=ddb, dz=dz)
+    return dict(du=du, ddelta=ddelta, dA=dA, dB=dB, dC=dC, dD=dD, ddelta_bias=ddb, dz=dz, _ws=ws)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -183,6 +183,24 @@ static inline hipemu_u32x2 hipemu_permlane16_swap(uint32_t vdst, uint32_t vsrc, 
 }
 #define __builtin_amdgcn_permlane16_swap hipemu_permlane16_swap
 
+// ---- raw buffer resources (scan_fast.h Stream / StageStream): base pointer + lane byte offset + uniform byte offset ------------
+struct hipemu_rsrc { char* base; };
+typedef hipemu_rsrc __amdgpu_buffer_rsrc_t;
+static inline hipemu_rsrc hipemu_make_rsrc(void* p, short, int, int) { hipemu_rsrc r; r.base = static_cast<char*>(p); return r; }
+#define __builtin_amdgcn_make_buffer_rsrc hipemu_make_rsrc
+template <typename V> static inline V hipemu_buf_ld(hipemu_rsrc r, uint32_t voff, uint32_t soff) {
+    V v; memcpy(&v, r.base + (size_t)voff + (size_t)soff, sizeof(V)); return v;
+}
+template <typename V> static inline void hipemu_buf_st(V v, hipemu_rsrc r, uint32_t voff, uint32_t soff) {
+    memcpy(r.base + (size_t)voff + (size_t)soff, &v, sizeof(V));
+}
+#define __builtin_amdgcn_raw_buffer_load_b16(r, v, s, aux) hipemu_buf_ld<unsigned short>(r, v, s)
+#define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, aux) hipemu_buf_ld<uint32_t>(r, v, s)
+typedef uint32_t hipemu_u32x4 __attribute__((ext_vector_type(4)));
+#define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, aux) hipemu_buf_ld<hipemu_u32x4>(r, v, s)
+#define __builtin_amdgcn_raw_buffer_store_b16(d, r, v, s, aux) hipemu_buf_st<unsigned short>(d, r, v, s)
+#define __builtin_amdgcn_raw_buffer_store_b32(d, r, v, s, aux) hipemu_buf_st<uint32_t>(d, r, v, s)
+
 // ---- MFMA / funnel-shift emulation (conv3d_wgrad.hip) -------------------------------------------------------------
 static inline uint32_t hipemu_alignbyte(uint32_t hi, uint32_t lo, uint32_t n) {
     uint64_t v = ((uint64_t)hi << 32) | lo;

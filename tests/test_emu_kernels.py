@@ -392,6 +392,38 @@ def test_scan_regular_shape_kernels_emulated(emu, monkeypatch, dim, seqlen, chun
             assert (fast[k].float() - slow[k].float()).abs().max() <= tol * max(1.0, float(slow[k].float().abs().max())), k
 
 
+@pytest.mark.parametrize("dim,seqlen,chunk,dtype", [(96, 128, 32, torch.bfloat16), (64, 128, 64, torch.float32), (20, 70, 32, torch.float32)])
+def test_scan_three_directions_in_one_launch_emulated(emu, dim, seqlen, chunk, dtype):
+    """segm_selective_scan_fwd_multi / _bwd_multi: the three directions of a Mamba v3 layer (forward, reversed, slice-interleaved;
+    own parameters, inputs and outputs each) as ONE grid with a direction axis must equal three separate launches bit for bit
+    (regular shapes), and fall back to separate launches for a ragged shape (dim 20, L 70)."""
+    orders = [(L.TIME_FORWARD, 1), (L.TIME_REVERSED, 1), (L.TIME_INTERLEAVED, 8 if seqlen % 8 == 0 and chunk % 8 == 0 else 2)]
+    cases = [H.to_dev_layout(H.scan_case(2, dim, 16, seqlen, dtype=dtype, seed=7 + i), "cpu", True) for i in range(3)]
+    fcalls, single_f = [], []
+    for d, (order, ns) in zip(cases, orders):
+        kw = dict(u=d["u"], delta=d["delta"], A=d["A"], B=d["B"], C=d["C"], D=d["D"], z=d["z"], delta_bias=d["delta_bias"],
+                  delta_softplus=True, channel_last=True, time_order=order, nslices=ns, chunk=chunk, need_out=True, need_ckpt=True)
+        fcalls.append(kw)
+        single_f.append(ops_raw.scan_fwd(emu, **kw))
+    multi_f = ops_raw.scan_fwd_multi(emu, fcalls)
+    for a, b in zip(single_f, multi_f):
+        for k in ("out", "out_z", "ckpt"):
+            assert torch.equal(a[k], b[k]), k
+    bcalls, single_b = [], []
+    for d, (order, ns), f in zip(cases, orders, single_f):
+        kw = dict(u=d["u"], delta=d["delta"], A=d["A"], B=d["B"], C=d["C"], D=d["D"], z=d["z"], delta_bias=d["delta_bias"],
+                  dout=d["g"], out=f["out"], ckpt=f["ckpt"], delta_softplus=True, channel_last=True, time_order=order,
+                  nslices=ns, chunk=f["chunk"])
+        bcalls.append(kw)
+        single_b.append(ops_raw.scan_bwd(emu, **kw))
+    multi_b = ops_raw.scan_bwd_multi(emu, bcalls)
+    for a, b in zip(single_b, multi_b):
+        for k in ("du", "ddelta", "dz", "dA", "dD", "ddelta_bias"):
+            assert torch.equal(a[k], b[k]), k
+        for k in ("dB", "dC"):                                   # several channel tiles add atomically: order-dependent last bits
+            assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-5), k
+
+
 def test_scan_rejects_views_beyond_32bit_offsets(emu):
     """L > 2^24 or a row stride >= 2^24 bytes is outside the kernels' 32-bit offset arithmetic: SEGM_E_SHAPE, nothing launched."""
     a = L.ScanFwdArgs()
