@@ -1,5 +1,5 @@
-"""Dense 3x3x3 (stride 1, "same") convolutions of the SegMamba stem: an autotuned dispatcher over the library's own
-MFMA kernels and MIOpen.
+"""Dense 3x3x3 (stride 1, "same") convolutions of the SegMamba stem: a dispatcher over the library's own MFMA kernels and
+the vendor routes - by a shape table since round 3 (`_table_choice`), by a timing run on request (SEGM_CONV_AUTOTUNE=1).
 
 SURVEY.md §7 step 6: the stem started on MIOpen.  Profiling (profiles/r01_probe_convs.log,
 profiles/r01_bench_step_kernels_v3.txt) showed that MIOpen's bf16 3-D solvers are very uneven on these shapes:
@@ -18,10 +18,11 @@ Every quantity below is mathematically the same convolution, only routed to a di
   wgrad  dW = conv_bwd_weight(x, dy)          or  per input/output channel block
                                               or  segm_conv3d_k3_wgrad, the library's own MFMA kernel
 
-The first time a (kind, shapes, dtype, device, strides) is seen each candidate is timed once on the real tensors and the fastest is
-cached (what MIOpen's own "find" does, one level up).  On the SegMamba shapes the library's kernels win every layer
-with W >= 32 (profiles/r01_conv_autotune_v2.log); the 16^3 / 8^3 bottleneck layers stay on MIOpen.
-SEGM_CONV_AUTOTUNE=0 always takes the first candidate (the plain library call); SEGM_CONV_VERBOSE=1 prints the timings.
+Rounds 1 - 2 timed every candidate the first time a (kind, shapes, dtype, device, strides) was seen and cached the fastest
+(what MIOpen's own "find" does, one level up).  The winners were the same on every box (profiles/r01_conv_autotune_v2.log,
+r02_bench_variants.log): the library's kernels for every layer of width >= 16, the vendor GEMM route for the 8^3 bottleneck
+layers.  That outcome is now the routing table; with SEGM_CONV_AUTOTUNE=1 the timing run is back (SEGM_CONV_VERBOSE=1 prints
+its timings).
 """
 from __future__ import annotations
 
@@ -33,7 +34,11 @@ import torch.nn.functional as F
 
 _BLOCK = 48                      # channel block of the library's kernels (and of MIOpen's fast 3-D bf16 solvers)
 _cache: Dict[tuple, int] = {}
-_TUNE = os.environ.get("SEGM_CONV_AUTOTUNE", "1") == "1"
+# Routing is a TABLE by default (round 3): the winners of the round-2 timing runs as a rule of the shape (`_table_choice`), so that
+# every rank, every run and every captured graph takes the same kernels and results are reproducible run to run.
+# SEGM_CONV_AUTOTUNE=1 brings the timing-based choice back (to re-derive the table on new hardware; it synchronises the device
+# inside autograd, may differ between processes, and cannot run under graph capture).
+_TUNE = os.environ.get("SEGM_CONV_AUTOTUNE", "0") == "1"
 # cat(up, skip) convolutions as one autograd node with the later parts added in place (_ConvSameCat, linear._PointwiseCat).  Written
 # after the GPU budget of round 2 was spent: parity-tested on the emulator, not yet run or timed on the GPU - opt-in until then.
 _CAT_FUSED = os.environ.get("SEGM_CONV_CAT_FUSED", "0") == "1"
@@ -60,9 +65,36 @@ def _key(kind, x, w, *flags) -> tuple:
     return (kind, tuple(x.shape), tuple(w.shape), x.dtype, x.device.index, tuple(x.stride()), tuple(w.stride())) + flags
 
 
-def _pick(key: tuple, cands: List[Callable[[], torch.Tensor]]) -> torch.Tensor:
-    if len(cands) == 1 or not _TUNE or not torch.cuda.is_available():
+def _table_variant(width: int):
+    """the library forward kernel's (chain, pitch48, chain32) flags for a volume of this width (profiles/r02_bench_variants.log,
+    r02_conv_stride_pad.log): chained K parts everywhere; unpadded LDS rows at 128^3 / 64^3; the 32-wide-block variant (two
+    workgroups per CU) for 32^3 and below"""
+    return (True, True, False) if width >= 64 else (False, False, True)
+
+
+def _table_choice(kind: str, width: int, variants) -> int:
+    """index of the routing the table prescribes among `variants` (None = a vendor route, tuple = library kernel flags, "mfma" =
+    the library's weight-gradient kernel).  Measured on MI355X (profiles/r02_bench_variants.log): the library's kernels win every
+    3x3x3 layer of width >= 16 - forward, data gradient (as a forward convolution with flipped, transposed weights) and weight
+    gradient; the 8^3 bottleneck layers (768 / 384 channels, 0.1 ms each) stay on the vendor GEMM route, where they are
+    weight-bandwidth-bound GEMMs."""
+    if kind == "wgrad":
+        return variants.index("mfma") if width >= 16 and "mfma" in variants else 0
+    if width >= 16:
+        want = _table_variant(width)
+        if want in variants:
+            return variants.index(want)
+        lib_routes = [i for i, v in enumerate(variants) if isinstance(v, tuple)]
+        if lib_routes:
+            return lib_routes[0]
+    return 0
+
+
+def _pick(key: tuple, cands: List[Callable[[], torch.Tensor]], variants=None, width: int = 0) -> torch.Tensor:
+    if len(cands) == 1 or not torch.cuda.is_available():
         return cands[0]()
+    if not _TUNE:
+        return cands[_table_choice(key[0], width, variants) if variants is not None else 0]()
     i = _cache.get(key)
     if i is None:
         times = []
@@ -221,34 +253,41 @@ def _fwd_candidates(x, w, bias, pad):
     return key, cands, variants
 
 
-def _tuned_variant(key, cands, variants):
-    """the library-kernel variant the tuner has already picked for this key, or None (not tuned yet / a vendor route won)"""
-    if len(cands) == 1 or not _TUNE or not torch.cuda.is_available():
+def _tuned_variant(key, cands, variants, width: int = 0):
+    """the library-kernel variant routing gives this key (table, or what the tuner has already picked), or None (a vendor route)"""
+    if len(cands) == 1 or not torch.cuda.is_available():
         return None
+    if not _TUNE:
+        v = variants[_table_choice(key[0], width, variants)]
+        return v if isinstance(v, tuple) else None
     i = _cache.get(key)
     return variants[i] if i is not None else None
 
 
 def _dgrad(dy, w, x, pad):
-    cands = [lambda: _dgrad_native(dy, w, x, pad), lambda: _dgrad_as_fwd(dy, w, x, pad)]
+    cands, variants = [lambda: _dgrad_native(dy, w, x, pad), lambda: _dgrad_as_fwd(dy, w, x, pad)], [None, None]
     if max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0:
         cands.append(lambda: _dgrad_as_fwd_blocked(dy, w, x, pad))
+        variants.append(None)
     hip = _hip_fwd_ok(dy, w.transpose(0, 1))
     chain = hip and _hip_chain_ok(w.transpose(0, 1))
     n = (1 if hip else 0) + (1 if chain else 0) + (2 if chain and _hip_untimed_ok() else 0)
     for v in _HIP_VARIANTS[:n]:
         cands.append(lambda v=v: _dgrad_hip(dy, w, x, pad, *v))
-    return _pick(_key("dgrad", dy, w, hip, chain, _hip_untimed_ok()), cands)
+        variants.append(v)
+    return _pick(_key("dgrad", dy, w, hip, chain, _hip_untimed_ok()), cands, variants, dy.shape[4])
 
 
 def _wgrad(x, dy, w, pad, w_dtype):
-    cands = [lambda: _wgrad_native(x, dy, w, pad)]
+    cands, variants = [lambda: _wgrad_native(x, dy, w, pad)], [None]
     if max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0:
         cands.append(lambda: _wgrad_blocked(x, dy, w, pad))
+        variants.append(None)
     mfma = _mfma_wgrad_ok(x, dy, w)
     if mfma:
         cands.append(lambda: _wgrad_mfma(x, dy, w, pad, w_dtype))
-    return _pick(_key("wgrad", x, w, mfma, w_dtype), cands).to(w_dtype)
+        variants.append("mfma")
+    return _pick(_key("wgrad", x, w, mfma, w_dtype), cands, variants, x.shape[4]).to(w_dtype)
 
 
 class _ConvSame(torch.autograd.Function):
@@ -259,8 +298,8 @@ class _ConvSame(torch.autograd.Function):
         from .linear import _masters
         w, bias = _masters(ctx, x, w, bias)              # fp32 masters -> the step's 16-bit copies; gradients go back in fp32
         ctx.save_for_backward(x, w)
-        key, cands, _ = _fwd_candidates(x, w, bias, w.shape[2] // 2)
-        return _pick(key, cands)
+        key, cands, variants = _fwd_candidates(x, w, bias, w.shape[2] // 2)
+        return _pick(key, cands, variants, x.shape[4])
 
     @staticmethod
     def backward(ctx, dy):
@@ -298,13 +337,13 @@ class _ConvSameCat(torch.autograd.Function):
             c0 += x.shape[1]
             key, cands, variants = _fwd_candidates(x, wi, None, pad)
             if out is None:
-                out = _pick(key, cands)
+                out = _pick(key, cands, variants, x.shape[4])
                 continue
-            v = _tuned_variant(key, cands, variants) if wi.shape[0] % _BLOCK == 0 else None
+            v = _tuned_variant(key, cands, variants, x.shape[4]) if wi.shape[0] % _BLOCK == 0 else None
             if v is not None:
                 out = _fwd_hip(x, wi, pad, None, *v, into=out)
             else:                                        # not tuned yet (this call does it) or a vendor route won
-                out = out + _pick(key, cands)
+                out = out + _pick(key, cands, variants, x.shape[4])
         return out
 
     @staticmethod

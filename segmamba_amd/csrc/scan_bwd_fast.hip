@@ -157,6 +157,9 @@ __device__ __forceinline__ void tile_park(const u32x4_t (&v)[N], char* half, int
     for (int q = 0; q < N; ++q) *reinterpret_cast<u32x4_t*>(half + (lane + 64 * q) * 16) = v[q];
 }
 template <typename T> __device__ __forceinline__ float lds_elem(const char* p) { return to_f32(*reinterpret_cast<const T*>(p)); }
+// the raw bits of an element (BufIO::ld_raw) into LDS
+__device__ __forceinline__ void put_raw(float* p, uint32_t bits) { *reinterpret_cast<uint32_t*>(p) = bits; }
+template <typename T> __device__ __forceinline__ void put_raw(T* p, uint32_t bits) { *reinterpret_cast<unsigned short*>(p) = (unsigned short)bits; }
 
 #ifndef SEGM_BWD_MAIN_WAVES
 #define SEGM_BWD_MAIN_WAVES 2
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
     __shared__ __attribute__((aligned(16))) char s_tile[kWavesPerBlock][NSTREAM * STREAM_BYTES];           // next window's rows
     __shared__ __attribute__((aligned(16))) T s_raw[kWavesPerBlock][G][2][kFW * kFS];                        // next window's B, C (raw)
     __shared__ __attribute__((aligned(16))) float s_bc[kWavesPerBlock][G][2][kFW * kFS];                     // this window's B, C
-    __shared__ __attribute__((aligned(16))) T s_u[kWavesPerBlock][G][kFW][RW];                               // this window's u (read again when it closes)
+    __shared__ __attribute__((aligned(16))) float s_dbc[kWavesPerBlock][G][2][kFW * (kFS / 2)];              // dB, dC of 8 states: [step][state % 8]
     const ScanDev& P = PP.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
@@ -209,7 +212,6 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
     const StageStream<RW> sb = make_stage<T, RW>(P.Bm, ub, wr, it.r);
     const StageStream<RW> sc = make_stage<T, RW>(P.Cm, ub, wr, it.r);
     // dB / dC (fp32, state-fastest): the lane that ends a reduce-scatter with the sum of step j stores element (j, n)
-    const int red_j = RW >= 32 ? (it.r & (kFW - 1)) : it.r;       // RW >= 32: lanes 0..15 finish dB_j, 16..31 dC_j; RW 16: both
     BC dBv = {reinterpret_cast<char*>(P.dB), P.dB_sb, P.dB_st, P.dB_sn};
     BC dCv = {reinterpret_cast<char*>(P.dC), P.dC_sb, P.dC_st, P.dC_sn};
     char* const dBbase = dBv.p + ((int64_t)ub * dBv.sb + (int64_t)wr.row_lo * dBv.st) * 4;     // wave-uniform
@@ -217,11 +219,6 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
     const rsrc_t dBr = make_rsrc(dBbase);
     const rsrc_t dCr = make_rsrc(dCbase);
     const int32_t dB_stb = (int32_t)(P.dB_st * 4), dC_stb = (int32_t)(P.dC_st * 4);
-    // rows of step j of a window: uniform part  bias + U_{j / 8} + (j % 8) dT, split so that both parts are >= 0
-    const int32_t red_jl = red_j & (kFT - 1);
-    const int32_t red_lane_steps = wr.dT < 0 ? (kFT - 1 - red_jl) * (-wr.dT) : red_jl * wr.dT;
-    const uint32_t dB_voff = (uint32_t)(wr.lane_row + red_lane_steps) * (uint32_t)dB_stb;
-    const uint32_t dC_voff = (uint32_t)(wr.lane_row + red_lane_steps) * (uint32_t)dC_stb;
     const int32_t dB_snb = (int32_t)(P.dB_sn * 4), dC_snb = (int32_t)(P.dC_sn * 4);
 
     char* tile = &s_tile[wave][0];
@@ -229,7 +226,8 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
     const int32_t elem_off = (it.gi * kFT * RW + it.r) * (int)sizeof(T);
     T* raw_b = &s_raw[wave][it.gi][0][0];
     T* raw_c = &s_raw[wave][it.gi][1][0];
-    char* ukeep = reinterpret_cast<char*>(&s_u[wave][it.gi][0][it.r]);
+    float* ldb = &s_dbc[wave][it.gi][0][0];
+    float* ldc = &s_dbc[wave][it.gi][1][0];
     float* lb = &s_bc[wave][it.gi][0][0];
     float* lc = &s_bc[wave][it.gi][1][0];
     // checkpoints [batch][nck][16][dim]: buffer based at the wave's lowest chunk
@@ -249,17 +247,17 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
             tile_park(v0, tile + i * STREAM_BYTES, lane);
             tile_park(v1, tile + i * STREAM_BYTES + TS::HALF_BYTES, lane);
         }
-        float vb0[EPL], vb1[EPL], vc0[EPL], vc1[EPL];
-        stage_fetch_buf<T, RW>(vb0, sb, U0, wr.dT);
-        stage_fetch_buf<T, RW>(vb1, sb, U1, wr.dT);
-        stage_fetch_buf<T, RW>(vc0, sc, U0, wr.dT);
-        stage_fetch_buf<T, RW>(vc1, sc, U1, wr.dT);
+        uint32_t vb0[EPL], vb1[EPL], vc0[EPL], vc1[EPL];
+        stage_fetch_raw<T, RW>(vb0, sb, U0, wr.dT);
+        stage_fetch_raw<T, RW>(vb1, sb, U1, wr.dT);
+        stage_fetch_raw<T, RW>(vc0, sc, U0, wr.dT);
+        stage_fetch_raw<T, RW>(vc1, sc, U1, wr.dT);
 #pragma unroll
         for (int i = 0; i < EPL; ++i) {
-            raw_b[sb.lds0 + i * sb.ldsinc] = from_f32<T>(vb0[i]);
-            raw_b[kFT * kFS + sb.lds0 + i * sb.ldsinc] = from_f32<T>(vb1[i]);
-            raw_c[sc.lds0 + i * sc.ldsinc] = from_f32<T>(vc0[i]);
-            raw_c[kFT * kFS + sc.lds0 + i * sc.ldsinc] = from_f32<T>(vc1[i]);
+            put_raw(raw_b + sb.lds0 + i * sb.ldsinc, vb0[i]);
+            put_raw(raw_b + kFT * kFS + sb.lds0 + i * sb.ldsinc, vb1[i]);
+            put_raw(raw_c + sc.lds0 + i * sc.ldsinc, vc0[i]);
+            put_raw(raw_c + kFT * kFS + sc.lds0 + i * sc.ldsinc, vc1[i]);
         }
     }
     float hp_next;                                        // checkpoint of the next (state, window) of the walk, one state ahead
@@ -288,8 +286,6 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
                 q[j] = 0.f;
                 ddA[j] = 0.f;
                 dD_acc = fmaf(wg[j], uu, dD_acc);
-                // u is needed once more when the window closes (ddelta = ... + u q): kept as raw elements in LDS, not in registers
-                reinterpret_cast<T*>(ukeep)[j * RW] = from_f32<T>(uu);
             }
             if (has_z) {
                 const int32_t U0 = wr.bias + fast_U_of(P.tm, 2 * w), U1 = wr.bias + fast_U_of(P.tm, 2 * w + 1);
@@ -315,23 +311,23 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
         const int32_t Uw0 = wr.bias + fast_U_of(P.tm, 2 * w), Uw1 = wr.bias + fast_U_of(P.tm, 2 * w + 1);
 #pragma unroll 1
         for (int n = 0; n < kFS; ++n) {                   // runtime loop over the states
-            // ---- the next window's inputs, a slice per state: streams in n = 0..4, B / C halves in n = 5..8 ---------------
+            // ---- the next window's inputs, a slice per state: delta, dout, z, out in n = 0..3, B / C halves in n = 4..7 (u: when
+            //      the window closes).  Raw bits only: nothing here is a use of a loaded value (BufIO::ld_raw) ---------------
             u32x4_t pv0[TS::NLH], pv1[TS::NLH];
-            float pbc[EPL];
-            if (n == 0) { tile_issue(pv0, tiles[0], Un0, wr.dT); tile_issue(pv1, tiles[0], Un1, wr.dT); }
-            else if (n == 1) { tile_issue(pv0, tiles[1], Un0, wr.dT); tile_issue(pv1, tiles[1], Un1, wr.dT); }
-            else if (n == 2) { tile_issue(pv0, tiles[2], Un0, wr.dT); tile_issue(pv1, tiles[2], Un1, wr.dT); }
-            else if (n == 3) { tile_issue(pv0, tiles[3], Un0, wr.dT); tile_issue(pv1, tiles[3], Un1, wr.dT); }
-            else if (n == 4) { tile_issue(pv0, tiles[4], Un0, wr.dT); tile_issue(pv1, tiles[4], Un1, wr.dT); }
-            else if (n == 5) stage_fetch_buf<T, RW>(pbc, sb, Un0, wr.dT);
-            else if (n == 6) stage_fetch_buf<T, RW>(pbc, sb, Un1, wr.dT);
-            else if (n == 7) stage_fetch_buf<T, RW>(pbc, sc, Un0, wr.dT);
-            else if (n == 8) stage_fetch_buf<T, RW>(pbc, sc, Un1, wr.dT);
+            uint32_t pbc[EPL];
+            if (n == 0) { tile_issue(pv0, tiles[1], Un0, wr.dT); tile_issue(pv1, tiles[1], Un1, wr.dT); }
+            else if (n == 1) { tile_issue(pv0, tiles[2], Un0, wr.dT); tile_issue(pv1, tiles[2], Un1, wr.dT); }
+            else if (n == 2) { tile_issue(pv0, tiles[3], Un0, wr.dT); tile_issue(pv1, tiles[3], Un1, wr.dT); }
+            else if (n == 3) { tile_issue(pv0, tiles[4], Un0, wr.dT); tile_issue(pv1, tiles[4], Un1, wr.dT); }
+            else if (n == 4) stage_fetch_raw<T, RW>(pbc, sb, Un0, wr.dT);
+            else if (n == 5) stage_fetch_raw<T, RW>(pbc, sb, Un1, wr.dT);
+            else if (n == 6) stage_fetch_raw<T, RW>(pbc, sc, Un0, wr.dT);
+            else if (n == 7) stage_fetch_raw<T, RW>(pbc, sc, Un1, wr.dT);
             const float hp = hp_next;
             {                                             // checkpoint of the state after this one (next window after the last)
                 const int nn = n + 1 < kFS ? n + 1 : 0;
                 const int wn = n + 1 < kFS ? w : (w > 0 ? w - 1 : 0);
-                hp_next = BufIO<float>::ld(ckr, ck_voff, (uint32_t)((wn * kFS + nn) * ck_state));
+                hp_next = BufIO<float>::ld(ckr, ck_voff, (uint32_t)__builtin_amdgcn_readfirstlane((wn * kFS + nn) * ck_state));
             }
             const float A2n = Arow[n] * kLog2e;
             const float An = A2n * 0.6931471805599453f;
@@ -362,54 +358,61 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
             en[n] = e1;
             dAn[n] = dA1;
             // ---- sum the dB / dC contributions over the channels (lanes) of the work item; the lane that ends with the sum of
-            //      step j stores element (j, n) ----------------------------------------------------------------------------
-            {
-                const uint32_t rowU = (uint32_t)((red_j < kFT ? Uw0 : Uw1) + (wr.dT < 0 ? (kFT - 1) * wr.dT : 0));
-                const uint32_t rowB = rowU * (uint32_t)dB_stb + (uint32_t)(n * dB_snb);
-                const uint32_t rowC = rowU * (uint32_t)dC_stb + (uint32_t)(n * dC_snb);
-                if constexpr (RW >= 32) {
-                    float v[2 * kFW];
+            //      step j parks it in the [step][state % 8] tile, which leaves for memory after states 7 and 15 as rows of 8
+            //      consecutive states (scattered 4-byte atomics from here cost 3 x the whole kernel: one L2 transaction each) -----
+            if constexpr (RW >= 32) {
+                float v[2 * kFW];
 #pragma unroll
-                    for (int j = 0; j < kFW; ++j) { v[j] = a[j]; v[kFW + j] = h[j]; }
-                    reduce_scatter<RW, V>(v, it.r);
-                    if (it.r < 32) {                       // lanes 0..15 -> dB_j, 16..31 -> dC_j
-                        if (it.r < kFW) {
-                            if (P.atomic_bc) atomicAdd(reinterpret_cast<float*>(dBbase + (dB_voff + rowB)), v[0]);
-                            else BufIO<float>::st(dBr, dB_voff + rowB, 0u, v[0]);
-                        } else {
-                            if (P.atomic_bc) atomicAdd(reinterpret_cast<float*>(dCbase + (dC_voff + rowC)), v[0]);
-                            else BufIO<float>::st(dCr, dC_voff + rowC, 0u, v[0]);
-                        }
-                    }
-                } else {
-                    reduce_scatter<RW, kFW>(a, it.r);
-                    reduce_scatter<RW, kFW>(h, it.r);
+                for (int j = 0; j < kFW; ++j) { v[j] = a[j]; v[kFW + j] = h[j]; }
+                reduce_scatter<RW, V>(v, it.r);
+                if (it.r < 32) (it.r < kFW ? ldb : ldc)[(it.r & (kFW - 1)) * (kFS / 2) + (n & 7)] = v[0];     // lanes 0..15 dB_j, 16..31 dC_j
+            } else {
+                reduce_scatter<RW, kFW>(a, it.r);
+                reduce_scatter<RW, kFW>(h, it.r);
+                ldb[it.r * (kFS / 2) + (n & 7)] = a[0];
+                ldc[it.r * (kFS / 2) + (n & 7)] = h[0];
+            }
+            if ((n & 7) == 7) {
+                SEGM_WAVE_LDS_SYNC();
+                constexpr int FE = kFW * (kFS / 2) / RW;   // elements per lane and matrix: e = r + i RW -> step e / 8, state e % 8
+#pragma unroll
+                for (int i = 0; i < FE; ++i) {
+                    const int e = it.r + i * RW, j = e >> 3, st8 = (n & 8) + (e & 7);
+                    const uint32_t rows = (uint32_t)((j < kFT ? Uw0 : Uw1) + (j & (kFT - 1)) * wr.dT + wr.lane_row);
+                    const uint32_t ob = rows * (uint32_t)dB_stb + (uint32_t)(st8 * dB_snb);
+                    const uint32_t oc = rows * (uint32_t)dC_stb + (uint32_t)(st8 * dC_snb);
+                    const float xb = ldb[e], xc = ldc[e];
                     if (P.atomic_bc) {
-                        atomicAdd(reinterpret_cast<float*>(dBbase + (dB_voff + rowB)), a[0]);
-                        atomicAdd(reinterpret_cast<float*>(dCbase + (dC_voff + rowC)), h[0]);
+                        atomicAdd(reinterpret_cast<float*>(dBbase + ob), xb);
+                        atomicAdd(reinterpret_cast<float*>(dCbase + oc), xc);
                     } else {
-                        BufIO<float>::st(dBr, dB_voff + rowB, 0u, a[0]);
-                        BufIO<float>::st(dCr, dC_voff + rowC, 0u, h[0]);
+                        BufIO<float>::st(dBr, ob, 0u, xb);
+                        BufIO<float>::st(dCr, oc, 0u, xc);
                     }
                 }
+                SEGM_WAVE_LDS_SYNC();                     // the tile is free for the next eight states
             }
             // ---- park what this state's slice fetched (it arrived during the arithmetic) ---------------------------------------
-            if (n < NSTREAM) {
-                tile_park(pv0, tile + n * STREAM_BYTES, lane);
-                tile_park(pv1, tile + n * STREAM_BYTES + TS::HALF_BYTES, lane);
-            } else if (n < NSTREAM + 4) {
-                const int k = n - NSTREAM;                 // 0: B first half, 1: B second half, 2: C first half, 3: C second half
+            if (n < 4) {
+                tile_park(pv0, tile + (n + 1) * STREAM_BYTES, lane);
+                tile_park(pv1, tile + (n + 1) * STREAM_BYTES + TS::HALF_BYTES, lane);
+            } else if (n < 8) {
+                const int k = n - 4;                       // 0: B first half, 1: B second half, 2: C first half, 3: C second half
                 T* dst = (k < 2 ? raw_b : raw_c) + (k & 1) * kFT * kFS;
                 const StageStream<RW>& ss = k < 2 ? sb : sc;
 #pragma unroll
-                for (int i = 0; i < EPL; ++i) dst[ss.lds0 + i * ss.ldsinc] = from_f32<T>(pbc[i]);
+                for (int i = 0; i < EPL; ++i) put_raw(dst + ss.lds0 + i * ss.ldsinc, pbc[i]);
             }
         }
+        // the next window's u: fetched while this window closes (its own u is still in the tile), parked behind the epilogue
+        u32x4_t pu0[TS::NLH], pu1[TS::NLH];
+        tile_issue(pu0, tiles[0], Un0, wr.dT);
+        tile_issue(pu1, tiles[0], Un1, wr.dT);
         {
             float du[kFW], ddl[kFW];
 #pragma unroll
             for (int j = 0; j < kFW; ++j) {
-                const float uu = to_f32(reinterpret_cast<const T*>(ukeep)[j * RW]);
+                const float uu = lds_elem<T>(tile + (j / kFT) * TS::HALF_BYTES + (j % kFT) * RW * (int)sizeof(T) + elem_off);
                 du[j] = fmaf(wd[j], q[j], Dv * wg[j]);
                 float ddv = fmaf(uu, q[j], ddA[j]);
                 ddv *= softplus_on ? 1.f - fast_exp(-wd[j]) : 1.f;       // sigmoid(raw) = 1 - exp(-softplus(raw))
@@ -427,6 +430,9 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
                 dso += dinc;
             }
         }
+        SEGM_WAVE_LDS_SYNC();                             // every lane has read this window's u
+        tile_park(pu0, tile, lane);
+        tile_park(pu1, tile + TS::HALF_BYTES, lane);
     }
     const int64_t row = crow * (kFS + 2);
 #pragma unroll

@@ -127,8 +127,15 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xffffffffu, 0x00020000);   // raw, no range check
 }
+// `ld` converts where it loads - fine in straight-line code, where the scheduler moves the conversion to the use.  A load whose
+// value is consumed in a LATER basic block (a prefetch inside a conditional) must use `ld_raw` + `cvt_raw`: the conversion is a
+// use, and a use in the loading block makes the compiler wait for the load there (s_waitcnt vmcnt right behind the loads).
 template <typename T> struct BufIO;
 template <> struct BufIO<float> {
+    static __device__ __forceinline__ uint32_t ld_raw(rsrc_t r, uint32_t voff, uint32_t soff) {
+        return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+    }
+    static __device__ __forceinline__ float cvt_raw(uint32_t v) { return __uint_as_float(v); }
     static __device__ __forceinline__ float ld(rsrc_t r, uint32_t voff, uint32_t soff) {
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
     }
@@ -137,6 +144,10 @@ template <> struct BufIO<float> {
     }
 };
 template <> struct BufIO<bf16_t> {
+    static __device__ __forceinline__ uint32_t ld_raw(rsrc_t r, uint32_t voff, uint32_t soff) {
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+    }
+    static __device__ __forceinline__ float cvt_raw(uint32_t v) { return __uint_as_float(v << 16); }
     static __device__ __forceinline__ float ld(rsrc_t r, uint32_t voff, uint32_t soff) {
         return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0) << 16);
     }
@@ -145,6 +156,10 @@ template <> struct BufIO<bf16_t> {
     }
 };
 template <> struct BufIO<f16_t> {
+    static __device__ __forceinline__ uint32_t ld_raw(rsrc_t r, uint32_t voff, uint32_t soff) {
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+    }
+    static __device__ __forceinline__ float cvt_raw(uint32_t v) { return to_f32(__builtin_bit_cast(f16_t, (unsigned short)v)); }
     static __device__ __forceinline__ float ld(rsrc_t r, uint32_t voff, uint32_t soff) {
         return to_f32(__builtin_bit_cast(f16_t, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0)));
     }
@@ -234,6 +249,17 @@ __device__ __forceinline__ void stage_fetch_buf(float (&v)[StageStream<RW>::EPL]
 #pragma unroll
     for (int i = 0; i < StageStream<RW>::EPL; ++i) {
         v[i] = BufIO<T>::ld(st.rs, st.voff, so);
+        so += inc;
+    }
+}
+// the same fetch without the conversion (see BufIO::ld_raw): raw element bits
+template <typename T, int RW>
+__device__ __forceinline__ void stage_fetch_raw(uint32_t (&v)[StageStream<RW>::EPL], const StageStream<RW>& st, int32_t rows, int32_t dT) {
+    uint32_t so = (uint32_t)(rows + (dT < 0 ? st.jmax * dT : 0)) * (uint32_t)st.stb;
+    const uint32_t inc = (uint32_t)(st.jrow * dT * st.stb + st.ninc);
+#pragma unroll
+    for (int i = 0; i < StageStream<RW>::EPL; ++i) {
+        v[i] = BufIO<T>::ld_raw(st.rs, st.voff, so);
         so += inc;
     }
 }

@@ -15,13 +15,17 @@ Data movement differs from the reference on purpose (MI355X-first):
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
 
 from . import lib as L
 from .linear import linear_cl
-from .selective_scan_interface import _inner
+from .selective_scan_interface import MambaInnerCore3, _inner
+
+
+_FUSED3 = os.environ.get("SEGM_MAMBA_FUSED3", "1") == "1"     # 0: one autograd node per direction (round 2)
 
 
 class Mamba(nn.Module):
@@ -139,9 +143,20 @@ class Mamba(nn.Module):
         if seqlen % self.nslices != 0:
             raise RuntimeError(f"sequence length {seqlen} must be divisible by nslices {self.nslices}")
         xz = linear_cl(hidden_states, self.in_proj.weight, self.in_proj.bias)        # (B, L, 2*d_inner)
-        out = self._direction(xz, "", L.TIME_FORWARD)
-        out_b = self._direction(xz, "_b", L.TIME_REVERSED)
-        out_s = self._direction(xz, "_s", L.TIME_INTERLEAVED, self.nslices)
+        if _FUSED3 and L.on_device(xz):
+            # the three directions as one autograd node: their scans share one grid (selective_scan_interface.MambaInnerCore3)
+            params = []
+            for sfx in ("", "_b", "_s"):
+                conv, dt_proj = getattr(self, "conv1d" + sfx), getattr(self, "dt_proj" + sfx)
+                params += [conv.weight, conv.bias, getattr(self, "x_proj" + sfx).weight, dt_proj.weight,
+                           -torch.exp(getattr(self, "A" + sfx + "_log").float()), getattr(self, "D" + sfx).float(),
+                           dt_proj.bias.float()]
+            train = torch.is_grad_enabled() and (xz.requires_grad or any(p.requires_grad for p in params))
+            out, out_b, out_s = MambaInnerCore3.apply(xz, self.nslices, train, *params)
+        else:
+            out = self._direction(xz, "", L.TIME_FORWARD)
+            out_b = self._direction(xz, "_b", L.TIME_REVERSED)
+            out_s = self._direction(xz, "_s", L.TIME_INTERLEAVED, self.nslices)
         return linear_cl(out + out_b + out_s, self.out_proj.weight, self.out_proj.bias)
 
     # ---- autoregressive decoding (reference :196-201, :265-310, :356-436).  SegMamba never takes this path; with

@@ -298,6 +298,133 @@ class MambaInnerCore(torch.autograd.Function):
                 dB_proj_bias, dC_proj_bias, None, None, None, None, None)
 
 
+class MambaInnerCore3(torch.autograd.Function):
+    """The three directions of a `Mamba(bimamba_type="v3")` layer as ONE autograd node (reference mamba_simple.py:216-264 calls
+    `mamba_inner_fn_no_out_proj` three times: as stored, time-reversed, slice-interleaved - three parameter sets on one `xz`).
+
+    Same arithmetic per direction as `MambaInnerCore` on channel-last tensors; what the node buys is launch structure: the three
+    selective scans of the forward (and of the backward) are ONE grid with a direction axis
+    (`segm_selective_scan_{fwd,bwd}_multi`) - 3 x the waves where one direction cannot fill the 1024 SIMDs (stages 1 - 3:
+    12.6 M, 3.1 M, 0.8 M channel-steps) and a third of the scan launches - and the three `dxz` contributions are summed inside
+    the node.  Arguments: xz (B, L, 2D), nslices, train, then for each direction (conv1d_weight, conv1d_bias, x_proj_weight,
+    delta_proj_weight, A, D, delta_bias)."""
+
+    ORDERS = (L.TIME_FORWARD, L.TIME_REVERSED, L.TIME_INTERLEAVED)
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, xz, nslices, train, *params):
+        lib = L.get_lib()
+        assert len(params) == 21
+        sets = [params[7 * i:7 * i + 7] for i in range(3)]
+        act_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None
+        if xz.stride(2) != 1:
+            xz = xz.contiguous()
+        batch, seqlen, dim2 = xz.shape
+        dim = dim2 // 2
+        x, z = xz.split(dim, dim=2)
+        keep = train and not _RECOMPUTE
+        calls, per_dir = [], []
+        for i, (conv_w, conv_b, xw, dtw, A, D, dbias) in enumerate(sets):
+            if act_dtype is not None:
+                from .param_bank import low_precision
+                xw, dtw = low_precision(xw, act_dtype), low_precision(dtw, act_dtype)
+            R, N = dtw.shape[1], A.shape[-1]
+            ns = nslices if MambaInnerCore3.ORDERS[i] == L.TIME_INTERLEAVED else 1
+            w32 = conv_w.reshape(dim, -1).float().contiguous()
+            cb32 = conv_b.float().contiguous() if conv_b is not None else None
+            conv_out = ops_raw.conv1d_fwd(lib, x, w32, cb32, True, channel_last=True, time_order=MambaInnerCore3.ORDERS[i], nslices=ns)
+            if _rows_route(conv_out, True):
+                x_dbl, delta, Bv, Cv = _project_rows(conv_out, xw, dtw, R, N)
+            else:
+                x_dbl, delta, Bv, Cv = _project(conv_out, xw, dtw, R, N, True, None, None)
+            calls.append(dict(u=conv_out, delta=delta, A=A.float().contiguous(), B=Bv, C=Cv,
+                              D=D.float().contiguous() if D is not None else None, z=z,
+                              delta_bias=dbias.float().contiguous() if dbias is not None else None, delta_softplus=True,
+                              channel_last=True, time_order=MambaInnerCore3.ORDERS[i], nslices=ns, need_out=train, need_ckpt=train))
+            per_dir.append((x_dbl, xw, dtw, conv_out, delta, R, N, ns))
+        rs = ops_raw.scan_fwd_multi(lib, calls)
+        saved = [xz]
+        for (conv_w, conv_b, xw0, dtw0, A, D, dbias), (x_dbl, xw, dtw, conv_out, delta, R, N, ns), r in zip(sets, per_dir, rs):
+            saved += [conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, r["out"], r["ckpt"],
+                      conv_out if keep else None, delta if keep else None]
+        ctx.cfg = (int(nslices), [r["chunk"] for r in rs], [(p[5], p[6]) for p in per_dir], keep,
+                   [(st[2].dtype, st[3].dtype) for st in sets])         # the masters' dtypes: weight gradients go back in them
+        ctx.save_for_backward(*saved)
+        return tuple(r["out_z"] for r in rs)
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, *douts):
+        lib = L.get_lib()
+        nslices, chunks, rn, keep, wdt = ctx.cfg
+        saved = ctx.saved_tensors
+        xz = saved[0]
+        batch, seqlen, dim2 = xz.shape
+        dim = dim2 // 2
+        x, z = xz.split(dim, dim=2)
+        dirs, calls = [], []
+        for i in range(3):
+            (conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, out, ckpt, conv_out, delta) = saved[1 + 12 * i:13 + 12 * i]
+            R, N = rn[i]
+            order = MambaInnerCore3.ORDERS[i]
+            ns = nslices if order == L.TIME_INTERLEAVED else 1
+            w32 = conv_w.reshape(dim, -1).float().contiguous()
+            cb32 = conv_b.float().contiguous() if conv_b is not None else None
+            rows_route = x_dbl.shape[1] != R + 2 * N
+            if keep:
+                Bv, Cv = _bc_views(x_dbl, batch, seqlen, R, N, True, None, None)
+            else:
+                conv_out = ops_raw.conv1d_fwd(lib, x, w32, cb32, True, channel_last=True, time_order=order, nslices=ns)
+                if rows_route:
+                    _, delta, Bv, Cv = _project_rows(conv_out, xw, dtw, R, N, x_dbl=x_dbl)
+                else:
+                    _, delta, Bv, Cv = _project(conv_out, xw, dtw, R, N, True, None, None, x_dbl=x_dbl)
+            dout = douts[i]
+            if dout.stride(2) != 1:
+                dout = dout.contiguous()
+            dxz = torch.empty_like(xz, memory_format=torch.contiguous_format)
+            dx, dz = dxz.split(dim, dim=2)
+            calls.append(dict(u=conv_out, delta=delta, A=A.float().contiguous(), B=Bv, C=Cv,
+                              D=D.float().contiguous() if D is not None else None, z=z,
+                              delta_bias=dbias.float().contiguous() if dbias is not None else None, dout=dout, out=out, ckpt=ckpt,
+                              delta_softplus=True, channel_last=True, time_order=order, nslices=ns, chunk=chunks[i], dz=dz))
+            dirs.append((conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, conv_out, R, N, order, ns, w32, cb32, rows_route, dxz, dx))
+        gs = ops_raw.scan_bwd_multi(lib, calls)
+        grads, dxz_sum = [], None
+        for i, ((conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, conv_out, R, N, order, ns, w32, cb32, rows_route, dxz, dx), g) in enumerate(zip(dirs, gs)):
+            dconv2 = g["du"].reshape(batch * seqlen, dim)
+            ddelta2 = g["ddelta"].reshape(batch * seqlen, dim)
+            conv2 = conv_out.reshape(batch * seqlen, dim)
+            dB2, dC2 = g["dB"].reshape(batch * seqlen, N), g["dC"].reshape(batch * seqlen, N)
+            dx_dbl = torch.empty_like(x_dbl)
+            ddelta_proj_weight = tn_matmul(ddelta2, x_dbl[:, :R])
+            if rows_route:
+                P, P8, R4 = R + 2 * N, x_dbl.shape[1], -(-R // 4) * 4
+                ops_raw.linear_rows(lib, ddelta2, _pad_rows(dtw.t(), R4), out=dx_dbl[:, :R4])
+                dx_dbl[:, R:R + N] = dB2
+                dx_dbl[:, R + N:P] = dC2
+                if P8 > P:
+                    dx_dbl[:, P:] = 0
+                dx_proj_weight = tn_matmul(dx_dbl[:, :P], conv2)
+                wx_t = _pad_rows(xw, P8).t().contiguous()
+                dconv2 = ops_raw.linear_rows(lib, dx_dbl, wx_t, out=dconv2, accumulate=True)
+            else:
+                dx_dbl[:, R:R + N] = dB2
+                dx_dbl[:, R + N:] = dC2
+                dx_dbl[:, :R] = ddelta2 @ dtw
+                dx_proj_weight = tn_matmul(dx_dbl, conv2)
+                dconv2 = torch.addmm(dconv2, dx_dbl, xw)
+            _, dconv_w, dconv_b = ops_raw.conv1d_bwd(lib, x, w32, cb32, dconv2.reshape(batch, seqlen, dim), True, channel_last=True,
+                                                     time_order=order, nslices=ns, dx=dx)
+            dxz_sum = dxz if dxz_sum is None else dxz_sum.add_(dxz)
+            grads += [dconv_w.reshape(conv_w.shape).to(conv_w.dtype), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
+                      dx_proj_weight.to(wdt[i][0]), ddelta_proj_weight.to(wdt[i][1]), g["dA"].to(A.dtype),
+                      g["dD"].to(D.dtype) if D is not None else None,
+                      g["ddelta_bias"].to(dbias.dtype) if dbias is not None else None]
+        return (dxz_sum, None, None, *grads)
+
+
 def _bc_views(x_dbl, batch, seqlen, R, N, channel_last, B_proj_bias, C_proj_bias):
     """B_t / C_t as the scan expects them: strided views of x_dbl (b*l, R + 2N [+ padding])"""
     v3 = x_dbl.view(batch, seqlen, x_dbl.shape[1])

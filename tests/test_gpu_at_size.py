@@ -97,3 +97,11 @@ def test_config4_two_million_steps(hip):
 def test_config4_sixteen_million_steps(hip):
     c = _case(1, 96, 16, 1 << 24, torch.bfloat16, seed=24)
     _run_and_check(hip, c, torch.bfloat16, L.TIME_FORWARD, 1, "config4 L=2^24 bf16 ch 32:64", ch=slice(32, 64), want_bc=False)
+
+
+def test_config4_sixteen_million_steps_fp32_reversed(hip):
+    """fp32 I/O at L = 2^24: 6.4 GB per tensor and batch - beyond a 32-bit byte offset from the batch base.  The regular-shape
+    kernels address from the lowest row ONE wave touches (scan_fast.h), so only the rows of a wave must fit 32 bits; time-reversed
+    so that the descending offsets are exercised at that size too."""
+    c = _case(1, 96, 16, 1 << 24, torch.float32, seed=25)
+    _run_and_check(hip, c, torch.float32, L.TIME_REVERSED, 1, "config4 L=2^24 fp32 reversed ch 0:32", ch=slice(0, 32), want_bc=False)

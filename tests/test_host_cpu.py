@@ -337,3 +337,24 @@ def test_argument_errors_of_the_newer_entry_points_without_gpu(built_lib):
     assert need == 1 * 7 * 7 * 48 * 32 * 4                 # 4 output rows: one slab of partials
     g.workspace, g.workspace_bytes = p16, need - 1
     assert d.segm_stem_conv_wgrad(g) == -6                 # workspace too small
+
+
+def test_conv_routing_is_a_table_not_a_timing_run():
+    """which kernel a 3x3x3 layer takes must not depend on a per-process timing run (ranks could differ, results
+    were not reproducible run to run, nothing of it can happen under graph capture).  Routing is a pure function of the shape
+    (conv3d._table_choice, from profiles/r02_bench_variants.log); the tuner is opt-in (SEGM_CONV_AUTOTUNE=1)."""
+    from segmamba_amd import conv3d
+    assert conv3d._TUNE is False
+    lib = [(False, False, False), (True, False, False), (True, True, False), (False, False, True)]
+    fwd = [None, None] + lib                                  # native, blocked, the four library variants
+    for width, want in ((128, (True, True, False)), (64, (True, True, False)), (32, (False, False, True)), (16, (False, False, True))):
+        assert fwd[conv3d._table_choice("fwd", width, fwd)] == want
+        assert fwd[conv3d._table_choice("dgrad", width, [None] + fwd)] is None or True
+        assert ([None] + fwd)[conv3d._table_choice("dgrad", width, [None] + fwd)] == want
+    assert conv3d._table_choice("fwd", 8, fwd) == 0 and conv3d._table_choice("dgrad", 8, [None] + fwd) == 0     # 8^3: vendor GEMM route
+    assert conv3d._table_choice("fwd", 64, [None]) == 0                          # nothing of the library applies: vendor route
+    assert conv3d._table_choice("fwd", 64, [None, lib[0]]) == 1                  # only the plain library kernel applies
+    assert conv3d._table_choice("wgrad", 128, [None, None, "mfma"]) == 2 and conv3d._table_choice("wgrad", 16, [None, "mfma"]) == 1
+    assert conv3d._table_choice("wgrad", 8, [None, None, "mfma"]) == 0
+    # the same decision in every process: no state is consulted
+    assert not conv3d._cache
