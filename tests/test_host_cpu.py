@@ -349,7 +349,6 @@ def test_conv_routing_is_a_table_not_a_timing_run():
     fwd = [None, None] + lib                                  # native, blocked, the four library variants
     for width, want in ((128, (True, True, False)), (64, (True, True, False)), (32, (False, False, True)), (16, (False, False, True))):
         assert fwd[conv3d._table_choice("fwd", width, fwd)] == want
-        assert fwd[conv3d._table_choice("dgrad", width, [None] + fwd)] is None or True
         assert ([None] + fwd)[conv3d._table_choice("dgrad", width, [None] + fwd)] == want
     assert conv3d._table_choice("fwd", 8, fwd) == 0 and conv3d._table_choice("dgrad", 8, [None] + fwd) == 0     # 8^3: vendor GEMM route
     assert conv3d._table_choice("fwd", 64, [None]) == 0                          # nothing of the library applies: vendor route
