@@ -182,6 +182,10 @@ typedef struct segm_conv1d_args {
 
 int segm_causal_conv1d_fwd(const segm_conv1d_args* args);
 int segm_causal_conv1d_bwd(const segm_conv1d_args* args);
+/* `n` launches in one call; consecutive blocks that share batch / dim / width / seqlen / dtype / stream (up to three: the three
+ * directions of a Mamba v3 layer, reference mamba_simple.py:216-264) run as one grid with a direction axis */
+int segm_causal_conv1d_fwd_multi(const segm_conv1d_args* args, int32_t n);
+int segm_causal_conv1d_bwd_multi(const segm_conv1d_args* args, int32_t n);
 size_t segm_causal_conv1d_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t width, int64_t seqlen);
 
 /* ------------------------------------------------------------------------------------------------

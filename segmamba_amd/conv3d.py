@@ -130,17 +130,32 @@ def _hip_fwd_ok(x, w) -> bool:
         ops_raw.conv3d_k3_fwd_supported(x[:, :_BLOCK], w.shape[0])
 
 
-def _fwd_hip(x, w, pad, bias=None, chain=False, pitch48=False, chain32=False, into=None):
+def _packed_block(w, ib, flipped, dtype):
+    """the library kernel's register layout of one 48-channel input block of a weight: (Cout, 3, 3, 3, 48) in the activations'
+    dtype; `flipped`: the block of the data-gradient weight flip(W)^T.  A re-arrangement of the step's 16-bit copy: inside a
+    bank step it is a view of the bank's gather buffer (param_bank.packed), not a per-call copy chain."""
+    from . import ops_raw
+    from .param_bank import packed
+    if w.dtype != dtype:
+        return ops_raw.pack_conv3d_weight((w.flip(2, 3, 4).transpose(0, 1) if flipped else w)[:, ib], dtype)
+    if flipped:
+        return packed(w, ("conv3d_k3_dgrad", ib.start, ib.stop),
+                      lambda t: ops_raw.pack_conv3d_weight(t.flip(2, 3, 4).transpose(0, 1)[:, ib], t.dtype))
+    return packed(w, ("conv3d_k3_fwd", ib.start, ib.stop), lambda t: ops_raw.pack_conv3d_weight(t[:, ib], t.dtype))
+
+
+def _fwd_hip(x, w, pad, bias=None, chain=False, pitch48=False, chain32=False, into=None, flipped=False):
     """segm_conv3d_k3_fwd per 48-channel input block (the kernel keeps one block's weights in registers).  With
     Cout % 48 == 0 the later blocks accumulate into the first block's output in place; `chain` picks the kernel whose K
     parts are pipelined (csrc/conv3d_fwd.hip, variant 1).  `into`: an existing result every block is added to (the next part
     of a concatenated input; Cout % 48 == 0, no bias)."""
     from . import lib as L, ops_raw
     hip = L.get_lib()
-    inplace = w.shape[0] % _BLOCK == 0
+    cout, cin = (w.shape[1], w.shape[0]) if flipped else (w.shape[0], w.shape[1])     # flipped: w is the forward weight
+    inplace = cout % _BLOCK == 0
     out = into
-    for i, ib in enumerate(_blocks(w.shape[1])):
-        wp = ops_raw.pack_conv3d_weight(w[:, ib], x.dtype)
+    for i, ib in enumerate(_blocks(cin)):
+        wp = _packed_block(w, ib, flipped, x.dtype)
         if inplace:
             out = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None, out=out, accumulate=i > 0 or into is not None,
                                         chain=chain, pitch48=pitch48, chain32=chain32)
@@ -195,7 +210,7 @@ def _dgrad_as_fwd_blocked(dy, w, x, pad):
 
 
 def _dgrad_hip(dy, w, x, pad, chain=False, pitch48=False, chain32=False):
-    return _fwd_hip(dy, _flipT(w), pad, None, chain, pitch48, chain32)
+    return _fwd_hip(dy, w, pad, None, chain, pitch48, chain32, flipped=True)
 
 
 def _wgrad_native(x, dy, w, pad):

@@ -26,9 +26,12 @@ struct ConvDev {
     int32_t silu;
     float* part;         // backward: [batch][nchunks][W + 1][dim] partial dweight / dbias
 };
+struct ConvDevN { ConvDev d[kMaxDirs]; };
+
 
 template <typename T, int W, int TS>
-__global__ void __launch_bounds__(kBlock) conv1d_fwd_kernel(ConvDev P) {
+__global__ void __launch_bounds__(kBlock) conv1d_fwd_kernel(ConvDevN PP) {
+    const ConvDev& P = PP.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
     const TimeMap tm = P.tm;
@@ -92,7 +95,8 @@ __global__ void __launch_bounds__(kBlock) conv1d_fwd_kernel(ConvDev P) {
 //   if i in this chunk:  dweight[k] += g_i * x[i-(W-1-k)],  dbias += g_i
 //   tau = i-(W-1):  dx_tau = sum_k wt[k] * g_{tau+(W-1-k)} = sum_k wt[k] * gw[k]   with gw[k] = g_{i-k}... see below
 template <typename T, int W, int TS>
-__global__ void __launch_bounds__(kBlock) conv1d_bwd_kernel(ConvDev P) {
+__global__ void __launch_bounds__(kBlock) conv1d_bwd_kernel(ConvDevN PP) {
+    const ConvDev& P = PP.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
     const TimeMap tm = P.tm;
@@ -261,26 +265,31 @@ static void fill_conv_dev(ConvDev& P, const segm_conv1d_args* a) {
     P.weight = a->weight; P.bias = a->bias; P.silu = a->silu;
 }
 
+// `ndir` argument blocks of ONE geometry (the three directions of a Mamba v3 layer) as one grid, blockIdx.y = direction
 template <typename T, int W>
-static int launch_conv(const ConvDev& P, bool bwd, hipStream_t stream) {
+static int launch_conv(const ConvDevN& PP, int ndir, bool bwd, hipStream_t stream) {
     constexpr int TS = 8;
-    const unsigned nblocks = (unsigned)((P.gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (bwd) hipLaunchKernelGGL((conv1d_bwd_kernel<T, W, TS>), dim3(nblocks), dim3(kBlock), 0, stream, P);
-    else hipLaunchKernelGGL((conv1d_fwd_kernel<T, W, TS>), dim3(nblocks), dim3(kBlock), 0, stream, P);
+    const unsigned nblocks = (unsigned)((PP.d[0].gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (bwd) hipLaunchKernelGGL((conv1d_bwd_kernel<T, W, TS>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+    else hipLaunchKernelGGL((conv1d_fwd_kernel<T, W, TS>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
     return (int)hipGetLastError();
 }
 
 template <typename T>
-static int launch_conv_w(const ConvDev& P, int width, bool bwd, hipStream_t stream) {
-    if (width == 2) return launch_conv<T, 2>(P, bwd, stream);
-    if (width == 3) return launch_conv<T, 3>(P, bwd, stream);
-    return launch_conv<T, 4>(P, bwd, stream);
+static int launch_conv_w(const ConvDevN& PP, int ndir, int width, bool bwd, hipStream_t stream) {
+    if (width == 2) return launch_conv<T, 2>(PP, ndir, bwd, stream);
+    if (width == 3) return launch_conv<T, 3>(PP, ndir, bwd, stream);
+    return launch_conv<T, 4>(PP, ndir, bwd, stream);
 }
 
-static int launch_conv_t(const ConvDev& P, int dtype, int width, bool bwd, hipStream_t stream) {
-    if (dtype == SEGM_F32) return launch_conv_w<float>(P, width, bwd, stream);
-    if (dtype == SEGM_F16) return launch_conv_w<f16_t>(P, width, bwd, stream);
-    return launch_conv_w<bf16_t>(P, width, bwd, stream);
+static int launch_conv_t(const ConvDevN& PP, int ndir, int dtype, int width, bool bwd, hipStream_t stream) {
+    if (dtype == SEGM_F32) return launch_conv_w<float>(PP, ndir, width, bwd, stream);
+    if (dtype == SEGM_F16) return launch_conv_w<f16_t>(PP, ndir, width, bwd, stream);
+    return launch_conv_w<bf16_t>(PP, ndir, width, bwd, stream);
+}
+static bool conv_same_launch(const segm_conv1d_args* a, const segm_conv1d_args* b) {
+    return a->batch == b->batch && a->dim == b->dim && a->width == b->width && a->seqlen == b->seqlen && a->dtype == b->dtype &&
+           a->stream == b->stream;
 }
 
 }  // namespace segm
@@ -294,26 +303,42 @@ extern "C" size_t segm_causal_conv1d_bwd_workspace_bytes(int32_t batch, int32_t 
     return align256((size_t)batch * nch * (width + 1) * dim * sizeof(float));
 }
 
-extern "C" int segm_causal_conv1d_fwd(const segm_conv1d_args* a) {
-    int rc = validate_conv(a, false);
-    if (rc != SEGM_OK) return rc;
-    ConvDev P;
-    fill_conv_dev(P, a);
-    return launch_conv_t(P, a->dtype, a->width, false, (hipStream_t)a->stream);
-}
-
-extern "C" int segm_causal_conv1d_bwd(const segm_conv1d_args* a) {
-    int rc = validate_conv(a, true);
-    if (rc != SEGM_OK) return rc;
-    const size_t need = segm_causal_conv1d_bwd_workspace_bytes(a->batch, a->dim, a->width, a->seqlen);
-    if (!a->workspace || a->workspace_bytes < need) return SEGM_E_WORKSPACE;
-    ConvDev P;
-    fill_conv_dev(P, a);
-    P.part = (float*)a->workspace;
-    hipStream_t stream = (hipStream_t)a->stream;
-    rc = launch_conv_t(P, a->dtype, a->width, true, stream);
-    if (rc != 0) return rc;
-    launch_reduce_partials(P.part, (int64_t)a->batch * P.gm.nchunks, a->width + 1, a->dim, a->dweight, a->width,
-                           a->dbias, nullptr, stream);
+// `n` launches: one grid with a direction axis when they share geometry / dtype / stream (n <= 3), else one after the other
+static int conv_multi(const segm_conv1d_args* args, int32_t n, bool bwd) {
+    if (!args || n <= 0) return SEGM_E_NULL;
+    for (int i = 0; i < n; ++i) {
+        const int rc = validate_conv(&args[i], bwd);
+        if (rc != SEGM_OK) return rc;
+        if (bwd) {
+            const size_t need = segm_causal_conv1d_bwd_workspace_bytes(args[i].batch, args[i].dim, args[i].width, args[i].seqlen);
+            if (!args[i].workspace || args[i].workspace_bytes < need) return SEGM_E_WORKSPACE;
+        }
+    }
+    int i = 0;
+    while (i < n) {
+        int m = 1;
+        while (i + m < n && m < kMaxDirs && conv_same_launch(&args[i], &args[i + m])) ++m;
+        ConvDevN PP;
+        memset(&PP, 0, sizeof(PP));
+        for (int k = 0; k < m; ++k) {
+            fill_conv_dev(PP.d[k], &args[i + k]);
+            if (bwd) PP.d[k].part = (float*)args[i + k].workspace;
+        }
+        hipStream_t stream = (hipStream_t)args[i].stream;
+        const int rc = launch_conv_t(PP, m, args[i].dtype, args[i].width, bwd, stream);
+        if (rc != 0) return rc;
+        if (bwd)
+            for (int k = 0; k < m; ++k) {
+                const segm_conv1d_args* a = &args[i + k];
+                launch_reduce_partials(PP.d[k].part, (int64_t)a->batch * PP.d[k].gm.nchunks, a->width + 1, a->dim, a->dweight, a->width,
+                                       a->dbias, nullptr, stream);
+            }
+        i += m;
+    }
     return (int)hipGetLastError();
 }
+
+extern "C" int segm_causal_conv1d_fwd(const segm_conv1d_args* a) { return conv_multi(a, a ? 1 : 0, false); }
+extern "C" int segm_causal_conv1d_bwd(const segm_conv1d_args* a) { return conv_multi(a, a ? 1 : 0, true); }
+extern "C" int segm_causal_conv1d_fwd_multi(const segm_conv1d_args* args, int32_t n) { return conv_multi(args, n, false); }
+extern "C" int segm_causal_conv1d_bwd_multi(const segm_conv1d_args* args, int32_t n) { return conv_multi(args, n, true); }

@@ -18,6 +18,8 @@
 //     stores it): no LDS tile, no flush phase.
 // Per (step, state): forward  a = exp2(delta A2), h = a h_prev + (delta u) B;  backward  dh = g C + e, en = a dh,
 //   t2 = en h_prev, dA += t2 delta, q += dh B, ddelta += t2 A, dB_c = dh (delta u), dC_c = g h - 11 packed half-ops + 1 v_exp.
+#include <stdlib.h>
+
 #include "scan_fast.h"
 
 namespace segm {
@@ -262,6 +264,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
     }
     float hp_next;                                        // checkpoint of the next (state, window) of the walk, one state ahead
     hp_next = BufIO<float>::ld(ckr, ck_voff, (uint32_t)((nwin - 1) * kFS * ck_state));
+    float A_next = Arow[0];                               // likewise A[d][n]: a load per state, never waited for where it is issued
 
     for (int w = nwin - 1; w >= 0; --w) {
         SEGM_WAVE_LDS_SYNC();                             // the tiles of this window are parked (by this wave)
@@ -300,10 +303,11 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2 * EPL; ++i) {              // raw [16][16] -> fp32, element e = r + i RW of each matrix
+        for (int i = 0; i < 2 * EPL; ++i) {              // raw [step][state] -> fp32 [state][step]: a state's 16 steps are 64 bytes
             const int e = it.r + i * RW;
-            lb[e] = to_f32(raw_b[e]);
-            lc[e] = to_f32(raw_c[e]);
+            const int t = (e & (kFS - 1)) * kFW + (e >> 4);
+            lb[t] = to_f32(raw_b[e]);
+            lc[t] = to_f32(raw_c[e]);
         }
         SEGM_WAVE_LDS_SYNC();                             // tiles and raw B / C are consumed: the state loop may refill them
 
@@ -329,22 +333,33 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
                 const int wn = n + 1 < kFS ? w : (w > 0 ? w - 1 : 0);
                 hp_next = BufIO<float>::ld(ckr, ck_voff, (uint32_t)__builtin_amdgcn_readfirstlane((wn * kFS + nn) * ck_state));
             }
-            const float A2n = Arow[n] * kLog2e;
+            const float A2n = A_next * kLog2e;
             const float An = A2n * 0.6931471805599453f;
+            A_next = Arow[(n + 1) & (kFS - 1)];
             float e1 = en[n];
             float dA1 = dAn[n];
+            // this state's B_t / C_t of the window: eight broadcast 16-byte reads up front (per-step reads from a [step][state] tile
+            // put one LDS round trip on the critical path of each of the 32 steps of the two loops: half the kernel's time)
+            float bbv[kFW], ccv[kFW];
+#pragma unroll
+            for (int q4 = 0; q4 < kFW / 4; ++q4) {
+                const float4 b4 = reinterpret_cast<const float4*>(lb + n * kFW)[q4];
+                const float4 c4 = reinterpret_cast<const float4*>(lc + n * kFW)[q4];
+                bbv[4 * q4] = b4.x; bbv[4 * q4 + 1] = b4.y; bbv[4 * q4 + 2] = b4.z; bbv[4 * q4 + 3] = b4.w;
+                ccv[4 * q4] = c4.x; ccv[4 * q4 + 1] = c4.y; ccv[4 * q4 + 2] = c4.z; ccv[4 * q4 + 3] = c4.w;
+            }
             float a[kFW], h[kFW];
 #pragma unroll
             for (int j = 0; j < kFW; ++j) {
-                const float bb = lb[j * kFS + n];
+                const float bb = bbv[j];
                 a[j] = fast_exp2(A2n * wd[j]);
                 h[j] = fmaf(a[j], j ? h[j - 1] : hp, bb * wdu[j]);
             }
 #pragma unroll
             for (int jj = 0; jj < kFW; ++jj) {
                 const int j = kFW - 1 - jj;
-                const float bb = lb[j * kFS + n];
-                const float cc = lc[j * kFS + n];
+                const float bb = bbv[j];
+                const float cc = ccv[j];
                 const float dh = fmaf(cc, wg[j], e1);
                 e1 = a[j] * dh;
                 const float t2 = e1 * (j ? h[j - 1] : hp);
@@ -353,7 +368,6 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MAIN_WAVES) scan_bwd_main_fas
                 ddA[j] = fmaf(t2, An, ddA[j]);
                 a[j] = dh * wdu[j];                        // dB contribution of (j, n), in a's register
                 h[j] = h[j] * wg[j];                       // dC contribution, in h's register
-                SEGM_PIN_F32(e1);                          // one step at a time: keeps the LDS reads of earlier steps from being hoisted
             }
             en[n] = e1;
             dAn[n] = dA1;
@@ -472,8 +486,31 @@ static void launch_bwd_fast_t(const ScanDevN& PP, int ndir, bool main, hipStream
     else if (PP.d[0].gm.rw == 32) launch_bwd_fast_rw<T, 32>(PP, ndir, main, stream);
     else launch_bwd_fast_rw<T, 16>(PP, ndir, main, stream);
 }
+bool scan_full_span_fits(const ScanDev& P, size_t esize) {
+    const int64_t lim = (int64_t)1 << 32, L = P.gm.L, es = (int64_t)esize;
+    const Seq* sq[9] = {&P.u, &P.delta, &P.z, &P.out, &P.dout, &P.du, &P.ddelta, &P.dz, nullptr};
+    for (const Seq* s : sq)
+        if (s && s->p && ((L - 1) * s->st + (int64_t)(P.gm.dim - 1) * s->sd + 1) * es >= lim) return false;
+    const BC* bc[2] = {&P.Bm, &P.Cm};
+    for (const BC* m : bc)
+        if (((L - 1) * m->st + (int64_t)(P.gm.nstate - 1) * m->sn + 1) * es >= lim) return false;
+    return ((L - 1) * P.dB_st + (P.gm.nstate - 1) * P.dB_sn + 1) * 4 < lim && ((L - 1) * P.dC_st + (P.gm.nstate - 1) * P.dC_sn + 1) * 4 < lim;
+}
+// main kernel choice: "r2" = the pair kernel (scan_bwd_pair.hip), "r3" = the kernel above; SEGM_BWD_MAIN overrides the default
+static bool use_pair_kernel(const ScanDevN& PP, int ndir, int dtype) {
+    const char* e = getenv("SEGM_BWD_MAIN");               // read per launch: tests switch it inside one process
+    const int forced = !e ? 0 : (e[0] == 'r' && e[1] == '3' ? 3 : 2);
+    const size_t es = dtype == SEGM_F32 ? 4 : 2;
+    for (int i = 0; i < ndir; ++i)
+        if (!scan_full_span_fits(PP.d[i], es)) return false;
+    return forced != 3;
+}
 // launches K1 (main == false) or K3 (main == true) of the regular-shape backward for `ndir` blocks of one geometry
 void launch_scan_bwd_fast(const ScanDevN& PP, int ndir, int dtype, bool main, hipStream_t stream) {
+    if (main && use_pair_kernel(PP, ndir, dtype)) {
+        launch_scan_bwd_main_pair(PP, ndir, dtype, stream);
+        return;
+    }
     if (dtype == SEGM_F32) launch_bwd_fast_t<float>(PP, ndir, main, stream);
     else if (dtype == SEGM_F16) launch_bwd_fast_t<f16_t>(PP, ndir, main, stream);
     else launch_bwd_fast_t<bf16_t>(PP, ndir, main, stream);

@@ -234,7 +234,7 @@ class TransposeArgs(C.Structure):
 EXPORTS = (
     "segm_selective_scan_fwd", "segm_selective_scan_fwd_workspace_bytes", "segm_selective_scan_ckpt_bytes",
     "segm_selective_scan_default_chunk", "segm_selective_scan_bwd", "segm_selective_scan_bwd_workspace_bytes",
-    "segm_selective_scan_fwd_multi", "segm_selective_scan_bwd_multi",
+    "segm_selective_scan_fwd_multi", "segm_selective_scan_bwd_multi", "segm_causal_conv1d_fwd_multi", "segm_causal_conv1d_bwd_multi",
     "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
     "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes", "segm_conv3d_k3_fwd",
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add",
@@ -270,6 +270,8 @@ class SegmLib:
         sig("segm_selective_scan_default_chunk", [C.c_int32, C.c_int32, C.c_int64], C.c_int32)
         sig("segm_causal_conv1d_fwd", [C.POINTER(Conv1dArgs)], C.c_int)
         sig("segm_causal_conv1d_bwd", [C.POINTER(Conv1dArgs)], C.c_int)
+        sig("segm_causal_conv1d_fwd_multi", [C.POINTER(Conv1dArgs), C.c_int32], C.c_int)
+        sig("segm_causal_conv1d_bwd_multi", [C.POINTER(Conv1dArgs), C.c_int32], C.c_int)
         sig("segm_causal_conv1d_bwd_workspace_bytes", [C.c_int32, C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
         sig("segm_conv3d_k3_wgrad", [C.POINTER(Conv3dWgradArgs)], C.c_int)
         sig("segm_conv3d_k3_wgrad_workspace_bytes", [C.c_int32] * 6, C.c_size_t)

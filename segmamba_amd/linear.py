@@ -123,7 +123,8 @@ class _LinearCL(torch.autograd.Function):
         dx = dw = db = None
         dy2 = dy.reshape(-1, dy.shape[-1])
         if ctx.needs_input_grad[0]:
-            dx = _rows_hip(dy2, w.t().contiguous(), None)
+            from .param_bank import packed
+            dx = _rows_hip(dy2, packed(w, "linear_t", lambda t: t.t().contiguous()), None)
             dx = (dy2 @ w if dx is None else dx).reshape(x.shape)
         if ctx.needs_input_grad[1]:
             dw = tn_matmul(dy2, x.reshape(-1, x.shape[-1])).to(ctx.w_dtype)

@@ -262,10 +262,53 @@ def conv1d_fwd(lib: L.SegmLib, x, weight, bias=None, silu=False, *, channel_last
     return out
 
 
+def conv1d_fwd_multi(lib: L.SegmLib, calls):
+    """several conv1d_fwd launches in one C call (`calls`: keyword dicts of conv1d_fwd with keys x, weight, bias, silu,
+    channel_last, time_order, nslices, out): the three directions of a Mamba v3 layer run as one grid -> list of outputs"""
+    n = len(calls)
+    arr = (L.Conv1dArgs * n)()
+    outs = []
+    for i, c in enumerate(calls):
+        x = c["x"]
+        _fill_conv_args(arr[i], x, c["weight"], c.get("bias"), c.get("silu", False), c.get("channel_last", False),
+                        c.get("time_order", L.TIME_FORWARD), c.get("nslices", 1))
+        out = c.get("out")
+        out = torch.empty_like(x, memory_format=torch.contiguous_format) if out is None else out
+        _check_seq("out", out, x, x.dtype)
+        arr[i].out = L.seq_view(out, c.get("channel_last", False))
+        outs.append(out)
+    lib.check(lib.dll.segm_causal_conv1d_fwd_multi(arr, n), "causal_conv1d_fwd_multi")
+    return outs
+
+
+def conv1d_bwd_multi(lib: L.SegmLib, calls):
+    """the backward counterpart: keyword dicts of conv1d_bwd (x, weight, bias, dout, silu, channel_last, time_order, nslices, dx)
+    -> list of (dx, dweight, dbias)"""
+    n = len(calls)
+    arr = (L.Conv1dArgs * n)()
+    res, keep = [], []
+    for i, c in enumerate(calls):
+        r = _conv1d_bwd_prepare(lib, arr[i], c["x"], c["weight"], c.get("bias"), c["dout"], c.get("silu", False),
+                                channel_last=c.get("channel_last", False), time_order=c.get("time_order", L.TIME_FORWARD),
+                                nslices=c.get("nslices", 1), dx=c.get("dx"))
+        res.append(r[:3])
+        keep.append(r[3])
+    lib.check(lib.dll.segm_causal_conv1d_bwd_multi(arr, n), "causal_conv1d_bwd_multi")
+    return res
+
+
 def conv1d_bwd(lib: L.SegmLib, x, weight, bias, dout, silu=False, *, channel_last=False,
                time_order=L.TIME_FORWARD, nslices=1, dx=None):
     """-> (dx, dweight fp32 (dim, width), dbias fp32 (dim) or None)"""
     a = L.Conv1dArgs()
+    dx, dweight, dbias, _ws = _conv1d_bwd_prepare(lib, a, x, weight, bias, dout, silu, channel_last=channel_last,
+                                                  time_order=time_order, nslices=nslices, dx=dx)
+    lib.check(lib.dll.segm_causal_conv1d_bwd(a), "causal_conv1d_bwd")
+    return dx, dweight, dbias
+
+
+def _conv1d_bwd_prepare(lib, a, x, weight, bias, dout, silu=False, *, channel_last=False, time_order=L.TIME_FORWARD, nslices=1,
+                        dx=None):
     batch, seqlen, dim, width = _fill_conv_args(a, x, weight, bias, silu, channel_last, time_order, nslices)
     _check_seq("dout", dout, x, x.dtype)
     dx = torch.empty_like(x, memory_format=torch.contiguous_format) if dx is None else dx
@@ -278,8 +321,7 @@ def conv1d_bwd(lib: L.SegmLib, x, weight, bias, dout, silu=False, *, channel_las
     a.dout, a.dx = L.seq_view(dout, channel_last), L.seq_view(dx, channel_last)
     a.dweight, a.dbias = dweight.data_ptr(), L.fptr(dbias)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
-    lib.check(lib.dll.segm_causal_conv1d_bwd(a), "causal_conv1d_bwd")
-    return dx, dweight, dbias
+    return dx, dweight, dbias, ws
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -44,7 +44,10 @@ class ParamBank:
             offs.append(total)
             total += (p.numel() + 7) // 8 * 8                  # 16-byte aligned 16-bit views (MFMA operand loads)
         self.flat32 = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.flat16 = torch.zeros(total, dtype=dtype, device=dev)
+        # the 16-bit twin sits behind 8 zero elements (16 bytes: the views stay 16-byte aligned): index 0 of `flat16z` is the
+        # "zero" every padding element of a derived pack gathers (see `packed`)
+        self.flat16z = torch.zeros(total + 8, dtype=dtype, device=dev)
+        self.flat16 = self.flat16z[8:]
         self.views16: Dict[int, torch.Tensor] = {}
         self.offsets: Dict[int, int] = {}
         with torch.no_grad():
@@ -57,18 +60,51 @@ class ParamBank:
         self.params = params                                   # keeps the ids alive
         self.fresh = False
         self.flat_grad: Optional[torch.Tensor] = None
+        # derived packs (see `packed`): re-arranged copies of weights, all produced by ONE gather per step
+        self._iota: Optional[torch.Tensor] = None              # int32: position of every flat16 element inside flat16z
+        self._dkeys: Dict[tuple, tuple] = {}                   # key -> (offset, shape) inside _dbuf
+        self._dmaps: list = []                                 # per pack: int32 source indices (0 = the zero element)
+        self._dtotal = 0
+        self._dmap: Optional[torch.Tensor] = None              # the maps concatenated (rebuilt when a pack was registered)
+        self._dbuf: Optional[torch.Tensor] = None
+        self._dready = 0                                       # packs [0, _dready) of _dkeys were filled by the last refresh
 
     def attach_flat_grads(self) -> torch.Tensor:
         """`p.grad` of every parameter becomes a window of ONE flat fp32 buffer laid out like `flat32` (what DDP's
-        `gradient_as_bucket_view` does per bucket): autograd accumulates in place, so the addresses never change - a captured
-        step (trainer.GraphedStep) replays into them, a data-parallel run all-reduces the single buffer, and the optimizer
-        walks three flat arrays instead of 286 tensors.  Zero it (`flat_grad.zero_()`) where the loop set `p.grad = None`."""
+        `gradient_as_bucket_view` does per bucket): a data-parallel run all-reduces the single buffer and the optimizer walks
+        three flat arrays instead of 286 tensors.  Two ways to fill it per step: leave the windows attached and zero the buffer
+        (autograd then accumulates in place: one add launch per parameter), or `release_grads()` before the backward pass and
+        `gather_grads()` behind it (autograd assigns fresh tensors, ONE multi-tensor copy moves them: what the trainer does)."""
         if self.flat_grad is None:
             self.flat_grad = torch.zeros_like(self.flat32)
-        for p in self.params:
-            o = self.offsets[id(p)]
-            p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+            self.grad_windows = [self.flat_grad[self.offsets[id(p)]:self.offsets[id(p)] + p.numel()].view(p.shape)
+                                 for p in self.params]
+        for p, w in zip(self.params, self.grad_windows):
+            p.grad = w
         return self.flat_grad
+
+    def release_grads(self) -> None:
+        """`p.grad = None` for every parameter (reference trainer.py:445): the backward pass ASSIGNS its gradients"""
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self) -> None:
+        """the gradients the backward pass left on the parameters -> their windows of `flat_grad` by one multi-tensor copy
+        (a parameter without a gradient: zeros), and `p.grad` points at the windows again.  Replaces 286 in-place accumulation
+        launches plus the zero fill of the buffer (profiles/r03_step_v1_step_kernels.txt: 305 fp32 adds, 1.2 ms per step)."""
+        dst, src = [], []
+        with torch.no_grad():
+            for p, w in zip(self.params, self.grad_windows):
+                g = p.grad
+                if g is None:
+                    w.zero_()
+                elif g.data_ptr() != w.data_ptr():
+                    dst.append(w)
+                    src.append(g if g.dtype == torch.float32 else g.float())
+            if dst:
+                torch._foreach_copy_(dst, src)
+        for p, w in zip(self.params, self.grad_windows):
+            p.grad = w
 
     def grads_attached(self) -> bool:
         """every parameter's gradient still is its window of `flat_grad` (nobody set `p.grad = None` or swapped it)"""
@@ -88,7 +124,57 @@ class ParamBank:
     def refresh(self) -> None:
         with torch.no_grad():
             self.flat16.copy_(self.flat32)                     # every parameter, one launch
+            if self._dmaps:
+                if self._dmap is None or self._dmap.numel() != self._dtotal:
+                    self._dmap = torch.cat(self._dmaps)
+                    self._dbuf = torch.empty(self._dtotal, dtype=self.dtype, device=self.flat16.device)
+                torch.index_select(self.flat16z, 0, self._dmap, out=self._dbuf)      # every derived pack, one launch
+                self._dready = len(self._dmaps)
         self.fresh = True
+
+    # ---- derived packs ---------------------------------------------------------------------------------------------------------
+    def _window_offset(self, w: torch.Tensor) -> Optional[int]:
+        """element offset of `w` inside flat16 when it is a (possibly strided) window of it"""
+        if w.dtype != self.dtype or w.device != self.flat16.device:
+            return None
+        d = w.data_ptr() - self.flat16.data_ptr()
+        if d < 0 or d >= 2 * self.flat16.numel() or w.untyped_storage().data_ptr() != self.flat16z.untyped_storage().data_ptr():
+            return None
+        return d // 2
+
+    def derived(self, w: torch.Tensor, tag, fn):
+        """`fn(w)` for a window `w` of the step's 16-bit copies, where `fn` only RE-ARRANGES elements (slice, permute, flip,
+        transpose, reshape, zero padding, contiguous).  The first call evaluates `fn` directly and records WHERE every element
+        of the result comes from (by running `fn` on the window's element indices); from the next `refresh()` on the pack is a
+        view of one buffer that a single gather launch fills for all registered packs."""
+        off = self._window_offset(w)
+        if off is None or not self.fresh:
+            return fn(w)
+        key = (tag, off, tuple(w.shape), tuple(w.stride()))
+        hit = self._dkeys.get(key)
+        if hit is not None:
+            idx, o, shape = hit
+            if idx < self._dready:
+                n = 1
+                for d_ in shape:
+                    n *= d_
+                return self._dbuf[o:o + n].view(shape)
+            return fn(w)                                       # registered after the last refresh: direct once more
+        out = fn(w)
+        if self._iota is None:
+            self._iota = torch.arange(8, 8 + self.flat16.numel(), dtype=torch.int32, device=self.flat16.device)
+        m = fn(self._iota.as_strided(w.size(), w.stride(), off))
+        if m.dtype != torch.int32 or tuple(m.shape) != tuple(out.shape):
+            return out                                         # not a pure re-arrangement: stays a per-call computation
+        m = m.reshape(-1)
+        pad = (-m.numel()) % 8                                 # 16-byte aligned packs (MFMA operand loads)
+        if pad:
+            m = torch.cat([m, m.new_zeros(pad)])
+        self._dkeys[key] = (len(self._dmaps), self._dtotal, tuple(out.shape))
+        self._dmaps.append(m)
+        self._dtotal += m.numel()
+        return out
+
 
     def lookup(self, w: torch.Tensor) -> Optional[torch.Tensor]:
         base = w._base if w._is_view() else w
@@ -114,6 +200,14 @@ class ParamBank:
         finally:
             _ACTIVE = prev
             self.fresh = False
+
+
+def packed(w: torch.Tensor, tag, fn):
+    """A re-arranged copy `fn(w)` of a weight (packed / padded / transposed layouts the kernels read): inside a bank step and for
+    a window of the bank's 16-bit copies it comes out of the bank's one-launch gather (`ParamBank.derived`), else `fn(w)`."""
+    if _ACTIVE is not None:
+        return _ACTIVE.derived(w, tag, fn)
+    return fn(w)
 
 
 def low_precision(p: Optional[torch.Tensor], dtype: torch.dtype) -> Optional[torch.Tensor]:

@@ -270,13 +270,13 @@ class MambaInnerCore(torch.autograd.Function):
         if rows_route:
             P, P8, R4 = R + 2 * N, x_dbl.shape[1], -(-R // 4) * 4
             # (bl, R) = ddelta2 @ dt_proj_weight (reference :273), written - with zero padding columns - before dB lands
-            ops_raw.linear_rows(lib, ddelta2, _pad_rows(delta_proj_weight.t(), R4), out=dx_dbl[:, :R4])
+            ops_raw.linear_rows(lib, ddelta2, _pk(delta_proj_weight, ("dt_proj_t_rows", R4), lambda t: _pad_rows(t.t(), R4)), out=dx_dbl[:, :R4])
             dx_dbl[:, R:R + N] = dB2
             dx_dbl[:, R + N:P] = dC2
             if P8 > P:
                 dx_dbl[:, P:] = 0
             dx_proj_weight = tn_matmul(dx_dbl[:, :P], conv2)                    # (R+2N, d) reference :275
-            wx_t = _pad_rows(x_proj_weight, P8).t().contiguous()                # (d, P8)
+            wx_t = _pk(x_proj_weight, ("x_proj_t", P8), lambda t: _pad_rows(t, P8).t().contiguous())       # (d, P8)
             dconv2 = ops_raw.linear_rows(lib, dx_dbl, wx_t, out=dconv2, accumulate=True)        # reference :276
         else:
             dx_dbl[:, R:R + N] = dB2
@@ -317,7 +317,10 @@ class MambaInnerCore3(torch.autograd.Function):
         lib = L.get_lib()
         assert len(params) == 21
         sets = [params[7 * i:7 * i + 7] for i in range(3)]
-        act_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None
+        # 16-bit activations with fp32 master weights (autocast, or a caller that feeds 16-bit tokens): the projections take the
+        # step's 16-bit copies of the masters (param_bank.low_precision), their gradients go back in fp32
+        act_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else (
+            xz.dtype if xz.dtype in (torch.bfloat16, torch.float16) else None)
         if xz.stride(2) != 1:
             xz = xz.contiguous()
         batch, seqlen, dim2 = xz.shape
@@ -325,15 +328,17 @@ class MambaInnerCore3(torch.autograd.Function):
         x, z = xz.split(dim, dim=2)
         keep = train and not _RECOMPUTE
         calls, per_dir = [], []
+        conv_outs = ops_raw.conv1d_fwd_multi(lib, [
+            dict(x=x, weight=st[0].reshape(dim, -1).float().contiguous(), bias=st[1].float().contiguous() if st[1] is not None else None,
+                 silu=True, channel_last=True, time_order=MambaInnerCore3.ORDERS[i],
+                 nslices=nslices if MambaInnerCore3.ORDERS[i] == L.TIME_INTERLEAVED else 1) for i, st in enumerate(sets)])
         for i, (conv_w, conv_b, xw, dtw, A, D, dbias) in enumerate(sets):
-            if act_dtype is not None:
+            if act_dtype is not None and xw.dtype != act_dtype:
                 from .param_bank import low_precision
                 xw, dtw = low_precision(xw, act_dtype), low_precision(dtw, act_dtype)
             R, N = dtw.shape[1], A.shape[-1]
             ns = nslices if MambaInnerCore3.ORDERS[i] == L.TIME_INTERLEAVED else 1
-            w32 = conv_w.reshape(dim, -1).float().contiguous()
-            cb32 = conv_b.float().contiguous() if conv_b is not None else None
-            conv_out = ops_raw.conv1d_fwd(lib, x, w32, cb32, True, channel_last=True, time_order=MambaInnerCore3.ORDERS[i], nslices=ns)
+            conv_out = conv_outs[i]
             if _rows_route(conv_out, True):
                 x_dbl, delta, Bv, Cv = _project_rows(conv_out, xw, dtw, R, N)
             else:
@@ -391,7 +396,7 @@ class MambaInnerCore3(torch.autograd.Function):
                               delta_softplus=True, channel_last=True, time_order=order, nslices=ns, chunk=chunks[i], dz=dz))
             dirs.append((conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, conv_out, R, N, order, ns, w32, cb32, rows_route, dxz, dx))
         gs = ops_raw.scan_bwd_multi(lib, calls)
-        grads, dxz_sum = [], None
+        grads, dxz_sum, ccalls, part = [], None, [], []
         for i, ((conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, conv_out, R, N, order, ns, w32, cb32, rows_route, dxz, dx), g) in enumerate(zip(dirs, gs)):
             dconv2 = g["du"].reshape(batch * seqlen, dim)
             ddelta2 = g["ddelta"].reshape(batch * seqlen, dim)
@@ -401,13 +406,13 @@ class MambaInnerCore3(torch.autograd.Function):
             ddelta_proj_weight = tn_matmul(ddelta2, x_dbl[:, :R])
             if rows_route:
                 P, P8, R4 = R + 2 * N, x_dbl.shape[1], -(-R // 4) * 4
-                ops_raw.linear_rows(lib, ddelta2, _pad_rows(dtw.t(), R4), out=dx_dbl[:, :R4])
+                ops_raw.linear_rows(lib, ddelta2, _pk(dtw, ("dt_proj_t_rows", R4), lambda t: _pad_rows(t.t(), R4)), out=dx_dbl[:, :R4])
                 dx_dbl[:, R:R + N] = dB2
                 dx_dbl[:, R + N:P] = dC2
                 if P8 > P:
                     dx_dbl[:, P:] = 0
                 dx_proj_weight = tn_matmul(dx_dbl[:, :P], conv2)
-                wx_t = _pad_rows(xw, P8).t().contiguous()
+                wx_t = _pk(xw, ("x_proj_t", P8), lambda t: _pad_rows(t, P8).t().contiguous())
                 dconv2 = ops_raw.linear_rows(lib, dx_dbl, wx_t, out=dconv2, accumulate=True)
             else:
                 dx_dbl[:, R:R + N] = dB2
@@ -415,8 +420,13 @@ class MambaInnerCore3(torch.autograd.Function):
                 dx_dbl[:, :R] = ddelta2 @ dtw
                 dx_proj_weight = tn_matmul(dx_dbl, conv2)
                 dconv2 = torch.addmm(dconv2, dx_dbl, xw)
-            _, dconv_w, dconv_b = ops_raw.conv1d_bwd(lib, x, w32, cb32, dconv2.reshape(batch, seqlen, dim), True, channel_last=True,
-                                                     time_order=order, nslices=ns, dx=dx)
+            ccalls.append(dict(x=x, weight=w32, bias=cb32, dout=dconv2.reshape(batch, seqlen, dim), silu=True, channel_last=True,
+                               time_order=order, nslices=ns, dx=dx))
+            part.append((dx_proj_weight, ddelta_proj_weight))
+        cres = ops_raw.conv1d_bwd_multi(lib, ccalls)
+        for i, ((conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, conv_out, R, N, order, ns, w32, cb32, rows_route, dxz, dx), g) in enumerate(zip(dirs, gs)):
+            _, dconv_w, dconv_b = cres[i]
+            dx_proj_weight, ddelta_proj_weight = part[i]
             dxz_sum = dxz if dxz_sum is None else dxz_sum.add_(dxz)
             grads += [dconv_w.reshape(conv_w.shape).to(conv_w.dtype), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
                       dx_proj_weight.to(wdt[i][0]), ddelta_proj_weight.to(wdt[i][1]), g["dA"].to(A.dtype),
@@ -447,6 +457,20 @@ def _rows_route(conv_out, channel_last) -> bool:
                 and conv_out.shape[2] <= 192 and conv_out.is_contiguous())
 
 
+def _pk(w, tag, fn):
+    from .param_bank import packed
+    return packed(w, tag, fn)
+
+
+def _pad_cols(w, cols):
+    """w (r, c) -> (r, cols) with zero columns appended"""
+    if w.shape[1] == cols:
+        return w.contiguous()
+    out = w.new_zeros(w.shape[0], cols)
+    out[:, :w.shape[1]] = w
+    return out
+
+
 def _pad_rows(w, rows):
     """w (r, c) -> (rows, c) with zero rows appended"""
     if w.shape[0] == rows:
@@ -465,9 +489,9 @@ def _project_rows(conv_out, x_proj_weight, delta_proj_weight, R, N, x_dbl=None):
     P = R + 2 * N
     P8, R8 = -(-P // 8) * 8, -(-R // 8) * 8
     if x_dbl is None:
-        x_dbl = ops_raw.linear_rows(lib, conv_out.reshape(batch * seqlen, dim), _pad_rows(x_proj_weight, P8))
-    wdt = delta_proj_weight.new_zeros(dim, R8)
-    wdt[:, :R] = delta_proj_weight
+        x_dbl = ops_raw.linear_rows(lib, conv_out.reshape(batch * seqlen, dim),
+                                    _pk(x_proj_weight, ("x_proj_rows", P8), lambda t: _pad_rows(t, P8)))
+    wdt = _pk(delta_proj_weight, ("dt_proj_cols", R8), lambda t: _pad_cols(t, R8))
     delta = ops_raw.linear_rows(lib, x_dbl[:, :R8], wdt).reshape(batch, seqlen, dim)
     v3 = x_dbl.view(batch, seqlen, P8)
     return x_dbl, delta, v3[:, :, R:R + N], v3[:, :, R + N:P]

@@ -164,11 +164,12 @@ def forward_backward(st: TrainingState, image: torch.Tensor, label: torch.Tensor
     autocast forward, loss, backward.  With `st.world` ranks the loss is scaled by 1 / world before the backward pass so that
     the SUM all-reduce in finish_step() leaves the mean gradient (what DDP's bucket division does)."""
     with st.bank.step():
-        st.bank.flat_grad.zero_()                                  # trainer.py:445 sets every p.grad to None
+        st.bank.release_grads()                                    # trainer.py:445 sets every p.grad to None
         with torch.autocast(image.device.type, dtype=st.autocast_dtype, enabled=image.device.type == "cuda"):
             pred = st.model(image)
             loss = st.loss_fn(pred, label)                         # 3_train.py:62
         (loss / st.world if st.world > 1 else loss).backward()
+        st.bank.gather_grads()                                     # the fresh gradient tensors -> the flat array, one launch
     return loss.detach()
 
 

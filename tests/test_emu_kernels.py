@@ -293,7 +293,7 @@ def test_unet_res_block_on_padded_volumes_emulated(emu, monkeypatch):
     from segmamba_amd import lib as L, unet_blocks as UB, conv3d as C3
     monkeypatch.setattr(L, "get_lib", lambda: emu)
     monkeypatch.setattr(L, "on_device", lambda t: True)
-    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())     # the library's candidates (forward, dgrad, wgrad)
+    monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest: cands[-1]())     # the library's candidates (forward, dgrad, wgrad)
     torch.manual_seed(3)
     blk = UB.UnetResBlock(96, 48).bfloat16()
     g = torch.Generator().manual_seed(9)
@@ -319,7 +319,7 @@ def test_first_layer_takes_the_thin_input_kernels_emulated(emu, monkeypatch):
     from segmamba_amd import lib as L, unet_blocks as UB, conv3d as C3, fused_norm as FN
     monkeypatch.setattr(L, "get_lib", lambda: emu)
     monkeypatch.setattr(L, "on_device", lambda t: True)
-    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
+    monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest: cands[-1]())
     torch.manual_seed(5)
     blk = UB.UnetResBlock(4, 48)
     g = torch.Generator().manual_seed(6)
@@ -378,10 +378,15 @@ def test_transpose_add_emulated(emu, shape, dtype, with_add):
     (96, 64, 32, True, L.TIME_FORWARD, 1, torch.bfloat16),         # SegMamba stage-0 width
 ])
 def test_scan_regular_shape_kernels_emulated(emu, monkeypatch, dim, seqlen, chunk, channel_last, order, ns, dtype):
-    """scan_fwd_fast.hip (uniform addressing, packed fp32) against the oracle AND against the general kernels."""
+    """scan_fwd_fast.hip / scan_bwd_fast.hip / scan_bwd_pair.hip (uniform addressing) against the oracle AND against the general
+    kernels; the backward with both main kernels (SEGM_BWD_MAIN=r2: packed state pairs, the default; r3: LDS-tile prefetch)."""
     c = H.scan_case(1, dim, 16, seqlen, dtype=dtype, seed=dim + seqlen)
     ref = H.scan_oracle(c, order, ns)
     monkeypatch.delenv("SEGM_SCAN_FAST", raising=False)
+    monkeypatch.setenv("SEGM_BWD_MAIN", "r3")
+    fast = H.run_scan(emu, c, "cpu", channel_last, order, ns, chunk=chunk)
+    H.check_scan(fast, ref, dtype, f"emu fast (r3 main) D={dim} L={seqlen}")
+    monkeypatch.setenv("SEGM_BWD_MAIN", "r2")
     fast = H.run_scan(emu, c, "cpu", channel_last, order, ns, chunk=chunk)
     H.check_scan(fast, ref, dtype, f"emu fast D={dim} L={seqlen}")
     monkeypatch.setenv("SEGM_SCAN_FAST", "0")
@@ -874,7 +879,7 @@ def test_conv_same_autograd_with_every_library_candidate_on_emulated_kernels(emu
     want = torch.autograd.grad(torch.nn.functional.conv3d(x2, w2, b2, 1, 1), (x2, w2, b2), dy.float())
     y_want = torch.nn.functional.conv3d(x2, w2, b2, 1, 1).detach()
     for idx in (-1, -2, -3, -4):                           # chain32, chained + unpadded rows, chained, reduce-per-row
-        monkeypatch.setattr(C3, "_pick", lambda key, cands, idx=idx: cands[max(idx, -len(cands))]())
+        monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest, idx=idx: cands[max(idx, -len(cands))]())
         y = C3._ConvSame.apply(x, w, bias)
         got = torch.autograd.grad(y, (x, w, bias), dy)
         for a, b in zip((y,) + got, (y_want,) + want):
@@ -910,7 +915,7 @@ def test_segmamba_bf16_forward_with_library_convolutions_on_emulated_kernels(emu
     monkeypatch.setattr(L, "on_device", lambda t: True)
     monkeypatch.setenv("SEGM_CONV_FWD_UNTIMED", "1")
     routed = []
-    monkeypatch.setattr(C3, "_pick", lambda key, cands: (routed.append(len(cands)), cands[-1]())[1])
+    monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest: (routed.append(len(cands)), cands[-1]())[1])
     from model_segmamba.segmamba import SegMamba
     from tests.golden.make_golden import named_fill
     f = H.load_golden("segmamba_tiny.npz")
@@ -1183,7 +1188,7 @@ def test_concatenated_input_convolution_is_one_node_with_in_place_parts(emu, mon
     from segmamba_amd import lib as L, conv3d as C3
     monkeypatch.setattr(L, "get_lib", lambda: emu)
     monkeypatch.setattr(L, "on_device", lambda t: True)
-    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
+    monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest: cands[-1]())
     monkeypatch.setattr(C3, "_CAT_FUSED", True)
     g = torch.Generator().manual_seed(8)
     a = torch.randn(1, 48, 2, 3, 64, generator=g).bfloat16().requires_grad_()
@@ -1253,7 +1258,7 @@ def test_decoder_block_with_fused_concatenation_emulated(emu, monkeypatch):
     from segmamba_amd import lib as L, unet_blocks as UB, conv3d as C3, linear as LN
     monkeypatch.setattr(L, "get_lib", lambda: emu)
     monkeypatch.setattr(L, "on_device", lambda t: True)
-    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
+    monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest: cands[-1]())
     monkeypatch.setattr(C3, "_tuned_variant", lambda key, cands, variants: variants[-1])
     monkeypatch.setattr(LN, "_PW_MIN", 64)
     torch.manual_seed(3)
@@ -1292,7 +1297,7 @@ def test_every_routing_candidate_of_the_conv_dispatcher_runs_and_agrees(emu, mon
     monkeypatch.setattr(L, "on_device", lambda t: True)
     seen = {}
 
-    def run_all(key, cands):
+    def run_all(key, cands, *rest):
         outs = [c() for c in cands]
         seen[key[0]] = len(cands)
         for o in outs[1:]:

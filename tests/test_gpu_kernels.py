@@ -296,7 +296,7 @@ def test_conv3d_same_autograd_with_mfma_wgrad(hip, monkeypatch):
     dy = torch.randn(1, 48, 8, 16, 32, device=DEV, generator=g).bfloat16()
     # the last candidates: the chained forward kernel (forward / data gradient) and the MFMA weight-gradient kernel
     # (the two untimed forward variants are candidates only with SEGM_CONV_FWD_UNTIMED=1: tests/test_zz_gpu_unmeasured.py)
-    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
+    monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest: cands[-1]())
     y = C3.conv3d_same(x, w)
     gx, gw = torch.autograd.grad(y, (x, w), dy)
     x2, w2 = x.detach().float().requires_grad_(), w.detach().float().requires_grad_()
@@ -444,7 +444,7 @@ def test_conv3d_same_autograd_with_library_kernels(hip, monkeypatch):
     dy = torch.randn(2, 48, 8, 16, 32, device=DEV, generator=g).bfloat16()
     # the last candidates: the chained forward kernel (forward / data gradient) and the MFMA weight-gradient kernel
     # (the two untimed forward variants are candidates only with SEGM_CONV_FWD_UNTIMED=1: tests/test_zz_gpu_unmeasured.py)
-    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[-1]())
+    monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest: cands[-1]())
     y = C3.conv3d_same(x, w, bias)
     gx, gw, gb = torch.autograd.grad(y, (x, w, bias), dy)
     x2, w2, b2 = (t.detach().float().requires_grad_() for t in (x, w, bias))

@@ -214,3 +214,63 @@ def test_functions_take_fp32_masters_and_return_fp32_gradients():
         # (a short contraction like this one is a single 16-bit GEMM; the split-K route of tall operands keeps fp32 partial sums)
         assert (lin.weight.grad - ref_w.grad).abs().max() <= 1e-2 * float(ref_w.grad.abs().max())
         assert (lin.bias.grad - ref_b.grad).abs().max() <= 1e-4 * float(ref_b.grad.abs().max())     # fp32 reduction
+
+
+def test_derived_weight_packs_come_from_one_gather_and_change_nothing(monkeypatch):
+    """param_bank.packed / ParamBank.derived: the packed / padded / transposed weight layouts the kernels read (3x3x3 register
+    layout forward and flipped-transposed for the data gradient, padded projection weights of the Mamba block, transposed linear
+    weights) are registered on first use and from the second step on are views of ONE buffer filled by ONE index_select per
+    step.  Three training steps of the real network on the emulated kernels must give bit-identical parameters with the
+    mechanism on and off, the packs must live in the gather buffer from step 2, and nothing new may be registered after step 1
+    (a captured graph replays the step-2 launch sequence)."""
+    from tests import emu_util
+    import pytest
+    if not emu_util.emu_available():
+        pytest.skip("no host clang for the emulation build")
+    from segmamba_amd import conv3d as C3, lib as L, param_bank
+    from segmamba_amd.mamba_simple import Mamba
+    from segmamba_amd.unet_blocks import UnetResBlock
+    monkeypatch.setattr(L, "_lib", emu_util.emu_lib())
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest: cands[-1]())      # the library's kernels wherever they apply
+    from segmamba_amd import linear as LN
+    monkeypatch.setattr(LN, "_ROWS_MIN", 1)                                      # ... also for 128 rows of tokens
+    monkeypatch.setattr(LN, "_ROWS_HIP", True)
+
+    class Tiny(nn.Module):                                   # one 48-channel residual block + one Mamba(v3) layer
+        def __init__(self):
+            super().__init__()
+            self.block = UnetResBlock(48, 48)
+            self.mamba = Mamba(d_model=48, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=8)
+
+        def forward(self, v):
+            y = self.block(v)                                # (1, 48, 2, 4, 16)
+            t = y.flatten(2).transpose(1, 2)                 # (1, 128, 48) tokens
+            return self.mamba(t)
+
+    g = torch.Generator().manual_seed(3)
+    vol = torch.randn(1, 48, 2, 4, 16, generator=g).bfloat16()     # 16-bit activations against fp32 masters: what autocast produces
+
+    def run(enabled):
+        torch.manual_seed(0)
+        st = build_training_state(torch.device("cpu"), model=Tiny())
+        if not enabled:
+            monkeypatch.setattr(param_bank, "packed", lambda w, tag, fn: fn(w))
+            monkeypatch.setattr(param_bank.ParamBank, "derived", lambda self, w, tag, fn: fn(w))
+        counts = []
+        for _ in range(3):
+            with st.bank.step():
+                st.bank.release_grads()
+                st.model(vol).float().pow(2).mean().backward()
+                st.bank.gather_grads()
+            st.optimizer.step()
+            counts.append(len(st.bank._dmaps))
+        return st, counts
+
+    on, counts = run(True)
+    assert counts[0] >= 15 and counts[0] == counts[1] == counts[2], counts       # everything registered in step 1
+    assert on.bank._dbuf is not None and on.bank._dready == counts[0]
+    off, counts_off = run(False)
+    assert counts_off == [0, 0, 0]
+    for a, b in zip(on.model.parameters(), off.model.parameters()):
+        assert torch.equal(a, b)

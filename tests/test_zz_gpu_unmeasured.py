@@ -48,7 +48,7 @@ def test_conv3d_same_autograd_with_newer_library_candidates(hip, monkeypatch, id
     w = (0.05 * torch.randn(48, 48, 3, 3, 3, device=DEV, generator=g)).bfloat16().requires_grad_()
     bias = torch.randn(48, device=DEV, generator=g).bfloat16().requires_grad_()
     dy = torch.randn(2, 48, 8, 16, 32, device=DEV, generator=g).bfloat16()
-    monkeypatch.setattr(C3, "_pick", lambda key, cands: cands[idx if key[0] != "wgrad" else -1]())
+    monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest: cands[idx if key[0] != "wgrad" else -1]())
     y = C3.conv3d_same(x, w, bias)
     gx, gw, gb = torch.autograd.grad(y, (x, w, bias), dy)
     x2, w2, b2 = (t.detach().float().requires_grad_() for t in (x, w, bias))

@@ -2,7 +2,7 @@
 # rocprofv3 kernel trace of two training steps; prints the per-kernel totals per step grouped by owner (own kernels / BLAS /
 # MIOpen / ATen) and writes the table to gpurun_out/<tag>_step_kernels.txt:   tools/gpu_step_profile.sh <tag>
 TAG=${1:-step}; mkdir -p gpurun_out/prof; R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof/$TAG -o bench -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/prof/$TAG.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof/$TAG -o bench -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline --no-configs --no-graph > $R/gpurun_out/prof/$TAG.log 2>&1
 echo "rc=$?"; tail -1 $R/gpurun_out/prof/$TAG.log | cut -c1-200
 python3 - $R/gpurun_out/prof/$TAG $R/gpurun_out/${TAG}_step_kernels.txt <<'PY'
 import csv, glob, sys, collections
