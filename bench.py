@@ -138,8 +138,23 @@ def scan_roofline(dtype, device):
                                 chunk=f["chunk"])
     ms_f = time_gpu(fwd, 20)
     ms_b = time_gpu(bwd, 10)
+    # what the training step launches: the three directions of a Mamba v3 layer (as stored / reversed / slice-interleaved, nslices
+    # 64 at this stage) as ONE grid with a direction axis (segm_selective_scan_{fwd,bwd}_multi) on three sets of tensors
+    orders = [(L.TIME_FORWARD, 1), (L.TIME_REVERSED, 1), (L.TIME_INTERLEAVED, 64)]
+    sets = [dict(u=u, delta=delta, A=A, B=Bm, C=Cm, D=Dv, z=z, delta_bias=db)] + [
+        dict(u=rn(B, Lq, D), delta=(0.5 * torch.rand(B, Lq, D, device=device, generator=g)).to(dtype), A=A.clone(), B=rn(B, Lq, N),
+             C=rn(B, Lq, N), D=Dv.clone(), z=rn(B, Lq, D), delta_bias=db.clone()) for _ in range(2)]
+    fcalls = [dict(s_, delta_softplus=True, channel_last=True, time_order=o, nslices=ns, need_out=True, need_ckpt=True)
+              for s_, (o, ns) in zip(sets, orders)]
+    f3 = ops_raw.scan_fwd_multi(hip, fcalls)
+    bcalls = [dict(s_, dout=dout, out=r["out"], ckpt=r["ckpt"], delta_softplus=True, channel_last=True, time_order=o, nslices=ns,
+                   chunk=r["chunk"]) for s_, (o, ns), r in zip(sets, orders, f3)]
+    ms_f3 = time_gpu(lambda: ops_raw.scan_fwd_multi(hip, fcalls), 10)
+    ms_b3 = time_gpu(lambda: ops_raw.scan_bwd_multi(hip, bcalls), 5)
+    del sets, fcalls, bcalls, f3
     bytes_f = algorithmic_bytes_scan(B, D, Lq, N, es)
     bytes_b = algorithmic_bytes_scan(B, D, Lq, N, es, backward=True)
+    gf3, gb3 = 3 * bytes_f / ms_f3 * 1e-6, 3 * bytes_b / ms_b3 * 1e-6
     gf, gb = bytes_f / ms_f * 1e-6, bytes_b / ms_b * 1e-6
     tr = scan_traffic({torch.bfloat16: "bf16", torch.float32: "fp32", torch.float16: "fp16"}[dtype])
     # The kernels are bound by VALU issue, not by HBM (profiles/r02_scan_proto_notes.md): one v_exp_f32 per
@@ -164,6 +179,11 @@ def scan_roofline(dtype, device):
                 "vs 8 TB/s); valu.frac prices the same launch against the measured VALU issue ceiling",
         "backward": {"achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4), "ms": round(ms_b, 4),
                      "algorithmic_bytes": bytes_b},
+        "three_directions_per_launch": {
+            "what": "the launch the training step issues: forward / reversed / slice-interleaved scans of one layer as one grid",
+            "fwd_ms": round(ms_f3, 4), "fwd_achieved": round(gf3, 1), "fwd_frac": round(gf3 / HBM_PEAK_GBPS, 4),
+            "bwd_ms": round(ms_b3, 4), "bwd_achieved": round(gb3, 1), "bwd_frac": round(gb3 / HBM_PEAK_GBPS, 4),
+            "algorithmic_bytes": {"fwd": 3 * bytes_f, "bwd": 3 * bytes_b}},
     }
 
 

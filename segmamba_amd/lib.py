@@ -242,8 +242,15 @@ EXPORTS = (
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
     "segm_causal_conv1d_update", "segm_selective_state_update", "segm_linear_rows", "segm_pointwise_cf", "segm_stem_conv_fwd",
     "segm_stem_conv_wgrad", "segm_stem_conv_wgrad_workspace_bytes", "segm_stem_conv_wgrad_workspace_bytes2", "segm_wgrad_gemm", "segm_wgrad_gemm_workspace_bytes",
+    "segm_skinny_tn", "segm_skinny_tn_workspace_bytes",
     "segm_abi_version", "segm_status_string",
 )
+
+
+class SkinnyTnArgs(C.Structure):
+    _fields_ = [("k", C.c_int64), ("m", C.c_int32), ("n", C.c_int32), ("dtype", C.c_int32), ("reserved", C.c_int32),
+                ("wide", C.c_void_p), ("wide_stride_row", C.c_int64), ("skinny", C.c_void_p), ("skinny_stride_row", C.c_int64),
+                ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p)]
 
 
 class SegmLib:
@@ -297,6 +304,8 @@ class SegmLib:
         sig("segm_stem_conv_wgrad_workspace_bytes2", [C.c_int32] * 6, C.c_size_t)
         sig("segm_wgrad_gemm", [C.POINTER(WgradGemmArgs)], C.c_int)
         sig("segm_wgrad_gemm_workspace_bytes", [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32], C.c_size_t)
+        sig("segm_skinny_tn", [C.POINTER(SkinnyTnArgs)], C.c_int)
+        sig("segm_skinny_tn_workspace_bytes", [C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
         sig("segm_abi_version", [], C.c_int)
         sig("segm_status_string", [C.c_int], C.c_char_p)
 

@@ -64,10 +64,17 @@ def _split(K: int) -> int:
     return s if K // max(s, 1) <= 4 * _SLAB else 1
 
 
+_SKINNY = os.environ.get("SEGM_SKINNY_TN", "1") == "1"
+
+
 def tn_matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a^T b for tall operands a (K, M), b (K, N), K >> M, N; fp32 result.  Row slices / column slices of larger
     matrices are fine (only views are taken)."""
     K = a.shape[0]
+    if _SKINNY and K >= 4096 and _on_device(a) and b.shape[1] <= 32 < a.shape[1]:
+        from . import lib as L, ops_raw
+        if ops_raw.skinny_tn_supported(a, b):               # a tall-and-wide, b tall-and-skinny (dt_proj's weight gradient)
+            return ops_raw.skinny_tn(L.get_lib(), a, b)
     if _WG_HIP and _WG_TN and K >= _MIN_K and _on_device(a):
         from . import lib as L, ops_raw
         if ops_raw.wgrad_gemm_tn_supported(a, b):

@@ -772,6 +772,31 @@ def linear_rows(lib: L.SegmLib, x2: torch.Tensor, w: torch.Tensor, bias: Optiona
     return y
 
 
+def skinny_tn_supported(wide: torch.Tensor, skinny: torch.Tensor) -> bool:
+    return bool(wide.dim() == 2 and skinny.dim() == 2 and wide.shape[0] == skinny.shape[0] and skinny.shape[1] <= 32 and
+                wide.dtype in (torch.bfloat16, torch.float16) and skinny.dtype == wide.dtype and wide.stride(1) == 1 and
+                skinny.stride(1) == 1 and wide.shape[0] > 0)
+
+
+def skinny_tn(lib: L.SegmLib, wide: torch.Tensor, skinny: torch.Tensor) -> torch.Tensor:
+    """wide (k, m)^T @ skinny (k, n <= 32) -> (m, n) fp32: the dt_proj weight gradient as a streaming reduction"""
+    if not skinny_tn_supported(wide, skinny):
+        raise RuntimeError("skinny_tn: wide (k, m), skinny (k, n <= 32), one 16-bit dtype, unit column strides")
+    K, M = wide.shape
+    N = skinny.shape[1]
+    out = torch.empty(M, N, dtype=torch.float32, device=wide.device)
+    ws_bytes = lib.dll.segm_skinny_tn_workspace_bytes(M, N, K)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=wide.device)
+    a = L.SkinnyTnArgs()
+    a.k, a.m, a.n, a.dtype = K, M, N, L.dtype_code(wide)
+    a.wide, a.wide_stride_row = wide.data_ptr(), wide.stride(0)
+    a.skinny, a.skinny_stride_row = skinny.data_ptr(), skinny.stride(0)
+    a.out, a.workspace, a.workspace_bytes = out.data_ptr(), ws.data_ptr(), ws_bytes
+    a.stream = L.stream_handle(wide)
+    lib.check(lib.dll.segm_skinny_tn(a), "skinny_tn")
+    return out
+
+
 def pointwise_cf_supported(x3: torch.Tensor, cout: int) -> bool:
     """x3 (B, Cin <= 96, S) 16-bit with contiguous voxels, S % 64 == 0, 16-byte aligned channel rows; Cout <= 96"""
     return bool(x3.dim() == 3 and x3.dtype in (torch.bfloat16, torch.float16) and x3.shape[1] <= 96 and cout <= 96
@@ -978,5 +1003,5 @@ def _device_guard(fn):
 
 for _name in ("scan_fwd", "scan_bwd", "conv1d_fwd", "conv1d_bwd", "conv3d_k3_wgrad", "conv3d_k3_fwd", "instnorm_fwd",
               "instnorm_bwd", "transpose_add", "layernorm_tokens_fwd", "layernorm_tokens_bwd", "sgd_clip_step", "cross_entropy",
-              "conv1d_update", "state_update", "linear_rows", "pointwise_cf", "stem_conv_fwd", "stem_conv_wgrad", "wgrad_gemm"):
+              "conv1d_update", "state_update", "linear_rows", "skinny_tn", "pointwise_cf", "stem_conv_fwd", "stem_conv_wgrad", "wgrad_gemm"):
     globals()[_name] = _device_guard(globals()[_name])

@@ -1201,7 +1201,7 @@ def test_concatenated_input_convolution_is_one_node_with_in_place_parts(emu, mon
     ref.backward(dy.float())
     outs = []
     for variant in (None,) + C3._HIP_VARIANTS:
-        monkeypatch.setattr(C3, "_tuned_variant", lambda key, cands, variants, v=variant: v)
+        monkeypatch.setattr(C3, "_tuned_variant", lambda key, cands, variants, *rest, v=variant: v)
         for t in (a, b, w):
             t.grad = None
         y = C3.conv3d_same_cat((a, b), w)
@@ -1259,7 +1259,7 @@ def test_decoder_block_with_fused_concatenation_emulated(emu, monkeypatch):
     monkeypatch.setattr(L, "get_lib", lambda: emu)
     monkeypatch.setattr(L, "on_device", lambda t: True)
     monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest: cands[-1]())
-    monkeypatch.setattr(C3, "_tuned_variant", lambda key, cands, variants: variants[-1])
+    monkeypatch.setattr(C3, "_tuned_variant", lambda key, cands, variants, *rest: variants[-1])
     monkeypatch.setattr(LN, "_PW_MIN", 64)
     torch.manual_seed(3)
     blk = UB.UnetResBlock(96, 48)
@@ -1314,3 +1314,17 @@ def test_every_routing_candidate_of_the_conv_dispatcher_runs_and_agrees(emu, mon
     y.backward(torch.randn(y.shape, generator=g).bfloat16())
     assert seen == {"fwd": 6, "dgrad": 7, "wgrad": 3}, seen       # vendor, blocked, four library variants (+ dgrad-as-forward)
     assert w.grad.dtype == torch.float32 and b.grad.dtype == torch.float32 and x.grad.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("K,M,N,dtype,lda,ldb", [(5000, 96, 3, torch.bfloat16, 96, 40), (4096 + 77, 192, 6, torch.bfloat16, 192, 6),
+                                                  (300, 70, 12, torch.float16, 80, 56), (9000, 384, 24, torch.bfloat16, 768, 64)])
+def test_skinny_tn_emulated(emu, K, M, N, dtype, lda, ldb):
+    """segm_skinny_tn: wide^T skinny (the dt_proj weight gradient, reference selective_scan_interface.py:272) against an fp32
+    matmul on the same rounded operands; views with row strides, a ragged last slab, a ragged channel tile"""
+    g = torch.Generator().manual_seed(K + M)
+    wide = torch.randn(K, lda, generator=g).to(dtype)[:, :M]
+    skinny = torch.randn(K, ldb, generator=g).to(dtype)[:, 2:2 + N] if ldb > N + 2 else torch.randn(K, ldb, generator=g).to(dtype)[:, :N]
+    out = ops_raw.skinny_tn(emu, wide, skinny)
+    ref = wide.float().t() @ skinny.float()
+    assert out.shape == (M, N) and out.dtype == torch.float32
+    assert (out - ref).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max()))

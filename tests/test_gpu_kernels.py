@@ -664,6 +664,24 @@ def test_wgrad_gemm_tn_matches_fp32_product(K, M, N, lda, ldb):
     assert torch.equal(out, ops_raw.wgrad_gemm(hip, a, b, ops_raw.WGEMM_TN))
 
 
+@pytest.mark.parametrize("K,M,N,lda,ldb,dtype", [(524288, 96, 3, 96, 40, torch.bfloat16), (65536, 192, 6, 192, 40, torch.bfloat16),
+                                                 (8192, 384, 12, 384, 48, torch.bfloat16), (4096, 768, 24, 768, 56, torch.bfloat16),
+                                                 (524288, 96, 3, 96, 35, torch.float16)])
+def test_skinny_tn_matches_fp64_product(K, M, N, lda, ldb, dtype):
+    """segm_skinny_tn at the four stages' dt_proj weight-gradient shapes (reference selective_scan_interface.py:272: ddelta^T x_dbl[:, :R])
+    against the fp64 product of the same operands; the skinny operand is a column window of the x_proj output; bitwise repeatable"""
+    hip = L.get_lib()
+    g = torch.Generator(device=DEV).manual_seed(K % 1000 + M)
+    a = torch.randn(K, lda, device=DEV, generator=g).to(dtype)[:, :M]
+    b = torch.randn(K, ldb, device=DEV, generator=g).to(dtype)[:, :N]
+    assert ops_raw.skinny_tn_supported(a, b)
+    out = ops_raw.skinny_tn(hip, a, b)
+    ref = (a.double().t() @ b.double()).float()
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    assert (out - ref).abs().max() <= 1e-3 * float(ref.abs().max())
+    assert torch.equal(out, ops_raw.skinny_tn(hip, a, b))
+
+
 @pytest.mark.parametrize("Bn,M,N,K", [(2, 48, 48, 128 ** 3), (2, 4, 48, 128 ** 3), (2, 96, 96, 64 ** 3)])
 def test_wgrad_gemm_nt_matches_fp32_product(Bn, M, N, K):
     """segm_wgrad_gemm (NT) on channel-first volumes of the BASELINE size (padded channel stride as the convolutions write them)"""
