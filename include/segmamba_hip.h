@@ -578,8 +578,8 @@ typedef struct segm_wgrad_gemm_args {
 
 size_t segm_wgrad_gemm_workspace_bytes(int32_t layout, int32_t m, int32_t n, int64_t k, int32_t batch);
 
-/* out (m, n) fp32 = wide^T skinny: wide (k, m) with unit column stride, skinny (k, n <= 32), both 16-bit, row strides in elements,
- * k = tokens.  The weight gradient of Mamba's dt_proj - `einsum("dB,Br->dr", ddelta, x_dbl[:, :R])`, reference
+/* out (m, n) fp32 = wide^T skinny: wide (k, m) with unit column stride, m % 8 == 0, m <= 2048, rows 16-byte aligned (base pointer and
+ * wide_stride_row % 8 == 0; otherwise SEGM_E_SHAPE); skinny (k, n <= 32); both 16-bit, row strides in elements, k = tokens.  The weight gradient of Mamba's dt_proj - `einsum("dB,Br->dr", ddelta, x_dbl[:, :R])`, reference
  * selective_scan_interface.py:272, R = 3 ... 24 - as the streaming reduction it is (the vendor GEMM spends a tile on three
  * columns).  Per-slab partial sums in the workspace, added in a fixed order.  out is OVERWRITTEN. */
 typedef struct segm_skinny_tn_args {

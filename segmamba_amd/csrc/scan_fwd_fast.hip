@@ -14,6 +14,8 @@
 //     the non-transcendental issue slots of a step:  per state pair  2 v_exp + 2 v_pk_mul + 1 (agg) or 2 (apply) v_pk_fma.
 // Results are bit-identical in structure to the general kernels (same operation order per state), so the backward pass
 // and the checkpoint format are unchanged.
+#include <stdlib.h>
+
 #include "scan_fast.h"
 
 namespace segm {
@@ -21,7 +23,9 @@ namespace segm {
 // ------------------------------------------------------------------------------------------------------
 // K1 (regular shapes): chunk aggregates.  grid.y = direction (up to kMaxDirs launches of identical geometry in one).
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int RW>
+// MODE: what the per-step flags are known to be at compile time (they are wave-uniform branches in every step otherwise):
+//   0 = read from the arguments,  1 = softplus + gate z + un-gated output kept (training),  2 = softplus + gate z (inference)
+template <typename T, int RW, int MODE>
 __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) {
     constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     __shared__ __attribute__((aligned(16))) float s_b[2][kWavesPerBlock][G][kFT * kFS];
@@ -31,7 +35,7 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
     if (!it.wave_valid) return;                           // the last workgroup may have spare waves (no workgroup barriers here)
     const int ub = uniform_batch(it);
-    const bool softplus_on = P.delta_softplus != 0;
+    const bool softplus_on = MODE != 0 || P.delta_softplus != 0;
     FastClock ck;
     ck.init(P.tm);
     const WaveRows wr = wave_rows(P.tm, gm, it);
@@ -47,10 +51,14 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
     const Stream dp = make_stream<T>(P.delta, ub, wr, it.d);
     const StageStream<RW> sb = make_stage<T, RW>(P.Bm, ub, wr, it.r);
 
+    // the B rows first: at the loop head they are then the oldest loads on both paths into it (vmcnt is in order, and the
+    // compiler merges the pending-load state of the prologue with that of the back edge - with the stage loads issued last here
+    // every sub-tile would begin with s_waitcnt vmcnt(0))
     float nu[kFT], nd[kFT], nb[EPL];
+    stage_fetch_buf<T, RW>(nb, sb, wr.bias + ck.U, wr.dT);
+    __builtin_amdgcn_sched_barrier(0);                    // keep that order
     stream_fetch<T>(nu, up, wr.bias + ck.U, wr.dT);
     stream_fetch<T>(nd, dp, wr.bias + ck.U, wr.dT);
-    stage_fetch_buf<T, RW>(nb, sb, wr.bias + ck.U, wr.dT);
 
     float sumd = 0.f;
     int buf = 0;
@@ -59,24 +67,31 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
         float* lb = &s_b[buf][wave][it.gi][0];
         stage_park_buf<RW>(nb, sb, lb);
         SEGM_WAVE_LDS_SYNC();
-        float cu[kFT], cd[kFT];
-#pragma unroll
-        for (int j = 0; j < kFT; ++j) { cu[j] = nu[j]; cd[j] = nd[j]; }
-        // prefetch the next sub-tile (after the last one: re-read this one, never past the chunk)
+        // the row streams are a ring of kFT registers each: step j's value is consumed and its register refilled with step j of
+        // the NEXT sub-tile in the same step (after the last sub-tile: re-read this one, never past the chunk)
         const int32_t Un = wr.bias + ((s + 1 < nsub) ? ck.next_U() : ck.U);
-        stream_fetch<T>(nu, up, Un, wr.dT);
-        stream_fetch<T>(nd, dp, Un, wr.dT);
         stage_fetch_buf<T, RW>(nb, sb, Un, wr.dT);
         ck.advance();
+        uint32_t su = (uint32_t)Un * (uint32_t)up.stb, sd = (uint32_t)Un * (uint32_t)dp.stb;
+        const uint32_t iu = (uint32_t)(wr.dT * up.stb), id = (uint32_t)(wr.dT * dp.stb);
         float4 bq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = reinterpret_cast<const float4*>(lb)[q];
 #pragma unroll
         for (int j = 0; j < kFT; ++j) {
-            float dl = cd[j] + bias;
+            const float uu = nu[j];
+            float dl = nd[j] + bias;
+            nu[j] = BufIO<T>::ld(up.rs, up.voff, su);
+            nd[j] = BufIO<T>::ld(dp.rs, dp.voff, sd);
+            su += iu;
+            sd += id;
             dl = softplus_on ? softplus20(dl) : dl;
-            const float dlu = dl * cu[j];
             sumd += dl;
+            // both halves written: a packed operand with op_sel broadcast reads the odd register of its pair too, and that register
+            // may be the destination of a ring load in flight (a false dependency the compiler then waits on)
+            f2 dl2 = {dl, dl}, dlu2 = {dl * uu, dl * uu};
+            SEGM_PIN_F2(dl2);
+            SEGM_PIN_F2(dlu2);
             float4 bn[4];
             if (j + 1 < kFT) {
 #pragma unroll
@@ -85,11 +100,11 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f2 b0 = {bq[q].x, bq[q].y}, b1 = {bq[q].z, bq[q].w};
-                const f2 da0 = A2[2 * q] * dl, da1 = A2[2 * q + 1] * dl;
+                const f2 da0 = A2[2 * q] * dl2, da1 = A2[2 * q + 1] * dl2;
                 const f2 a0 = {fast_exp2(da0.x), fast_exp2(da0.y)};
                 const f2 a1 = {fast_exp2(da1.x), fast_exp2(da1.y)};
-                h[2 * q] = a0 * h[2 * q] + b0 * dlu;
-                h[2 * q + 1] = a1 * h[2 * q + 1] + b1 * dlu;
+                h[2 * q] = a0 * h[2 * q] + b0 * dlu2;
+                h[2 * q + 1] = a1 * h[2 * q + 1] + b1 * dlu2;
             }
 #pragma unroll
             for (int n = 0; n < kFS / 2; ++n) SEGM_PIN_F2(h[n]);      // finish this step before the LDS reads two steps ahead
@@ -112,7 +127,7 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
 // ------------------------------------------------------------------------------------------------------
 // K3 (regular shapes): apply
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int RW>
+template <typename T, int RW, int MODE>
 __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fast_kernel(ScanDevN PP) {
     constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     __shared__ __attribute__((aligned(16))) float s_bc[2][kWavesPerBlock][G][2][kFT * kFS];
@@ -122,8 +137,8 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
     const Item it = locate(gm, (int64_t)blockIdx.x * kWavesPerBlock + wave, lane);
     if (!it.wave_valid) return;                           // the last workgroup may have spare waves (no workgroup barriers here)
     const int ub = uniform_batch(it);
-    const bool softplus_on = P.delta_softplus != 0;
-    const bool has_z = P.z.p != nullptr, has_out = P.out.p != nullptr;
+    const bool softplus_on = MODE != 0 || P.delta_softplus != 0;
+    const bool has_z = MODE != 0 || P.z.p != nullptr, has_out = MODE == 1 || (MODE == 0 && P.out.p != nullptr);
     FastClock ck;
     ck.init(P.tm);
     const int32_t tau0 = it.chunk * gm.chunk;
@@ -153,11 +168,12 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
     const int32_t ck_state = gm.dim * 4;                  // bytes between consecutive states of one checkpoint
 
     float nu[kFT], nd[kFT], nz[kFT], nb[EPL], nc[EPL];
+    stage_fetch_buf<T, RW>(nb, sb, wr.bias + ck.U, wr.dT);        // oldest loads at the loop head (see the aggregate kernel)
+    stage_fetch_buf<T, RW>(nc, sc, wr.bias + ck.U, wr.dT);
+    __builtin_amdgcn_sched_barrier(0);                    // keep that order
     stream_fetch<T>(nu, up, wr.bias + ck.U, wr.dT);
     stream_fetch<T>(nd, dp, wr.bias + ck.U, wr.dT);
     stream_fetch<T>(nz, zp, wr.bias + ck.U, wr.dT);
-    stage_fetch_buf<T, RW>(nb, sb, wr.bias + ck.U, wr.dT);
-    stage_fetch_buf<T, RW>(nc, sc, wr.bias + ck.U, wr.dT);
 
     int buf = 0;
     const int nsub = gm.chunk / kFT;
@@ -167,17 +183,14 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
         stage_park_buf<RW>(nb, sb, lb);
         stage_park_buf<RW>(nc, sc, lc);
         SEGM_WAVE_LDS_SYNC();
-        float cu[kFT], cd[kFT], cz[kFT];
-#pragma unroll
-        for (int j = 0; j < kFT; ++j) { cu[j] = nu[j]; cd[j] = nd[j]; cz[j] = nz[j]; }
         const int32_t Uc = wr.bias + ck.U;
         const int32_t Un = wr.bias + ((s + 1 < nsub) ? ck.next_U() : ck.U);
-        stream_fetch<T>(nu, up, Un, wr.dT);
-        stream_fetch<T>(nd, dp, Un, wr.dT);
-        stream_fetch<T>(nz, zp, Un, wr.dT);
         stage_fetch_buf<T, RW>(nb, sb, Un, wr.dT);
         stage_fetch_buf<T, RW>(nc, sc, Un, wr.dT);
         ck.advance();
+        // row streams: rings of kFT registers, refilled step by step with the next sub-tile's rows (see the aggregate kernel)
+        uint32_t su = (uint32_t)Un * (uint32_t)up.stb, sd = (uint32_t)Un * (uint32_t)dp.stb, sz = (uint32_t)Un * (uint32_t)zp.stb;
+        const uint32_t iu = (uint32_t)(wr.dT * up.stb), id = (uint32_t)(wr.dT * dp.stb), iz = (uint32_t)(wr.dT * zp.stb);
         if (P.ckpt && (s & 1) == 0) {                      // kCkpt = 2 sub-tiles
             uint32_t kso = (uint32_t)((s >> 1) * kFS * ck_state);
 #pragma unroll
@@ -191,10 +204,18 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
         const uint32_t oinc = (uint32_t)(wr.dT * op.stb), ozinc = (uint32_t)(wr.dT * ozp.stb);
 #pragma unroll
         for (int j = 0; j < kFT; ++j) {
-            float dl = cd[j] + bias;
+            const float uu = nu[j], zz = nz[j];
+            float dl = nd[j] + bias;
+            nu[j] = BufIO<T>::ld(up.rs, up.voff, su);
+            nd[j] = BufIO<T>::ld(dp.rs, dp.voff, sd);
+            nz[j] = BufIO<T>::ld(zp.rs, zp.voff, sz);          // without a gate the stream aliases u: loaded, never used
+            su += iu;
+            sd += id;
+            sz += iz;
             dl = softplus_on ? softplus20(dl) : dl;
-            const float uu = cu[j];
-            const float dlu = dl * uu;
+            f2 dl2 = {dl, dl}, dlu2 = {dl * uu, dl * uu};      // real pairs, not op_sel broadcasts (see the aggregate kernel)
+            SEGM_PIN_F2(dl2);
+            SEGM_PIN_F2(dlu2);
             // this step's B / C rows (wave-uniform addresses: LDS broadcast reads); with 3 waves per SIMD resident the
             // read latency is covered by the other waves, so nothing is prefetched into registers
             float4 bq[4], cq[4];
@@ -208,20 +229,17 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
             for (int q = 0; q < 4; ++q) {
                 const f2 b0 = {bq[q].x, bq[q].y}, b1 = {bq[q].z, bq[q].w};
                 const f2 c0 = {cq[q].x, cq[q].y}, c1 = {cq[q].z, cq[q].w};
-                const f2 da0 = A2[2 * q] * dl, da1 = A2[2 * q + 1] * dl;
+                const f2 da0 = A2[2 * q] * dl2, da1 = A2[2 * q + 1] * dl2;
                 const f2 a0 = {fast_exp2(da0.x), fast_exp2(da0.y)};
                 const f2 a1 = {fast_exp2(da1.x), fast_exp2(da1.y)};
-                h[2 * q] = a0 * h[2 * q] + b0 * dlu;
-                h[2 * q + 1] = a1 * h[2 * q + 1] + b1 * dlu;
+                h[2 * q] = a0 * h[2 * q] + b0 * dlu2;
+                h[2 * q + 1] = a1 * h[2 * q + 1] + b1 * dlu2;
                 ya = c0 * h[2 * q] + ya;
                 yb = c1 * h[2 * q + 1] + yb;
             }
             const float y = (ya.x + yb.x) + (ya.y + yb.y);
             if (has_out) BufIO<T>::st(op.rs, op.voff, oso, y);
-            if (has_z) {
-                const float zz = cz[j];
-                BufIO<T>::st(ozp.rs, ozp.voff, ozso, y * zz * sigmoidf(zz));
-            }
+            if (has_z) BufIO<T>::st(ozp.rs, ozp.voff, ozso, y * zz * sigmoidf(zz));
             oso += oinc;
             ozso += ozinc;
 #pragma unroll
@@ -244,11 +262,33 @@ bool scan_fast_shape(const ScanDev& P) {
     return true;
 }
 
+template <typename T, int RW, int MODE>
+static void launch_fast_mode(const ScanDevN& PP, int ndir, bool apply, hipStream_t stream) {
+    const unsigned nblocks = (unsigned)((PP.d[0].gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (apply) hipLaunchKernelGGL((scan_fwd_apply_fast_kernel<T, RW, MODE>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+    else hipLaunchKernelGGL((scan_fwd_agg_fast_kernel<T, RW, MODE>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+}
+// the compile-time flag set every direction of the launch agrees with (0 = none: flags read per step)
+static int fast_mode(const ScanDevN& PP, int ndir, bool apply) {
+    static const bool off = [] { const char* e = getenv("SEGM_SCAN_FLAGS"); return e && atoi(e) == 0; }();     // experiments only
+    if (off) return 0;
+    int mode = -1;
+    for (int i = 0; i < ndir; ++i) {
+        const ScanDev& P = PP.d[i];
+        int m = 0;
+        if (P.delta_softplus != 0 && (!apply || P.z.p != nullptr)) m = (!apply || P.out.p != nullptr) ? 1 : 2;
+        if (mode >= 0 && m != mode) return 0;
+        mode = m;
+    }
+    return mode < 0 ? 0 : mode;
+}
 template <typename T, int RW>
 static void launch_fast_rw(const ScanDevN& PP, int ndir, bool apply, hipStream_t stream) {
-    const unsigned nblocks = (unsigned)((PP.d[0].gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (apply) hipLaunchKernelGGL((scan_fwd_apply_fast_kernel<T, RW>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
-    else hipLaunchKernelGGL((scan_fwd_agg_fast_kernel<T, RW>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+    const int mode = fast_mode(PP, ndir, apply);
+    if (mode == 1) launch_fast_mode<T, RW, 1>(PP, ndir, apply, stream);
+    else if (mode == 2 && apply) launch_fast_mode<T, RW, 2>(PP, ndir, apply, stream);
+    else if (mode == 2) launch_fast_mode<T, RW, 1>(PP, ndir, apply, stream);          // the aggregate pass only has the softplus flag
+    else launch_fast_mode<T, RW, 0>(PP, ndir, apply, stream);
 }
 template <typename T>
 static void launch_fast_t(const ScanDevN& PP, int ndir, bool apply, hipStream_t stream) {

@@ -3,10 +3,14 @@
 // The weight gradient of Mamba's dt_proj (reference selective_scan_interface.py:272: `einsum("dB,Br->dr", ddelta, x_dbl[:, :R])`)
 // at SegMamba's sizes: ddelta (524 288 x 96), dt (524 288 x 3).  As a split-K batched GEMM in the vendor library it takes 72 us
 // for 100 MB of operands (profiles/r03_copy_shapes.log: bmm [128, 96, 4096] x [128, 4096, 3], 0.43 ms per step for six of them;
-// the same again at stage 1 with n = 6): a GEMM tile with three useful output columns.  It is a streaming reduction: one lane per
-// channel m keeps n running sums, reads its column of `a` row by row (a wave reads 128 contiguous bytes per row) and the row of `b`
-// through wave-uniform loads; a workgroup's four waves take interleaved rows of one k slab, add their sums through LDS and leave one
-// partial per slab, summed in a fixed order by reduce_partials (deterministic).  HBM-bound: bytes = k (m + n) e.
+// the same again at stage 1 with n = 6): a GEMM tile with three useful output columns.  It is a streaming reduction and HBM-bound
+// (bytes = k (m + n) e), so the kernel is shaped by the loads, not by the arithmetic:
+//   * a thread owns EIGHT consecutive channels (one 16-byte load per row) and a tile of NT columns: 8 NT running sums;
+//   * m / 8 threads cover a row, the workgroup's 256 threads cover 256 / (m / 8) consecutive rows per pass and walk their slab
+//     with four or eight passes of loads in flight (64 - 128 B per thread);
+//   * the rows a workgroup's threads summed separately are folded through LDS in a fixed order, one partial (n x m) per slab is
+//     written, and reduce_partials adds the slabs in a fixed order: deterministic, no atomics.
+// (The first version - one lane per channel, 2-byte loads, wave-uniform reads of b - ran at 0.1 TB/s: profiles/r03_step_kernels_v4.txt.)
 #include <stdlib.h>
 #include <string.h>
 
@@ -18,60 +22,91 @@ void launch_reduce_partials(const float* part, int64_t nrows, int K, int dim, fl
                             float* out2, hipStream_t stream);
 
 constexpr int kSkMaxN = 32;
-constexpr int kSkRows = 4096;          // rows of k per workgroup (slab)
+constexpr int kSkCh = 8;               // channels per thread = one 16-byte load
+constexpr int kSkSlabs = 1024;         // slabs the rows are cut into at most (four workgroups per CU)
+constexpr int kSkMaxLds = 12288;       // floats of the fold buffer (m x column tile)
 
 struct SkinnyDev {
     const char* a; int64_t a_sr;       // (k, m), unit column stride, row stride in elements
     const char* b; int64_t b_sr;       // (k, n)
     float* part;                       // [slab][n][m]
-    int64_t k;
-    int32_t m, n, nslab;
+    int64_t k, slab_rows;
+    int32_t m, n, nslab, threads_per_row, rows_per_pass;
 };
 
-template <typename T, int N>
+// rows of one pass / of one slab for a problem: shared by the launcher and segm_skinny_tn_workspace_bytes
+static inline int skinny_tile(int32_t n) { return n <= 4 ? 4 : 8; }          // columns per workgroup (16 x 8 running sums would spill)
+static inline int skinny_passes(int nt) { return nt == 4 ? 8 : 4; }          // passes of loads in flight (16 bytes per thread each)
+static inline void skinny_geometry(int32_t m, int32_t n, int64_t k, int32_t* threads_per_row, int32_t* rows_per_pass, int64_t* slab_rows,
+                                   int32_t* nslab) {
+    *threads_per_row = m / kSkCh;
+    *rows_per_pass = kBlock / *threads_per_row;
+    const int64_t macro = (int64_t)*rows_per_pass * skinny_passes(skinny_tile(n));
+    const int64_t nmacro = (k + macro - 1) / macro;
+    *slab_rows = ((nmacro + kSkSlabs - 1) / kSkSlabs) * macro;
+    *nslab = (int32_t)((k + *slab_rows - 1) / *slab_rows);
+}
+
+template <typename T, int NT, int kSkU>
 __global__ void __launch_bounds__(kBlock) skinny_tn_kernel(SkinnyDev P) {
-    __shared__ float s_acc[kWavesPerBlock][N][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int mm = blockIdx.y * 64 + lane;
-    const bool valid = mm < P.m;
-    const int64_t k0 = (int64_t)blockIdx.x * kSkRows;
-    const int64_t k1 = k0 + kSkRows < P.k ? k0 + kSkRows : P.k;
-    const T* a = reinterpret_cast<const T*>(P.a) + (valid ? mm : 0);
-    const T* b = reinterpret_cast<const T*>(P.b);
-    float acc[N];
+    __shared__ float s_fold[kSkMaxLds];
+    const int tid = threadIdx.x;
+    const int row = tid / P.threads_per_row, cg = tid - row * P.threads_per_row;
+    const bool active = row < P.rows_per_pass;
+    const int j0 = blockIdx.y * NT;                          // first column of this workgroup's tile
+    const int nj = P.n - j0 < NT ? P.n - j0 : NT;
+    const int64_t k0 = (int64_t)blockIdx.x * P.slab_rows;
+    const int64_t k1 = k0 + P.slab_rows < P.k ? k0 + P.slab_rows : P.k;
+    const T* a = reinterpret_cast<const T*>(P.a) + cg * kSkCh;
+    const T* b = reinterpret_cast<const T*>(P.b) + j0;
+    float acc[kSkCh][NT];
 #pragma unroll
-    for (int j = 0; j < N; ++j) acc[j] = 0.f;
-    constexpr int U = 8;                                    // rows in flight per wave
-    int64_t r = k0 + wave;
-    for (; r + (U - 1) * kWavesPerBlock < k1; r += U * kWavesPerBlock) {
-        float av[U];
+    for (int i = 0; i < kSkCh; ++i)
 #pragma unroll
-        for (int u = 0; u < U; ++u) av[u] = to_f32(a[(r + u * kWavesPerBlock) * P.a_sr]);
+        for (int j = 0; j < NT; ++j) acc[i][j] = 0.f;
+    if (active) {
+        for (int64_t r = k0 + row; r < k1; r += (int64_t)kSkU * P.rows_per_pass) {
+            uint4 raw[kSkU];
+            T bv[kSkU][NT];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const T* br = b + (r + u * kWavesPerBlock) * P.b_sr;       // wave-uniform address: broadcast loads
+            for (int u = 0; u < kSkU; ++u) {
+                const int64_t ru = r + (int64_t)u * P.rows_per_pass;
+                const bool ok = ru < k1;
+                raw[u] = ok ? *reinterpret_cast<const uint4*>(a + ru * P.a_sr) : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int j = 0; j < N; ++j)
-                if (j < P.n) acc[j] = fmaf(av[u], to_f32(br[j]), acc[j]);
+                for (int j = 0; j < NT; ++j) bv[u][j] = (ok && j < nj) ? b[ru * P.b_sr + j] : (T)0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < kSkU; ++u) {
+                T av[kSkCh];
+                memcpy(av, &raw[u], 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float bj = to_f32(bv[u][j]);
+#pragma unroll
+                    for (int i = 0; i < kSkCh; ++i) acc[i][j] = fmaf(to_f32(av[i]), bj, acc[i][j]);
+                }
+            }
         }
     }
-    for (; r < k1; r += kWavesPerBlock) {
-        const float av = to_f32(a[r * P.a_sr]);
-        const T* br = b + r * P.b_sr;
+    // fold the rows_per_pass partial sums of every (column, channel) in row order; s_fold[j][m]
+    for (int q = 0; q < P.rows_per_pass; ++q) {
+        if (active && row == q) {
 #pragma unroll
-        for (int j = 0; j < N; ++j)
-            if (j < P.n) acc[j] = fmaf(av, to_f32(br[j]), acc[j]);
-    }
+            for (int j = 0; j < NT; ++j) {
+                if (j >= nj) break;
 #pragma unroll
-    for (int j = 0; j < N; ++j) s_acc[wave][j][lane] = acc[j];
-    __syncthreads();
-    if (wave == 0 && valid) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            if (j >= P.n) break;
-            const float t = (s_acc[0][j][lane] + s_acc[1][j][lane]) + (s_acc[2][j][lane] + s_acc[3][j][lane]);
-            P.part[((int64_t)blockIdx.x * P.n + j) * P.m + mm] = t;
+                for (int i = 0; i < kSkCh; ++i) {
+                    float* d = &s_fold[j * P.m + cg * kSkCh + i];
+                    *d = q == 0 ? acc[i][j] : *d + acc[i][j];
+                }
+            }
         }
+        __syncthreads();
+    }
+    for (int id = tid; id < nj * P.m; id += kBlock) {
+        const int j = id / P.m, mm = id - j * P.m;
+        P.part[((int64_t)blockIdx.x * P.n + j0 + j) * P.m + mm] = s_fold[id];
     }
 }
 
@@ -80,8 +115,10 @@ __global__ void __launch_bounds__(kBlock) skinny_tn_kernel(SkinnyDev P) {
 using namespace segm;
 
 extern "C" size_t segm_skinny_tn_workspace_bytes(int32_t m, int32_t n, int64_t k) {
-    if (m <= 0 || n <= 0 || k <= 0) return 0;
-    const int64_t nslab = (k + kSkRows - 1) / kSkRows;
+    if (m <= 0 || n <= 0 || k <= 0 || m % kSkCh != 0 || m / kSkCh > kBlock) return 0;
+    int32_t tpr, rpp, nslab;
+    int64_t slab_rows;
+    skinny_geometry(m, n, k, &tpr, &rpp, &slab_rows, &nslab);
     return (size_t)nslab * n * m * sizeof(float);
 }
 
@@ -89,6 +126,8 @@ extern "C" int segm_skinny_tn(const segm_skinny_tn_args* a) {
     if (!a) return SEGM_E_NULL;
     if (!a->wide || !a->skinny || !a->out || !a->workspace) return SEGM_E_NULL;
     if (a->m <= 0 || a->n <= 0 || a->n > kSkMaxN || a->k <= 0 || a->wide_stride_row < a->m || a->skinny_stride_row < a->n) return SEGM_E_SHAPE;
+    if (a->m % kSkCh != 0 || a->m / kSkCh > kBlock || a->wide_stride_row % kSkCh != 0) return SEGM_E_SHAPE;     // 16-byte loads of whole rows
+    if (((uintptr_t)a->wide & 15u) != 0) return SEGM_E_SHAPE;
     if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
     if (a->workspace_bytes < segm_skinny_tn_workspace_bytes(a->m, a->n, a->k)) return SEGM_E_WORKSPACE;
     SkinnyDev P;
@@ -97,19 +136,21 @@ extern "C" int segm_skinny_tn(const segm_skinny_tn_args* a) {
     P.b = (const char*)a->skinny; P.b_sr = a->skinny_stride_row;
     P.part = (float*)a->workspace;
     P.k = a->k; P.m = a->m; P.n = a->n;
-    P.nslab = (int32_t)((a->k + kSkRows - 1) / kSkRows);
+    skinny_geometry(a->m, a->n, a->k, &P.threads_per_row, &P.rows_per_pass, &P.slab_rows, &P.nslab);
+    // column tile: the largest whose fold buffer (m x tile floats) fits; 8 x tile running sums per thread
+    int nt = skinny_tile(a->n);
+    while (nt > 4 && (int64_t)nt * a->m > kSkMaxLds) nt >>= 1;
+    if ((int64_t)nt * a->m > kSkMaxLds) return SEGM_E_SHAPE;
     hipStream_t st = (hipStream_t)a->stream;
-    const dim3 grid(P.nslab, (a->m + 63) / 64), block(kBlock);
+    const dim3 grid(P.nslab, (a->n + nt - 1) / nt), block(kBlock);
     const bool f16 = a->dtype == SEGM_F16;
-#define SEGM_SK(NN)                                                                                      \
+#define SEGM_SK(NN, UU)                                                                                     \
     do {                                                                                                 \
-        if (f16) hipLaunchKernelGGL((skinny_tn_kernel<f16_t, NN>), grid, block, 0, st, P);               \
-        else hipLaunchKernelGGL((skinny_tn_kernel<bf16_t, NN>), grid, block, 0, st, P);                  \
+        if (f16) hipLaunchKernelGGL((skinny_tn_kernel<f16_t, NN, UU>), grid, block, 0, st, P);           \
+        else hipLaunchKernelGGL((skinny_tn_kernel<bf16_t, NN, UU>), grid, block, 0, st, P);              \
     } while (0)
-    if (a->n <= 4) SEGM_SK(4);
-    else if (a->n <= 8) SEGM_SK(8);
-    else if (a->n <= 16) SEGM_SK(16);
-    else SEGM_SK(32);
+    if (nt == 4) SEGM_SK(4, 8);            // (rows beyond the slab are masked, so the passes need not divide the slab)
+    else SEGM_SK(8, 4);
 #undef SEGM_SK
     launch_reduce_partials(P.part, P.nslab, a->n, a->m, a->out, a->n, nullptr, nullptr, st);
     return (int)hipGetLastError();

@@ -775,13 +775,15 @@ def linear_rows(lib: L.SegmLib, x2: torch.Tensor, w: torch.Tensor, bias: Optiona
 def skinny_tn_supported(wide: torch.Tensor, skinny: torch.Tensor) -> bool:
     return bool(wide.dim() == 2 and skinny.dim() == 2 and wide.shape[0] == skinny.shape[0] and skinny.shape[1] <= 32 and
                 wide.dtype in (torch.bfloat16, torch.float16) and skinny.dtype == wide.dtype and wide.stride(1) == 1 and
-                skinny.stride(1) == 1 and wide.shape[0] > 0)
+                skinny.stride(1) == 1 and wide.shape[0] > 0 and
+                # whole rows as 16-byte loads: eight channels per thread, at most 256 threads per row
+                wide.shape[1] % 8 == 0 and wide.shape[1] <= 2048 and wide.stride(0) % 8 == 0 and wide.data_ptr() % 16 == 0)
 
 
 def skinny_tn(lib: L.SegmLib, wide: torch.Tensor, skinny: torch.Tensor) -> torch.Tensor:
     """wide (k, m)^T @ skinny (k, n <= 32) -> (m, n) fp32: the dt_proj weight gradient as a streaming reduction"""
     if not skinny_tn_supported(wide, skinny):
-        raise RuntimeError("skinny_tn: wide (k, m), skinny (k, n <= 32), one 16-bit dtype, unit column strides")
+        raise RuntimeError("skinny_tn: wide (k, m % 8 == 0, m <= 2048, 16-byte aligned rows), skinny (k, n <= 32), one 16-bit dtype, unit column strides")
     K, M = wide.shape
     N = skinny.shape[1]
     out = torch.empty(M, N, dtype=torch.float32, device=wide.device)

@@ -378,14 +378,15 @@ def test_transpose_add_emulated(emu, shape, dtype, with_add):
     (96, 64, 32, True, L.TIME_FORWARD, 1, torch.bfloat16),         # SegMamba stage-0 width
 ])
 def test_scan_regular_shape_kernels_emulated(emu, monkeypatch, dim, seqlen, chunk, channel_last, order, ns, dtype):
-    """scan_fwd_fast.hip / scan_bwd_fast.hip / scan_bwd_pair.hip (uniform addressing) against the oracle AND against the general
-    kernels; the backward with both main kernels (SEGM_BWD_MAIN=r2: packed state pairs, the default; r3: LDS-tile prefetch)."""
+    """scan_fwd_fast.hip / scan_bwd_fast.hip / scan_bwd_pair.hip / scan_bwd_half.hip (uniform addressing) against the oracle AND against the general
+    kernels; the backward with each main kernel (SEGM_BWD_MAIN=r2: 16-step windows; half: 8-step half windows (scan_bwd_half.hip); r3: LDS tiles)."""
     c = H.scan_case(1, dim, 16, seqlen, dtype=dtype, seed=dim + seqlen)
     ref = H.scan_oracle(c, order, ns)
     monkeypatch.delenv("SEGM_SCAN_FAST", raising=False)
-    monkeypatch.setenv("SEGM_BWD_MAIN", "r3")
-    fast = H.run_scan(emu, c, "cpu", channel_last, order, ns, chunk=chunk)
-    H.check_scan(fast, ref, dtype, f"emu fast (r3 main) D={dim} L={seqlen}")
+    for main in ("r3", "half"):
+        monkeypatch.setenv("SEGM_BWD_MAIN", main)
+        fast = H.run_scan(emu, c, "cpu", channel_last, order, ns, chunk=chunk)
+        H.check_scan(fast, ref, dtype, f"emu fast ({main} main) D={dim} L={seqlen}")
     monkeypatch.setenv("SEGM_BWD_MAIN", "r2")
     fast = H.run_scan(emu, c, "cpu", channel_last, order, ns, chunk=chunk)
     H.check_scan(fast, ref, dtype, f"emu fast D={dim} L={seqlen}")
@@ -1317,10 +1318,12 @@ def test_every_routing_candidate_of_the_conv_dispatcher_runs_and_agrees(emu, mon
 
 
 @pytest.mark.parametrize("K,M,N,dtype,lda,ldb", [(5000, 96, 3, torch.bfloat16, 96, 40), (4096 + 77, 192, 6, torch.bfloat16, 192, 6),
-                                                  (300, 70, 12, torch.float16, 80, 56), (9000, 384, 24, torch.bfloat16, 768, 64)])
+                                                  (300, 72, 12, torch.float16, 80, 56), (9000, 384, 24, torch.bfloat16, 768, 64),
+                                                  (1100, 768, 24, torch.bfloat16, 768, 56), (50, 2048, 5, torch.float16, 2048, 8)])
 def test_skinny_tn_emulated(emu, K, M, N, dtype, lda, ldb):
     """segm_skinny_tn: wide^T skinny (the dt_proj weight gradient, reference selective_scan_interface.py:272) against an fp32
-    matmul on the same rounded operands; views with row strides, a ragged last slab, a ragged channel tile"""
+    matmul on the same rounded operands; views with row strides, ragged last slabs and passes, column tiles of 4 / 8 (three tiles for
+    24 columns, narrowed by the fold buffer at 2048 channels); unsupported operands are refused"""
     g = torch.Generator().manual_seed(K + M)
     wide = torch.randn(K, lda, generator=g).to(dtype)[:, :M]
     skinny = torch.randn(K, ldb, generator=g).to(dtype)[:, 2:2 + N] if ldb > N + 2 else torch.randn(K, ldb, generator=g).to(dtype)[:, :N]
@@ -1328,3 +1331,6 @@ def test_skinny_tn_emulated(emu, K, M, N, dtype, lda, ldb):
     ref = wide.float().t() @ skinny.float()
     assert out.shape == (M, N) and out.dtype == torch.float32
     assert (out - ref).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max()))
+    assert not ops_raw.skinny_tn_supported(wide[:, :M - 2], skinny) and not ops_raw.skinny_tn_supported(wide[:, 1:], skinny[:, :N])
+    with pytest.raises(RuntimeError):
+        ops_raw.skinny_tn(emu, wide[:, :M - 2], skinny)

@@ -15,7 +15,9 @@ from segmamba_amd import ops_raw
 hip = L.get_lib()
 for dt in (torch.bfloat16, torch.float32):
     r = scan_roofline(dt, torch.device("cuda"))
-    print("    %%-8s chunk %%d  fwd %%.4f ms (frac %%.3f)  bwd %%.4f ms" %% (str(dt).split(".")[1], r["shape"]["chunk"], r["ms"], r["frac"], r["backward"]["ms"]), flush=True)
+    t3 = r.get("three_directions_per_launch") or {}
+    print("    %%-8s chunk %%d  fwd %%.4f ms (frac %%.3f)  bwd %%.4f ms   three directions per launch: fwd %%s ms  bwd %%s ms" %% (
+        str(dt).split(".")[1], r["shape"]["chunk"], r["ms"], r["frac"], r["backward"]["ms"], t3.get("fwd_ms"), t3.get("bwd_ms")), flush=True)
 # fingerprint of the results (same seeded inputs in every variant)
 g = torch.Generator(device="cuda").manual_seed(1)
 B, D, N, Lq = 2, 96, 16, 8192
@@ -30,9 +32,13 @@ torch.save({"out_z": f["out_z"].cpu(), "du": b["du"].cpu(), "dB": b["dB"].cpu(),
 ''' % ROOT
 outs = []
 for i, so in enumerate(a for a in sys.argv[1:] if not a.startswith("--")):
-    print("variant", so, flush=True)
+    print("variant", so, flush=True)                      # "NAME=VALUE,NAME=VALUE:path.so" runs the library with that environment
+    env = dict(os.environ)
+    if ":" in so:
+        sets, so = so.split(":", 1)
+        env.update(kv.split("=", 1) for kv in sets.split(","))
     out = f"/tmp/scan_ab_{i}.pt"
-    subprocess.run([sys.executable, "-c", code, os.path.abspath(so), out])
+    subprocess.run([sys.executable, "-c", code, os.path.abspath(so), out], env=env)
     outs.append(out)
 if len(outs) > 1:
     import torch
