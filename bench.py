@@ -157,26 +157,34 @@ def scan_roofline(dtype, device):
     gf3, gb3 = 3 * bytes_f / ms_f3 * 1e-6, 3 * bytes_b / ms_b3 * 1e-6
     gf, gb = bytes_f / ms_f * 1e-6, bytes_b / ms_b * 1e-6
     tr = scan_traffic({torch.bfloat16: "bf16", torch.float32: "fp32", torch.float16: "fp16"}[dtype])
-    # The kernels are bound by VALU issue, not by HBM (profiles/r02_scan_proto_notes.md): one v_exp_f32 per
-    # step and state per pass plus the packed multiply-adds of the recurrence.  `valu` prices the same launch against that ceiling
-    # with the issue rates MEASURED on this MI355X (profiles/r02_probe_valu2.log: v_exp_f32 8.3, packed fp32 2.25 per lane-op, plain
-    # 2.7 cycles per wave-instruction on a SIMD with enough resident waves; 2.1 GHz under this load): cycles per
-    # (batch, channel, step) element the algorithm needs / the cycles the launch took per element.
-    cyc_needed = round(N * (8.3 + 3 * 2.25) + 50 + N * (8.3 + 4 * 2.25) + 80)      # aggregate pass + apply pass
+    # The kernels are bound by instruction issue, not by HBM.  Round 3 measured what an instruction costs a SIMD
+    # in these kernels (profiles/r03_probe_valu3.log, r03_scan_occupancy.log, r03_scan_ablations.log): ~9 cycles for v_exp_f32 / v_log /
+    # v_rcp, ~4.4 for every other vector instruction - packed or not - and ~2 for a scalar / LDS / memory instruction, at ANY number of
+    # resident waves (time grows linearly from 3 waves per SIMD on; the round-2 model - 8.3 / 2.25 per lane-op / 2.7 - came from a probe
+    # whose plain ops rotated over the four register banks and counted nothing but vector instructions).  Per wave-step the aggregate
+    # pass issues 18 transcendental + 37 other vector + ~17 scalar / LDS / memory instructions, the apply pass 20 + 58 + ~40
+    # (tools/isa_mix.py on the shipped binary): 359 + 515 cycles.  Measured with 6 waves per SIMD of work: 340 - 357 and 503 - 528.
+    cyc_needed = round(18 * 9.0 + 37 * 4.4 + 17 * 2.0) + round(20 * 9.0 + 58 * 4.4 + 40 * 2.0)      # aggregate pass + apply pass
     elems_per_simd = B * D * Lq / 64 / 1024                    # wave-steps per SIMD (256 CUs x 4 SIMDs)
     cyc_taken = ms_f * 1e-3 * 2.1e9 / elems_per_simd
+    cyc_taken3 = ms_f3 * 1e-3 * 2.1e9 / (3 * elems_per_simd)
     return {
         "bound": "valu", "priced_against": "hbm", "kernel": "selective_scan_fwd (scan_fwd_agg + scan_carry + scan_fwd_apply)",
         "shape": {"B": B, "D": D, "N": N, "L": Lq, "layout": "channel-last", "chunk": f["chunk"]},
         "achieved": round(gf, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gf / HBM_PEAK_GBPS, 4),
         "ms": round(ms_f, 4), "algorithmic_bytes": bytes_f,
         "traffic": tr["bytes"] if tr else None, "traffic_source": tr,
-        "valu": {"bound": "valu-issue", "cycles_needed_per_wave_step": cyc_needed,
+        "valu": {"bound": "instruction issue", "cycles_needed_per_wave_step": cyc_needed,
                  "cycles_taken_per_wave_step_at_2.1GHz": round(cyc_taken, 1), "frac": round(cyc_needed / cyc_taken, 4),
-                 "busy_cycles_per_wave_step_SQ_counters": {"aggregate": 304, "apply": 402, "source": "profiles/r02_scan_pmc_bwd2.txt"}},
-        "note": "bound = what limits the kernel: VALU issue (one v_exp_f32 per step and state in each of the two passes). "
-                "achieved / peak / frac price it against the HBM roofline BASELINE.json's metric names (algorithmic bytes / time "
-                "vs 8 TB/s); valu.frac prices the same launch against the measured VALU issue ceiling",
+                 "three_directions_per_launch": {"cycles_taken_per_wave_step": round(cyc_taken3, 1), "frac": round(cyc_needed / cyc_taken3, 4)},
+                 "instruction_costs_cycles": {"transcendental": 9.0, "other_vector": 4.4, "scalar_lds_memory": 2.0,
+                                              "source": "profiles/r03_probe_valu3.log, r03_scan_occupancy.log, r03_scan_ablations.log"},
+                 "instructions_per_wave_step": {"aggregate": [18, 37, 17], "apply": [20, 58, 40]},
+                 "measured_with_6_waves_per_simd": {"aggregate": [340, 357], "apply": [503, 528]}},
+        "note": "bound = what limits the kernel: instructions issued per SIMD (one v_exp_f32 per step and state in each of the two "
+                "passes plus the recurrence; ~4.4 cycles per vector instruction whatever the occupancy).  achieved / peak / frac price "
+                "it against the HBM roofline BASELINE.json's metric names (algorithmic bytes / time vs 8 TB/s); valu.frac prices the "
+                "same launch against the issue bound of the shipped instruction stream",
         "backward": {"achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4), "ms": round(ms_b, 4),
                      "algorithmic_bytes": bytes_b},
         "three_directions_per_launch": {

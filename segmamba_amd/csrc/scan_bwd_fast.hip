@@ -496,29 +496,24 @@ bool scan_full_span_fits(const ScanDev& P, size_t esize) {
         if (((L - 1) * m->st + (int64_t)(P.gm.nstate - 1) * m->sn + 1) * es >= lim) return false;
     return ((L - 1) * P.dB_st + (P.gm.nstate - 1) * P.dB_sn + 1) * 4 < lim && ((L - 1) * P.dC_st + (P.gm.nstate - 1) * P.dC_sn + 1) * 4 < lim;
 }
-// main kernel choice: "r2" = the pair kernel (scan_bwd_pair.hip, 16-step windows, one wave per SIMD), "half" = 8-step half windows at
-// three waves per SIMD (scan_bwd_half.hip), "r3" = the kernel above; SEGM_BWD_MAIN overrides the default
-enum { kMainPair = 2, kMainR3 = 3, kMainHalf = 4 };
-#ifndef SEGM_BWD_MAIN_DEFAULT
-#define SEGM_BWD_MAIN_DEFAULT kMainPair
-#endif
-static int main_kernel_choice(const ScanDevN& PP, int ndir, int dtype) {
+// main kernel choice: "r2" = the pair kernel (scan_bwd_pair.hip: 16-step windows, one wave per SIMD, 32-bit offsets from the batch
+// base), "r3" = the kernel above (wave-local bases: any span).  The pair kernel is the default wherever it can address the tensors:
+// what bounds these kernels is the NUMBER of instructions a SIMD issues (~4.4 cycles each, v_exp_f32 ~9, whatever the number of
+// resident waves - profiles/r03_scan_occupancy.log), and both multi-wave kernels of round 3 issue more of them (this one: LDS
+// tiles and per-state loops; the half-window kernel of tools/experiments: +50 % recurrence exponentials and spills).
+static bool use_pair_kernel(const ScanDevN& PP, int ndir, int dtype) {
     const char* e = getenv("SEGM_BWD_MAIN");               // read per launch: tests switch it inside one process
-    int k = SEGM_BWD_MAIN_DEFAULT;
-    if (e) k = e[0] == 'h' ? kMainHalf : (e[0] == 'r' && e[1] == '3') ? kMainR3 : kMainPair;
-    if (k == kMainPair) {                                  // 32-bit offsets from the batch base: the whole span must fit
-        const size_t es = dtype == SEGM_F32 ? 4 : 2;
-        for (int i = 0; i < ndir; ++i)
-            if (!scan_full_span_fits(PP.d[i], es)) return kMainR3;
-    }
-    return k;
+    if (e && e[0] == 'r' && e[1] == '3') return false;
+    const size_t es = dtype == SEGM_F32 ? 4 : 2;
+    for (int i = 0; i < ndir; ++i)
+        if (!scan_full_span_fits(PP.d[i], es)) return false;
+    return true;
 }
 // launches K1 (main == false) or K3 (main == true) of the regular-shape backward for `ndir` blocks of one geometry
 void launch_scan_bwd_fast(const ScanDevN& PP, int ndir, int dtype, bool main, hipStream_t stream) {
-    if (main) {
-        const int k = main_kernel_choice(PP, ndir, dtype);
-        if (k == kMainPair) { launch_scan_bwd_main_pair(PP, ndir, dtype, stream); return; }
-        if (k == kMainHalf) { launch_scan_bwd_main_half(PP, ndir, dtype, stream); return; }
+    if (main && use_pair_kernel(PP, ndir, dtype)) {
+        launch_scan_bwd_main_pair(PP, ndir, dtype, stream);
+        return;
     }
     if (dtype == SEGM_F32) launch_bwd_fast_t<float>(PP, ndir, main, stream);
     else if (dtype == SEGM_F16) launch_bwd_fast_t<f16_t>(PP, ndir, main, stream);

@@ -1,11 +1,14 @@
-// Selective scan backward, regular shapes: the round-2 main kernel ("pair" kernel: two states per iteration in packed fp32, one
-// wave per SIMD, per-batch base + 32-bit row offsets), kept next to the round-3 kernel of scan_bwd_fast.hip.
+// Selective scan backward, regular shapes: the main kernel on 16-step windows ("pair" kernel: two states per iteration in packed
+// fp32, one wave per SIMD, per-batch base + 32-bit row offsets).  The default main kernel.
 //
-// Round 3 rebuilt the main kernel for two waves per SIMD (LDS-tile prefetch, per-state loop, register-indexed carries).  On the
-// MI355X it is correct and SLOWER (profiles/r03_scan_ab*.log: 1.2 - 1.4 ms against 0.90 ms at the stage-0 shape): a lone wave
-// of it needs ~12 cycles per instruction where this kernel needs ~7.7.  Until that is understood this kernel stays the default
-// for every launch whose per-batch span fits 32 bits (all SegMamba stages and BASELINE configs in 16-bit); SEGM_BWD_MAIN=r3
-// selects the other one, and spans beyond 4 GiB (fp32 at 2^24 steps) always take it (it addresses from the wave's lowest row).
+// Round 3 built two alternatives with more waves per SIMD (scan_bwd_fast.hip: LDS-tile prefetch and a per-state loop at two waves;
+// tools/experiments/scan_bwd_halfwindow_r3.hip.txt: 8-step half windows at three).  Both are correct and SLOWER on the MI355X
+// (1.2 - 1.5 ms against 0.90 ms at the stage-0 shape, profiles/r03_scan_ab*.log), and round 3 also found why: a SIMD retires about
+// one instruction per 4.4 cycles (v_exp_f32: 9) however many waves it picks them from - this kernel runs at 2 300 cycles per
+// wave-step for its ~510 instructions with ONE wave per SIMD, and exactly as fast per wave with one to eight waves of work per SIMD
+// (profiles/r03_scan_occupancy.log).  More resident waves buy nothing; only fewer instructions per step do, and the multi-wave
+// kernels issue more (recomputed exponentials, LDS staging, spills).  SEGM_BWD_MAIN=r3 selects the other kernel, and spans beyond
+// 4 GiB (fp32 at 2^24 steps) always take it (it addresses from the wave's lowest row).
 #include "scan_fast.h"
 
 namespace segm {

@@ -148,7 +148,6 @@ void launch_scan_fwd_fast(const ScanDevN& PP, int ndir, int dtype, bool apply, h
 bool scan_bwd_fast_shape(const ScanDev& P, size_t esize);      // scan_bwd_fast.hip
 void launch_scan_bwd_fast(const ScanDevN& PP, int ndir, int dtype, bool main, hipStream_t stream);
 void launch_scan_bwd_main_pair(const ScanDevN& PP, int ndir, int dtype, hipStream_t stream);       // scan_bwd_pair.hip
-void launch_scan_bwd_main_half(const ScanDevN& PP, int ndir, int dtype, hipStream_t stream);       // scan_bwd_half.hip
 // the whole sequence of every view of the launch fits a 32-bit byte offset from its batch base (what the pair kernel needs)
 bool scan_full_span_fits(const ScanDev& P, size_t esize);
 // carry composition of `ndir` argument blocks of one geometry; forward: agg_* / carry / carry_seg of each block, reverse: the

@@ -8,11 +8,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from segmamba_amd import lib as L, ops_raw
 from bench import time_gpu
 
+if os.environ.get("SEGM_OCC_LIB"):                      # a variant build (tools/build_scan_ablations.py)
+    L.LIB_PATH = os.path.abspath(os.environ["SEGM_OCC_LIB"])
 hip = L.get_lib()
 dev = torch.device("cuda")
 dtype = torch.bfloat16
 B, D, N = 2, 32, 16
-for k in (1, 2, 3, 4, 5, 6, 8):
+for k in [int(x) for x in os.environ.get("SEGM_OCC_K", "1,2,3,4,5,6,8").split(",")]:
     Lq = 262144 * k
     g = torch.Generator(device=dev).manual_seed(k)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g).to(dtype)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel durations of tools/gpu_scan_occupancy.py by grid size:  tools/gpu_scan_occupancy.sh <tag>   (env passes through)
 mkdir -p gpurun_out/prof; R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof/occ_$1 -o occ -- python $R/tools/gpu_scan_occupancy.py 2>&1 | grep "waves/SIMD"
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof/occ_$1 -o occ -- python $R/tools/gpu_scan_occupancy.py 2>&1 | grep -E "waves/SIMD|Error|error"
 python3 - $R/gpurun_out/prof/occ_$1 <<'PY'
 import csv, glob, sys, collections, statistics
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
