@@ -15,7 +15,9 @@ is restated from its published implementation:
                            trilinear / nearest here (grid_sample has no 3-D cubic mode); labels outside the volume become 0
                            (RemoveLabelTransform(-1, 0), :57)
   GaussianNoise            p 0.1: x += N(0, s), s ~ U(0, 0.1)   (batchgenerators passes its "variance" as numpy's scale)
-  GaussianBlur             p 0.2, each channel with p 0.5: separable gaussian, sigma ~ U(0.5, 1) per channel
+  GaussianBlur             p 0.2, each channel with p 0.5: separable gaussian, sigma ~ U(0.5, 1) per channel; the kernel is cut at
+                           radius 3 (>= 3 sigma) and the border replicated, where scipy's gaussian_filter cuts at 4 sigma and
+                           reflects: differences below 1e-3 of the kernel mass, at the border voxels only
   BrightnessMultiplicative p 0.15: each channel x U(0.75, 1.25)
   ContrastAugmentation     p 0.15: each channel (x - mean) f + mean, f from (0.75, 1) or (1, 1.25) with equal odds, clipped
                            to the channel's former range
