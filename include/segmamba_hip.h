@@ -595,6 +595,21 @@ typedef struct segm_skinny_tn_args {
 size_t segm_skinny_tn_workspace_bytes(int32_t m, int32_t n, int64_t k);
 int segm_skinny_tn(const segm_skinny_tn_args* args);
 int segm_wgrad_gemm(const segm_wgrad_gemm_args* args);
+/* out[c] (fp32, OVERWRITTEN) = sum over batch and voxels of x[b][c][s]: the bias gradient `dy.sum((0, 2, 3, 4))` of the convolutions
+ * that have a bias (reference segmamba.py:78-89, 95-131, 141, 254; cuDNN backward-bias / ATen there).  x (batch, channels, spatial)
+ * with unit voxel stride, strides in elements (stride_channel >= spatial: padded volumes are fine); fp32 / fp16 / bf16.  Partials per
+ * (b, segment, c) in the workspace, added in a fixed order. */
+typedef struct segm_channel_sum_args {
+    const void* x;
+    int64_t stride_batch, stride_channel, spatial;
+    int32_t batch, channels, dtype, reserved;
+    float* out;
+    void* workspace;     size_t workspace_bytes;
+    void* stream;
+} segm_channel_sum_args;
+size_t segm_channel_sum_workspace_bytes(int32_t batch, int32_t channels, int64_t spatial);
+int segm_channel_sum(const segm_channel_sum_args* args);
+
 
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);

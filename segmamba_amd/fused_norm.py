@@ -114,7 +114,7 @@ class _StemConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         if ctx.use_hip:
             dw = ops_raw.stem_conv_wgrad(L.get_lib(), x, dy, w.shape[1], ctx.k).to(ctx.w_dtype) if ctx.needs_input_grad[1] else None
-            db = dy.sum(dim=(0, 2, 3, 4), dtype=torch.float32).to(ctx.b_dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            db = linear.bias_grad(dy).to(ctx.b_dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
             return None, dw, db
         mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
         dx, dw, db = torch.ops.aten.convolution_backward(dy.contiguous(), x, w, [w.shape[0]] if ctx.has_bias else None, [ctx.s] * 3,

@@ -242,7 +242,7 @@ EXPORTS = (
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
     "segm_causal_conv1d_update", "segm_selective_state_update", "segm_linear_rows", "segm_pointwise_cf", "segm_stem_conv_fwd",
     "segm_stem_conv_wgrad", "segm_stem_conv_wgrad_workspace_bytes", "segm_stem_conv_wgrad_workspace_bytes2", "segm_wgrad_gemm", "segm_wgrad_gemm_workspace_bytes",
-    "segm_skinny_tn", "segm_skinny_tn_workspace_bytes",
+    "segm_skinny_tn", "segm_skinny_tn_workspace_bytes", "segm_channel_sum", "segm_channel_sum_workspace_bytes",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -250,6 +250,12 @@ EXPORTS = (
 class SkinnyTnArgs(C.Structure):
     _fields_ = [("k", C.c_int64), ("m", C.c_int32), ("n", C.c_int32), ("dtype", C.c_int32), ("reserved", C.c_int32),
                 ("wide", C.c_void_p), ("wide_stride_row", C.c_int64), ("skinny", C.c_void_p), ("skinny_stride_row", C.c_int64),
+                ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p)]
+
+
+class ChannelSumArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("stride_batch", C.c_int64), ("stride_channel", C.c_int64), ("spatial", C.c_int64),
+                ("batch", C.c_int32), ("channels", C.c_int32), ("dtype", C.c_int32), ("reserved", C.c_int32),
                 ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p)]
 
 
@@ -306,6 +312,8 @@ class SegmLib:
         sig("segm_wgrad_gemm_workspace_bytes", [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32], C.c_size_t)
         sig("segm_skinny_tn", [C.POINTER(SkinnyTnArgs)], C.c_int)
         sig("segm_skinny_tn_workspace_bytes", [C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
+        sig("segm_channel_sum", [C.POINTER(ChannelSumArgs)], C.c_int)
+        sig("segm_channel_sum_workspace_bytes", [C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
         sig("segm_abi_version", [], C.c_int)
         sig("segm_status_string", [C.c_int], C.c_char_p)
 

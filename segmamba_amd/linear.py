@@ -67,6 +67,20 @@ def _split(K: int) -> int:
 _SKINNY = os.environ.get("SEGM_SKINNY_TN", "1") == "1"
 
 
+_CHSUM = os.environ.get("SEGM_CHANNEL_SUM_HIP", "1") == "1"
+
+
+def bias_grad(dy: torch.Tensor) -> torch.Tensor:
+    """sum of dy (B, C, *spatial) over the batch and the voxels, fp32: a convolution's bias gradient.  The library's streaming
+    reduction where the rows are unit-stride runs on the device (ATen's generic reduction reads these tensors at 0.3 - 0.7 TB/s),
+    `dy.sum` otherwise."""
+    if _CHSUM and _on_device(dy):
+        from . import lib as L, ops_raw
+        if ops_raw.channel_sum_supported(dy):
+            return ops_raw.channel_sum(L.get_lib(), dy)
+    return dy.sum([0] + list(range(2, dy.dim())), dtype=torch.float32)
+
+
 def tn_matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a^T b for tall operands a (K, M), b (K, N), K >> M, N; fp32 result.  Row slices / column slices of larger
     matrices are fine (only views are taken)."""
@@ -192,7 +206,7 @@ class _Pointwise(torch.autograd.Function):
                     dys = dys.contiguous()
                 dw = sum(tn_matmul(dys[i], xs[i]) for i in range(x.shape[0])).to(ctx.w_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2), dtype=torch.float32).to(ctx.b_dtype)
+            db = bias_grad(dy).to(ctx.b_dtype)
         return dx, dw, db
 
 
@@ -237,7 +251,7 @@ class _PointwiseCat(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dws.append(nt_matmul_rows(dy, x))
         dw = torch.cat(dws, dim=1).to(ctx.w_dtype) if ctx.needs_input_grad[0] else None
-        db = dy.sum((0, 2), dtype=torch.float32).to(ctx.b_dtype) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        db = bias_grad(dy).to(ctx.b_dtype) if ctx.has_bias and ctx.needs_input_grad[1] else None
         return (dw, db, *dxs)
 
 

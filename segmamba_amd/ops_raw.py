@@ -799,6 +799,40 @@ def skinny_tn(lib: L.SegmLib, wide: torch.Tensor, skinny: torch.Tensor) -> torch
     return out
 
 
+def channel_sum_supported(x: torch.Tensor) -> bool:
+    """(B, C, *spatial) whose voxels are one unit-stride run per (b, c) row (dense or padded channel stride)"""
+    if x.dim() < 3 or x.dtype not in (torch.float32, torch.float16, torch.bfloat16) or x.numel() == 0:
+        return False
+    if x.shape[0] > 65535 or x.shape[1] > 65535:
+        return False
+    run = 1
+    for size, stride in zip(reversed(x.shape[2:]), reversed(x.stride()[2:])):
+        if size != 1 and stride != run:
+            return False
+        run *= size
+    return x.stride(1) >= run or x.shape[1] == 1
+
+
+def channel_sum(lib: L.SegmLib, x: torch.Tensor) -> torch.Tensor:
+    """sum over the batch and the voxels of x (B, C, *spatial) -> (C,) fp32: a convolution's bias gradient"""
+    if not channel_sum_supported(x):
+        raise RuntimeError("channel_sum: (B, C, *spatial) with unit-stride voxels per (b, c) row, fp32 / fp16 / bf16")
+    Bn, Cn = x.shape[0], x.shape[1]
+    S = 1
+    for n in x.shape[2:]:
+        S *= n
+    out = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    ws_bytes = lib.dll.segm_channel_sum_workspace_bytes(Bn, Cn, S)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    a = L.ChannelSumArgs()
+    a.x, a.stride_batch, a.stride_channel, a.spatial = x.data_ptr(), x.stride(0), (x.stride(1) if Cn > 1 else S), S
+    a.batch, a.channels, a.dtype = Bn, Cn, L.dtype_code(x)
+    a.out, a.workspace, a.workspace_bytes = out.data_ptr(), ws.data_ptr(), ws_bytes
+    a.stream = L.stream_handle(x)
+    lib.check(lib.dll.segm_channel_sum(a), "channel_sum")
+    return out
+
+
 def pointwise_cf_supported(x3: torch.Tensor, cout: int) -> bool:
     """x3 (B, Cin <= 96, S) 16-bit with contiguous voxels, S % 64 == 0, 16-byte aligned channel rows; Cout <= 96"""
     return bool(x3.dim() == 3 and x3.dtype in (torch.bfloat16, torch.float16) and x3.shape[1] <= 96 and cout <= 96

@@ -173,31 +173,34 @@ def scan_tolerances(dtype):
     return t, t, t, t
 
 
-def check_scan(res, ref, dtype, what=""):
+def check_scan(res, ref, dtype, what="", elem_scale=1.0):
     """|err| <= tol * |ref| + tol * S per element, tol = the north-star bound of the dtype.  S = 1 for the per-element
     outputs (out, last state, du, ddelta, dz, dB, dC - values of order 1 ... 10 on the test distributions) and
     S = max |ref| for the reductions over batch x time (dA, dD, ddelta_bias), whose magnitude grows with the sequence
-    length (fp32 accumulation order differs from the oracle's)."""
+    length (fp32 accumulation order differs from the oracle's).  `elem_scale` multiplies the absolute term of the per-element
+    outputs for cases whose values are NOT of order 1 ... 10 (L = 2^24 in fp32: |out| reaches 1.3e3 and rounding over 16.7 M
+    steps is relative to that magnitude)."""
     t = north_star_tol(dtype)
+    ta = t * elem_scale
 
     def red(k):
         return t * max(1.0, float(ref[k].abs().max()))
 
-    assert_close(res["out"], ref["out"], t, t, what + " out")
+    assert_close(res["out"], ref["out"], t, ta, what + " out")
     if res.get("last_state") is not None and ref.get("last_state") is not None:
-        assert_close(res["last_state"], ref["last_state"], t, t, what + " last_state")
+        assert_close(res["last_state"], ref["last_state"], t, ta, what + " last_state")
     if "du" not in res:
         return
-    assert_close(res["du"], ref["du"], t, t, what + " du")
-    assert_close(res["ddelta"], ref["ddelta"], t, t, what + " ddelta")
+    assert_close(res["du"], ref["du"], t, ta, what + " du")
+    assert_close(res["ddelta"], ref["ddelta"], t, ta, what + " ddelta")
     assert_close(res["dA"], ref["dA"], t, red("dA"), what + " dA")
     if ref.get("dB") is not None:
-        assert_close(res["dB"], ref["dB"], t, t, what + " dB")
-        assert_close(res["dC"], ref["dC"], t, t, what + " dC")
+        assert_close(res["dB"], ref["dB"], t, ta, what + " dB")
+        assert_close(res["dC"], ref["dC"], t, ta, what + " dC")
     if ref.get("dD") is not None:
         assert_close(res["dD"], ref["dD"], t, red("dD"), what + " dD")
     if ref.get("dz") is not None:
-        assert_close(res["dz"], ref["dz"], t, t, what + " dz")
+        assert_close(res["dz"], ref["dz"], t, ta, what + " dz")
     if ref.get("ddelta_bias") is not None:
         assert_close(res["ddelta_bias"], ref["ddelta_bias"], t, red("ddelta_bias"), what + " ddelta_bias")
 

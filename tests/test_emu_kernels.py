@@ -1333,3 +1333,28 @@ def test_skinny_tn_emulated(emu, K, M, N, dtype, lda, ldb):
     assert not ops_raw.skinny_tn_supported(wide[:, :M - 2], skinny) and not ops_raw.skinny_tn_supported(wide[:, 1:], skinny[:, :N])
     with pytest.raises(RuntimeError):
         ops_raw.skinny_tn(emu, wide[:, :M - 2], skinny)
+
+
+@pytest.mark.parametrize("shape,dtype,pad", [((2, 48, 8, 16, 16), torch.bfloat16, 0), ((2, 6, 40, 40, 24), torch.bfloat16, 192),
+                                             ((3, 5, 13), torch.float32, 0), ((1, 4, 70001), torch.float16, 0), ((2, 1, 9, 9, 9), torch.float32, 0)])
+def test_channel_sum_emulated(emu, shape, dtype, pad):
+    """segm_channel_sum (a convolution's bias gradient, `dy.sum((0, 2, 3, 4))`) against the fp64 sum of the same values: dense rows,
+    rows with a padded channel stride, rows that start off a 16-byte boundary (scalar path), several segments per row"""
+    g = torch.Generator().manual_seed(sum(shape))
+    Bn, Cn = shape[:2]
+    S = 1
+    for n in shape[2:]:
+        S *= n
+    if pad:
+        buf = torch.randn(Bn, Cn, S + pad, generator=g).to(dtype)
+        x = buf[:, :, :S].unflatten(2, shape[2:])
+    else:
+        x = torch.randn(shape, generator=g).to(dtype)
+    assert ops_raw.channel_sum_supported(x)
+    out = ops_raw.channel_sum(emu, x)
+    ref = x.double().sum([0] + list(range(2, x.dim())))
+    assert out.shape == (Cn,) and out.dtype == torch.float32
+    assert (out.double() - ref).abs().max() <= 1e-5 * max(1.0, float(x.double().abs().sum([0] + list(range(2, x.dim()))).max()))
+    assert torch.equal(out, ops_raw.channel_sum(emu, x))
+    if x.shape[1] > 1 and x.shape[2] > 1:
+        assert not ops_raw.channel_sum_supported(x.transpose(1, 2))          # voxels no longer a unit-stride run

@@ -52,7 +52,7 @@ def _back(t, order, ns):
     return H.iperm(t, order, ns).transpose(1, 2)
 
 
-def _run_and_check(hip, c, dtype, order, ns, what, ch=None, want_bc=True):
+def _run_and_check(hip, c, dtype, order, ns, what, ch=None, want_bc=True, elem_scale=None):
     f = ops_raw.scan_fwd(hip, c["u"], c["delta"], c["A"], c["B"], c["C"], c["D"], c["z"], c["delta_bias"], True,
                          channel_last=True, time_order=order, nslices=ns, need_out=True, need_ckpt=True, need_last_state=True)
     r = ops_raw.scan_bwd(hip, c["u"], c["delta"], c["A"], c["B"], c["C"], c["D"], c["z"], c["delta_bias"], c["g"], f["out"],
@@ -74,7 +74,7 @@ def _run_and_check(hip, c, dtype, order, ns, what, ch=None, want_bc=True):
     if want_bc:
         res["dB"], res["dC"] = r["dB"], r["dC"]
         ref["dB"], ref["dC"] = _back(ob["dB"], order, ns), _back(ob["dC"], order, ns)
-    H.check_scan(res, ref, dtype, what)
+    H.check_scan(res, ref, dtype, what, elem_scale=elem_scale(ref) if elem_scale else 1.0)
 
 
 @pytest.mark.parametrize("order,dtype", [(L.TIME_FORWARD, torch.float32), (L.TIME_REVERSED, torch.float32),
@@ -104,4 +104,9 @@ def test_config4_sixteen_million_steps_fp32_reversed(hip):
     kernels address from the lowest row ONE wave touches (scan_fast.h), so only the rows of a wave must fit 32 bits; time-reversed
     so that the descending offsets are exercised at that size too."""
     c = _case(1, 96, 16, 1 << 24, torch.float32, seed=25)
-    _run_and_check(hip, c, torch.float32, L.TIME_REVERSED, 1, "config4 L=2^24 fp32 reversed ch 0:32", ch=slice(0, 32), want_bc=False)
+    # |out| reaches 1.3e3 in this case (every other case: order 1 ... 10) and fp32 rounding over 16.7 M steps is relative to the
+    # magnitude of the running state, so the absolute term of the 1e-3 bound is scaled by max|out| / 64: 2e-5 of the signal
+    # (measured: max |err| 1.2e-2 against the fp64 oracle - bit-identical before and after the round-3 rewrite of the forward row streams,
+    # profiles/r03_fp32_2p24_ab.log)
+    _run_and_check(hip, c, torch.float32, L.TIME_REVERSED, 1, "config4 L=2^24 fp32 reversed ch 0:32", ch=slice(0, 32), want_bc=False,
+                   elem_scale=lambda ref: max(1.0, float(ref["out"].abs().max()) / 64.0))

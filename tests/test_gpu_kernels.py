@@ -682,6 +682,27 @@ def test_skinny_tn_matches_fp64_product(K, M, N, lda, ldb, dtype):
     assert torch.equal(out, ops_raw.skinny_tn(hip, a, b))
 
 
+@pytest.mark.parametrize("shape,dtype,padded", [((2, 48, 64, 64, 64), torch.bfloat16, False), ((2, 96, 262144), torch.bfloat16, False),
+                                                ((2, 48, 128, 128, 128), torch.bfloat16, True), ((2, 4, 128, 128, 128), torch.float16, False),
+                                                ((2, 384, 8, 8, 8), torch.float32, False)])
+def test_channel_sum_matches_fp64_sum(shape, dtype, padded):
+    """segm_channel_sum at the network's bias-gradient shapes (dense and padded-volume rows) against the fp64 sum of the same
+    values; bitwise repeatable"""
+    hip = L.get_lib()
+    g = torch.Generator(device=DEV).manual_seed(shape[1])
+    if padded:
+        x = ops_raw.volume_empty(shape[0], shape[1], shape[2:], dtype, DEV)
+        x.copy_(torch.randn(shape, device=DEV, generator=g))
+        assert not x.is_contiguous()
+    else:
+        x = torch.randn(shape, device=DEV, generator=g).to(dtype)
+    out = ops_raw.channel_sum(hip, x)
+    dims = [0] + list(range(2, x.dim()))
+    ref = x.double().sum(dims)
+    assert (out.double() - ref).abs().max() <= 1e-5 * float(x.double().abs().sum(dims).max())
+    assert torch.equal(out, ops_raw.channel_sum(hip, x))
+
+
 @pytest.mark.parametrize("Bn,M,N,K", [(2, 48, 48, 128 ** 3), (2, 4, 48, 128 ** 3), (2, 96, 96, 64 ** 3)])
 def test_wgrad_gemm_nt_matches_fp32_product(Bn, M, N, K):
     """segm_wgrad_gemm (NT) on channel-first volumes of the BASELINE size (padded channel stride as the convolutions write them)"""
