@@ -7,16 +7,21 @@
 Step = one training step of BASELINE config 2/3: SegMamba(4 -> 4, depths [2,2,2,2], widths [48,96,192,384]) on a
 synthetic BraTS batch of 2 volumes of 128x128x128x4 per GPU, bf16 autocast, cross-entropy loss, backward, gradient
 clip 12, SGD(lr 1e-2, momentum 0.99, nesterov, wd 3e-5) step - the loop body of the reference trainer
-(light_training/trainer.py:445-470, 3_train.py:51-66).  N > 1: one process per GPU, DistributedDataParallel over RCCL
-(the reference's wrapper, trainer.py:353-357, with find_unused_parameters=False, gradient_as_bucket_view=True and 64 MB
-buckets - stated in `config.ddp`), batch per GPU fixed (weak scaling).  `--gpus N` without a torchrun environment
+(light_training/trainer.py:445-470, 3_train.py:51-66).  The forward + backward of a step replay as one captured HIP graph
+(`--no-graph` / SEGM_GRAPH=0: eager launches; `config.launch` says which ran).  N > 1: one process per GPU over RCCL, batch per
+GPU fixed (weak scaling); the gradients of a step are ONE flat fp32 array that is all-reduced in a single call (default), or
+SEGM_DDP=torch wraps the model in DistributedDataParallel as the reference does (trainer.py:353-357; find_unused_parameters
+off, 64 MB buckets as gradient views).  `config.ddp` states the mode, the RCCL version, per-rank step times and the measured
+all-reduce time.  `--gpus N` without a torchrun environment
 re-executes itself through `python -m torch.distributed.run --nproc-per-node N` (as the reference's launch.py:89-108
 does with torchrun); under torchrun WORLD_SIZE must equal --gpus.
 
 Rank 0 prints ONE JSON line.  `value` = volumes / s over all GPUs.  `roofline` = the selective-scan forward at
 SegMamba's largest stage (B=2, D=96, N=16, L=64^3, same dtype as the step): algorithmic bytes (SURVEY.md §8d:
-e*B*L*(5D+2N)) / its measured duration (HIP events on the launch stream), against 8 TB/s HBM; the backward is reported
-next to it.  `traffic` = HBM-side bytes of one forward launch from rocprofv3 PMC counters (FETCH_SIZE + WRITE_SIZE,
+e*B*L*(5D+2N)) / its measured duration (HIP events on the launch stream), against 8 TB/s HBM; the backward, the
+three-directions-per-launch form the training step uses and `valu` (the same launch against the instruction-issue bound that
+actually limits it) are reported next to it; `roofline_fp32` repeats it with fp32 I/O.  `config1` / `config4` = BASELINE's other
+two measured configurations (one Mamba block at 2 x 64^3 x 384; scans of 2^21 and 2^24 steps).  `traffic` = HBM-side bytes of one forward launch from rocprofv3 PMC counters (FETCH_SIZE + WRITE_SIZE,
 separate passes, calibrated on kernels with known byte counts), read from profiles/scan_traffic.json - the file
 tools/gpu_pmc_traffic.sh regenerates together with the commit it was measured at (counters cannot be read from inside
 the timed process); null when the file does not cover the dtype.  `cpu_baseline` = the CPU oracle timed on this box's

@@ -3,7 +3,7 @@
 // scan_fwd.hip handles every shape: ragged chunk tails, padded channel tiles, arbitrary slice counts.  That generality
 // costs instructions the SegMamba shapes never need - per-lane time-index arithmetic, bounds masks and the selects that
 // apply them are ~45 % of the issue slots of its apply kernel (tools/isa_mix.py), and the kernel is VALU-issue bound
-// (profiles/r01_probe_valu.log: v_exp_f32 is half rate, nothing co-issues).  When
+// (nothing co-issues with a v_exp_f32).  When
 //     nstate == 16,  dim % RW == 0,  L % chunk == 0,  nchunks % (64/RW) == 0,  and the time order is affine inside a
 //     sub-tile and identical for every work item  (FORWARD / REVERSED always; INTERLEAVED when nslices % 8 == 0 and
 //     chunk % nslices == 0)
@@ -11,7 +11,15 @@
 //   * address = wave-uniform base (SGPR arithmetic: batch, sub-tile, step) + one per-lane byte offset that is constant
 //     for the whole kernel - no per-access VALU address math, no masks;
 //   * the 16-state update runs on packed fp32 (v_pk_mul_f32 / v_pk_fma_f32: two states per instruction), which halves
-//     the non-transcendental issue slots of a step:  per state pair  2 v_exp + 2 v_pk_mul + 1 (agg) or 2 (apply) v_pk_fma.
+//     the non-transcendental issue slots of a step:  per state pair  2 v_exp + 2 v_pk_mul + 1 (agg) or 2 (apply) v_pk_fma;
+//   * (round 3) the row streams u / delta / z are rings of 8 registers each: a step consumes its value and refills the register
+//     with the same step of the next sub-tile (no second copy of the sub-tile: apply 134 -> 94 VGPRs), the B / C stage loads are
+//     the oldest loads on both paths into the loop (no vmcnt(0) at the loop head), the per-step flags are template arguments
+//     for the two combinations training and inference use, and broadcast operands of packed instructions are real pairs (an
+//     op_sel broadcast reads the odd register of its pair, which may be a ring load in flight).  None of this changed the time:
+//     the kernels are bound by the instructions a SIMD issues, ~4.4 cycles each (9 for v_exp / v_log / v_rcp) at any occupancy -
+//     340 / 520 cycles per wave-step for the 72 / 118 instructions of the two passes (profiles/r03_scan_occupancy.log,
+//     r03_probe_valu3.log, r03_scan_ablations.log).
 // Results are bit-identical in structure to the general kernels (same operation order per state), so the backward pass
 // and the checkpoint format are unchanged.
 #include <stdlib.h>
@@ -216,8 +224,8 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
             f2 dl2 = {dl, dl}, dlu2 = {dl * uu, dl * uu};      // real pairs, not op_sel broadcasts (see the aggregate kernel)
             SEGM_PIN_F2(dl2);
             SEGM_PIN_F2(dlu2);
-            // this step's B / C rows (wave-uniform addresses: LDS broadcast reads); with 3 waves per SIMD resident the
-            // read latency is covered by the other waves, so nothing is prefetched into registers
+            // this step's B / C rows (wave-uniform addresses: LDS broadcast reads, 4 LDS cycles each); the read latency is covered
+            // by the other resident waves, so nothing is prefetched into registers
             float4 bq[4], cq[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
