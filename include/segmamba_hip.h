@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SEGM_ABI_VERSION 3
+#define SEGM_ABI_VERSION 4
 
 enum segm_dtype { SEGM_F32 = 0, SEGM_F16 = 1, SEGM_BF16 = 2 };
 enum segm_time_order { SEGM_TIME_FORWARD = 0, SEGM_TIME_REVERSED = 1, SEGM_TIME_INTERLEAVED = 2 };
@@ -103,6 +103,15 @@ typedef struct segm_scan_fwd_args {
     void* workspace;          /* segm_selective_scan_fwd_workspace_bytes()                           */
     size_t workspace_bytes;
     void* stream;
+    /* Optional (ABI 4): the causal depthwise conv1d + SiLU in front of the scan computed INSIDE the scan launches ("causal
+     * depthwise conv1d fused into the same launch").  conv_width 0 = off.  With conv_width in [2, 4], `u` is the conv INPUT x and
+     * every pass forms u_t = SiLU(conv_bias + sum_k conv_weight[d][k] x[t - (width-1-k)]) along this call's time order, rounded to
+     * the element type exactly as segm_causal_conv1d_fwd stores it (results are bit-identical to conv1d followed by the scan).
+     * Regular shapes with delta_softplus and a gate z only (SEGM_E_SHAPE otherwise).  Measured slower than the separate conv1d
+     * launch on MI355X (the scan passes are bound by instructions issued): opt-in, see DESIGN.md section 0 row N1. */
+    const float* conv_weight; /* (dim, conv_width) contiguous fp32                                  */
+    const float* conv_bias;   /* (dim) fp32 or NULL                                                  */
+    int32_t conv_width, reserved2;
 } segm_scan_fwd_args;
 
 int segm_selective_scan_fwd(const segm_scan_fwd_args* args);

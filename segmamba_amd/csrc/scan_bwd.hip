@@ -443,6 +443,7 @@ static int scan_bwd_one(const segm_scan_bwd_args* b, ScanDev* batched) {
     int rc = validate_scan_common(a);
     if (rc != SEGM_OK) return rc;
     if (a->chunk <= 0) return SEGM_E_SHAPE;                 // must be the forward's chunk
+    if (a->conv_width != 0) return SEGM_E_SHAPE;            // the backward takes the conv OUTPUT as u (forward-only option)
     if (!a->ckpt || !b->dout.ptr || !b->du.ptr || !b->ddelta.ptr || !b->dA || !b->dB.ptr || !b->dC.ptr) return SEGM_E_NULL;
     if (a->z.ptr && (!b->dz.ptr || !a->out.ptr)) return SEGM_E_NULL;
     const segm_seq* sv[4] = {&b->dout, &b->du, &b->ddelta, &b->dz};

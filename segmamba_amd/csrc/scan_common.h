@@ -33,6 +33,10 @@ struct ScanDev {
     float* dC;  int64_t dC_sb, dC_st, dC_sn;
     float* part;                           // [batch][nchunks][nstate + 2][dim]  per-item dA / dD / ddelta_bias partials
     int32_t atomic_bc;                     // more than one d-tile contributes to dB / dC -> accumulate atomically
+    // forward, optional: u = SiLU(conv1d(x) + b) formed inside the passes (`u` then holds x); conv_width 0 = off
+    const float* conv_w;                   // (dim, conv_width)
+    const float* conv_b;                   // (dim) or null
+    int32_t conv_width;
 };
 
 // up to three launches of ONE geometry (the three directions of a Mamba v3 layer: same shapes, different time order,

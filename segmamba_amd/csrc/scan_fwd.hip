@@ -591,6 +591,12 @@ static int scan_fwd_one(const segm_scan_fwd_args* a, ScanDev* batched) {
         const bool fast = use_fast_path() && scan_fast_shape(P);
         rc = validate_spans(sv, 5, bv, 2, a->dim, a->dstate, a->seqlen, dtype_size(a->dtype), fast ? fast_span_rows(P) : 0);
         if (rc != SEGM_OK) return rc;
+        if (a->conv_width != 0) {                          // conv1d + SiLU inside the passes: regular-shape kernels, training / inference flags
+            if (a->conv_width < 2 || a->conv_width > 4) return SEGM_E_WIDTH;
+            if (!a->conv_weight) return SEGM_E_NULL;
+            if (!fast || G != 1 || !a->delta_softplus || !a->z.ptr) return SEGM_E_SHAPE;
+            P.conv_w = a->conv_weight; P.conv_b = a->conv_bias; P.conv_width = a->conv_width;
+        }
         if (batched) {
             if (!fast || G != 1) return SEGM_E_SHAPE;       // the caller falls back to one launch per block
             *batched = P;
@@ -616,7 +622,7 @@ namespace segm {
 // true when the launches share geometry, element type and stream, i.e. can be ONE grid with a direction axis
 bool scan_same_launch(const segm_scan_fwd_args* a, const segm_scan_fwd_args* b) {
     return a->batch == b->batch && a->dim == b->dim && a->dstate == b->dstate && a->n_groups == 1 && b->n_groups == 1 &&
-           a->seqlen == b->seqlen && a->dtype == b->dtype && a->stream == b->stream &&
+           a->seqlen == b->seqlen && a->dtype == b->dtype && a->stream == b->stream && a->conv_width == b->conv_width &&
            (a->chunk > 0 ? a->chunk : default_chunk(a->batch, a->dim, a->seqlen)) ==
                (b->chunk > 0 ? b->chunk : default_chunk(b->batch, b->dim, b->seqlen));
 }

@@ -33,7 +33,46 @@ namespace segm {
 // ------------------------------------------------------------------------------------------------------
 // MODE: what the per-step flags are known to be at compile time (they are wave-uniform branches in every step otherwise):
 //   0 = read from the arguments,  1 = softplus + gate z + un-gated output kept (training),  2 = softplus + gate z (inference)
-template <typename T, int RW, int MODE>
+// FUSED: `u` holds the INPUT of the causal depthwise conv1d; u_t = SiLU(conv(x)_t + b) is formed here, step by step, from the last
+// four inputs (conv_step below) - the north star's "causal depthwise conv1d fused into the same launch".  Opt-in: it adds ~9 vector
+// and 2 transcendental instructions per step to passes that are bound by instructions issued, and the conv output is needed in
+// memory anyway (x_proj reads all of its channels before any scan step can start).
+struct ConvTaps { float w0, w1, w2, w3, b; };            // taps of x[t-3], x[t-2], x[t-1], x[t] (leading ones zero for width < 4)
+template <typename T>
+__device__ __forceinline__ float conv_step(const ConvTaps& k, float xt, float& xm1, float& xm2, float& xm3) {
+    float o = fmaf(k.w3, xt, k.b);                         // the operation order of conv1d_fwd_kernel: bit-identical results
+    o = fmaf(k.w0, xm3, o);
+    o = fmaf(k.w1, xm2, o);
+    o = fmaf(k.w2, xm1, o);
+    xm3 = xm2; xm2 = xm1; xm1 = xt;
+    o = o * sigmoidf(o);
+    return to_f32(from_f32<T>(o));                         // as stored by the separate launch
+}
+// taps of channel d and the three inputs in front of the chunk that starts at logical step tau0 (zero before the sequence)
+template <typename T>
+__device__ __forceinline__ void conv_init(const ScanDev& P, const Item& it, int32_t tau0, ConvTaps& k, float& xm1, float& xm2, float& xm3) {
+    const int W = P.conv_width;
+    const float* wr = P.conv_w + (int64_t)it.d * W;
+    k.w3 = wr[W - 1];
+    k.w2 = W >= 2 ? wr[W - 2] : 0.f;
+    k.w1 = W >= 3 ? wr[W - 3] : 0.f;
+    k.w0 = W >= 4 ? wr[W - 4] : 0.f;
+    k.b = P.conv_b ? P.conv_b[it.d] : 0.f;
+    TimeIter ti;
+    ti.seek(P.tm, tau0);
+    float h[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ti.prev(P.tm);
+        const bool ok = tau0 - 1 - i >= 0;
+        const int64_t off = (int64_t)it.b * P.u.sb + row_off(ok ? ti.t : 0, P.u.st) + (int64_t)it.d * P.u.sd;
+        const float v = to_f32(reinterpret_cast<const T*>(P.u.p)[off]);
+        h[i] = ok ? v : 0.f;
+    }
+    xm1 = h[0]; xm2 = h[1]; xm3 = h[2];
+}
+
+template <typename T, int RW, int MODE, bool FUSED>
 __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) {
     constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     __shared__ __attribute__((aligned(16))) float s_b[2][kWavesPerBlock][G][kFT * kFS];
@@ -58,6 +97,9 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
     const Stream up = make_stream<T>(P.u, ub, wr, it.d);
     const Stream dp = make_stream<T>(P.delta, ub, wr, it.d);
     const StageStream<RW> sb = make_stage<T, RW>(P.Bm, ub, wr, it.r);
+    ConvTaps ck4 = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float xm1 = 0.f, xm2 = 0.f, xm3 = 0.f;
+    if constexpr (FUSED) conv_init<T>(P, it, it.chunk * gm.chunk, ck4, xm1, xm2, xm3);
 
     // the B rows first: at the loop head they are then the oldest loads on both paths into it (vmcnt is in order, and the
     // compiler merges the pending-load state of the prologue with that of the back edge - with the stage loads issued last here
@@ -87,12 +129,13 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
         for (int q = 0; q < 4; ++q) bq[q] = reinterpret_cast<const float4*>(lb)[q];
 #pragma unroll
         for (int j = 0; j < kFT; ++j) {
-            const float uu = nu[j];
+            float uu = nu[j];
             float dl = nd[j] + bias;
             nu[j] = BufIO<T>::ld(up.rs, up.voff, su);
             nd[j] = BufIO<T>::ld(dp.rs, dp.voff, sd);
             su += iu;
             sd += id;
+            if constexpr (FUSED) uu = conv_step<T>(ck4, uu, xm1, xm2, xm3);
             dl = softplus_on ? softplus20(dl) : dl;
             sumd += dl;
             // both halves written: a packed operand with op_sel broadcast reads the odd register of its pair too, and that register
@@ -135,7 +178,7 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
 // ------------------------------------------------------------------------------------------------------
 // K3 (regular shapes): apply
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int RW, int MODE>
+template <typename T, int RW, int MODE, bool FUSED>
 __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fast_kernel(ScanDevN PP) {
     constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     __shared__ __attribute__((aligned(16))) float s_bc[2][kWavesPerBlock][G][2][kFT * kFS];
@@ -161,6 +204,9 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
     }
     const float bias = P.delta_bias ? P.delta_bias[it.d] : 0.f;
     const float Dv = P.D ? P.D[it.d] : 0.f;
+    ConvTaps ck4 = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float xm1 = 0.f, xm2 = 0.f, xm3 = 0.f;
+    if constexpr (FUSED) conv_init<T>(P, it, tau0, ck4, xm1, xm2, xm3);
     const Stream up = make_stream<T>(P.u, ub, wr, it.d);
     const Stream dp = make_stream<T>(P.delta, ub, wr, it.d);
     const Stream zp = make_stream<T>(has_z ? P.z : P.u, ub, wr, it.d);            // without a gate: aliases u, unused
@@ -212,7 +258,8 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
         const uint32_t oinc = (uint32_t)(wr.dT * op.stb), ozinc = (uint32_t)(wr.dT * ozp.stb);
 #pragma unroll
         for (int j = 0; j < kFT; ++j) {
-            const float uu = nu[j], zz = nz[j];
+            float uu = nu[j];
+            const float zz = nz[j];
             float dl = nd[j] + bias;
             nu[j] = BufIO<T>::ld(up.rs, up.voff, su);
             nd[j] = BufIO<T>::ld(dp.rs, dp.voff, sd);
@@ -220,6 +267,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
             su += iu;
             sd += id;
             sz += iz;
+            if constexpr (FUSED) uu = conv_step<T>(ck4, uu, xm1, xm2, xm3);
             dl = softplus_on ? softplus20(dl) : dl;
             f2 dl2 = {dl, dl}, dlu2 = {dl * uu, dl * uu};      // real pairs, not op_sel broadcasts (see the aggregate kernel)
             SEGM_PIN_F2(dl2);
@@ -270,11 +318,11 @@ bool scan_fast_shape(const ScanDev& P) {
     return true;
 }
 
-template <typename T, int RW, int MODE>
+template <typename T, int RW, int MODE, bool FUSED>
 static void launch_fast_mode(const ScanDevN& PP, int ndir, bool apply, hipStream_t stream) {
     const unsigned nblocks = (unsigned)((PP.d[0].gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (apply) hipLaunchKernelGGL((scan_fwd_apply_fast_kernel<T, RW, MODE>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
-    else hipLaunchKernelGGL((scan_fwd_agg_fast_kernel<T, RW, MODE>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+    if (apply) hipLaunchKernelGGL((scan_fwd_apply_fast_kernel<T, RW, MODE, FUSED>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+    else hipLaunchKernelGGL((scan_fwd_agg_fast_kernel<T, RW, MODE, FUSED>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
 }
 // the compile-time flag set every direction of the launch agrees with (0 = none: flags read per step)
 static int fast_mode(const ScanDevN& PP, int ndir, bool apply) {
@@ -293,10 +341,16 @@ static int fast_mode(const ScanDevN& PP, int ndir, bool apply) {
 template <typename T, int RW>
 static void launch_fast_rw(const ScanDevN& PP, int ndir, bool apply, hipStream_t stream) {
     const int mode = fast_mode(PP, ndir, apply);
-    if (mode == 1) launch_fast_mode<T, RW, 1>(PP, ndir, apply, stream);
-    else if (mode == 2 && apply) launch_fast_mode<T, RW, 2>(PP, ndir, apply, stream);
-    else if (mode == 2) launch_fast_mode<T, RW, 1>(PP, ndir, apply, stream);          // the aggregate pass only has the softplus flag
-    else launch_fast_mode<T, RW, 0>(PP, ndir, apply, stream);
+    if (PP.d[0].conv_width != 0) {                         // conv1d inside the passes
+        if (mode == 1 || (mode == 2 && !apply)) launch_fast_mode<T, RW, 1, true>(PP, ndir, apply, stream);
+        else if (mode == 2) launch_fast_mode<T, RW, 2, true>(PP, ndir, apply, stream);
+        else launch_fast_mode<T, RW, 0, true>(PP, ndir, apply, stream);
+        return;
+    }
+    if (mode == 1) launch_fast_mode<T, RW, 1, false>(PP, ndir, apply, stream);
+    else if (mode == 2 && apply) launch_fast_mode<T, RW, 2, false>(PP, ndir, apply, stream);
+    else if (mode == 2) launch_fast_mode<T, RW, 1, false>(PP, ndir, apply, stream);          // the aggregate pass only has the softplus flag
+    else launch_fast_mode<T, RW, 0, false>(PP, ndir, apply, stream);
 }
 template <typename T>
 static void launch_fast_t(const ScanDevN& PP, int ndir, bool apply, hipStream_t stream) {

@@ -52,6 +52,7 @@ class ScanFwdArgs(C.Structure):
         ("last_state", C.c_void_p), ("ckpt", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("stream", C.c_void_p),
+        ("conv_weight", C.c_void_p), ("conv_bias", C.c_void_p), ("conv_width", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 

@@ -98,16 +98,30 @@ def _fill_scan_args(a: L.ScanFwdArgs, u, delta, A, B, C, D, z, delta_bias, delta
 
 def scan_fwd(lib: L.SegmLib, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *,
              channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, need_out=True,
-             need_ckpt=False, need_last_state=False, ckpt_buf=None):
+             need_ckpt=False, need_last_state=False, ckpt_buf=None, conv_weight=None, conv_bias=None):
     """-> dict(out, out_z, ckpt, last_state, chunk).  `out` is the un-gated y (None unless need_out or z is None).
-    `ckpt_buf`: a caller-owned fp32 buffer of segm_selective_scan_ckpt_bytes() for the checkpoints."""
+    `ckpt_buf`: a caller-owned fp32 buffer of segm_selective_scan_ckpt_bytes() for the checkpoints.
+    `conv_weight` (dim, width) [+ `conv_bias` (dim)]: the causal depthwise conv1d + SiLU in front of the scan is computed inside the
+    scan launches and `u` is its INPUT x (regular shapes with softplus and a gate only; results equal conv1d_fwd followed by the scan)."""
     a = L.ScanFwdArgs()
     r = _scan_fwd_prepare(lib, a, u, delta, A, B, C, D, z, delta_bias, delta_softplus, channel_last=channel_last,
                           time_order=time_order, nslices=nslices, chunk=chunk, need_out=need_out, need_ckpt=need_ckpt,
-                          need_last_state=need_last_state, ckpt_buf=ckpt_buf)
+                          need_last_state=need_last_state, ckpt_buf=ckpt_buf, conv_weight=conv_weight, conv_bias=conv_bias)
     lib.check(lib.dll.segm_selective_scan_fwd(a), "selective_scan_fwd")
     r.pop("_ws")
     return r
+
+
+def scan_fused_conv_supported(lib: L.SegmLib, batch: int, dim: int, seqlen: int, nslices: int, time_order: int, chunk: int = 0) -> bool:
+    """whether scan_fwd(..., conv_weight=) can run: the regular-shape kernels' conditions (16 states are the caller's business)"""
+    rw = 64 if dim % 64 == 0 else 32 if dim % 32 == 0 else 16 if dim % 16 == 0 else 0
+    if rw == 0:
+        return False
+    if chunk == 0:
+        chunk = lib.dll.segm_selective_scan_default_chunk(batch, dim, seqlen)
+    if seqlen % chunk != 0 or (seqlen // chunk) % (64 // rw) != 0 or chunk % 8 != 0:
+        return False
+    return time_order != L.TIME_INTERLEAVED or (nslices % 8 == 0 and chunk % nslices == 0)
 
 
 def scan_fwd_multi(lib: L.SegmLib, calls):
@@ -125,7 +139,7 @@ def scan_fwd_multi(lib: L.SegmLib, calls):
 
 def _scan_fwd_prepare(lib, a, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *,
                       channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, need_out=True,
-                      need_ckpt=False, need_last_state=False, ckpt_buf=None):
+                      need_ckpt=False, need_last_state=False, ckpt_buf=None, conv_weight=None, conv_bias=None):
     """fills the argument block `a` and allocates outputs / workspace; -> result dict (+ `_ws`, alive until the launch)"""
     batch, seqlen, dim, dstate, groups, B4, C4 = _fill_scan_args(
         a, u, delta, A, B, C, D, z, delta_bias, delta_softplus, channel_last, time_order, nslices, chunk)
@@ -151,7 +165,15 @@ def _scan_fwd_prepare(lib, a, u, delta, A, B, C, D=None, z=None, delta_bias=None
     a.out, a.out_z = L.seq_view(out, channel_last), L.seq_view(out_z, channel_last)
     a.last_state, a.ckpt = L.fptr(last_state), L.fptr(ckpt)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
-    return dict(out=out, out_z=out_z, ckpt=ckpt, last_state=last_state, chunk=chunk, _ws=ws)
+    keep = [ws]
+    if conv_weight is not None:
+        if conv_weight.dim() != 2 or conv_weight.shape[0] != dim or not 2 <= conv_weight.shape[1] <= 4:
+            raise RuntimeError("scan_fwd: conv_weight must be (dim, width) with width in [2, 4]")
+        cw = conv_weight.detach().to(torch.float32).contiguous()
+        cb = conv_bias.detach().to(torch.float32).contiguous() if conv_bias is not None else None
+        a.conv_weight, a.conv_bias, a.conv_width = cw.data_ptr(), L.fptr(cb), cw.shape[1]
+        keep += [cw, cb]
+    return dict(out=out, out_z=out_z, ckpt=ckpt, last_state=last_state, chunk=chunk, _ws=keep)
 
 
 def scan_bwd(lib: L.SegmLib, u, delta, A, B, C, D, z, delta_bias, dout, out, ckpt, delta_softplus, *,

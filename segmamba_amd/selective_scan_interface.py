@@ -155,6 +155,7 @@ def _scan_constant_bc(u, delta, A, B, C, D, z, delta_bias, delta_softplus, retur
 
 
 _RECOMPUTE = os.environ.get("SEGM_RECOMPUTE", "0") == "1"     # reference trade: recompute conv output / delta in backward
+_FUSED_CONV1D = os.environ.get("SEGM_SCAN_FUSED_CONV1D", "0") == "1"     # conv1d + SiLU inside the scan passes (opt-in, slower)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -347,6 +348,11 @@ class MambaInnerCore3(torch.autograd.Function):
                               D=D.float().contiguous() if D is not None else None, z=z,
                               delta_bias=dbias.float().contiguous() if dbias is not None else None, delta_softplus=True,
                               channel_last=True, time_order=MambaInnerCore3.ORDERS[i], nslices=ns, need_out=train, need_ckpt=train))
+            if _FUSED_CONV1D and ops_raw.scan_fused_conv_supported(lib, batch, dim, seqlen, ns, calls[-1]["time_order"]):
+                # the north star's "conv1d fused into the scan launch": the passes read x and form u themselves (bit-identical).
+                # conv_out is still produced above - x_proj needs every channel of it before the scan can start - so this only
+                # moves work into the instruction-bound scan passes; measured slower, hence opt-in
+                calls[-1].update(u=x, conv_weight=conv_w.reshape(dim, -1), conv_bias=conv_b)
             per_dir.append((x_dbl, xw, dtw, conv_out, delta, R, N, ns))
         rs = ops_raw.scan_fwd_multi(lib, calls)
         saved = [xz]

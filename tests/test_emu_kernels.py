@@ -1358,3 +1358,67 @@ def test_channel_sum_emulated(emu, shape, dtype, pad):
     assert torch.equal(out, ops_raw.channel_sum(emu, x))
     if x.shape[1] > 1 and x.shape[2] > 1:
         assert not ops_raw.channel_sum_supported(x.transpose(1, 2))          # voxels no longer a unit-stride run
+
+
+@pytest.mark.parametrize("dim,seqlen,chunk,order,ns,dtype,width", [
+    (32, 128, 32, L.TIME_FORWARD, 1, torch.float32, 4), (64, 64, 32, L.TIME_REVERSED, 1, torch.bfloat16, 4),
+    (16, 256, 64, L.TIME_INTERLEAVED, 8, torch.float32, 3), (96, 64, 32, L.TIME_INTERLEAVED, 8, torch.bfloat16, 4),
+    (32, 64, 16, L.TIME_FORWARD, 1, torch.float16, 2)])
+def test_scan_with_conv1d_inside_the_launch_emulated(emu, dim, seqlen, chunk, order, ns, dtype, width):
+    """`conv_weight=`: the causal depthwise conv1d + SiLU formed inside the two scan passes from the conv INPUT (north star: "causal
+    depthwise conv1d fused into the same launch") must equal segm_causal_conv1d_fwd followed by the scan BIT FOR BIT - output, gated
+    output and the checkpoints the backward restarts from - in all three time orders (the halo in front of a chunk follows the
+    order), for widths 2 - 4; a shape the regular kernels do not take is refused."""
+    g = torch.Generator().manual_seed(dim + seqlen + width)
+    Bn, N = 2, 16
+    rn = lambda *s: torch.randn(*s, generator=g).to(dtype)
+    x, z = rn(Bn, seqlen, dim), rn(Bn, seqlen, dim)
+    delta = (0.5 * torch.rand(Bn, seqlen, dim, generator=g)).to(dtype)
+    A = -0.5 * torch.rand(dim, N, generator=g)
+    Bm, Cm = rn(Bn, seqlen, N), rn(Bn, seqlen, N)
+    Dv, db = torch.randn(dim, generator=g), 0.5 * torch.rand(dim, generator=g)
+    cw, cb = 0.5 * torch.randn(dim, width, generator=g), 0.1 * torch.randn(dim, generator=g)
+    u = ops_raw.conv1d_fwd(emu, x, cw, cb, True, channel_last=True, time_order=order, nslices=ns)
+    kw = dict(channel_last=True, time_order=order, nslices=ns, chunk=chunk, need_out=True, need_ckpt=True, need_last_state=True)
+    ref = ops_raw.scan_fwd(emu, u, delta, A, Bm, Cm, Dv, z, db, True, **kw)
+    assert ops_raw.scan_fused_conv_supported(emu, Bn, dim, seqlen, ns, order, chunk)
+    fused = ops_raw.scan_fwd(emu, x, delta, A, Bm, Cm, Dv, z, db, True, conv_weight=cw, conv_bias=cb, **kw)
+    for k in ("out", "out_z", "ckpt", "last_state"):
+        assert torch.equal(fused[k], ref[k]), k
+    inference = ops_raw.scan_fwd(emu, x, delta, A, Bm, Cm, Dv, z, db, True, conv_weight=cw, conv_bias=cb,
+                                 **dict(kw, need_out=False, need_ckpt=False, need_last_state=False))
+    assert inference["out"] is None and torch.equal(inference["out_z"], ref["out_z"])
+    assert not ops_raw.scan_fused_conv_supported(emu, Bn, dim, seqlen - 3, ns, order, chunk)
+    with pytest.raises(RuntimeError):                      # no gate: the kernels with the conv inside are built for softplus + gate
+        ops_raw.scan_fwd(emu, x, delta, A, Bm, Cm, Dv, None, db, True, conv_weight=cw, conv_bias=cb, **kw)
+
+
+def test_mamba_block_with_conv1d_inside_the_scan_launch_on_emulated_kernels(emu, monkeypatch):
+    """SEGM_SCAN_FUSED_CONV1D=1: a Mamba(v3) block whose scan launches form u = SiLU(conv1d(x)) themselves == the default block bit
+    for bit - output, input gradient, all 23 parameter gradients (the backward is the same code: it starts from the kept conv output)."""
+    monkeypatch.setattr(L, "_lib", emu)
+    from mamba_ssm import Mamba
+    from tests.golden.make_golden import named_fill
+    from segmamba_amd import selective_scan_interface as SSI
+    m = Mamba(d_model=16, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=8)
+    m.load_state_dict(named_fill(m.state_dict()))
+    g = torch.Generator().manual_seed(4)
+    x0, dy = torch.randn(2, 64, 16, generator=g), torch.randn(2, 64, 16, generator=g)
+    seen, res = [], []
+    real = ops_raw.scan_fwd_multi
+    monkeypatch.setattr(ops_raw, "scan_fwd_multi", lambda lib, calls: (seen.append(sum("conv_weight" in c for c in calls)), real(lib, calls))[1])
+    monkeypatch.setattr(SSI.L, "on_device", lambda t: True, raising=False)
+    import segmamba_amd.mamba_simple as MS
+    monkeypatch.setattr(MS.L, "on_device", lambda t: True, raising=False)
+    for fused in (False, True):
+        monkeypatch.setattr(SSI, "_FUSED_CONV1D", fused)
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_()
+        y = m(x)
+        y.backward(dy)
+        res.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert seen == [0, 3], seen                            # all three directions took the fused form
+    (y0, gx0, gp0), (y1, gx1, gp1) = res
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+    for k in gp0:
+        assert torch.equal(gp0[k], gp1[k]), k

@@ -682,6 +682,29 @@ def test_skinny_tn_matches_fp64_product(K, M, N, lda, ldb, dtype):
     assert torch.equal(out, ops_raw.skinny_tn(hip, a, b))
 
 
+@pytest.mark.parametrize("order,ns", [(L.TIME_FORWARD, 1), (L.TIME_REVERSED, 1), (L.TIME_INTERLEAVED, 64)])
+def test_scan_with_conv1d_inside_the_launch_equals_conv1d_then_scan(order, ns):
+    """`conv_weight=` at the stage-0 size (B=2, D=96, L=64^3, bf16): the scan launches that form u = SiLU(conv1d(x) + b) themselves
+    against segm_causal_conv1d_fwd followed by the scan - bit for bit (output, gated output, checkpoints)"""
+    hip = L.get_lib()
+    g = torch.Generator(device=DEV).manual_seed(11 + order)
+    Bn, D, N, Lq = 2, 96, 16, 64 ** 3
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g).bfloat16()
+    x, z = rn(Bn, Lq, D), rn(Bn, Lq, D)
+    delta = (0.5 * torch.rand(Bn, Lq, D, device=DEV, generator=g)).bfloat16()
+    A = -0.5 * torch.rand(D, N, device=DEV, generator=g)
+    Bm, Cm = rn(Bn, Lq, N), rn(Bn, Lq, N)
+    Dv, db = torch.randn(D, device=DEV, generator=g), 0.5 * torch.rand(D, device=DEV, generator=g)
+    cw, cb = 0.5 * torch.randn(D, 4, device=DEV, generator=g), 0.1 * torch.randn(D, device=DEV, generator=g)
+    u = ops_raw.conv1d_fwd(hip, x, cw, cb, True, channel_last=True, time_order=order, nslices=ns)
+    kw = dict(channel_last=True, time_order=order, nslices=ns, need_out=True, need_ckpt=True)
+    ref = ops_raw.scan_fwd(hip, u, delta, A, Bm, Cm, Dv, z, db, True, **kw)
+    assert ops_raw.scan_fused_conv_supported(hip, Bn, D, Lq, ns, order)
+    fused = ops_raw.scan_fwd(hip, x, delta, A, Bm, Cm, Dv, z, db, True, conv_weight=cw, conv_bias=cb, **kw)
+    for k in ("out", "out_z", "ckpt"):
+        assert torch.equal(fused[k], ref[k]), k
+
+
 @pytest.mark.parametrize("shape,dtype,padded", [((2, 48, 64, 64, 64), torch.bfloat16, False), ((2, 96, 262144), torch.bfloat16, False),
                                                 ((2, 48, 128, 128, 128), torch.bfloat16, True), ((2, 4, 128, 128, 128), torch.float16, False),
                                                 ((2, 384, 8, 8, 8), torch.float32, False)])
