@@ -126,6 +126,11 @@ size_t segm_selective_scan_fwd_workspace_bytes(int32_t batch, int32_t dim, int32
 size_t segm_selective_scan_ckpt_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen);
 /* the chunk length `chunk = 0` resolves to (so callers can record it for the backward) */
 int32_t segm_selective_scan_default_chunk(int32_t batch, int32_t dim, int64_t seqlen);
+/* 1 when a scan of this geometry runs on the regular-shape kernels (dstate 16, channel count a multiple of 16 / 32 / 64, whole
+ * chunks, a time order that is affine inside 8-step sub-tiles): the condition of segm_selective_scan_{fwd,bwd}_multi sharing one
+ * grid and of the conv_weight option.  One B / C group is assumed; chunk 0 = the default chunk. */
+int32_t segm_selective_scan_regular_shape(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen, int32_t chunk,
+                                          int32_t time_order, int32_t nslices);
 
 /* ------------------------------------------------------------------------------------------------
  * Selective scan, backward.

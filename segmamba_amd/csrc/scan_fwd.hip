@@ -547,6 +547,18 @@ extern "C" int32_t segm_selective_scan_default_chunk(int32_t batch, int32_t dim,
     return default_chunk(batch, dim, seqlen);
 }
 
+extern "C" int32_t segm_selective_scan_regular_shape(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen, int32_t chunk,
+                                                     int32_t time_order, int32_t nslices) {
+    if (batch <= 0 || dim <= 0 || dstate <= 0 || seqlen <= 0 || seqlen >= ((int64_t)1 << 31)) return 0;
+    if (time_order < SEGM_TIME_FORWARD || time_order > SEGM_TIME_INTERLEAVED) return 0;
+    if (time_order == SEGM_TIME_INTERLEAVED && (nslices <= 0 || seqlen % nslices != 0)) return 0;
+    ScanDev P;
+    memset(&P, 0, sizeof(P));
+    P.gm = make_geom(batch, dim, dstate, seqlen, chunk > 0 ? chunk : default_chunk(batch, dim, seqlen));
+    P.tm = make_timemap(time_order, time_order == SEGM_TIME_INTERLEAVED ? nslices : 1, seqlen);
+    return use_fast_path() && scan_fast_shape(P) ? 1 : 0;
+}
+
 extern "C" size_t segm_selective_scan_fwd_workspace_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen,
                                                           int32_t chunk) {
     if (batch <= 0 || dim <= 0 || dstate <= 0 || seqlen <= 0) return 0;

@@ -243,7 +243,7 @@ EXPORTS = (
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
     "segm_causal_conv1d_update", "segm_selective_state_update", "segm_linear_rows", "segm_pointwise_cf", "segm_stem_conv_fwd",
     "segm_stem_conv_wgrad", "segm_stem_conv_wgrad_workspace_bytes", "segm_stem_conv_wgrad_workspace_bytes2", "segm_wgrad_gemm", "segm_wgrad_gemm_workspace_bytes",
-    "segm_skinny_tn", "segm_skinny_tn_workspace_bytes", "segm_channel_sum", "segm_channel_sum_workspace_bytes",
+    "segm_skinny_tn", "segm_skinny_tn_workspace_bytes", "segm_channel_sum", "segm_channel_sum_workspace_bytes", "segm_selective_scan_regular_shape",
     "segm_abi_version", "segm_status_string",
 )
 
@@ -313,6 +313,7 @@ class SegmLib:
         sig("segm_wgrad_gemm_workspace_bytes", [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32], C.c_size_t)
         sig("segm_skinny_tn", [C.POINTER(SkinnyTnArgs)], C.c_int)
         sig("segm_skinny_tn_workspace_bytes", [C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
+        sig("segm_selective_scan_regular_shape", [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32], C.c_int32)
         sig("segm_channel_sum", [C.POINTER(ChannelSumArgs)], C.c_int)
         sig("segm_channel_sum_workspace_bytes", [C.c_int32, C.c_int32, C.c_int64], C.c_size_t)
         sig("segm_abi_version", [], C.c_int)

@@ -112,16 +112,10 @@ def scan_fwd(lib: L.SegmLib, u, delta, A, B, C, D=None, z=None, delta_bias=None,
     return r
 
 
-def scan_fused_conv_supported(lib: L.SegmLib, batch: int, dim: int, seqlen: int, nslices: int, time_order: int, chunk: int = 0) -> bool:
-    """whether scan_fwd(..., conv_weight=) can run: the regular-shape kernels' conditions (16 states are the caller's business)"""
-    rw = 64 if dim % 64 == 0 else 32 if dim % 32 == 0 else 16 if dim % 16 == 0 else 0
-    if rw == 0:
-        return False
-    if chunk == 0:
-        chunk = lib.dll.segm_selective_scan_default_chunk(batch, dim, seqlen)
-    if seqlen % chunk != 0 or (seqlen // chunk) % (64 // rw) != 0 or chunk % 8 != 0:
-        return False
-    return time_order != L.TIME_INTERLEAVED or (nslices % 8 == 0 and chunk % nslices == 0)
+def scan_fused_conv_supported(lib: L.SegmLib, batch: int, dim: int, seqlen: int, nslices: int, time_order: int, chunk: int = 0,
+                              dstate: int = 16) -> bool:
+    """whether scan_fwd(..., conv_weight=) can run: the library's regular-shape condition"""
+    return bool(lib.dll.segm_selective_scan_regular_shape(batch, dim, dstate, seqlen, chunk, int(time_order), int(nslices)))
 
 
 def scan_fwd_multi(lib: L.SegmLib, calls):
