@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SEGM_ABI_VERSION 4
+#define SEGM_ABI_VERSION 5
 
 enum segm_dtype { SEGM_F32 = 0, SEGM_F16 = 1, SEGM_BF16 = 2 };
 enum segm_time_order { SEGM_TIME_FORWARD = 0, SEGM_TIME_REVERSED = 1, SEGM_TIME_INTERLEAVED = 2 };
@@ -150,18 +150,29 @@ typedef struct segm_scan_bwd_args {
     segm_seq dout;            /* required; gradient w.r.t. out_z (or out when no z)                    */
     segm_seq du, ddelta;      /* required                                                             */
     segm_seq dz;              /* required iff f.z.ptr                                                  */
-    segm_bc dB, dC;           /* fp32, logical (batch, group, time, state)                             */
+    segm_bc dB, dC;           /* logical (batch, group, time, state); fp32 unless dbc_native           */
     float* dA;                /* (dim, dstate) fp32                                                    */
     float* dD;                /* (dim) fp32 or NULL                                                    */
     float* ddelta_bias;       /* (dim) fp32 or NULL                                                    */
     void* workspace;          /* segm_selective_scan_bwd_workspace_bytes()                             */
     size_t workspace_bytes;
+    int32_t dbc_native;       /* ABI 5.  0: dB / dC are fp32 (the reference's accumulation buffers,
+                                 selective_scan.cpp:461-462).  1: dB / dC have f.dtype - what the reference
+                                 returns after its final cast (:488) - and are written once, finished, e.g.
+                                 straight into columns of the x_proj gradient operand.  Only the
+                                 deterministic kernel does this (segm_selective_scan_bwd_deterministic()
+                                 tells whether a launch takes it); SEGM_E_SHAPE otherwise             */
+    int32_t reserved_b;
 } segm_scan_bwd_args;
 
 int segm_selective_scan_bwd(const segm_scan_bwd_args* args);
 int segm_selective_scan_bwd_multi(const segm_scan_bwd_args* args, int32_t n);   /* see segm_selective_scan_fwd_multi */
 size_t segm_selective_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen,
                                                int32_t chunk);
+/* 1 when segm_selective_scan_bwd(args) runs the kernel whose dB / dC are sums in a fixed order (all d-tiles of a chunk in
+ * one workgroup: no atomics, no zero-initialised buffer, dbc_native allowed), 0 when it takes the kernels that accumulate
+ * dB / dC atomically over d-tiles (irregular shapes, views beyond 4 GiB per batch element); no launch, no side effect */
+int segm_selective_scan_bwd_deterministic(const segm_scan_bwd_args* args);
 
 /* ------------------------------------------------------------------------------------------------
  * Causal depthwise conv1d (+ optional SiLU), forward / backward.

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(kBlock) scan_bwd_agg_kernel(ScanDev P) {
 #endif
 template <typename T, int NS, int RW>
 __global__ void __launch_bounds__(kBlock, SEGM_BWD_MIN_WAVES) scan_bwd_main_kernel(ScanDev P) {
-    static_assert(kWin == kCkpt, "one window per forward checkpoint");
+    static_assert(kWin % kCkpt == 0 && kChunkQuantum % kWin == 0, "a window starts at a forward checkpoint");
     constexpr int G = 64 / RW;
     constexpr int V = RW < 32 ? RW : 32;
     __shared__ __attribute__((aligned(16))) float s_bc[kWavesPerBlock][G][2][NS * kWin];    // [n][s]: B then C
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(256) clear_bc_kernel(float* p, int64_t sb, int
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
-struct BwdWs { size_t sd, e, carry, part, seg, total; };
+struct BwdWs { size_t sd, e, carry, part, seg, slab, total; };
 static BwdWs bwd_ws_layout(int batch, int dim, int nstate, int64_t L, int chunk) {
     const int64_t nch = (L + chunk - 1) / chunk;
     BwdWs w;
@@ -384,7 +384,8 @@ static BwdWs bwd_ws_layout(int batch, int dim, int nstate, int64_t L, int chunk)
     w.carry = w.e + align256((size_t)batch * nch * nstate * dim * sizeof(float));
     w.part = w.carry + align256((size_t)batch * nch * nstate * dim * sizeof(float));
     w.seg = w.part + align256((size_t)batch * nch * (nstate + 2) * dim * sizeof(float));
-    w.total = w.seg + scan_carry_scratch_bytes(batch, dim, nstate, nch);
+    w.slab = w.seg + align256(scan_carry_scratch_bytes(batch, dim, nstate, nch));
+    w.total = w.slab + scan_bwd_w8_slab_bytes(batch, dim, nstate, L);      // one B / C group (the regular-shape kernels take no other)
     return w;
 }
 
@@ -463,7 +464,7 @@ static int scan_bwd_one(const segm_scan_bwd_args* b, ScanDev* batched) {
     char* wsb = (char*)b->workspace;
     const segm_seq* all[8] = {&a->u, &a->delta, &a->z, &a->out, &b->dout, &b->du, &b->ddelta, &b->dz};
     const segm_bc* bv[2] = {&a->B, &a->C};
-    const segm_bc* gv[2] = {&b->dB, &b->dC};                            // fp32
+    const segm_bc* gv[2] = {&b->dB, &b->dC};                            // fp32, or the tensors' type (dbc_native)
 
     for (int g = 0; g < G; ++g) {
         const int64_t d0 = (int64_t)g * Dg;
@@ -480,12 +481,17 @@ static int scan_bwd_one(const segm_scan_bwd_args* b, ScanDev* batched) {
         P.dB_sb = b->dB.stride_b; P.dB_st = b->dB.stride_t; P.dB_sn = b->dB.stride_n;
         P.dC = (float*)b->dC.ptr + (int64_t)g * b->dC.stride_g;
         P.dC_sb = b->dC.stride_b; P.dC_st = b->dC.stride_t; P.dC_sn = b->dC.stride_n;
-        P.atomic_bc = P.gm.ndt > 1;
-        const bool fast = use_fast_bwd() && scan_bwd_fast_shape(P, es);
+        const bool fast = use_fast_bwd() && G == 1 && scan_bwd_fast_shape(P, es);
+        P.dbc_part = (float*)(wsb + ws.slab);
+        // the regular-shape main kernel leaves one fp32 slab of dB / dC per d-tile, added in a fixed order by a second kernel; the
+        // general kernels add one partial per d-tile atomically onto a zeroed fp32 buffer
+        P.atomic_bc = !fast && P.gm.ndt > 1;
+        P.dbc_native = b->dbc_native != 0;
+        if (P.dbc_native && !fast) return SEGM_E_SHAPE;
         const int64_t span = fast ? fast_span_rows(P) : 0;
         rc = validate_spans(all, 8, bv, 2, a->dim, a->dstate, a->seqlen, es, span);
         if (rc != SEGM_OK) return rc;
-        rc = validate_spans(nullptr, 0, gv, 2, a->dim, a->dstate, a->seqlen, sizeof(float), span);
+        rc = validate_spans(nullptr, 0, gv, 2, a->dim, a->dstate, a->seqlen, P.dbc_native ? es : sizeof(float), span);
         if (rc != SEGM_OK) return rc;
         if (batched && (!fast || G != 1)) return SEGM_E_SHAPE;          // the caller falls back to one launch per block
         if (P.atomic_bc) {
@@ -517,6 +523,16 @@ static int scan_bwd_one(const segm_scan_bwd_args* b, ScanDev* batched) {
 }
 
 extern "C" int segm_selective_scan_bwd(const segm_scan_bwd_args* b) { return scan_bwd_one(b, nullptr); }
+
+extern "C" int segm_selective_scan_bwd_deterministic(const segm_scan_bwd_args* b) {
+    if (!b || !use_fast_bwd()) return 0;
+    const segm_scan_fwd_args* a = &b->f;
+    if (validate_scan_common(a) != SEGM_OK || a->chunk <= 0 || a->n_groups <= 0) return 0;
+    if (a->n_groups != 1) return 0;
+    ScanDev P;
+    fill_scan_dev(P, a, 0, a->chunk);
+    return scan_bwd_fast_shape(P, dtype_size(a->dtype)) ? 1 : 0;
+}
 
 extern "C" int segm_selective_scan_bwd_multi(const segm_scan_bwd_args* args, int32_t n) {
     if (!args || n <= 0) return SEGM_E_NULL;

@@ -23,7 +23,7 @@ struct ScanDev {
     float* agg_h;                          // [batch][nchunks][nstate][dim]  chunk end state from a zero start
     float* carry;                          // [batch][nchunks][nstate][dim]  state entering the chunk
     float* carry_seg;                      // [batch][nseg][nstate + 1][dim] scratch of the carry kernels (segment composites)
-    float* ckpt;                           // [batch][nck][nstate][dim]      state entering step 16*k (or null)
+    float* ckpt;                           // [batch][nck][nstate][dim]      state entering step kCkpt*k (or null)
     int32_t nck;
     float* last_state;                     // (batch, dim, nstate) or null
     int64_t last_state_sb;                 // = full_dim * nstate
@@ -33,6 +33,8 @@ struct ScanDev {
     float* dC;  int64_t dC_sb, dC_st, dC_sn;
     float* part;                           // [batch][nchunks][nstate + 2][dim]  per-item dA / dD / ddelta_bias partials
     int32_t atomic_bc;                     // more than one d-tile contributes to dB / dC -> accumulate atomically
+    int32_t dbc_native;                    // dB / dC have the tensors' element type (scan_bwd_w8.hip only), else fp32
+    float* dbc_part;                       // [ndt][batch][L][dB 16 | dC 16]  per-d-tile sums (scan_bwd_w8.hip, ndt > 1)
     // forward, optional: u = SiLU(conv1d(x) + b) formed inside the passes (`u` then holds x); conv_width 0 = off
     const float* conv_w;                   // (dim, conv_width)
     const float* conv_b;                   // (dim) or null
@@ -151,7 +153,9 @@ bool scan_fast_shape(const ScanDev& P);                        // scan_fwd_fast.
 void launch_scan_fwd_fast(const ScanDevN& PP, int ndir, int dtype, bool apply, hipStream_t stream);
 bool scan_bwd_fast_shape(const ScanDev& P, size_t esize);      // scan_bwd_fast.hip
 void launch_scan_bwd_fast(const ScanDevN& PP, int ndir, int dtype, bool main, hipStream_t stream);
-void launch_scan_bwd_main_pair(const ScanDevN& PP, int ndir, int dtype, hipStream_t stream);       // scan_bwd_pair.hip
+bool scan_bwd_w8_shape(const ScanDev& P, size_t esize);        // scan_bwd_w8.hip: launches its main kernel takes
+void launch_scan_bwd_main_w8(const ScanDevN& PP, int ndir, int dtype, hipStream_t stream);
+size_t scan_bwd_w8_slab_bytes(int batch, int dim, int nstate, int64_t L);
 // the whole sequence of every view of the launch fits a 32-bit byte offset from its batch base (what the pair kernel needs)
 bool scan_full_span_fits(const ScanDev& P, size_t esize);
 // carry composition of `ndir` argument blocks of one geometry; forward: agg_* / carry / carry_seg of each block, reverse: the

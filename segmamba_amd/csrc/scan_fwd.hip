@@ -383,11 +383,11 @@ Geom make_geom(int batch, int dim, int nstate, int64_t L, int chunk) {   // L < 
 
 int32_t default_chunk(int32_t batch, int32_t dim, int64_t L) {
     static int forced = [] { const char* e = getenv("SEGM_CHUNK"); return e ? atoi(e) : 0; }();   // experiments only
-    if (forced >= kCkpt && forced % kCkpt == 0) return forced;
+    if (forced >= kChunkQuantum && forced % kChunkQuantum == 0) return forced;
     // aim at ~3 waves per SIMD (256 CUs x 4 SIMDs) while keeping <= 4096 chunks for the carry kernel
     const double lanes_steps = (double)batch * (double)dim * (double)L;
     const int64_t c = (int64_t)(lanes_steps / (64.0 * 3072.0));
-    int32_t chunk = kCkpt;
+    int32_t chunk = kChunkQuantum;
     while ((int64_t)chunk * 2 <= c && chunk < 4096) chunk *= 2;
     while ((L + chunk - 1) / chunk > 4096 && chunk < (1 << 20)) chunk *= 2;
     return chunk;
@@ -459,7 +459,7 @@ int validate_scan_common(const segm_scan_fwd_args* a) {
     if (a->dtype != SEGM_F32 && a->dtype != SEGM_F16 && a->dtype != SEGM_BF16) return SEGM_E_DTYPE;
     if (a->time_order < SEGM_TIME_FORWARD || a->time_order > SEGM_TIME_INTERLEAVED) return SEGM_E_TIME_ORDER;
     if (a->time_order == SEGM_TIME_INTERLEAVED && (a->nslices <= 0 || a->nslices > 4096 || a->seqlen % a->nslices != 0)) return SEGM_E_SHAPE;
-    if (a->chunk < 0 || (a->chunk % kCkpt) != 0) return SEGM_E_SHAPE;
+    if (a->chunk < 0 || (a->chunk % kChunkQuantum) != 0) return SEGM_E_SHAPE;
     if (!a->u.ptr || !a->delta.ptr || !a->B.ptr || !a->C.ptr || !a->A) return SEGM_E_NULL;
     if (!strides_ok(a->u) || !strides_ok(a->delta) || !strides_ok(a->z) || !strides_ok(a->out) ||
         !strides_ok(a->out_z) || !bc_strides_ok(a->B) || !bc_strides_ok(a->C))
@@ -543,7 +543,7 @@ void fill_scan_dev(ScanDev& P, const segm_scan_fwd_args* a, int g, int chunk) {
 using namespace segm;
 
 extern "C" int32_t segm_selective_scan_default_chunk(int32_t batch, int32_t dim, int64_t seqlen) {
-    if (batch <= 0 || dim <= 0 || seqlen <= 0) return kCkpt;
+    if (batch <= 0 || dim <= 0 || seqlen <= 0) return kChunkQuantum;
     return default_chunk(batch, dim, seqlen);
 }
 

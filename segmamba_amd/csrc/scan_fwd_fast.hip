@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
     const Stream ozp = make_stream<T>(has_z ? P.out_z : P.u, ub, wr, it.d);
     const StageStream<RW> sb = make_stage<T, RW>(P.Bm, ub, wr, it.r);
     const StageStream<RW> sc = make_stage<T, RW>(P.Cm, ub, wr, it.r);
-    // checkpoints: state entering step 16 k of the sequence, [batch][nck][16][dim]; the wave's window as a buffer
+    // checkpoints: state entering step kCkpt k of the sequence, [batch][nck][16][dim]; the wave's window as a buffer
     // (base = first checkpoint row of the wave's lowest chunk), one scalar offset per checkpoint and state
     const int32_t chunk0 = __builtin_amdgcn_readfirstlane(it.chunk - it.gi);
     const rsrc_t ckr = make_rsrc(P.ckpt ? P.ckpt + (((int64_t)ub * P.nck + (int64_t)chunk0 * (gm.chunk / kCkpt)) * kFS) * gm.dim : nullptr);
@@ -245,8 +245,8 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
         // row streams: rings of kFT registers, refilled step by step with the next sub-tile's rows (see the aggregate kernel)
         uint32_t su = (uint32_t)Un * (uint32_t)up.stb, sd = (uint32_t)Un * (uint32_t)dp.stb, sz = (uint32_t)Un * (uint32_t)zp.stb;
         const uint32_t iu = (uint32_t)(wr.dT * up.stb), id = (uint32_t)(wr.dT * dp.stb), iz = (uint32_t)(wr.dT * zp.stb);
-        if (P.ckpt && (s & 1) == 0) {                      // kCkpt = 2 sub-tiles
-            uint32_t kso = (uint32_t)((s >> 1) * kFS * ck_state);
+        if (P.ckpt) {                                      // kCkpt = one sub-tile
+            uint32_t kso = (uint32_t)(s * kFS * ck_state);
 #pragma unroll
             for (int n = 0; n < kFS / 2; ++n) {
                 BufIO<float>::st(ckr, ck_voff, kso, h[n].x);

@@ -24,7 +24,9 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;           // 4 waves per workgroup
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxState = 16;
-constexpr int kCkpt = 16;             // spacing (steps) of the forward state checkpoints kept for backward
+constexpr int kCkpt = 8;              // spacing (steps) of the forward state checkpoints kept for backward (round 4: 8 - the
+                                      // backward's windows are 8 steps, scan_bwd_w8.hip; 2 x the checkpoint bytes of rounds 1 - 3)
+constexpr int kChunkQuantum = 16;      // chunk lengths are multiples of this (the general backward kernel walks 16-step windows)
 constexpr float kLog2e = 1.4426950408889634f;
 
 // Pins a value to "computed here": an empty asm that reads and writes the register, so the compiler can neither

@@ -63,6 +63,7 @@ class ScanBwdArgs(C.Structure):
         ("dB", SegmBC), ("dC", SegmBC),
         ("dA", C.c_void_p), ("dD", C.c_void_p), ("ddelta_bias", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("dbc_native", C.c_int32), ("reserved_b", C.c_int32),
     ]
 
 
@@ -235,6 +236,7 @@ class TransposeArgs(C.Structure):
 EXPORTS = (
     "segm_selective_scan_fwd", "segm_selective_scan_fwd_workspace_bytes", "segm_selective_scan_ckpt_bytes",
     "segm_selective_scan_default_chunk", "segm_selective_scan_bwd", "segm_selective_scan_bwd_workspace_bytes",
+    "segm_selective_scan_bwd_deterministic",
     "segm_selective_scan_fwd_multi", "segm_selective_scan_bwd_multi", "segm_causal_conv1d_fwd_multi", "segm_causal_conv1d_bwd_multi",
     "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
     "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes", "segm_conv3d_k3_fwd",
@@ -276,6 +278,7 @@ class SegmLib:
 
         sig("segm_selective_scan_fwd", [C.POINTER(ScanFwdArgs)], C.c_int)
         sig("segm_selective_scan_bwd", [C.POINTER(ScanBwdArgs)], C.c_int)
+        sig("segm_selective_scan_bwd_deterministic", [C.POINTER(ScanBwdArgs)], C.c_int)
         sig("segm_selective_scan_fwd_multi", [C.POINTER(ScanFwdArgs), C.c_int32], C.c_int)
         sig("segm_selective_scan_bwd_multi", [C.POINTER(ScanBwdArgs), C.c_int32], C.c_int)
         for n in ("segm_selective_scan_fwd_workspace_bytes", "segm_selective_scan_bwd_workspace_bytes"):

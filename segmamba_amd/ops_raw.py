@@ -172,9 +172,10 @@ def _scan_fwd_prepare(lib, a, u, delta, A, B, C, D=None, z=None, delta_bias=None
 
 def scan_bwd(lib: L.SegmLib, u, delta, A, B, C, D, z, delta_bias, dout, out, ckpt, delta_softplus, *,
              channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, du=None, ddelta=None, dz=None, dB=None, dC=None):
-    """-> dict(du, ddelta, dA, dB, dC, dD, ddelta_bias, dz).  du / ddelta / dz may be pre-allocated views
-    (e.g. halves of one dxz buffer, reference selective_scan_interface.py:244-245); dB / dC are fp32 and have
-    the layout and rank of B / C."""
+    """-> dict(du, ddelta, dA, dB, dC, dD, ddelta_bias, dz, dbc_native).  du / ddelta / dz may be pre-allocated views
+    (e.g. halves of one dxz buffer, reference selective_scan_interface.py:244-245); dB / dC have the layout and rank of
+    B / C and are fp32 (the reference's accumulation buffers) unless the caller offers destinations of u's own 16-bit type
+    AND the launch takes the deterministic kernel (`dbc_native` in the result says which happened: see _scan_bwd_prepare)."""
     a = L.ScanBwdArgs()
     r = _scan_bwd_prepare(lib, a, u, delta, A, B, C, D, z, delta_bias, dout, out, ckpt, delta_softplus, channel_last=channel_last,
                           time_order=time_order, nslices=nslices, chunk=chunk, du=du, ddelta=ddelta, dz=dz, dB=dB, dC=dC)
@@ -197,8 +198,12 @@ def scan_bwd_multi(lib: L.SegmLib, calls):
 def _scan_bwd_prepare(lib, a, u, delta, A, B, C, D, z, delta_bias, dout, out, ckpt, delta_softplus, *,
                       channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, du=None, ddelta=None, dz=None,
                       dB=None, dC=None):
-    """`dB` / `dC`: optional caller-owned fp32 tensors shaped like B / C (e.g. column windows of the fp32 dx_dbl buffer)"""
-    if chunk and os.environ.get("SEGM_BWD_CHUNK"):        # experiments only: the backward's own chunking (the checkpoints are per 16 steps, not per chunk)
+    """`dB` / `dC`: optional caller-owned tensors shaped like B / C.  fp32: always honoured.  u's 16-bit dtype (e.g. column
+    windows of the x_proj gradient operand): honoured when the launch takes the kernel that sums dB / dC over the d-tiles in a
+    fixed order and writes the finished values once (segm_selective_scan_bwd_deterministic) - the result then has
+    `dbc_native` True and dB / dC ARE the caller's tensors; otherwise fp32 tensors are allocated and `dbc_native` is False (the
+    caller copies, as the reference's final cast does, selective_scan.cpp:488)."""
+    if chunk and os.environ.get("SEGM_BWD_CHUNK"):        # experiments only: the backward's own chunking (the checkpoints are per 8 steps, not per chunk)
         chunk = int(os.environ["SEGM_BWD_CHUNK"])
     batch, seqlen, dim, dstate, groups, B4, C4 = _fill_scan_args(
         a.f, u, delta, A, B, C, D, z, delta_bias, delta_softplus, channel_last, time_order, nslices, chunk)
@@ -218,21 +223,25 @@ def _scan_bwd_prepare(lib, a, u, delta, A, B, C, D, z, delta_bias, dout, out, ck
     for name, t in (("du", du), ("ddelta", ddelta), ("dz", dz)):
         _check_seq(name, t, u, u.dtype)
     dA = torch.empty(dim, dstate, dtype=torch.float32, device=dev)
-    own_bc = dB is None
-    if own_bc:
+    a.f.out = L.seq_view(out, channel_last)
+    a.f.ckpt = ckpt.data_ptr()
+    native = False
+    if dB is not None:
+        dB, dC = _bc4(dB, channel_last), _bc4(dC, channel_last)
+        native = dB.dtype == u.dtype and u.dtype != torch.float32
+        for name, t in (("dB", dB), ("dC", dC)):
+            if tuple(t.shape) != tuple(B4.shape) or t.dtype != (u.dtype if native else torch.float32) or t.device != dev:
+                raise RuntimeError(f"{name} must be an fp32 (or, both, {u.dtype}) tensor of B's shape {tuple(B4.shape)} on the same device")
+        if native and not lib.dll.segm_selective_scan_bwd_deterministic(a):
+            dB, native = None, False                        # the atomically accumulating kernels need zeroed fp32 buffers
+    if dB is None:
         dB = torch.empty(B4.shape, dtype=torch.float32, device=dev)
         dC = torch.empty(C4.shape, dtype=torch.float32, device=dev)
-    else:
-        dB, dC = _bc4(dB, channel_last), _bc4(dC, channel_last)
-        for name, t in (("dB", dB), ("dC", dC)):
-            if tuple(t.shape) != tuple(B4.shape) or t.dtype != torch.float32 or t.device != dev:
-                raise RuntimeError(f"{name} must be an fp32 tensor of B's shape {tuple(B4.shape)} on the same device")
+    a.dbc_native = int(native)
     dD = torch.empty(dim, dtype=torch.float32, device=dev) if D is not None else None
     ddb = torch.empty(dim, dtype=torch.float32, device=dev) if delta_bias is not None else None
     ws_bytes = lib.dll.segm_selective_scan_bwd_workspace_bytes(batch, dim, dstate, seqlen, chunk)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    a.f.out = L.seq_view(out, channel_last)
-    a.f.ckpt = ckpt.data_ptr()
     a.dout, a.du, a.ddelta, a.dz = (L.seq_view(t, channel_last) for t in (dout, du, ddelta, dz))
     a.dB, a.dC = L.bc_view(dB, channel_last), L.bc_view(dC, channel_last)
     a.dA, a.dD, a.ddelta_bias = dA.data_ptr(), L.fptr(dD), L.fptr(ddb)
@@ -241,7 +250,7 @@ def _scan_bwd_prepare(lib, a, u, delta, A, B, C, D, z, delta_bias, dout, out, ck
         dB = dB.squeeze(2 if channel_last else 1)
     if C.dim() == 3:
         dC = dC.squeeze(2 if channel_last else 1)
-    return dict(du=du, ddelta=ddelta, dA=dA, dB=dB, dC=dC, dD=dD, ddelta_bias=ddb, dz=dz, _ws=ws)
+    return dict(du=du, ddelta=ddelta, dA=dA, dB=dB, dC=dC, dD=dD, ddelta_bias=ddb, dz=dz, dbc_native=native, _ws=ws)
 
 
 # ---------------------------------------------------------------------------------------------------------

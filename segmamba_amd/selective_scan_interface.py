@@ -248,40 +248,34 @@ class MambaInnerCore(torch.autograd.Function):
                                             B_proj_bias, C_proj_bias, x_dbl=x_dbl)
         dxz = torch.empty_like(xz, memory_format=torch.contiguous_format)
         dx, dz = dxz.split(dim, dim=cdim)                 # dx / dz written in place (reference :244-245)
+        # dB / dC: offered the columns of the x_proj gradient operand as destinations (taken by the deterministic kernel)
+        dx_dbl, dBv, dCv = _dx_dbl_targets(x_dbl, batch, seqlen, R, N, channel_last)
         g = ops_raw.scan_bwd(lib, conv_out, delta, A32, Bv, Cv, D32, z, db32, dout, out, ckpt, delta_softplus,
-                             channel_last=channel_last, time_order=time_order, nslices=nslices, chunk=chunk, dz=dz)
+                             channel_last=channel_last, time_order=time_order, nslices=nslices, chunk=chunk, dz=dz,
+                             dB=dBv, dC=dCv)
         dconv_out, ddelta = g["du"], g["ddelta"]
         # (b*l, .) matrices for the projection gradients
         if channel_last:
-            dB2 = g["dB"].reshape(batch * seqlen, N)
-            dC2 = g["dC"].reshape(batch * seqlen, N)
             ddelta2 = ddelta.reshape(batch * seqlen, dim)                       # (bl, d)
             conv2 = conv_out.reshape(batch * seqlen, dim)
             dconv2 = dconv_out.reshape(batch * seqlen, dim)
         else:
-            dB2 = g["dB"].reshape(batch, N, seqlen).permute(0, 2, 1).reshape(batch * seqlen, N)
-            dC2 = g["dC"].reshape(batch, N, seqlen).permute(0, 2, 1).reshape(batch * seqlen, N)
             ddelta2 = ddelta.permute(0, 2, 1).reshape(batch * seqlen, dim)
             conv2 = conv_out.permute(0, 2, 1).reshape(batch * seqlen, dim)
             dconv2 = dconv_out.permute(0, 2, 1).reshape(batch * seqlen, dim)
-        dx_dbl = torch.empty_like(x_dbl)
-        dB_proj_bias = dB2.sum(0).to(B_proj_bias.dtype) if has_Bb else None
-        dC_proj_bias = dC2.sum(0).to(C_proj_bias.dtype) if has_Cb else None
+        _dx_dbl_finish(dx_dbl, g, batch, seqlen, R, N, channel_last)
+        c0 = _bc_col(x_dbl, R, N)
+        dB_proj_bias = dx_dbl[:, c0:c0 + N].float().sum(0).to(B_proj_bias.dtype) if has_Bb else None
+        dC_proj_bias = dx_dbl[:, c0 + N:c0 + 2 * N].float().sum(0).to(C_proj_bias.dtype) if has_Cb else None
         ddelta_proj_weight = tn_matmul(ddelta2, x_dbl[:, :R])                   # (d, R)    reference :272
         if rows_route:
-            P, P8, R4 = R + 2 * N, x_dbl.shape[1], -(-R // 4) * 4
-            # (bl, R) = ddelta2 @ dt_proj_weight (reference :273), written - with zero padding columns - before dB lands
+            R4, P4, P8 = _rows_cols(R, N)
+            # (bl, R) = ddelta2 @ dt_proj_weight (reference :273), with the zero padding columns up to R4
             ops_raw.linear_rows(lib, ddelta2, _pk(delta_proj_weight, ("dt_proj_t_rows", R4), lambda t: _pad_rows(t.t(), R4)), out=dx_dbl[:, :R4])
-            dx_dbl[:, R:R + N] = dB2
-            dx_dbl[:, R + N:P] = dC2
-            if P8 > P:
-                dx_dbl[:, P:] = 0
-            dx_proj_weight = tn_matmul(dx_dbl[:, :P], conv2)                    # (R+2N, d) reference :275
-            wx_t = _pk(x_proj_weight, ("x_proj_t", P8), lambda t: _pad_rows(t, P8).t().contiguous())       # (d, P8)
+            dx_proj_weight = _x_proj_grad_rows(tn_matmul(dx_dbl[:, :P4], conv2), R, N)          # (R+2N, d) reference :275
+            wx_t = _pk(x_proj_weight, ("x_proj_t4", P8), lambda t: _x_proj_rows4(t, R, N).t().contiguous())     # (d, P8)
             dconv2 = ops_raw.linear_rows(lib, dx_dbl, wx_t, out=dconv2, accumulate=True)        # reference :276
         else:
-            dx_dbl[:, R:R + N] = dB2
-            dx_dbl[:, R + N:] = dC2
             dx_dbl[:, :R] = ddelta2 @ delta_proj_weight                         # (bl, R)   reference :273
             dx_proj_weight = tn_matmul(dx_dbl, conv2)                          # (R+2N, d) reference :275
             dconv2 = torch.addmm(dconv2, dx_dbl, x_proj_weight)                 # (bl, d)   reference :276
@@ -396,33 +390,28 @@ class MambaInnerCore3(torch.autograd.Function):
                 dout = dout.contiguous()
             dxz = torch.empty_like(xz, memory_format=torch.contiguous_format)
             dx, dz = dxz.split(dim, dim=2)
+            dx_dbl, dBv, dCv = _dx_dbl_targets(x_dbl, batch, seqlen, R, N, True)
             calls.append(dict(u=conv_out, delta=delta, A=A.float().contiguous(), B=Bv, C=Cv,
                               D=D.float().contiguous() if D is not None else None, z=z,
                               delta_bias=dbias.float().contiguous() if dbias is not None else None, dout=dout, out=out, ckpt=ckpt,
-                              delta_softplus=True, channel_last=True, time_order=order, nslices=ns, chunk=chunks[i], dz=dz))
-            dirs.append((conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, conv_out, R, N, order, ns, w32, cb32, rows_route, dxz, dx))
+                              delta_softplus=True, channel_last=True, time_order=order, nslices=ns, chunk=chunks[i], dz=dz,
+                              dB=dBv, dC=dCv))
+            dirs.append((conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, conv_out, R, N, order, ns, w32, cb32, rows_route, dxz, dx, dx_dbl))
         gs = ops_raw.scan_bwd_multi(lib, calls)
         grads, dxz_sum, ccalls, part = [], None, [], []
-        for i, ((conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, conv_out, R, N, order, ns, w32, cb32, rows_route, dxz, dx), g) in enumerate(zip(dirs, gs)):
+        for i, ((conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, conv_out, R, N, order, ns, w32, cb32, rows_route, dxz, dx, dx_dbl), g) in enumerate(zip(dirs, gs)):
             dconv2 = g["du"].reshape(batch * seqlen, dim)
             ddelta2 = g["ddelta"].reshape(batch * seqlen, dim)
             conv2 = conv_out.reshape(batch * seqlen, dim)
-            dB2, dC2 = g["dB"].reshape(batch * seqlen, N), g["dC"].reshape(batch * seqlen, N)
-            dx_dbl = torch.empty_like(x_dbl)
+            _dx_dbl_finish(dx_dbl, g, batch, seqlen, R, N, True)
             ddelta_proj_weight = tn_matmul(ddelta2, x_dbl[:, :R])
             if rows_route:
-                P, P8, R4 = R + 2 * N, x_dbl.shape[1], -(-R // 4) * 4
+                R4, P4, P8 = _rows_cols(R, N)
                 ops_raw.linear_rows(lib, ddelta2, _pk(dtw, ("dt_proj_t_rows", R4), lambda t: _pad_rows(t.t(), R4)), out=dx_dbl[:, :R4])
-                dx_dbl[:, R:R + N] = dB2
-                dx_dbl[:, R + N:P] = dC2
-                if P8 > P:
-                    dx_dbl[:, P:] = 0
-                dx_proj_weight = tn_matmul(dx_dbl[:, :P], conv2)
-                wx_t = _pk(xw, ("x_proj_t", P8), lambda t: _pad_rows(t, P8).t().contiguous())
+                dx_proj_weight = _x_proj_grad_rows(tn_matmul(dx_dbl[:, :P4], conv2), R, N)
+                wx_t = _pk(xw, ("x_proj_t4", P8), lambda t: _x_proj_rows4(t, R, N).t().contiguous())
                 dconv2 = ops_raw.linear_rows(lib, dx_dbl, wx_t, out=dconv2, accumulate=True)
             else:
-                dx_dbl[:, R:R + N] = dB2
-                dx_dbl[:, R + N:] = dC2
                 dx_dbl[:, :R] = ddelta2 @ dtw
                 dx_proj_weight = tn_matmul(dx_dbl, conv2)
                 dconv2 = torch.addmm(dconv2, dx_dbl, xw)
@@ -430,7 +419,7 @@ class MambaInnerCore3(torch.autograd.Function):
                                time_order=order, nslices=ns, dx=dx))
             part.append((dx_proj_weight, ddelta_proj_weight))
         cres = ops_raw.conv1d_bwd_multi(lib, ccalls)
-        for i, ((conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, conv_out, R, N, order, ns, w32, cb32, rows_route, dxz, dx), g) in enumerate(zip(dirs, gs)):
+        for i, ((conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, conv_out, R, N, order, ns, w32, cb32, rows_route, dxz, dx, dx_dbl), g) in enumerate(zip(dirs, gs)):
             _, dconv_w, dconv_b = cres[i]
             dx_proj_weight, ddelta_proj_weight = part[i]
             dxz_sum = dxz if dxz_sum is None else dxz_sum.add_(dxz)
@@ -441,10 +430,17 @@ class MambaInnerCore3(torch.autograd.Function):
         return (dxz_sum, None, None, *grads)
 
 
+def _bc_col(x_dbl, R, N):
+    """first B column of an x_dbl / dx_dbl matrix: R in the reference layout (dt | B | C), R rounded up to 4 in the padded
+    layout of the row-streaming projection route (dt | 0.. | B | C | 0..; see _project_rows)"""
+    return R if x_dbl.shape[1] == R + 2 * N else -(-R // 4) * 4
+
+
 def _bc_views(x_dbl, batch, seqlen, R, N, channel_last, B_proj_bias, C_proj_bias):
-    """B_t / C_t as the scan expects them: strided views of x_dbl (b*l, R + 2N [+ padding])"""
+    """B_t / C_t as the scan expects them: strided views of x_dbl (b*l, R + 2N), or of its padded form"""
     v3 = x_dbl.view(batch, seqlen, x_dbl.shape[1])
-    Bv, Cv = v3[:, :, R:R + N], v3[:, :, R + N:R + 2 * N]
+    c0 = _bc_col(x_dbl, R, N)
+    Bv, Cv = v3[:, :, c0:c0 + N], v3[:, :, c0 + N:c0 + 2 * N]
     if not channel_last:
         Bv, Cv = Bv.permute(0, 2, 1), Cv.permute(0, 2, 1)
     if B_proj_bias is not None:
@@ -486,21 +482,73 @@ def _pad_rows(w, rows):
     return out
 
 
+def _rows_cols(R, N):
+    """column layout of x_dbl / dx_dbl on the row-streaming route: dt in [0, R), zeros up to R4 = R rounded up to 4, B in
+    [R4, R4 + N), C behind it, zeros up to P8 (a multiple of 8; 40 columns for R = 3 or 6 with N = 16, as many as the plain
+    padding of R + 2N needs).  B starts on a 4-column group so that the kernel that writes the dt gradient (four columns per
+    lane) never touches a B column: the scan backward stores dB / dC straight into these columns of dx_dbl."""
+    R4 = -(-R // 4) * 4
+    P4 = R4 + 2 * N
+    return R4, P4, -(-P4 // 8) * 8
+
+
+def _x_proj_rows4(w, R, N):
+    """x_proj weight (R + 2N, d) -> (P8, d) in the padded column layout"""
+    R4, P4, P8 = _rows_cols(R, N)
+    out = w.new_zeros(P8, w.shape[1])
+    out[:R] = w[:R]
+    out[R4:P4] = w[R:]
+    return out
+
+
 def _project_rows(conv_out, x_proj_weight, delta_proj_weight, R, N, x_dbl=None):
-    """`_project` for channel-last activations through segm_linear_rows.  x_dbl is kept with its columns padded to a
-    multiple of 8 (R + 2N = 35 -> 40; the extra columns are zero) so that it can be both an output and - its first
-    8-column group, against a zero-padded dt_proj weight - an input of the kernel."""
+    """`_project` for channel-last activations through segm_linear_rows.  x_dbl is kept in the padded column layout of
+    `_rows_cols` (the extra columns are zero: zero weight rows) so that it can be both an output and - its first 8-column
+    group, against a zero-padded dt_proj weight - an input of the kernel."""
     lib = L.get_lib()
     batch, seqlen, dim = conv_out.shape
-    P = R + 2 * N
-    P8, R8 = -(-P // 8) * 8, -(-R // 8) * 8
+    R4, P4, P8 = _rows_cols(R, N)
+    R8 = -(-R // 8) * 8
     if x_dbl is None:
         x_dbl = ops_raw.linear_rows(lib, conv_out.reshape(batch * seqlen, dim),
-                                    _pk(x_proj_weight, ("x_proj_rows", P8), lambda t: _pad_rows(t, P8)))
+                                    _pk(x_proj_weight, ("x_proj_rows4", P8), lambda t: _x_proj_rows4(t, R, N)))
     wdt = _pk(delta_proj_weight, ("dt_proj_cols", R8), lambda t: _pad_cols(t, R8))
     delta = ops_raw.linear_rows(lib, x_dbl[:, :R8], wdt).reshape(batch, seqlen, dim)
     v3 = x_dbl.view(batch, seqlen, P8)
-    return x_dbl, delta, v3[:, :, R:R + N], v3[:, :, R + N:P]
+    return x_dbl, delta, v3[:, :, R4:R4 + N], v3[:, :, R4 + N:P4]
+
+
+def _dx_dbl_targets(x_dbl, batch, seqlen, R, N, channel_last):
+    """the x_proj gradient operand dx_dbl (same shape as x_dbl) and its dB / dC column windows in the layout the scan backward
+    expects - offered to it as destinations of the activations' own type (ops_raw.scan_bwd: `dbc_native`)"""
+    dx_dbl = torch.empty_like(x_dbl)
+    c0 = _bc_col(x_dbl, R, N)
+    v3 = dx_dbl.view(batch, seqlen, dx_dbl.shape[1])
+    dBv, dCv = v3[:, :, c0:c0 + N], v3[:, :, c0 + N:c0 + 2 * N]
+    if not channel_last:
+        dBv, dCv = dBv.permute(0, 2, 1), dCv.permute(0, 2, 1)
+    return dx_dbl, dBv, dCv
+
+
+def _dx_dbl_finish(dx_dbl, g, batch, seqlen, R, N, channel_last):
+    """dB / dC into their columns unless the scan already wrote them there; zero padding columns"""
+    c0 = _bc_col(dx_dbl, R, N)
+    if not g["dbc_native"]:
+        if channel_last:
+            dB2, dC2 = g["dB"].reshape(batch * seqlen, N), g["dC"].reshape(batch * seqlen, N)
+        else:
+            dB2 = g["dB"].reshape(batch, N, seqlen).permute(0, 2, 1).reshape(batch * seqlen, N)
+            dC2 = g["dC"].reshape(batch, N, seqlen).permute(0, 2, 1).reshape(batch * seqlen, N)
+        dx_dbl[:, c0:c0 + N] = dB2
+        dx_dbl[:, c0 + N:c0 + 2 * N] = dC2
+    if dx_dbl.shape[1] > c0 + 2 * N:
+        dx_dbl[:, c0 + 2 * N:] = 0
+
+
+def _x_proj_grad_rows(dw, R, N):
+    """weight gradient in the padded column layout (P4, d) -> (R + 2N, d)"""
+    R4 = -(-R // 4) * 4
+    return dw if R4 == R else torch.cat([dw[:R], dw[R4:R4 + 2 * N]], 0)
 
 
 def _project(conv_out, x_proj_weight, delta_proj_weight, R, N, channel_last, B_proj_bias, C_proj_bias, x_dbl=None):

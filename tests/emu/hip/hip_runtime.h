@@ -182,6 +182,18 @@ static inline hipemu_u32x2 hipemu_permlane16_swap(uint32_t vdst, uint32_t vsrc, 
     return r;
 }
 #define __builtin_amdgcn_permlane16_swap hipemu_permlane16_swap
+// v_permlane32_swap_b32 vdst, vsrc: the upper 32 lanes of vdst trade places with the lower 32 lanes of vsrc
+static inline hipemu_u32x2 hipemu_permlane32_swap(uint32_t vdst, uint32_t vsrc, bool, bool) {
+    const int lane = hipemu::t_linear % 64;
+    const bool upper = lane >= 32;
+    const uint32_t src_of_partner = hipemu::exchange(vsrc, lane ^ 32);
+    const uint32_t dst_of_partner = hipemu::exchange(vdst, lane ^ 32);
+    hipemu_u32x2 r;
+    r.x = upper ? src_of_partner : vdst;
+    r.y = upper ? vsrc : dst_of_partner;
+    return r;
+}
+#define __builtin_amdgcn_permlane32_swap hipemu_permlane32_swap
 
 // ---- raw buffer resources (scan_fast.h Stream / StageStream): base pointer + lane byte offset + uniform byte offset ------------
 struct hipemu_rsrc { char* base; };
@@ -200,6 +212,7 @@ typedef uint32_t hipemu_u32x4 __attribute__((ext_vector_type(4)));
 #define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, aux) hipemu_buf_ld<hipemu_u32x4>(r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b16(d, r, v, s, aux) hipemu_buf_st<unsigned short>(d, r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b32(d, r, v, s, aux) hipemu_buf_st<uint32_t>(d, r, v, s)
+#define __builtin_amdgcn_raw_buffer_store_b128(d, r, v, s, aux) hipemu_buf_st<hipemu_u32x4>(d, r, v, s)
 
 // ---- MFMA / funnel-shift emulation (conv3d_wgrad.hip) -------------------------------------------------------------
 static inline uint32_t hipemu_alignbyte(uint32_t hi, uint32_t lo, uint32_t n) {

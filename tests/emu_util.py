@@ -21,7 +21,8 @@ def build_emu(force: bool = False) -> str:
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     flags = ["-O1", "-std=c++17", "-fPIC", "-pthread", "-I" + EMU_DIR, "-Wno-unused-value", "-DSEGM_PIN_F32(x)=",
-             "-DSEGM_SCHED_FENCE()=", "-DSEGM_EMU=1", "-DSEGM_PIN_F2(x)=", "-DSEGM_WAVE_LDS_SYNC()=hipemu::sync_wave()"]
+             "-DSEGM_SCHED_FENCE()=", "-DSEGM_EMU=1", "-DSEGM_PIN_F2(x)=", "-DSEGM_WAVE_LDS_SYNC()=hipemu::sync_wave()",
+             "-DSEGM_BLOCK_LDS_SYNC()=hipemu::sync_block()"]
     # one object per kernel translation unit (as in the product build), compiled in parallel as plain C++
     units = sorted(glob.glob(os.path.join(ROOT, "segmamba_amd", "csrc", "*.hip"))) + [os.path.join(EMU_DIR, "hip_emu_runtime.cpp")]
     objdir = os.path.join(os.path.dirname(OUT), "obj")

@@ -378,15 +378,11 @@ def test_transpose_add_emulated(emu, shape, dtype, with_add):
     (96, 64, 32, True, L.TIME_FORWARD, 1, torch.bfloat16),         # SegMamba stage-0 width
 ])
 def test_scan_regular_shape_kernels_emulated(emu, monkeypatch, dim, seqlen, chunk, channel_last, order, ns, dtype):
-    """scan_fwd_fast.hip / scan_bwd_fast.hip / scan_bwd_pair.hip (uniform addressing) against the oracle AND against the general
-    kernels; the backward with both main kernels (SEGM_BWD_MAIN=r2: packed state pairs, the default; r3: LDS-tile prefetch)."""
+    """scan_fwd_fast.hip / scan_bwd_fast.hip / scan_bwd_w8.hip (uniform addressing; the backward main kernel on 8-step windows,
+    one workgroup per chunk group with a wave per d-tile) against the oracle AND against the general kernels."""
     c = H.scan_case(1, dim, 16, seqlen, dtype=dtype, seed=dim + seqlen)
     ref = H.scan_oracle(c, order, ns)
     monkeypatch.delenv("SEGM_SCAN_FAST", raising=False)
-    monkeypatch.setenv("SEGM_BWD_MAIN", "r3")
-    fast = H.run_scan(emu, c, "cpu", channel_last, order, ns, chunk=chunk)
-    H.check_scan(fast, ref, dtype, f"emu fast (r3 main) D={dim} L={seqlen}")
-    monkeypatch.setenv("SEGM_BWD_MAIN", "r2")
     fast = H.run_scan(emu, c, "cpu", channel_last, order, ns, chunk=chunk)
     H.check_scan(fast, ref, dtype, f"emu fast D={dim} L={seqlen}")
     monkeypatch.setenv("SEGM_SCAN_FAST", "0")
@@ -425,8 +421,64 @@ def test_scan_three_directions_in_one_launch_emulated(emu, dim, seqlen, chunk, d
     for a, b in zip(single_b, multi_b):
         for k in ("du", "ddelta", "dz", "dA", "dD", "ddelta_bias"):
             assert torch.equal(a[k], b[k]), k
-        for k in ("dB", "dC"):                                   # several channel tiles add atomically: order-dependent last bits
-            assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-5), k
+        for k in ("dB", "dC"):
+            if dim % 16 == 0:                                    # regular shapes: d-tiles summed in a fixed order inside one workgroup
+                assert torch.equal(a[k], b[k]), k
+            else:                                                # general kernels: several channel tiles add atomically
+                assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-5), k
+
+
+@pytest.mark.parametrize("dim,seqlen,chunk,order,ns,dtype", [
+    (192, 64, 32, L.TIME_FORWARD, 1, torch.bfloat16),            # RW 64, three d-tiles (SegMamba stage 1)
+    (384, 32, 16, L.TIME_REVERSED, 1, torch.float16),            # six d-tiles (stage 2)
+    (768, 32, 16, L.TIME_INTERLEAVED, 8, torch.bfloat16),        # twelve (stage 3, BASELINE config 1)
+    (48, 64, 16, L.TIME_FORWARD, 1, torch.float32),              # RW 16: four items per wave, three d-tiles
+    (128, 48, 16, L.TIME_REVERSED, 1, torch.float32),            # RW 64, two d-tiles, chunk groups of one
+])
+def test_scan_backward_workgroup_per_chunk_group_emulated(emu, dim, seqlen, chunk, order, ns, dtype):
+    """scan_bwd_w8.hip over its workgroup shapes (1 - 12 waves): every gradient against the oracle; dB / dC are sums in a fixed
+    order - bit-identical run to run - and, offered destinations of the tensors' own 16-bit type that are column windows of a
+    wider matrix (the x_proj gradient operand), are written there once, rounded from the fp32 sum."""
+    c = H.scan_case(2, dim, 16, seqlen, dtype=dtype, seed=dim)
+    ref = H.scan_oracle(c, order, ns)
+    res = H.run_scan(emu, c, "cpu", True, order, ns, chunk=chunk)
+    H.check_scan(res, ref, dtype, f"emu w8 D={dim} L={seqlen}")
+    d = H.to_dev_layout(c, "cpu", True)
+    f = ops_raw.scan_fwd(emu, d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], d["z"], d["delta_bias"], True,
+                         channel_last=True, time_order=order, nslices=ns, chunk=chunk, need_out=True, need_ckpt=True)
+    kw = dict(channel_last=True, time_order=order, nslices=ns, chunk=f["chunk"])
+    args = (d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], d["z"], d["delta_bias"], d["g"], f["out"], f["ckpt"], True)
+    r1 = ops_raw.scan_bwd(emu, *args, **kw)
+    r2 = ops_raw.scan_bwd(emu, *args, **kw)
+    assert not r1["dbc_native"] and r1["dB"].dtype == torch.float32
+    for k in ("dB", "dC", "du", "ddelta", "dA"):
+        assert torch.equal(r1[k], r2[k]), k
+    if dtype != torch.float32:
+        wide = torch.full((2, seqlen, 40), 7.0, dtype=dtype)     # dt | pad | dB | dC | pad, as _rows_cols lays it out for R = 3
+        r3 = ops_raw.scan_bwd(emu, *args, dB=wide[:, :, 4:20], dC=wide[:, :, 20:36], **kw)
+        assert r3["dbc_native"]
+        assert torch.equal(wide[:, :, 4:20], r1["dB"].to(dtype)) and torch.equal(wide[:, :, 20:36], r1["dC"].to(dtype))
+        assert bool((wide[:, :, :4] == 7).all()) and bool((wide[:, :, 36:] == 7).all())      # nothing else is touched
+        assert torch.equal(r3["du"], r1["du"]) and torch.equal(r3["dA"], r1["dA"])
+
+
+def test_scan_backward_native_destinations_fall_back_on_irregular_shapes(emu):
+    """a ragged shape takes the general kernels (atomic fp32 accumulation): 16-bit destinations are NOT written, the result
+    says so and carries fp32 tensors; the C entry refuses `dbc_native` there instead of producing partial sums"""
+    c = H.scan_case(1, 20, 16, 70, dtype=torch.bfloat16, seed=3)
+    d = H.to_dev_layout(c, "cpu", True)
+    f = ops_raw.scan_fwd(emu, d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], d["z"], d["delta_bias"], True,
+                         channel_last=True, chunk=32, need_out=True, need_ckpt=True)
+    dBn, dCn = torch.full((1, 70, 16), 7.0, dtype=torch.bfloat16), torch.full((1, 70, 16), 7.0, dtype=torch.bfloat16)
+    r = ops_raw.scan_bwd(emu, d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], d["z"], d["delta_bias"], d["g"], f["out"],
+                         f["ckpt"], True, channel_last=True, chunk=f["chunk"], dB=dBn, dC=dCn)
+    assert not r["dbc_native"] and r["dB"].dtype == torch.float32 and bool((dBn == 7).all())
+    a = L.ScanBwdArgs()
+    ops_raw._scan_bwd_prepare(emu, a, d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], d["z"], d["delta_bias"], d["g"], f["out"],
+                              f["ckpt"], True, channel_last=True, chunk=f["chunk"])
+    assert emu.dll.segm_selective_scan_bwd_deterministic(a) == 0
+    a.dbc_native = 1
+    assert emu.dll.segm_selective_scan_bwd(a) == -2          # SEGM_E_SHAPE
 
 
 def test_scan_rejects_views_beyond_32bit_offsets(emu):

@@ -33,9 +33,9 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_abi_queries_without_gpu(built_lib):
     from segmamba_amd import lib
     l = lib.SegmLib(built_lib)
-    assert l.dll.segm_abi_version() == 4
+    assert l.dll.segm_abi_version() == 5
     assert l.dll.segm_status_string(-3).decode().startswith("dstate")
-    # SegMamba stage 0: B=2, D=96, L=64^3 -> 256-step work items, 16-step checkpoints
+    # SegMamba stage 0: B=2, D=96, L=64^3 -> 256-step work items, 8-step checkpoints
     assert l.dll.segm_selective_scan_default_chunk(2, 96, 262144) == 256
     # which geometries run on the regular-shape kernels (one grid for three directions, conv_weight option): every SegMamba stage does
     for dim, Lq, ns in ((96, 64 ** 3, 64), (192, 32 ** 3, 32), (384, 16 ** 3, 16), (768, 8 ** 3, 8)):
@@ -45,7 +45,7 @@ def test_abi_queries_without_gpu(built_lib):
     assert l.dll.segm_selective_scan_regular_shape(2, 96, 8, 64 ** 3, 0, lib.TIME_FORWARD, 1) == 0           # 8 states: general kernels
     assert l.dll.segm_selective_scan_regular_shape(2, 20, 16, 4096, 0, lib.TIME_FORWARD, 1) == 0             # 20 channels
     assert l.dll.segm_selective_scan_regular_shape(2, 96, 16, 64 ** 3, 0, lib.TIME_INTERLEAVED, 5) == 0      # 5 slices: not affine in a sub-tile
-    assert l.dll.segm_selective_scan_ckpt_bytes(2, 96, 16, 262144) == 2 * (262144 // 16) * 16 * 96 * 4
+    assert l.dll.segm_selective_scan_ckpt_bytes(2, 96, 16, 262144) == 2 * (262144 // 8) * 16 * 96 * 4
     assert l.dll.segm_selective_scan_fwd_workspace_bytes(2, 96, 16, 262144, 0) > 0
     # argument errors are reported without touching the device
     a = lib.ScanFwdArgs()
