@@ -245,9 +245,9 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MIN_WAVES) scan_bwd_main_kern
 
         // state entering the window = forward checkpoint (zero past the end of the sequence)
         const bool ck_ok = it.valid && tw.tau < tm.L;
-        const float* ck = P.ckpt + (((int64_t)it.b * P.nck + (ck_ok ? tw.tau / kCkpt : 0)) * nstate) * gm.dim + dsafe;
+        const float* ck = P.ckpt + ((int64_t)it.b * P.nck + (ck_ok ? tw.tau / kCkpt : 0)) * ((nstate + 1) / 2) * gm.dim * 2 + (int64_t)dsafe * 2;
         float A2n_next = Arow[0] * kLog2e;
-        float hp_next = ck[0];
+        float hp_next = ck[0];                               // state n of the checkpoint: ck[(n / 2) * 2 dim + (n & 1)]
 #pragma unroll 1
         for (int n = 0; n < NS; ++n) {                      // runtime loop over states
             const bool on = it.valid && n < nstate;
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_BWD_MIN_WAVES) scan_bwd_main_kern
             {
                 const int nn = (n + 1 < nstate) ? n + 1 : nstate - 1;          // prefetch the next state's scalars
                 A2n_next = Arow[nn] * kLog2e;
-                hp_next = ck[(int64_t)nn * gm.dim];
+                hp_next = ck[(int64_t)(nn >> 1) * gm.dim * 2 + (nn & 1)];
             }
             const float An = A2n * 0.6931471805599453f;
             float en = s_e[n][threadIdx.x];

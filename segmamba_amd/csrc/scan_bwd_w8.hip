@@ -57,6 +57,20 @@ __device__ __forceinline__ void stream_store(const float (&src)[kFT], const Stre
     }
 }
 
+// the raw rows of u kept for the window epilogue: two 16-bit elements per register
+template <typename T> struct RawKeep {
+    static constexpr int N = sizeof(T) == 2 ? kW8 / 2 : kW8;
+    uint32_t v[N];
+    __device__ __forceinline__ void put(const uint32_t (&r)[kW8]) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = sizeof(T) == 2 ? (r[2 * i] | (r[2 * i + 1] << 16)) : r[i];
+    }
+    __device__ __forceinline__ float get(int j) const {
+        if (sizeof(T) == 2) return BufIO<T>::cvt_raw((j & 1) ? (v[j >> 1] >> 16) : (v[j >> 1] & 0xffffu));
+        return BufIO<T>::cvt_raw(v[j]);
+    }
+};
+
 // LDS image of a window's B / C: [step][state pair][B_2p, B_2p+1, C_2p, C_2p+1] - one 16-byte broadcast read per step and pair
 __device__ __forceinline__ int bc_index(int m, int j, int n) { return (j * (kFS / 2) + (n >> 1)) * 4 + m * 2 + (n & 1); }
 
@@ -214,14 +228,22 @@ __device__ __forceinline__ void reduce_scatter_pair(f2 (&a)[kW8], f2 (&h)[kW8], 
 // ------------------------------------------------------------------------------------------------------
 // MODE 1: delta_softplus and a gate z are known at compile time (what Mamba launches); 0: read from the arguments - as
 // wave-uniform branches around every step's softplus / gate arithmetic and stores, which the compiler does not unswitch
-template <typename T, int RW, int MODE>
+// SAME: u, delta, dout, out, du, ddelta have one set of strides and z, dz another (what Mamba launches: contiguous (B, L, D)
+// tensors and the halves of xz / dxz) - two lane offsets instead of eight (the kernel is built at the register limit of two waves
+// per SIMD: every register it keeps out of the state-pair loop is a spill it does not take there)
+template <typename T, int RW, int MODE, bool SAME>
 __global__ void __launch_bounds__(kBlock, SEGM_W8_MIN_WAVES) scan_bwd_main_w8_kernel(ScanDevN PP) {
     constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     constexpr int ITEM = 2 * kW8 * kFS;                   // floats of one item's dB + dC tile of a window: [j][m][n]
-    __shared__ __attribute__((aligned(16))) float s_bc[2][kWavesPerBlock][G][kW8 * (kFS / 2) * 4];     // this / the next window's B, C
+    // Nothing inside the state-pair loop comes from memory: vmcnt is ONE in-order counter, so a load issued there could only be
+    // waited for together with the 40 row loads of the next window that are in flight around it (measured: the loop then starts
+    // every window by waiting out that prefetch).  What a pair needs is in LDS - 18 KB per wave, two workgroups per CU:
+    __shared__ __attribute__((aligned(16))) float s_bc[kWavesPerBlock][G][kW8 * (kFS / 2) * 4];        // the window's B, C
     __shared__ __attribute__((aligned(16))) float s_dbc[kWavesPerBlock][G][ITEM];                      // channel sums of dB / dC
     __shared__ f2 s_e[kFS / 2][kBlock];                   // adjoint entering from the right, per thread and state pair
     __shared__ f2 s_dA[kFS / 2][kBlock];
+    __shared__ f2 s_hp[kFS / 2][kBlock];                  // state entering the window (forward checkpoint)
+    __shared__ f2 s_A[kFS / 2][kWavesPerBlock * RW];      // A[d][2p], A[d][2p + 1] of the wave's channels
     const ScanDev& P = PP.d[blockIdx.y];
     const Geom& gm = P.gm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -240,19 +262,29 @@ __global__ void __launch_bounds__(kBlock, SEGM_W8_MIN_WAVES) scan_bwd_main_w8_ke
         s_e[p][tid] = f2{P.carry[(crow * kFS + 2 * p) * gm.dim + it.d], P.carry[(crow * kFS + 2 * p + 1) * gm.dim + it.d]};
         s_dA[p][tid] = f2{0.f, 0.f};
     }
-    const f2* Arow = reinterpret_cast<const f2*>(P.A + (int64_t)it.d * kFS);
+    {
+        const f2* Arow = reinterpret_cast<const f2*>(P.A + (int64_t)it.d * kFS);
+#pragma unroll
+        for (int p = 0; p < kFS / 2; ++p) s_A[p][wave * RW + it.r] = Arow[p];     // the items of a wave share the channels: same value
+    }
     const float bias = P.delta_bias ? P.delta_bias[it.d] : 0.f;
     const float Dv = P.D ? P.D[it.d] : 0.f;
     float dD_acc = 0.f, dbias_acc = 0.f;
 
     const Stream up = make_stream<T>(P.u, ub, wr, it.d);
-    const Stream dp = make_stream<T>(P.delta, ub, wr, it.d);
-    const Stream gp = make_stream<T>(P.dout, ub, wr, it.d);
+    Stream dp = make_stream<T>(P.delta, ub, wr, it.d);
+    Stream gp = make_stream<T>(P.dout, ub, wr, it.d);
     const Stream zp = make_stream<T>(has_z ? P.z : P.dout, ub, wr, it.d);
-    const Stream yp = make_stream<T>(has_z ? P.out : P.dout, ub, wr, it.d);
-    const Stream dup = make_stream<T>(P.du, ub, wr, it.d);
-    const Stream ddp = make_stream<T>(P.ddelta, ub, wr, it.d);
-    const Stream dzp = make_stream<T>(has_z ? P.dz : P.du, ub, wr, it.d);
+    Stream yp = make_stream<T>(has_z ? P.out : P.dout, ub, wr, it.d);
+    Stream dup = make_stream<T>(P.du, ub, wr, it.d);
+    Stream ddp = make_stream<T>(P.ddelta, ub, wr, it.d);
+    Stream dzp = make_stream<T>(has_z ? P.dz : P.du, ub, wr, it.d);
+    if constexpr (SAME) {
+        dp.voff = gp.voff = yp.voff = dup.voff = ddp.voff = up.voff;
+        dp.stb = gp.stb = yp.stb = dup.stb = ddp.stb = up.stb;
+        dzp.voff = zp.voff;
+        dzp.stb = zp.stb;
+    }
     const StageStream<RW> sb = make_stage<T, RW>(P.Bm, ub, wr, it.r);
     const StageStream<RW> sc = make_stage<T, RW>(P.Cm, ub, wr, it.r);
     int lds_b0, lds_c0, lds_binc, lds_cinc;               // where this lane's staged elements go in the [step][pair][4] image
@@ -266,10 +298,11 @@ __global__ void __launch_bounds__(kBlock, SEGM_W8_MIN_WAVES) scan_bwd_main_w8_ke
         lds_binc = tfast_b ? (RW / kFT / 2) * 4 : (RW >= kFS ? RW / kFS : 1) * (kFS / 2) * 4;
         lds_cinc = tfast_c ? (RW / kFT / 2) * 4 : (RW >= kFS ? RW / kFS : 1) * (kFS / 2) * 4;
     }
-    // checkpoints [batch][nck][16][dim]: a buffer based at the wave's lowest chunk
+    // checkpoints [batch][nck][8 pairs][dim][2]: a buffer based at the wave's lowest chunk; a pair's entering state is one 8-byte load
     const rsrc_t ckr = make_rsrc(P.ckpt + (((int64_t)ub * P.nck + (int64_t)chunk0 * (gm.chunk / kCkpt)) * kFS) * gm.dim);
-    const uint32_t ck_voff = ((uint32_t)(it.gi * (gm.chunk / kCkpt)) * kFS * (uint32_t)gm.dim + (uint32_t)it.d) * 4u;
-    const int32_t ck_state = gm.dim * 4;
+    const uint32_t ck_voff = ((uint32_t)(it.gi * (gm.chunk / kCkpt)) * kFS * (uint32_t)gm.dim + 2u * (uint32_t)it.d) * 4u;
+    const int32_t ck_pair = gm.dim * 8;                   // bytes between consecutive state pairs of one checkpoint
+    const int32_t ck_row = ck_pair * (kFS / 2);           // bytes of one checkpoint (all channels)
     // dB / dC of a window: one d-tile -> finished values straight to the destination (fp32, or T when the caller asked for the
     // tensors' own type); several d-tiles -> this tile's sums to its fp32 slab [d-tile][batch][row][dB 16 | dC 16], a row = 128
     // bytes, added over the d-tiles in a fixed order by scan_bwd_dbc_sum_kernel
@@ -292,8 +325,12 @@ __global__ void __launch_bounds__(kBlock, SEGM_W8_MIN_WAVES) scan_bwd_main_w8_ke
 
     const int nwin = gm.chunk / kW8;
     uint32_t ru[kW8], rd[kW8], rg[kW8], rz[kW8], ry[kW8], nbv[EPL], ncv[EPL];
+    u32x2_t rh[kFS / 2];                                  // a window's checkpoint, raw
+    float* const img = &s_bc[wave][it.gi][0];
     {                                                      // the first window's inputs (the only exposed fetch of the chunk)
         const int32_t U = wr.bias + fast_U_of(P.tm, nwin - 1);
+#pragma unroll
+        for (int p = 0; p < kFS / 2; ++p) rh[p] = __builtin_amdgcn_raw_buffer_load_b64(ckr, ck_voff, (uint32_t)((nwin - 1) * ck_row + p * ck_pair), 0);
         stage_fetch_raw<T, RW>(nbv, sb, U, wr.dT);
         stage_fetch_raw<T, RW>(ncv, sc, U, wr.dT);
         stream_fetch_raw<T>(rz, zp, U, wr.dT);
@@ -301,28 +338,25 @@ __global__ void __launch_bounds__(kBlock, SEGM_W8_MIN_WAVES) scan_bwd_main_w8_ke
         stream_fetch_raw<T>(rg, gp, U, wr.dT);
         stream_fetch_raw<T>(rd, dp, U, wr.dT);
         stream_fetch_raw<T>(ru, up, U, wr.dT);
-        float* img = &s_bc[(nwin - 1) & 1][wave][it.gi][0];
 #pragma unroll
         for (int i = 0; i < EPL; ++i) {
             img[lds_b0 + i * lds_binc] = BufIO<T>::cvt_raw(nbv[i]);
             img[lds_c0 + i * lds_cinc] = BufIO<T>::cvt_raw(ncv[i]);
         }
-    }
-    f2 A_next = Arow[0];
-    f2 hp_next;
-    {
-        const uint32_t so = (uint32_t)((nwin - 1) * kFS * ck_state);
-        hp_next = f2{BufIO<float>::ld(ckr, ck_voff, so), BufIO<float>::ld(ckr, ck_voff, so + (uint32_t)ck_state)};
+#pragma unroll
+        for (int p = 0; p < kFS / 2; ++p) s_hp[p][tid] = f2{__uint_as_float(rh[p].x), __uint_as_float(rh[p].y)};
     }
 
     for (int w = nwin - 1; w >= 0; --w) {
         const int32_t Uw = wr.bias + fast_U_of(P.tm, w);
         const int32_t Un = wr.bias + fast_U_of(P.tm, w > 0 ? w - 1 : 0);
         // ---- window prologue: this lane's 8 steps ------------------------------------------------------------------------------
-        float wu[kW8], wd[kW8], wg[kW8], wdu[kW8];
+        float wd[kW8], wg[kW8], wdu[kW8];
+        RawKeep<T> ku;
         f2 qs[kW8], ddA[kW8];                              // sum over states of dh B and of t2 A, two partial sums each
         {
             float dzv[kW8];
+            ku.put(ru);
 #pragma unroll
             for (int j = 0; j < kW8; ++j) {
                 wg[j] = BufIO<T>::cvt_raw(rg[j]);
@@ -332,17 +366,22 @@ __global__ void __launch_bounds__(kBlock, SEGM_W8_MIN_WAVES) scan_bwd_main_w8_ke
                     dzv[j] = wg[j] * yy * sg * fmaf(zz, 1.f - sg, 1.f);
                     wg[j] *= zz * sg;
                 }
-                wu[j] = BufIO<T>::cvt_raw(ru[j]);
+                const float uu = BufIO<T>::cvt_raw(ru[j]);
                 const float dl = BufIO<T>::cvt_raw(rd[j]) + bias;
                 wd[j] = softplus_on ? softplus20(dl) : dl;
-                wdu[j] = wd[j] * wu[j];
+                wdu[j] = wd[j] * uu;
                 qs[j] = f2{0.f, 0.f};
                 ddA[j] = f2{0.f, 0.f};
-                dD_acc = fmaf(wg[j], wu[j], dD_acc);
+                dD_acc = fmaf(wg[j], uu, dD_acc);
             }
             if (has_z) stream_store<T>(dzv, dzp, Uw, wr.dT);
         }
-        // ---- the next window's rows: in flight during the state loop (raw bits: nothing here is a use of a loaded value) ----------
+        // ---- the next window's inputs: in flight during the state loop (raw bits: nothing here is a use of a loaded value) --------
+        {
+            const uint32_t so = (uint32_t)((w > 0 ? w - 1 : 0) * ck_row);
+#pragma unroll
+            for (int p = 0; p < kFS / 2; ++p) rh[p] = __builtin_amdgcn_raw_buffer_load_b64(ckr, ck_voff, so + (uint32_t)(p * ck_pair), 0);
+        }
         stage_fetch_raw<T, RW>(nbv, sb, Un, wr.dT);
         stage_fetch_raw<T, RW>(ncv, sc, Un, wr.dT);
         if (has_z) {
@@ -354,20 +393,12 @@ __global__ void __launch_bounds__(kBlock, SEGM_W8_MIN_WAVES) scan_bwd_main_w8_ke
         stream_fetch_raw<T>(ru, up, Un, wr.dT);
 
         SEGM_WAVE_LDS_SYNC();                             // this window's B / C image is parked, the dB / dC tile has been flushed
-        const float* img = &s_bc[w & 1][wave][it.gi][0];
         float* part = &s_dbc[wave][it.gi][0];
 #pragma unroll 1
         for (int p = 0; p < kFS / 2; ++p) {               // runtime loop over state pairs
-            const f2 An = A_next;
+            const f2 An = s_A[p][wave * RW + it.r];
             const f2 A2n = An * kLog2e;
-            const f2 hp = hp_next;
-            {                                             // the next pair's A and checkpoint (next window's first pair after the last)
-                const int pn = (p + 1) & (kFS / 2 - 1);
-                const int wn = p + 1 < kFS / 2 ? w : (w > 0 ? w - 1 : 0);
-                A_next = Arow[pn];
-                const uint32_t so = (uint32_t)((wn * kFS + 2 * pn) * ck_state);
-                hp_next = f2{BufIO<float>::ld(ckr, ck_voff, so), BufIO<float>::ld(ckr, ck_voff, so + (uint32_t)ck_state)};
-            }
+            const f2 hp = s_hp[p][tid];
             f2 en = s_e[p][tid];
             f2 dAn = s_dA[p][tid];
             const float* bcp = img + p * 4;
@@ -411,7 +442,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_W8_MIN_WAVES) scan_bwd_main_w8_ke
             for (int j = 0; j < kW8; ++j) {
                 const float q = qs[j].x + qs[j].y;
                 du[j] = fmaf(wd[j], q, Dv * wg[j]);
-                float ddv = fmaf(wu[j], q, ddA[j].x + ddA[j].y);
+                float ddv = fmaf(ku.get(j), q, ddA[j].x + ddA[j].y);
                 ddv *= softplus_on ? 1.f - fast_exp(-wd[j]) : 1.f;       // sigmoid(raw) = 1 - exp(-softplus(raw))
                 dbias_acc += ddv;
                 ddl[j] = ddv;
@@ -419,14 +450,14 @@ __global__ void __launch_bounds__(kBlock, SEGM_W8_MIN_WAVES) scan_bwd_main_w8_ke
             stream_store<T>(du, dup, Uw, wr.dT);
             stream_store<T>(ddl, ddp, Uw, wr.dT);
         }
-        {                                                  // the next window's B / C: the image this window does not read
-            float* nimg = &s_bc[(w & 1) ^ 1][wave][it.gi][0];
+        // the next window's B / C and checkpoint (this window's pairs are done with theirs)
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) {
-                nimg[lds_b0 + i * lds_binc] = BufIO<T>::cvt_raw(nbv[i]);
-                nimg[lds_c0 + i * lds_cinc] = BufIO<T>::cvt_raw(ncv[i]);
-            }
+        for (int i = 0; i < EPL; ++i) {
+            img[lds_b0 + i * lds_binc] = BufIO<T>::cvt_raw(nbv[i]);
+            img[lds_c0 + i * lds_cinc] = BufIO<T>::cvt_raw(ncv[i]);
         }
+#pragma unroll
+        for (int p = 0; p < kFS / 2; ++p) s_hp[p][tid] = f2{__uint_as_float(rh[p].x), __uint_as_float(rh[p].y)};
         SEGM_WAVE_LDS_SYNC();                             // the dB / dC tile of every item of the wave is complete
         // ---- dB / dC of the window ---------------------------------------------------------------------------------------------
         if (!direct) {
@@ -512,10 +543,17 @@ template <typename T, int RW>
 static void launch_w8_rw(const ScanDevN& PP, int ndir, hipStream_t stream) {
     const Geom& gm = PP.d[0].gm;
     const unsigned nblocks = (unsigned)((gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
-    bool mamba = true;                                     // every direction: softplus on delta, gated by z
-    for (int i = 0; i < ndir; ++i) mamba = mamba && PP.d[i].delta_softplus != 0 && PP.d[i].z.p != nullptr;
-    if (mamba) hipLaunchKernelGGL((scan_bwd_main_w8_kernel<T, RW, 1>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
-    else hipLaunchKernelGGL((scan_bwd_main_w8_kernel<T, RW, 0>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+    bool mamba = true, same = true;                        // every direction: softplus on delta, gated by z; the two stride sets
+    for (int i = 0; i < ndir; ++i) {
+        const ScanDev& P = PP.d[i];
+        mamba = mamba && P.delta_softplus != 0 && P.z.p != nullptr;
+        const Seq* six[5] = {&P.delta, &P.dout, &P.out, &P.du, &P.ddelta};
+        for (const Seq* s : six) same = same && s->p && s->sb == P.u.sb && s->st == P.u.st && s->sd == P.u.sd;
+        same = same && P.z.p && P.dz.p && P.dz.sb == P.z.sb && P.dz.st == P.z.st && P.dz.sd == P.z.sd;
+    }
+    if (mamba && same) hipLaunchKernelGGL((scan_bwd_main_w8_kernel<T, RW, 1, true>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+    else if (mamba) hipLaunchKernelGGL((scan_bwd_main_w8_kernel<T, RW, 1, false>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+    else hipLaunchKernelGGL((scan_bwd_main_w8_kernel<T, RW, 0, false>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
     if (gm.ndt > 1)
         hipLaunchKernelGGL((scan_bwd_dbc_sum_kernel<T>), dim3((unsigned)(((int64_t)gm.L * 8 + 255) / 256), gm.batch, ndir), dim3(256), 0, stream, PP);
 }

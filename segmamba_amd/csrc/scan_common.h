@@ -23,7 +23,8 @@ struct ScanDev {
     float* agg_h;                          // [batch][nchunks][nstate][dim]  chunk end state from a zero start
     float* carry;                          // [batch][nchunks][nstate][dim]  state entering the chunk
     float* carry_seg;                      // [batch][nseg][nstate + 1][dim] scratch of the carry kernels (segment composites)
-    float* ckpt;                           // [batch][nck][nstate][dim]      state entering step kCkpt*k (or null)
+    float* ckpt;                           // [batch][nck][state pair][dim][2]  state entering step kCkpt*k (or null): a wave's
+                                           // access to a pair is 64 lanes x 8 contiguous bytes, forward (store) and backward (load)
     int32_t nck;
     float* last_state;                     // (batch, dim, nstate) or null
     int64_t last_state_sb;                 // = full_dim * nstate

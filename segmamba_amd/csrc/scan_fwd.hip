@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_apply_kernel(ScanDev P) {
             const int64_t krow = (int64_t)it.b * P.nck + tau0 / kCkpt;
 #pragma unroll
             for (int n = 0; n < NS; ++n)
-                if (n < nstate) P.ckpt[(krow * nstate + n) * gm.dim + it.d] = h[n];
+                if (n < nstate) P.ckpt[((krow * ((nstate + 1) / 2) + n / 2) * gm.dim + it.d) * 2 + (n & 1)] = h[n];
         }
         float4 bq[NS / 4], cq[NS / 4];
 #pragma unroll
@@ -535,7 +535,7 @@ void fill_scan_dev(ScanDev& P, const segm_scan_fwd_args* a, int g, int chunk) {
     P.delta_bias = a->delta_bias ? a->delta_bias + d0 : nullptr;
     P.delta_softplus = a->delta_softplus;
     P.nck = (int32_t)((a->seqlen + kCkpt - 1) / kCkpt);
-    P.ckpt = a->ckpt ? a->ckpt + (size_t)g * a->batch * P.nck * N * Dg : nullptr;
+    P.ckpt = a->ckpt ? a->ckpt + (size_t)g * a->batch * P.nck * (2 * ((N + 1) / 2)) * Dg : nullptr;
 }
 
 }  // namespace segm
@@ -569,7 +569,7 @@ extern "C" size_t segm_selective_scan_fwd_workspace_bytes(int32_t batch, int32_t
 extern "C" size_t segm_selective_scan_ckpt_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen) {
     if (batch <= 0 || dim <= 0 || dstate <= 0 || seqlen <= 0) return 0;
     const int64_t nck = (seqlen + kCkpt - 1) / kCkpt;
-    return (size_t)batch * nck * dstate * dim * sizeof(float);
+    return (size_t)batch * nck * (2 * ((dstate + 1) / 2)) * dim * sizeof(float);      // state pairs (an odd dstate pads one)
 }
 
 // one forward launch: validation, workspace slices, regular-shape or general kernels.  `PPout` (optional): instead of

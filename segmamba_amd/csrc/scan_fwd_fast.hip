@@ -214,12 +214,15 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
     const Stream ozp = make_stream<T>(has_z ? P.out_z : P.u, ub, wr, it.d);
     const StageStream<RW> sb = make_stage<T, RW>(P.Bm, ub, wr, it.r);
     const StageStream<RW> sc = make_stage<T, RW>(P.Cm, ub, wr, it.r);
-    // checkpoints: state entering step kCkpt k of the sequence, [batch][nck][16][dim]; the wave's window as a buffer
-    // (base = first checkpoint row of the wave's lowest chunk), one scalar offset per checkpoint and state
+    // checkpoints: state entering step kCkpt k of the sequence, [batch][nck][8 state pairs][dim][2]; the wave's window as a
+    // buffer (base = first checkpoint row of the wave's lowest chunk), one scalar offset per checkpoint and pair: eight stores of
+    // 64 lanes x 8 contiguous bytes.  (Round 4 measured the alternatives at one checkpoint per 8 steps, stage 0: sixteen 4-byte
+    // stores per lane 280 us, four 16-byte stores of a state-fastest layout - 64-byte lane stride - 334 us;
+    // profiles/r04_scan_kernels_*.txt)
     const int32_t chunk0 = __builtin_amdgcn_readfirstlane(it.chunk - it.gi);
     const rsrc_t ckr = make_rsrc(P.ckpt ? P.ckpt + (((int64_t)ub * P.nck + (int64_t)chunk0 * (gm.chunk / kCkpt)) * kFS) * gm.dim : nullptr);
-    const uint32_t ck_voff = ((uint32_t)(it.gi * (gm.chunk / kCkpt)) * kFS * (uint32_t)gm.dim + (uint32_t)it.d) * 4u;
-    const int32_t ck_state = gm.dim * 4;                  // bytes between consecutive states of one checkpoint
+    const uint32_t ck_voff = ((uint32_t)(it.gi * (gm.chunk / kCkpt)) * kFS * (uint32_t)gm.dim + 2u * (uint32_t)it.d) * 4u;
+    const int32_t ck_pair = gm.dim * 8;                   // bytes between consecutive state pairs of one checkpoint
 
     float nu[kFT], nd[kFT], nz[kFT], nb[EPL], nc[EPL];
     stage_fetch_buf<T, RW>(nb, sb, wr.bias + ck.U, wr.dT);        // oldest loads at the loop head (see the aggregate kernel)
@@ -246,12 +249,13 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
         uint32_t su = (uint32_t)Un * (uint32_t)up.stb, sd = (uint32_t)Un * (uint32_t)dp.stb, sz = (uint32_t)Un * (uint32_t)zp.stb;
         const uint32_t iu = (uint32_t)(wr.dT * up.stb), id = (uint32_t)(wr.dT * dp.stb), iz = (uint32_t)(wr.dT * zp.stb);
         if (P.ckpt) {                                      // kCkpt = one sub-tile
-            uint32_t kso = (uint32_t)(s * kFS * ck_state);
+            uint32_t kso = (uint32_t)(s * (kFS / 2) * ck_pair);
 #pragma unroll
             for (int n = 0; n < kFS / 2; ++n) {
-                BufIO<float>::st(ckr, ck_voff, kso, h[n].x);
-                BufIO<float>::st(ckr, ck_voff, kso + (uint32_t)ck_state, h[n].y);
-                kso += 2u * (uint32_t)ck_state;
+                typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+                const u32x2_t v = {__float_as_uint(h[n].x), __float_as_uint(h[n].y)};
+                __builtin_amdgcn_raw_buffer_store_b64(v, ckr, ck_voff, kso, 0);
+                kso += (uint32_t)ck_pair;
             }
         }
         uint32_t oso = (uint32_t)Uc * (uint32_t)op.stb, ozso = (uint32_t)Uc * (uint32_t)ozp.stb;     // running scalar offsets

@@ -1040,12 +1040,19 @@ def wgrad_gemm(lib: L.SegmLib, a: torch.Tensor, b: torch.Tensor, layout: int) ->
 # belong to.  Every launching wrapper above therefore runs with the device of its first CUDA tensor current (a model on
 # cuda:1 while the process's current device is cuda:0 must work); nothing happens - one integer compare - when it already is.
 def _first_cuda_tensor(args):
+    """the first CUDA tensor among the arguments, looking into lists / tuples and into the keyword dicts of the `*_multi` calls"""
     for a in args:
         if isinstance(a, torch.Tensor):
             if a.is_cuda:
                 return a
-        elif isinstance(a, (list, tuple)) and a and isinstance(a[0], torch.Tensor) and a[0].is_cuda:
-            return a[0]
+        elif isinstance(a, dict):
+            t = _first_cuda_tensor(a.values())
+            if t is not None:
+                return t
+        elif isinstance(a, (list, tuple)) and a:
+            t = _first_cuda_tensor(a)
+            if t is not None:
+                return t
     return None
 
 
@@ -1055,6 +1062,8 @@ def _device_guard(fn):
     @functools.wraps(fn)
     def guarded(lib, *args, **kw):
         t = _first_cuda_tensor(args)
+        if t is None:
+            t = _first_cuda_tensor(kw.values())
         if t is not None and t.device.index != torch.cuda.current_device():
             with torch.cuda.device(t.device):
                 return fn(lib, *args, **kw)
@@ -1064,5 +1073,6 @@ def _device_guard(fn):
 
 for _name in ("scan_fwd", "scan_bwd", "conv1d_fwd", "conv1d_bwd", "conv3d_k3_wgrad", "conv3d_k3_fwd", "instnorm_fwd",
               "instnorm_bwd", "transpose_add", "layernorm_tokens_fwd", "layernorm_tokens_bwd", "sgd_clip_step", "cross_entropy",
-              "conv1d_update", "state_update", "linear_rows", "skinny_tn", "pointwise_cf", "stem_conv_fwd", "stem_conv_wgrad", "wgrad_gemm"):
+              "conv1d_update", "state_update", "linear_rows", "skinny_tn", "pointwise_cf", "stem_conv_fwd", "stem_conv_wgrad", "wgrad_gemm",
+              "scan_fwd_multi", "scan_bwd_multi", "conv1d_fwd_multi", "conv1d_bwd_multi", "channel_sum"):
     globals()[_name] = _device_guard(globals()[_name])

@@ -67,6 +67,7 @@ class ParamBank:
         self._dtotal = 0
         self._dmap: Optional[torch.Tensor] = None              # the maps concatenated (rebuilt when a pack was registered)
         self._dbuf: Optional[torch.Tensor] = None
+        self.frozen = False                                    # a captured graph gathers through _dmap into _dbuf: no new packs
         self._dready = 0                                       # packs [0, _dready) of _dkeys were filled by the last refresh
 
     def attach_flat_grads(self) -> torch.Tensor:
@@ -161,6 +162,8 @@ class ParamBank:
                 return self._dbuf[o:o + n].view(shape)
             return fn(w)                                       # registered after the last refresh: direct once more
         out = fn(w)
+        if self.frozen:                                        # a HIP graph replays the gather with today's map and buffer: registering a
+            return out                                         # pack would re-create both under it (trainer.GraphedStep); stay per-call
         if self._iota is None:
             self._iota = torch.arange(8, 8 + self.flat16.numel(), dtype=torch.int32, device=self.flat16.device)
         m = fn(self._iota.as_strided(w.size(), w.stride(), off))

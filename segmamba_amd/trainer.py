@@ -208,6 +208,12 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = forward_backward(st, self.image, self.label)
+        # the graph holds raw pointers into the parameter bank's gather map / pack buffer (allocated eagerly during the warm-up,
+        # outside the graph's pool): keep them alive with the graph and stop the bank from re-creating them
+        bank = getattr(st, "bank", None)
+        if bank is not None:
+            self._bank_buffers = (bank._dmap, bank._dbuf, bank.flat16z)
+            bank.frozen = True
         st.graphed = self
 
     def __call__(self, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
@@ -215,7 +221,7 @@ class GraphedStep:
         self.label.copy_(label)
         self.graph.replay()
         finish_step(self.st)
-        return self.loss
+        return self.loss.clone()                                   # the graph's output tensor is overwritten by the next replay
 
 
 def _train_step(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:

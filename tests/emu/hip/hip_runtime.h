@@ -210,9 +210,11 @@ template <typename V> static inline void hipemu_buf_st(V v, hipemu_rsrc r, uint3
 #define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, aux) hipemu_buf_ld<uint32_t>(r, v, s)
 typedef uint32_t hipemu_u32x4 __attribute__((ext_vector_type(4)));
 #define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, aux) hipemu_buf_ld<hipemu_u32x4>(r, v, s)
+#define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, aux) hipemu_buf_ld<hipemu_u32x2>(r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b16(d, r, v, s, aux) hipemu_buf_st<unsigned short>(d, r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b32(d, r, v, s, aux) hipemu_buf_st<uint32_t>(d, r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b128(d, r, v, s, aux) hipemu_buf_st<hipemu_u32x4>(d, r, v, s)
+#define __builtin_amdgcn_raw_buffer_store_b64(d, r, v, s, aux) hipemu_buf_st<hipemu_u32x2>(d, r, v, s)
 
 // ---- MFMA / funnel-shift emulation (conv3d_wgrad.hip) -------------------------------------------------------------
 static inline uint32_t hipemu_alignbyte(uint32_t hi, uint32_t lo, uint32_t n) {

@@ -435,10 +435,10 @@ def test_scan_three_directions_in_one_launch_emulated(emu, dim, seqlen, chunk, d
     (48, 64, 16, L.TIME_FORWARD, 1, torch.float32),              # RW 16: four items per wave, three d-tiles
     (128, 48, 16, L.TIME_REVERSED, 1, torch.float32),            # RW 64, two d-tiles, chunk groups of one
 ])
-def test_scan_backward_workgroup_per_chunk_group_emulated(emu, dim, seqlen, chunk, order, ns, dtype):
-    """scan_bwd_w8.hip over its workgroup shapes (1 - 12 waves): every gradient against the oracle; dB / dC are sums in a fixed
-    order - bit-identical run to run - and, offered destinations of the tensors' own 16-bit type that are column windows of a
-    wider matrix (the x_proj gradient operand), are written there once, rounded from the fp32 sum."""
+def test_scan_backward_eight_step_windows_emulated(emu, dim, seqlen, chunk, order, ns, dtype):
+    """scan_bwd_w8.hip over 1 - 12 d-tiles and the three lane groupings: every gradient against the oracle; dB / dC are sums over
+    the d-tiles in a fixed order - bit-identical run to run - and, offered destinations of the tensors' own 16-bit type that are
+    column windows of a wider matrix (the x_proj gradient operand), are written there once, rounded from the fp32 sum."""
     c = H.scan_case(2, dim, 16, seqlen, dtype=dtype, seed=dim)
     ref = H.scan_oracle(c, order, ns)
     res = H.run_scan(emu, c, "cpu", True, order, ns, chunk=chunk)

@@ -66,3 +66,28 @@ def test_kernels_follow_the_tensors_device_not_the_current_device():
     res = H.run_scan(L.get_lib(), c, "cuda:1", True, backward=False)
     assert res["out"].device.index == 1 and torch.cuda.current_device() == 0
     H.assert_close(res["out"], ref["out"], 1e-3, 1e-3, "scan on cuda:1 with cuda:0 current")
+
+
+def test_whole_mamba_block_follows_the_tensors_device():
+    """the three-direction entry points (`*_multi`) and `channel_sum` take the device of their tensors too - a whole
+    Mamba(v3) block, forward and backward, on cuda:1 while cuda:0 is current equals the same block on cuda:0 (two GPUs needed)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    from mamba_ssm import Mamba
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    m0 = Mamba(d_model=48, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=8).to("cuda:0")
+    m1 = Mamba(d_model=48, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=8).to("cuda:1")
+    m1.load_state_dict(m0.state_dict())
+    x = torch.randn(2, 512, 48)
+    outs = []
+    for m, dev in ((m0, "cuda:0"), (m1, "cuda:1")):
+        xi = x.to(dev).requires_grad_()
+        y = m(xi)
+        y.square().mean().backward()
+        assert torch.cuda.current_device() == 0 and y.device == torch.device(dev)
+        outs.append((y.detach().cpu(), xi.grad.cpu(), {k: p.grad.cpu() for k, p in m.named_parameters()}))
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)
+    for k in outs[0][2]:
+        assert torch.allclose(outs[0][2][k], outs[1][2][k], rtol=1e-4, atol=1e-6), k

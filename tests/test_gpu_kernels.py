@@ -239,6 +239,37 @@ def test_causal_conv1d_repeatability(hip):
         assert torch.equal(out, out0) and torch.equal(dx, dx0) and torch.equal(dw, dw0) and torch.equal(db, db0)
 
 
+def test_selective_scan_backward_repeatability(hip):
+    """Round 4: dB / dC are sums over the d-tiles in a FIXED order (per-tile fp32 slabs + a sum kernel, csrc/scan_bwd_w8.hip) - no
+    float atomics: every gradient of the SegMamba stage-0 shape (three d-tiles of 32 channels) is bit-identical across 20
+    launches; and dB / dC written in the tensors' own type into strided column windows equal the fp32 results rounded once."""
+    torch.manual_seed(1)
+    B, Lq, D, N = 2, 4096, 96, 16
+    rn = lambda *s: torch.randn(*s, device=DEV)
+    dt = torch.bfloat16
+    u, z, g = rn(B, Lq, D).to(dt), rn(B, Lq, D).to(dt), rn(B, Lq, D).to(dt)
+    delta = (0.5 * torch.rand(B, Lq, D, device=DEV)).to(dt)
+    A = -0.5 * torch.rand(D, N, device=DEV) - 0.05
+    Bm, Cm = rn(B, Lq, N).to(dt), rn(B, Lq, N).to(dt)
+    Dv, db = rn(D), 0.5 * torch.rand(D, device=DEV)
+    for order, ns in ((L.TIME_FORWARD, 1), (L.TIME_REVERSED, 1), (L.TIME_INTERLEAVED, 64)):
+        f = ops_raw.scan_fwd(hip, u, delta, A, Bm, Cm, Dv, z, db, True, channel_last=True, time_order=order, nslices=ns,
+                             need_out=True, need_ckpt=True)
+        kw = dict(channel_last=True, time_order=order, nslices=ns, chunk=f["chunk"])
+        args = (u, delta, A, Bm, Cm, Dv, z, db, g, f["out"], f["ckpt"], True)
+        r0 = ops_raw.scan_bwd(hip, *args, **kw)
+        assert not r0["dbc_native"]
+        for _ in range(20):
+            r = ops_raw.scan_bwd(hip, *args, **kw)
+            for k in ("du", "ddelta", "dz", "dA", "dB", "dC", "dD", "ddelta_bias"):
+                assert torch.equal(r[k], r0[k]), (k, order)
+        wide = torch.zeros(B, Lq, 40, device=DEV, dtype=dt)
+        r = ops_raw.scan_bwd(hip, *args, dB=wide[:, :, 4:20], dC=wide[:, :, 20:36], **kw)
+        assert r["dbc_native"]
+        assert torch.equal(wide[:, :, 4:20], r0["dB"].to(dt)) and torch.equal(wide[:, :, 20:36], r0["dC"].to(dt))
+        assert not bool(wide[:, :, :4].any()) and not bool(wide[:, :, 36:].any())
+
+
 def test_error_behaviour(hip):
     """reference TORCH_CHECKs (selective_scan.cpp:233-303, causal_conv1d.cpp:136-170) surface as RuntimeError."""
     x = torch.randn(1, 8, 16, device=DEV)

@@ -117,7 +117,8 @@ def test_segmamba_bf16_library_path_matches_fp32_forward_128cube():
 
 def test_graphed_step_matches_eager_step():
     """trainer.GraphedStep (forward + backward replayed from a captured HIP graph, optimizer eager) == the eager flat step:
-    loss and every parameter after three steps on alternating batches (atomics in dB / dC make the last bits run-dependent)"""
+    loss and every parameter after three steps on alternating batches (the routes a capture freezes may differ from the eager
+    step's in their rounding; round 4 removed the float atomics of dB / dC, see test_selective_scan_backward_repeatability)"""
     from segmamba_amd.trainer import GraphedStep, build_training_state, train_step
     sd = {k: v.clone() for k, v in _model().state_dict().items()}
     batches = [_batch(32, 1, seed=s) for s in (1, 2)]
