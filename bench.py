@@ -169,7 +169,14 @@ def scan_roofline(dtype, device):
     # whose plain ops rotated over the four register banks and counted nothing but vector instructions).  Per wave-step the aggregate
     # pass issues 18 transcendental + 37 other vector + ~17 scalar / LDS / memory instructions, the apply pass 20 + 58 + ~40
     # (tools/isa_mix.py on the shipped binary): 359 + 515 cycles.  Measured with 6 waves per SIMD of work: 340 - 357 and 503 - 528.
-    cyc_needed = round(18 * 9.0 + 37 * 4.4 + 17 * 2.0) + round(20 * 9.0 + 58 * 4.4 + 40 * 2.0)      # aggregate pass + apply pass
+    # Round 4: the counts of the shipped binary (tools/isa_mix.py; checkpoints every 8 steps now) and, next to the shipped stream,
+    # the FLOOR of the two-pass algorithm - what no implementation of it can go below, so that `frac` cannot improve by recounting
+    # (VERDICT r03): 32 v_exp (one per step, state and pass) + 4 transcendentals of softplus and the gate at 9 cycles; the packed
+    # recurrence 3 (aggregate) + 4 (apply) instructions per state pair = 56, and ~10 others (one load + convert per row stream
+    # and pass, the two stores, the output sum) at 4.4 cycles: 324 + 246 + 44 = 614 cycles per wave-step.
+    shipped = {"aggregate": [18, 38, 15], "apply": [20, 55, 31]}      # [transcendental, other vector, scalar / LDS / memory / wait]
+    cyc_needed = round(sum(t * 9.0 + v * 4.4 + o * 2.0 for t, v, o in shipped.values()))
+    cyc_floor = round(36 * 9.0 + 56 * 4.4 + 10 * 4.4)
     elems_per_simd = B * D * Lq / 64 / 1024                    # wave-steps per SIMD (256 CUs x 4 SIMDs)
     cyc_taken = ms_f * 1e-3 * 2.1e9 / elems_per_simd
     cyc_taken3 = ms_f3 * 1e-3 * 2.1e9 / (3 * elems_per_simd)
@@ -179,19 +186,29 @@ def scan_roofline(dtype, device):
         "achieved": round(gf, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gf / HBM_PEAK_GBPS, 4),
         "ms": round(ms_f, 4), "algorithmic_bytes": bytes_f,
         "traffic": tr["bytes"] if tr else None, "traffic_source": tr,
-        "valu": {"bound": "instruction issue", "cycles_needed_per_wave_step": cyc_needed,
+        "valu": {"bound": "instruction issue",
+                 "floor": {"cycles_per_wave_step": cyc_floor, "frac": round(cyc_floor / cyc_taken, 4),
+                           "frac_three_directions_per_launch": round(cyc_floor / cyc_taken3, 4),
+                           "what": "minimal instruction stream of the two-pass algorithm: 32 v_exp + 4 softplus / gate transcendentals, "
+                                   "56 packed recurrence instructions, ~10 load / convert / store / sum"},
+                 "cycles_needed_per_wave_step": cyc_needed,
                  "cycles_taken_per_wave_step_at_2.1GHz": round(cyc_taken, 1), "frac": round(cyc_needed / cyc_taken, 4),
                  "three_directions_per_launch": {"cycles_taken_per_wave_step": round(cyc_taken3, 1), "frac": round(cyc_needed / cyc_taken3, 4)},
                  "instruction_costs_cycles": {"transcendental": 9.0, "other_vector": 4.4, "scalar_lds_memory": 2.0,
                                               "source": "profiles/r03_probe_valu3.log, r03_scan_occupancy.log, r03_scan_ablations.log"},
-                 "instructions_per_wave_step": {"aggregate": [18, 37, 17], "apply": [20, 58, 40]},
+                 "instructions_per_wave_step": shipped,
                  "measured_with_6_waves_per_simd": {"aggregate": [340, 357], "apply": [503, 528]}},
         "note": "bound = what limits the kernel: instructions issued per SIMD (one v_exp_f32 per step and state in each of the two "
                 "passes plus the recurrence; ~4.4 cycles per vector instruction whatever the occupancy).  achieved / peak / frac price "
                 "it against the HBM roofline BASELINE.json's metric names (algorithmic bytes / time vs 8 TB/s); valu.frac prices the "
                 "same launch against the issue bound of the shipped instruction stream",
         "backward": {"achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4), "ms": round(ms_b, 4),
-                     "algorithmic_bytes": bytes_b},
+                     "algorithmic_bytes": bytes_b,
+                     "main_kernel": {"file": "csrc/scan_bwd_w8.hip", "instructions_per_step": 290,
+                                     "per_state_pair_and_8_steps": {"vector": 152, "transcendental": 16, "lds": 13, "other": 23},
+                                     "round_3": {"file": "scan_bwd_pair.hip (removed)", "instructions_per_step": 510, "ms": 0.915},
+                                     "source": "tools/isa_mix.py on the shipped binary (profiles/r04_scan_bwd_isa.txt)"},
+                     "deterministic": "dB / dC: per-d-tile fp32 slabs added in tile order (no atomics)"},
         "three_directions_per_launch": {
             "what": "the launch the training step issues: forward / reversed / slice-interleaved scans of one layer as one grid",
             "fwd_ms": round(ms_f3, 4), "fwd_achieved": round(gf3, 1), "fwd_frac": round(gf3 / HBM_PEAK_GBPS, 4),
@@ -416,8 +433,15 @@ def main():
     # The forward + backward bracket as ONE captured HIP graph (trainer.GraphedStep); the batch is copied into the graph's
     # static input buffers every step, the all-reduce / optimizer / scheduler run eagerly behind the replay.  The capture
     # warm-up runs the bracket without an optimizer step, so it is not part of --warmup.
+    # N > 1: eager launches by default - the gradient exchange then runs in segments on a side stream while the backward pass is
+    # still producing gradients (trainer.SegmentedExchange); a captured bracket can only be followed by ONE exposed all-reduce.
+    # SEGM_GRAPH_DDP=1 times the graph + one-call form instead; the other form is measured behind the timed region either way.
     graph_note = "off (--no-graph / SEGM_GRAPH=0)"
-    if state.flat and not dry and not args.no_graph and os.environ.get("SEGM_GRAPH", "1") == "1":
+    graph_ddp = os.environ.get("SEGM_GRAPH_DDP", "0") == "1"
+    if state.exchange is not None and not graph_ddp:
+        graph_note = "off (N > 1: eager launches, gradient exchange in segments overlapped with the backward pass)"
+        state.exchange.record_exposed = True
+    elif state.flat and not dry and not args.no_graph and os.environ.get("SEGM_GRAPH", "1") == "1":
         from segmamba_amd.trainer import GraphedStep
         try:
             GraphedStep(state, *data.next())
@@ -442,7 +466,24 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     rank_ms = [elapsed / args.steps * 1e3]
-    allreduce_ms = None
+    allreduce_ms = exposed_ms = other_form = None
+    overlapped = state.exchange is not None and not state.exchange.suspended      # the form the timed region ran
+    if distributed and state.exchange is not None and not dry:
+        exposed_ms = state.exchange.exposed_ms() if state.exchange.record_exposed else None
+        state.exchange.record_exposed = False
+        if state.graphed is None and not args.no_graph:   # the other form behind the timed region: captured bracket + one call
+            try:
+                from segmamba_amd.trainer import GraphedStep
+                GraphedStep(state, *data.next())
+                step()
+                dist.barrier(); sync()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                dist.barrier(); sync()
+                other_form = {"form": "hipGraph replay + one all-reduce behind it", "ms_per_step": round((time.perf_counter() - t1) / 3 * 1e3, 3)}
+            except Exception as e:                          # noqa: BLE001
+                other_form = {"form": "hipGraph replay + one all-reduce behind it", "error": f"{type(e).__name__}: {str(e)[:160]}"}
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
@@ -463,12 +504,20 @@ def main():
         vols = world * args.batch * args.steps
         ddp = None
         if distributed:
-            ddp = {"mode": "flat: one all-reduce of the flat fp32 gradient array per step, no wrapper"} if state.flat else dict(DDP_SETTINGS, mode="torch DistributedDataParallel")
+            if state.flat and overlapped:
+                ddp = {"mode": f"flat: the fp32 gradient array exchanged in {len(state.exchange.ranges)} segments on a side stream while the "
+                               "backward pass runs, no wrapper", "segments": len(state.exchange.ranges)}
+            elif state.flat:
+                ddp = {"mode": "flat: one all-reduce of the flat fp32 gradient array per step, no wrapper"}
+            else:
+                ddp = dict(DDP_SETTINGS, mode="torch DistributedDataParallel")
             ddp["backend"] = "gloo (cpu dry run)" if dry else "nccl = RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
             ddp["rank_ms_per_step"] = {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)}
             if state.flat:
                 ddp["gradient_bytes"] = int(state.bank.flat_grad.numel()) * 4
-                ddp["allreduce_ms"] = allreduce_ms
+                ddp["allreduce_ms"] = allreduce_ms           # the whole array as one call, on its own
+                ddp["allreduce_exposed_ms"] = None if exposed_ms is None else round(exposed_ms, 3)   # main stream waiting behind the backward pass
+                ddp["other_form"] = other_form
         amp_name = {torch.bfloat16: "bf16", torch.float16: "fp16"}.get(state.autocast_dtype, str(state.autocast_dtype))
         out = {
             "metric": f"volumes/sec fwd+bwd+step, SegMamba {args.size}^3x4 (whole job; divide by n_gpus for per-GPU)",

@@ -89,10 +89,30 @@ class ParamBank:
         for p in self.params:
             p.grad = None
 
-    def gather_grads(self) -> None:
+    def point_grads_at_windows(self) -> None:
+        for p, w in zip(self.params, self.grad_windows):
+            p.grad = w
+
+    def gather_grads(self, first: int = 0, last: Optional[int] = None) -> None:
         """the gradients the backward pass left on the parameters -> their windows of `flat_grad` by one multi-tensor copy
         (a parameter without a gradient: zeros), and `p.grad` points at the windows again.  Replaces 286 in-place accumulation
-        launches plus the zero fill of the buffer (profiles/r03_step_v1_step_kernels.txt: 305 fp32 adds, 1.2 ms per step)."""
+        launches plus the zero fill of the buffer (profiles/r03_step_v1_step_kernels.txt: 305 fp32 adds, 1.2 ms per step).
+        `first` / `last`: only the parameters [first, last) - one segment of an overlapped exchange (trainer.SegmentedExchange);
+        `p.grad` is then left alone (the backward pass may still be running)."""
+        part = last is not None
+        if part:
+            dst, src = [], []
+            with torch.no_grad():
+                for p, w in zip(self.params[first:last], self.grad_windows[first:last]):
+                    g = p.grad
+                    if g is None:
+                        w.zero_()
+                    elif g.data_ptr() != w.data_ptr():
+                        dst.append(w)
+                        src.append(g if g.dtype == torch.float32 else g.float())
+                if dst:
+                    torch._foreach_copy_(dst, src)
+            return
         dst, src = [], []
         with torch.no_grad():
             for p, w in zip(self.params, self.grad_windows):

@@ -15,10 +15,12 @@ lr_scheduler.py:36 poly 0.9).  Differences, all deliberate:
   * multi-GPU is data parallel by volume over RCCL, one process per GPU launched by torchrun, batch per GPU 2 (weak scaling).
     Two forms of the same arithmetic (mean of the ranks' gradients, then one identical update on every rank):
       ddp="flat" (default on the GPU)  the parameters, their gradients and momenta live in three flat fp32 arrays
-                 (param_bank.py); a step is  [forward + backward]  ->  ONE all-reduce of the flat gradient array
-                 (269.7 MB over xGMI)  ->  clip + SGD over the flat arrays.  The bracket has fixed addresses and no host
-                 decision in it, so it is captured once as a HIP graph (`GraphedStep`) and replayed: ~2000 kernel launches per
-                 step cost the host one `hipGraphLaunch`;
+                 (param_bank.py); a step is  [forward + backward]  ->  all-reduce of the flat gradient array
+                 (269.7 MB over xGMI)  ->  clip + SGD over the flat arrays.  Eager launches: the array is exchanged in K
+                 segments, each on a side stream as soon as the backward pass has produced it (`SegmentedExchange`, K = 4;
+                 round 4 - the one call behind the backward pass was fully exposed).  The bracket has fixed addresses, so it
+                 can also be captured once as a HIP graph (`GraphedStep`) and replayed - ~1500 kernel launches per step cost the
+                 host one `hipGraphLaunch` - with the exchange as ONE call behind the replay (a graph holds no host decisions);
       ddp="torch"  the reference's wrapper - DistributedDataParallel (trainer.py:353-357), bucketed all-reduce overlapped
                  with the backward pass, eager launches.
 """
@@ -80,13 +82,16 @@ class TrainingState:
     flat: bool = False             # gradients / momenta in flat arrays next to the bank's parameters (attach_flat_grads)
     world: int = 1                 # ranks averaging their gradients through ONE all-reduce of the flat array (ddp="flat")
     graphed: object = None         # GraphedStep once the forward + backward bracket has been captured
+    exchange: object = None        # SegmentedExchange: the flat all-reduce in segments overlapped with the backward pass
 
 
 def build_training_state(device, distributed: bool = False, local_rank: int = 0, max_steps: int = 250 * 1000,
                          model: nn.Module | None = None, amp: str | None = None, ddp: str | None = None,
-                         flat: bool | None = None) -> TrainingState:
+                         flat: bool | None = None, ddp_segments: int | None = None) -> TrainingState:
     """ddp: "flat" | "torch" (see the module docstring; default SEGM_DDP, else "flat" where the parameter bank exists).
-    flat: keep gradients / momenta in flat arrays also on one GPU (default: yes with the bank and the fused optimizer)."""
+    flat: keep gradients / momenta in flat arrays also on one GPU (default: yes with the bank and the fused optimizer).
+    ddp_segments: ddp="flat" exchanges the flat gradient array in this many segments, each started as soon as the backward pass
+    has produced it (SegmentedExchange; default SEGM_DDP_SEGMENTS, else 4); 1 = one all-reduce behind the backward pass."""
     amp = (amp or os.environ.get("SEGM_AMP", "bf16")).lower()
     if amp not in ("bf16", "fp16"):
         raise ValueError(f"amp must be 'bf16' or 'fp16', got {amp!r}")
@@ -140,6 +145,10 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
         bank.attach_flat_grads()
         opt.use_flat(bank)
         st.flat = True
+    if st.flat and world > 1:
+        k = int(ddp_segments if ddp_segments is not None else os.environ.get("SEGM_DDP_SEGMENTS", "4"))
+        if k > 1:
+            st.exchange = SegmentedExchange(bank, world, k)
     if amp == "fp16":
         st.autocast_dtype = torch.float16
         st.scaler = torch.amp.GradScaler(device.type)     # the reference's GradScaler() defaults: 2^16, x2 / 2000 steps, x0.5 on inf
@@ -159,25 +168,132 @@ def train_step(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> t
         return _train_step(st, image, label)
 
 
+class SegmentedExchange:
+    """The gradient exchange of ddp="flat" in K segments that start while the backward pass is still running - what DDP's
+    bucketed all-reduce does for the reference (light_training/trainer.py:353-357), on the flat array.
+
+    The backward pass produces gradients in reverse parameter order (decoder first, stem last).  The flat array is cut at
+    parameter boundaries into K contiguous segments of about equal bytes; a post-accumulate hook per parameter counts a
+    segment down, and when its last gradient exists the segment is copied into its window of the flat array (main stream), an
+    event is recorded and a side stream issues `all_reduce(flat_grad[a:b])` behind it.  finish() makes the main stream wait
+    for the side stream (and exchanges what the hooks never completed: parameters without a gradient).  The sums are
+    element-wise, so the result equals the one-call exchange bit for bit.  K = 1: the one call behind the backward pass.
+    A captured HIP graph cannot hold the hooks' host decisions: while `suspended` (GraphedStep's capture and its replays) the
+    hooks do nothing and finish() is the one call."""
+
+    def __init__(self, bank, world: int, segments: int):
+        self.bank, self.world = bank, world
+        self.suspended = False
+        params = bank.params
+        sizes = [p.numel() for p in params]
+        total = sum(sizes)
+        k = max(1, min(int(segments), len(params)))
+        self.ranges = []                                   # (first parameter, one past the last, element offset a, b)
+        i0, acc, a = 0, 0, bank.offsets[id(params[0])]
+        for i, n in enumerate(sizes):
+            acc += n
+            if acc >= total * (len(self.ranges) + 1) / k or i == len(sizes) - 1:
+                b = bank.offsets[id(params[i])] + n
+                self.ranges.append((i0, i + 1, a, b))
+                i0, a = i + 1, b
+        self.seg_of = {}
+        for s, (p0, p1, _, _) in enumerate(self.ranges):
+            for i in range(p0, p1):
+                self.seg_of[id(params[i])] = s
+        self.left = [0] * len(self.ranges)
+        self.sent = [True] * len(self.ranges)
+        self.stream = torch.cuda.Stream() if bank.flat_grad.is_cuda else None
+        self.works = []
+        self.exposed_events = []                           # (backward done, exchange done) on the main stream, per step
+        self.record_exposed = False
+        self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in params]
+
+    def arm(self):
+        """before the backward pass of a step"""
+        self.left = [p1 - p0 for p0, p1, _, _ in self.ranges]
+        self.sent = [False] * len(self.ranges)
+        self.works = []
+
+    def _hook(self, p):
+        if self.suspended or all(self.sent):
+            return
+        s = self.seg_of[id(p)]
+        self.left[s] -= 1
+        if self.left[s] == 0 and not self.sent[s]:
+            self._send(s)
+
+    def _send(self, s):
+        import torch.distributed as dist
+        p0, p1, a, b = self.ranges[s]
+        self.bank.gather_grads(p0, p1)                     # this segment's fresh gradients -> their windows (main stream)
+        seg = self.bank.flat_grad[a:b]
+        self.sent[s] = True
+        if self.stream is None:
+            self.works.append(dist.all_reduce(seg, async_op=True))
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            dist.all_reduce(seg)
+
+    def finish(self):
+        """behind the backward pass: every segment is exchanged and visible to the main stream"""
+        import torch.distributed as dist
+        if self.suspended:
+            dist.all_reduce(self.bank.flat_grad)            # one call (the gradients were gathered inside the graph)
+            return
+        e0 = e1 = None
+        if self.record_exposed and self.stream is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for s in range(len(self.ranges)):
+            if not self.sent[s]:
+                self._send(s)
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        if e0 is not None:
+            e1.record()
+            self.exposed_events.append((e0, e1))
+        self.bank.point_grads_at_windows()
+
+    def exposed_ms(self):
+        """average milliseconds per step the main stream waited for the exchange behind the backward pass"""
+        if not self.exposed_events:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.exposed_events) / len(self.exposed_events)
+
+
 def forward_backward(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
     """The bracket of a flat-mode step that a HIP graph can hold: 16-bit parameter copies, zeroed flat gradient array,
     autocast forward, loss, backward.  With `st.world` ranks the loss is scaled by 1 / world before the backward pass so that
     the SUM all-reduce in finish_step() leaves the mean gradient (what DDP's bucket division does)."""
+    overlapped = st.exchange is not None and not st.exchange.suspended
     with st.bank.step():
         st.bank.release_grads()                                    # trainer.py:445 sets every p.grad to None
+        if overlapped:
+            st.exchange.arm()
         with torch.autocast(image.device.type, dtype=st.autocast_dtype, enabled=image.device.type == "cuda"):
             pred = st.model(image)
             loss = st.loss_fn(pred, label)                         # 3_train.py:62
         (loss / st.world if st.world > 1 else loss).backward()
-        st.bank.gather_grads()                                     # the fresh gradient tensors -> the flat array, one launch
+        if not overlapped:
+            st.bank.gather_grads()                                 # the fresh gradient tensors -> the flat array, one launch
     return loss.detach()
 
 
 def finish_step(st: TrainingState) -> None:
     """exchange + update of a flat-mode step: all-reduce (world > 1), clip 12 + SGD-Nesterov over the flat arrays, poly LR"""
     if st.world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(st.bank.flat_grad)                          # 269.7 MB fp32 over xGMI, one collective
+        if st.exchange is not None:
+            st.exchange.finish()                                    # segments already in flight behind the backward pass
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(st.bank.flat_grad)                      # 269.7 MB fp32 over xGMI, one collective
     st.optimizer.step()
     st.scheduler.step()
     st.step += 1
@@ -198,6 +314,8 @@ class GraphedStep:
         self.st = st
         self.image = image.clone()
         self.label = label.clone()
+        if st.exchange is not None:
+            st.exchange.suspended = True                            # no host decisions inside a captured bracket: one-call exchange
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                              # lazy initialisation and the routing tuner run here, eagerly

@@ -34,14 +34,19 @@ def _net(st):
     return st.model.module if hasattr(st.model, "module") else st.model
 
 
-def _worker(rank, world, port, out, library=False, ddp="torch"):
+def _worker(rank, world, port, out, library=False, ddp="torch", segments=None, suspend=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if library:
         _use_emulated_library()
     from segmamba_amd.trainer import build_training_state, train_step
-    st = build_training_state(torch.device("cpu"), distributed=True, model=_tiny_model(), ddp=ddp)
+    st = build_training_state(torch.device("cpu"), distributed=True, model=_tiny_model(), ddp=ddp, ddp_segments=segments)
     assert st.flat == (library and ddp == "flat") and st.world == (world if st.flat else 1)
+    if st.flat and segments is not None:
+        assert (st.exchange is not None) == (segments > 1)
+        if st.exchange is not None:
+            assert len(st.exchange.ranges) == min(segments, 4)       # four parameters: at most four segments
+            st.exchange.suspended = suspend                          # what GraphedStep sets: hooks idle, one call in finish()
     img, lab = _batch(rank)
     for _ in range(2):
         loss = train_step(st, img, lab)
@@ -106,6 +111,32 @@ def test_two_process_ddp_with_library_loss_and_optimizer(monkeypatch, ddp):
     monkeypatch.setattr(L, "_lib", emu_util.emu_lib())
     monkeypatch.setattr(L, "on_device", lambda t: True)
     assert isinstance(build_training_state(torch.device("cpu"), model=_tiny_model()).optimizer, FusedClipSGD)
+
+
+def test_segmented_exchange_equals_the_one_call_exchange_bit_for_bit():
+    """ddp="flat": the gradient all-reduce in K segments started from post-accumulate hooks while the backward pass runs
+    (trainer.SegmentedExchange; the reference's DDP overlaps its buckets the same way, light_training/trainer.py:353-357) must
+    leave exactly the parameters of the one-call exchange - sums are element-wise - for K = 2, 3, 8 (more segments than
+    parameters), and so must the suspended form a captured HIP graph uses (hooks idle, one call behind the bracket)."""
+    from tests import emu_util
+    if not emu_util.emu_available():
+        pytest.skip("no host clang for the emulation build")
+    emu_util.build_emu()
+    results = {}
+    for key, (segments, suspend) in {"one": (1, False), "k2": (2, False), "k3": (3, False), "k8": (8, False), "graph": (3, True)}.items():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_worker, args=(2, port, out, True, "flat", segments, suspend), nprocs=2, join=True)
+        for a, b in zip(out[0][1], out[1][1]):
+            assert torch.equal(a, b), f"ranks diverged ({key})"
+        results[key] = (out[0][0], [t.clone() for t in out[0][1]])
+    for key in ("k2", "k3", "k8", "graph"):
+        assert results[key][0] == results["one"][0], key
+        for a, b in zip(results[key][1], results["one"][1]):
+            assert torch.equal(a, b), key
 
 
 def _segmamba_worker(rank, world, port, out, ddp="torch"):

@@ -78,7 +78,8 @@ def _run_and_check(hip, c, dtype, order, ns, what, ch=None, want_bc=True, elem_s
 
 
 @pytest.mark.parametrize("order,dtype", [(L.TIME_FORWARD, torch.float32), (L.TIME_REVERSED, torch.float32),
-                                         (L.TIME_INTERLEAVED, torch.float32), (L.TIME_INTERLEAVED, torch.bfloat16)])
+                                         (L.TIME_INTERLEAVED, torch.float32), (L.TIME_INTERLEAVED, torch.bfloat16),
+                                         (L.TIME_INTERLEAVED, torch.float16)])      # fp16: the reference's AMP dtype
 def test_stage0_size_forward_and_all_gradients(hip, order, dtype):
     c = _case(2, 96, 16, 64 ** 3, dtype, seed=1 + order)
     _run_and_check(hip, c, dtype, order, 64, f"stage0 L=262144 order={order} {dtype}")

@@ -1,0 +1,204 @@
+"""GPU parity of single blocks at the network's REAL widths, conditioned on identical inputs:
+
+the whole-network bf16 gradient test (test_gpu_network_bf16.py) measures the library path against the rounding floor of bf16
+storage, a floor that is 20 - 45 % per tensor in deep layers - a kernel error of that order in one layer could hide in it.
+Here every block gets the SAME bf16-representable input x and the SAME bf16-representable upstream gradient dy on both routes -
+the library route (bf16 autocast: MFMA convolutions, fused norm / pointwise / scan kernels, fp32 master weights) and the fp32
+route (no autocast: ATen convolutions, fp32 norm / scan kernels, same weights) - so the error of one block's kernels is not
+multiplied by the conditioning of the sixty layers around it:
+
+    out, dx, every dW :   max |lib - fp32|  <=  tol * max |fp32|        (per tensor; tol per block below, <= 2e-2)
+
+plus the benchmarked shape itself (2 x 128^3, padded channel strides): forward, data gradient and weight gradient of the 48 -> 48
+layer and of the cat(up, skip) 96 -> 48 layer against fp32 ATen on the same rounded operands, and the fp16 route - the
+reference's actual AMP dtype (light_training/trainer.py:65-67) - through the scan at the stage-0 size and through the network.
+"""
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _r16(t, dt=torch.bfloat16):
+    return t.to(dt).float()
+
+
+def _log(what, err, ref, tol):
+    H._parity_log({"what": what, "max_abs_err": float(err), "ref_max": float(ref), "worst": float(err / tol) if tol else 0.0,
+                   "rtol": 0.0, "atol": float(tol), "dev": "cuda"})
+
+
+def _run(block, inputs, dy, lib: bool, dt=torch.bfloat16):
+    """forward + backward of `block` on `inputs` (tuple) with upstream gradient dy; lib: 16-bit autocast route"""
+    for p in block.parameters():
+        p.grad = None
+    xs = [x.detach().clone().requires_grad_() for x in inputs]
+    if lib:
+        with torch.autocast("cuda", dtype=dt):
+            y = block(*[x.to(dt) for x in xs])
+        y.backward(dy.to(y.dtype))
+    else:
+        y = block(*xs)
+        y.backward(dy)
+    return (y.detach().float(), [x.grad.detach().float() for x in xs],
+            {k: p.grad.detach().float().clone() for k, p in block.named_parameters()})
+
+
+def _compare(name, block, inputs, tol, dt=torch.bfloat16, seed=0):
+    block = block.to(DEV)
+    with torch.no_grad():
+        shape = block(*inputs).shape
+    dy = _r16(torch.randn(shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed + 1)), dt)
+    yr, dxr, dwr = _run(block, inputs, dy, False)
+    yl, dxl, dwl = _run(block, inputs, dy, True, dt)
+    bad = []
+
+    def check(what, a, b):
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        _log(f"{name} {what}", err, scale, tol * scale)
+        if err > tol * scale:
+            bad.append((what, err, scale))
+    check("out", yl, yr)
+    for i, (a, b) in enumerate(zip(dxl, dxr)):
+        check(f"dx{i}", a, b)
+    for k in dwr:
+        check("d" + k, dwl[k], dwr[k])
+    assert not bad, (name, bad[:6])
+
+
+def _vol(c, s, seed, batch=1):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return _r16(torch.randn(batch, c, s, s, s, device=DEV, generator=g))
+
+
+@pytest.mark.parametrize("cin,cout,size", [(48, 48, 32), (96, 96, 16), (96, 48, 32), (192, 192, 8)])
+def test_unet_res_block_conditioned(cin, cout, size):
+    """UnetResBlock (3x3x3 conv -> IN -> LeakyReLU -> 3x3x3 conv -> IN [, 1x1x1 conv -> IN], add, LeakyReLU):
+    monai dynunet_block.py:25-111 at the encoder / decoder widths"""
+    from segmamba_amd.unet_blocks import UnetResBlock
+    torch.manual_seed(cin + cout)
+    _compare(f"UnetResBlock {cin}->{cout} @{size}^3", UnetResBlock(cin, cout), (_vol(cin, size, 3),), 2e-2)
+
+
+@pytest.mark.parametrize("c,size", [(48, 32), (96, 16)])
+def test_gsc_block_conditioned(c, size):
+    """GSC (model_segmamba/segmamba.py:78-131): 3^3 conv x 2 + 1^3 branch, IN + ReLU each, sum, 1^3 conv, residual"""
+    from segmamba_amd.segmamba import GSC
+    torch.manual_seed(c)
+    _compare(f"GSC {c} @{size}^3", GSC(c), (_vol(c, size, 4),), 2e-2)
+
+
+@pytest.mark.parametrize("c,size,ns", [(48, 32, 32), (96, 16, 16), (384, 8, 8)])
+def test_mamba_layer_conditioned(c, size, ns):
+    """MambaLayer (segmamba.py:49-76): LayerNorm -> Mamba v3 (three directions: in_proj, conv1d, x_proj, dt_proj, scan, out_proj)
+    -> + skip, at stage widths 48 / 96 / 384 (d_inner 96 / 192 / 768)"""
+    from segmamba_amd.segmamba import MambaLayer
+    torch.manual_seed(c)
+    _compare(f"MambaLayer {c} @{size}^3", MambaLayer(c, num_slices=ns), (_vol(c, size, 5),), 2e-2)
+
+
+def test_up_block_conditioned():
+    """UnetrUpBlock 96 -> 48 (unetr_block.py:22-86): ConvTranspose k2 s2, cat with the skip (never materialised here), UnetResBlock"""
+    from segmamba_amd.unet_blocks import UnetrUpBlock
+    torch.manual_seed(7)
+    _compare("UnetrUpBlock 96->48 @16->32^3", UnetrUpBlock(3, 96, 48, 3, 2), (_vol(96, 16, 6), _vol(48, 32, 7)), 2e-2)
+
+
+def test_mlp_channel_conditioned():
+    from segmamba_amd.segmamba import MlpChannel
+    torch.manual_seed(9)
+    _compare("MlpChannel 48 @32^3", MlpChannel(48, 96), (_vol(48, 32, 8),), 2e-2)
+
+
+# ---- the benchmarked shape itself: 2 x 128^3 on padded channel strides --------------------------------------------------------
+def _padded(t):
+    from segmamba_amd import ops_raw
+    out = ops_raw.volume_empty(t.shape[0], t.shape[1], tuple(t.shape[2:]), t.dtype, t.device)
+    out.copy_(t)
+    return out
+
+
+@pytest.mark.parametrize("cin", [48, 96])
+def test_conv3_forward_dgrad_wgrad_at_the_benchmarked_shape(cin):
+    """the 48 -> 48 layer and the cat(up, skip) 96 -> 48 layer (decoder2.conv_block.conv1, the largest layer of the network:
+    522 GFLOP) at 2 x 128^3 on padded channel strides: forward, data gradient and weight gradient of the library route against
+    fp32 ATen on the same bf16-rounded operands"""
+    from segmamba_amd import conv3d as C3
+    torch.manual_seed(cin)
+    B, S, cout = 2, 128, 48
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = (0.5 * torch.randn(B, cin, S, S, S, device=DEV, generator=g)).bfloat16()
+    w = (torch.randn(cout, cin, 3, 3, 3, device=DEV, generator=g) / (27 * cin) ** 0.5)
+    dy = (0.5 * torch.randn(B, cout, S, S, S, device=DEV, generator=g)).bfloat16()
+    parts = tuple(_padded(x[:, i:i + 48]).requires_grad_() for i in range(0, cin, 48))
+    wl = w.clone().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = C3.conv3d_same_cat(parts, wl) if cin > 48 else C3.conv3d_same(parts[0], wl)
+    y.backward(_padded(dy) if y.stride(1) != S ** 3 else dy)
+    w16 = w.bfloat16().float()
+    # reference in two 1 x halves (fp32 activations at this size are 1.6 GB each)
+    for b in range(B):
+        xr = x[b:b + 1].float().requires_grad_()
+        wr = w16.clone().requires_grad_()
+        yr = torch.nn.functional.conv3d(xr, wr, None, 1, 1)
+        yr.backward(dy[b:b + 1].float())
+        sc = float(yr.abs().max())
+        e = float((y[b:b + 1].float() - yr).abs().max())
+        _log(f"conv3 {cin}->48 @128^3 out b{b}", e, sc, 1e-2 * sc)
+        assert e <= 1e-2 * sc, (e, sc)
+        dxl = torch.cat([p.grad[b:b + 1].float() for p in parts], 1)
+        sc = float(xr.grad.abs().max())
+        e = float((dxl - xr.grad).abs().max())
+        _log(f"conv3 {cin}->48 @128^3 dx b{b}", e, sc, 1e-2 * sc)
+        assert e <= 1e-2 * sc, (e, sc)
+        if b == 0:
+            dw_ref = wr.grad.clone()
+        else:
+            dw_ref += wr.grad
+        del xr, yr
+    sc = float(dw_ref.abs().max())
+    e = float((wl.grad.float() - dw_ref).abs().max())
+    _log(f"conv3 {cin}->48 @128^3 dw", e, sc, 1e-2 * sc)
+    assert e <= 1e-2 * sc, (e, sc)
+
+
+# ---- fp16: the reference's AMP dtype ---------------------------------------------------------------------------------------------
+# (the fp16 scan at the stage-0 size against the fp64 C oracle: tests/test_gpu_at_size.py::test_stage0_size_forward_and_all_gradients)
+def test_segmamba_fp16_library_path_matches_fp32_64cube():
+    """the whole network under fp16 autocast (what 3_train.py runs: light_training/trainer.py:65-67) against the fp32 route at
+    64^3: loss, logits, and the gradients against the fp16 storage floor as in the bf16 test (fp16 has three more mantissa
+    bits: the floor and the bounds shrink accordingly)"""
+    import numpy as np
+    from tests.test_gpu_network_bf16 import _model, _batch, _fp32_reference
+    base = _model()
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    x, y = _batch(64, 1)
+    ref_logits, ref_loss, ref_grads = _fp32_reference(sd, x, y)
+    m = base.to(DEV)
+    with torch.autocast("cuda", dtype=torch.float16):
+        logits = m(x)
+        loss = torch.nn.functional.cross_entropy(logits.float(), y)
+    scale_loss = 1024.0                                     # a static loss scale (GradScaler's job in the training loop)
+    (loss * scale_loss).backward()
+    assert abs(float(loss) - float(ref_loss)) <= 3e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    scale = float(ref_logits.abs().max())
+    err = (logits.float() - ref_logits).abs()
+    _log("fp16 network 64^3 logits max", err.max(), scale, 2e-2 * scale)
+    assert float(err.max()) <= 2e-2 * scale and float(err.mean()) <= 3e-3 * scale, (float(err.max()), float(err.mean()), scale)
+    gmax = max(float(g.norm()) for g in ref_grads.values())
+    rel = []
+    for k, p in m.named_parameters():
+        gl, r = p.grad.float() / scale_loss, ref_grads[k].float()
+        assert torch.isfinite(gl).all(), k
+        d, rn = float((gl - r).norm()), float(r.norm())
+        _log("fp16 network 64^3 grad " + k, d, rn, 0.12 * rn + 2e-3 * gmax)
+        assert d <= 0.12 * rn + 2e-3 * gmax, (k, d, rn)
+        if rn > 1e-3 * gmax:
+            rel.append(d / rn)
+    med = float(np.median(rel))
+    _log("fp16 network 64^3 median relative gradient error", med, 1.0, 5e-2)
+    assert med <= 5e-2, med
