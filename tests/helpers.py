@@ -238,15 +238,17 @@ def check_inner_fn(out, grads, f, what, rtol=6e-4, atol=2e-3, rtolw=1e-3, atolw=
 
 # ---- "fp32 arithmetic, bf16 storage": what ANY bf16 pipeline of this network loses to rounding ------------------------------
 class _RoundBF16(torch.autograd.Function):
-    """identity whose value and gradient are rounded to bf16 (and kept in the incoming dtype)"""
+    """identity whose value and gradient are rounded to a 16-bit type (bf16 unless the simulation says fp16) and kept in the
+    incoming dtype"""
+    dtype = torch.bfloat16
 
     @staticmethod
     def forward(ctx, x):
-        return x.to(torch.bfloat16).to(x.dtype)
+        return x.to(_RoundBF16.dtype).to(x.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(g.dtype)
+        return g.to(_RoundBF16.dtype).to(g.dtype)
 
 
 class bf16_storage_simulation:
@@ -265,9 +267,14 @@ class bf16_storage_simulation:
                ("segmamba_amd.layout", ("volume_to_tokens_layernorm", "tokens_to_volume_add")),
                ("segmamba_amd.mamba_simple", ("linear_cl", "_inner")))
 
+    def __init__(self, dtype=torch.bfloat16):
+        self.dtype = dtype
+
     def __enter__(self):
         import importlib
         self.saved = []
+        self.prev_dtype = _RoundBF16.dtype
+        _RoundBF16.dtype = self.dtype
         for modname, names in self.TARGETS:
             mod = importlib.import_module(modname)
             for n in names:
@@ -283,4 +290,5 @@ class bf16_storage_simulation:
     def __exit__(self, *exc):
         for mod, n, orig in self.saved:
             setattr(mod, n, orig)
+        _RoundBF16.dtype = self.prev_dtype
         return False

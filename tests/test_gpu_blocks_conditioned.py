@@ -7,7 +7,8 @@ the library route (bf16 autocast: MFMA convolutions, fused norm / pointwise / sc
 route (no autocast: ATen convolutions, fp32 norm / scan kernels, same weights) - so the error of one block's kernels is not
 multiplied by the conditioning of the sixty layers around it:
 
-    out, dx, every dW :   max |lib - fp32|  <=  tol * max |fp32|        (per tensor; tol per block below, <= 2e-2)
+    out, dx, every dW :   ||lib - fp32||  <=  2 ||sim - fp32|| + tol ||fp32||     (per tensor, L2; `sim` = fp32 arithmetic with the
+                          block's stored tensors rounded to 16 bits: the block's own rounding floor, 1 - 8 %; tol 5e-3)
 
 plus the benchmarked shape itself (2 x 128^3, padded channel strides): forward, data gradient and weight gradient of the 48 -> 48
 layer and of the cat(up, skip) 96 -> 48 layer against fp32 ATen on the same rounded operands, and the fp16 route - the
@@ -48,25 +49,35 @@ def _run(block, inputs, dy, lib: bool, dt=torch.bfloat16):
 
 
 def _compare(name, block, inputs, tol, dt=torch.bfloat16, seed=0):
+    """Three routes on the same weights, inputs and upstream gradient: fp32 (reference), fp32 arithmetic with every stored tensor
+    rounded to 16 bits (tests/helpers.bf16_storage_simulation: what ANY 16-bit pipeline of this block loses - activations with a
+    kink flip their derivative where a pre-activation lies within rounding distance of zero, InstanceNorm's backward subtracts
+    means of rounded gradients), and the library route.  Per tensor, in the L2 norm:
+        ||lib - fp32||  <=  2 ||sim - fp32||  +  tol * scale        scale = ||fp32|| (outputs, dx), max_W ||dW_fp32|| (parameters)
+    - a kernel error of a few per cent in ONE tensor of ONE block fails it (the floors here are 1 - 8 %, where the whole-network
+    floors are 20 - 45 %)."""
     block = block.to(DEV)
     with torch.no_grad():
         shape = block(*inputs).shape
     dy = _r16(torch.randn(shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed + 1)), dt)
     yr, dxr, dwr = _run(block, inputs, dy, False)
+    with H.bf16_storage_simulation(dt):
+        ys, dxs, dws = _run(block, inputs, dy, False)
     yl, dxl, dwl = _run(block, inputs, dy, True, dt)
+    wscale = max(float(v.norm()) for v in dwr.values())
     bad = []
 
-    def check(what, a, b):
-        scale = float(b.abs().max())
-        err = float((a - b).abs().max())
-        _log(f"{name} {what}", err, scale, tol * scale)
-        if err > tol * scale:
-            bad.append((what, err, scale))
-    check("out", yl, yr)
-    for i, (a, b) in enumerate(zip(dxl, dxr)):
-        check(f"dx{i}", a, b)
+    def check(what, lib, sim, ref, scale):
+        d_lib, d_sim = float((lib - ref).norm()), float((sim - ref).norm())
+        bound = 2.0 * d_sim + tol * scale
+        _log(f"{name} {what} (L2; rounding floor {d_sim / max(scale, 1e-30):.2e})", d_lib, scale, bound)
+        if d_lib > bound:
+            bad.append((what, d_lib / max(scale, 1e-30), d_sim / max(scale, 1e-30)))
+    check("out", yl, ys, yr, float(yr.norm()))
+    for i in range(len(dxr)):
+        check(f"dx{i}", dxl[i], dxs[i], dxr[i], float(dxr[i].norm()))
     for k in dwr:
-        check("d" + k, dwl[k], dwr[k])
+        check("d" + k, dwl[k], dws[k], dwr[k], wscale)
     assert not bad, (name, bad[:6])
 
 
@@ -81,7 +92,7 @@ def test_unet_res_block_conditioned(cin, cout, size):
     monai dynunet_block.py:25-111 at the encoder / decoder widths"""
     from segmamba_amd.unet_blocks import UnetResBlock
     torch.manual_seed(cin + cout)
-    _compare(f"UnetResBlock {cin}->{cout} @{size}^3", UnetResBlock(cin, cout), (_vol(cin, size, 3),), 2e-2)
+    _compare(f"UnetResBlock {cin}->{cout} @{size}^3", UnetResBlock(cin, cout), (_vol(cin, size, 3),), 5e-3)
 
 
 @pytest.mark.parametrize("c,size", [(48, 32), (96, 16)])
@@ -89,7 +100,7 @@ def test_gsc_block_conditioned(c, size):
     """GSC (model_segmamba/segmamba.py:78-131): 3^3 conv x 2 + 1^3 branch, IN + ReLU each, sum, 1^3 conv, residual"""
     from segmamba_amd.segmamba import GSC
     torch.manual_seed(c)
-    _compare(f"GSC {c} @{size}^3", GSC(c), (_vol(c, size, 4),), 2e-2)
+    _compare(f"GSC {c} @{size}^3", GSC(c), (_vol(c, size, 4),), 5e-3)
 
 
 @pytest.mark.parametrize("c,size,ns", [(48, 32, 32), (96, 16, 16), (384, 8, 8)])
@@ -98,20 +109,20 @@ def test_mamba_layer_conditioned(c, size, ns):
     -> + skip, at stage widths 48 / 96 / 384 (d_inner 96 / 192 / 768)"""
     from segmamba_amd.segmamba import MambaLayer
     torch.manual_seed(c)
-    _compare(f"MambaLayer {c} @{size}^3", MambaLayer(c, num_slices=ns), (_vol(c, size, 5),), 2e-2)
+    _compare(f"MambaLayer {c} @{size}^3", MambaLayer(c, num_slices=ns), (_vol(c, size, 5),), 5e-3)
 
 
 def test_up_block_conditioned():
     """UnetrUpBlock 96 -> 48 (unetr_block.py:22-86): ConvTranspose k2 s2, cat with the skip (never materialised here), UnetResBlock"""
     from segmamba_amd.unet_blocks import UnetrUpBlock
     torch.manual_seed(7)
-    _compare("UnetrUpBlock 96->48 @16->32^3", UnetrUpBlock(3, 96, 48, 3, 2), (_vol(96, 16, 6), _vol(48, 32, 7)), 2e-2)
+    _compare("UnetrUpBlock 96->48 @16->32^3", UnetrUpBlock(3, 96, 48, 3, 2), (_vol(96, 16, 6), _vol(48, 32, 7)), 5e-3)
 
 
 def test_mlp_channel_conditioned():
     from segmamba_amd.segmamba import MlpChannel
     torch.manual_seed(9)
-    _compare("MlpChannel 48 @32^3", MlpChannel(48, 96), (_vol(48, 32, 8),), 2e-2)
+    _compare("MlpChannel 48 @32^3", MlpChannel(48, 96), (_vol(48, 32, 8),), 5e-3)
 
 
 # ---- the benchmarked shape itself: 2 x 128^3 on padded channel strides --------------------------------------------------------
@@ -170,19 +181,21 @@ def test_conv3_forward_dgrad_wgrad_at_the_benchmarked_shape(cin):
 # (the fp16 scan at the stage-0 size against the fp64 C oracle: tests/test_gpu_at_size.py::test_stage0_size_forward_and_all_gradients)
 def test_segmamba_fp16_library_path_matches_fp32_64cube():
     """the whole network under fp16 autocast (what 3_train.py runs: light_training/trainer.py:65-67) against the fp32 route at
-    64^3: loss, logits, and the gradients against the fp16 storage floor as in the bf16 test (fp16 has three more mantissa
-    bits: the floor and the bounds shrink accordingly)"""
+    64^3: loss, logits, and the gradients against the fp16 storage floor, as the bf16 test does against the bf16 one (fp16 has
+    three more mantissa bits: floor and bounds shrink accordingly).  A static loss scale stands in for the GradScaler."""
     import numpy as np
     from tests.test_gpu_network_bf16 import _model, _batch, _fp32_reference
     base = _model()
     sd = {k: v.clone() for k, v in base.state_dict().items()}
     x, y = _batch(64, 1)
     ref_logits, ref_loss, ref_grads = _fp32_reference(sd, x, y)
+    with H.bf16_storage_simulation(torch.float16):
+        _, _, sim_grads = _fp32_reference(sd, x.half().float(), y)
     m = base.to(DEV)
     with torch.autocast("cuda", dtype=torch.float16):
         logits = m(x)
         loss = torch.nn.functional.cross_entropy(logits.float(), y)
-    scale_loss = 1024.0                                     # a static loss scale (GradScaler's job in the training loop)
+    scale_loss = 4096.0
     (loss * scale_loss).backward()
     assert abs(float(loss) - float(ref_loss)) <= 3e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
     scale = float(ref_logits.abs().max())
@@ -190,15 +203,19 @@ def test_segmamba_fp16_library_path_matches_fp32_64cube():
     _log("fp16 network 64^3 logits max", err.max(), scale, 2e-2 * scale)
     assert float(err.max()) <= 2e-2 * scale and float(err.mean()) <= 3e-3 * scale, (float(err.max()), float(err.mean()), scale)
     gmax = max(float(g.norm()) for g in ref_grads.values())
-    rel = []
+    rel_lib, rel_sim, bad = [], [], []
     for k, p in m.named_parameters():
-        gl, r = p.grad.float() / scale_loss, ref_grads[k].float()
+        gl, r, sg = p.grad.float() / scale_loss, ref_grads[k].float(), sim_grads[k].float()
         assert torch.isfinite(gl).all(), k
-        d, rn = float((gl - r).norm()), float(r.norm())
-        _log("fp16 network 64^3 grad " + k, d, rn, 0.12 * rn + 2e-3 * gmax)
-        assert d <= 0.12 * rn + 2e-3 * gmax, (k, d, rn)
+        d, ds, rn = float((gl - r).norm()), float((sg - r).norm()), float(r.norm())
+        tol = 2.5 * ds + 2e-3 * gmax
+        _log("fp16 network 64^3 grad " + k, d, rn, tol)
+        if d > tol:
+            bad.append((k, d, ds, rn))
         if rn > 1e-3 * gmax:
-            rel.append(d / rn)
-    med = float(np.median(rel))
-    _log("fp16 network 64^3 median relative gradient error", med, 1.0, 5e-2)
-    assert med <= 5e-2, med
+            rel_lib.append(d / rn)
+            rel_sim.append(ds / rn)
+    assert not bad, bad[:8]
+    med_lib, med_sim = float(np.median(rel_lib)), float(np.median(rel_sim))
+    _log("fp16 network 64^3 median relative gradient error (library vs fp16 rounding floor)", med_lib, med_sim, 1.5 * med_sim + 5e-3)
+    assert med_lib <= 1.5 * med_sim + 5e-3, (med_lib, med_sim)

@@ -253,8 +253,11 @@ def test_selective_scan_backward_repeatability(hip):
     Bm, Cm = rn(B, Lq, N).to(dt), rn(B, Lq, N).to(dt)
     Dv, db = rn(D), 0.5 * torch.rand(D, device=DEV)
     for order, ns in ((L.TIME_FORWARD, 1), (L.TIME_REVERSED, 1), (L.TIME_INTERLEAVED, 64)):
+        # chunk 256 as at the stage-0 length (the default for L = 4096 is 16 steps: shorter than the 64 slices, and an interleaved
+        # order is only a regular shape when whole slice rounds fit a chunk - the general kernels accumulate dB / dC atomically)
         f = ops_raw.scan_fwd(hip, u, delta, A, Bm, Cm, Dv, z, db, True, channel_last=True, time_order=order, nslices=ns,
-                             need_out=True, need_ckpt=True)
+                             chunk=256, need_out=True, need_ckpt=True)
+        assert f["chunk"] == 256 and hip.dll.segm_selective_scan_regular_shape(B, D, N, Lq, 256, order, ns) == 1
         kw = dict(channel_last=True, time_order=order, nslices=ns, chunk=f["chunk"])
         args = (u, delta, A, Bm, Cm, Dv, z, db, g, f["out"], f["ckpt"], True)
         r0 = ops_raw.scan_bwd(hip, *args, **kw)
