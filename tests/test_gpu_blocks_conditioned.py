@@ -7,7 +7,7 @@ the library route (bf16 autocast: MFMA convolutions, fused norm / pointwise / sc
 route (no autocast: ATen convolutions, fp32 norm / scan kernels, same weights) - so the error of one block's kernels is not
 multiplied by the conditioning of the sixty layers around it:
 
-    out, dx, every dW :   ||lib - fp32||  <=  2 ||sim - fp32|| + tol ||fp32||     (per tensor, L2; `sim` = fp32 arithmetic with the
+    out, dx, every dW :   ||lib - fp32||  <=  1.75 ||sim - fp32|| + tol ||fp32||     (per tensor, L2; `sim` = fp32 arithmetic with the
                           block's stored tensors rounded to 16 bits: the block's own rounding floor, 1 - 8 %; tol 5e-3)
 
 plus the benchmarked shape itself (2 x 128^3, padded channel strides): forward, data gradient and weight gradient of the 48 -> 48
@@ -53,7 +53,7 @@ def _compare(name, block, inputs, tol, dt=torch.bfloat16, seed=0):
     rounded to 16 bits (tests/helpers.bf16_storage_simulation: what ANY 16-bit pipeline of this block loses - activations with a
     kink flip their derivative where a pre-activation lies within rounding distance of zero, InstanceNorm's backward subtracts
     means of rounded gradients), and the library route.  Per tensor, in the L2 norm:
-        ||lib - fp32||  <=  2 ||sim - fp32||  +  tol * scale        scale = ||fp32|| (outputs, dx), max_W ||dW_fp32|| (parameters)
+        ||lib - fp32||  <=  1.75 ||sim - fp32||  +  tol * scale      scale = ||fp32|| (outputs, dx), max_W ||dW_fp32|| (parameters)
     - a kernel error of a few per cent in ONE tensor of ONE block fails it (the floors here are 1 - 8 %, where the whole-network
     floors are 20 - 45 %)."""
     block = block.to(DEV)
@@ -69,7 +69,7 @@ def _compare(name, block, inputs, tol, dt=torch.bfloat16, seed=0):
 
     def check(what, lib, sim, ref, scale):
         d_lib, d_sim = float((lib - ref).norm()), float((sim - ref).norm())
-        bound = 2.0 * d_sim + tol * scale
+        bound = 1.75 * d_sim + tol * scale
         _log(f"{name} {what} (L2; rounding floor {d_sim / max(scale, 1e-30):.2e})", d_lib, scale, bound)
         if d_lib > bound:
             bad.append((what, d_lib / max(scale, 1e-30), d_sim / max(scale, 1e-30)))
