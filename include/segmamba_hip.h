@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SEGM_ABI_VERSION 5
+#define SEGM_ABI_VERSION 6
 
 enum segm_dtype { SEGM_F32 = 0, SEGM_F16 = 1, SEGM_BF16 = 2 };
 enum segm_time_order { SEGM_TIME_FORWARD = 0, SEGM_TIME_REVERSED = 1, SEGM_TIME_INTERLEAVED = 2 };
@@ -112,6 +112,16 @@ typedef struct segm_scan_fwd_args {
     const float* conv_weight; /* (dim, conv_width) contiguous fp32                                  */
     const float* conv_bias;   /* (dim) fp32 or NULL                                                  */
     int32_t conv_width, reserved2;
+    /* Optional (ABI 6): delta = dt_proj(x_dbl[:, :dt_rank]) formed INSIDE the forward passes (reference
+     * selective_scan_interface.py:181-182 computes it with a GEMM launch and stores it).  dt_rank 0 = off.  With dt_rank in
+     * [1, 8]: `dt_x` points at the dt columns of x_dbl (element type `dtype`, dt_rank consecutive columns per time row, strides in
+     * elements), `dt_weight` is the (dim, dt_rank) projection weight as fp32, and `delta` becomes an OUTPUT: both passes form
+     * delta_t = sum_r dt_weight[d][r] dt_x[t][r], rounded to `dtype` as the stored tensor is, and the apply pass writes it for the
+     * backward.  Regular shapes with one B / C group only (SEGM_E_SHAPE otherwise).  Opt-in: see DESIGN.md section 0 row N1. */
+    const void* dt_x;
+    int64_t dt_stride_b, dt_stride_t;
+    const float* dt_weight;
+    int32_t dt_rank, reserved3;
 } segm_scan_fwd_args;
 
 int segm_selective_scan_fwd(const segm_scan_fwd_args* args);

@@ -40,6 +40,10 @@ struct ScanDev {
     const float* conv_w;                   // (dim, conv_width)
     const float* conv_b;                   // (dim) or null
     int32_t conv_width;
+    // forward, optional: delta = dt_weight . dt_x formed inside the passes (`delta` is then written by the apply pass); dt_rank 0 = off
+    BC dt_x;                               // rows of dt_rank consecutive elements (sn = 1)
+    const float* dt_w;                     // (dim, dt_rank)
+    int32_t dt_rank;
 };
 
 // up to three launches of ONE geometry (the three directions of a Mamba v3 layer: same shapes, different time order,

@@ -609,6 +609,19 @@ static int scan_fwd_one(const segm_scan_fwd_args* a, ScanDev* batched) {
             if (!fast || G != 1 || !a->delta_softplus || !a->z.ptr) return SEGM_E_SHAPE;
             P.conv_w = a->conv_weight; P.conv_b = a->conv_bias; P.conv_width = a->conv_width;
         }
+        if (a->dt_rank != 0) {                             // dt_proj inside the passes: regular-shape kernels only
+            if (a->dt_rank < 1 || a->dt_rank > 8) return SEGM_E_SHAPE;
+            if (!a->dt_x || !a->dt_weight) return SEGM_E_NULL;
+            if (!fast || G != 1 || a->conv_width != 0) return SEGM_E_SHAPE;
+            if (a->dt_stride_t < a->dt_rank || a->dt_stride_t >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;
+            P.dt_x = BC{(char*)a->dt_x, a->dt_stride_b, a->dt_stride_t, 1};
+            P.dt_w = a->dt_weight;
+            P.dt_rank = a->dt_rank;
+            const segm_bc dtb = {const_cast<void*>(a->dt_x), a->dt_stride_b, 0, a->dt_stride_t, 1};
+            const segm_bc* dv[1] = {&dtb};
+            rc = validate_spans(nullptr, 0, dv, 1, a->dim, a->dt_rank, a->seqlen, dtype_size(a->dtype), fast_span_rows(P));
+            if (rc != SEGM_OK) return rc;
+        }
         if (batched) {
             if (!fast || G != 1) return SEGM_E_SHAPE;       // the caller falls back to one launch per block
             *batched = P;
@@ -635,6 +648,7 @@ namespace segm {
 bool scan_same_launch(const segm_scan_fwd_args* a, const segm_scan_fwd_args* b) {
     return a->batch == b->batch && a->dim == b->dim && a->dstate == b->dstate && a->n_groups == 1 && b->n_groups == 1 &&
            a->seqlen == b->seqlen && a->dtype == b->dtype && a->stream == b->stream && a->conv_width == b->conv_width &&
+           a->dt_rank == b->dt_rank &&
            (a->chunk > 0 ? a->chunk : default_chunk(a->batch, a->dim, a->seqlen)) ==
                (b->chunk > 0 ? b->chunk : default_chunk(b->batch, b->dim, b->seqlen));
 }

@@ -72,10 +72,69 @@ __device__ __forceinline__ void conv_init(const ScanDev& P, const Item& it, int3
     xm1 = h[0]; xm2 = h[1]; xm3 = h[2];
 }
 
-template <typename T, int RW, int MODE, bool FUSED>
+// DTR > 0: delta_t = sum_r dt_w[d][r] dt_x[t][r] formed here (DTR = 4 or 8 = the rank rounded up; columns at or beyond the rank
+// count as zero) - the north star's "fused into the same launch" taken one operator further: `delta = dt_proj(x_dbl[:, :R])`
+// (reference selective_scan_interface.py:181-182) is no launch and no tensor read any more.  The dt rows of a sub-tile are staged
+// like B / C (fetched by the item's own lanes a sub-tile ahead, parked in LDS as fp32, read per step as wave-uniform 16-byte
+// reads); the sum is rounded to the element type as the stored tensor would be, so that both passes and the backward (which
+// reads the delta the apply pass stores) see the same value.  Opt-in, measured: DESIGN.md section 0, row N1.
+template <int RW, int DTR> struct DtStage {
+    static constexpr int NE = kFT * (DTR > 0 ? DTR : 1);          // elements of a sub-tile's dt block per item: [step][column]
+    static constexpr int E = (NE + RW - 1) / RW;                   // per lane
+    rsrc_t rs;
+    uint32_t voff[E];
+    int32_t lds[E];
+    bool ok[E];
+    int32_t stb;
+};
+template <typename T, int RW, int DTR>
+__device__ __forceinline__ DtStage<RW, DTR> make_dt_stage(const ScanDev& P, int b_uniform, const WaveRows& w, int r) {
+    DtStage<RW, DTR> st;
+    st.stb = (int32_t)(P.dt_x.st * (int64_t)sizeof(T));
+    st.rs = make_rsrc(P.dt_x.p + ((int64_t)b_uniform * P.dt_x.sb + (int64_t)w.row_lo * P.dt_x.st) * (int64_t)sizeof(T));
+#pragma unroll
+    for (int i = 0; i < DtStage<RW, DTR>::E; ++i) {
+        const int e = r + i * RW;
+        const int j = (e / DTR) % kFT, c = e % DTR;
+        st.ok[i] = e < DtStage<RW, DTR>::NE && c < P.dt_rank;
+        const int32_t lane_steps = w.dT < 0 ? (kFT - 1 - j) * (-w.dT) : j * w.dT;
+        st.voff[i] = st.ok[i] ? (uint32_t)(w.lane_row + lane_steps) * (uint32_t)st.stb + (uint32_t)(c * (int)sizeof(T)) : 0u;
+        st.lds[i] = j * DTR + c;
+    }
+    return st;
+}
+template <typename T, int RW, int DTR, int E>
+__device__ __forceinline__ void dt_fetch(uint32_t (&v)[E], const DtStage<RW, DTR>& st, int32_t rows, int32_t dT) {
+    const uint32_t so = (uint32_t)(rows + (dT < 0 ? (kFT - 1) * dT : 0)) * (uint32_t)st.stb;
+#pragma unroll
+    for (int i = 0; i < DtStage<RW, DTR>::E; ++i) v[i] = BufIO<T>::ld_raw(st.rs, st.voff[i], so);
+}
+template <typename T, int RW, int DTR, int E>
+__device__ __forceinline__ void dt_park(const uint32_t (&v)[E], const DtStage<RW, DTR>& st, float* lds_item, int r) {
+#pragma unroll
+    for (int i = 0; i < DtStage<RW, DTR>::E; ++i)
+        if (r + i * RW < DtStage<RW, DTR>::NE) lds_item[st.lds[i]] = st.ok[i] ? BufIO<T>::cvt_raw(v[i]) : 0.f;
+}
+// delta of one step from its staged dt row (wave-uniform reads) and the lane's weights, rounded as the stored tensor
+template <typename T, int DTR>
+__device__ __forceinline__ float dt_delta(const float* row, const float (&w)[DTR > 0 ? DTR : 1]) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < DTR / 4; ++q) {
+        const float4 x = reinterpret_cast<const float4*>(row)[q];
+        s = fmaf(w[4 * q], x.x, s);
+        s = fmaf(w[4 * q + 1], x.y, s);
+        s = fmaf(w[4 * q + 2], x.z, s);
+        s = fmaf(w[4 * q + 3], x.w, s);
+    }
+    return to_f32(from_f32<T>(s));
+}
+
+template <typename T, int RW, int MODE, bool FUSED, int DTR>
 __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) {
     constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     __shared__ __attribute__((aligned(16))) float s_b[2][kWavesPerBlock][G][kFT * kFS];
+    __shared__ __attribute__((aligned(16))) float s_dt[2][kWavesPerBlock][G][DTR > 0 ? kFT * DTR : 4];
     const ScanDev& P = PP.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
@@ -100,27 +159,40 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
     ConvTaps ck4 = {0.f, 0.f, 0.f, 0.f, 0.f};
     float xm1 = 0.f, xm2 = 0.f, xm3 = 0.f;
     if constexpr (FUSED) conv_init<T>(P, it, it.chunk * gm.chunk, ck4, xm1, xm2, xm3);
+    typedef DtStage<RW, DTR> DS;
+    DS ds;
+    float wdt[DTR > 0 ? DTR : 1];
+    uint32_t ndt[DS::E];
+    if constexpr (DTR > 0) {
+        ds = make_dt_stage<T, RW, DTR>(P, ub, wr, it.r);
+#pragma unroll
+        for (int c = 0; c < DTR; ++c) wdt[c] = c < P.dt_rank ? P.dt_w[(int64_t)it.d * P.dt_rank + c] : 0.f;
+    }
 
     // the B rows first: at the loop head they are then the oldest loads on both paths into it (vmcnt is in order, and the
     // compiler merges the pending-load state of the prologue with that of the back edge - with the stage loads issued last here
     // every sub-tile would begin with s_waitcnt vmcnt(0))
     float nu[kFT], nd[kFT], nb[EPL];
     stage_fetch_buf<T, RW>(nb, sb, wr.bias + ck.U, wr.dT);
+    if constexpr (DTR > 0) dt_fetch<T>(ndt, ds, wr.bias + ck.U, wr.dT);
     __builtin_amdgcn_sched_barrier(0);                    // keep that order
     stream_fetch<T>(nu, up, wr.bias + ck.U, wr.dT);
-    stream_fetch<T>(nd, dp, wr.bias + ck.U, wr.dT);
+    if constexpr (DTR == 0) stream_fetch<T>(nd, dp, wr.bias + ck.U, wr.dT);
 
     float sumd = 0.f;
     int buf = 0;
     const int nsub = gm.chunk / kFT;
     for (int s = 0; s < nsub; ++s) {
         float* lb = &s_b[buf][wave][it.gi][0];
+        float* ldt = &s_dt[buf][wave][it.gi][0];
         stage_park_buf<RW>(nb, sb, lb);
+        if constexpr (DTR > 0) dt_park<T>(ndt, ds, ldt, it.r);
         SEGM_WAVE_LDS_SYNC();
         // the row streams are a ring of kFT registers each: step j's value is consumed and its register refilled with step j of
         // the NEXT sub-tile in the same step (after the last sub-tile: re-read this one, never past the chunk)
         const int32_t Un = wr.bias + ((s + 1 < nsub) ? ck.next_U() : ck.U);
         stage_fetch_buf<T, RW>(nb, sb, Un, wr.dT);
+        if constexpr (DTR > 0) dt_fetch<T>(ndt, ds, Un, wr.dT);
         ck.advance();
         uint32_t su = (uint32_t)Un * (uint32_t)up.stb, sd = (uint32_t)Un * (uint32_t)dp.stb;
         const uint32_t iu = (uint32_t)(wr.dT * up.stb), id = (uint32_t)(wr.dT * dp.stb);
@@ -130,9 +202,11 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
 #pragma unroll
         for (int j = 0; j < kFT; ++j) {
             float uu = nu[j];
-            float dl = nd[j] + bias;
+            float dl;
+            if constexpr (DTR > 0) dl = dt_delta<T, DTR>(ldt + j * DTR, wdt) + bias;
+            else dl = nd[j] + bias;
             nu[j] = BufIO<T>::ld(up.rs, up.voff, su);
-            nd[j] = BufIO<T>::ld(dp.rs, dp.voff, sd);
+            if constexpr (DTR == 0) nd[j] = BufIO<T>::ld(dp.rs, dp.voff, sd);
             su += iu;
             sd += id;
             if constexpr (FUSED) uu = conv_step<T>(ck4, uu, xm1, xm2, xm3);
@@ -178,10 +252,11 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
 // ------------------------------------------------------------------------------------------------------
 // K3 (regular shapes): apply
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int RW, int MODE, bool FUSED>
+template <typename T, int RW, int MODE, bool FUSED, int DTR>
 __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fast_kernel(ScanDevN PP) {
     constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     __shared__ __attribute__((aligned(16))) float s_bc[2][kWavesPerBlock][G][2][kFT * kFS];
+    __shared__ __attribute__((aligned(16))) float s_dt[2][kWavesPerBlock][G][DTR > 0 ? kFT * DTR : 4];
     const ScanDev& P = PP.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
@@ -224,12 +299,22 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
     const uint32_t ck_voff = ((uint32_t)(it.gi * (gm.chunk / kCkpt)) * kFS * (uint32_t)gm.dim + 2u * (uint32_t)it.d) * 4u;
     const int32_t ck_pair = gm.dim * 8;                   // bytes between consecutive state pairs of one checkpoint
 
+    typedef DtStage<RW, DTR> DS;
+    DS ds;
+    float wdt[DTR > 0 ? DTR : 1];
+    uint32_t ndt[DS::E];
+    if constexpr (DTR > 0) {
+        ds = make_dt_stage<T, RW, DTR>(P, ub, wr, it.r);
+#pragma unroll
+        for (int c = 0; c < DTR; ++c) wdt[c] = c < P.dt_rank ? P.dt_w[(int64_t)it.d * P.dt_rank + c] : 0.f;
+    }
     float nu[kFT], nd[kFT], nz[kFT], nb[EPL], nc[EPL];
     stage_fetch_buf<T, RW>(nb, sb, wr.bias + ck.U, wr.dT);        // oldest loads at the loop head (see the aggregate kernel)
     stage_fetch_buf<T, RW>(nc, sc, wr.bias + ck.U, wr.dT);
+    if constexpr (DTR > 0) dt_fetch<T>(ndt, ds, wr.bias + ck.U, wr.dT);
     __builtin_amdgcn_sched_barrier(0);                    // keep that order
     stream_fetch<T>(nu, up, wr.bias + ck.U, wr.dT);
-    stream_fetch<T>(nd, dp, wr.bias + ck.U, wr.dT);
+    if constexpr (DTR == 0) stream_fetch<T>(nd, dp, wr.bias + ck.U, wr.dT);
     stream_fetch<T>(nz, zp, wr.bias + ck.U, wr.dT);
 
     int buf = 0;
@@ -237,13 +322,16 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
     for (int s = 0; s < nsub; ++s) {
         float* lb = &s_bc[buf][wave][it.gi][0][0];
         float* lc = &s_bc[buf][wave][it.gi][1][0];
+        float* ldt = &s_dt[buf][wave][it.gi][0];
         stage_park_buf<RW>(nb, sb, lb);
         stage_park_buf<RW>(nc, sc, lc);
+        if constexpr (DTR > 0) dt_park<T>(ndt, ds, ldt, it.r);
         SEGM_WAVE_LDS_SYNC();
         const int32_t Uc = wr.bias + ck.U;
         const int32_t Un = wr.bias + ((s + 1 < nsub) ? ck.next_U() : ck.U);
         stage_fetch_buf<T, RW>(nb, sb, Un, wr.dT);
         stage_fetch_buf<T, RW>(nc, sc, Un, wr.dT);
+        if constexpr (DTR > 0) dt_fetch<T>(ndt, ds, Un, wr.dT);
         ck.advance();
         // row streams: rings of kFT registers, refilled step by step with the next sub-tile's rows (see the aggregate kernel)
         uint32_t su = (uint32_t)Un * (uint32_t)up.stb, sd = (uint32_t)Un * (uint32_t)dp.stb, sz = (uint32_t)Un * (uint32_t)zp.stb;
@@ -260,13 +348,22 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
         }
         uint32_t oso = (uint32_t)Uc * (uint32_t)op.stb, ozso = (uint32_t)Uc * (uint32_t)ozp.stb;     // running scalar offsets
         const uint32_t oinc = (uint32_t)(wr.dT * op.stb), ozinc = (uint32_t)(wr.dT * ozp.stb);
+        uint32_t dso = (uint32_t)Uc * (uint32_t)dp.stb;    // DTR: delta is written here, for the backward
 #pragma unroll
         for (int j = 0; j < kFT; ++j) {
             float uu = nu[j];
             const float zz = nz[j];
-            float dl = nd[j] + bias;
+            float dl;
+            if constexpr (DTR > 0) {
+                const float draw = dt_delta<T, DTR>(ldt + j * DTR, wdt);
+                BufIO<T>::st(dp.rs, dp.voff, dso, draw);
+                dso += id;
+                dl = draw + bias;
+            } else {
+                dl = nd[j] + bias;
+            }
             nu[j] = BufIO<T>::ld(up.rs, up.voff, su);
-            nd[j] = BufIO<T>::ld(dp.rs, dp.voff, sd);
+            if constexpr (DTR == 0) nd[j] = BufIO<T>::ld(dp.rs, dp.voff, sd);
             nz[j] = BufIO<T>::ld(zp.rs, zp.voff, sz);          // without a gate the stream aliases u: loaded, never used
             su += iu;
             sd += id;
@@ -322,11 +419,11 @@ bool scan_fast_shape(const ScanDev& P) {
     return true;
 }
 
-template <typename T, int RW, int MODE, bool FUSED>
+template <typename T, int RW, int MODE, bool FUSED, int DTR = 0>
 static void launch_fast_mode(const ScanDevN& PP, int ndir, bool apply, hipStream_t stream) {
     const unsigned nblocks = (unsigned)((PP.d[0].gm.nwaves + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (apply) hipLaunchKernelGGL((scan_fwd_apply_fast_kernel<T, RW, MODE, FUSED>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
-    else hipLaunchKernelGGL((scan_fwd_agg_fast_kernel<T, RW, MODE, FUSED>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+    if (apply) hipLaunchKernelGGL((scan_fwd_apply_fast_kernel<T, RW, MODE, FUSED, DTR>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
+    else hipLaunchKernelGGL((scan_fwd_agg_fast_kernel<T, RW, MODE, FUSED, DTR>), dim3(nblocks, ndir), dim3(kBlock), 0, stream, PP);
 }
 // the compile-time flag set every direction of the launch agrees with (0 = none: flags read per step)
 static int fast_mode(const ScanDevN& PP, int ndir, bool apply) {
@@ -345,6 +442,12 @@ static int fast_mode(const ScanDevN& PP, int ndir, bool apply) {
 template <typename T, int RW>
 static void launch_fast_rw(const ScanDevN& PP, int ndir, bool apply, hipStream_t stream) {
     const int mode = fast_mode(PP, ndir, apply);
+    if (PP.d[0].dt_rank != 0) {                            // dt_proj inside the passes (flags read per step unless Mamba's training set)
+        const bool m1 = mode == 1 || (mode == 2 && !apply);
+        if (PP.d[0].dt_rank <= 4) { if (m1) launch_fast_mode<T, RW, 1, false, 4>(PP, ndir, apply, stream); else launch_fast_mode<T, RW, 0, false, 4>(PP, ndir, apply, stream); }
+        else { if (m1) launch_fast_mode<T, RW, 1, false, 8>(PP, ndir, apply, stream); else launch_fast_mode<T, RW, 0, false, 8>(PP, ndir, apply, stream); }
+        return;
+    }
     if (PP.d[0].conv_width != 0) {                         // conv1d inside the passes
         if (mode == 1 || (mode == 2 && !apply)) launch_fast_mode<T, RW, 1, true>(PP, ndir, apply, stream);
         else if (mode == 2) launch_fast_mode<T, RW, 2, true>(PP, ndir, apply, stream);

@@ -53,6 +53,8 @@ class ScanFwdArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("stream", C.c_void_p),
         ("conv_weight", C.c_void_p), ("conv_bias", C.c_void_p), ("conv_width", C.c_int32), ("reserved2", C.c_int32),
+        ("dt_x", C.c_void_p), ("dt_stride_b", C.c_int64), ("dt_stride_t", C.c_int64),
+        ("dt_weight", C.c_void_p), ("dt_rank", C.c_int32), ("reserved3", C.c_int32),
     ]
 
 

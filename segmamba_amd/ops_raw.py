@@ -98,15 +98,19 @@ def _fill_scan_args(a: L.ScanFwdArgs, u, delta, A, B, C, D, z, delta_bias, delta
 
 def scan_fwd(lib: L.SegmLib, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *,
              channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, need_out=True,
-             need_ckpt=False, need_last_state=False, ckpt_buf=None, conv_weight=None, conv_bias=None):
+             need_ckpt=False, need_last_state=False, ckpt_buf=None, conv_weight=None, conv_bias=None, dt_x=None, dt_weight=None):
     """-> dict(out, out_z, ckpt, last_state, chunk).  `out` is the un-gated y (None unless need_out or z is None).
+    `dt_x` (batch, seqlen, R) rows of R <= 8 consecutive elements [a column window of x_dbl] + `dt_weight` (dim, R) fp32:
+    delta = dt_weight . dt_x is formed inside the scan launches (reference selective_scan_interface.py:181-182 without its
+    launch) and `delta` is an OUTPUT the apply pass fills, rounded to its dtype, for the backward (regular shapes, one group).
     `ckpt_buf`: a caller-owned fp32 buffer of segm_selective_scan_ckpt_bytes() for the checkpoints.
     `conv_weight` (dim, width) [+ `conv_bias` (dim)]: the causal depthwise conv1d + SiLU in front of the scan is computed inside the
     scan launches and `u` is its INPUT x (regular shapes with softplus and a gate only; results equal conv1d_fwd followed by the scan)."""
     a = L.ScanFwdArgs()
     r = _scan_fwd_prepare(lib, a, u, delta, A, B, C, D, z, delta_bias, delta_softplus, channel_last=channel_last,
                           time_order=time_order, nslices=nslices, chunk=chunk, need_out=need_out, need_ckpt=need_ckpt,
-                          need_last_state=need_last_state, ckpt_buf=ckpt_buf, conv_weight=conv_weight, conv_bias=conv_bias)
+                          need_last_state=need_last_state, ckpt_buf=ckpt_buf, conv_weight=conv_weight, conv_bias=conv_bias,
+                          dt_x=dt_x, dt_weight=dt_weight)
     lib.check(lib.dll.segm_selective_scan_fwd(a), "selective_scan_fwd")
     r.pop("_ws")
     return r
@@ -133,7 +137,8 @@ def scan_fwd_multi(lib: L.SegmLib, calls):
 
 def _scan_fwd_prepare(lib, a, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *,
                       channel_last=False, time_order=L.TIME_FORWARD, nslices=1, chunk=0, need_out=True,
-                      need_ckpt=False, need_last_state=False, ckpt_buf=None, conv_weight=None, conv_bias=None):
+                      need_ckpt=False, need_last_state=False, ckpt_buf=None, conv_weight=None, conv_bias=None,
+                      dt_x=None, dt_weight=None):
     """fills the argument block `a` and allocates outputs / workspace; -> result dict (+ `_ws`, alive until the launch)"""
     batch, seqlen, dim, dstate, groups, B4, C4 = _fill_scan_args(
         a, u, delta, A, B, C, D, z, delta_bias, delta_softplus, channel_last, time_order, nslices, chunk)
@@ -167,6 +172,17 @@ def _scan_fwd_prepare(lib, a, u, delta, A, B, C, D=None, z=None, delta_bias=None
         cb = conv_bias.detach().to(torch.float32).contiguous() if conv_bias is not None else None
         a.conv_weight, a.conv_bias, a.conv_width = cw.data_ptr(), L.fptr(cb), cw.shape[1]
         keep += [cw, cb]
+    if dt_x is not None:
+        R = dt_x.shape[-1]
+        if dt_x.dim() != 3 or tuple(dt_x.shape[:2]) != (batch, seqlen) or not 1 <= R <= 8 or dt_x.stride(2) != 1 or \
+                dt_x.dtype != u.dtype or dt_x.device != dev:
+            raise RuntimeError("scan_fwd: dt_x must be (batch, seqlen, R <= 8) of u's dtype with unit stride along R")
+        if dt_weight is None or tuple(dt_weight.shape) != (dim, R) or dt_weight.dtype != torch.float32 or \
+                not dt_weight.is_contiguous() or dt_weight.device != dev:
+            raise RuntimeError("scan_fwd: dt_weight must be a contiguous fp32 (dim, R) tensor")
+        a.dt_x, a.dt_stride_b, a.dt_stride_t = dt_x.data_ptr(), dt_x.stride(0), dt_x.stride(1)
+        a.dt_weight, a.dt_rank = dt_weight.data_ptr(), R
+        keep += [dt_x, dt_weight]
     return dict(out=out, out_z=out_z, ckpt=ckpt, last_state=last_state, chunk=chunk, _ws=keep)
 
 

@@ -156,6 +156,7 @@ def _scan_constant_bc(u, delta, A, B, C, D, z, delta_bias, delta_softplus, retur
 
 _RECOMPUTE = os.environ.get("SEGM_RECOMPUTE", "0") == "1"     # reference trade: recompute conv output / delta in backward
 _FUSED_CONV1D = os.environ.get("SEGM_SCAN_FUSED_CONV1D", "0") == "1"     # conv1d + SiLU inside the scan passes (opt-in, slower)
+_FUSED_DTPROJ = os.environ.get("SEGM_SCAN_FUSED_DTPROJ", "0") == "1"     # dt_proj inside the scan passes (opt-in)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -334,14 +335,21 @@ class MambaInnerCore3(torch.autograd.Function):
             R, N = dtw.shape[1], A.shape[-1]
             ns = nslices if MambaInnerCore3.ORDERS[i] == L.TIME_INTERLEAVED else 1
             conv_out = conv_outs[i]
+            # dt_proj inside the scan launches (opt-in): the stored-delta forms only (with recompute the backward would form delta
+            # through the other kernel and the two roundings could differ by an ulp of the 16-bit type)
+            dt_in_scan = _FUSED_DTPROJ and not _FUSED_CONV1D and R <= 8 and _rows_route(conv_out, True) and (keep or not train) and \
+                ops_raw.scan_fused_conv_supported(lib, batch, dim, seqlen, ns, MambaInnerCore3.ORDERS[i])
             if _rows_route(conv_out, True):
-                x_dbl, delta, Bv, Cv = _project_rows(conv_out, xw, dtw, R, N)
+                x_dbl, delta, Bv, Cv = _project_rows(conv_out, xw, dtw, R, N, delta_in_scan=dt_in_scan)
             else:
                 x_dbl, delta, Bv, Cv = _project(conv_out, xw, dtw, R, N, True, None, None)
             calls.append(dict(u=conv_out, delta=delta, A=A.float().contiguous(), B=Bv, C=Cv,
                               D=D.float().contiguous() if D is not None else None, z=z,
                               delta_bias=dbias.float().contiguous() if dbias is not None else None, delta_softplus=True,
                               channel_last=True, time_order=MambaInnerCore3.ORDERS[i], nslices=ns, need_out=train, need_ckpt=train))
+            if dt_in_scan:
+                calls[-1].update(dt_x=x_dbl.view(batch, seqlen, -1)[:, :, :R],
+                                 dt_weight=_pk(dtw, ("dt_proj_f32", R), lambda t: t.float().contiguous()))
             if _FUSED_CONV1D and ops_raw.scan_fused_conv_supported(lib, batch, dim, seqlen, ns, calls[-1]["time_order"]):
                 # the north star's "conv1d fused into the scan launch": the passes read x and form u themselves (bit-identical).
                 # conv_out is still produced above - x_proj needs every channel of it before the scan can start - so this only
@@ -501,10 +509,11 @@ def _x_proj_rows4(w, R, N):
     return out
 
 
-def _project_rows(conv_out, x_proj_weight, delta_proj_weight, R, N, x_dbl=None):
+def _project_rows(conv_out, x_proj_weight, delta_proj_weight, R, N, x_dbl=None, delta_in_scan=False):
     """`_project` for channel-last activations through segm_linear_rows.  x_dbl is kept in the padded column layout of
     `_rows_cols` (the extra columns are zero: zero weight rows) so that it can be both an output and - its first 8-column
-    group, against a zero-padded dt_proj weight - an input of the kernel."""
+    group, against a zero-padded dt_proj weight - an input of the kernel.  `delta_in_scan`: delta comes back as an empty tensor
+    the scan's apply pass fills (ops_raw.scan_fwd: dt_x = x_dbl's first R columns)."""
     lib = L.get_lib()
     batch, seqlen, dim = conv_out.shape
     R4, P4, P8 = _rows_cols(R, N)
@@ -512,8 +521,11 @@ def _project_rows(conv_out, x_proj_weight, delta_proj_weight, R, N, x_dbl=None):
     if x_dbl is None:
         x_dbl = ops_raw.linear_rows(lib, conv_out.reshape(batch * seqlen, dim),
                                     _pk(x_proj_weight, ("x_proj_rows4", P8), lambda t: _x_proj_rows4(t, R, N)))
-    wdt = _pk(delta_proj_weight, ("dt_proj_cols", R8), lambda t: _pad_cols(t, R8))
-    delta = ops_raw.linear_rows(lib, x_dbl[:, :R8], wdt).reshape(batch, seqlen, dim)
+    if delta_in_scan:
+        delta = torch.empty(batch, seqlen, dim, dtype=conv_out.dtype, device=conv_out.device)
+    else:
+        wdt = _pk(delta_proj_weight, ("dt_proj_cols", R8), lambda t: _pad_cols(t, R8))
+        delta = ops_raw.linear_rows(lib, x_dbl[:, :R8], wdt).reshape(batch, seqlen, dim)
     v3 = x_dbl.view(batch, seqlen, P8)
     return x_dbl, delta, v3[:, :, R4:R4 + N], v3[:, :, R4 + N:P4]
 

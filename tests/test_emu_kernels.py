@@ -428,6 +428,38 @@ def test_scan_three_directions_in_one_launch_emulated(emu, dim, seqlen, chunk, d
                 assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-5), k
 
 
+def test_scan_multi_call_with_different_flags_per_block_emulated(emu):
+    """One segm_selective_scan_{fwd,bwd}_multi call whose blocks share the geometry but NOT the per-block flags - one without a
+    gate, one without softplus, one with both, different time orders: the launch falls back to the kernels that read the flags
+    per step (scan_fwd_fast.hip: fast_mode; scan_bwd_w8.hip: MODE 0) and must equal three separate launches bit for bit."""
+    dim, seqlen, chunk = 64, 128, 32
+    orders = [(L.TIME_FORWARD, 1), (L.TIME_REVERSED, 1), (L.TIME_INTERLEAVED, 8)]
+    flags = [(False, True), (True, False), (True, True)]             # (gate, softplus)
+    cases = [H.to_dev_layout(H.scan_case(2, dim, 16, seqlen, dtype=torch.float32, seed=21 + i), "cpu", True) for i in range(3)]
+    fcalls, single_f = [], []
+    for d, (order, ns), (gate, sp) in zip(cases, orders, flags):
+        kw = dict(u=d["u"], delta=d["delta"], A=d["A"], B=d["B"], C=d["C"], D=d["D"], z=d["z"] if gate else None,
+                  delta_bias=d["delta_bias"], delta_softplus=sp, channel_last=True, time_order=order, nslices=ns, chunk=chunk,
+                  need_out=True, need_ckpt=True)
+        fcalls.append(kw)
+        single_f.append(ops_raw.scan_fwd(emu, **kw))
+    multi_f = ops_raw.scan_fwd_multi(emu, fcalls)
+    for a, b, (gate, _) in zip(single_f, multi_f, flags):
+        for k in ("out", "ckpt") + (("out_z",) if gate else ()):
+            assert torch.equal(a[k], b[k]), k
+    bcalls, single_b = [], []
+    for d, (order, ns), (gate, sp), f in zip(cases, orders, flags, single_f):
+        kw = dict(u=d["u"], delta=d["delta"], A=d["A"], B=d["B"], C=d["C"], D=d["D"], z=d["z"] if gate else None,
+                  delta_bias=d["delta_bias"], dout=d["g"], out=f["out"], ckpt=f["ckpt"], delta_softplus=sp, channel_last=True,
+                  time_order=order, nslices=ns, chunk=f["chunk"])
+        bcalls.append(kw)
+        single_b.append(ops_raw.scan_bwd(emu, **kw))
+    multi_b = ops_raw.scan_bwd_multi(emu, bcalls)
+    for a, b, (gate, _) in zip(single_b, multi_b, flags):
+        for k in ("du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias") + (("dz",) if gate else ()):
+            assert torch.equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("dim,seqlen,chunk,order,ns,dtype", [
     (192, 64, 32, L.TIME_FORWARD, 1, torch.bfloat16),            # RW 64, three d-tiles (SegMamba stage 1)
     (384, 32, 16, L.TIME_REVERSED, 1, torch.float16),            # six d-tiles (stage 2)
@@ -1474,3 +1506,82 @@ def test_mamba_block_with_conv1d_inside_the_scan_launch_on_emulated_kernels(emu,
     assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
     for k in gp0:
         assert torch.equal(gp0[k], gp1[k]), k
+
+
+@pytest.mark.parametrize("dim,seqlen,chunk,order,ns,dtype,R,stride", [
+    (32, 128, 32, L.TIME_FORWARD, 1, torch.float32, 3, 40), (64, 64, 32, L.TIME_REVERSED, 1, torch.bfloat16, 3, 40),
+    (16, 256, 64, L.TIME_INTERLEAVED, 8, torch.float32, 6, 40), (96, 64, 32, L.TIME_INTERLEAVED, 8, torch.bfloat16, 8, 8),
+    (32, 64, 16, L.TIME_FORWARD, 1, torch.float16, 1, 1), (128, 64, 32, L.TIME_REVERSED, 1, torch.bfloat16, 5, 5)])
+def test_scan_with_dt_proj_inside_the_launch_emulated(emu, dim, seqlen, chunk, order, ns, dtype, R, stride):
+    """`dt_x=, dt_weight=`: delta = dt_weight . x_dbl[:, :R] formed inside the two scan passes (reference
+    selective_scan_interface.py:181-182 without its launch).  The delta tensor the apply pass writes must be the projection
+    rounded to the element type (<= 1 ulp from the fp32-accumulated product of the same operands: the summation order differs),
+    and the scan run on THAT delta must equal the fused launch bit for bit - outputs, checkpoints, last state - in all three time
+    orders, for ranks 1 - 8 with tight and padded rows; a rank above 8 or an irregular shape is refused."""
+    g = torch.Generator().manual_seed(dim + seqlen + R)
+    Bn, N = 2, 16
+    rn = lambda *s: torch.randn(*s, generator=g).to(dtype)
+    u, z = rn(Bn, seqlen, dim), rn(Bn, seqlen, dim)
+    rows = rn(Bn, seqlen, stride)
+    dt_x = rows[:, :, :R]
+    dt_w = (0.3 * torch.randn(dim, R, generator=g)).to(dtype).float().contiguous()
+    A = -0.5 * torch.rand(dim, N, generator=g)
+    Bm, Cm = rn(Bn, seqlen, N), rn(Bn, seqlen, N)
+    Dv, db = torch.randn(dim, generator=g), 0.5 * torch.rand(dim, generator=g)
+    kw = dict(channel_last=True, time_order=order, nslices=ns, chunk=chunk, need_out=True, need_ckpt=True, need_last_state=True)
+    delta = torch.full((Bn, seqlen, dim), float("nan"), dtype=dtype)
+    fused = ops_raw.scan_fwd(emu, u, delta, A, Bm, Cm, Dv, z, db, True, dt_x=dt_x, dt_weight=dt_w, **kw)
+    exact = dt_x.double() @ dt_w.double().t()
+    assert torch.isfinite(delta.float()).all()
+    ulp = {torch.float32: 2.0 ** -23, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    assert ((delta.double() - exact).abs() <= ulp * exact.abs() + 1e-6).all()
+    ref = ops_raw.scan_fwd(emu, u, delta.clone(), A, Bm, Cm, Dv, z, db, True, **kw)
+    for k in ("out", "out_z", "ckpt", "last_state"):
+        assert torch.equal(fused[k], ref[k]), k
+    plain = ops_raw.scan_fwd(emu, u, torch.empty_like(delta), A, Bm, Cm, Dv, None, db, False, dt_x=dt_x, dt_weight=dt_w, **kw)
+    ref2 = ops_raw.scan_fwd(emu, u, delta, A, Bm, Cm, Dv, None, db, False, **kw)        # the per-step-flag kernels
+    assert torch.equal(plain["out"], ref2["out"]) and torch.equal(plain["ckpt"], ref2["ckpt"])
+    with pytest.raises(RuntimeError):
+        ops_raw.scan_fwd(emu, u, delta, A, Bm, Cm, Dv, z, db, True, dt_x=rn(Bn, seqlen, 9), dt_weight=torch.zeros(dim, 9), **kw)
+    with pytest.raises(RuntimeError):                      # not a regular shape
+        ops_raw.scan_fwd(emu, u[:, :-3], delta[:, :-3], A, Bm[:, :-3], Cm[:, :-3], Dv, z[:, :-3], db, True, dt_x=dt_x[:, :-3],
+                         dt_weight=dt_w, **dict(kw, time_order=L.TIME_FORWARD, nslices=1))
+
+
+def test_mamba_block_with_dt_proj_inside_the_scan_launch_on_emulated_kernels(emu, monkeypatch):
+    """SEGM_SCAN_FUSED_DTPROJ=1: a bf16 Mamba(v3) block (row-streaming projections: the padded x_dbl layout the scan reads its dt
+    rows from) whose scan launches form delta themselves, against the same block with the dt_proj launch - output, input
+    gradient, all parameter gradients; the two deltas differ by at most an ulp of bf16 where the summation order rounds
+    differently, so the comparison is at the bf16 level, not bit for bit."""
+    monkeypatch.setattr(L, "_lib", emu)
+    from mamba_ssm import Mamba
+    from tests.golden.make_golden import named_fill
+    from segmamba_amd import selective_scan_interface as SSI
+    from segmamba_amd import linear as LN
+    monkeypatch.setattr(LN, "_ROWS_HIP", True)
+    monkeypatch.setattr(LN, "_ROWS_MIN", 1)
+    monkeypatch.setattr(LN, "_on_device", lambda t: True)
+    m = Mamba(d_model=16, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=8)
+    m.load_state_dict(named_fill(m.state_dict()))
+    m = m.bfloat16()
+    g = torch.Generator().manual_seed(4)
+    x0, dy = torch.randn(2, 64, 16, generator=g).bfloat16(), torch.randn(2, 64, 16, generator=g).bfloat16()
+    seen, res = [], []
+    real = ops_raw.scan_fwd_multi
+    monkeypatch.setattr(ops_raw, "scan_fwd_multi", lambda lib, calls: (seen.append(sum("dt_x" in c for c in calls)), real(lib, calls))[1])
+    monkeypatch.setattr(SSI.L, "on_device", lambda t: True, raising=False)
+    import segmamba_amd.mamba_simple as MS
+    monkeypatch.setattr(MS.L, "on_device", lambda t: True, raising=False)
+    for fused in (False, True):
+        monkeypatch.setattr(SSI, "_FUSED_DTPROJ", fused)
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_()
+        y = m(x)
+        y.backward(dy)
+        res.append((y.detach().float(), x.grad.float(), {k: p.grad.float().clone() for k, p in m.named_parameters()}))
+    assert seen == [0, 3], seen
+    (y0, gx0, gp0), (y1, gx1, gp1) = res
+    close = lambda a, b: float((a - b).abs().max()) <= 2e-2 * max(1e-2, float(b.abs().max()))
+    assert close(y1, y0) and close(gx1, gx0)
+    for k in gp0:
+        assert close(gp1[k], gp0[k]), k

@@ -239,6 +239,33 @@ def test_causal_conv1d_repeatability(hip):
         assert torch.equal(out, out0) and torch.equal(dx, dx0) and torch.equal(dw, dw0) and torch.equal(db, db0)
 
 
+@pytest.mark.parametrize("order,ns", [(L.TIME_FORWARD, 1), (L.TIME_REVERSED, 1), (L.TIME_INTERLEAVED, 64)])
+def test_scan_with_dt_proj_inside_the_launch(hip, order, ns):
+    """Round 4 (north star N1, opt-in): delta = W_dt . x_dbl[:, :R] formed inside the forward scan passes at SegMamba's stage-0
+    row layout (R = 3 of 40-column x_dbl rows, 96 channels).  The delta the apply pass writes is the fp64 product rounded to bf16
+    within one ulp; the scan over that written delta equals the fused launch bit for bit (out, out_z, checkpoints)."""
+    torch.manual_seed(3)
+    B, Lq, D, N, R, P8 = 2, 64 * 256, 96, 16, 3, 40
+    dt = torch.bfloat16
+    rn = lambda *s: torch.randn(*s, device=DEV).to(dt)
+    u, z = rn(B, Lq, D), rn(B, Lq, D)
+    x_dbl = rn(B, Lq, P8)
+    w = (0.3 * torch.randn(D, R, device=DEV)).to(dt).float().contiguous()
+    A = -0.5 * torch.rand(D, N, device=DEV)
+    Dv, db = torch.randn(D, device=DEV), 0.5 * torch.rand(D, device=DEV)
+    Bm, Cm = x_dbl[:, :, 4:4 + N], x_dbl[:, :, 4 + N:4 + 2 * N]
+    kw = dict(channel_last=True, time_order=order, nslices=ns, chunk=256, need_out=True, need_ckpt=True)
+    assert ops_raw.scan_fused_conv_supported(hip, B, D, Lq, ns, order, 256)          # the regular-shape kernels take it
+    delta = torch.full((B, Lq, D), float("nan"), device=DEV, dtype=dt)
+    fused = ops_raw.scan_fwd(hip, u, delta, A, Bm, Cm, Dv, z, db, True, dt_x=x_dbl[:, :, :R], dt_weight=w, **kw)
+    exact = x_dbl[:, :, :R].double() @ w.double().t()
+    assert torch.isfinite(delta.float()).all()
+    assert ((delta.double() - exact).abs() <= 2.0 ** -8 * exact.abs() + 1e-6).all()
+    ref = ops_raw.scan_fwd(hip, u, delta.clone(), A, Bm, Cm, Dv, z, db, True, **kw)
+    for k in ("out", "out_z", "ckpt"):
+        assert torch.equal(fused[k], ref[k]), k
+
+
 def test_selective_scan_backward_repeatability(hip):
     """Round 4: dB / dC are sums over the d-tiles in a FIXED order (per-tile fp32 slabs + a sum kernel, csrc/scan_bwd_w8.hip) - no
     float atomics: every gradient of the SegMamba stage-0 shape (three d-tiles of 32 channels) is bit-identical across 20
