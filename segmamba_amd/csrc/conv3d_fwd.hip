@@ -472,9 +472,17 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 // reduce + epilogue phase).  CP = ci pitch of a ring position in elements: 56 as above, or 48 (no padding) - by the LDS
 // bank model of MI355X_MICROARCH.md (ds_read_b128: four groups of 16 lanes over 64 banks) the unpadded rows make the A
 // fragment reads conflict-free where the padded ones are 2-way (tools/lds_conflicts.py); SEGM_CONV_FWD_PITCH48.
-template <typename T, bool ACC, int CP>
+// VAR: bit 0 - K parts 1 - 3 skip their eleventh (all-zero) chunk instead of running it (41 chunks of 32 split 11 + 10 + 10 + 10;
+// the loop is unrolled over 11); bits 1 - 2 - the A fragments are read PF = 1 + that many chunks ahead of their MFMAs.  Shipped:
+// VAR 3 (skip, two chunks ahead) on the unpadded-pitch kernel and the 32-wide one; SEGM_CONV_CHAIN_VAR=0 launches the round-3
+// schedule (VAR 0).  Measured in round 4 (profiles/r04_conv_chain_var_time.log): 48 -> 48 @128^3 0.626 -> 0.588 ms, the 32-wide
+// kernel 0.776 -> 0.680 ms there and 0.369 -> 0.355 ms at 96 -> 96 @64^3; three chunks ahead spills (256 registers at two waves
+// per SIMD) and loses; whole step 61.97 -> 61.6 ms.
+template <typename T, bool ACC, int CP, int VAR = 0>
 __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDev P) {
     typedef typename Mfma16<T>::v8 frag8;
+    constexpr bool SKIP = (VAR & 1) != 0;
+    constexpr int PF = 1 + ((VAR >> 1) & 3);
     constexpr int XT = 2;                                 // x tiles per wave
     constexpr int XP = 2;                                 // waves per K part
     constexpr int kSlot = kFwXP * CP;                     // elements per ring row
@@ -558,8 +566,9 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
         // the partial sums of the previous K part for this row, then the first chunk's A fragments: issued before the
         // global fetches so that their latency is covered by the address arithmetic
         f32x4 acc[3][XT];
-        frag8 a[2][XT];
+        frag8 a[PF + 1][XT];
         const T* pl = &xs[0][0][0];
+        auto live = [&](int c) { return !SKIP || c + 1 < kF48Chunks || part == 0; };
         auto load_a = [&](frag8 (&dst)[XT], int c) {
             const int slot = (row + (aoff[c] >> 28) + 7) & 3;              // input row = row + ky - 1
             const T* ap = pl + slot * kSlot + (aoff[c] & 0x0fffffff);
@@ -578,7 +587,8 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
 #pragma unroll
                     for (int u = 0; u < XT; ++u) acc[t][u] = hand[(s + 1) & 1][part - 1][xp][t * XT + u][lane];
             }
-            load_a(a[0], 0);
+#pragma unroll
+            for (int c = 0; c < PF; ++c) load_a(a[c], c);
         }
         RowRegs r[2];
         fetch(r, s, true);                                // in flight during this step's MFMAs
@@ -586,12 +596,14 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
         if (active) {
 #pragma unroll
             for (int c = 0; c < kF48Chunks; ++c) {
-                if (c + 1 < kF48Chunks) load_a(a[(c + 1) & 1], c + 1);     // one chunk (6 MFMAs) ahead of its use
+                if (c + PF < kF48Chunks && live(c + PF)) load_a(a[(c + PF) % (PF + 1)], c + PF);     // PF chunks (6 MFMAs each) ahead of its use
                 SEGM_SCHED_FENCE();
+                if (live(c)) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
+                    for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int u = 0; u < XT; ++u) acc[t][u] = Mfma16<T>::run(a[c & 1][u], wf[t][c], acc[t][u]);
+                        for (int u = 0; u < XT; ++u) acc[t][u] = Mfma16<T>::run(a[c % (PF + 1)][u], wf[t][c], acc[t][u]);
+                }
                 SEGM_SCHED_FENCE();
             }
             if (part < 3) {
@@ -669,9 +681,11 @@ __device__ __forceinline__ CopyLane copy_lane32(const ConvFwdDev& P, bool halo, 
     return L;
 }
 
-template <typename T, bool ACC>
+template <typename T, bool ACC, int VAR = 0>
 __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwdDev P) {
     typedef typename Mfma16<T>::v8 frag8;
+    constexpr bool SKIP = (VAR & 1) != 0;
+    constexpr int PF = 1 + ((VAR >> 1) & 3);
     constexpr int XT = 2, CP = kC32CP;
     constexpr int kSlot = kC32XP * CP;                    // elements per ring row
     __shared__ __attribute__((aligned(16))) T xs[3][4][kSlot];
@@ -761,8 +775,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
         const int row = s - part;                         // this part's output row
         const bool active = row >= y0 && row < y1;
         f32x4 acc[3][XT];
-        frag8 a[2][XT];
+        frag8 a[PF + 1][XT];
         const T* pl = &xs[0][0][0];
+        auto live = [&](int c) { return !SKIP || c + 1 < kF48Chunks || part == 0; };
         auto load_a = [&](frag8 (&dst)[XT], int c) {
             const int slot = (row + (aoff[c] >> 28) + 7) & 3;              // input row = row + ky - 1
             const T* ap = pl + slot * kSlot + (aoff[c] & 0x0fffffff);
@@ -781,7 +796,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
 #pragma unroll
                     for (int u = 0; u < XT; ++u) acc[t][u] = hand[(s + 1) & 1][part - 1][t * XT + u][lane];
             }
-            load_a(a[0], 0);
+#pragma unroll
+            for (int c = 0; c < PF; ++c) load_a(a[c], c);
         }
         RowRegs r[3];
         fetch(r, s, true);                                // in flight during this step's MFMAs
@@ -789,12 +805,14 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
         if (active) {
 #pragma unroll
             for (int c = 0; c < kF48Chunks; ++c) {
-                if (c + 1 < kF48Chunks) load_a(a[(c + 1) & 1], c + 1);     // one chunk (6 MFMAs) ahead of its use
+                if (c + PF < kF48Chunks && live(c + PF)) load_a(a[(c + PF) % (PF + 1)], c + PF);     // PF chunks (6 MFMAs each) ahead of its use
                 SEGM_SCHED_FENCE();
+                if (live(c)) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
+                    for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int u = 0; u < XT; ++u) acc[t][u] = Mfma16<T>::run(a[c & 1][u], wf[t][c], acc[t][u]);
+                        for (int u = 0; u < XT; ++u) acc[t][u] = Mfma16<T>::run(a[c % (PF + 1)][u], wf[t][c], acc[t][u]);
+                }
                 SEGM_SCHED_FENCE();
             }
             if (part < 3) {
@@ -842,8 +860,20 @@ static FwPlan fwd_plan(int batch, int cout, int d, int h, int w, bool chain = fa
     return p;
 }
 
+static int chain_var() {                                // 3 = the shipped schedule, 0 = round 3's (A/B timing)
+    static const int v = [] { const char* e = getenv("SEGM_CONV_CHAIN_VAR"); return e && atoi(e) == 0 ? 0 : 3; }();
+    return v;
+}
+
 template <int CHAIN>                                    // 0: reduce-per-row kernel; else the chained kernel with that ci pitch
 static void launch48(const ConvFwdDev& P, dim3 grid, bool f16, bool acc, hipStream_t stream) {
+    if (CHAIN == 48 && chain_var() != 0) {
+#define SEGM_LV(T) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, true, 48, 3>), grid, dim3(512), 0, stream, P); \
+                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, false, 48, 3>), grid, dim3(512), 0, stream, P); } while (0)
+        if (f16) SEGM_LV(f16_t); else SEGM_LV(bf16_t);
+#undef SEGM_LV
+        return;
+    }
 #define SEGM_L48(T, A)                                                                                          \
     do {                                                                                                        \
         if (CHAIN) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, A, CHAIN ? CHAIN : kFwCP>), grid, dim3(512), 0, stream, P); \
@@ -895,6 +925,13 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     if (chain32) {
         const dim3 grid(pl.nitems * (a->cout / 48));
 #define SEGM_L32(T, A) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, A>), grid, dim3(256), 0, stream, P)
+#define SEGM_LV(T) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, true, 3>), grid, dim3(256), 0, stream, P); \
+                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, false, 3>), grid, dim3(256), 0, stream, P); } while (0)
+        if (chain_var() != 0) {
+            if (f16) SEGM_LV(f16_t); else SEGM_LV(bf16_t);
+            return (int)hipGetLastError();
+        }
+#undef SEGM_LV
         if (f16) { if (acc) SEGM_L32(f16_t, true); else SEGM_L32(f16_t, false); }
         else { if (acc) SEGM_L32(bf16_t, true); else SEGM_L32(bf16_t, false); }
 #undef SEGM_L32

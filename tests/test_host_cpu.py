@@ -365,3 +365,25 @@ def test_conv_routing_is_a_table_not_a_timing_run():
     assert conv3d._table_choice("wgrad", 8, [None, None, "mfma"]) == 0
     # the same decision in every process: no state is consulted
     assert not conv3d._cache
+
+
+def test_conv_table_small_volumes_follow_the_logged_winners():
+    """conv3d._table_choice sends 3x3x3 layers narrower than 16 voxels to candidate 0 (the vendor convolution) - which is what the
+    timing-based dispatcher had chosen for every 8^3 layer on the MI355X (profiles/r02_bench_variants.log: '-> 0' on each
+    8x8x8 line); wider volumes take a library kernel whenever one is offered."""
+    import re
+    from segmamba_amd import conv3d as C3
+    log = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_bench_variants.log")
+    seen = 0
+    for line in open(log):
+        m = re.match(r"\[conv3d autotune\] \('(\w+)', \((\d+), (\d+), (\d+), (\d+), (\d+)\).* -> (\d+)\s*$", line)
+        if not m or int(m.group(6)) >= 16 or "3, 3, 3)" not in line:
+            continue
+        seen += 1
+        assert int(m.group(7)) == 0, line
+        assert C3._table_choice(m.group(1), int(m.group(6)), [None, None, (True, True, False), "mfma"]) == 0
+    assert seen >= 3
+    variants = [None, None, (True, False, False), (True, True, False), (False, False, True)]
+    assert variants[C3._table_choice("fwd", 128, variants)] == (True, True, False)
+    assert variants[C3._table_choice("dgrad", 32, variants)] == (False, False, True)
+    assert C3._table_choice("wgrad", 64, [None, None, "mfma"]) == 2
