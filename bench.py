@@ -435,7 +435,7 @@ def main():
     # warm-up runs the bracket without an optimizer step, so it is not part of --warmup.
     # N > 1: eager launches by default - the gradient exchange then runs in segments on a side stream while the backward pass is
     # still producing gradients (trainer.SegmentedExchange); a captured bracket can only be followed by ONE exposed all-reduce.
-    # SEGM_GRAPH_DDP=1 times the graph + one-call form instead; the other form is measured behind the timed region either way.
+    # SEGM_GRAPH_DDP=1 times the graph + one-call form instead; SEGM_BENCH_OTHER_FORM=1 measures it behind the timed region.
     graph_note = "off (--no-graph / SEGM_GRAPH=0)"
     graph_ddp = os.environ.get("SEGM_GRAPH_DDP", "0") == "1"
     if state.exchange is not None and not graph_ddp:
@@ -471,7 +471,9 @@ def main():
     if distributed and state.exchange is not None and not dry:
         exposed_ms = state.exchange.exposed_ms() if state.exchange.record_exposed else None
         state.exchange.record_exposed = False
-        if state.graphed is None and not args.no_graph:   # the other form behind the timed region: captured bracket + one call
+        # the other form behind the timed region (captured bracket + one call): opt-in - a capture that fails on one rank only would
+        # leave the ranks in different collectives, and the driver's scaling run is not the place to find that out
+        if state.graphed is None and not args.no_graph and os.environ.get("SEGM_BENCH_OTHER_FORM", "0") == "1":
             try:
                 from segmamba_amd.trainer import GraphedStep
                 GraphedStep(state, *data.next())

@@ -477,7 +477,8 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 // VAR 3 (skip, two chunks ahead) on the unpadded-pitch kernel and the 32-wide one; SEGM_CONV_CHAIN_VAR=0 launches the round-3
 // schedule (VAR 0).  Measured in round 4 (profiles/r04_conv_chain_var_time.log): 48 -> 48 @128^3 0.626 -> 0.588 ms, the 32-wide
 // kernel 0.776 -> 0.680 ms there and 0.369 -> 0.355 ms at 96 -> 96 @64^3; three chunks ahead spills (256 registers at two waves
-// per SIMD) and loses; whole step 61.97 -> 61.6 ms.
+// per SIMD) and loses; whole step 61.97 -> 61.6 ms.  `s_setprio 1` for the second-dispatched half of the workgroup (the guide's
+// two-waves-per-SIMD section, item 4) measured nothing here (0.605 / 0.612 vs 0.618 / 0.631 ms, profiles/r04_call9_ab.log).
 template <typename T, bool ACC, int CP, int VAR = 0>
 __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDev P) {
     typedef typename Mfma16<T>::v8 frag8;
@@ -868,9 +869,9 @@ static int chain_var() {                                // 3 = the shipped sched
 template <int CHAIN>                                    // 0: reduce-per-row kernel; else the chained kernel with that ci pitch
 static void launch48(const ConvFwdDev& P, dim3 grid, bool f16, bool acc, hipStream_t stream) {
     if (CHAIN == 48 && chain_var() != 0) {
-#define SEGM_LV(T) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, true, 48, 3>), grid, dim3(512), 0, stream, P); \
-                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, false, 48, 3>), grid, dim3(512), 0, stream, P); } while (0)
-        if (f16) SEGM_LV(f16_t); else SEGM_LV(bf16_t);
+#define SEGM_LV(T, V) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, true, 48, V>), grid, dim3(512), 0, stream, P); \
+                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, false, 48, V>), grid, dim3(512), 0, stream, P); } while (0)
+        if (f16) SEGM_LV(f16_t, 3); else SEGM_LV(bf16_t, 3);
 #undef SEGM_LV
         return;
     }

@@ -250,6 +250,45 @@ __global__ void __launch_bounds__(256) conv3d_k3_wgrad_reduce_kernel(const float
     }
 }
 
+// The same sum with 16-byte loads (cin a multiple of 4: every SegMamba layer): a lane owns four consecutive ci of one (tap, co),
+// a wave reads 1 KB contiguous per slab instead of 256 B, eight waves take slabs w, w + 8, ... with eight loads in flight each -
+// four times the bytes in flight per workgroup for the same fixed summation order per element class (wave-strided partial sums,
+// then waves in order).  NOT bit-identical to the kernel above (eight strided classes instead of four): both are deterministic.
+template <typename T>
+__global__ void __launch_bounds__(512) conv3d_k3_wgrad_reduce4_kernel(const float* __restrict__ part, T* __restrict__ dw,
+                                                                       int nslab, int ncib, int cout, int cin) {
+    __shared__ f32x4 s_sum[8][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane;               // over 27 * cout * cin / 4, ci fastest
+    const int total4 = cout * cin * 27 / 4;
+    const bool in = idx < total4;
+    const int ii = (in ? idx : 0) * 4;
+    const int ci = ii % cin;
+    const int rest = ii / cin;
+    const int co = rest % cout;
+    const int tap = rest / cout;
+    const int cob = co / kWgCo, cib = ci / kWgBlock;
+    const f32x4* p = reinterpret_cast<const f32x4*>(part + ((((int64_t)cob * ncib + cib) * nslab) * 27 + tap) * (kWgCo * kWgBlock) +
+                                                   (co - cob * kWgCo) * kWgBlock + (ci - cib * kWgBlock));
+    const int64_t slab4 = (int64_t)27 * kWgCo * kWgBlock / 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a8[8] = {z4, z4, z4, z4, z4, z4, z4, z4};
+    int k = w;
+    for (; k + 56 < nslab; k += 64) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a8[u] += p[(int64_t)(k + 8 * u) * slab4];
+    }
+    for (int u = 0; k < nslab; k += 8, ++u) a8[u & 7] += p[(int64_t)k * slab4];
+    s_sum[w][lane] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    __syncthreads();
+    if (w == 0 && in) {
+        const f32x4 t = ((s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane])) +
+                        ((s_sum[4][lane] + s_sum[5][lane]) + (s_sum[6][lane] + s_sum[7][lane]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dw[((int64_t)co * cin + ci + q) * 27 + tap] = from_f32<T>(t[q]);
+    }
+}
+
 // work decomposition: items = (batch, depth) planes x 64-wide (32 if W % 64) x blocks x y parts
 struct WgPlan { int nq, nxb, ysplit, rows_per_part, nitems; };
 static WgPlan wgrad_plan(int batch, int cin, int cout, int d, int h, int w) {
@@ -314,6 +353,19 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
         }
     }
     const int total = a->cout * a->cin * 27;
+    // 16-byte loads where they measured faster (profiles/r04_call9_ab.log: 96 -> 96 @64^3 0.368 -> 0.336 ms; 48 -> 48 @128^3 0.69 ->
+    // 0.72 ms - one (co, ci) block pair has too few 1 KB pieces per slab to fill the chip); SEGM_WGRAD_REDUCE4 = 0 / 1 forces a side
+    static const int wide = [] { const char* e = getenv("SEGM_WGRAD_REDUCE4"); return e ? atoi(e) : -1; }();
+    if (a->cin % 4 == 0 && (wide == 1 || (wide < 0 && (int64_t)a->cin * a->cout >= 96 * 96))) {
+        const dim3 g4((total / 4 + 63) / 64);
+        if (a->dw_dtype == SEGM_F32)
+            hipLaunchKernelGGL((conv3d_k3_wgrad_reduce4_kernel<float>), g4, dim3(512), 0, stream, (const float*)P.part, (float*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
+        else if (a->dw_dtype == SEGM_F16)
+            hipLaunchKernelGGL((conv3d_k3_wgrad_reduce4_kernel<f16_t>), g4, dim3(512), 0, stream, (const float*)P.part, (f16_t*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
+        else
+            hipLaunchKernelGGL((conv3d_k3_wgrad_reduce4_kernel<bf16_t>), g4, dim3(512), 0, stream, (const float*)P.part, (bf16_t*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
+        return (int)hipGetLastError();
+    }
     if (a->dw_dtype == SEGM_F32)
         hipLaunchKernelGGL((conv3d_k3_wgrad_reduce_kernel<float>), dim3((total + 63) / 64), dim3(256), 0, stream,
                            (const float*)P.part, (float*)a->dw, P.nitems, P.ncib, a->cout, a->cin);

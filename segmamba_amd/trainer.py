@@ -145,7 +145,9 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
         bank.attach_flat_grads()
         opt.use_flat(bank)
         st.flat = True
-    if st.flat and world > 1:
+    # SEGM_FORCE_DDP=1: the exchange machinery on ONE rank (hooks, side stream, RCCL on slices) - what a single-GPU box can test
+    forced = os.environ.get("SEGM_FORCE_DDP") == "1" and torch.distributed.is_available() and torch.distributed.is_initialized()
+    if st.flat and (world > 1 or forced):
         k = int(ddp_segments if ddp_segments is not None else os.environ.get("SEGM_DDP_SEGMENTS", "4"))
         if k > 1:
             st.exchange = SegmentedExchange(bank, world, k)
@@ -288,12 +290,11 @@ def forward_backward(st: TrainingState, image: torch.Tensor, label: torch.Tensor
 
 def finish_step(st: TrainingState) -> None:
     """exchange + update of a flat-mode step: all-reduce (world > 1), clip 12 + SGD-Nesterov over the flat arrays, poly LR"""
-    if st.world > 1:
-        if st.exchange is not None:
-            st.exchange.finish()                                    # segments already in flight behind the backward pass
-        else:
-            import torch.distributed as dist
-            dist.all_reduce(st.bank.flat_grad)                      # 269.7 MB fp32 over xGMI, one collective
+    if st.exchange is not None:
+        st.exchange.finish()                                        # segments already in flight behind the backward pass
+    elif st.world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(st.bank.flat_grad)                          # 269.7 MB fp32 over xGMI, one collective
     st.optimizer.step()
     st.scheduler.step()
     st.step += 1

@@ -141,6 +141,7 @@ static inline float hipemu_log2f(float x) { return log2f(x); }
 #define __builtin_amdgcn_rcpf hipemu_rcpf
 #define __builtin_amdgcn_logf hipemu_log2f
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
