@@ -47,6 +47,7 @@ constexpr int kWgWaves = 3;                  // ky
 constexpr int kWgThreads = kWgWaves * 64;
 constexpr int kPitch = 88;                   // LDS row pitch (elements): 8 halo + 64 + 8 halo + 8 (bank spread)
 constexpr int kCopies = 5;                   // granules per thread per step: ceil((48 * 10 + 48 * 8) / 192)
+constexpr int wg_copies(int qs) { return qs == 1 ? kCopies : 3; }     // six waves: ceil(864 / 384)
 
 struct WgradDev {
     const char* x;   int64_t x_sb, x_sc, x_sz, x_sy;      // element strides, x contiguous
@@ -57,21 +58,30 @@ struct WgradDev {
     int32_t ncob, ncib;
 };
 
-// One thread's share of the per-step global -> LDS copy: up to kCopies 16-byte granules.
-struct WgCopy {
-    int64_t src[kCopies];      // element offset from the row base (X granules: from the X row, dY granules: from the dY row)
-    int32_t dst[kCopies];      // element offset inside an X ring slot / a dY buffer
-    bool is_x[kCopies], live[kCopies], inside[kCopies];   // inside: the granule's x range is inside the volume
+// One thread's share of the per-step global -> LDS copy: up to NC 16-byte granules.
+template <int NC> struct WgCopy {
+    int64_t src[NC];           // element offset from the row base (X granules: from the X row, dY granules: from the dY row)
+    int32_t dst[NC];           // element offset inside an X ring slot / a dY buffer
+    bool is_x[NC], live[NC], inside[NC];                  // inside: the granule's x range is inside the volume
 };
 
-template <typename T, int NQ>
-__global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev P) {
+// QS = 1: three waves (ky), each walks both 32-wide halves (q) of a 64-wide x block.  QS = 2 (64-wide blocks only): SIX waves =
+// ky x q, each with the 27 accumulator tiles of its ky over its own half of x, summed through LDS after the row loop.  Why: two
+// three-wave workgroups put 2, 2, 1, 1 waves on a CU's four SIMDs and the row loop runs at the speed of the SIMDs that hold two
+// (a SIMD's matrix pipe and issue slots are shared by its waves, MI355X_MICROARCH.md "two waves per SIMD"); two six-wave
+// workgroups of half the work per wave are 3, 3, 3, 3.  Needs <= 168 registers (three waves per SIMD): the half-width wave holds
+// the same 108 accumulator registers and fewer fragments.
+template <typename T, int NQ, int QS>
+__global__ void __launch_bounds__(kWgThreads * QS, QS == 2 ? 3 : 2) conv3d_k3_wgrad_kernel(WgradDev P) {
     typedef typename Mfma16<T>::v8 frag8;
+    static_assert(QS == 1 || NQ == 2, "the six-wave layout splits a 64-wide block");
     constexpr int NCO = kWgCo / 16;
+    constexpr int NC = wg_copies(QS), NTHR = kWgThreads * QS;
     __shared__ __attribute__((aligned(16))) T xs[4][kWgBlock][kPitch];
     __shared__ __attribute__((aligned(16))) T dys[2][kWgCo][kPitch];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int ky = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: row / tap arithmetic stays on the SALU
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: row / tap arithmetic stays on the SALU
+    const int ky = wave % 3, qw = wave / 3;                           // QS = 2: this wave's half of the x block
     const int i16 = lane & 15, g = lane >> 4;
     // blockIdx.x runs over (co block, item, kz) with kz fastest, re-ordered so that every XCD owns a contiguous range: the three
     // tap planes of an item read the same dY rows, items that are neighbours in z the same X rows - one L2 fetches them once
@@ -103,10 +113,10 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
         constexpr int XG = 4 * NQ + 2;                    // granules per X row: left halo, data, right halo
         constexpr int DG = 4 * NQ;                        // granules per dY row
         constexpr int NX = kWgBlock * XG, ND = NCO * 16 * DG;
-        WgCopy cp;
+        WgCopy<NC> cp;
 #pragma unroll
-        for (int k = 0; k < kCopies; ++k) {
-            const int id = tid + k * kWgThreads;
+        for (int k = 0; k < NC; ++k) {
+            const int id = tid + k * NTHR;
             cp.is_x[k] = id < NX;
             cp.live[k] = id < NX + ND;
             if (cp.is_x[k]) {
@@ -129,20 +139,20 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
         const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
         // fetch X row yy and dY row yd into registers (rows outside the volume / range read a valid row and are zeroed)
-        auto fetch = [&](u32x4 (&r)[kCopies], int yy, int yd) {
+        auto fetch = [&](u32x4 (&r)[NC], int yy, int yd) {
             const bool x_ok = yy >= 0 && yy < P.H;
             const T* xr = xplane + (int64_t)(x_ok ? yy : 0) * P.x_sy;
             const T* dr = dyplane + (int64_t)(yd < P.H ? yd : 0) * P.dy_sy;
 #pragma unroll
-            for (int k = 0; k < kCopies; ++k) {
+            for (int k = 0; k < NC; ++k) {
                 const T* src = (cp.is_x[k] ? xr : dr) + cp.src[k];
                 r[k] = *reinterpret_cast<const u32x4*>(src);
             }
         };
-        auto park = [&](const u32x4 (&r)[kCopies], int yy, int slot, int buf) {
+        auto park = [&](const u32x4 (&r)[NC], int yy, int slot, int buf) {
             const bool x_ok = yy >= 0 && yy < P.H;
 #pragma unroll
-            for (int k = 0; k < kCopies; ++k) {
+            for (int k = 0; k < NC; ++k) {
                 if (!cp.live[k]) continue;
                 const bool keep = cp.is_x[k] ? (x_ok && cp.inside[k]) : cp.inside[k];
                 T* dst = (cp.is_x[k] ? &xs[slot][0][0] : &dys[buf][0][0]) + cp.dst[k];
@@ -152,7 +162,7 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
 
         // ---- prologue: rows y0 - 1, y0, y0 + 1 and dY row y0 ---------------------------------------------------------
         {
-            u32x4 r[kCopies];
+            u32x4 r[NC];
 #pragma unroll
             for (int d = -1; d <= 1; ++d) {
                 fetch(r, y0 + d, y0);
@@ -163,12 +173,13 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
 
         // ---- main loop ------------------------------------------------------------------------------------------------
         for (int y = y0; y < y1; ++y) {
-            u32x4 r[kCopies];
+            u32x4 r[NC];
             fetch(r, y + 2, y + 1);                       // in flight during this step's MFMAs
             SEGM_SCHED_FENCE();
             const int slot = (y + ky - 1 + 4) & 3, buf = (y - y0) & 1;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
+            for (int qi = 0; qi < NQ / QS; ++qi) {
+                const int q = QS == 2 ? qw : qi;
                 u32x4 av[NCO];
 #pragma unroll
                 for (int co = 0; co < NCO; ++co)
@@ -197,6 +208,29 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
             park(r, y + 2, (y + 2) & 3, buf ^ 1);
             __syncthreads();
         }
+    }
+    if constexpr (QS == 2) {
+        // the two halves of x: the q = 1 waves hand their tiles to the q = 0 waves through the (now idle) X ring, one co tile per
+        // round (3 waves x 9 tiles x 1 KB = 27 KB of the ring's 33 KB)
+        f32x4* lf = reinterpret_cast<f32x4*>(&xs[0][0][0]);
+#pragma unroll
+        for (int ct = 0; ct < NCO; ++ct) {
+            __syncthreads();                              // the ring is free (first round: every wave is out of the row loop)
+            if (qw == 1) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) lf[((ky * 3 + kx) * 3 + ci) * 64 + lane] = acc[ct][kx][ci];
+            }
+            __syncthreads();
+            if (qw == 0) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) acc[ct][kx][ci] += lf[((ky * 3 + kx) * 3 + ci) * 64 + lane];
+            }
+        }
+        if (qw == 1) return;
     }
     // partial block: part[((cob * ncib + cib) * nitems + item)][tap = kz*9 + ky*3 + kx][co (32)][ci (48)]
     float* out = P.part + ((((int64_t)cob * P.ncib + cib) * P.nitems + item_id) * 27) * (kWgCo * kWgBlock);
@@ -344,12 +378,15 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
     hipStream_t stream = (hipStream_t)a->stream;
     {
         const dim3 grid(P.nitems * 3 * P.ncob, P.ncib);
+        static const bool six = [] { const char* e = getenv("SEGM_WGRAD_SIX"); return e && atoi(e) == 1; }();     // A/B: six-wave layout
         if (a->dtype == SEGM_F16) {
-            if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 2>), grid, dim3(kWgThreads), 0, stream, P);
-            else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 1>), grid, dim3(kWgThreads), 0, stream, P);
+            if (pl.nq == 2 && six) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 2, 2>), grid, dim3(kWgThreads * 2), 0, stream, P);
+            else if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 2, 1>), grid, dim3(kWgThreads), 0, stream, P);
+            else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 1, 1>), grid, dim3(kWgThreads), 0, stream, P);
         } else {
-            if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 2>), grid, dim3(kWgThreads), 0, stream, P);
-            else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 1>), grid, dim3(kWgThreads), 0, stream, P);
+            if (pl.nq == 2 && six) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 2, 2>), grid, dim3(kWgThreads * 2), 0, stream, P);
+            else if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 2, 1>), grid, dim3(kWgThreads), 0, stream, P);
+            else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 1, 1>), grid, dim3(kWgThreads), 0, stream, P);
         }
     }
     const int total = a->cout * a->cin * 27;
