@@ -29,6 +29,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "segm_device.h"
 
 namespace segm {
@@ -477,7 +479,8 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 // VAR 3 (skip, two chunks ahead) on the unpadded-pitch kernel and the 32-wide one; SEGM_CONV_CHAIN_VAR=0 launches the round-3
 // schedule (VAR 0).  Measured in round 4 (profiles/r04_conv_chain_var_time.log): 48 -> 48 @128^3 0.626 -> 0.588 ms, the 32-wide
 // kernel 0.776 -> 0.680 ms there and 0.369 -> 0.355 ms at 96 -> 96 @64^3; three chunks ahead spills (256 registers at two waves
-// per SIMD) and loses; whole step 61.97 -> 61.6 ms.  `s_setprio 1` for the second-dispatched half of the workgroup (the guide's
+// per SIMD) and loses; whole step 61.97 -> 61.6 ms.  The 64-wide kernel ships VAR 11: bit 3 instantiates its row loop once per K
+// part (profiles/r04_conv_chain_perpart.log: 96 -> 96 @64^3 0.345 -> 0.327 ms, 192 -> 192 @32^3 0.377 -> 0.364, 48 -> 48 @128^3 equal).  `s_setprio 1` for the second-dispatched half of the workgroup (the guide's
 // two-waves-per-SIMD section, item 4) measured nothing here (0.605 / 0.612 vs 0.618 / 0.631 ms, profiles/r04_call9_ab.log).
 template <typename T, bool ACC, int CP, int VAR = 0>
 __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDev P) {
@@ -561,15 +564,33 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
         }
     }
     __syncthreads();
+    // VAR bit 3: the row loop is instantiated once per K part (PART >= 0) and entered through a switch - which part starts from the
+    // bias, reads / writes hand-off tiles, stores, stages which planes and has an eleventh chunk are then compile-time facts
+    // instead of scalar branches in every step (profiles/r04_conv_pmc.log: 1.3 scalar instructions per MFMA)
+    auto steps = [&](auto pc) {
+    constexpr int PART = decltype(pc)::value;
+    const int prt = PART >= 0 ? PART : part;
+    const bool second_ = PART >= 0 ? PART < 2 : second;
+    const int plane_a_ = PART >= 0 ? (PART >> 1) : plane_a, soff_a_ = plane_a_ == 0 ? 2 : 0;
+    const bool halo_ = PART >= 0 ? ((PART & 1) == 0 && xp == 0) : halo_wave;
+    auto fetch_s = [&](RowRegs (&r)[2], int base) {
+        row_fetch<T>(r[0], row_base<T>(P, b, z + plane_a_ - 1, base + soff_a_), cl, halo_);
+        if (second_) row_fetch<T>(r[1], row_base<T>(P, b, z + 1, base - 1), cl, halo_);
+    };
+    auto park_s = [&](const RowRegs (&r)[2], int base) {
+        const int ya = base + soff_a_, yb = base - 1;
+        row_park<T, CP>(r[0], ring + (plane_a_ * 4 + ((ya + 8) & 3)) * kSlot * (int)sizeof(T), cl, halo_);
+        if (second_) row_park<T, CP>(r[1], ring + (2 * 4 + ((yb + 8) & 3)) * kSlot * (int)sizeof(T), cl, halo_);
+    };
     for (int s = y0; s < y1 + 3; ++s) {
-        const int row = s - part;                         // this part's output row
+        const int row = s - prt;                          // this part's output row
         const bool active = row >= y0 && row < y1;
         // the partial sums of the previous K part for this row, then the first chunk's A fragments: issued before the
         // global fetches so that their latency is covered by the address arithmetic
         f32x4 acc[3][XT];
         frag8 a[PF + 1][XT];
         const T* pl = &xs[0][0][0];
-        auto live = [&](int c) { return !SKIP || c + 1 < kF48Chunks || part == 0; };
+        auto live = [&](int c) { return !SKIP || c + 1 < kF48Chunks || prt == 0; };
         auto load_a = [&](frag8 (&dst)[XT], int c) {
             const int slot = (row + (aoff[c] >> 28) + 7) & 3;              // input row = row + ky - 1
             const T* ap = pl + slot * kSlot + (aoff[c] & 0x0fffffff);
@@ -577,7 +598,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
             for (int u = 0; u < XT; ++u) dst[u] = *reinterpret_cast<const frag8*>(ap + u * 16 * CP);
         };
         if (active) {
-            if (part == 0) {                              // the chain starts from the bias (a lane's four results share a co)
+            if (prt == 0) {                               // the chain starts from the bias (a lane's four results share a co)
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -586,13 +607,13 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int u = 0; u < XT; ++u) acc[t][u] = hand[(s + 1) & 1][part - 1][xp][t * XT + u][lane];
+                    for (int u = 0; u < XT; ++u) acc[t][u] = hand[(s + 1) & 1][prt - 1][xp][t * XT + u][lane];
             }
 #pragma unroll
             for (int c = 0; c < PF; ++c) load_a(a[c], c);
         }
         RowRegs r[2];
-        fetch(r, s, true);                                // in flight during this step's MFMAs
+        fetch_s(r, s);                                    // in flight during this step's MFMAs
         SEGM_SCHED_FENCE();
         if (active) {
 #pragma unroll
@@ -607,19 +628,19 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
                 }
                 SEGM_SCHED_FENCE();
             }
-            if (part < 3) {
+            if (prt < 3) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int u = 0; u < XT; ++u) hand[s & 1][part][xp][t * XT + u][lane] = acc[t][u];
+                    for (int u = 0; u < XT; ++u) hand[s & 1][prt][xp][t * XT + u][lane] = acc[t][u];
             }
         }
         SEGM_SCHED_FENCE();
-        park(r, s, true);
+        park_s(r, s);
         // the last K part stores AFTER the rows are parked: vmcnt counts loads and stores in order, so a park behind the stores
         // would wait for their write acknowledgements (a memory round trip on the critical path of every step); here the
         // stores drain during the next step
-        if (active && part == 3) {
+        if (active && prt == 3) {
 #pragma unroll
             for (int u = 0; u < XT; ++u) {
                 const int xg = x0 + (xp * XT + u) * 16 + 4 * g;            // this lane's 4 output positions
@@ -637,6 +658,17 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
             }
         }
         __syncthreads();                                  // incoming rows and the hand-off tiles are in LDS
+    }
+    };
+    if constexpr ((VAR & 8) != 0) {
+        switch (part) {
+            case 0: steps(std::integral_constant<int, 0>{}); break;
+            case 1: steps(std::integral_constant<int, 1>{}); break;
+            case 2: steps(std::integral_constant<int, 2>{}); break;
+            default: steps(std::integral_constant<int, 3>{}); break;
+        }
+    } else {
+        steps(std::integral_constant<int, -1>{});
     }
 }
 
@@ -871,7 +903,7 @@ static void launch48(const ConvFwdDev& P, dim3 grid, bool f16, bool acc, hipStre
     if (CHAIN == 48 && chain_var() != 0) {
 #define SEGM_LV(T, V) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, true, 48, V>), grid, dim3(512), 0, stream, P); \
                         else hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, false, 48, V>), grid, dim3(512), 0, stream, P); } while (0)
-        if (f16) SEGM_LV(f16_t, 3); else SEGM_LV(bf16_t, 3);
+        if (f16) SEGM_LV(f16_t, 11); else SEGM_LV(bf16_t, 11);       // the 64-wide kernel: also instantiated per K part (bit 3)
 #undef SEGM_LV
         return;
     }
