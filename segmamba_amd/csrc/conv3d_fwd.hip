@@ -291,14 +291,19 @@ __device__ __forceinline__ void row_fetch(RowRegs& r, const char* rb, const Copy
         r.c[0] = *reinterpret_cast<const uint16_t*>(rb + L.goff1);
     }
 }
+// true when no lane of the wave has to zero what it fetched (interior x range, all 48 input channels): wave-uniform
+__device__ __forceinline__ bool park_unmasked(const CopyLane& L) { return __ballot(L.has && !(L.live0 && L.live1)) == 0ull; }
+
 template <typename T, int CP = kFwCP, bool GUARD = false>   // GUARD: granule waves may hold lanes without a task
-__device__ __forceinline__ void row_park(const RowRegs& r, char* ring_row, const CopyLane& L, bool halo_wave) {
+__device__ __forceinline__ void row_park(const RowRegs& r, char* ring_row, const CopyLane& L, bool halo_wave, bool unmasked = false) {
     char* dst = ring_row + L.loff;
     if (!halo_wave) {
         if (GUARD && !L.has) return;
         u32x4 a = r.a, c = r.c;
+        if (!unmasked) {                                  // uniform
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { a[i] = L.live0 ? a[i] : 0u; c[i] = L.live1 ? c[i] : 0u; }
+            for (int i = 0; i < 4; ++i) { a[i] = L.live0 ? a[i] : 0u; c[i] = L.live1 ? c[i] : 0u; }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e)                       // {channel 2 tcp, channel 2 tcp + 1} at x position e
             *reinterpret_cast<uint32_t*>(dst + e * CP * (int)sizeof(T)) =
@@ -577,10 +582,11 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
         row_fetch<T>(r[0], row_base<T>(P, b, z + plane_a_ - 1, base + soff_a_), cl, halo_);
         if (second_) row_fetch<T>(r[1], row_base<T>(P, b, z + 1, base - 1), cl, halo_);
     };
+    const bool unm = (VAR & 8) != 0 && park_unmasked(cl);
     auto park_s = [&](const RowRegs (&r)[2], int base) {
         const int ya = base + soff_a_, yb = base - 1;
-        row_park<T, CP>(r[0], ring + (plane_a_ * 4 + ((ya + 8) & 3)) * kSlot * (int)sizeof(T), cl, halo_);
-        if (second_) row_park<T, CP>(r[1], ring + (2 * 4 + ((yb + 8) & 3)) * kSlot * (int)sizeof(T), cl, halo_);
+        row_park<T, CP>(r[0], ring + (plane_a_ * 4 + ((ya + 8) & 3)) * kSlot * (int)sizeof(T), cl, halo_, unm);
+        if (second_) row_park<T, CP>(r[1], ring + (2 * 4 + ((yb + 8) & 3)) * kSlot * (int)sizeof(T), cl, halo_, unm);
     };
     for (int s = y0; s < y1 + 3; ++s) {
         const int row = s - prt;                          // this part's output row
@@ -804,13 +810,40 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
         }
     }
     __syncthreads();
+    // VAR bit 3: the row loop once per K part, entered through a switch (see the 64-wide kernel)
+    auto steps = [&](auto pc) {
+    constexpr int PART = decltype(pc)::value;
+    const int prt = PART >= 0 ? PART : part;
+    const bool halo_ = PART >= 0 ? PART == 3 : halo_wave;
+    const bool unm0 = (VAR & 8) != 0 && park_unmasked(cl0), unm1 = (VAR & 8) != 0 && park_unmasked(cl1);
+    auto fetch_s = [&](RowRegs (&r)[3], int base) {
+        if (!halo_) {
+            const char* rb = row_base<T>(P, b, z + prt - 1, srow(prt, base, true));
+            row_fetch<T>(r[0], rb, cl0, false);
+            row_fetch<T>(r[1], rb, cl1, false);
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) row_fetch<T>(r[pl], row_base<T>(P, b, z + pl - 1, srow(pl, base, true)), cl0, true);
+        }
+    };
+    auto park_s = [&](const RowRegs (&r)[3], int base) {
+        if (!halo_) {
+            char* row = ring + (prt * 4 + ((srow(prt, base, true) + 8) & 3)) * kSlot * (int)sizeof(T);
+            row_park<T, CP, true>(r[0], row, cl0, false, unm0);
+            row_park<T, CP, true>(r[1], row, cl1, false, unm1);
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                row_park<T, CP>(r[pl], ring + (pl * 4 + ((srow(pl, base, true) + 8) & 3)) * kSlot * (int)sizeof(T), cl0, true);
+        }
+    };
     for (int s = y0; s < y1 + 3; ++s) {
-        const int row = s - part;                         // this part's output row
+        const int row = s - prt;                          // this part's output row
         const bool active = row >= y0 && row < y1;
         f32x4 acc[3][XT];
         frag8 a[PF + 1][XT];
         const T* pl = &xs[0][0][0];
-        auto live = [&](int c) { return !SKIP || c + 1 < kF48Chunks || part == 0; };
+        auto live = [&](int c) { return !SKIP || c + 1 < kF48Chunks || prt == 0; };
         auto load_a = [&](frag8 (&dst)[XT], int c) {
             const int slot = (row + (aoff[c] >> 28) + 7) & 3;              // input row = row + ky - 1
             const T* ap = pl + slot * kSlot + (aoff[c] & 0x0fffffff);
@@ -818,7 +851,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
             for (int u = 0; u < XT; ++u) dst[u] = *reinterpret_cast<const frag8*>(ap + u * 16 * CP);
         };
         if (active) {
-            if (part == 0) {                              // the chain starts from the bias (a lane's four results share a co)
+            if (prt == 0) {                               // the chain starts from the bias (a lane's four results share a co)
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -827,13 +860,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int u = 0; u < XT; ++u) acc[t][u] = hand[(s + 1) & 1][part - 1][t * XT + u][lane];
+                    for (int u = 0; u < XT; ++u) acc[t][u] = hand[(s + 1) & 1][prt - 1][t * XT + u][lane];
             }
 #pragma unroll
             for (int c = 0; c < PF; ++c) load_a(a[c], c);
         }
         RowRegs r[3];
-        fetch(r, s, true);                                // in flight during this step's MFMAs
+        fetch_s(r, s);                                    // in flight during this step's MFMAs
         SEGM_SCHED_FENCE();
         if (active) {
 #pragma unroll
@@ -848,11 +881,11 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
                 }
                 SEGM_SCHED_FENCE();
             }
-            if (part < 3) {
+            if (prt < 3) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int u = 0; u < XT; ++u) hand[s & 1][part][t * XT + u][lane] = acc[t][u];
+                    for (int u = 0; u < XT; ++u) hand[s & 1][prt][t * XT + u][lane] = acc[t][u];
             } else {
 #pragma unroll
                 for (int u = 0; u < XT; ++u) {
@@ -872,8 +905,19 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
             }
         }
         SEGM_SCHED_FENCE();
-        park(r, s, true);
+        park_s(r, s);
         __syncthreads();                                  // incoming rows and the hand-off tiles are in LDS
+    }
+    };
+    if constexpr ((VAR & 8) != 0) {
+        switch (part) {
+            case 0: steps(std::integral_constant<int, 0>{}); break;
+            case 1: steps(std::integral_constant<int, 1>{}); break;
+            case 2: steps(std::integral_constant<int, 2>{}); break;
+            default: steps(std::integral_constant<int, 3>{}); break;
+        }
+    } else {
+        steps(std::integral_constant<int, -1>{});
     }
 }
 
@@ -958,10 +1002,10 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     if (chain32) {
         const dim3 grid(pl.nitems * (a->cout / 48));
 #define SEGM_L32(T, A) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, A>), grid, dim3(256), 0, stream, P)
-#define SEGM_LV(T) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, true, 3>), grid, dim3(256), 0, stream, P); \
-                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, false, 3>), grid, dim3(256), 0, stream, P); } while (0)
+#define SEGM_LV(T, V) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, true, V>), grid, dim3(256), 0, stream, P); \
+                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, false, V>), grid, dim3(256), 0, stream, P); } while (0)
         if (chain_var() != 0) {
-            if (f16) SEGM_LV(f16_t); else SEGM_LV(bf16_t);
+            if (f16) SEGM_LV(f16_t, 9); else SEGM_LV(bf16_t, 9);     // 9: skip + per-part loop, fragments one chunk ahead (two ahead spills here)
             return (int)hipGetLastError();
         }
 #undef SEGM_LV
