@@ -69,9 +69,10 @@ def _key(kind, x, w, *flags) -> tuple:
 
 def _table_variant(width: int):
     """the library forward kernel's (chain, pitch48, chain32) flags for a volume of this width (profiles/r02_bench_variants.log,
-    r02_conv_stride_pad.log): chained K parts everywhere; unpadded LDS rows at 128^3 / 64^3; the 32-wide-block variant (two
-    workgroups per CU) for 32^3 and below"""
-    return (True, True, False) if width >= 64 else (False, False, True)
+    r02_conv_stride_pad.log, r04_conv_chain_final.log): chained K parts everywhere; 64-wide blocks with unpadded LDS rows at 128^3;
+    the 32-wide-block variant (two workgroups per CU) for 64^3 and below - since round 4, when its storing wave stopped staging
+    the halo columns, it is level at 48 -> 48 @64^3 (0.074 ms both) and ahead at 96 -> 96 @64^3 (0.315 vs 0.334 ms)"""
+    return (True, True, False) if width >= 128 else (False, False, True)
 
 
 def _table_choice(kind: str, width: int, variants) -> int:

@@ -743,8 +743,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
     const int y0 = ypart * P.rows_per_part;
     const int y1 = (y0 + P.rows_per_part < P.H) ? y0 + P.rows_per_part : P.H;
     const int x0 = xb * kC32XB;
-    const int c_begin = part == 0 ? 0 : 11 + 10 * (part - 1);     // first chunk of this K part
-    const int c_count = part == 0 ? 11 : 10;
+    const int c_begin = 10 * part;                                // first chunk of this K part: 41 chunks = 10 + 10 + 10 + 11 - the eleven
+    const int c_count = part == 3 ? 11 : 10;                      // go to the wave that stages nothing (registers: 120 + staging vs 132)
 
     // ---- stationary weights and the matching A fragment offsets (x tile 0) ---------------------------------------------------
     frag8 wf[3][kF48Chunks];
@@ -773,30 +773,30 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
 
     // ---- row staging: plane q's incoming row during step s is s + {2, 0, -1}[q] -----------------------------------------------
     // waves 0 - 2: slots 0 / 1 = granule tasks lane / 64 + lane of plane `part`; wave 3: slots 0 - 2 = halo tasks of planes 0 - 2
-    const bool halo_wave = part == 3;
-    const CopyLane cl0 = copy_lane32<T>(P, halo_wave, lane, x0);
-    const CopyLane cl1 = copy_lane32<T>(P, halo_wave, halo_wave ? lane : 64 + lane, x0);
+    // waves 0 - 2 stage plane `part` completely: slots 0 / 1 = its 96 granule tasks (lane, 64 + lane), slot 2 = its 48 halo tasks.
+    // Wave 3 - the storing wave - stages nothing: in round 3's plan it carried the halo tasks of all three planes, and its loads sat
+    // behind `s_waitcnt vmcnt(0)` for the output stores of the step before (their source registers are reused: the compiler waits for
+    // the stores to complete) - a memory round trip at the head of every step of the wave the chain ends in.
+    const bool stager = part < 3;
+    const CopyLane cl0 = copy_lane32<T>(P, false, lane, x0);
+    const CopyLane cl1 = copy_lane32<T>(P, false, 64 + lane, x0);
+    const CopyLane clh = copy_lane32<T>(P, true, lane, x0);
     char* ring = reinterpret_cast<char*>(&xs[0][0][0]);
     auto srow = [&](int pl, int base, bool skewed) { return base + (skewed ? (pl == 0 ? 2 : (pl == 1 ? 0 : -1)) : 0); };
     auto fetch = [&](RowRegs (&r)[3], int base, bool skewed) {
-        if (!halo_wave) {
+        if (stager) {
             const char* rb = row_base<T>(P, b, z + part - 1, srow(part, base, skewed));
             row_fetch<T>(r[0], rb, cl0, false);
             row_fetch<T>(r[1], rb, cl1, false);
-        } else {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) row_fetch<T>(r[pl], row_base<T>(P, b, z + pl - 1, srow(pl, base, skewed)), cl0, true);
+            row_fetch<T>(r[2], rb, clh, true);
         }
     };
     auto park = [&](const RowRegs (&r)[3], int base, bool skewed) {
-        if (!halo_wave) {
+        if (stager) {
             char* row = ring + (part * 4 + ((srow(part, base, skewed) + 8) & 3)) * kSlot * (int)sizeof(T);
             row_park<T, CP, true>(r[0], row, cl0, false);
             row_park<T, CP, true>(r[1], row, cl1, false);
-        } else {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                row_park<T, CP>(r[pl], ring + (pl * 4 + ((srow(pl, base, skewed) + 8) & 3)) * kSlot * (int)sizeof(T), cl0, true);
+            row_park<T, CP>(r[2], row, clh, true);
         }
     };
 
@@ -814,27 +814,22 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
     auto steps = [&](auto pc) {
     constexpr int PART = decltype(pc)::value;
     const int prt = PART >= 0 ? PART : part;
-    const bool halo_ = PART >= 0 ? PART == 3 : halo_wave;
+    const bool stager_ = PART >= 0 ? PART < 3 : stager;
     const bool unm0 = (VAR & 8) != 0 && park_unmasked(cl0), unm1 = (VAR & 8) != 0 && park_unmasked(cl1);
     auto fetch_s = [&](RowRegs (&r)[3], int base) {
-        if (!halo_) {
+        if (stager_) {
             const char* rb = row_base<T>(P, b, z + prt - 1, srow(prt, base, true));
             row_fetch<T>(r[0], rb, cl0, false);
             row_fetch<T>(r[1], rb, cl1, false);
-        } else {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) row_fetch<T>(r[pl], row_base<T>(P, b, z + pl - 1, srow(pl, base, true)), cl0, true);
+            row_fetch<T>(r[2], rb, clh, true);
         }
     };
     auto park_s = [&](const RowRegs (&r)[3], int base) {
-        if (!halo_) {
+        if (stager_) {
             char* row = ring + (prt * 4 + ((srow(prt, base, true) + 8) & 3)) * kSlot * (int)sizeof(T);
             row_park<T, CP, true>(r[0], row, cl0, false, unm0);
             row_park<T, CP, true>(r[1], row, cl1, false, unm1);
-        } else {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                row_park<T, CP>(r[pl], ring + (pl * 4 + ((srow(pl, base, true) + 8) & 3)) * kSlot * (int)sizeof(T), cl0, true);
+            row_park<T, CP>(r[2], row, clh, true);
         }
     };
     for (int s = y0; s < y1 + 3; ++s) {
@@ -843,7 +838,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
         f32x4 acc[3][XT];
         frag8 a[PF + 1][XT];
         const T* pl = &xs[0][0][0];
-        auto live = [&](int c) { return !SKIP || c + 1 < kF48Chunks || prt == 0; };
+        auto live = [&](int c) { return !SKIP || c + 1 < kF48Chunks || prt == 3; };
         auto load_a = [&](frag8 (&dst)[XT], int c) {
             const int slot = (row + (aoff[c] >> 28) + 7) & 3;              // input row = row + ky - 1
             const T* ap = pl + slot * kSlot + (aoff[c] & 0x0fffffff);
@@ -1005,7 +1000,8 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
 #define SEGM_LV(T, V) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, true, V>), grid, dim3(256), 0, stream, P); \
                         else hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, false, V>), grid, dim3(256), 0, stream, P); } while (0)
         if (chain_var() != 0) {
-            if (f16) SEGM_LV(f16_t, 9); else SEGM_LV(bf16_t, 9);     // 9: skip + per-part loop, fragments one chunk ahead (two ahead spills here)
+            static const bool pf2 = [] { const char* e = getenv("SEGM_CONV_CHAIN32_PF2"); return e && atoi(e) == 1; }();     // A/B: fragments two chunks ahead
+            if (f16) SEGM_LV(f16_t, 9); else if (pf2) SEGM_LV(bf16_t, 11); else SEGM_LV(bf16_t, 9);     // 9: skip + per-part loop, fragments one chunk ahead (two ahead spills here)
             return (int)hipGetLastError();
         }
 #undef SEGM_LV
