@@ -569,6 +569,14 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
         }
     }
     __syncthreads();
+    // output addresses = uniform base (row, co tile, x tile: scalar arithmetic) + one 32-bit lane offset (co and x within the tile;
+    // the host checks that 16 channel strides fit 32 bits)
+    const uint32_t ylane = (uint32_t)(((int64_t)i16 * P.y_sc + 4 * g) * (int64_t)sizeof(T));
+    const uint32_t ylane0 = (uint32_t)((int64_t)i16 * P.y_sc * (int64_t)sizeof(T));
+    auto ybase = [&](int row, int t, int u) {
+        return P.y + ((int64_t)b * P.y_sb + (int64_t)(cob * 48 + t * 16) * P.y_sc + (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + x0 +
+                      (xp * XT + u) * 16) * (int64_t)sizeof(T);
+    };
     // VAR bit 3: the row loop is instantiated once per K part (PART >= 0) and entered through a switch - which part starts from the
     // bias, reads / writes hand-off tiles, stores, stages which planes and has an eleventh chunk are then compile-time facts
     // instead of scalar branches in every step (profiles/r04_conv_pmc.log: 1.3 scalar instructions per MFMA)
@@ -620,6 +628,17 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
         }
         RowRegs r[2];
         fetch_s(r, s);                                    // in flight during this step's MFMAs
+        // accumulate variant: what y holds for this row is fetched now and added after the MFMAs (see the 32-wide kernel)
+        u32x2 oldy[XT][3];
+        if (ACC && active && prt == 3) {
+#pragma unroll
+            for (int u = 0; u < XT; ++u) {
+                const int xg = x0 + (xp * XT + u) * 16 + 4 * g;
+#pragma unroll
+                for (int t = 0; t < 3; ++t)                // lanes beyond W re-read their tile's first column (never stored)
+                    oldy[u][t] = *reinterpret_cast<const u32x2*>(ybase(row, t, u) + (xg < P.W ? ylane : ylane0));
+            }
+        }
         SEGM_SCHED_FENCE();
         if (active) {
 #pragma unroll
@@ -656,10 +675,14 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
                     float v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = acc[t][u][q];
-                    const int co = cob * 48 + t * 16 + i16;
-                    T* dst = reinterpret_cast<T*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
-                                  (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + xg;
-                    store4<T, ACC>(dst, v);
+                    T* dst = reinterpret_cast<T*>(ybase(row, t, u) + ylane);
+                    if (ACC) {
+                        T o[4];
+                        memcpy(o, &oldy[u][t], 8);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += to_f32(o[q]);
+                    }
+                    store4<T, false>(dst, v);
                 }
             }
         }
@@ -810,6 +833,15 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
         }
     }
     __syncthreads();
+    // output addresses = uniform base (row, co tile, x tile: scalar arithmetic) + one 32-bit lane offset (co within the tile, x
+    // within the tile; the host checks that 16 channel strides fit 32 bits).  (As a buffer resource + scalar offset the accumulate
+    // variant's last K part - eleven chunks of weights, the old outputs in flight - spilled 22 registers; this form spills 3.)
+    const uint32_t ylane = (uint32_t)(((int64_t)i16 * P.y_sc + 4 * g) * (int64_t)sizeof(T));
+    const uint32_t ylane0 = (uint32_t)((int64_t)i16 * P.y_sc * (int64_t)sizeof(T));
+    auto ybase = [&](int row, int t, int u) {
+        return P.y + ((int64_t)b * P.y_sb + (int64_t)(cob * 48 + t * 16) * P.y_sc + (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + x0 + u * 16) *
+                         (int64_t)sizeof(T);
+    };
     // VAR bit 3: the row loop once per K part, entered through a switch (see the 64-wide kernel)
     auto steps = [&](auto pc) {
     constexpr int PART = decltype(pc)::value;
@@ -862,6 +894,19 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
         }
         RowRegs r[3];
         fetch_s(r, s);                                    // in flight during this step's MFMAs
+        // accumulate variant: what y holds for this row is fetched NOW and added after the MFMAs (round 3 loaded it in the epilogue:
+        // a memory round trip between the last MFMA and the stores of every row - profiles/r04_conv_pmc.log: the `_Accum`
+        // launches took twice the wave cycles of the plain ones)
+        u32x2 oldy[XT][3];
+        if (ACC && active && prt == 3) {
+#pragma unroll
+            for (int u = 0; u < XT; ++u) {
+                const int xg = x0 + u * 16 + 4 * g;
+#pragma unroll
+                for (int t = 0; t < 3; ++t)                // lanes beyond W re-read their tile's first column (never stored)
+                    oldy[u][t] = *reinterpret_cast<const u32x2*>(ybase(row, t, u) + (xg < P.W ? ylane : ylane0));
+            }
+        }
         SEGM_SCHED_FENCE();
         if (active) {
 #pragma unroll
@@ -891,10 +936,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
                         float v[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = acc[t][u][q];
-                        const int co = cob * 48 + t * 16 + i16;
-                        T* dst = reinterpret_cast<T*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc +
-                                      (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + xg;
-                        store4<T, ACC>(dst, v);
+                        if (ACC) {
+                            T o[4];
+                            memcpy(o, &oldy[u][t], 8);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] += to_f32(o[q]);
+                        }
+                        store4<T, false>(reinterpret_cast<T*>(ybase(row, t, u) + ylane), v);
                     }
                 }
             }
@@ -940,7 +988,8 @@ static int chain_var() {                                // 3 = the shipped sched
 template <int CHAIN>                                    // 0: reduce-per-row kernel; else the chained kernel with that ci pitch
 static void launch48(const ConvFwdDev& P, dim3 grid, bool f16, bool acc, hipStream_t stream) {
     if (CHAIN == 48 && chain_var() != 0) {
-#define SEGM_LV(T, V) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, true, 48, V>), grid, dim3(512), 0, stream, P); \
+    // the accumulate variant keeps the old outputs of a row in flight during its MFMAs: fragments ONE chunk ahead there (V & ~2)
+#define SEGM_LV(T, V) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, true, 48, (V) & ~2>), grid, dim3(512), 0, stream, P); \
                         else hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, false, 48, V>), grid, dim3(512), 0, stream, P); } while (0)
         if (f16) SEGM_LV(f16_t, 11); else SEGM_LV(bf16_t, 11);       // the 64-wide kernel: also instantiated per K part (bit 3)
 #undef SEGM_LV
@@ -994,14 +1043,14 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     // the 48-channel kernels address a row as [uniform base + 32-bit lane offset]: 48 channel strides must fit
     const bool off32 = ((int64_t)47 * a->x_stride_c + a->width) * 2 < ((int64_t)1 << 32);
     if ((a->flags & (SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_CHAIN32)) && !off32) return SEGM_E_SHAPE;
+    if ((a->flags & (SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_CHAIN32)) && ((int64_t)16 * a->y_stride_c + a->width) * 2 >= ((int64_t)1 << 32)) return SEGM_E_SHAPE;
     if (chain32) {
         const dim3 grid(pl.nitems * (a->cout / 48));
 #define SEGM_L32(T, A) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, A>), grid, dim3(256), 0, stream, P)
 #define SEGM_LV(T, V) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, true, V>), grid, dim3(256), 0, stream, P); \
                         else hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, false, V>), grid, dim3(256), 0, stream, P); } while (0)
         if (chain_var() != 0) {
-            static const bool pf2 = [] { const char* e = getenv("SEGM_CONV_CHAIN32_PF2"); return e && atoi(e) == 1; }();     // A/B: fragments two chunks ahead
-            if (f16) SEGM_LV(f16_t, 9); else if (pf2) SEGM_LV(bf16_t, 11); else SEGM_LV(bf16_t, 9);     // 9: skip + per-part loop, fragments one chunk ahead (two ahead spills here)
+            if (f16) SEGM_LV(f16_t, 9); else SEGM_LV(bf16_t, 9);     // two chunks ahead measured nothing here (profiles/r04_conv_chain32_pf2.log)     // 9: skip + per-part loop, fragments one chunk ahead (two ahead spills here)
             return (int)hipGetLastError();
         }
 #undef SEGM_LV
