@@ -572,7 +572,6 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
     // output addresses = uniform base (row, co tile, x tile: scalar arithmetic) + one 32-bit lane offset (co and x within the tile;
     // the host checks that 16 channel strides fit 32 bits)
     const uint32_t ylane = (uint32_t)(((int64_t)i16 * P.y_sc + 4 * g) * (int64_t)sizeof(T));
-    const uint32_t ylane0 = (uint32_t)((int64_t)i16 * P.y_sc * (int64_t)sizeof(T));
     auto ybase = [&](int row, int t, int u) {
         return P.y + ((int64_t)b * P.y_sb + (int64_t)(cob * 48 + t * 16) * P.y_sc + (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + x0 +
                       (xp * XT + u) * 16) * (int64_t)sizeof(T);
@@ -634,9 +633,10 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
 #pragma unroll
             for (int u = 0; u < XT; ++u) {
                 const int xg = x0 + (xp * XT + u) * 16 + 4 * g;
+                if (xg < P.W) {                            // lanes beyond W neither load nor store (a tile beyond W starts past the row's end)
 #pragma unroll
-                for (int t = 0; t < 3; ++t)                // lanes beyond W re-read their tile's first column (never stored)
-                    oldy[u][t] = *reinterpret_cast<const u32x2*>(ybase(row, t, u) + (xg < P.W ? ylane : ylane0));
+                    for (int t = 0; t < 3; ++t) oldy[u][t] = *reinterpret_cast<const u32x2*>(ybase(row, t, u) + ylane);
+                }
             }
         }
         SEGM_SCHED_FENCE();
@@ -837,7 +837,6 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
     // within the tile; the host checks that 16 channel strides fit 32 bits).  (As a buffer resource + scalar offset the accumulate
     // variant's last K part - eleven chunks of weights, the old outputs in flight - spilled 22 registers; this form spills 3.)
     const uint32_t ylane = (uint32_t)(((int64_t)i16 * P.y_sc + 4 * g) * (int64_t)sizeof(T));
-    const uint32_t ylane0 = (uint32_t)((int64_t)i16 * P.y_sc * (int64_t)sizeof(T));
     auto ybase = [&](int row, int t, int u) {
         return P.y + ((int64_t)b * P.y_sb + (int64_t)(cob * 48 + t * 16) * P.y_sc + (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + x0 + u * 16) *
                          (int64_t)sizeof(T);
@@ -902,9 +901,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
 #pragma unroll
             for (int u = 0; u < XT; ++u) {
                 const int xg = x0 + u * 16 + 4 * g;
+                if (xg < P.W) {                            // lanes beyond W neither load nor store (a tile beyond W starts past the row's end)
 #pragma unroll
-                for (int t = 0; t < 3; ++t)                // lanes beyond W re-read their tile's first column (never stored)
-                    oldy[u][t] = *reinterpret_cast<const u32x2*>(ybase(row, t, u) + (xg < P.W ? ylane : ylane0));
+                    for (int t = 0; t < 3; ++t) oldy[u][t] = *reinterpret_cast<const u32x2*>(ybase(row, t, u) + ylane);
+                }
             }
         }
         SEGM_SCHED_FENCE();

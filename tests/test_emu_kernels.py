@@ -567,10 +567,16 @@ def test_conv3d_k3_fwd_chained_k_parts_emulated(emu, shape):
     assert torch.equal(y48, y)                                                                               # same sums, other LDS layout
     y32 = ops_raw.conv3d_k3_fwd(emu, x[:, :48], ops_raw.pack_conv3d_weight(w[:, :48]), bias, chain32=True)
     assert torch.equal(y32, y)                                                                               # same sums, 32-wide x blocks
-    if shape != (1, 48, 2, 2, 16):
-        return
     ref = torch.nn.functional.conv3d(x.float(), w.float(), bias, 1, 1)
     w1 = ops_raw.pack_conv3d_weight(w[:, 48:])
+    # in-place accumulation of the second 48-channel input block with every chained kernel, on every shape (widths 8 / 16: x tiles
+    # beyond W, whose lanes must neither read nor write - the old outputs are fetched at the head of the step since round 4)
+    for kw in (dict(chain=True, pitch48=True), dict(chain32=True)):
+        ya = y.clone()
+        ops_raw.conv3d_k3_fwd(emu, x[:, 48:], w1, None, out=ya, accumulate=True, **kw)
+        assert (ya.float() - ref).abs().max() <= 2 * tol, kw
+    if shape != (1, 48, 2, 2, 16):
+        return
     y2 = ops_raw.conv3d_k3_fwd(emu, x[:, 48:], w1, None, out=y, accumulate=True, chain=True)
     assert y2 is y and (y.float() - ref).abs().max() <= 2 * tol
     y3 = ref0.bfloat16()

@@ -355,7 +355,7 @@ def test_conv_routing_is_a_table_not_a_timing_run():
     assert conv3d._TUNE is False
     lib = [(False, False, False), (True, False, False), (True, True, False), (False, False, True)]
     fwd = [None, None] + lib                                  # native, blocked, the four library variants
-    for width, want in ((128, (True, True, False)), (64, (True, True, False)), (32, (False, False, True)), (16, (False, False, True))):
+    for width, want in ((128, (True, True, False)), (64, (False, False, True)), (32, (False, False, True)), (16, (False, False, True))):     # 64^3: the 32-wide kernel since round 4
         assert fwd[conv3d._table_choice("fwd", width, fwd)] == want
         assert ([None] + fwd)[conv3d._table_choice("dgrad", width, [None] + fwd)] == want
     assert conv3d._table_choice("fwd", 8, fwd) == 0 and conv3d._table_choice("dgrad", 8, [None] + fwd) == 0     # 8^3: vendor GEMM route
