@@ -633,7 +633,8 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
 #pragma unroll
             for (int u = 0; u < XT; ++u) {
                 const int xg = x0 + (xp * XT + u) * 16 + 4 * g;
-                if (xg < P.W) {                            // lanes beyond W neither load nor store (a tile beyond W starts past the row's end)
+                // lanes beyond W neither load nor store (a tile beyond W starts past the row's end); a block inside W: no lane mask
+                if (x0 + kFwXB <= P.W || xg < P.W) {
 #pragma unroll
                     for (int t = 0; t < 3; ++t) oldy[u][t] = *reinterpret_cast<const u32x2*>(ybase(row, t, u) + ylane);
                 }
@@ -901,7 +902,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
 #pragma unroll
             for (int u = 0; u < XT; ++u) {
                 const int xg = x0 + u * 16 + 4 * g;
-                if (xg < P.W) {                            // lanes beyond W neither load nor store (a tile beyond W starts past the row's end)
+                // lanes beyond W neither load nor store (a tile beyond W starts past the row's end); a block inside W: no lane mask
+                if (x0 + kC32XB <= P.W || xg < P.W) {
 #pragma unroll
                     for (int t = 0; t < 3; ++t) oldy[u][t] = *reinterpret_cast<const u32x2*>(ybase(row, t, u) + ylane);
                 }
