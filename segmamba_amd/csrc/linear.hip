@@ -38,7 +38,7 @@ struct LinDev {
 // KC = 32-wide chunks of K held per wave; NT = 16-column tiles of W per wave (at most 24 fragments = 96 VGPRs, which
 // leaves room for two to three waves per SIMD - the kernel lives on memory-level parallelism)
 constexpr int lin_tiles(int kc) { return kc <= 2 ? 12 : (kc == 3 ? 8 : (kc == 4 ? 6 : 4)); }
-template <typename T, int KC>
+template <typename T, int KC, bool ACCUM = false>
 __global__ void __launch_bounds__(kLinWaves * 64) linear_rows_kernel(LinDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     constexpr int NT = lin_tiles(KC);
@@ -82,6 +82,14 @@ __global__ void __launch_bounds__(kLinWaves * 64) linear_rows_kernel(LinDev P) {
         const int64_t m = tile * 16 + i16;
         const bool row_ok = tile < ntiles && m < P.rows;
         T* yrow = reinterpret_cast<T*>(P.y) + (row_ok ? m : 0) * P.ldy + n0 + 4 * g;
+        // accumulate: what y holds is fetched for ALL column tiles before the first MFMA (round 3 loaded each tile's old values
+        // after its MFMAs and waited for them: one memory round trip per column tile and row tile on the critical path)
+        lin_u32x2 oldv[ACCUM ? NT : 1];
+        if constexpr (ACCUM) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t < nt_live && row_ok && n0 + 16 * t + 4 * g < P.n) oldv[t] = *reinterpret_cast<const lin_u32x2*>(yrow + 16 * t);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (t < nt_live) {                               // uniform
@@ -92,10 +100,9 @@ __global__ void __launch_bounds__(kLinWaves * 64) linear_rows_kernel(LinDev P) {
 #pragma unroll
                 for (int c = 0; c < KC; ++c) acc = Mfma16<T>::run(wf[t][c], xf[c], acc);
                 if (row_ok && col_ok) {
-                    if (P.accumulate) {                      // uniform
-                        const lin_u32x2 old = *reinterpret_cast<const lin_u32x2*>(yrow + 16 * t);
+                    if constexpr (ACCUM) {
                         T o[4];
-                        memcpy(o, &old, 8);
+                        memcpy(o, &oldv[t], 8);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) acc[q] += to_f32(o[q]);
                     }
@@ -132,7 +139,12 @@ static int launch_linear(const LinDev& P, hipStream_t st) {
     if (gx >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;
     const dim3 grid((unsigned)gx, (unsigned)((P.n + nt * 16 - 1) / (nt * 16)));
     const dim3 block(kLinWaves * 64);
-    if (kc <= 2) hipLaunchKernelGGL((linear_rows_kernel<T, 2>), grid, block, 0, st, P);
+    if (P.accumulate) {
+        if (kc <= 2) hipLaunchKernelGGL((linear_rows_kernel<T, 2, true>), grid, block, 0, st, P);
+        else if (kc == 3) hipLaunchKernelGGL((linear_rows_kernel<T, 3, true>), grid, block, 0, st, P);
+        else if (kc == 4) hipLaunchKernelGGL((linear_rows_kernel<T, 4, true>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((linear_rows_kernel<T, 6, true>), grid, block, 0, st, P);
+    } else if (kc <= 2) hipLaunchKernelGGL((linear_rows_kernel<T, 2>), grid, block, 0, st, P);
     else if (kc == 3) hipLaunchKernelGGL((linear_rows_kernel<T, 3>), grid, block, 0, st, P);
     else if (kc == 4) hipLaunchKernelGGL((linear_rows_kernel<T, 4>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((linear_rows_kernel<T, 6>), grid, block, 0, st, P);
