@@ -264,6 +264,16 @@ class ChannelSumArgs(C.Structure):
                 ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p)]
 
 
+def header_abi_version() -> int:
+    """SEGM_ABI_VERSION as include/segmamba_hip.h declares it (what a freshly built library must report)"""
+    import re
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "segmamba_hip.h")
+    m = re.search(r"#define\s+SEGM_ABI_VERSION\s+(\d+)", open(hdr).read())
+    if not m:
+        raise RuntimeError("include/segmamba_hip.h does not define SEGM_ABI_VERSION")
+    return int(m.group(1))
+
+
 class SegmLib:
     """A loaded C-ABI library (the HIP one in production; tests may load the CPU emulation build)."""
 

@@ -387,3 +387,13 @@ def test_conv_table_small_volumes_follow_the_logged_winners():
     assert variants[C3._table_choice("fwd", 128, variants)] == (True, True, False)
     assert variants[C3._table_choice("dgrad", 32, variants)] == (False, False, True)
     assert C3._table_choice("wgrad", 64, [None, None, "mfma"]) == 2
+
+
+def test_graft_entry_build_runs_and_checks_the_header_abi():
+    """`__graft_entry__.build()` is the driver's "does it build" check: it must pass on the tree as it is (round 4 found it
+    comparing the library's ABI number with a stale literal) and take the expected number from include/segmamba_hip.h."""
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
+    from segmamba_amd import lib as L
+    assert L.header_abi_version() == L.SegmLib(L.LIB_PATH).dll.segm_abi_version()
