@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SEGM_ABI_VERSION 6
+#define SEGM_ABI_VERSION 7
 
 enum segm_dtype { SEGM_F32 = 0, SEGM_F16 = 1, SEGM_BF16 = 2 };
 enum segm_time_order { SEGM_TIME_FORWARD = 0, SEGM_TIME_REVERSED = 1, SEGM_TIME_INTERLEAVED = 2 };
@@ -649,6 +649,29 @@ int segm_channel_sum(const segm_channel_sum_args* args);
 /* ------------------------------------------------------------------------------------------------ */
 int segm_abi_version(void);
 const char* segm_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------------
+ * Depth-to-space / space-to-depth by 2 x 2 x 2 (ABI 7).
+ * Replaces the permuting copy behind the GEMM of a ConvTranspose3d with kernel_size = stride = 2 (reference
+ * monai/networks/blocks/unetr_block.py:52-60 via dynunet_block.get_conv_layer) and, in its backward, the inverse gather:
+ *
+ *   direction 0 (depth-to-space)   vol[b, c, 2z+i, 2y+j, 2x+k] = blk[b, c, i, j, k, z, y, x]
+ *   direction 1 (space-to-depth)   blk[b, c, i, j, k, z, y, x] = vol[b, c, 2z+i, 2y+j, 2x+k]
+ *
+ * blk is contiguous (batch, channels, 2, 2, 2, depth, height, width); vol is (batch, channels, 2 depth, 2 height, 2 width) with
+ * element strides vol_stride_b / _c / _z / _y and unit stride along x (padded volumes).  16-bit element types; width % 8 == 0;
+ * 16-byte aligned rows.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_d2s_args {
+    int32_t batch, channels, depth, height, width;      /* of the LOW-resolution block tensor */
+    int32_t dtype, direction, reserved;
+    void* blk;
+    void* vol;
+    int64_t vol_stride_b, vol_stride_c, vol_stride_z, vol_stride_y;
+    void* stream;
+} segm_d2s_args;
+
+int segm_depth_to_space2(const segm_d2s_args* args);
 
 #ifdef __cplusplus
 }

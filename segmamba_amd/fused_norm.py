@@ -167,6 +167,27 @@ def patch_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | Non
     return y.reshape(B, cout, D // k, H // k, W // k)
 
 
+class _DepthToSpace2(torch.autograd.Function):
+    """(B, C * 8, D, H, W) -> (B, C, 2D, 2H, 2W), vol[b, c, 2z+i, 2y+j, 2x+k] = blk[b, c, i, j, k, z, y, x] through
+    segm_depth_to_space2 (16-byte accesses on both sides; ATen's strided copy moved these at ~2 TB/s); the backward is the inverse
+    gather through the same kernel."""
+
+    @staticmethod
+    def forward(ctx, blk):
+        from . import lib as L, ops_raw
+        return ops_raw.depth_to_space2(L.get_lib(), blk)
+
+    @staticmethod
+    def backward(ctx, dvol):
+        from . import lib as L, ops_raw
+        if dvol.stride(4) != 1 or any(s % 8 for s in dvol.stride()[:4]) or dvol.data_ptr() % 16:
+            dvol = dvol.contiguous()
+        return ops_raw.space_to_depth2(L.get_lib(), dvol)
+
+
+_D2S_HIP = os.environ.get("SEGM_D2S_HIP", "1") == "1"
+
+
 def patch_conv_transpose3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, k: int) -> torch.Tensor:
     """ConvTranspose3d with kernel_size == stride == k, no padding (the UNETR up-sampling, unetr_block.py:52-60):
     every input voxel writes its own k^3 output block, so it is one GEMM followed by a depth-to-space permute.
@@ -175,7 +196,11 @@ def patch_conv_transpose3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Te
     B, C, D, H, W = x.shape
     cout = weight.shape[1]
     y = linear.pointwise(x, weight.reshape(C, cout * k ** 3).t())                              # (B, Cout*k^3, D, H, W)
-    y = y.reshape(B, cout, k, k, k, D, H, W).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(B, cout, D * k, H * k, W * k)
+    from . import ops_raw
+    if _D2S_HIP and k == 2 and ops_raw.depth_to_space2_supported(y):
+        y = _DepthToSpace2.apply(y)                                                            # the permute as one library kernel
+    else:
+        y = y.reshape(B, cout, k, k, k, D, H, W).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(B, cout, D * k, H * k, W * k)
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1, 1)
     return y

@@ -228,6 +228,16 @@ class WgradGemmArgs(C.Structure):
     ]
 
 
+class D2sArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("channels", C.c_int32), ("depth", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+        ("dtype", C.c_int32), ("direction", C.c_int32), ("reserved", C.c_int32),
+        ("blk", C.c_void_p), ("vol", C.c_void_p),
+        ("vol_stride_b", C.c_int64), ("vol_stride_c", C.c_int64), ("vol_stride_z", C.c_int64), ("vol_stride_y", C.c_int64),
+        ("stream", C.c_void_p),
+    ]
+
+
 class TransposeArgs(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("dtype", C.c_int32),
@@ -242,7 +252,7 @@ EXPORTS = (
     "segm_selective_scan_fwd_multi", "segm_selective_scan_bwd_multi", "segm_causal_conv1d_fwd_multi", "segm_causal_conv1d_bwd_multi",
     "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
     "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes", "segm_conv3d_k3_fwd",
-    "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add",
+    "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add", "segm_depth_to_space2",
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
     "segm_causal_conv1d_update", "segm_selective_state_update", "segm_linear_rows", "segm_pointwise_cf", "segm_stem_conv_fwd",
@@ -309,6 +319,7 @@ class SegmLib:
         sig("segm_instnorm_bwd", [C.POINTER(InstNormBwdArgs)], C.c_int)
         sig("segm_instnorm_workspace_bytes", [C.c_int32, C.c_int64], C.c_size_t)
         sig("segm_transpose_add", [C.POINTER(TransposeArgs)], C.c_int)
+        sig("segm_depth_to_space2", [C.POINTER(D2sArgs)], C.c_int)
         sig("segm_layernorm_tokens_fwd", [C.POINTER(LayerNormArgs)], C.c_int)
         sig("segm_layernorm_tokens_bwd", [C.POINTER(LayerNormArgs)], C.c_int)
         sig("segm_layernorm_tokens_workspace_bytes", [C.c_int32, C.c_int32, C.c_int64], C.c_size_t)

@@ -591,6 +591,53 @@ def instnorm_bwd(lib: L.SegmLib, x, dy, mean, rstd, y=None, act="none", slope=0.
 
 
 # ---------------------------------------------------------------------------------------------------------
+# depth-to-space / space-to-depth by 2 x 2 x 2 (the permute behind a kernel-2 stride-2 transposed convolution)
+# ---------------------------------------------------------------------------------------------------------
+def _d2s_shape_ok(t: torch.Tensor) -> bool:
+    return t.dtype in (torch.bfloat16, torch.float16) and t.dim() == 5 and t.shape[4] % 8 == 0 and t.shape[1] % 8 == 0 and t.is_contiguous()
+
+
+def depth_to_space2_supported(t: torch.Tensor) -> bool:
+    return L.on_device(t) and _d2s_shape_ok(t)
+
+
+def depth_to_space2(lib: L.SegmLib, blk: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """blk (B, C * 8, D, H, W) contiguous [channel index = ((c * 2 + i) * 2 + j) * 2 + k] -> vol (B, C, 2D, 2H, 2W) with
+    vol[b, c, 2z+i, 2y+j, 2x+k] = blk[b, c, i, j, k, z, y, x]; `out`: a volume with unit x stride (e.g. ops_raw.volume_empty)."""
+    B, C8, D, H, W = blk.shape
+    if not _d2s_shape_ok(blk):
+        raise RuntimeError("depth_to_space2: blk must be a contiguous 16-bit (B, C * 8, D, H, W) tensor with W % 8 == 0")
+    Cc = C8 // 8
+    if out is None:
+        out = torch.empty(B, Cc, 2 * D, 2 * H, 2 * W, dtype=blk.dtype, device=blk.device)
+    _d2s_call(lib, blk, out, 0)
+    return out
+
+
+def space_to_depth2(lib: L.SegmLib, vol: torch.Tensor) -> torch.Tensor:
+    """the inverse gather: vol (B, C, 2D, 2H, 2W), unit x stride -> blk (B, C * 8, D, H, W) contiguous"""
+    B, Cc, D2, H2, W2 = vol.shape
+    if D2 % 2 or H2 % 2 or W2 % 16 or vol.dtype not in (torch.bfloat16, torch.float16) or vol.stride(4) != 1:
+        raise RuntimeError("space_to_depth2: vol must be a 16-bit (B, C, 2D, 2H, 2W) tensor with unit x stride and 2W % 16 == 0")
+    blk = torch.empty(B, Cc * 8, D2 // 2, H2 // 2, W2 // 2, dtype=vol.dtype, device=vol.device)
+    _d2s_call(lib, blk, vol, 1)
+    return blk
+
+
+def _d2s_call(lib, blk, vol, direction):
+    B, C8, D, H, W = blk.shape
+    if tuple(vol.shape) != (B, C8 // 8, 2 * D, 2 * H, 2 * W) or vol.dtype != blk.dtype or vol.stride(4) != 1 or vol.device != blk.device:
+        raise RuntimeError("depth_to_space2: vol must be (B, C, 2D, 2H, 2W) of blk's dtype with unit x stride")
+    a = L.D2sArgs()
+    a.batch, a.channels, a.depth, a.height, a.width = B, C8 // 8, D, H, W
+    a.dtype, a.direction = L.dtype_code(blk), direction
+    a.blk, a.vol = blk.data_ptr(), vol.data_ptr()
+    a.vol_stride_b, a.vol_stride_c, a.vol_stride_z, a.vol_stride_y = vol.stride(0), vol.stride(1), vol.stride(2), vol.stride(3)
+    a.stream = L.stream_handle(blk)
+    lib.check(lib.dll.segm_depth_to_space2(a), "depth_to_space2")
+
+
+# ---------------------------------------------------------------------------------------------------------
 # channel-first <-> channel-last
 # ---------------------------------------------------------------------------------------------------------
 def transpose_add(lib: L.SegmLib, x: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -1090,5 +1137,6 @@ def _device_guard(fn):
 for _name in ("scan_fwd", "scan_bwd", "conv1d_fwd", "conv1d_bwd", "conv3d_k3_wgrad", "conv3d_k3_fwd", "instnorm_fwd",
               "instnorm_bwd", "transpose_add", "layernorm_tokens_fwd", "layernorm_tokens_bwd", "sgd_clip_step", "cross_entropy",
               "conv1d_update", "state_update", "linear_rows", "skinny_tn", "pointwise_cf", "stem_conv_fwd", "stem_conv_wgrad", "wgrad_gemm",
-              "scan_fwd_multi", "scan_bwd_multi", "conv1d_fwd_multi", "conv1d_bwd_multi", "channel_sum"):
+              "scan_fwd_multi", "scan_bwd_multi", "conv1d_fwd_multi", "conv1d_bwd_multi", "channel_sum", "depth_to_space2",
+              "space_to_depth2"):
     globals()[_name] = _device_guard(globals()[_name])

@@ -1591,3 +1591,46 @@ def test_mamba_block_with_dt_proj_inside_the_scan_launch_on_emulated_kernels(emu
     assert close(y1, y0) and close(gx1, gx0)
     for k in gp0:
         assert close(gp1[k], gp0[k]), k
+
+
+@pytest.mark.parametrize("shape,dtype,pad", [((2, 3, 2, 3, 16), torch.bfloat16, 0), ((1, 48, 1, 2, 8), torch.float16, 24), ((1, 2, 3, 1, 40), torch.bfloat16, 8)])
+def test_depth_to_space2_emulated(emu, shape, dtype, pad):
+    """segm_depth_to_space2: vol[b, c, 2z+i, 2y+j, 2x+k] = blk[b, c, i, j, k, z, y, x] and its inverse, bit for bit against the
+    reshape / permute of fused_norm.patch_conv_transpose3d (reference unetr_block.py:52-60 does it inside ConvTranspose3d), into a
+    dense volume and into one with a padded channel stride."""
+    B, Cc, D, H_, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    blk = torch.randn(B, Cc * 8, D, H_, W, generator=g).to(dtype)
+    ref = blk.reshape(B, Cc, 2, 2, 2, D, H_, W).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(B, Cc, 2 * D, 2 * H_, 2 * W)
+    out = None
+    if pad:
+        buf = torch.full((B, Cc, 8 * D * H_ * W + pad), float("nan"), dtype=dtype)
+        out = buf[:, :, :8 * D * H_ * W].view(B, Cc, 2 * D, 2 * H_, 2 * W)
+    vol = ops_raw.depth_to_space2(emu, blk, out=out)
+    assert torch.equal(vol, ref)
+    back = ops_raw.space_to_depth2(emu, vol)
+    assert torch.equal(back, blk)
+    with pytest.raises(RuntimeError):
+        ops_raw.depth_to_space2(emu, blk[..., :W - 4].contiguous())          # W % 8
+
+
+def test_transposed_conv_takes_the_depth_to_space_kernel(emu, monkeypatch):
+    """patch_conv_transpose3d (kernel 2, stride 2) with the permute as the library kernel == the ATen permute path: output and
+    the gradients of input, weight and bias, bit for bit (same GEMMs, same copies of the same values)."""
+    monkeypatch.setattr(L, "_lib", emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    from segmamba_amd import fused_norm as FN
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(1, 16, 2, 2, 8, generator=g).bfloat16()
+    w0 = (0.2 * torch.randn(16, 8, 2, 2, 2, generator=g)).bfloat16()
+    b0 = torch.randn(8, generator=g).bfloat16()
+    dy = torch.randn(1, 8, 4, 4, 16, generator=g).bfloat16()
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(FN, "_D2S_HIP", on)
+        x, w, b = x0.clone().requires_grad_(), w0.clone().requires_grad_(), b0.clone().requires_grad_()
+        y = FN.patch_conv_transpose3d(x, w, b, 2)
+        y.backward(dy)
+        res.append((y.detach(), x.grad, w.grad, b.grad))
+    for a, b_ in zip(*res):
+        assert torch.equal(a, b_)

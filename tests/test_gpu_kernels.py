@@ -818,3 +818,21 @@ def test_thin_input_conv3_matches_conv3d_at_size():
     ref.backward(dy.float())
     dw = ops_raw.stem_conv_wgrad(hip, ops_raw.stem_channel_last4(x), dy, 4, 3)
     assert (dw - wr.grad).abs().max() <= 1e-3 * float(wr.grad.abs().max())
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 48, 64, 64, 64), torch.bfloat16), ((1, 96, 32, 32, 32), torch.float16), ((2, 4, 3, 5, 24), torch.bfloat16)])
+def test_depth_to_space2(hip, shape, dtype):
+    """Round 4: the permute behind a kernel-2 stride-2 transposed convolution (reference unetr_block.py:52-60) and its inverse as
+    one library kernel each - bit for bit against ATen's reshape / permute, at the decoder's two large shapes, into dense volumes
+    and into a volume with a padded channel stride (ops_raw.volume_empty)."""
+    B, Cc, D, Hh, W = shape
+    torch.manual_seed(sum(shape))
+    blk = torch.randn(B, Cc * 8, D, Hh, W, device=DEV).to(dtype)
+    ref = blk.reshape(B, Cc, 2, 2, 2, D, Hh, W).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(B, Cc, 2 * D, 2 * Hh, 2 * W)
+    vol = ops_raw.depth_to_space2(hip, blk)
+    assert torch.equal(vol, ref)
+    padded = ops_raw.volume_empty(B, Cc, (2 * D, 2 * Hh, 2 * W), dtype, torch.device(DEV))
+    ops_raw.depth_to_space2(hip, blk, out=padded)
+    assert torch.equal(padded, ref)
+    assert torch.equal(ops_raw.space_to_depth2(hip, padded), blk)
+    assert torch.equal(ops_raw.space_to_depth2(hip, vol), blk)
