@@ -161,6 +161,11 @@ def patch_conv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | Non
     patches do not overlap, so it is one GEMM on a space-to-depth view.  x (B, C, D, H, W), weight (Cout, C, k, k, k)."""
     B, C, D, H, W = x.shape
     cout = weight.shape[0]
+    from . import lib as L
+    if _D2S_HIP and k == 2 and L.on_device(x) and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 5 and W % 16 == 0 \
+            and D % 2 == 0 and H % 2 == 0 and x.stride(4) == 1 and all(s % 8 == 0 for s in x.stride()[:4]) and x.data_ptr() % 16 == 0:
+        blk = _SpaceToDepth2.apply(x)                                                          # (B, C*8, d, h, w) channel-first, one kernel
+        return linear.pointwise(blk, weight.reshape(cout, C * 8), bias)
     xp = x.reshape(B, C, D // k, k, H // k, k, W // k, k).permute(0, 2, 4, 6, 1, 3, 5, 7)     # (B, d, h, w, C, k, k, k)
     xp = xp.reshape(B, (D // k) * (H // k) * (W // k), C * k ** 3)                             # the one gather copy
     y = linear.pointwise(xp.transpose(1, 2), weight.reshape(cout, C * k ** 3), bias)          # (B, Cout, d*h*w)
@@ -183,6 +188,21 @@ class _DepthToSpace2(torch.autograd.Function):
         if dvol.stride(4) != 1 or any(s % 8 for s in dvol.stride()[:4]) or dvol.data_ptr() % 16:
             dvol = dvol.contiguous()
         return ops_raw.space_to_depth2(L.get_lib(), dvol)
+
+
+class _SpaceToDepth2(torch.autograd.Function):
+    """the inverse: (B, C, 2D, 2H, 2W) -> (B, C * 8, D, H, W) for the kernel-2 stride-2 down-sampling convolutions (reference
+    model_segmamba/segmamba.py:145-150); backward = depth-to-space of the gradient"""
+
+    @staticmethod
+    def forward(ctx, vol):
+        from . import lib as L, ops_raw
+        return ops_raw.space_to_depth2(L.get_lib(), vol)
+
+    @staticmethod
+    def backward(ctx, dblk):
+        from . import lib as L, ops_raw
+        return ops_raw.depth_to_space2(L.get_lib(), dblk.contiguous())
 
 
 _D2S_HIP = os.environ.get("SEGM_D2S_HIP", "1") == "1"

@@ -1634,3 +1634,29 @@ def test_transposed_conv_takes_the_depth_to_space_kernel(emu, monkeypatch):
         res.append((y.detach(), x.grad, w.grad, b.grad))
     for a, b_ in zip(*res):
         assert torch.equal(a, b_)
+
+
+def test_downsampling_conv_takes_the_space_to_depth_kernel(emu, monkeypatch):
+    """patch_conv3d (kernel 2, stride 2: SegMamba's down-sampling convolutions, segmamba.py:145-150) with the gather as the library
+    kernel + a channel-first GEMM == the permute path and == F.conv3d: output and the gradients of input, weight and bias."""
+    monkeypatch.setattr(L, "_lib", emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    from segmamba_amd import fused_norm as FN
+    g = torch.Generator().manual_seed(6)
+    x0 = torch.randn(2, 8, 4, 6, 16, generator=g).bfloat16()
+    w0 = (0.2 * torch.randn(16, 8, 2, 2, 2, generator=g)).bfloat16()
+    b0 = torch.randn(16, generator=g).bfloat16()
+    dy = torch.randn(2, 16, 2, 3, 8, generator=g).bfloat16()
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(FN, "_D2S_HIP", on)
+        x, w, b = x0.clone().requires_grad_(), w0.clone().requires_grad_(), b0.clone().requires_grad_()
+        y = FN.patch_conv3d(x, w, b, 2)
+        y.backward(dy)
+        res.append((y.detach().float(), x.grad.float(), w.grad.float(), b.grad.float()))
+    xr, wr, br = x0.float().requires_grad_(), w0.float().requires_grad_(), b0.float().requires_grad_()
+    yr = torch.nn.functional.conv3d(xr, wr, br, stride=2)
+    yr.backward(dy.float())
+    for got in res:
+        for a, ref in zip(got, (yr.detach(), xr.grad, wr.grad, br.grad)):
+            assert (a - ref).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max()))
