@@ -55,6 +55,7 @@ struct WgradDev {
     int32_t B, D, H, W, cin;
     int32_t nxb, ysplit, rows_per_part, nitems;
     int32_t ncob, ncib;
+    int32_t ipw, nslab;                                   // work items per workgroup (round 5), partial slabs = ceil(nitems / ipw)
 };
 
 // One thread's share of the per-step global -> LDS copy: up to kCopies 16-byte granules.
@@ -65,7 +66,7 @@ struct WgCopy {
 };
 
 template <typename T, int NQ>
-__global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev P) {
+__global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_v1_kernel(WgradDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     constexpr int NCO = kWgCo / 16;
     __shared__ __attribute__((aligned(16))) T xs[4][kWgBlock][kPitch];
@@ -213,6 +214,191 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev
                 }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the same decomposition, the row loop rebuilt around its INSTRUCTION COUNT.  The round-4 counters put the kernel at
+// 2.0 vector + 1.2 scalar instructions per MFMA (profiles/r04_conv_pmc.log) on SIMDs that retire about one instruction per 4.4
+// cycles whatever the occupancy: ~300 instructions per row step for 54 MFMAs, two waves per SIMD - the matrix pipe waits for the
+// instruction stream.  What the v1 loop spent them on, and what replaces it:
+//   * row addresses: three 64-bit row bases per step on the SALU (multiplies, selects, clamps: ~37 instructions) and a 64-bit
+//     per-lane address per load (select between the X and the dY row, v_lshl_add_u64: ~20).  Now every row is a BUFFER load:
+//     the descriptor holds the (batch, plane, channel block) base, the lane a constant 32-bit byte offset computed once per work
+//     item, the row a scalar byte offset (one s_mul per step).  Fetch = one instruction per granule.
+//   * zero padding: v1 selected zeros per dword while parking (4 v_cndmask per granule + a branch per granule, ~45).  Now the
+//     hardware's range check does it: a lane whose granule lies outside the volume (x halo beyond the edge, channel >= cin,
+//     pad granule) carries an offset beyond num_records and reads zeros; a row outside the volume (y = -1, y >= H) is fetched
+//     through the same descriptor with num_records = 0.  Park = one ds_write_b128 per granule, no select, no branch.
+//   * the copy plan: X rounds first (flat granule ids over the 48 x PG slot, so the LDS destination of round k is an immediate
+//     offset from ONE address register), then the dY rounds (same: co advances by 24 per round) - uniform per round, where v1
+//     mixed X and dY granules inside a round (per-lane selects on pointers).
+//   * one workgroup accumulates `ipw` consecutive work items into the same registers before it writes its 27 x 48 x 48 partial
+//     block: the grid is one resident round (512 workgroups at 128^3 instead of 1536), a third of the partial-slab traffic
+//     (382 -> 127 MB written and re-read by the reduce kernel per 48 -> 48 layer) and of the 108-store epilogues.
+// The fragment side (16-byte LDS reads, v_alignbyte for the kx = 0 / 2 operands, 54 MFMAs per step) is v1's.
+// SEGM_WGRAD_V1=1 launches the round-1..4 kernel (A/B).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t wg_rsrc_t;
+constexpr uint32_t kWgNumRec = 0xFFFFF000u;        // bytes a descriptor covers; a lane offset at / beyond it reads zeros
+constexpr uint32_t kWgOob = 0xFFFFF000u;
+
+template <int NQ> struct WgGeo {
+    static constexpr int PG = 4 * NQ + 3;          // granules per LDS row: left halo, 4 NQ data, right halo, one pad (bank spread)
+    static constexpr int PITCH = 8 * PG;           // elements: 88 (44 dwords) / 56 (28 dwords) - 16 fragment lanes hit 16 distinct 4-bank groups
+    static constexpr int XG = 4 * NQ + 2;          // granules fetched per X row
+    static constexpr int DG = 4 * NQ;              // granules per dY row
+    static constexpr int RX = (48 * PG + kWgThreads - 1) / kWgThreads;    // fetch rounds per X row: 3 / 2
+    static constexpr int RD = 48 * DG / kWgThreads;                       // per dY row: 2 / 1
+    static constexpr int XSLOT = RX * kWgThreads * 8;     // elements per ring slot = whole rounds of flat granule ids (tail unused)
+    static constexpr int DSLOT = 48 * PITCH;
+    static constexpr int NR = RX + RD;
+};
+
+template <typename T, int NQ>
+__global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_kernel(WgradDev P) {
+    typedef typename Mfma16<T>::v8 frag8;
+    typedef WgGeo<NQ> G;
+    constexpr int NCO = kWgCo / 16;
+    __shared__ __attribute__((aligned(16))) T xs[4 * G::XSLOT];
+    __shared__ __attribute__((aligned(16))) T dys[2 * G::DSLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ky = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: slot arithmetic stays on the SALU
+    const int i16 = lane & 15, g = lane >> 4;
+    // blockIdx.x runs over (co block, item group, kz) with kz fastest, re-ordered so that every XCD owns a contiguous range (v1)
+    const int vid = xcd_item(blockIdx.x, gridDim.x);
+    const int kz = vid % 3, cib = blockIdx.y;
+    const int grp = (vid / 3) % P.nslab, cob = vid / (3 * P.nslab);
+    constexpr int XB = 32 * NQ;
+
+    f32x4 acc[NCO][3][3];                                 // [co tile][kx][ci tile]
+#pragma unroll
+    for (int a = 0; a < NCO; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) acc[a][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int xrd = i16 * G::PITCH + 8 + 8 * g;           // this lane's X fragment of (ci tile 0, chunk 0) inside a ring slot
+    const int yrd = i16 * G::PITCH + 8 * g;               // its dY fragment of (co tile 0, chunk 0) inside a dY buffer
+    const int dco = tid / G::DG, dgr = tid - dco * G::DG; // dY granule of round 0 (round k: co + k * 192 / DG)
+    const int ddst = dco * G::PITCH + 8 * dgr;
+    const uint32_t x_sy2 = (uint32_t)(P.x_sy * 2), dy_sy2 = (uint32_t)(P.dy_sy * 2);      // row pitch in bytes (host: fits 32 bits)
+
+    for (int it = 0; it < P.ipw; ++it) {
+        const int item_id = grp * P.ipw + it;
+        if (item_id >= P.nitems) break;
+        int item = item_id;
+        const int ypart = item % P.ysplit;  item /= P.ysplit;
+        const int xb = item % P.nxb;        item /= P.nxb;
+        const int z = item % P.D, b = item / P.D;
+        const int zz = z + kz - 1;
+        const int y0 = ypart * P.rows_per_part;
+        const int y1 = (y0 + P.rows_per_part < P.H) ? y0 + P.rows_per_part : P.H;
+        if (zz < 0 || zz >= P.D || y1 <= y0) continue;    // the whole tap plane reads z padding -> contributes zeros
+        const int x0 = xb * XB;
+
+        // ---- copy plan: byte offsets from the descriptor bases, kWgOob = "reads zeros" ------------------------------------
+        uint32_t xv[G::RX], dv[G::RD];
+#pragma unroll
+        for (int k = 0; k < G::RX; ++k) {
+            const int id = tid + k * kWgThreads;
+            const int ci = id / G::PG, gr = id - ci * G::PG;
+            const int xg = x0 - 8 + 8 * gr;               // first x of the granule (W % 8 == 0: all inside or all outside)
+            const bool ok = id < 48 * G::PG && gr < G::XG && xg >= 0 && xg < P.W && cib * kWgBlock + ci < P.cin;
+            xv[k] = ok ? (uint32_t)(((int64_t)ci * P.x_sc + xg) * 2) : kWgOob;
+        }
+#pragma unroll
+        for (int k = 0; k < G::RD; ++k) {
+            const int co = dco + k * (kWgThreads / G::DG);
+            const bool ok = x0 + 8 * dgr < P.W;           // widths below 32: the rest of the k-chunk is zero
+            dv[k] = ok ? (uint32_t)(((int64_t)co * P.dy_sc + x0 + 8 * dgr) * 2) : kWgOob;
+        }
+        const T* xbase = reinterpret_cast<const T*>(P.x) + (int64_t)b * P.x_sb + (int64_t)zz * P.x_sz + (int64_t)cib * kWgBlock * P.x_sc;
+        const T* dbase = reinterpret_cast<const T*>(P.dy) + (int64_t)b * P.dy_sb + (int64_t)z * P.dy_sz + (int64_t)cob * kWgCo * P.dy_sc;
+
+        // X row yy and dY row yd -> registers; a row outside the volume comes back as zeros (num_records = 0), no access
+        auto fetch = [&](u32x4 (&r)[G::NR], int yy, int yd) {
+            const bool x_ok = yy >= 0 && yy < P.H, d_ok = yd < P.H;
+            const wg_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xbase), 0, x_ok ? (int)kWgNumRec : 0, 0x00020000);
+            const wg_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dbase), 0, d_ok ? (int)kWgNumRec : 0, 0x00020000);
+            const uint32_t sx = (uint32_t)(x_ok ? yy : 0) * x_sy2, sd = (uint32_t)(d_ok ? yd : 0) * dy_sy2;
+#pragma unroll
+            for (int k = 0; k < G::RX; ++k) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, xv[k], sx, 0);
+#pragma unroll
+            for (int k = 0; k < G::RD; ++k) r[G::RX + k] = __builtin_amdgcn_raw_buffer_load_b128(rd, dv[k], sd, 0);
+        };
+        auto park = [&](const u32x4 (&r)[G::NR], int slot, int buf) {
+            T* xd = xs + slot * G::XSLOT + tid * 8;
+#pragma unroll
+            for (int k = 0; k < G::RX; ++k) *reinterpret_cast<u32x4*>(xd + k * kWgThreads * 8) = r[k];
+            T* dd = dys + buf * G::DSLOT + ddst;
+#pragma unroll
+            for (int k = 0; k < G::RD; ++k) *reinterpret_cast<u32x4*>(dd + k * (kWgThreads / G::DG) * G::PITCH) = r[G::RX + k];
+        };
+
+        // ---- prologue: rows y0 - 1, y0, y0 + 1 -> slots 0, 1, 2; dY row y0 -> buffer 0 ------------------------------------
+        {
+            u32x4 r[G::NR];
+#pragma unroll
+            for (int d = -1; d <= 1; ++d) {
+                fetch(r, y0 + d, y0);
+                park(r, d + 1, 0);                        // the dY row is parked three times (same data): harmless
+            }
+        }
+        __syncthreads();
+
+        // ---- row loop: step rel = y - y0 reads slot (rel + ky) & 3 and dY buffer rel & 1, parks row y + 2 / dY row y + 1 -------
+        for (int y = y0; y < y1; ++y) {
+            const int rel = y - y0;
+            u32x4 r[G::NR];
+            fetch(r, y + 2, y + 1);                       // in flight during this step's MFMAs
+            SEGM_SCHED_FENCE();
+            const T* xsl = xs + ((rel + ky) & 3) * G::XSLOT + xrd;
+            const T* dyl = dys + (rel & 1) * G::DSLOT + yrd;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                u32x4 av[NCO];
+#pragma unroll
+                for (int co = 0; co < NCO; ++co)
+                    av[co] = *reinterpret_cast<const u32x4*>(dyl + co * 16 * G::PITCH + 32 * q);
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const T* xc = xsl + ci * 16 * G::PITCH + 32 * q;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(xc);
+                    const uint32_t hl = *reinterpret_cast<const uint32_t*>(xc - 2);     // elements (x-2, x-1)
+                    const uint32_t hr = *reinterpret_cast<const uint32_t*>(xc + 8);     // elements (x+8, x+9)
+                    const uint32_t s1 = __builtin_amdgcn_alignbyte(v[1], v[0], 2);
+                    const uint32_t s2 = __builtin_amdgcn_alignbyte(v[2], v[1], 2);
+                    const uint32_t s3 = __builtin_amdgcn_alignbyte(v[3], v[2], 2);
+                    const u32x4 vl = {__builtin_amdgcn_alignbyte(v[0], hl, 2), s1, s2, s3};   // X[x-1 ..]  (kx = 0)
+                    const u32x4 vr = {s1, s2, s3, __builtin_amdgcn_alignbyte(hr, v[3], 2)};   // X[x+1 ..]  (kx = 2)
+#pragma unroll
+                    for (int co = 0; co < NCO; ++co) {
+                        const frag8 a = __builtin_bit_cast(frag8, av[co]);
+                        acc[co][0][ci] = Mfma16<T>::run(a, __builtin_bit_cast(frag8, vl), acc[co][0][ci]);
+                        acc[co][1][ci] = Mfma16<T>::run(a, __builtin_bit_cast(frag8, v), acc[co][1][ci]);
+                        acc[co][2][ci] = Mfma16<T>::run(a, __builtin_bit_cast(frag8, vr), acc[co][2][ci]);
+                    }
+                }
+            }
+            SEGM_SCHED_FENCE();
+            park(r, (rel + 3) & 3, (rel & 1) ^ 1);
+            __syncthreads();
+        }
+    }
+    // partial block: part[((cob * ncib + cib) * nslab + grp)][tap = kz*9 + ky*3 + kx][co (48)][ci (48)]
+    float* out = P.part + ((((int64_t)cob * P.ncib + cib) * P.nslab + grp) * 27) * (kWgCo * kWgBlock);
+#pragma unroll
+    for (int ct = 0; ct < NCO; ++ct)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = ct * 16 + g * 4 + r, cin = ci * 16 + i16;
+                    out[((int64_t)(kz * 9 + ky * 3 + kx) * kWgCo + co) * kWgBlock + cin] = acc[ct][kx][ci][r];
+                }
+}
+
 // dW[co][ci][tap] (contiguous (Cout, Cin, 3, 3, 3)) = sum over slabs of the partial blocks, fixed order:
 // wave w of a workgroup adds slabs w, w + 4, ...; the four partial sums are then added in wave order.
 template <typename T>
@@ -289,18 +475,31 @@ __global__ void __launch_bounds__(512) conv3d_k3_wgrad_reduce4_kernel(const floa
     }
 }
 
-// work decomposition: items = (batch, depth) planes x 64-wide (32 if W % 64) x blocks x y parts
-struct WgPlan { int nq, nxb, ysplit, rows_per_part, nitems; };
+// work decomposition: items = (batch, depth) planes x 64-wide (32 if W % 64) x blocks x y parts; a workgroup of the round-5 kernel
+// accumulates `ipw` consecutive items (one resident round of workgroups: 256 CUs x 2)
+struct WgPlan { int nq, nxb, ysplit, rows_per_part, nitems, ipw, nslab; };
+static bool wgrad_v1() {
+    const char* e = getenv("SEGM_WGRAD_V1");           // read per call (tests switch it): a getenv is nothing next to a launch
+    return e && atoi(e) == 1;
+}
 static WgPlan wgrad_plan(int batch, int cin, int cout, int d, int h, int w) {
     WgPlan p;
     p.nq = (w % 64 == 0) ? 2 : 1;
     p.nxb = (w + 32 * p.nq - 1) / (32 * p.nq);
-    const int64_t wgs = (int64_t)batch * d * p.nxb * 3 * ((cout + kWgCo - 1) / kWgCo) * ((cin + kWgBlock - 1) / kWgBlock);
+    const int64_t blocks = (int64_t)3 * ((cout + kWgCo - 1) / kWgCo) * ((cin + kWgBlock - 1) / kWgBlock);
+    const int64_t wgs = (int64_t)batch * d * p.nxb * blocks;
     int split = 1;                                        // cut y when there are too few workgroups to fill 256 CUs x 3
     while (wgs * split < 1536 && h / (split * 2) >= 8) split *= 2;
     p.ysplit = split;
     p.rows_per_part = (h + split - 1) / split;
     p.nitems = batch * d * p.nxb * split;
+    const char* ipw_s = getenv("SEGM_WGRAD_IPW");
+    const int ipw_env = ipw_s ? atoi(ipw_s) : 0;
+    int64_t ipw = ipw_env > 0 ? ipw_env : ((int64_t)p.nitems * blocks) / 512;      // one round of 512 resident workgroups
+    if (wgrad_v1() || ipw < 1) ipw = 1;
+    if (ipw > p.nitems) ipw = p.nitems;
+    p.ipw = (int)ipw;
+    p.nslab = (p.nitems + p.ipw - 1) / p.ipw;
     return p;
 }
 
@@ -311,7 +510,7 @@ using namespace segm;
 extern "C" size_t segm_conv3d_k3_wgrad_workspace_bytes(int32_t batch, int32_t cin, int32_t cout, int32_t d, int32_t h, int32_t w) {
     if (batch <= 0 || cin <= 0 || cout <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;
     const WgPlan pl = wgrad_plan(batch, cin, cout, d, h, w);
-    return (size_t)((cout + kWgCo - 1) / kWgCo) * ((cin + kWgBlock - 1) / kWgBlock) * pl.nitems * 27 * kWgCo * kWgBlock * sizeof(float);
+    return (size_t)((cout + kWgCo - 1) / kWgCo) * ((cin + kWgBlock - 1) / kWgBlock) * pl.nslab * 27 * kWgCo * kWgBlock * sizeof(float);
 }
 
 extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
@@ -341,10 +540,25 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
     const WgPlan pl = wgrad_plan(a->batch, a->cin, a->cout, a->depth, a->height, a->width);
     P.nxb = pl.nxb; P.ysplit = pl.ysplit; P.rows_per_part = pl.rows_per_part; P.nitems = pl.nitems;
     P.ncob = (a->cout + kWgCo - 1) / kWgCo; P.ncib = (a->cin + kWgBlock - 1) / kWgBlock;
+    P.ipw = pl.ipw; P.nslab = pl.nslab;
     hipStream_t stream = (hipStream_t)a->stream;
+    // the round-5 kernel addresses a (batch, plane, 48-channel block) through 32-bit byte offsets: 48 channel strides and a plane's
+    // rows must stay below the descriptor's 0xFFFFF000 bytes (volumes up to ~350^3 elements per channel); beyond: the v1 kernel
+    const uint64_t lim = kWgNumRec - 4096;
+    const bool fits32 = (uint64_t)a->x_stride_c * 96 + 2 * (uint64_t)a->width < lim && (uint64_t)a->dy_stride_c * 96 + 2 * (uint64_t)a->width < lim &&
+                        (uint64_t)a->x_stride_y * 2 * (uint64_t)a->height < lim && (uint64_t)a->dy_stride_y * 2 * (uint64_t)a->height < lim;
+    if (!fits32 && !wgrad_v1()) return SEGM_E_SHAPE;
     {
-        const dim3 grid(P.nitems * 3 * P.ncob, P.ncib);
-        if (a->dtype == SEGM_F16) {
+        const dim3 grid(P.nslab * 3 * P.ncob, P.ncib);
+        if (wgrad_v1()) {
+            if (a->dtype == SEGM_F16) {
+                if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_v1_kernel<f16_t, 2>), grid, dim3(kWgThreads), 0, stream, P);
+                else hipLaunchKernelGGL((conv3d_k3_wgrad_v1_kernel<f16_t, 1>), grid, dim3(kWgThreads), 0, stream, P);
+            } else {
+                if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_v1_kernel<bf16_t, 2>), grid, dim3(kWgThreads), 0, stream, P);
+                else hipLaunchKernelGGL((conv3d_k3_wgrad_v1_kernel<bf16_t, 1>), grid, dim3(kWgThreads), 0, stream, P);
+            }
+        } else if (a->dtype == SEGM_F16) {
             if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 2>), grid, dim3(kWgThreads), 0, stream, P);
             else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 1>), grid, dim3(kWgThreads), 0, stream, P);
         } else {
@@ -359,21 +573,21 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
     if (a->cin % 4 == 0 && (wide == 1 || (wide < 0 && (int64_t)a->cin * a->cout >= 96 * 96))) {
         const dim3 g4((total / 4 + 63) / 64);
         if (a->dw_dtype == SEGM_F32)
-            hipLaunchKernelGGL((conv3d_k3_wgrad_reduce4_kernel<float>), g4, dim3(512), 0, stream, (const float*)P.part, (float*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
+            hipLaunchKernelGGL((conv3d_k3_wgrad_reduce4_kernel<float>), g4, dim3(512), 0, stream, (const float*)P.part, (float*)a->dw, P.nslab, P.ncib, a->cout, a->cin);
         else if (a->dw_dtype == SEGM_F16)
-            hipLaunchKernelGGL((conv3d_k3_wgrad_reduce4_kernel<f16_t>), g4, dim3(512), 0, stream, (const float*)P.part, (f16_t*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
+            hipLaunchKernelGGL((conv3d_k3_wgrad_reduce4_kernel<f16_t>), g4, dim3(512), 0, stream, (const float*)P.part, (f16_t*)a->dw, P.nslab, P.ncib, a->cout, a->cin);
         else
-            hipLaunchKernelGGL((conv3d_k3_wgrad_reduce4_kernel<bf16_t>), g4, dim3(512), 0, stream, (const float*)P.part, (bf16_t*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
+            hipLaunchKernelGGL((conv3d_k3_wgrad_reduce4_kernel<bf16_t>), g4, dim3(512), 0, stream, (const float*)P.part, (bf16_t*)a->dw, P.nslab, P.ncib, a->cout, a->cin);
         return (int)hipGetLastError();
     }
     if (a->dw_dtype == SEGM_F32)
         hipLaunchKernelGGL((conv3d_k3_wgrad_reduce_kernel<float>), dim3((total + 63) / 64), dim3(256), 0, stream,
-                           (const float*)P.part, (float*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
+                           (const float*)P.part, (float*)a->dw, P.nslab, P.ncib, a->cout, a->cin);
     else if (a->dw_dtype == SEGM_F16)
         hipLaunchKernelGGL((conv3d_k3_wgrad_reduce_kernel<f16_t>), dim3((total + 63) / 64), dim3(256), 0, stream,
-                           (const float*)P.part, (f16_t*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
+                           (const float*)P.part, (f16_t*)a->dw, P.nslab, P.ncib, a->cout, a->cin);
     else
         hipLaunchKernelGGL((conv3d_k3_wgrad_reduce_kernel<bf16_t>), dim3((total + 63) / 64), dim3(256), 0, stream,
-                           (const float*)P.part, (bf16_t*)a->dw, P.nitems, P.ncib, a->cout, a->cin);
+                           (const float*)P.part, (bf16_t*)a->dw, P.nslab, P.ncib, a->cout, a->cin);
     return (int)hipGetLastError();
 }

@@ -197,14 +197,20 @@ static inline hipemu_u32x2 hipemu_permlane32_swap(uint32_t vdst, uint32_t vsrc, 
 #define __builtin_amdgcn_permlane32_swap hipemu_permlane32_swap
 
 // ---- raw buffer resources (scan_fast.h Stream / StageStream): base pointer + lane byte offset + uniform byte offset ------------
-struct hipemu_rsrc { char* base; };
+// Range check as the hardware applies it to a raw buffer (stride 0): the LANE offset (voffset + immediate) is compared with
+// num_records - the scalar offset takes no part in it; a load out of range returns zeros without touching memory, a store is
+// dropped (conv3d_wgrad.hip relies on both: zero padding by offset, whole rows by num_records = 0).
+struct hipemu_rsrc { char* base; uint32_t num_records; };
 typedef hipemu_rsrc __amdgpu_buffer_rsrc_t;
-static inline hipemu_rsrc hipemu_make_rsrc(void* p, short, int, int) { hipemu_rsrc r; r.base = static_cast<char*>(p); return r; }
+static inline hipemu_rsrc hipemu_make_rsrc(void* p, short, int n, int) { hipemu_rsrc r; r.base = static_cast<char*>(p); r.num_records = (uint32_t)n; return r; }
 #define __builtin_amdgcn_make_buffer_rsrc hipemu_make_rsrc
 template <typename V> static inline V hipemu_buf_ld(hipemu_rsrc r, uint32_t voff, uint32_t soff) {
-    V v; memcpy(&v, r.base + (size_t)voff + (size_t)soff, sizeof(V)); return v;
+    V v;
+    if ((uint64_t)voff + sizeof(V) > (uint64_t)r.num_records) { memset(&v, 0, sizeof(V)); return v; }
+    memcpy(&v, r.base + (size_t)voff + (size_t)soff, sizeof(V)); return v;
 }
 template <typename V> static inline void hipemu_buf_st(V v, hipemu_rsrc r, uint32_t voff, uint32_t soff) {
+    if ((uint64_t)voff + sizeof(V) > (uint64_t)r.num_records) return;
     memcpy(r.base + (size_t)voff + (size_t)soff, &v, sizeof(V));
 }
 #define __builtin_amdgcn_raw_buffer_load_b16(r, v, s, aux) hipemu_buf_ld<unsigned short>(r, v, s)

@@ -1660,3 +1660,20 @@ def test_downsampling_conv_takes_the_space_to_depth_kernel(emu, monkeypatch):
     for got in res:
         for a, ref in zip(got, (yr.detach(), xr.grad, wr.grad, br.grad)):
             assert (a - ref).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("ipw", [2, 3, 5])
+def test_conv3d_k3_wgrad_items_per_workgroup_emulated(emu, monkeypatch, ipw):
+    """round 5: a workgroup accumulates `ipw` consecutive work items (batch / depth / x block / y part) before it writes its partial
+    block - forced here on a small volume (the plan picks ipw > 1 only when there are more than 512 workgroups); also the v1 kernel."""
+    g = torch.Generator().manual_seed(31 + ipw)
+    x = torch.randn(2, 48, 3, 4, 128, generator=g).bfloat16()            # nxb = 2, items = 2 * 3 * 2 = 12
+    dy = torch.randn(2, 96, 3, 4, 128, generator=g).bfloat16()
+    ref = _wgrad_reference(x, dy)
+    monkeypatch.setenv("SEGM_WGRAD_IPW", str(ipw))
+    dw = ops_raw.conv3d_k3_wgrad(emu, x, dy, torch.float32)
+    assert (dw - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-4
+    monkeypatch.delenv("SEGM_WGRAD_IPW")
+    monkeypatch.setenv("SEGM_WGRAD_V1", "1")
+    dw1 = ops_raw.conv3d_k3_wgrad(emu, x, dy, torch.float32)
+    assert (dw1 - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-4
