@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SEGM_ABI_VERSION 7
+#define SEGM_ABI_VERSION 8
 
 enum segm_dtype { SEGM_F32 = 0, SEGM_F16 = 1, SEGM_BF16 = 2 };
 enum segm_time_order { SEGM_TIME_FORWARD = 0, SEGM_TIME_REVERSED = 1, SEGM_TIME_INTERLEAVED = 2 };
@@ -412,6 +412,12 @@ typedef struct segm_sgd_args {
     void* workspace;
     size_t workspace_bytes;
     void* stream;
+    /* ABI 8: fp16 autocast with a loss scale (GradScaler, reference light_training/trainer.py:65-67,461-466).  loss_scale: device
+     * pointer to the scale S the gradients carry, or NULL (no scaling).  With it the step is unscale_ -> clip -> step without a pass
+     * over the gradients: norm = |g| / S, update coefficient = clip / S; if |g| is inf / nan the parameters and momenta are left
+     * untouched.  found_inf: device pointer that receives 1.0f (skipped) or 0.0f - the tensor torch._amp_update_scale_ takes - or NULL. */
+    const float* loss_scale;
+    float* found_inf;
 } segm_sgd_args;
 
 int segm_sgd_clip_step(const segm_sgd_args* args);

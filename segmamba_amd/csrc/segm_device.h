@@ -72,9 +72,12 @@ __device__ __forceinline__ int xcd_item(int bid, int nitems) {
 #ifdef SEGM_NO_XCD_MAP
     return bid;
 #else
-    const int per = nitems >> 3;
-    if ((nitems & 7) != 0 || per == 0) return bid;
-    return (bid & 7) * per + (bid >> 3);
+    // any grid size (round 5: a 513-workgroup grid fell through to "no mapping" and lost every L2 hit - profiles/r05_wgrad_pmc.log):
+    // XCD x runs workgroups x, x + 8, ... = per or per + 1 of them; it takes the range that starts at x * per + min(x, rem)
+    const int per = nitems >> 3, rem = nitems & 7;
+    if (per == 0) return bid;
+    const int x = bid & 7, j = bid >> 3;
+    return x * per + (x < rem ? x : rem) + j;
 #endif
 }
 

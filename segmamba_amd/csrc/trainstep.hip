@@ -78,8 +78,13 @@ __global__ void __launch_bounds__(kMtBlock) sgd_norm_kernel(MtArgs A) {
 }
 
 // one workgroup: norm = sqrt(sum of partials), coefficient = min(1, max_norm / (norm + 1e-6))
-// (torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1.0); max_norm <= 0 = no clipping
-__global__ void __launch_bounds__(kMtBlock) sgd_coef_kernel(const float* partial, int n, float max_norm, float* out) {
+// (torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1.0); max_norm <= 0 = no clipping.
+// With a loss scale (fp16 autocast: the gradients are S x the true ones) the step is GradScaler's unscale_ -> clip -> step
+// (reference light_training/trainer.py:461-466) without a pass over the gradients: the true norm is norm / S, the coefficient
+// the update applies to the SCALED gradients is clip / S, and a non-finite norm (an inf / nan anywhere in the gradients) raises
+// found_inf and makes the update kernels return without touching parameters or momenta - what GradScaler.step skips.
+__global__ void __launch_bounds__(kMtBlock) sgd_coef_kernel(const float* partial, int n, float max_norm, float* out,
+                                                            const float* loss_scale, float* found_inf) {
     __shared__ float red[kMtBlock];
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += kMtBlock) s += partial[i];
@@ -90,14 +95,20 @@ __global__ void __launch_bounds__(kMtBlock) sgd_coef_kernel(const float* partial
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const float norm = sqrtf(red[0]);
+        const float raw = sqrtf(red[0]);
+        const float inv = loss_scale ? 1.f / loss_scale[0] : 1.f;
+        const float norm = raw * inv;
         float c = 1.f;
         if (max_norm > 0.f) {
             c = max_norm / (norm + 1e-6f);
             c = c > 1.f ? 1.f : c;           // a NaN norm gives a NaN coefficient, as in torch
         }
-        out[0] = c;
+        const bool bad = loss_scale != nullptr && !(raw <= 3.4028234e38f);      // inf or nan
+        out[0] = c * inv;
         out[1] = norm;
+        out[2] = bad ? 1.f : 0.f;            // the update kernels skip the step (only ever set with a loss scale)
+        out[3] = 0.f;
+        if (found_inf) found_inf[0] = bad ? 1.f : 0.f;
     }
 }
 
@@ -116,6 +127,7 @@ __global__ void __launch_bounds__(kMtBlock) sgd_update_kernel(MtArgs A) {
     const int64_t e0 = (int64_t)(blockIdx.x - A.blk0[ti]) * kMtChunk;
     const int64_t e1 = e0 + kMtChunk < T.n ? e0 + kMtChunk : T.n;
     const float c = A.coef[0];
+    if (A.coef[2] != 0.f) return;                 // inf / nan gradients under a loss scale: the step is skipped (uniform)
     const bool vec = ((reinterpret_cast<uintptr_t>(T.g) | reinterpret_cast<uintptr_t>(T.p) | reinterpret_cast<uintptr_t>(T.m)) & 15) == 0;
     int64_t tail = e0;
     if (vec) {
@@ -283,7 +295,8 @@ extern "C" int segm_sgd_clip_step(const segm_sgd_args* a) {
             part0 += nb;
         }
         if (phase == 0)
-            hipLaunchKernelGGL(sgd_coef_kernel, dim3(1), dim3(kMtBlock), 0, st, partial, (int)blocks, a->max_norm, coef);
+            hipLaunchKernelGGL(sgd_coef_kernel, dim3(1), dim3(kMtBlock), 0, st, partial, (int)blocks, a->max_norm, coef,
+                               a->loss_scale, a->found_inf);
     }
     return (int)hipGetLastError();
 }

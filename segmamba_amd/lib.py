@@ -145,6 +145,7 @@ class SgdArgs(C.Structure):
         ("params", C.c_void_p), ("grads", C.c_void_p), ("momenta", C.c_void_p), ("numel", C.c_void_p),
         ("lr", C.c_float), ("momentum", C.c_float), ("weight_decay", C.c_float), ("max_norm", C.c_float),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+        ("loss_scale", C.c_void_p), ("found_inf", C.c_void_p),
     ]
 
 

@@ -713,9 +713,12 @@ def layernorm_tokens_bwd(lib: L.SegmLib, x, dy, mean, rstd, gamma):
 # training-step glue: gradient clipping + SGD over a tensor list, cross entropy with its gradient
 # ---------------------------------------------------------------------------------------------------------
 def sgd_clip_step(lib: L.SegmLib, params, grads, momenta, lr: float, momentum: float, weight_decay: float,
-                  nesterov: bool, max_norm: float) -> torch.Tensor:
+                  nesterov: bool, max_norm: float, loss_scale: Optional[torch.Tensor] = None,
+                  found_inf: Optional[torch.Tensor] = None) -> torch.Tensor:
     """In place: clip_grad_norm_(max_norm) + SGD step over lists of contiguous fp32 tensors (params / momenta updated,
-    grads only read).  Returns the 4-float workspace head {clip coefficient, gradient norm, -, -} (device tensor)."""
+    grads only read).  Returns the 4-float workspace head {update coefficient, gradient norm, skipped, -} (device tensor).
+    loss_scale (1-element fp32 device tensor): the gradients carry that factor (GradScaler) - the norm and the clip are those of
+    the unscaled gradients, and a non-finite norm skips the step and writes 1 to `found_inf` (1-element fp32), else 0."""
     n = len(params)
     if not (len(grads) == len(momenta) == n):
         raise RuntimeError("sgd_clip_step: params, grads and momenta must have the same length")
@@ -736,6 +739,11 @@ def sgd_clip_step(lib: L.SegmLib, params, grads, momenta, lr: float, momentum: f
     a.lr, a.momentum, a.weight_decay, a.max_norm = lr, momentum, weight_decay, max_norm
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
     a.stream = L.stream_handle(params[0])
+    for t in (loss_scale, found_inf):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != 1 or t.device != params[0].device):
+            raise RuntimeError("sgd_clip_step: loss_scale / found_inf must be 1-element fp32 tensors on the parameters' device")
+    a.loss_scale = loss_scale.data_ptr() if loss_scale is not None else None
+    a.found_inf = found_inf.data_ptr() if found_inf is not None else None
     lib.check(lib.dll.segm_sgd_clip_step(a), "sgd_clip_step")
     return ws[:4]
 

@@ -68,6 +68,20 @@ class FusedClipSGD(torch.optim.Optimizer):
         self.last_clip = None                 # device tensor {clip coefficient, gradient norm, -, -} of the last step
         self.bank = None                      # param_bank.ParamBank with flat gradients attached: see use_flat()
         self._flat_mom = None
+        # fp16 autocast (the reference's GradScaler loop, light_training/trainer.py:461-466) without passes over the gradients:
+        # `loss_scale` = the 1-element fp32 tensor holding the factor the gradients carry (GradScaler's own scale tensor); step()
+        # then clips by the norm of the UNSCALED gradients, updates with clip / scale, and skips the whole step - parameters and
+        # momenta untouched, 1 written to `found_inf` - when a gradient is inf / nan (what unscale_ + scaler.step do)
+        self.loss_scale = None
+        self.found_inf = None
+
+    def use_loss_scale(self, scale: torch.Tensor) -> torch.Tensor:
+        """-> found_inf (1-element fp32, rewritten by every step()): the tensor torch._amp_update_scale_ takes"""
+        if scale.dtype != torch.float32 or scale.numel() != 1:
+            raise RuntimeError("FusedClipSGD.use_loss_scale: a 1-element fp32 tensor (GradScaler's scale) is required")
+        self.loss_scale = scale
+        self.found_inf = torch.zeros(1, dtype=torch.float32, device=scale.device)
+        return self.found_inf
 
     def use_flat(self, bank) -> None:
         """Step over the bank's three flat arrays (parameters, gradients, momenta) - ONE tensor per launch instead of a table of
@@ -115,7 +129,8 @@ class FusedClipSGD(torch.optim.Optimizer):
                 gr = self.param_groups[0]
                 self.last_clip = ops_raw.sgd_clip_step(L.get_lib(), [self.bank.flat32], [self.bank.flat_grad], [self._flat_mom],
                                                        gr["lr"], gr["momentum"], gr["weight_decay"], gr["nesterov"],
-                                                       float(self.max_norm) if self.max_norm else 0.0)
+                                                       float(self.max_norm) if self.max_norm else 0.0,
+                                                       loss_scale=self.loss_scale, found_inf=self.found_inf)
                 return loss
         groups = []
         for gr in self.param_groups:
@@ -140,20 +155,29 @@ class FusedClipSGD(torch.optim.Optimizer):
         from . import lib as L, ops_raw
         hip = L.get_lib()
         same = len({(g["lr"], g["momentum"], g["weight_decay"], g["nesterov"]) for g, _ in groups}) == 1
-        if not same and max_norm > 0:
-            raise RuntimeError("FusedClipSGD: clipping needs one set of hyper-parameters over all groups")
+        if not same and (max_norm > 0 or self.loss_scale is not None):
+            raise RuntimeError("FusedClipSGD: clipping / loss scaling need one set of hyper-parameters over all groups")
         for gr, ps in ([(groups[0][0], allp)] if same else groups):
             if not ps:
                 continue
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
             self.last_clip = ops_raw.sgd_clip_step(hip, [p.data for p in ps], grads, [self.state[p]["momentum_buffer"] for p in ps],
-                                                   gr["lr"], gr["momentum"], gr["weight_decay"], gr["nesterov"], max_norm)
+                                                   gr["lr"], gr["momentum"], gr["weight_decay"], gr["nesterov"], max_norm,
+                                                   loss_scale=self.loss_scale, found_inf=self.found_inf)
 
     def _step_aten(self, groups, allp, max_norm):
         coef = 1.0
-        if max_norm > 0:
-            norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.grad) for p in allp]))
-            coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        inv = 1.0 if self.loss_scale is None else 1.0 / self.loss_scale
+        if max_norm > 0 or self.loss_scale is not None:
+            raw = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.grad) for p in allp]))
+            if self.loss_scale is not None:
+                bad = not bool(torch.isfinite(raw))
+                self.found_inf.fill_(1.0 if bad else 0.0)
+                if bad:
+                    return
+            if max_norm > 0:
+                coef = torch.clamp(max_norm / (raw * inv + 1e-6), max=1.0)
+        coef = coef * inv
         for gr, ps in groups:
             for p in ps:
                 g = p.grad * coef + gr["weight_decay"] * p

@@ -83,6 +83,7 @@ class TrainingState:
     world: int = 1                 # ranks averaging their gradients through ONE all-reduce of the flat array (ddp="flat")
     graphed: object = None         # GraphedStep once the forward + backward bracket has been captured
     exchange: object = None        # SegmentedExchange: the flat all-reduce in segments overlapped with the backward pass
+    found_inf: object = None       # flat fp16 mode: 1-element tensor the fused step writes (1 = inf / nan gradients, step skipped)
 
 
 def build_training_state(device, distributed: bool = False, local_rank: int = 0, max_steps: int = 250 * 1000,
@@ -113,7 +114,7 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
     fused_ok = L.on_device(next(model.parameters())) and os.environ.get("SEGM_FUSED_TRAIN_OPS", "1") != "0"
     if flat is None:
         flat = os.environ.get("SEGM_FLAT_GRADS", "1") == "1"
-    flat = bool(flat and bank is not None and fused_ok and amp == "bf16")
+    flat = bool(flat and bank is not None and fused_ok)
     world = 1
     if distributed and flat and ddp == "flat":
         import torch.distributed as dist
@@ -154,6 +155,12 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
     if amp == "fp16":
         st.autocast_dtype = torch.float16
         st.scaler = torch.amp.GradScaler(device.type)     # the reference's GradScaler() defaults: 2^16, x2 / 2000 steps, x0.5 on inf
+        if st.flat:
+            # flat mode keeps the GradScaler as the holder of the scale / growth-tracker tensors; unscale_, the inf check and the
+            # skipped step happen inside the fused clip + SGD pass (FusedClipSGD.use_loss_scale), the scale update is the same
+            # device-side op scaler.update() runs.  Nothing in the step reads the scale on the host: the bracket stays capturable.
+            st.scaler._lazy_init_scale_growth_tracker(device)
+            st.found_inf = opt.use_loss_scale(st.scaler._scale)
     return st
 
 
@@ -279,10 +286,14 @@ def forward_backward(st: TrainingState, image: torch.Tensor, label: torch.Tensor
         st.bank.release_grads()                                    # trainer.py:445 sets every p.grad to None
         if overlapped:
             st.exchange.arm()
-        with torch.autocast(image.device.type, dtype=st.autocast_dtype, enabled=image.device.type == "cuda"):
+        with torch.autocast(image.device.type, dtype=st.autocast_dtype,
+                            enabled=image.device.type == "cuda" or st.scaler is not None):
             pred = st.model(image)
             loss = st.loss_fn(pred, label)                         # 3_train.py:62
-        (loss / st.world if st.world > 1 else loss).backward()
+        out = loss / st.world if st.world > 1 else loss
+        if st.scaler is not None:
+            out = out * st.scaler._scale                               # GradScaler.scale(loss): a device-side multiply
+        out.backward()
         if not overlapped:
             st.bank.gather_grads()                                 # the fresh gradient tensors -> the flat array, one launch
     return loss.detach()
@@ -295,7 +306,11 @@ def finish_step(st: TrainingState) -> None:
     elif st.world > 1:
         import torch.distributed as dist
         dist.all_reduce(st.bank.flat_grad)                          # 269.7 MB fp32 over xGMI, one collective
-    st.optimizer.step()
+    st.optimizer.step()                                             # fp16: unscale + inf check + skip inside (train_ops.FusedClipSGD)
+    if st.scaler is not None:
+        sc = st.scaler                                              # what GradScaler.update() does, with the fused step's found_inf
+        torch._amp_update_scale_(sc._scale, sc._growth_tracker, st.found_inf, sc.get_growth_factor(), sc.get_backoff_factor(),
+                                 sc.get_growth_interval())
     st.scheduler.step()
     st.step += 1
 

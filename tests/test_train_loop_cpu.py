@@ -274,3 +274,45 @@ def test_derived_weight_packs_come_from_one_gather_and_change_nothing(monkeypatc
     assert counts_off == [0, 0, 0]
     for a, b in zip(on.model.parameters(), off.model.parameters()):
         assert torch.equal(a, b)
+
+
+def test_fp16_flat_mode_folds_unscale_and_inf_check_into_the_fused_step(monkeypatch):
+    """round 5: amp='fp16' on the flat-gradient state.  The loss scale stays a device tensor (GradScaler's own),
+    the fused clip + SGD pass divides the norm by it, applies clip / scale to the scaled gradients and skips the step on inf / nan;
+    the scale update is the op GradScaler.update() runs.  Same parameters as the per-tensor GradScaler route (unscale_ -> clip ->
+    scaler.step -> update, reference light_training/trainer.py:461-466) - the scale is a power of two, so bit for bit."""
+    from tests import emu_util
+    import pytest
+    if not emu_util.emu_available():
+        pytest.skip("no host clang for the emulation build")
+    from segmamba_amd import lib as L
+    monkeypatch.setattr(L, "_lib", emu_util.emu_lib())
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    g = torch.Generator().manual_seed(1)
+    img, lab = torch.rand(1, 4, 8, 8, 8, generator=g), torch.randint(0, 4, (1, 8, 8, 8), generator=g)
+    a = build_training_state(torch.device("cpu"), model=_tiny(), amp="fp16", flat=True)
+    b = build_training_state(torch.device("cpu"), model=_tiny(), amp="fp16", flat=False)
+    assert a.flat and a.scaler is not None and a.optimizer.loss_scale is a.scaler._scale and not b.flat
+    for _ in range(2):
+        la, lb = train_step(a, img, lab), train_step(b, img, lab)
+        assert torch.equal(la, lb)
+    for pa, pb in zip(a.model.parameters(), b.model.parameters()):
+        assert torch.equal(pa, pb)
+        assert torch.equal(a.optimizer.state[pa]["momentum_buffer"], b.optimizer.state[pb]["momentum_buffer"])
+    assert float(a.found_inf) == 0.0 and a.scaler.get_scale() == b.scaler.get_scale() == 65536.0
+    assert float(a.optimizer.last_clip[1]) == pytest.approx(float(torch.linalg.vector_norm(a.bank.flat_grad)) / 65536.0, rel=1e-5)
+    # an overflowing step: parameters and momenta untouched, found_inf raised, scale halved - in both routes
+    before = [p.detach().clone() for p in a.model.parameters()]
+    mom = [a.optimizer.state[p]["momentum_buffer"].clone() for p in a.model.parameters()]
+    bad = img.clone()
+    bad[0, 0, 0, 0, 0] = float("inf")
+    train_step(a, bad, lab), train_step(b, bad, lab)
+    assert float(a.found_inf) == 1.0
+    assert all(torch.equal(x, p.detach()) for x, p in zip(before, a.model.parameters()))
+    assert all(torch.equal(x, a.optimizer.state[p]["momentum_buffer"]) for x, p in zip(mom, a.model.parameters()))
+    assert a.scaler.get_scale() == b.scaler.get_scale() == 32768.0
+    # and it goes on from there
+    la, lb = train_step(a, img, lab), train_step(b, img, lab)
+    assert torch.equal(la, lb) and float(a.found_inf) == 0.0
+    for pa, pb in zip(a.model.parameters(), b.model.parameters()):
+        assert torch.equal(pa, pb)
