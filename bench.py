@@ -69,13 +69,14 @@ def scan_traffic(dtype_name):
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=8)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=20)   # defaults = the command the driver runs
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--size", type=int, default=128, help="edge of the cubic volume (128 = the BASELINE config)")
     p.add_argument("--batch", type=int, default=2, help="volumes per GPU")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-configs", action="store_true", help="skip the BASELINE config 1 / config 4 measurements")
+    p.add_argument("--no-dropin", action="store_true", help="skip the drop-in (reference loop, fp16 + GradScaler, eager) and fp16 flat-mode steps")
     p.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a captured HIP graph")
     p.add_argument("--cpu-baseline-full", action="store_true", help="add the whole-network 64^3 / 32^3 fwd+bwd CPU legs (~80 s)")
     p.add_argument("--cpu-dry-run", action="store_true",
@@ -180,11 +181,29 @@ def scan_roofline(dtype, device):
     elems_per_simd = B * D * Lq / 64 / 1024                    # wave-steps per SIMD (256 CUs x 4 SIMDs)
     cyc_taken = ms_f * 1e-3 * 2.1e9 / elems_per_simd
     cyc_taken3 = ms_f3 * 1e-3 * 2.1e9 / (3 * elems_per_simd)
+    # Round 5: the floor expressed as an HBM fraction - what `frac` could reach if the launch issued nothing but
+    # the floor stream: algorithmic bytes / (wave-steps per SIMD x floor cycles / 2.1 GHz) against 8 TB/s.  ~0.30 with 16-bit I/O,
+    # ~0.60 with fp32 I/O: BASELINE.json's ">= 0.60 of the HBM roofline" is out of reach of ANY exact two-pass scan at N = 16 in
+    # bf16 on this issue rate; it is within reach of the fp32-I/O launch only.
+    ceiling = bytes_f / (elems_per_simd * cyc_floor / 2.1e9) * 1e-9 / HBM_PEAK_GBPS
+    # the backward's own floor, built the same way (per wave-step = one time step of 64 channels x 16 states, both passes):
+    #   transcendental: 32 v_exp (a = exp(delta A) in the reverse-aggregate and the main pass) + 6 (softplus, its derivative's sigmoid,
+    #                   the gate's sigmoid - recomputed, not stored) = 38 x 9 cycles
+    #   packed fp32 per state pair: aggregate 3; main: h recompute 1, dh 1, du 1, (h - b) 1, dh (h - b) 1, ddelta 2, dA 1, dB / dC
+    #                   products 2 + their share of the d-tile reduce-scatter ~4 = 15  ->  8 x 18 = 144 x 4.4 cycles
+    #   row streams: 7 loads + converts (u, delta, z, out, dout, B, C), 5 stores (du, ddelta, dz, dB, dC) ~ 14 x 4.4 cycles
+    cyc_floor_b = round(38 * 9.0 + 144 * 4.4 + 14 * 4.4)
+    cyc_taken_b = ms_b * 1e-3 * 2.1e9 / elems_per_simd
+    cyc_taken_b3 = ms_b3 * 1e-3 * 2.1e9 / (3 * elems_per_simd)
+    ceiling_b = bytes_b / (elems_per_simd * cyc_floor_b / 2.1e9) * 1e-9 / HBM_PEAK_GBPS
     return {
         "bound": "valu", "priced_against": "hbm", "kernel": "selective_scan_fwd (scan_fwd_agg + scan_carry + scan_fwd_apply)",
         "shape": {"B": B, "D": D, "N": N, "L": Lq, "layout": "channel-last", "chunk": f["chunk"]},
         "achieved": round(gf, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gf / HBM_PEAK_GBPS, 4),
         "ms": round(ms_f, 4), "algorithmic_bytes": bytes_f,
+        "ceiling": {"frac": round(ceiling, 4), "what": "the instruction-issue floor of the two-pass algorithm (valu.floor) expressed as a "
+                    "fraction of the 8 TB/s HBM roofline at this I/O width: the most `frac` can reach; the target >= 0.60 needs fp32 I/O",
+                    "frac_of_ceiling": round(gf / HBM_PEAK_GBPS / ceiling, 4)},
         "traffic": tr["bytes"] if tr else None, "traffic_source": tr,
         "valu": {"bound": "instruction issue",
                  "floor": {"cycles_per_wave_step": cyc_floor, "frac": round(cyc_floor / cyc_taken, 4),
@@ -204,6 +223,11 @@ def scan_roofline(dtype, device):
                 "same launch against the issue bound of the shipped instruction stream",
         "backward": {"achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4), "ms": round(ms_b, 4),
                      "algorithmic_bytes": bytes_b,
+                     "floor": {"cycles_per_wave_step": cyc_floor_b, "frac": round(cyc_floor_b / cyc_taken_b, 4),
+                               "frac_three_directions_per_launch": round(cyc_floor_b / cyc_taken_b3, 4),
+                               "ceiling_frac_of_hbm": round(ceiling_b, 4),
+                               "what": "38 transcendentals (32 v_exp over the two passes + softplus / gate), 144 packed fp32 (18 per state "
+                                       "pair: 3 aggregate + 11 main + ~4 reduce-scatter share), ~14 row-stream instructions"},
                      "main_kernel": {"file": "csrc/scan_bwd_w8.hip", "instructions_per_step": 290,
                                      "per_state_pair_and_8_steps": {"vector": 152, "transcendental": 16, "lds": 13, "other": 23},
                                      "round_3": {"file": "scan_bwd_pair.hip (removed)", "instructions_per_step": 510, "ms": 0.915},
@@ -309,6 +333,102 @@ def inference_rate(state, device, size):
     model.train(was_training)
     return {"cases_per_s": round(1e3 / ms, 2), "ms_per_case": round(ms, 3), "input": [1, 4, size, size, size],
             "published_reference": {"cases_per_s": 1.51, "hardware": "not stated (reference README table 5)"}}
+
+
+def gpu_state(local_rank=0):
+    """Clock / power state of this rank's GPU from rocm-smi (before and after the timed loop: a box whose clock sags under the
+    power cap explains a slower line - VERDICT r04 item 2).  Never raises: {} when rocm-smi is missing or its output changes."""
+    import re
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    out = {}
+    try:
+        r = subprocess.run([exe, "-d", str(local_rank), "--showclocks", "--showpower", "--showtemp", "--showperflevel"],
+                           capture_output=True, text=True, timeout=20)
+        txt = r.stdout
+        m = re.search(r"sclk clock level:\s*\w+:?\s*\((\d+)\s*Mhz\)", txt, re.I)
+        if m:
+            out["sclk_mhz"] = int(m.group(1))
+        m = re.search(r"mclk clock level:\s*\w+:?\s*\((\d+)\s*Mhz\)", txt, re.I)
+        if m:
+            out["mclk_mhz"] = int(m.group(1))
+        m = re.search(r"(?:Average|Current Socket) Graphics Package Power \(W\):\s*([\d.]+)", txt, re.I)
+        if m:
+            out["power_w"] = float(m.group(1))
+        m = re.search(r"Temperature \(Sensor (?:junction|edge)\) \(C\):\s*([\d.]+)", txt, re.I)
+        if m:
+            out["temp_c"] = float(m.group(1))
+        m = re.search(r"Performance Level:\s*(\w+)", txt, re.I)
+        if m:
+            out["perf_level"] = m.group(1)
+    except Exception as e:                                  # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {str(e)[:80]}"
+    return out
+
+
+def dropin_step(device, size, batch, steps, warmup):
+    """The loop the reference's 3_train.py actually runs, on the drop-in modules and nothing else of this repository's harness
+    (VERDICT r04 item 3): `from model_segmamba.segmamba import SegMamba`, torch.autocast("cuda") = fp16, GradScaler,
+    torch.optim.SGD(lr 1e-2, wd 3e-5, momentum .99, nesterov), nn.CrossEntropyLoss, clip_grad_norm_(12) - eager launches, no
+    parameter bank, no flat gradients, no fused optimizer, no graph (light_training/trainer.py:65-67, 445-466; 3_train.py:46-62).
+    Then the same arithmetic on this repository's flat-gradient state in fp16 (amp="fp16": unscale + inf check inside the fused clip +
+    SGD pass), eager and as a graph replay."""
+    import torch.nn as nn
+    from model_segmamba.segmamba import SegMamba
+    from segmamba_amd.trainer import GraphedStep, SyntheticBraTS, build_training_state, train_step
+    out = {}
+    data = SyntheticBraTS(batch, size, device, seed=42)
+
+    def timed(step_fn):
+        for _ in range(warmup):
+            step_fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step_fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, float(loss)
+
+    torch.manual_seed(0)
+    model = SegMamba(in_chans=4, out_chans=4, depths=[2, 2, 2, 2], feat_size=[48, 96, 192, 384]).to(device)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    scaler = torch.amp.GradScaler("cuda")
+    ce = nn.CrossEntropyLoss()
+
+    def reference_body():
+        image, label = data.next()
+        for p in model.parameters():
+            p.grad = None
+        with torch.autocast("cuda", enabled=True):
+            loss = ce(model(image), label)
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 12)
+        scaler.step(opt)
+        scaler.update()
+        return loss.detach()
+    ms, loss = timed(reference_body)
+    out["reference_loop"] = {"what": "model_segmamba.segmamba.SegMamba + torch.autocast('cuda') [fp16] + GradScaler + torch.optim.SGD + "
+                                     "clip_grad_norm_(12) + nn.CrossEntropyLoss, eager, no bank / flat / fused optimizer / graph",
+                             "ms_per_step": round(ms, 3), "volumes_per_s": round(batch / ms * 1e3, 3), "loss": round(loss, 5),
+                             "loss_scale": scaler.get_scale()}
+    del model, opt, scaler
+    torch.cuda.empty_cache()
+    for key, graph in (("fp16_flat_eager", False), ("fp16_flat_graph", True)):
+        try:
+            st = build_training_state(device, amp="fp16")
+            if graph:
+                GraphedStep(st, *data.next())
+            ms, loss = timed(lambda: train_step(st, *data.next()))
+            out[key] = {"ms_per_step": round(ms, 3), "volumes_per_s": round(batch / ms * 1e3, 3), "loss": round(loss, 5),
+                        "flat_gradients": st.flat, "loss_scale": st.scaler.get_scale(), "skipped_last_step": bool(float(st.found_inf))
+                        if st.found_inf is not None else None}
+            del st
+        except Exception as e:                              # noqa: BLE001 - a side measurement must not take the line with it
+            out[key] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(full=False):
@@ -451,13 +571,24 @@ def main():
             torch.cuda.synchronize()
             graph_note = f"capture failed, eager launches: {type(e).__name__}: {str(e)[:200]}"
     elif not state.flat:
-        graph_note = "off (no flat-gradient state: torch DDP wrapper, fp16 GradScaler loop or CPU dry run)"
+        graph_note = "off (no flat-gradient state: torch DDP wrapper or CPU dry run)"
 
     for _ in range(args.warmup):
         step()
     if distributed:
         dist.barrier()
     sync()
+    state_before = gpu_state(local_rank) if (rank == 0 and not dry) else {}
+    state_during = {}
+    sampler = None
+    if rank == 0 and not dry:                              # one rocm-smi reading WHILE the timed steps run (the GPU idles down within
+        import threading                                   # milliseconds of the final synchronize): a thread, the host loop only replays a graph
+
+        def _sample():
+            time.sleep(0.25)
+            state_during.update(gpu_state(local_rank))
+        sampler = threading.Thread(target=_sample, daemon=True)
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -465,6 +596,9 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.join(timeout=30)
+    state_after = gpu_state(local_rank) if (rank == 0 and not dry) else {}
     rank_ms = [elapsed / args.steps * 1e3]
     allreduce_ms = exposed_ms = other_form = None
     overlapped = state.exchange is not None and not state.exchange.suspended      # the form the timed region ran
@@ -535,7 +669,10 @@ def main():
                        # host-side arrangements that do not change the arithmetic: the step's 16-bit parameter copies in one launch
                        # (param_bank.py), 128^3 volumes with a padded channel stride (ops_raw.volume_empty)
                        "param_bank": state.bank is not None, "volume_pad": os.environ.get("SEGM_VOLUME_PAD", "1") == "1",
-                       "flat_gradients": state.flat, "launch": graph_note},
+                       "flat_gradients": state.flat, "launch": graph_note,
+                       "command": "python bench.py --gpus %d --steps %d --warmup %d" % (world, args.steps, args.warmup),
+                       "gpu_state": {"before_timed_loop": state_before, "during_timed_loop": state_during, "after_timed_loop": state_after,
+                                     "source": "rocm-smi --showclocks --showpower --showtemp --showperflevel, rank 0's GPU"}},
         }
         if not args.no_roofline and not dry:
             out["inference"] = inference_rate(state, device, args.size)
@@ -544,6 +681,12 @@ def main():
             if not args.no_configs and world == 1:
                 del state, data
                 torch.cuda.empty_cache()
+                if not args.no_dropin:
+                    try:
+                        out["dropin_step"] = dropin_step(device, args.size, args.batch, min(args.steps, 10), min(args.warmup, 3))
+                    except Exception as e:                  # noqa: BLE001
+                        out["dropin_step"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+                    torch.cuda.empty_cache()
                 for key, fn in (("config1", config1_mamba_block), ("config4", config4_long_scan)):
                     try:
                         out[key] = fn(device)

@@ -215,26 +215,39 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_v1_kernel(Wgrad
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 5: the same decomposition, the row loop rebuilt around its INSTRUCTION COUNT.  The round-4 counters put the kernel at
-// 2.0 vector + 1.2 scalar instructions per MFMA (profiles/r04_conv_pmc.log) on SIMDs that retire about one instruction per 4.4
-// cycles whatever the occupancy: ~300 instructions per row step for 54 MFMAs, two waves per SIMD - the matrix pipe waits for the
-// instruction stream.  What the v1 loop spent them on, and what replaces it:
-//   * row addresses: three 64-bit row bases per step on the SALU (multiplies, selects, clamps: ~37 instructions) and a 64-bit
-//     per-lane address per load (select between the X and the dY row, v_lshl_add_u64: ~20).  Now every row is a BUFFER load:
-//     the descriptor holds the (batch, plane, channel block) base, the lane a constant 32-bit byte offset computed once per work
-//     item, the row a scalar byte offset (one s_mul per step).  Fetch = one instruction per granule.
-//   * zero padding: v1 selected zeros per dword while parking (4 v_cndmask per granule + a branch per granule, ~45).  Now the
-//     hardware's range check does it: a lane whose granule lies outside the volume (x halo beyond the edge, channel >= cin,
-//     pad granule) carries an offset beyond num_records and reads zeros; a row outside the volume (y = -1, y >= H) is fetched
-//     through the same descriptor with num_records = 0.  Park = one ds_write_b128 per granule, no select, no branch.
-//   * the copy plan: X rounds first (flat granule ids over the 48 x PG slot, so the LDS destination of round k is an immediate
-//     offset from ONE address register), then the dY rounds (same: co advances by 24 per round) - uniform per round, where v1
-//     mixed X and dY granules inside a round (per-lane selects on pointers).
-//   * one workgroup accumulates `ipw` consecutive work items into the same registers before it writes its 27 x 48 x 48 partial
-//     block: the grid is one resident round (512 workgroups at 128^3 instead of 1536), a third of the partial-slab traffic
-//     (382 -> 127 MB written and re-read by the reduce kernel per 48 -> 48 layer) and of the 108-store epilogues.
-// The fragment side (16-byte LDS reads, v_alignbyte for the kx = 0 / 2 operands, 54 MFMAs per step) is v1's.
-// SEGM_WGRAD_V1=1 launches the round-1..4 kernel (A/B).
+// Round 5: conv3d_k3_wgrad_kernel - the shipped kernel.  Same problem decomposition as v1 above (one tap plane kz, one 48 x 48
+// channel block, one (batch, depth, x block, y range) work item per workgroup of three waves that walks y with the X rows and the
+// dY row staged in LDS), a different row loop.  Three designs were built and measured on the way (the sources are kept as text in
+// tools/experiments/conv3d_wgrad_r5_variants.hip.txt, the numbers in profiles/r05_wgrad_abl*.log, r05_wgrad_pmc*.log):
+//   1. v1's loop by INSTRUCTION COUNT (~300 -> ~180 per row step: buffer loads whose range check does the zero padding, uniform copy
+//      rounds, scalar row offsets): 0.686 -> 0.57 ms at 48 -> 48 @128^3.  Its ablations showed no single bound - without the row
+//      fetch, without the MFMAs or without the fragment reads a launch still took 0.48 - 0.50 of 0.57 ms, a third workgroup per CU
+//      gained 13 - 22 % - i.e. every wave sits through a serial chain per step: barrier -> fragment reads -> MFMAs -> park -> barrier.
+//   2. the same loop software-pipelined ACROSS the barrier (rows parked at the top of the step after their fetch, the next step's
+//      first fragments read before the barrier): 0.52 - 0.55 ms; parked-wave time halves (WAIT_ANY 0.32 -> 0.18 of the wave
+//      cycles) but the LDS pipe stays 55 % busy, half of it BANK CONFLICTS - the two halo dwords of every X fragment are 4-way
+//      conflicts no row pitch can avoid (all 32 lanes of a ds_read_b32 group address dword 3, or dword 0, of a granule).
+//   3. ONE WAVE = ONE ci TILE, all three ky (this kernel): with ky = wave (v1) every X row is read from LDS by three waves, on
+//      three consecutive steps, and shifted three times.  Here wave w owns ci tile w: an X row is read ONCE, by the one wave that
+//      needs it (16 of the 48 channels), kept in registers for the three steps it is used (ky = 2, then 1, then 0 - the compiler
+//      keeps the shifted operands too), and only the dY fragments (all 48 co, every wave) are re-read per step:
+//          LDS reads per wave and step   6 dY + 6 X fragments + 6 halo pairs  ->  6 dY + 2 X fragments + 2 halo pairs
+//          vector instructions           48 funnel shifts / moves             ->  16
+//          X ring                        4 rows                               ->  2 (the row being read, the row being parked)
+//      acc[ky][kx][co tile] for the wave's ci tile: the same 27 accumulators and 54 MFMAs per step; ~125 instructions per step.
+//      0.47 ms (1108 TF/s) at 48 -> 48 @128^3, 0.23 ms at 96 -> 96 @64^3 (v1: 0.675 / 0.312); LDS busy 25 %, conflicts 10 %.
+// Common to all three: every row is a BUFFER load (descriptor = the (batch, plane, channel block) base, lane = a constant 32-bit
+// byte offset computed once per work item, row = a scalar byte offset); a granule outside the volume (x halo beyond the edge,
+// channel >= cin, pad granule) carries an offset beyond num_records and reads zeros, a row outside the volume is fetched through
+// the same descriptor with num_records = 0 - park is one ds_write_b128 per granule, no select, no branch; flat granule ids make
+// the LDS destination of copy round k an immediate offset from ONE address register.  The grid is 1-D over (item group, co block,
+// ci block, kz) with kz fastest, mapped so that every XCD owns a contiguous range: the workgroups that read the same rows - the
+// three tap planes and the ci blocks (dY), the co blocks and the z neighbours (X) - are resident together in one L2 (hit rate 0.71).
+// A workgroup may accumulate `ipw` work items (strided by the number of groups, so that resident workgroups stay on neighbouring
+// items) before it writes its 27 x 48 x 48 partial block: fewer partial slabs for the reduce kernel when items are short.
+// What bounds it now (profiles/r05_wgrad_pmc3.log): WAIT_INST_ANY 0.49 of the wave cycles with the matrix pipe busy 0.39 per wave -
+// six waves on four SIMDs (2, 2, 1, 1): the two shared SIMDs run at ~77 % of the matrix pipe, the other two at half of that.
+// SEGM_WGRAD_V1=1 launches the round-1..4 kernel (A/B, and the fallback for strides beyond 32-bit byte offsets).
 // ---------------------------------------------------------------------------------------------------------------------
 typedef __amdgpu_buffer_rsrc_t wg_rsrc_t;
 constexpr uint32_t kWgNumRec = 0xFFFFF000u;        // bytes a descriptor covers; a lane offset at / beyond it reads zeros
@@ -252,380 +265,8 @@ template <int NQ> struct WgGeo {
     static constexpr int NR = RX + RD;
 };
 
-// OCC: workgroups per CU the register budget is cut for (2: 256 registers; 3: 168).  ABL != 0: TIMING ABLATIONS ONLY (wrong results,
-// tools/r05/wgrad_ab.py): 1 no row fetch, 2 no MFMA, 3 no fragment reads (MFMAs on stale registers), 4 no park, 5 no barrier.
-template <typename T, int NQ, int OCC = 2, int ABL = 0>
+template <typename T, int NQ, int OCC = 2>
 __global__ void __launch_bounds__(kWgThreads, OCC) conv3d_k3_wgrad_kernel(WgradDev P) {
-    typedef typename Mfma16<T>::v8 frag8;
-    typedef WgGeo<NQ> G;
-    constexpr int NCO = kWgCo / 16;
-    __shared__ __attribute__((aligned(16))) T xs[4 * G::XSLOT];
-    __shared__ __attribute__((aligned(16))) T dys[2 * G::DSLOT];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int ky = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: slot arithmetic stays on the SALU
-    const int i16 = lane & 15, g = lane >> 4;
-    // blockIdx.x runs over (item group, co block, ci block, kz) with kz fastest, re-ordered so that every XCD owns a contiguous
-    // range: the workgroups that read the same rows - the three tap planes (dY), the ci blocks (dY), the co blocks (X), the z
-    // neighbours (X) - are resident together in ONE L2.  (v1 had the ci blocks as grid rows, dispatched a whole grid row apart.)
-    const int vid = xcd_item(blockIdx.x, gridDim.x);
-    const int kz = vid % 3;
-    const int cib = (vid / 3) % P.ncib, cob = (vid / (3 * P.ncib)) % P.ncob;
-    const int grp = vid / (3 * P.ncib * P.ncob);
-    constexpr int XB = 32 * NQ;
-
-    f32x4 acc[NCO][3][3];                                 // [co tile][kx][ci tile]
-#pragma unroll
-    for (int a = 0; a < NCO; ++a)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) acc[a][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int xrd = i16 * G::PITCH + 8 + 8 * g;           // this lane's X fragment of (ci tile 0, chunk 0) inside a ring slot
-    const int yrd = i16 * G::PITCH + 8 * g;               // its dY fragment of (co tile 0, chunk 0) inside a dY buffer
-    const int dco = tid / G::DG, dgr = tid - dco * G::DG; // dY granule of round 0 (round k: co + k * 192 / DG)
-    const int ddst = dco * G::PITCH + 8 * dgr;
-    const uint32_t x_sy2 = (uint32_t)(P.x_sy * 2), dy_sy2 = (uint32_t)(P.dy_sy * 2);      // row pitch in bytes (host: fits 32 bits)
-
-    for (int it = 0; it < P.ipw; ++it) {
-        const int item_id = it * P.nslab + grp;          // strided: the resident workgroups work on neighbouring items at any time
-        if (item_id >= P.nitems) break;
-        int item = item_id;
-        const int ypart = item % P.ysplit;  item /= P.ysplit;
-        const int xb = item % P.nxb;        item /= P.nxb;
-        const int z = item % P.D, b = item / P.D;
-        const int zz = z + kz - 1;
-        const int y0 = ypart * P.rows_per_part;
-        const int y1 = (y0 + P.rows_per_part < P.H) ? y0 + P.rows_per_part : P.H;
-        if (zz < 0 || zz >= P.D || y1 <= y0) continue;    // the whole tap plane reads z padding -> contributes zeros
-        const int x0 = xb * XB;
-
-        // ---- copy plan: byte offsets from the descriptor bases, kWgOob = "reads zeros" ------------------------------------
-        uint32_t xv[G::RX], dv[G::RD];
-#pragma unroll
-        for (int k = 0; k < G::RX; ++k) {
-            const int id = tid + k * kWgThreads;
-            const int ci = id / G::PG, gr = id - ci * G::PG;
-            const int xg = x0 - 8 + 8 * gr;               // first x of the granule (W % 8 == 0: all inside or all outside)
-            const bool ok = id < 48 * G::PG && gr < G::XG && xg >= 0 && xg < P.W && cib * kWgBlock + ci < P.cin;
-            xv[k] = ok ? (uint32_t)(((int64_t)ci * P.x_sc + xg) * 2) : kWgOob;
-        }
-#pragma unroll
-        for (int k = 0; k < G::RD; ++k) {
-            const int co = dco + k * (kWgThreads / G::DG);
-            const bool ok = x0 + 8 * dgr < P.W;           // widths below 32: the rest of the k-chunk is zero
-            dv[k] = ok ? (uint32_t)(((int64_t)co * P.dy_sc + x0 + 8 * dgr) * 2) : kWgOob;
-        }
-        const T* xbase = reinterpret_cast<const T*>(P.x) + (int64_t)b * P.x_sb + (int64_t)zz * P.x_sz + (int64_t)cib * kWgBlock * P.x_sc;
-        const T* dbase = reinterpret_cast<const T*>(P.dy) + (int64_t)b * P.dy_sb + (int64_t)z * P.dy_sz + (int64_t)cob * kWgCo * P.dy_sc;
-
-        // X row yy and dY row yd -> registers; a row outside the volume comes back as zeros (num_records = 0), no access
-        auto fetch = [&](u32x4 (&r)[G::NR], int yy, int yd) {
-            const bool x_ok = yy >= 0 && yy < P.H, d_ok = yd < P.H;
-            const wg_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xbase), 0, x_ok ? (int)kWgNumRec : 0, 0x00020000);
-            const wg_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dbase), 0, d_ok ? (int)kWgNumRec : 0, 0x00020000);
-            const uint32_t sx = (uint32_t)(x_ok ? yy : 0) * x_sy2, sd = (uint32_t)(d_ok ? yd : 0) * dy_sy2;
-#pragma unroll
-            for (int k = 0; k < G::RX; ++k) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, xv[k], sx, 0);
-#pragma unroll
-            for (int k = 0; k < G::RD; ++k) r[G::RX + k] = __builtin_amdgcn_raw_buffer_load_b128(rd, dv[k], sd, 0);
-        };
-        auto fetch_loop = [&](u32x4 (&r)[G::NR], int yy, int yd) {
-            if constexpr (ABL == 1) {
-#pragma unroll
-                for (int k = 0; k < G::NR; ++k) r[k] = u32x4{0u, 0u, 0u, 0u};
-            } else {
-                fetch(r, yy, yd);
-            }
-        };
-        auto park = [&](const u32x4 (&r)[G::NR], int slot, int buf) {
-            T* xd = xs + slot * G::XSLOT + tid * 8;
-#pragma unroll
-            for (int k = 0; k < G::RX; ++k) *reinterpret_cast<u32x4*>(xd + k * kWgThreads * 8) = r[k];
-            T* dd = dys + buf * G::DSLOT + ddst;
-#pragma unroll
-            for (int k = 0; k < G::RD; ++k) *reinterpret_cast<u32x4*>(dd + k * (kWgThreads / G::DG) * G::PITCH) = r[G::RX + k];
-        };
-
-        // ---- prologue: rows y0 - 1, y0, y0 + 1 -> slots 0, 1, 2; dY row y0 -> buffer 0 ------------------------------------
-        {
-            u32x4 r[G::NR];
-#pragma unroll
-            for (int d = -1; d <= 1; ++d) {
-                fetch(r, y0 + d, y0);
-                park(r, d + 1, 0);                        // the dY row is parked three times (same data): harmless
-            }
-        }
-        __syncthreads();
-
-        // ---- row loop: step rel = y - y0 reads slot (rel + ky) & 3 and dY buffer rel & 1, parks row y + 2 / dY row y + 1 -------
-        for (int y = y0; y < y1; ++y) {
-            const int rel = y - y0;
-            u32x4 r[G::NR];
-            fetch_loop(r, y + 2, y + 1);                  // in flight during this step's MFMAs
-            SEGM_SCHED_FENCE();
-            const T* xsl = xs + ((rel + ky) & 3) * G::XSLOT + xrd;
-            const T* dyl = dys + (rel & 1) * G::DSLOT + yrd;
-            if constexpr (ABL == 3) {
-                const u32x4 c1 = {0x3f803f80u + (uint32_t)rel, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                    for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-                        for (int co = 0; co < NCO; ++co)
-#pragma unroll
-                            for (int kx = 0; kx < 3; ++kx)
-                                acc[co][kx][ci] = Mfma16<T>::run(__builtin_bit_cast(frag8, c1), __builtin_bit_cast(frag8, c1), acc[co][kx][ci]);
-            } else
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                u32x4 av[NCO];
-#pragma unroll
-                for (int co = 0; co < NCO; ++co)
-                    av[co] = *reinterpret_cast<const u32x4*>(dyl + co * 16 * G::PITCH + 32 * q);
-#pragma unroll
-                for (int ci = 0; ci < 3; ++ci) {
-                    const T* xc = xsl + ci * 16 * G::PITCH + 32 * q;
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(xc);
-                    const uint32_t hl = *reinterpret_cast<const uint32_t*>(xc - 2);     // elements (x-2, x-1)
-                    const uint32_t hr = *reinterpret_cast<const uint32_t*>(xc + 8);     // elements (x+8, x+9)
-                    const uint32_t s1 = __builtin_amdgcn_alignbyte(v[1], v[0], 2);
-                    const uint32_t s2 = __builtin_amdgcn_alignbyte(v[2], v[1], 2);
-                    const uint32_t s3 = __builtin_amdgcn_alignbyte(v[3], v[2], 2);
-                    const u32x4 vl = {__builtin_amdgcn_alignbyte(v[0], hl, 2), s1, s2, s3};   // X[x-1 ..]  (kx = 0)
-                    const u32x4 vr = {s1, s2, s3, __builtin_amdgcn_alignbyte(hr, v[3], 2)};   // X[x+1 ..]  (kx = 2)
-                    if constexpr (ABL == 2) {
-                        asm volatile("" :: "v"(vl), "v"(v), "v"(vr), "v"(av[0]), "v"(av[1]), "v"(av[2]));
-                    } else {
-#pragma unroll
-                        for (int co = 0; co < NCO; ++co) {
-                            const frag8 a = __builtin_bit_cast(frag8, av[co]);
-                            acc[co][0][ci] = Mfma16<T>::run(a, __builtin_bit_cast(frag8, vl), acc[co][0][ci]);
-                            acc[co][1][ci] = Mfma16<T>::run(a, __builtin_bit_cast(frag8, v), acc[co][1][ci]);
-                            acc[co][2][ci] = Mfma16<T>::run(a, __builtin_bit_cast(frag8, vr), acc[co][2][ci]);
-                        }
-                    }
-                }
-            }
-            SEGM_SCHED_FENCE();
-            if constexpr (ABL == 4) {
-#pragma unroll
-                for (int k = 0; k < G::NR; ++k) asm volatile("" :: "v"(r[k]));
-            } else {
-                park(r, (rel + 3) & 3, (rel & 1) ^ 1);
-            }
-            if constexpr (ABL != 5) __syncthreads();
-        }
-    }
-    // partial block: part[((cob * ncib + cib) * nslab + grp)][tap = kz*9 + ky*3 + kx][co (48)][ci (48)]
-    float* out = P.part + ((((int64_t)cob * P.ncib + cib) * P.nslab + grp) * 27) * (kWgCo * kWgBlock);
-#pragma unroll
-    for (int ct = 0; ct < NCO; ++ct)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = ct * 16 + g * 4 + r, cin = ci * 16 + i16;
-                    out[((int64_t)(kz * 9 + ky * 3 + kx) * kWgCo + co) * kWgBlock + cin] = acc[ct][kx][ci][r];
-                }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The same kernel with the row loop software-pipelined ACROSS the per-step barrier (round 5, second pass).  The ablations of the
-// kernel above (profiles/r05_wgrad_abl.log) show no single bound: without the row fetch, without the MFMAs or without the fragment
-// reads a 48 -> 48 @128^3 launch still takes 0.48 - 0.50 of 0.57 ms, and a third workgroup per CU gains 13 - 22 % - every wave sits
-// through a serial chain per step:  barrier -> first fragment read (LDS latency) -> MFMAs -> wait for the row loads -> park ->
-// LDS write latency -> barrier.  Here the chain is cut on both sides of the barrier:
-//   * rows are parked at the TOP of the step after the one that fetched them (ring of 5 X rows, 3 dY rows), so what the barrier
-//     at the end of a step waits for was written a whole step earlier;
-//   * the fragments of the next step's first k-chunk are read during the MFMAs of the last k-chunk of this step - every row a
-//     step reads has been visible since the previous barrier - so the matrix pipe starts right behind the barrier.
-// ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int NQ, int OCC = 2>
-__global__ void __launch_bounds__(kWgThreads, OCC) conv3d_k3_wgrad_pipe_kernel(WgradDev P) {
-    typedef typename Mfma16<T>::v8 frag8;
-    typedef WgGeo<NQ> G;
-    constexpr int NCO = kWgCo / 16;
-    constexpr int NXS = 5, NDS = 3;                       // ring slots: X rows y-1 .. y+3, dY rows y .. y+2
-    __shared__ __attribute__((aligned(16))) T xs[NXS * G::XSLOT];
-    __shared__ __attribute__((aligned(16))) T dys[NDS * G::DSLOT];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int ky = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i16 = lane & 15, g = lane >> 4;
-    const int vid = xcd_item(blockIdx.x, gridDim.x);
-    const int kz = vid % 3;
-    const int cib = (vid / 3) % P.ncib, cob = (vid / (3 * P.ncib)) % P.ncob;
-    const int grp = vid / (3 * P.ncib * P.ncob);
-    constexpr int XB = 32 * NQ;
-
-    f32x4 acc[NCO][3][3];                                 // [co tile][kx][ci tile]
-#pragma unroll
-    for (int a = 0; a < NCO; ++a)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) acc[a][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int xrd = i16 * G::PITCH + 8 + 8 * g;
-    const int yrd = i16 * G::PITCH + 8 * g;
-    const int dco = tid / G::DG, dgr = tid - dco * G::DG;
-    const int ddst = dco * G::PITCH + 8 * dgr;
-    const uint32_t x_sy2 = (uint32_t)(P.x_sy * 2), dy_sy2 = (uint32_t)(P.dy_sy * 2);
-
-    struct Frag { u32x4 a[NCO], v[3]; uint32_t hl[3], hr[3]; };
-    auto read_frags = [&](Frag& f, int xslot, int dbuf, int q) {
-        const T* xsl = xs + xslot * G::XSLOT + xrd + 32 * q;
-        const T* dyl = dys + dbuf * G::DSLOT + yrd + 32 * q;
-#pragma unroll
-        for (int co = 0; co < NCO; ++co) f.a[co] = *reinterpret_cast<const u32x4*>(dyl + co * 16 * G::PITCH);
-#pragma unroll
-        for (int ci = 0; ci < 3; ++ci) {
-            const T* xc = xsl + ci * 16 * G::PITCH;
-            f.v[ci] = *reinterpret_cast<const u32x4*>(xc);
-            f.hl[ci] = *reinterpret_cast<const uint32_t*>(xc - 2);
-            f.hr[ci] = *reinterpret_cast<const uint32_t*>(xc + 8);
-        }
-    };
-    auto mfmas = [&](const Frag& f) {
-#pragma unroll
-        for (int ci = 0; ci < 3; ++ci) {
-            const u32x4 v = f.v[ci];
-            const uint32_t s1 = __builtin_amdgcn_alignbyte(v[1], v[0], 2);
-            const uint32_t s2 = __builtin_amdgcn_alignbyte(v[2], v[1], 2);
-            const uint32_t s3 = __builtin_amdgcn_alignbyte(v[3], v[2], 2);
-            const u32x4 vl = {__builtin_amdgcn_alignbyte(v[0], f.hl[ci], 2), s1, s2, s3};
-            const u32x4 vr = {s1, s2, s3, __builtin_amdgcn_alignbyte(f.hr[ci], v[3], 2)};
-#pragma unroll
-            for (int co = 0; co < NCO; ++co) {
-                const frag8 a = __builtin_bit_cast(frag8, f.a[co]);
-                acc[co][0][ci] = Mfma16<T>::run(a, __builtin_bit_cast(frag8, vl), acc[co][0][ci]);
-                acc[co][1][ci] = Mfma16<T>::run(a, __builtin_bit_cast(frag8, v), acc[co][1][ci]);
-                acc[co][2][ci] = Mfma16<T>::run(a, __builtin_bit_cast(frag8, vr), acc[co][2][ci]);
-            }
-        }
-    };
-
-    for (int it = 0; it < P.ipw; ++it) {
-        const int item_id = it * P.nslab + grp;
-        if (item_id >= P.nitems) break;
-        int item = item_id;
-        const int ypart = item % P.ysplit;  item /= P.ysplit;
-        const int xb = item % P.nxb;        item /= P.nxb;
-        const int z = item % P.D, b = item / P.D;
-        const int zz = z + kz - 1;
-        const int y0 = ypart * P.rows_per_part;
-        const int y1 = (y0 + P.rows_per_part < P.H) ? y0 + P.rows_per_part : P.H;
-        if (zz < 0 || zz >= P.D || y1 <= y0) continue;
-        const int x0 = xb * XB;
-
-        uint32_t xv[G::RX], dv[G::RD];
-#pragma unroll
-        for (int k = 0; k < G::RX; ++k) {
-            const int id = tid + k * kWgThreads;
-            const int ci = id / G::PG, gr = id - ci * G::PG;
-            const int xg = x0 - 8 + 8 * gr;
-            const bool ok = id < 48 * G::PG && gr < G::XG && xg >= 0 && xg < P.W && cib * kWgBlock + ci < P.cin;
-            xv[k] = ok ? (uint32_t)(((int64_t)ci * P.x_sc + xg) * 2) : kWgOob;
-        }
-#pragma unroll
-        for (int k = 0; k < G::RD; ++k) {
-            const int co = dco + k * (kWgThreads / G::DG);
-            const bool ok = x0 + 8 * dgr < P.W;
-            dv[k] = ok ? (uint32_t)(((int64_t)co * P.dy_sc + x0 + 8 * dgr) * 2) : kWgOob;
-        }
-        const T* xbase = reinterpret_cast<const T*>(P.x) + (int64_t)b * P.x_sb + (int64_t)zz * P.x_sz + (int64_t)cib * kWgBlock * P.x_sc;
-        const T* dbase = reinterpret_cast<const T*>(P.dy) + (int64_t)b * P.dy_sb + (int64_t)z * P.dy_sz + (int64_t)cob * kWgCo * P.dy_sc;
-
-        auto fetch = [&](u32x4 (&r)[G::NR], int yy, int yd) {
-            const bool x_ok = yy >= 0 && yy < P.H, d_ok = yd < P.H;
-            const wg_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xbase), 0, x_ok ? (int)kWgNumRec : 0, 0x00020000);
-            const wg_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dbase), 0, d_ok ? (int)kWgNumRec : 0, 0x00020000);
-            const uint32_t sx = (uint32_t)(x_ok ? yy : 0) * x_sy2, sd = (uint32_t)(d_ok ? yd : 0) * dy_sy2;
-#pragma unroll
-            for (int k = 0; k < G::RX; ++k) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, xv[k], sx, 0);
-#pragma unroll
-            for (int k = 0; k < G::RD; ++k) r[G::RX + k] = __builtin_amdgcn_raw_buffer_load_b128(rd, dv[k], sd, 0);
-        };
-        auto park = [&](const u32x4 (&r)[G::NR], int slot, int buf) {
-            T* xd = xs + slot * G::XSLOT + tid * 8;
-#pragma unroll
-            for (int k = 0; k < G::RX; ++k) *reinterpret_cast<u32x4*>(xd + k * kWgThreads * 8) = r[k];
-            T* dd = dys + buf * G::DSLOT + ddst;
-#pragma unroll
-            for (int k = 0; k < G::RD; ++k) *reinterpret_cast<u32x4*>(dd + k * (kWgThreads / G::DG) * G::PITCH) = r[G::RX + k];
-        };
-
-        // ---- prologue: X rows y0 - 1 .. y0 + 2 -> slots 0 .. 3, dY rows y0, y0 + 1 -> buffers 0, 1; row y0 + 3 / dY y0 + 2 in flight ----
-        u32x4 r[G::NR];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            fetch(r, y0 - 1 + d, y0 + (d & 1));
-            park(r, d, d & 1);                            // dY rows y0, y0 + 1 are parked twice each (same data)
-        }
-        fetch(r, y0 + 3, y0 + 2);
-        __syncthreads();
-        Frag f0, f1;
-        int xr = ky, xw = 4, dr = 0, dw = 2;              // ring positions: X read / X park, dY read / dY park
-        read_frags(f0, xr, dr, 0);
-
-        for (int y = y0; y < y1; ++y) {
-            park(r, xw, dw);                              // row y + 3 / dY row y + 2: fetched during the previous step
-            fetch(r, y + 4, y + 3);
-            const int xr1 = xr + 1 >= NXS ? xr + 1 - NXS : xr + 1, dr1 = dr + 1 >= NDS ? 0 : dr + 1;
-            SEGM_SCHED_FENCE();
-            if constexpr (NQ == 2) {
-                read_frags(f1, xr, dr, 1);                // issued ahead of the MFMAs that cover their latency (the fences keep
-                SEGM_SCHED_FENCE();                       // the scheduler from sinking the reads to the end of the group)
-                mfmas(f0);
-                SEGM_SCHED_FENCE();
-                read_frags(f0, xr1, dr1, 0);              // the next step's first chunk: visible since the previous barrier
-                SEGM_SCHED_FENCE();
-                mfmas(f1);
-            } else {
-                mfmas(f0);
-                SEGM_SCHED_FENCE();
-                read_frags(f0, xr1, dr1, 0);
-            }
-            SEGM_SCHED_FENCE();
-            xr = xr1; dr = dr1;
-            xw = xw + 1 >= NXS ? 0 : xw + 1;
-            dw = dw + 1 >= NDS ? 0 : dw + 1;
-            __syncthreads();
-        }
-    }
-    float* out = P.part + ((((int64_t)cob * P.ncib + cib) * P.nslab + grp) * 27) * (kWgCo * kWgBlock);
-#pragma unroll
-    for (int ct = 0; ct < NCO; ++ct)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = ct * 16 + g * 4 + r, cin = ci * 16 + i16;
-                    out[((int64_t)(kz * 9 + ky * 3 + kx) * kWgCo + co) * kWgBlock + cin] = acc[ct][kx][ci][r];
-                }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 5, third pass: ONE WAVE = ONE ci TILE, all three ky.  The counters of the kernels above (profiles/r05_wgrad_pmc2.log): the
-// LDS pipe is busy 55 % of the kernel, half of that in bank conflicts (the two halo dwords of every X fragment are 4-way conflicts
-// that no row pitch can avoid: all 32 lanes of a ds_read_b32 group address dword 3 of a granule), and without the MFMAs the launch
-// still takes 0.39 of 0.58 ms - the fragment traffic, not the matrix pipe and not HBM, is what a step waits for.  With ky = wave
-// every X row is read from LDS by three waves (on three consecutive steps), shifted three times.  Here wave w owns ci tile w and
-// all of ky: an X row is read from LDS ONCE, by the one wave that needs it (16 of the 48 channels), kept in registers for the
-// three steps it is used (as ky = 2, then 1, then 0), and only the dY fragments (all 48 co, every wave) are re-read per step:
-//      LDS reads per wave and step   6 dY + 6 X fragments + 6 halo pairs  ->  6 dY + 2 X fragments + 2 halo pairs
-//      X ring                        4 - 5 rows                         ->  2 (the row being read, the row being parked)
-// acc[ky][kx][co tile] for the wave's ci tile: the same 27 accumulators and 54 MFMAs per step.  The pipelining across the barrier
-// is the second pass's: rows are parked at the top of the step after their fetch, row y + 1 is read while the MFMAs of ky = 0, 1
-// run, the next step's first dY chunk is read during the last chunk's MFMAs.
-// ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int NQ, int OCC = 2>
-__global__ void __launch_bounds__(kWgThreads, OCC) conv3d_k3_wgrad_ct_kernel(WgradDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     typedef WgGeo<NQ> G;
     constexpr int NCO = kWgCo / 16;
@@ -879,12 +520,6 @@ static bool wgrad_v1() {
     const char* e = getenv("SEGM_WGRAD_V1");           // read per call (tests switch it): a getenv is nothing next to a launch
     return e && atoi(e) == 1;
 }
-static int wgrad_variant() {                              // 10 x OCC + ABL, 0 = the shipped kernel
-    const char* o = getenv("SEGM_WGRAD_OCC");
-    const char* b = getenv("SEGM_WGRAD_ABL");
-    const int occ = o ? atoi(o) : 2, abl = b ? atoi(b) : 0;
-    return (occ == 2 && abl == 0) ? 0 : 10 * occ + abl;
-}
 static WgPlan wgrad_plan(int batch, int cin, int cout, int d, int h, int w) {
     WgPlan p;
     p.nq = (w % 64 == 0) ? 2 : 1;
@@ -898,7 +533,11 @@ static WgPlan wgrad_plan(int batch, int cin, int cout, int d, int h, int w) {
     p.nitems = batch * d * p.nxb * split;
     const char* ipw_s = getenv("SEGM_WGRAD_IPW");
     const int ipw_env = ipw_s ? atoi(ipw_s) : 0;
-    int64_t ipw = ipw_env > 0 ? ipw_env : ((int64_t)p.nitems * blocks) / 512;      // one round of 512 resident workgroups
+    // items per workgroup (profiles/r05_wgrad_abl3.log): many short-lived workgroups balance themselves - one resident round of
+    // long-lived ones loses to its own tail (513 workgroups on 512 slots = two rounds) - so only short items (H < 128 rows: the
+    // prologue and the 108-store epilogue weigh more) are paired up, and never below ~768 workgroups
+    int64_t ipw = ipw_env > 0 ? ipw_env : 128 / (p.rows_per_part > 0 ? p.rows_per_part : 1);
+    if (ipw_env <= 0 && ipw > ((int64_t)p.nitems * blocks) / 768) ipw = ((int64_t)p.nitems * blocks) / 768;
     if (wgrad_v1() || ipw < 1) ipw = 1;
     if (ipw > p.nitems) ipw = p.nitems;
     p.ipw = (int)ipw;
@@ -960,20 +599,6 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
             } else {
                 if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_v1_kernel<bf16_t, 2>), grid, dim3(kWgThreads), 0, stream, P);
                 else hipLaunchKernelGGL((conv3d_k3_wgrad_v1_kernel<bf16_t, 1>), grid, dim3(kWgThreads), 0, stream, P);
-            }
-        } else if (const int var = wgrad_variant(); var != 0 && a->dtype == SEGM_BF16 && pl.nq == 2) {
-            // experiments (tools/r05/wgrad_ab.py): SEGM_WGRAD_OCC=3 three workgroups per CU; SEGM_WGRAD_ABL=1..5 timing ablations
-            switch (var) {
-                case 30: hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 2, 3, 0>), grid, dim3(kWgThreads), 0, stream, P); break;
-                case 40: hipLaunchKernelGGL((conv3d_k3_wgrad_pipe_kernel<bf16_t, 2, 2>), grid, dim3(kWgThreads), 0, stream, P); break;
-                case 50: hipLaunchKernelGGL((conv3d_k3_wgrad_ct_kernel<bf16_t, 2, 2>), grid, dim3(kWgThreads), 0, stream, P); break;
-                case 60: hipLaunchKernelGGL((conv3d_k3_wgrad_ct_kernel<bf16_t, 2, 3>), grid, dim3(kWgThreads), 0, stream, P); break;
-                case 21: hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 2, 2, 1>), grid, dim3(kWgThreads), 0, stream, P); break;
-                case 22: hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 2, 2, 2>), grid, dim3(kWgThreads), 0, stream, P); break;
-                case 23: hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 2, 2, 3>), grid, dim3(kWgThreads), 0, stream, P); break;
-                case 24: hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 2, 2, 4>), grid, dim3(kWgThreads), 0, stream, P); break;
-                case 25: hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 2, 2, 5>), grid, dim3(kWgThreads), 0, stream, P); break;
-                default: return SEGM_E_SHAPE;
             }
         } else if (a->dtype == SEGM_F16) {
             if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 2>), grid, dim3(kWgThreads), 0, stream, P);

@@ -1677,18 +1677,3 @@ def test_conv3d_k3_wgrad_items_per_workgroup_emulated(emu, monkeypatch, ipw):
     monkeypatch.setenv("SEGM_WGRAD_V1", "1")
     dw1 = ops_raw.conv3d_k3_wgrad(emu, x, dy, torch.float32)
     assert (dw1 - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-4
-
-
-@pytest.mark.parametrize("occ,ipw", [(3, 0), (4, 0), (4, 2), (4, 5), (5, 0), (5, 2), (5, 3)])
-def test_conv3d_k3_wgrad_experimental_variants_emulated(emu, monkeypatch, occ, ipw):
-    """round 5: SEGM_WGRAD_OCC=3 (three workgroups per CU) and =4 (the row loop software-pipelined across the barrier: five-row X
-    ring, three dY buffers, next step's fragments read before the barrier) give v1's numbers; 64-wide bf16 blocks only."""
-    g = torch.Generator().manual_seed(77 + occ + ipw)
-    x = torch.randn(1, 96, 2, 7, 64, generator=g).bfloat16()
-    dy = torch.randn(1, 48, 2, 7, 64, generator=g).bfloat16()
-    ref = _wgrad_reference(x, dy)
-    monkeypatch.setenv("SEGM_WGRAD_OCC", str(occ))
-    if ipw:
-        monkeypatch.setenv("SEGM_WGRAD_IPW", str(ipw))
-    dw = ops_raw.conv3d_k3_wgrad(emu, x, dy, torch.float32)
-    assert (dw - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-4
