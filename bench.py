@@ -694,7 +694,21 @@ def main():
                         out[key] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         if not args.no_cpu_baseline and world == 1 and not dry:       # the host-core baseline is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)
+        # ONE JSON line, and the LAST line of stdout: the vendor libraries print diagnostics through C stdio ("GridwiseOp: ..." from the
+        # solvers MIOpen tries on the drop-in path), fully buffered when stdout is a pipe - flush them out first, and send whatever a
+        # library prints at teardown to /dev/null
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                   # noqa: BLE001
+            pass
         print(json.dumps(out), flush=True)
+        try:
+            devnull = os.open(os.devnull, os.O_WRONLY)
+            os.dup2(devnull, 1)
+        except OSError:
+            pass
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
