@@ -431,6 +431,53 @@ def dropin_step(device, size, batch, steps, warmup):
     return out
 
 
+def launch_forms(state, data, device, steps=10, warmup=3):
+    """N = 1 only: the same training step in the three forms a scaling curve mixes - the timed region of this
+    line replays a captured graph, the N > 1 default launches eagerly with one gradient hook per parameter and the exchange in
+    segments on a side stream.  Measured here on ONE rank (a 1-rank RCCL group: hooks, side stream, sliced all-reduce all run), so
+    that an efficiency figure can be read like for like: eager_hooks_ms(1 GPU) against ms_per_step(N GPUs)."""
+    import torch.distributed as dist
+    from segmamba_amd.trainer import SegmentedExchange, train_step
+    out = {}
+
+    def timed():
+        for _ in range(warmup):
+            train_step(state, *data.next())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            train_step(state, *data.next())
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / steps * 1e3, 3)
+    if state.graphed is not None:
+        out["graph_ms"] = timed()
+    state.graphed = None
+    out["eager_ms"] = timed()
+    try:
+        if not dist.is_initialized():
+            import datetime
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                    timeout=datetime.timedelta(seconds=120))
+        state.exchange = SegmentedExchange(state.bank, 1, int(os.environ.get("SEGM_DDP_SEGMENTS", "4")))
+        state.exchange.record_exposed = True
+        out["eager_hooks_ms"] = timed()
+        out["eager_hooks_exposed_ms"] = round(state.exchange.exposed_ms(), 3)
+        out["segments"] = len(state.exchange.ranges)
+        out["segment_order"] = state.exchange.order
+        out["fallback"] = state.exchange.fallback_reason
+        state.exchange.close()
+        state.exchange = None
+    except Exception as e:                                  # noqa: BLE001
+        out["eager_hooks_ms"] = f"{type(e).__name__}: {str(e)[:160]}"
+    out["note"] = "one rank; eager_hooks = hooks armed + 4 segments all-reduced on a side stream (what N > 1 runs by default)"
+    return out
+
+
 def cpu_baseline(full=False):
     """The reference's CPU path on this box's host cores, bounded samples:
       value            the C port of the scan (oracle/scan_ref.c, fp64 arithmetic, OpenMP) at the roofline shape, forward
@@ -534,7 +581,10 @@ def main():
         sync = torch.cuda.synchronize
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group(backend="gloo" if dry else "nccl", init_method="env://", rank=rank, world_size=world)
+        import datetime
+        # a collective that never completes ends the job with a message after 3 minutes instead of sitting until the driver's limit
+        dist.init_process_group(backend="gloo" if dry else "nccl", init_method="env://", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("SEGM_PG_TIMEOUT_S", "180"))))
 
     from segmamba_amd.trainer import DDP_SETTINGS, SyntheticBraTS, build_training_state, train_step
     model = None
@@ -627,14 +677,17 @@ def main():
         rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
         elapsed = max(float(x.item()) for x in every)                # MAX over ranks
         if state.flat and not dry:                                   # the exchange step on its own: one all-reduce of the flat gradients
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            dist.all_reduce(state.bank.flat_grad)
-            torch.cuda.synchronize()
-            e0.record()
-            dist.all_reduce(state.bank.flat_grad)
-            e1.record()
-            e1.synchronize()
-            allreduce_ms = round(e0.elapsed_time(e1), 3)
+            try:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                dist.all_reduce(state.bank.flat_grad)
+                torch.cuda.synchronize()
+                e0.record()
+                dist.all_reduce(state.bank.flat_grad)
+                e1.record()
+                e1.synchronize()
+                allreduce_ms = round(e0.elapsed_time(e1), 3)
+            except Exception as e:                          # noqa: BLE001 - the line survives a failed side measurement
+                allreduce_ms = f"{type(e).__name__}: {str(e)[:120]}"
 
     if rank == 0:
         vols = world * args.batch * args.steps
@@ -649,6 +702,11 @@ def main():
                 ddp = dict(DDP_SETTINGS, mode="torch DistributedDataParallel")
             ddp["backend"] = "gloo (cpu dry run)" if dry else "nccl = RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
             ddp["rank_ms_per_step"] = {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)}
+            ddp["rendezvous"] = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+            ddp["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_", "TORCH_NCCL", "SEGM_DDP", "SEGM_GRAPH"))}
+            if state.exchange is not None:
+                ddp["segment_order"] = state.exchange.order
+                ddp["fallback"] = state.exchange.fallback_reason      # None: the overlapped form ran all the way
             if state.flat:
                 ddp["gradient_bytes"] = int(state.bank.flat_grad.numel()) * 4
                 ddp["allreduce_ms"] = allreduce_ms           # the whole array as one call, on its own
@@ -679,6 +737,11 @@ def main():
             out["roofline"] = scan_roofline(torch.bfloat16, device)
             out["roofline_fp32"] = scan_roofline(torch.float32, device)
             if not args.no_configs and world == 1:
+                if state.flat and not distributed:
+                    try:
+                        out["config"]["launch_forms"] = launch_forms(state, data, device)
+                    except Exception as e:                  # noqa: BLE001
+                        out["config"]["launch_forms"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
                 del state, data
                 torch.cuda.empty_cache()
                 if not args.no_dropin:
@@ -712,6 +775,10 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    elif not dry:
+        import torch.distributed as dist2
+        if dist2.is_available() and dist2.is_initialized():     # the 1-rank group of launch_forms()
+            dist2.destroy_process_group()
 
 
 if __name__ == "__main__":

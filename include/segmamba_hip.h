@@ -179,9 +179,13 @@ int segm_selective_scan_bwd(const segm_scan_bwd_args* args);
 int segm_selective_scan_bwd_multi(const segm_scan_bwd_args* args, int32_t n);   /* see segm_selective_scan_fwd_multi */
 size_t segm_selective_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t dstate, int64_t seqlen,
                                                int32_t chunk);
-/* 1 when segm_selective_scan_bwd(args) runs the kernel whose dB / dC are sums in a fixed order (all d-tiles of a chunk in
- * one workgroup: no atomics, no zero-initialised buffer, dbc_native allowed), 0 when it takes the kernels that accumulate
- * dB / dC atomically over d-tiles (irregular shapes, views beyond 4 GiB per batch element); no launch, no side effect */
+/* 1 when segm_selective_scan_bwd(args) runs the kernels whose dB / dC are sums in a fixed order (per-d-tile fp32 slabs added in
+ * tile order: no atomics, no zero-initialised buffer, dbc_native allowed), 0 when it takes the kernels that accumulate dB / dC
+ * atomically over d-tiles - irregular shapes (dim not a multiple of 16, dstate != 16, ...) and views whose rows span more than
+ * 4 GiB per batch element; those results are NOT bit-reproducible run to run (float atomics).  The answer is formed from the
+ * forward tensors of args->f (shape, layout and the 32-bit span bound) - the same predicate the launch applies to all tensors: a
+ * gradient tensor that breaks the span bound sends a dbc_native = 0 launch to the general kernels and makes a dbc_native = 1
+ * launch return SEGM_E_SHAPE.  No launch, no side effect. */
 int segm_selective_scan_bwd_deterministic(const segm_scan_bwd_args* args);
 
 /* ------------------------------------------------------------------------------------------------

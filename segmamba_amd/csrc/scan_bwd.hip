@@ -481,7 +481,15 @@ static int scan_bwd_one(const segm_scan_bwd_args* b, ScanDev* batched) {
         P.dB_sb = b->dB.stride_b; P.dB_st = b->dB.stride_t; P.dB_sn = b->dB.stride_n;
         P.dC = (float*)b->dC.ptr + (int64_t)g * b->dC.stride_g;
         P.dC_sb = b->dC.stride_b; P.dC_st = b->dC.stride_t; P.dC_sn = b->dC.stride_n;
-        const bool fast = use_fast_bwd() && G == 1 && scan_bwd_fast_shape(P, es);
+        bool fast = use_fast_bwd() && G == 1 && scan_bwd_fast_shape(P, es);
+        if (fast) {
+            // ONE predicate for "the regular-shape kernels run" (ADVICE r04): the shape AND the 32-bit spans their buffer addressing
+            // needs - a view beyond 4 GiB per batch element falls back to the general kernels (64-bit addresses) instead of failing
+            const int64_t fspan = fast_span_rows(P);
+            if (validate_spans(all, 8, bv, 2, a->dim, a->dstate, a->seqlen, es, fspan) != SEGM_OK ||
+                validate_spans(nullptr, 0, gv, 2, a->dim, a->dstate, a->seqlen, b->dbc_native ? es : sizeof(float), fspan) != SEGM_OK)
+                fast = false;
+        }
         P.dbc_part = (float*)(wsb + ws.slab);
         // the regular-shape main kernel leaves one fp32 slab of dB / dC per d-tile, added in a fixed order by a second kernel; the
         // general kernels add one partial per d-tile atomically onto a zeroed fp32 buffer
@@ -531,7 +539,14 @@ extern "C" int segm_selective_scan_bwd_deterministic(const segm_scan_bwd_args* b
     if (a->n_groups != 1) return 0;
     ScanDev P;
     fill_scan_dev(P, a, 0, a->chunk);
-    return scan_bwd_fast_shape(P, dtype_size(a->dtype)) ? 1 : 0;
+    const size_t es = dtype_size(a->dtype);
+    if (!scan_bwd_fast_shape(P, es)) return 0;
+    // the same span bound scan_bwd_one applies, on the tensors this query can see (the forward's; the gradient tensors are laid
+    // out like them by every caller in this repository - if they are not, segm_selective_scan_bwd answers SEGM_E_SHAPE for
+    // dbc_native and falls back to the general kernels otherwise)
+    const segm_seq* fw[4] = {&a->u, &a->delta, &a->z, &a->out};
+    const segm_bc* bv[2] = {&a->B, &a->C};
+    return validate_spans(fw, 4, bv, 2, a->dim, a->dstate, a->seqlen, es, fast_span_rows(P)) == SEGM_OK ? 1 : 0;
 }
 
 extern "C" int segm_selective_scan_bwd_multi(const segm_scan_bwd_args* args, int32_t n) {

@@ -188,7 +188,24 @@ class SegmentedExchange:
     for the side stream (and exchanges what the hooks never completed: parameters without a gradient).  The sums are
     element-wise, so the result equals the one-call exchange bit for bit.  K = 1: the one call behind the backward pass.
     A captured HIP graph cannot hold the hooks' host decisions: while `suspended` (GraphedStep's capture and its replays) the
-    hooks do nothing and finish() is the one call."""
+    hooks do nothing and finish() is the one call.
+
+    Nothing here may hang or mislead the first N > 1 run (round 5):
+      * every rank must issue the SAME sequence of collectives.  The order in which segments complete is a property of the
+        autograd graph, identical on every rank - but nothing is sent on that assumption: in the FIRST step the hooks only record
+        the order, finish() exchanges every segment in index order, and an all-gather compares the recorded orders; only if all
+        ranks agree does it become `order` and do the hooks send from the second step on (a mismatch switches EVERY rank to the
+        one-call form and says so in `fallback_reason`).  A segment that later completes out of that order stops that rank's hook
+        sends BEFORE anything is issued, and finish() sends what the hooks did not in the recorded order - so a rank whose hook
+        stopped early still pairs its collectives with the other ranks';
+      * a hook that raises (or a send that raises) is caught: the rank stops sending from hooks, finish() completes the step's
+        exchange in the recorded order, and a one-element flag all-reduce (MAX) at the end of every finish() tells all ranks;
+        from the next step on every rank uses the one-call form (`suspended`).  The step in which it happened is still exact;
+      * a collective that never completes is the process group's timeout (bench.py passes 180 s to init_process_group): the job
+        dies with a message instead of sitting in a collective until the driver's limit.
+    Hooks go only on parameters that require a gradient (register_post_accumulate_grad_hook raises otherwise; a frozen
+    parameter's window stays zero and travels with its segment); close() removes them; the side stream lives on the gradients'
+    device, not on whatever device is current."""
 
     def __init__(self, bank, world: int, segments: int):
         self.bank, self.world = bank, world
@@ -206,30 +223,58 @@ class SegmentedExchange:
                 self.ranges.append((i0, i + 1, a, b))
                 i0, a = i + 1, b
         self.seg_of = {}
+        self.hooked = [0] * len(self.ranges)               # parameters with a hook per segment (those that require a gradient)
         for s, (p0, p1, _, _) in enumerate(self.ranges):
             for i in range(p0, p1):
                 self.seg_of[id(params[i])] = s
+                self.hooked[s] += int(params[i].requires_grad)
         self.left = [0] * len(self.ranges)
         self.sent = [True] * len(self.ranges)
-        self.stream = torch.cuda.Stream() if bank.flat_grad.is_cuda else None
+        dev = bank.flat_grad.device
+        self.device = dev
+        self.stream = torch.cuda.Stream(device=dev) if bank.flat_grad.is_cuda else None
         self.works = []
         self.exposed_events = []                           # (backward done, exchange done) on the main stream, per step
         self.record_exposed = False
-        self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in params]
+        self.order = None                                  # canonical send order (segment indices), recorded in the first step
+        self.this_order = []
+        self.steps_done = 0
+        self.observed = []                                 # segments in the order their last gradient arrived, this step
+        self.failed = None                                 # this rank's first exception (repr), if any
+        self.fallback_reason = None                        # why every rank went to the one-call form, if they did
+        self._flag = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._pending = []                                 # (pinned flag copy, event) of the last steps: read two steps later
+        self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in params if p.requires_grad]
+
+    def close(self):
+        """remove the hooks (a second build_training_state on the same model must not stack them)"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     def arm(self):
         """before the backward pass of a step"""
-        self.left = [p1 - p0 for p0, p1, _, _ in self.ranges]
+        self.left = list(self.hooked)
         self.sent = [False] * len(self.ranges)
         self.works = []
+        self.this_order = []
+        self.observed = []
 
     def _hook(self, p):
-        if self.suspended or all(self.sent):
+        if self.suspended or self.failed is not None or all(self.sent):
             return
-        s = self.seg_of[id(p)]
-        self.left[s] -= 1
-        if self.left[s] == 0 and not self.sent[s]:
-            self._send(s)
+        try:
+            s = self.seg_of[id(p)]
+            self.left[s] -= 1
+            if self.left[s] == 0 and not self.sent[s]:
+                self.observed.append(s)
+                if self.order is None:
+                    return                                  # first step: record only (finish() exchanges in index order)
+                if len(self.this_order) >= len(self.order) or self.order[len(self.this_order)] != s:
+                    raise RuntimeError(f"segment {s} completed out of the recorded order {self.order} at position {len(self.this_order)}")
+                self._send(s)
+        except Exception as e:                              # noqa: BLE001 - never out of an autograd hook: finish() completes the step
+            self.failed = f"{type(e).__name__}: {str(e)[:200]}"
 
     def _send(self, s):
         import torch.distributed as dist
@@ -237,37 +282,80 @@ class SegmentedExchange:
         self.bank.gather_grads(p0, p1)                     # this segment's fresh gradients -> their windows (main stream)
         seg = self.bank.flat_grad[a:b]
         self.sent[s] = True
+        self.this_order.append(s)
         if self.stream is None:
             self.works.append(dist.all_reduce(seg, async_op=True))
             return
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(self.stream):
-            self.stream.wait_event(ev)
-            dist.all_reduce(seg)
+        with torch.cuda.device(self.device):
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                dist.all_reduce(seg)
 
     def finish(self):
         """behind the backward pass: every segment is exchanged and visible to the main stream"""
         import torch.distributed as dist
         if self.suspended:
-            dist.all_reduce(self.bank.flat_grad)            # one call (the gradients were gathered inside the graph)
+            dist.all_reduce(self.bank.flat_grad)            # one call (the gradients were gathered inside the graph / by the caller)
             return
         e0 = e1 = None
         if self.record_exposed and self.stream is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        for s in range(len(self.ranges)):
-            if not self.sent[s]:
-                self._send(s)
+        # what the hooks did not send, in the canonical order (the recorded order; first step: index order, descending)
+        first = self.order is None
+        canon = self.order if not first else list(range(len(self.ranges) - 1, -1, -1))
+        for s in [s for s in canon if not self.sent[s]]:
+            self._send(s)
         for w in self.works:
             w.wait()
         self.works = []
         if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
         if e0 is not None:
             e1.record()
             self.exposed_events.append((e0, e1))
         self.bank.point_grads_at_windows()
+        bad = 1.0 if self.failed is not None else 0.0
+        if first:
+            # do the ranks agree on the order in which their backward passes complete the segments?  (segments no hook completes -
+            # all parameters frozen - go last, in index order)
+            seen = list(self.observed) + [s for s in canon if s not in self.observed]
+            mine = torch.tensor(seen if self.failed is None else [-2] * len(self.ranges), dtype=torch.int32, device=self.device)
+            every = [torch.empty_like(mine) for _ in range(self.world)]
+            if self.world > 1:
+                dist.all_gather(every, mine)
+            else:
+                every = [mine]
+            live = [e for e in every if int(e[0]) != -2]        # -2: that rank already failed (its flag says so below)
+            if live and all(torch.equal(e, live[0]) for e in live):
+                self.order = [int(v) for v in live[0].tolist()]     # a rank that failed in this step follows the others' order
+            elif self.failed is None:
+                bad = 1.0
+                self.failed = "ranks complete their segments in different orders: " + str([e.tolist() for e in every])
+        self._flag.fill_(bad)
+        dist.all_reduce(self._flag, op=dist.ReduceOp.MAX)
+        # The flag is read TWO steps later (a pinned copy + event): reading it now would make the host wait for the GPU every step.
+        # Every rank reads the same flag at the same step, so they switch forms together; in between a failed rank keeps completing
+        # its steps in finish(), in the recorded order.
+        if self.stream is None:
+            verdicts = [float(self._flag)]
+        else:
+            host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            host.copy_(self._flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._pending.append((host, ev))
+            verdicts = []
+            while len(self._pending) > 2:
+                h, e = self._pending.pop(0)
+                e.synchronize()
+                verdicts.append(float(h))
+        if any(v > 0 for v in verdicts):
+            self.suspended = True
+            self.fallback_reason = self.failed or "another rank reported a failed gradient hook / a different segment order"
+        self.steps_done += 1
 
     def exposed_ms(self):
         """average milliseconds per step the main stream waited for the exchange behind the backward pass"""

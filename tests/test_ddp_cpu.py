@@ -204,3 +204,71 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-dry-run", "--steps", "1", "--warmup", "0"],
                         capture_output=True, text=True, timeout=600, env=env2, cwd=root)
     assert r2.returncode != 0 and "WORLD_SIZE=1" in r2.stderr
+
+
+def _failing_worker(rank, world, port, out, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    _use_emulated_library()
+    from segmamba_amd.trainer import build_training_state, train_step
+    st = build_training_state(torch.device("cpu"), distributed=True, model=_tiny_model(), ddp="flat", ddp_segments=3 if mode != "one" else 1)
+    img, lab = _batch(rank)
+    if mode == "raise" and rank == 1:
+        ex, real, calls = st.exchange, st.exchange._send, []
+
+        def flaky(s):
+            calls.append(s)
+            if len(calls) == 5:                              # the second segment of the second step, from inside the autograd hook
+                raise RuntimeError("injected: slice not aligned")
+            return real(s)
+        ex._send = flaky
+    if mode == "order" and rank == 1:
+        ex, real = st.exchange, st.exchange._hook
+        held = []
+
+        def late(p):                                        # rank 1 completes its LAST-produced segment first: a different send order
+            if ex.seg_of[id(p)] == len(ex.ranges) - 1 and ex.steps_done == 0:
+                held.append(p)
+                return
+            real(p)
+        for h in ex._hooks:
+            h.remove()
+        ex._hooks = [p.register_post_accumulate_grad_hook(late) for p in ex.bank.params if p.requires_grad]
+    for _ in range(5):
+        loss = train_step(st, img, lab)
+    ex = st.exchange
+    out[rank] = (float(loss), [p.detach().clone() for p in st.model.parameters()],
+                 None if ex is None else (ex.suspended, ex.fallback_reason, ex.failed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["raise", "order"])
+def test_segmented_exchange_falls_back_to_one_call_when_a_rank_fails(mode):
+    """round 5: an exception inside rank 1's gradient hook - or ranks that complete their segments in different
+    orders - must neither hang the other rank in a collective nor change the result: the failing step is completed in finish() in
+    the recorded order, a flag all-reduce tells every rank, all of them go on in the one-call form, and after five steps the
+    parameters are those of the one-call exchange, bit for bit, on both ranks."""
+    from tests import emu_util
+    if not emu_util.emu_available():
+        pytest.skip("no host clang for the emulation build")
+    emu_util.build_emu()
+    res = {}
+    for m in ("one", mode):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_failing_worker, args=(2, port, out, m), nprocs=2, join=True)
+        res[m] = {r: out[r] for r in (0, 1)}
+    for r in (0, 1):
+        assert res[mode][r][0] == res["one"][r][0]
+        for a, b in zip(res[mode][r][1], res["one"][0][1]):
+            assert torch.equal(a, b), (mode, r)
+        suspended, reason, failed = res[mode][r][2]
+        assert suspended and reason, (mode, r, reason)
+    assert res[mode][1][2][2] is not None                       # rank 1 knows what happened to it ...
+    if mode == "raise":
+        assert "injected" in res[mode][1][2][2] and res[mode][0][2][2] is None and "another rank" in res[mode][0][2][1]

@@ -300,6 +300,41 @@ def test_selective_scan_backward_repeatability(hip):
         assert not bool(wide[:, :, :4].any()) and not bool(wide[:, :, 36:].any())
 
 
+def test_selective_scan_backward_native_dbc_channel_first(hip):
+    """the layouts the 8-step-window backward newly accepts - channel-FIRST rows (stride_d != 1: the reference's own
+    (B, D, L) layout) with time-fastest B / C (B, N, L) - through the native dB / dC path (dB / dC written once, in the tensors' own
+    16-bit type): equal to the fp32 results rounded once, and every gradient equal to the channel-last launch's on the same data."""
+    torch.manual_seed(3)
+    B, Lq, D, N = 2, 2048, 64, 16
+    dt = torch.bfloat16
+    rn = lambda *s: torch.randn(*s, device=DEV)
+    u, z, g = rn(B, D, Lq).to(dt), rn(B, D, Lq).to(dt), rn(B, D, Lq).to(dt)
+    delta = (0.5 * torch.rand(B, D, Lq, device=DEV)).to(dt)
+    A = -0.5 * torch.rand(D, N, device=DEV) - 0.05
+    Bm, Cm = rn(B, N, Lq).to(dt), rn(B, N, Lq).to(dt)
+    Dv, db = rn(D), 0.5 * torch.rand(D, device=DEV)
+    f = ops_raw.scan_fwd(hip, u, delta, A, Bm, Cm, Dv, z, db, True, channel_last=False, chunk=256, need_out=True, need_ckpt=True)
+    args = (u, delta, A, Bm, Cm, Dv, z, db, g, f["out"], f["ckpt"], True)
+    r0 = ops_raw.scan_bwd(hip, *args, channel_last=False, chunk=f["chunk"])
+    dBn, dCn = torch.zeros(B, N, Lq, device=DEV, dtype=dt), torch.zeros(B, N, Lq, device=DEV, dtype=dt)
+    r = ops_raw.scan_bwd(hip, *args, channel_last=False, chunk=f["chunk"], dB=dBn, dC=dCn)
+    if hip.dll.segm_selective_scan_regular_shape(B, D, N, Lq, f["chunk"], L.TIME_FORWARD, 1) == 1:
+        assert r["dbc_native"] and not r0["dbc_native"]
+        assert torch.equal(dBn, r0["dB"].reshape(B, N, Lq).to(dt)) and torch.equal(dCn, r0["dC"].reshape(B, N, Lq).to(dt))
+    else:
+        assert not r["dbc_native"]
+    for k in ("du", "ddelta", "dz", "dA", "dD", "ddelta_bias"):
+        assert torch.equal(r[k], r0[k]), k
+    # the same data channel-last: same arithmetic per (b, d) row and state, same d-tile summation order
+    tl = lambda t: t.transpose(1, 2).contiguous()
+    fl = ops_raw.scan_fwd(hip, tl(u), tl(delta), A, tl(Bm), tl(Cm), Dv, tl(z), db, True, channel_last=True, chunk=256, need_out=True, need_ckpt=True)
+    rl = ops_raw.scan_bwd(hip, tl(u), tl(delta), A, tl(Bm), tl(Cm), Dv, tl(z), db, tl(g), fl["out"], fl["ckpt"], True, channel_last=True, chunk=fl["chunk"])
+    for k in ("du", "ddelta", "dz"):
+        assert (tl(r0[k]).float() - rl[k].float()).abs().max() <= 1e-2 * rl[k].float().abs().max(), k
+    for k in ("dA", "dD", "ddelta_bias"):
+        assert (r0[k] - rl[k]).abs().max() <= 1e-3 * rl[k].abs().max() + 1e-4, k
+
+
 def test_error_behaviour(hip):
     """reference TORCH_CHECKs (selective_scan.cpp:233-303, causal_conv1d.cpp:136-170) surface as RuntimeError."""
     x = torch.randn(1, 8, 16, device=DEV)
