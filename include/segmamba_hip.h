@@ -286,9 +286,18 @@ typedef struct segm_conv3d_fwd_args {
     const void* w_packed;
     const float* bias;
     void* stream;
+    /* ABI 8: statistics of the result for the InstanceNorm behind the convolution (reference dynunet_block.py:98-111: every 3x3x3
+     * convolution of the stem / decoder is followed by one).  stats_partials (NULL = off): fp32 (batch, cout, stats_nparts, 4) that
+     * receives {count, sum y, sum y^2, 0} of the values this launch stores (the fp32 sums before rounding; with
+     * SEGM_CONV_FWD_ACCUMULATE: of the accumulated values), one partial per (depth, y part, x block [, x pair]) - hand it to
+     * segm_instnorm_fwd's stats_partials.  stats_nparts must equal segm_conv3d_k3_fwd_stats_parts(); only the launches with
+     * SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_PITCH48 or SEGM_CONV_FWD_CHAIN32 have the epilogue (SEGM_E_SHAPE otherwise). */
+    float* stats_partials;
+    int32_t stats_nparts, reserved;
 } segm_conv3d_fwd_args;
 
 int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* args);
+int32_t segm_conv3d_k3_fwd_stats_parts(int32_t depth, int32_t height, int32_t width, int32_t batch, int32_t cout, int32_t flags);
 
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d (+ residual) (+ activation), forward and backward.
@@ -318,6 +327,11 @@ typedef struct segm_instnorm_fwd_args {
     /* elements between consecutive (b, c) instances of x / residual / y; 0 = spatial (dense).  128^3 volumes are kept with a
      * padded channel stride (a 4 MiB stride puts all channels of a row into one L2 set / memory channel) */
     int64_t x_instance_stride, residual_instance_stride, y_instance_stride;
+    /* ABI 8: statistics already summed by the producer of x (segm_conv3d_k3_fwd's stats_partials): fp32 (instances, stats_nparts, 4)
+     * of {count, sum, sum of squares, -}; the statistics launch is skipped and the partials are merged (Chan's update, fixed order)
+     * by the apply launch.  NULL / 0: the library makes its own pass over x. */
+    const float* stats_partials;
+    int32_t stats_nparts, reserved2;
 } segm_instnorm_fwd_args;
 
 typedef struct segm_instnorm_bwd_args {

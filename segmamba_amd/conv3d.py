@@ -44,6 +44,10 @@ _TUNE = os.environ.get("SEGM_CONV_AUTOTUNE", "0") == "1"
 # cat(up, skip) convolutions as one autograd node with the later parts added in place (_ConvSameCat, linear._PointwiseCat).  Timed in
 # round 3: no gain on the MI355X (66.2 ms per step either way), so it stays opt-in.
 _CAT_FUSED = os.environ.get("SEGM_CONV_CAT_FUSED", "0") == "1"
+# round 5: the chained kernels' storing K part sums {count, y, y^2} of what it writes; the InstanceNorm behind the convolution
+# merges those partials instead of reading the volume again (csrc/conv3d_fwd.hip STATS; measured free on the convolution side,
+# profiles/r05_inorm_epilogue.log).  SEGM_CONV_STATS=0: every InstanceNorm makes its own statistics pass (A/B).
+_STATS = os.environ.get("SEGM_CONV_STATS", "1") == "1"
 
 
 def _time(fn: Callable[[], torch.Tensor], reps: int = 3) -> float:
@@ -147,21 +151,28 @@ def _packed_block(w, ib, flipped, dtype):
     return packed(w, ("conv3d_k3_fwd", ib.start, ib.stop), lambda t: ops_raw.pack_conv3d_weight(t[:, ib], t.dtype))
 
 
-def _fwd_hip(x, w, pad, bias=None, chain=False, pitch48=False, chain32=False, into=None, flipped=False):
+def _fwd_hip(x, w, pad, bias=None, chain=False, pitch48=False, chain32=False, into=None, flipped=False, stats_box=None):
     """segm_conv3d_k3_fwd per 48-channel input block (the kernel keeps one block's weights in registers).  With
     Cout % 48 == 0 the later blocks accumulate into the first block's output in place; `chain` picks the kernel whose K
     parts are pipelined (csrc/conv3d_fwd.hip, variant 1).  `into`: an existing result every block is added to (the next part
-    of a concatenated input; Cout % 48 == 0, no bias)."""
+    of a concatenated input; Cout % 48 == 0, no bias).  `stats_box` (a list): the LAST block's launch - the one that stores the
+    finished values - also sums the InstanceNorm statistics of the result and appends the partials (kernels with that epilogue only)."""
     from . import lib as L, ops_raw
     hip = L.get_lib()
     cout, cin = (w.shape[1], w.shape[0]) if flipped else (w.shape[0], w.shape[1])     # flipped: w is the forward weight
     inplace = cout % _BLOCK == 0
     out = into
-    for i, ib in enumerate(_blocks(cin)):
+    blocks = _blocks(cin)
+    for i, ib in enumerate(blocks):
         wp = _packed_block(w, ib, flipped, x.dtype)
         if inplace:
+            last = stats_box is not None and i + 1 == len(blocks) and ((chain and pitch48) or chain32)
             out = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None, out=out, accumulate=i > 0 or into is not None,
-                                        chain=chain, pitch48=pitch48, chain32=chain32)
+                                        chain=chain, pitch48=pitch48, chain32=chain32, want_stats=last)
+            if last:
+                out, st = out
+                if st is not None:
+                    stats_box.append(st)
         else:
             y = ops_raw.conv3d_k3_fwd(hip, x[:, ib], wp, bias if i == 0 else None)
             out = y if out is None else out + y
@@ -250,7 +261,7 @@ def _mfma_wgrad_ok(x, dy, w) -> bool:
 _HIP_VARIANTS = ((False, False, False), (True, False, False), (True, True, False), (False, False, True))   # (chain, pitch48, chain32)
 
 
-def _fwd_candidates(x, w, bias, pad):
+def _fwd_candidates(x, w, bias, pad, stats_box=None):
     """-> (key, candidates, variant per candidate): the mathematically identical routings of one forward convolution; variant =
     the library kernel's (chain, pitch48, chain32) flags, None for the vendor routes"""
     hip = _hip_fwd_ok(x, w)
@@ -266,9 +277,19 @@ def _fwd_candidates(x, w, bias, pad):
         variants.append(None)
     n = (1 if hip else 0) + (1 if chain else 0) + (2 if chain and _hip_untimed_ok() else 0)
     for v in _HIP_VARIANTS[:n]:                          # bias fused into the kernel's epilogue
-        cands.append(lambda v=v: _fwd_hip(x, w, pad, bias, *v))
+        cands.append(lambda v=v: _fwd_hip(x, w, pad, bias, *v, stats_box=stats_box))
         variants.append(v)
     return key, cands, variants
+
+
+def _pick_was_hip(key, cands, variants, width: int = 0) -> bool:
+    """did `_pick` return the result of a library-kernel candidate (only then are statistics in the box those of the result)"""
+    if len(cands) == 1 or not torch.cuda.is_available():
+        return isinstance(variants[0], tuple)
+    if not _TUNE:
+        return isinstance(variants[_table_choice(key[0], width, variants)], tuple)
+    i = _cache.get(key)
+    return i is not None and isinstance(variants[i], tuple)
 
 
 def _tuned_variant(key, cands, variants, width: int = 0):
@@ -312,15 +333,23 @@ class _ConvSame(torch.autograd.Function):
     """stride-1 "same" convolution, odd kernel; x already in the compute dtype, w / bias in any dtype (fp32 masters under autocast)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, want_stats=False):
         from .linear import _masters
         w, bias = _masters(ctx, x, w, bias)              # fp32 masters -> the step's 16-bit copies; gradients go back in fp32
         ctx.save_for_backward(x, w)
-        key, cands, variants = _fwd_candidates(x, w, bias, w.shape[2] // 2)
-        return _pick(key, cands, variants, x.shape[4])
+        box = [] if want_stats else None
+        key, cands, variants = _fwd_candidates(x, w, bias, w.shape[2] // 2, box)
+        out = _pick(key, cands, variants, x.shape[4])
+        ctx.with_stats = bool(want_stats)
+        if not want_stats:
+            return out
+        # (the tuner may have run several candidates: the last launch is the one whose result is returned)
+        stats = box[-1] if box and _pick_was_hip(key, cands, variants, x.shape[4]) else out.new_empty(0, dtype=torch.float32)
+        ctx.mark_non_differentiable(stats)
+        return out, stats
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         x, w = ctx.saved_tensors
         pad = w.shape[2] // 2
         from . import ops_raw
@@ -333,7 +362,7 @@ class _ConvSame(torch.autograd.Function):
             dw = _wgrad(x, dy, w, pad, ctx.w_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = linear.bias_grad(dy).to(ctx.b_dtype)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class _ConvSameCat(torch.autograd.Function):
@@ -343,14 +372,14 @@ class _ConvSameCat(torch.autograd.Function):
     for the whole layer: the weight gradient is assembled by one cat instead of autograd's zero-fill + copy + add per slice."""
 
     @staticmethod
-    def forward(ctx, w, *xs):
+    def forward(ctx, want_stats, w, *xs):
         from .param_bank import low_precision
         ctx.w_dtype = w.dtype
         w = low_precision(w, xs[0].dtype)
         pad = w.shape[2] // 2
         ctx.save_for_backward(w, *xs)
-        out, c0 = None, 0
-        for x in xs:
+        out, c0, stats = None, 0, None
+        for j, x in enumerate(xs):
             wi = w[:, c0:c0 + x.shape[1]]
             c0 += x.shape[1]
             key, cands, variants = _fwd_candidates(x, wi, None, pad)
@@ -359,13 +388,19 @@ class _ConvSameCat(torch.autograd.Function):
                 continue
             v = _tuned_variant(key, cands, variants, x.shape[4]) if wi.shape[0] % _BLOCK == 0 else None
             if v is not None:
-                out = _fwd_hip(x, wi, pad, None, *v, into=out)
+                box = [] if (want_stats and j + 1 == len(xs)) else None      # the launch that stores the finished values
+                out = _fwd_hip(x, wi, pad, None, *v, into=out, stats_box=box)
+                stats = box[-1] if box else None
             else:                                        # not tuned yet (this call does it) or a vendor route won
                 out = out + _pick(key, cands, variants, x.shape[4])
-        return out
+        if not want_stats:
+            return out
+        stats = stats if stats is not None else out.new_empty(0, dtype=torch.float32)
+        ctx.mark_non_differentiable(stats)
+        return out, stats
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         w, *xs = ctx.saved_tensors
         pad = w.shape[2] // 2
         from . import ops_raw
@@ -375,24 +410,35 @@ class _ConvSameCat(torch.autograd.Function):
         for i, x in enumerate(xs):
             wi = w[:, c0:c0 + x.shape[1]]
             c0 += x.shape[1]
-            dxs.append(_dgrad(dy, wi, x, pad) if ctx.needs_input_grad[1 + i] else None)
-            if ctx.needs_input_grad[0]:
+            dxs.append(_dgrad(dy, wi, x, pad) if ctx.needs_input_grad[2 + i] else None)
+            if ctx.needs_input_grad[1]:
                 dws.append(_wgrad(x, dy, wi, pad, ctx.w_dtype))
-        dw = torch.cat(dws, dim=1) if ctx.needs_input_grad[0] else None
-        return (dw, *dxs)
+        dw = torch.cat(dws, dim=1) if ctx.needs_input_grad[1] else None
+        return (None, dw, *dxs)
 
 
-def conv3d_same(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
-    """Conv3d(kernel k odd, stride 1, padding k//2).  Follows autocast like `F.conv3d` does."""
+def _unpack_stats(res):
+    y, st = res
+    return y, (st if st.numel() else None)
+
+
+def conv3d_same(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None, want_stats: bool = False):
+    """Conv3d(kernel k odd, stride 1, padding k//2).  Follows autocast like `F.conv3d` does.
+    want_stats: -> (y, stats); stats = the InstanceNorm partials of y for fused_norm.instance_norm_act(y, ..., stats=stats) when the
+    launch that produced y has the statistics epilogue, else None."""
     from . import lib as L
     if not L.on_device(x):
-        return F.conv3d(x, weight, bias, 1, weight.shape[2] // 2)
+        y = F.conv3d(x, weight, bias, 1, weight.shape[2] // 2)
+        return (y, None) if want_stats else y
     if torch.is_autocast_enabled():
         x = x.to(torch.get_autocast_dtype("cuda"))       # the weights stay masters: _ConvSame makes its own copies
-    return _ConvSame.apply(x, weight, bias)
+    if want_stats and _STATS:
+        return _unpack_stats(_ConvSame.apply(x, weight, bias, True))
+    y = _ConvSame.apply(x, weight, bias)
+    return (y, None) if want_stats else y
 
 
-def conv3d_same_cat(xs: Tuple[torch.Tensor, ...], weight: torch.Tensor) -> torch.Tensor:
+def conv3d_same_cat(xs: Tuple[torch.Tensor, ...], weight: torch.Tensor, want_stats: bool = False):
     """conv3d_same(torch.cat(xs, 1), weight) without materialising the concatenation: the convolution is linear in
     its input channels, so it is the sum of convolutions of the parts with the matching weight slices.  (The UNETR
     decoder convolves cat(upsampled, skip), unetr_block.py:82-84; MIOpen's 96 -> 48 @128^3 solver is the 600 ms one.)"""
@@ -402,11 +448,14 @@ def conv3d_same_cat(xs: Tuple[torch.Tensor, ...], weight: torch.Tensor) -> torch
             dt = torch.get_autocast_dtype("cuda")
             xs = tuple(x.to(dt) for x in xs)
         if all(x.dtype == xs[0].dtype for x in xs):
-            return _ConvSameCat.apply(weight, *xs)
+            if want_stats and _STATS:
+                return _unpack_stats(_ConvSameCat.apply(True, weight, *xs))
+            y = _ConvSameCat.apply(False, weight, *xs)
+            return (y, None) if want_stats else y
     out, c0 = None, 0
     for x in xs:
         c = x.shape[1]
         y = conv3d_same(x, weight[:, c0:c0 + c])
         out = y if out is None else out + y
         c0 += c
-    return out
+    return (out, None) if want_stats else out

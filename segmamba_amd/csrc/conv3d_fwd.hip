@@ -59,6 +59,7 @@ struct ConvFwdDev {
     const float* bias;                                    // (cout) or null
     int32_t B, D, H, W, cout, cob0, cin;
     int32_t nxb, ysplit, rows_per_part, ncob;
+    float* stats;                                         // STATS variants: per-workgroup partial sums {sum y, sum y^2} per output channel
 };
 
 // four consecutive outputs of one lane: convert and store, optionally on top of what y holds (a later 48-channel block
@@ -487,7 +488,12 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 // per SIMD) and loses; whole step 61.97 -> 61.6 ms.  The 64-wide kernel ships VAR 11: bit 3 instantiates its row loop once per K
 // part (profiles/r04_conv_chain_perpart.log: 96 -> 96 @64^3 0.345 -> 0.327 ms, 192 -> 192 @32^3 0.377 -> 0.364, 48 -> 48 @128^3 equal).  `s_setprio 1` for the second-dispatched half of the workgroup (the guide's
 // two-waves-per-SIMD section, item 4) measured nothing here (0.605 / 0.612 vs 0.618 / 0.631 ms, profiles/r04_call9_ab.log).
-template <typename T, bool ACC, int CP, int VAR = 0>
+// STATS (round 5): the storing K part also sums y and y^2 of what it stores (the fp32 values, before they are
+// rounded to 16 bits), per output channel, and writes one {count, sum, sum of squares} partial per workgroup and x pair; the
+// InstanceNorm behind this convolution merges D x H / rows x W / 32 partials per instance (Chan's update, segm_instnorm_fwd's
+// `stats_partials`) instead of reading the volume once more.  MEASURED price (profiles/r05_inorm_epilogue.log): none - 48 -> 48
+// @128^3 0.569 vs 0.546 ms, 96 -> 48 @128^3 1.225 vs 1.241 ms with / without; the statistics pass it replaces: ~0.08 ms per 128^3 layer.
+template <typename T, bool ACC, int CP, int VAR = 0, bool STATS = false>
 __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     constexpr bool SKIP = (VAR & 1) != 0;
@@ -576,6 +582,11 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
         return P.y + ((int64_t)b * P.y_sb + (int64_t)(cob * 48 + t * 16) * P.y_sc + (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + x0 +
                       (xp * XT + u) * 16) * (int64_t)sizeof(T);
     };
+    int32_t aoffs[kF48Chunks];                            // aoff without the ky bits
+#pragma unroll
+    for (int c = 0; c < kF48Chunks; ++c) aoffs[c] = aoff[c] & 0x0fffffff;
+    auto chunk_begin = [](int pt) { return pt == 0 ? 0 : 11 + 10 * (pt - 1); };
+    auto chunk_count = [](int pt) { return pt == 0 ? 11 : 10; };
     // VAR bit 3: the row loop is instantiated once per K part (PART >= 0) and entered through a switch - which part starts from the
     // bias, reads / writes hand-off tiles, stores, stages which planes and has an eleventh chunk are then compile-time facts
     // instead of scalar branches in every step (profiles/r04_conv_pmc.log: 1.3 scalar instructions per MFMA)
@@ -595,6 +606,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
         row_park<T, CP>(r[0], ring + (plane_a_ * 4 + ((ya + 8) & 3)) * kSlot * (int)sizeof(T), cl, halo_, unm);
         if (second_) row_park<T, CP>(r[1], ring + (2 * 4 + ((yb + 8) & 3)) * kSlot * (int)sizeof(T), cl, halo_, unm);
     };
+    float st_s[3] = {0.f, 0.f, 0.f}, st_q[3] = {0.f, 0.f, 0.f};       // STATS: this lane's sums over its co of every tile
     for (int s = y0; s < y1 + 3; ++s) {
         const int row = s - prt;                          // this part's output row
         const bool active = row >= y0 && row < y1;
@@ -605,8 +617,31 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
         const T* pl = &xs[0][0][0];
         auto live = [&](int c) { return !SKIP || c + 1 < kF48Chunks || prt == 0; };
         auto load_a = [&](frag8 (&dst)[XT], int c) {
-            const int slot = (row + (aoff[c] >> 28) + 7) & 3;              // input row = row + ky - 1
-            const T* ap = pl + slot * kSlot + (aoff[c] & 0x0fffffff);
+            const T* ap;
+            if constexpr (PART >= 0) {
+                // Round 5: with the K part a compile-time fact the tap row ky of every lane group of every chunk is one too (once
+                // the chunk loop is unrolled): 37 of the 41 chunks lie inside one ky - the ring slot is then SCALAR arithmetic
+                // shared by the chunks of that ky - and the rest split at a known lane group.  Per chunk: one v_add (two selects
+                // more in a split chunk) where the per-lane form below spends five vector instructions (shift, add, and,
+                // multiply-add, and): ~45 of the ~125 vector instructions of a step.
+                const int cb = chunk_begin(PART);
+                int ty[4];
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int k = 32 * (cb + c) + 8 * gg;
+                    const bool lv = c < chunk_count(PART) && k < kF48K;
+                    const int tap = (lv ? k : 32 * cb + 8 * gg) / kFwCi;
+                    ty[gg] = (tap % 9) / 3;
+                }
+                int off = ((row + ty[0] + 7) & 3) * kSlot;                 // scalar
+#pragma unroll
+                for (int gg = 1; gg < 4; ++gg)
+                    if (ty[gg] != ty[gg - 1]) off = g >= gg ? ((row + ty[gg] + 7) & 3) * kSlot : off;
+                ap = pl + off + aoffs[c];
+            } else {
+                const int slot = (row + (aoff[c] >> 28) + 7) & 3;          // input row = row + ky - 1
+                ap = pl + slot * kSlot + (aoff[c] & 0x0fffffff);
+            }
 #pragma unroll
             for (int u = 0; u < XT; ++u) dst[u] = *reinterpret_cast<const frag8*>(ap + u * 16 * CP);
         };
@@ -683,11 +718,31 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] += to_f32(o[q]);
                     }
+                    if constexpr (STATS) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { st_s[t] += v[q]; st_q[t] = fmaf(v[q], v[q], st_q[t]); }
+                    }
                     store4<T, false>(dst, v);
                 }
             }
         }
         __syncthreads();                                  // incoming rows and the hand-off tiles are in LDS
+    }
+    if constexpr (STATS) {
+        if (prt == 3) {                                   // sum over the four lane groups (x within the tiles), lane group 0 writes
+            const int nparts = P.D * P.ysplit * P.nxb * XP, pid = ((z * P.ysplit + ypart) * P.nxb + xb) * XP + xp;
+            const int xlo = x0 + xp * XT * 16;
+            const int nx = P.W - xlo < XT * 16 ? (P.W - xlo > 0 ? P.W - xlo : 0) : XT * 16;
+            const float cnt = (float)((y1 - y0) * nx);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float a_ = st_s[t], q_ = st_q[t];
+                a_ += __shfl_xor(a_, 16, 64); q_ += __shfl_xor(q_, 16, 64);
+                a_ += __shfl_xor(a_, 32, 64); q_ += __shfl_xor(q_, 32, 64);
+                if (g == 0)
+                    reinterpret_cast<float4*>(P.stats)[((int64_t)b * P.cout + cob * 48 + t * 16 + i16) * nparts + pid] = float4{cnt, a_, q_, 0.f};
+            }
+        }
     }
     };
     if constexpr ((VAR & 8) != 0) {
@@ -744,7 +799,7 @@ __device__ __forceinline__ CopyLane copy_lane32(const ConvFwdDev& P, bool halo, 
     return L;
 }
 
-template <typename T, bool ACC, int VAR = 0>
+template <typename T, bool ACC, int VAR = 0, bool STATS = false>
 __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwdDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     constexpr bool SKIP = (VAR & 1) != 0;
@@ -842,6 +897,11 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
         return P.y + ((int64_t)b * P.y_sb + (int64_t)(cob * 48 + t * 16) * P.y_sc + (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + x0 + u * 16) *
                          (int64_t)sizeof(T);
     };
+    int32_t aoffs[kF48Chunks];                            // aoff without the ky bits
+#pragma unroll
+    for (int c = 0; c < kF48Chunks; ++c) aoffs[c] = aoff[c] & 0x0fffffff;
+    auto chunk_begin = [](int pt) { return 10 * pt; };
+    auto chunk_count = [](int pt) { return pt == 3 ? 11 : 10; };
     // VAR bit 3: the row loop once per K part, entered through a switch (see the 64-wide kernel)
     auto steps = [&](auto pc) {
     constexpr int PART = decltype(pc)::value;
@@ -864,6 +924,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
             row_park<T, CP>(r[2], row, clh, true);
         }
     };
+    float st_s[3] = {0.f, 0.f, 0.f}, st_q[3] = {0.f, 0.f, 0.f};       // STATS: this lane's sums over its co of every tile
     for (int s = y0; s < y1 + 3; ++s) {
         const int row = s - prt;                          // this part's output row
         const bool active = row >= y0 && row < y1;
@@ -872,8 +933,31 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
         const T* pl = &xs[0][0][0];
         auto live = [&](int c) { return !SKIP || c + 1 < kF48Chunks || prt == 3; };
         auto load_a = [&](frag8 (&dst)[XT], int c) {
-            const int slot = (row + (aoff[c] >> 28) + 7) & 3;              // input row = row + ky - 1
-            const T* ap = pl + slot * kSlot + (aoff[c] & 0x0fffffff);
+            const T* ap;
+            if constexpr (PART >= 0) {
+                // Round 5: with the K part a compile-time fact the tap row ky of every lane group of every chunk is one too (once
+                // the chunk loop is unrolled): 37 of the 41 chunks lie inside one ky - the ring slot is then SCALAR arithmetic
+                // shared by the chunks of that ky - and the rest split at a known lane group.  Per chunk: one v_add (two selects
+                // more in a split chunk) where the per-lane form below spends five vector instructions (shift, add, and,
+                // multiply-add, and): ~45 of the ~125 vector instructions of a step.
+                const int cb = chunk_begin(PART);
+                int ty[4];
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int k = 32 * (cb + c) + 8 * gg;
+                    const bool lv = c < chunk_count(PART) && k < kF48K;
+                    const int tap = (lv ? k : 32 * cb + 8 * gg) / kFwCi;
+                    ty[gg] = (tap % 9) / 3;
+                }
+                int off = ((row + ty[0] + 7) & 3) * kSlot;                 // scalar
+#pragma unroll
+                for (int gg = 1; gg < 4; ++gg)
+                    if (ty[gg] != ty[gg - 1]) off = g >= gg ? ((row + ty[gg] + 7) & 3) * kSlot : off;
+                ap = pl + off + aoffs[c];
+            } else {
+                const int slot = (row + (aoff[c] >> 28) + 7) & 3;          // input row = row + ky - 1
+                ap = pl + slot * kSlot + (aoff[c] & 0x0fffffff);
+            }
 #pragma unroll
             for (int u = 0; u < XT; ++u) dst[u] = *reinterpret_cast<const frag8*>(ap + u * 16 * CP);
         };
@@ -944,6 +1028,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
 #pragma unroll
                             for (int q = 0; q < 4; ++q) v[q] += to_f32(o[q]);
                         }
+                        if constexpr (STATS) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { st_s[t] += v[q]; st_q[t] = fmaf(v[q], v[q], st_q[t]); }
+                        }
                         store4<T, false>(reinterpret_cast<T*>(ybase(row, t, u) + ylane), v);
                     }
                 }
@@ -952,6 +1040,21 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
         SEGM_SCHED_FENCE();
         park_s(r, s);
         __syncthreads();                                  // incoming rows and the hand-off tiles are in LDS
+    }
+    if constexpr (STATS) {
+        if (prt == 3) {
+            const int nparts = P.D * P.ysplit * P.nxb, pid = (z * P.ysplit + ypart) * P.nxb + xb;
+            const int nx = P.W - x0 < kC32XB ? (P.W - x0 > 0 ? P.W - x0 : 0) : kC32XB;
+            const float cnt = (float)((y1 - y0) * nx);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float a_ = st_s[t], q_ = st_q[t];
+                a_ += __shfl_xor(a_, 16, 64); q_ += __shfl_xor(q_, 16, 64);
+                a_ += __shfl_xor(a_, 32, 64); q_ += __shfl_xor(q_, 32, 64);
+                if (g == 0)
+                    reinterpret_cast<float4*>(P.stats)[((int64_t)b * P.cout + cob * 48 + t * 16 + i16) * nparts + pid] = float4{cnt, a_, q_, 0.f};
+            }
+        }
     }
     };
     if constexpr ((VAR & 8) != 0) {
@@ -993,6 +1096,13 @@ static void launch48(const ConvFwdDev& P, dim3 grid, bool f16, bool acc, hipStre
     // the accumulate variant keeps the old outputs of a row in flight during its MFMAs: fragments ONE chunk ahead there (V & ~2)
 #define SEGM_LV(T, V) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, true, 48, (V) & ~2>), grid, dim3(512), 0, stream, P); \
                         else hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, false, 48, V>), grid, dim3(512), 0, stream, P); } while (0)
+        if (P.stats) {                                  // + the statistics epilogue of the storing K part
+#define SEGM_LS(T) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, true, 48, 11 & ~2, true>), grid, dim3(512), 0, stream, P); \
+                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, false, 48, 11, true>), grid, dim3(512), 0, stream, P); } while (0)
+            if (f16) SEGM_LS(f16_t); else SEGM_LS(bf16_t);
+#undef SEGM_LS
+            return;
+        }
         if (f16) SEGM_LV(f16_t, 11); else SEGM_LV(bf16_t, 11);       // the 64-wide kernel: also instantiated per K part (bit 3)
 #undef SEGM_LV
         return;
@@ -1010,6 +1120,14 @@ static void launch48(const ConvFwdDev& P, dim3 grid, bool f16, bool acc, hipStre
 }  // namespace segm
 
 using namespace segm;
+
+extern "C" int32_t segm_conv3d_k3_fwd_stats_parts(int32_t depth, int32_t height, int32_t width, int32_t batch, int32_t cout, int32_t flags) {
+    if (depth <= 0 || height <= 0 || width <= 0 || batch <= 0 || cout <= 0) return 0;
+    const bool chain32 = (flags & SEGM_CONV_FWD_CHAIN32) != 0;
+    if (!chain32 && !(flags & SEGM_CONV_FWD_CHAIN)) return 0;
+    const FwPlan pl = fwd_plan(batch, cout, depth, height, width, true, chain32 ? kC32XB : kFwXB);
+    return depth * pl.ysplit * pl.nxb * (chain32 ? 1 : 2);
+}
 
 extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     if (!a) return SEGM_E_NULL;
@@ -1042,6 +1160,13 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     hipStream_t stream = (hipStream_t)a->stream;
     const bool f16 = a->dtype == SEGM_F16;
     const bool acc = (a->flags & SEGM_CONV_FWD_ACCUMULATE) != 0;
+    if (a->stats_partials) {
+        // the statistics epilogue exists in the shipped schedules of the two chained kernels (unpadded 64-wide, 32-wide)
+        const bool c64 = (a->flags & SEGM_CONV_FWD_CHAIN) && (a->flags & SEGM_CONV_FWD_PITCH48) && chain_var() != 0;
+        if (!(c64 || chain32) || a->cout % 48 != 0) return SEGM_E_SHAPE;
+        if (a->stats_nparts != segm_conv3d_k3_fwd_stats_parts(a->depth, a->height, a->width, a->batch, a->cout, a->flags)) return SEGM_E_WORKSPACE;
+        P.stats = a->stats_partials;
+    }
     // the 48-channel kernels address a row as [uniform base + 32-bit lane offset]: 48 channel strides must fit
     const bool off32 = ((int64_t)47 * a->x_stride_c + a->width) * 2 < ((int64_t)1 << 32);
     if ((a->flags & (SEGM_CONV_FWD_CHAIN | SEGM_CONV_FWD_CHAIN32)) && !off32) return SEGM_E_SHAPE;
@@ -1051,6 +1176,13 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
 #define SEGM_L32(T, A) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, A>), grid, dim3(256), 0, stream, P)
 #define SEGM_LV(T, V) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, true, V>), grid, dim3(256), 0, stream, P); \
                         else hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, false, V>), grid, dim3(256), 0, stream, P); } while (0)
+        if (P.stats) {                                  // + the statistics epilogue of the storing K part
+#define SEGM_LS(T) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, true, 9, true>), grid, dim3(256), 0, stream, P); \
+                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, false, 9, true>), grid, dim3(256), 0, stream, P); } while (0)
+            if (f16) SEGM_LS(f16_t); else SEGM_LS(bf16_t);
+#undef SEGM_LS
+            return (int)hipGetLastError();
+        }
         if (chain_var() != 0) {
             if (f16) SEGM_LV(f16_t, 9); else SEGM_LV(bf16_t, 9);     // two chunks ahead measured nothing here (profiles/r04_conv_chain32_pf2.log)     // 9: skip + per-part loop, fragments one chunk ahead (two ahead spills here)
             return (int)hipGetLastError();

@@ -33,6 +33,8 @@ struct NormDev {
     int32_t nsplit;
     int32_t act;           // 0 none, 1 relu, 2 leaky relu
     float slope, eps;
+    const float4* ext;     // forward: {count, sum, sum of squares, -} partials summed by the producer of x (conv3d_fwd.hip), or null
+    int32_t next;          // per instance
 };
 
 // sum over the workgroup of two values; result valid in every thread
@@ -85,6 +87,52 @@ __device__ __forceinline__ float2 merge_stats(const NormDev& P, int inst, float2
     return r;
 }
 
+// Chan's update of (count, mean, M2) by another such triple (either may be empty)
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float on, float omean, float om2) {
+    if (on <= 0.f) return;
+    if (n <= 0.f) { n = on; mean = omean; m2 = om2; return; }
+    const float d = omean - mean, nt = n + on;
+    mean += d * (on / nt);
+    m2 += om2 + d * d * (n * on / nt);
+    n = nt;
+}
+
+// the same merge over partials the PRODUCER of x summed (round 5: the statistics epilogue of the chained convolution kernels;
+// hundreds of small partials per instance, not <= 64 slabs): every thread folds its strided share, the waves merge by a
+// butterfly, thread 0 folds the waves - a fixed order, every thread gets the result
+__device__ __forceinline__ float2 merge_ext(const NormDev& P, int inst, float2* lds) {
+    __shared__ float wsum[kWavesPerBlock][3];
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    const float4* p = P.ext + (int64_t)inst * P.next;
+    for (int i = threadIdx.x; i < P.next; i += kBlock) {
+        const float4 v = p[i];
+        if (v.x > 0.f) {
+            const float ms = v.y / v.x;
+            chan_merge(n, mean, m2, v.x, ms, fmaxf(v.z - v.y * ms, 0.f));
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float on = __shfl_xor(n, m), om = __shfl_xor(mean, m), o2 = __shfl_xor(m2, m);
+        // both partners must fold in the SAME order (lower lane first), or the two halves of the butterfly drift apart by rounding
+        if ((threadIdx.x & m) == 0) chan_merge(n, mean, m2, on, om, o2);
+        else { float a = on, b = om, c = o2; chan_merge(a, b, c, n, mean, m2); n = a; mean = b; m2 = c; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { wsum[wave][0] = n; wsum[wave][1] = mean; wsum[wave][2] = m2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tn = 0.f, tm = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) chan_merge(tn, tm, t2, wsum[w][0], wsum[w][1], wsum[w][2]);
+        lds[0] = make_float2(tm, 1.0f / sqrtf(t2 / tn + P.eps));
+    }
+    __syncthreads();
+    const float2 r = lds[0];
+    __syncthreads();
+    return r;
+}
+
 template <typename T, bool VEC>
 __global__ void __launch_bounds__(kBlock) inorm_fwd_stats_kernel(NormDev P) {
     using Pk = Pack<T, VEC>;
@@ -125,7 +173,7 @@ __global__ void __launch_bounds__(kBlock) inorm_fwd_apply_kernel(NormDev P) {
     using Pk = Pack<T, VEC>;
     __shared__ float2 lds[kWavesPerBlock];
     const int split = blockIdx.x, inst = blockIdx.y;
-    const float2 st = merge_stats(P, inst, lds);
+    const float2 st = P.ext ? merge_ext(P, inst, lds) : merge_stats(P, inst, lds);
     const float mean = st.x, rstd = st.y;
     if (split == 0 && threadIdx.x == 0) { P.mean[inst] = mean; P.rstd[inst] = rstd; }
     const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.xs;
@@ -285,10 +333,10 @@ template <typename T>
 static int launch_norm_fwd(NormDev& P, int instances, bool vec, hipStream_t st) {
     dim3 grid(P.nsplit, instances);
     if (vec) {
-        hipLaunchKernelGGL((inorm_fwd_stats_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
+        if (!P.ext) hipLaunchKernelGGL((inorm_fwd_stats_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
         hipLaunchKernelGGL((inorm_fwd_apply_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
     } else {
-        hipLaunchKernelGGL((inorm_fwd_stats_kernel<T, false>), grid, dim3(kBlock), 0, st, P);
+        if (!P.ext) hipLaunchKernelGGL((inorm_fwd_stats_kernel<T, false>), grid, dim3(kBlock), 0, st, P);
         hipLaunchKernelGGL((inorm_fwd_apply_kernel<T, false>), grid, dim3(kBlock), 0, st, P);
     }
     return (int)hipGetLastError();
@@ -336,6 +384,10 @@ extern "C" int segm_instnorm_fwd(const segm_instnorm_fwd_args* a) {
     P.x = a->x; P.res = a->residual; P.y = a->y; P.mean = a->mean; P.rstd = a->rstd;
     P.part = (float2*)a->workspace;
     P.S = a->spatial; P.act = a->act; P.slope = a->slope; P.eps = a->eps;
+    if (a->stats_partials) {
+        if (a->stats_nparts <= 0 || ((uintptr_t)a->stats_partials & 15)) return SEGM_E_SHAPE;
+        P.ext = (const float4*)a->stats_partials; P.next = a->stats_nparts;
+    }
     if (!norm_stride(a->x_instance_stride, a->spatial, P.xs) || !norm_stride(a->residual_instance_stride, a->spatial, P.rs) ||
         !norm_stride(a->y_instance_stride, a->spatial, P.ys))
         return SEGM_E_SHAPE;

@@ -28,7 +28,7 @@ class _InstNormAct(torch.autograd.Function):
     """y = act(IN(x) + residual) through segm_instnorm_fwd / segm_instnorm_bwd."""
 
     @staticmethod
-    def forward(ctx, x, residual, act, slope, eps):
+    def forward(ctx, x, residual, act, slope, eps, stats=None):
         from . import lib as L, ops_raw
         if not ops_raw.channel_dense(x):                 # a convolution output with a padded channel stride is taken as it is
             x = x.contiguous()
@@ -36,7 +36,7 @@ class _InstNormAct(torch.autograd.Function):
             residual = residual.to(x.dtype)
             if not ops_raw.channel_dense(residual):
                 residual = residual.contiguous()
-        y, mean, rstd = ops_raw.instnorm_fwd(L.get_lib(), x, residual, act, slope, eps)
+        y, mean, rstd = ops_raw.instnorm_fwd(L.get_lib(), x, residual, act, slope, eps, stats=stats)
         need_y = residual is not None and act != "none"
         ctx.save_for_backward(x, mean, rstd, y if need_y else None)
         ctx.cfg = (act, slope, residual is not None)
@@ -49,20 +49,21 @@ class _InstNormAct(torch.autograd.Function):
         act, slope, has_res = ctx.cfg
         dx, dres = ops_raw.instnorm_bwd(L.get_lib(), x, dy, mean, rstd, y, act, slope,
                                         want_dresidual=has_res and ctx.needs_input_grad[1])
-        return dx, dres, None, None, None
+        return dx, dres, None, None, None, None
 
 
 def instance_norm_act(x: torch.Tensor, act: str = "none", slope: float = 0.01, eps: float = 1e-5,
-                      residual: torch.Tensor | None = None) -> torch.Tensor:
+                      residual: torch.Tensor | None = None, stats: torch.Tensor | None = None) -> torch.Tensor:
     """y = act(IN(x) [+ residual]) for x of shape (B, C, D, H, W).
 
-    act in {"none", "relu", "leaky_relu"}.
+    act in {"none", "relu", "leaky_relu"}.  stats: the partial {count, sum, sum of squares} the convolution that produced x summed
+    in its epilogue (conv3d.conv3d_same(..., want_stats=True)): the statistics pass over x is skipped.
     """
     if act not in ("none", "relu", "leaky_relu"):
         raise ValueError(f"unknown activation {act!r}")
     from . import lib as L
     if L.on_device(x):
-        return _InstNormAct.apply(x, residual, act, slope, eps)
+        return _InstNormAct.apply(x, residual, act, slope, eps, stats)
     y = F.instance_norm(x, eps=eps)
     if residual is not None:
         y = y + residual

@@ -104,6 +104,7 @@ class Conv3dFwdArgs(C.Structure):
         ("y", C.c_void_p), ("y_stride_b", C.c_int64), ("y_stride_c", C.c_int64), ("y_stride_z", C.c_int64),
         ("y_stride_y", C.c_int64),
         ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("stream", C.c_void_p),
+        ("stats_partials", C.c_void_p), ("stats_nparts", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -114,6 +115,7 @@ class InstNormFwdArgs(C.Structure):
         ("x", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
         ("x_instance_stride", C.c_int64), ("residual_instance_stride", C.c_int64), ("y_instance_stride", C.c_int64),
+        ("stats_partials", C.c_void_p), ("stats_nparts", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 
@@ -252,7 +254,7 @@ EXPORTS = (
     "segm_selective_scan_bwd_deterministic",
     "segm_selective_scan_fwd_multi", "segm_selective_scan_bwd_multi", "segm_causal_conv1d_fwd_multi", "segm_causal_conv1d_bwd_multi",
     "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
-    "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes", "segm_conv3d_k3_fwd",
+    "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes", "segm_conv3d_k3_fwd", "segm_conv3d_k3_fwd_stats_parts",
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add", "segm_depth_to_space2",
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
@@ -316,6 +318,7 @@ class SegmLib:
         sig("segm_conv3d_k3_wgrad", [C.POINTER(Conv3dWgradArgs)], C.c_int)
         sig("segm_conv3d_k3_wgrad_workspace_bytes", [C.c_int32] * 6, C.c_size_t)
         sig("segm_conv3d_k3_fwd", [C.POINTER(Conv3dFwdArgs)], C.c_int)
+        sig("segm_conv3d_k3_fwd_stats_parts", [C.c_int32] * 6, C.c_int32)
         sig("segm_instnorm_fwd", [C.POINTER(InstNormFwdArgs)], C.c_int)
         sig("segm_instnorm_bwd", [C.POINTER(InstNormBwdArgs)], C.c_int)
         sig("segm_instnorm_workspace_bytes", [C.c_int32, C.c_int64], C.c_size_t)

@@ -433,11 +433,13 @@ CONV_FWD_ACCUMULATE, CONV_FWD_CHAIN, CONV_FWD_PITCH48, CONV_FWD_CHAIN32 = 1, 2, 
 
 def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None, accumulate: bool = False, chain: bool = False,
-                  pitch48: bool = False, chain32: bool = False) -> torch.Tensor:
+                  pitch48: bool = False, chain32: bool = False, want_stats: bool = False):
     """y (B, Cout, D, H, W) = conv3d(x, w, bias, stride 1, padding 1); x (B, <= 48, D, H, W) bf16 / fp16, w_packed from
     pack_conv3d_weight().  `out` + `accumulate`: add to an existing result (the next 48-channel block of a wider
     layer; Cout % 48 == 0).  `chain`: the pipelined-K-parts kernel (Cout % 48 == 0); `pitch48`: its unpadded LDS layout; `chain32`: the
-    same pipeline on 32-wide x blocks, two workgroups per CU (exclusive with `chain`)."""
+    same pipeline on 32-wide x blocks, two workgroups per CU (exclusive with `chain`).
+    want_stats (chain + pitch48, or chain32): -> (y, stats), stats = fp32 (B, Cout, nparts, 4) partial {count, sum, sum of squares, -}
+    of what this launch stored, for instnorm_fwd(..., stats=stats); (y, None) when the launch has no statistics epilogue."""
     cout = w_packed.shape[0]
     if not conv3d_k3_fwd_supported(x, cout):
         raise RuntimeError("conv3d_k3_fwd: unsupported shape / dtype / layout")
@@ -471,8 +473,14 @@ def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias:
     a.y_stride_b, a.y_stride_c, a.y_stride_z, a.y_stride_y = y.stride()[:4]
     a.bias = bias.data_ptr() if bias is not None else None
     a.stream = L.stream_handle(x)
+    stats = None
+    if want_stats and ((chain and pitch48) or chain32):
+        nparts = lib.dll.segm_conv3d_k3_fwd_stats_parts(D, H, W, B, cout, a.flags)
+        if nparts > 0:
+            stats = torch.empty(B, cout, nparts, 4, dtype=torch.float32, device=x.device)
+            a.stats_partials, a.stats_nparts = stats.data_ptr(), nparts
     lib.check(lib.dll.segm_conv3d_k3_fwd(a), "conv3d_k3_fwd")
-    return y
+    return (y, stats) if want_stats else y
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -541,9 +549,14 @@ def _norm_geom(x):
     return inst, x.numel() // inst
 
 
-def instnorm_fwd(lib: L.SegmLib, x, residual=None, act="none", slope=0.01, eps=1e-5):
-    """-> (y, mean, rstd): y = act(IN(x) + residual); mean / rstd fp32 (B * C)."""
+def instnorm_fwd(lib: L.SegmLib, x, residual=None, act="none", slope=0.01, eps=1e-5, stats=None):
+    """-> (y, mean, rstd): y = act(IN(x) + residual); mean / rstd fp32 (B * C).
+    stats: fp32 (B, C, nparts, 4) of {count, sum, sum of squares, -} partials summed by the producer of x (conv3d_k3_fwd's `stats`):
+    the statistics pass over x is skipped."""
     inst, S = _norm_geom(x)
+    if stats is not None and (stats.dtype != torch.float32 or stats.dim() != 4 or stats.shape[0] * stats.shape[1] != inst or
+                              stats.shape[3] != 4 or not stats.is_contiguous() or stats.device != x.device):
+        raise RuntimeError("instnorm: stats must be a contiguous fp32 (B, C, nparts, 4) tensor on x's device")
     if residual is not None and (residual.shape != x.shape or residual.dtype != x.dtype or not channel_dense(residual)):
         raise RuntimeError("instnorm: residual must match x (shape, dtype, dense channels)")
     a = L.InstNormFwdArgs()
@@ -559,6 +572,8 @@ def instnorm_fwd(lib: L.SegmLib, x, residual=None, act="none", slope=0.01, eps=1
     a.x, a.residual, a.y = x.data_ptr(), (residual.data_ptr() if residual is not None else None), y.data_ptr()
     a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
     a.workspace, a.workspace_bytes, a.stream = ws.data_ptr(), ws_bytes, L.stream_handle(x)
+    if stats is not None:
+        a.stats_partials, a.stats_nparts = stats.data_ptr(), stats.shape[2]
     lib.check(lib.dll.segm_instnorm_fwd(a), "instnorm_fwd")
     return y, mean, rstd
 

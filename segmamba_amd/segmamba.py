@@ -82,9 +82,10 @@ class GSC(nn.Module):
         self.nonliner4 = nn.ReLU()
 
     def forward(self, x):
-        x1 = fused_norm.instance_norm_act(conv3d_same(x, self.proj.weight, self.proj.bias), act="relu", eps=self.norm.eps)
-        x1 = fused_norm.instance_norm_act(conv3d_same(x1, self.proj2.weight, self.proj2.bias), act="relu",
-                                          eps=self.norm2.eps)
+        x1, st = conv3d_same(x, self.proj.weight, self.proj.bias, want_stats=True)
+        x1 = fused_norm.instance_norm_act(x1, act="relu", eps=self.norm.eps, stats=st)
+        x1, st = conv3d_same(x1, self.proj2.weight, self.proj2.bias, want_stats=True)
+        x1 = fused_norm.instance_norm_act(x1, act="relu", eps=self.norm2.eps, stats=st)
         x2 = fused_norm.instance_norm_act(fused_norm.pointwise_conv3d(x, self.proj3.weight, self.proj3.bias),
                                           act="relu", eps=self.norm3.eps)
         y = fused_norm.instance_norm_act(fused_norm.pointwise_conv3d(x1 + x2, self.proj4.weight, self.proj4.bias),

@@ -70,8 +70,17 @@ class ConvOnly(nn.Sequential):
         self._transposed = transposed
         self._same = (not transposed) and stride == 1 and kernel_size == 3
 
-    def forward(self, x) -> torch.Tensor:
-        """`x` may be a tuple of tensors standing for their channel concatenation (never materialised)."""
+    def forward(self, x, want_stats: bool = False):
+        """`x` may be a tuple of tensors standing for their channel concatenation (never materialised).
+        want_stats: -> (y, stats) with the InstanceNorm partials the convolution summed in its epilogue, or None (conv3d.py)."""
+        if want_stats:
+            if self._same and not (not isinstance(x, (tuple, list)) and self.conv.weight.shape[1] <= 4):
+                if isinstance(x, (tuple, list)):
+                    if self.conv.bias is None:
+                        return conv3d_same_cat(tuple(x), self.conv.weight, want_stats=True)
+                else:
+                    return conv3d_same(x, self.conv.weight, self.conv.bias, want_stats=True)
+            return self.forward(x), None
         if isinstance(x, (tuple, list)):
             weight = self.conv.weight                    # sliced per part: the Functions copy the slices they are given
             if self._same and self.conv.bias is None:
@@ -129,16 +138,16 @@ class UnetResBlock(nn.Module):
 
     def forward(self, inp) -> torch.Tensor:
         """`inp`: a tensor, or a tuple of tensors meaning their channel concatenation (decoder: (upsampled, skip))."""
-        out = self.conv1(inp)
-        out = fused_norm.instance_norm_act(out, act="leaky_relu", slope=self.NEG_SLOPE, eps=self.norm1.eps)
-        out = self.conv2(out)
+        out, st = self.conv1(inp, want_stats=True)
+        out = fused_norm.instance_norm_act(out, act="leaky_relu", slope=self.NEG_SLOPE, eps=self.norm1.eps, stats=st)
+        out, st = self.conv2(out, want_stats=True)
         if self.downsample:
             residual = fused_norm.instance_norm_act(self.conv3(inp), act="none", eps=self.norm3.eps)
         else:
             residual = torch.cat(tuple(inp), dim=1) if isinstance(inp, (tuple, list)) else inp
         # IN(out) + residual -> LeakyReLU, one pass
         return fused_norm.instance_norm_act(out, act="leaky_relu", slope=self.NEG_SLOPE, eps=self.norm2.eps,
-                                            residual=residual)
+                                            residual=residual, stats=st)
 
 
 class UnetrBasicBlock(nn.Module):

@@ -1677,3 +1677,77 @@ def test_conv3d_k3_wgrad_items_per_workgroup_emulated(emu, monkeypatch, ipw):
     monkeypatch.setenv("SEGM_WGRAD_V1", "1")
     dw1 = ops_raw.conv3d_k3_wgrad(emu, x, dy, torch.float32)
     assert (dw1 - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-4
+
+
+@pytest.mark.parametrize("variant,shape", [("chain48", (2, 48, 48, 2, 5, 64)), ("chain48", (1, 96, 48, 2, 3, 72)), ("chain32", (1, 48, 96, 2, 4, 32)),
+                                           ("chain32", (1, 96, 48, 1, 9, 40))])
+def test_conv3d_statistics_epilogue_feeds_instnorm_emulated(emu, variant, shape):
+    """round 5: the chained 3x3x3 kernels sum {count, y, y^2} of what their storing K part writes (per workgroup and x pair); the
+    InstanceNorm behind the convolution merges those partials instead of reading the volume again.  Same y as without the epilogue;
+    the partials add up to the volume's sums; instnorm_fwd(stats=...) == instnorm_fwd() to rounding (the partials sum the fp32
+    values before they are rounded to bf16)."""
+    B, cin, cout, D, H_, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, cin, D, H_, W, generator=g).bfloat16()
+    w = (0.1 * torch.randn(cout, cin, 3, 3, 3, generator=g)).bfloat16()
+    kw = dict(chain=True, pitch48=True) if variant == "chain48" else dict(chain32=True)
+    out = ref = stats = None
+    blocks = list(range(0, cin, 48))
+    for i, c0 in enumerate(blocks):
+        wp = ops_raw.pack_conv3d_weight(w[:, c0:c0 + 48])
+        ref = ops_raw.conv3d_k3_fwd(emu, x[:, c0:c0 + 48], wp, None, out=ref, accumulate=i > 0, **kw)
+        if i + 1 < len(blocks):
+            out = ops_raw.conv3d_k3_fwd(emu, x[:, c0:c0 + 48], wp, None, out=out, accumulate=i > 0, **kw)
+        else:
+            out, stats = ops_raw.conv3d_k3_fwd(emu, x[:, c0:c0 + 48], wp, None, out=out, accumulate=i > 0, want_stats=True, **kw)
+    assert torch.equal(out, ref) and stats is not None and stats.shape[:2] == (B, cout) and stats.shape[3] == 4
+    yf = torch.nn.functional.conv3d(x.float(), w.float(), None, 1, 1)
+    assert torch.equal(stats[..., 0].sum(-1), torch.full((B, cout), float(D * H_ * W)))
+    # later 48-channel blocks add to the ROUNDED result of the earlier ones: the sums are those of the stored values up to that rounding
+    tol = 2e-2 if len(blocks) > 1 else 2e-5
+    assert (stats[..., 1].sum(-1) - yf.sum((2, 3, 4))).abs().max() <= tol * yf.abs().sum((2, 3, 4)).max()
+    assert (stats[..., 2].sum(-1) - (yf * yf).sum((2, 3, 4))).abs().max() <= tol * (yf * yf).sum((2, 3, 4)).max()
+    y0, m0, r0 = ops_raw.instnorm_fwd(emu, out, None, "leaky_relu", 0.01, 1e-5)
+    y1, m1, r1 = ops_raw.instnorm_fwd(emu, out, None, "leaky_relu", 0.01, 1e-5, stats=stats)
+    assert (m0 - m1).abs().max() <= 3e-3 * out.float().abs().max() and (r0 / r1 - 1).abs().max() <= 3e-3
+    assert (y0.float() - y1.float()).abs().max() <= 3e-2
+
+
+@pytest.mark.parametrize("cat_fused", [False, True])
+def test_unet_res_block_with_statistics_from_the_convolutions_emulated(emu, monkeypatch, cat_fused):
+    """round 5: UnetResBlock forward + backward with the InstanceNorm statistics summed in the convolutions' epilogues (conv3d._STATS,
+    the default) against the same block with every InstanceNorm making its own pass: outputs and all gradients agree to the
+    rounding of the statistics (fp32 sums before vs after the bf16 rounding of the activations), and the statistics launches
+    really are skipped (two of the block's three InstanceNorms follow a 3x3x3 convolution; with the cat convolution as one node -
+    SEGM_CONV_CAT_FUSED - the one behind the concatenated input too)."""
+    from segmamba_amd import lib as L, unet_blocks as UB, conv3d as C3
+    monkeypatch.setattr(L, "get_lib", lambda: emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest: cands[-1]())     # the library's candidates: chain32 is the last variant
+    monkeypatch.setattr(C3, "_pick_was_hip", lambda *a: True)
+    monkeypatch.setattr(C3, "_tuned_variant", lambda key, cands, variants, width=0: variants[-1])
+    monkeypatch.setattr(C3, "_CAT_FUSED", cat_fused)
+    torch.manual_seed(3)
+    blk = UB.UnetResBlock(96, 48).bfloat16()
+    g = torch.Generator().manual_seed(9)
+    xa = torch.randn(1, 48, 2, 4, 64, generator=g).bfloat16()
+    xb = torch.randn(1, 48, 2, 4, 64, generator=g).bfloat16()
+    dy = torch.randn(1, 48, 2, 4, 64, generator=g).bfloat16()
+    res, used = [], []
+    real = ops_raw.instnorm_fwd
+    monkeypatch.setattr(ops_raw, "instnorm_fwd", lambda *a, **k: (used.append(k.get("stats") is not None), real(*a, **k))[1])
+    for stats in (False, True):
+        monkeypatch.setattr(C3, "_STATS", stats)
+        used.clear()
+        a, b = xa.clone().requires_grad_(), xb.clone().requires_grad_()
+        blk.zero_grad()
+        y = blk((a, b))
+        y.backward(dy)
+        res.append([y.detach().clone(), a.grad.clone(), b.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
+        assert used == ([False, False, False] if not stats else ([True, False, True] if cat_fused else [False, False, True])), used
+    for u, v in zip(*res):
+        # a pre-activation that sits at the LeakyReLU kink may change sides with the last bit of the statistics: compare in the bulk
+        # (each such flip changes that voxel's gradient a hundredfold, and the data gradient spreads it over 27 neighbours: in this
+        # 512-voxel volume a handful of flips are ~1 % of a gradient tensor; the forward output must agree everywhere)
+        bad = ((u.float() - v.float()).abs() > 2e-2 * max(1.0, float(u.float().abs().max()))).float().mean()
+        assert bad <= (0.0 if u is res[0][0] else 2e-2), float(bad)

@@ -335,6 +335,31 @@ def test_selective_scan_backward_native_dbc_channel_first(hip):
         assert (r0[k] - rl[k]).abs().max() <= 1e-3 * rl[k].abs().max() + 1e-4, k
 
 
+@pytest.mark.parametrize("variant,S,bias", [("chain48", 128, 0.0), ("chain48", 128, 3.0), ("chain32", 64, 0.0), ("chain32", 32, 2.0)])
+def test_conv_statistics_epilogue_against_fp64(hip, variant, S, bias):
+    """round 5: InstanceNorm statistics summed in the convolution's epilogue, at 2 M voxels per instance
+    (128^3; and the 32-wide kernel's shapes), against fp64 statistics of the volume the convolution stored: the mean within 2e-4 of
+    the standard deviation, 1 / std within 2e-4 relative - also with a mean three standard deviations off zero (a bias), where a
+    sum-of-squares form loses the most; the normalised output equals the library's own-pass result within one bf16 step."""
+    torch.manual_seed(S + int(bias))
+    x = torch.randn(2, 48, S, S, S, device=DEV).bfloat16()
+    w = (0.04 * torch.randn(48, 48, 3, 3, 3, device=DEV)).bfloat16()
+    b = torch.full((48,), bias, device=DEV) if bias else None
+    wp = ops_raw.pack_conv3d_weight(w)
+    kw = dict(chain=True, pitch48=True) if variant == "chain48" else dict(chain32=True)
+    y, stats = ops_raw.conv3d_k3_fwd(hip, x, wp, b, want_stats=True, **kw)
+    assert stats is not None and torch.equal(y, ops_raw.conv3d_k3_fwd(hip, x, wp, b, **kw))
+    assert float(stats[..., 0].sum(-1).min()) == float(stats[..., 0].sum(-1).max()) == float(S ** 3)
+    yd = y.double()
+    mean64, var64 = yd.mean((2, 3, 4)).flatten(), yd.var((2, 3, 4), unbiased=False).flatten()
+    y1, m1, r1 = ops_raw.instnorm_fwd(hip, y, None, "leaky_relu", 0.01, 1e-5, stats=stats)
+    y0, m0, r0 = ops_raw.instnorm_fwd(hip, y, None, "leaky_relu", 0.01, 1e-5)
+    std64 = (var64 + 1e-5).sqrt()
+    assert ((m1.double() - mean64).abs() / std64).max() <= 2e-4, float(((m1.double() - mean64).abs() / std64).max())
+    assert (r1.double() * std64 - 1).abs().max() <= 2e-4, float((r1.double() * std64 - 1).abs().max())
+    assert (y1.float() - y0.float()).abs().max() <= 2.0 ** -7 * max(1.0, float(y0.float().abs().max()))
+
+
 def test_error_behaviour(hip):
     """reference TORCH_CHECKs (selective_scan.cpp:233-303, causal_conv1d.cpp:136-170) surface as RuntimeError."""
     x = torch.randn(1, 8, 16, device=DEV)
