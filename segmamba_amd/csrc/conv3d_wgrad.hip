@@ -522,8 +522,8 @@ static bool wgrad_v1() {
 }
 static WgPlan wgrad_plan(int batch, int cin, int cout, int d, int h, int w) {
     WgPlan p;
-    const char* nq_s = getenv("SEGM_WGRAD_NQ");           // experiments: 1 = 32-wide x blocks everywhere (tools/r05/wgrad_ab.py)
-    p.nq = (w % 64 == 0 && !(nq_s && atoi(nq_s) == 1)) ? 2 : 1;
+    p.nq = (w % 64 == 0) ? 2 : 1;                         // (32-wide blocks everywhere, three workgroups per CU: measured, 0.63 / 1.10 ms
+                                                          // against 0.50 ms at 48 -> 48 @128^3 - profiles/r05_wgrad_ab3.log)
     p.nxb = (w + 32 * p.nq - 1) / (32 * p.nq);
     const int64_t blocks = (int64_t)3 * ((cout + kWgCo - 1) / kWgCo) * ((cin + kWgBlock - 1) / kWgBlock);
     const int64_t wgs = (int64_t)batch * d * p.nxb * blocks;
@@ -601,8 +601,6 @@ extern "C" int segm_conv3d_k3_wgrad(const segm_conv3d_wgrad_args* a) {
                 if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_v1_kernel<bf16_t, 2>), grid, dim3(kWgThreads), 0, stream, P);
                 else hipLaunchKernelGGL((conv3d_k3_wgrad_v1_kernel<bf16_t, 1>), grid, dim3(kWgThreads), 0, stream, P);
             }
-        } else if (pl.nq == 1 && a->dtype == SEGM_BF16 && getenv("SEGM_WGRAD_OCC") && atoi(getenv("SEGM_WGRAD_OCC")) == 3) {
-            hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<bf16_t, 1, 3>), grid, dim3(kWgThreads), 0, stream, P);      // experiment: 168 registers
         } else if (a->dtype == SEGM_F16) {
             if (pl.nq == 2) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 2>), grid, dim3(kWgThreads), 0, stream, P);
             else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<f16_t, 1>), grid, dim3(kWgThreads), 0, stream, P);

@@ -283,6 +283,8 @@ class bf16_storage_simulation:
 
                 def wrapped(*a, _orig=orig, **k):
                     y = _orig(*a, **k)
+                    if isinstance(y, tuple) and y and torch.is_tensor(y[0]):      # conv3d_same(..., want_stats=True) -> (y, stats)
+                        return (_RoundBF16.apply(y[0]),) + tuple(y[1:])
                     return _RoundBF16.apply(y) if torch.is_tensor(y) else y
                 setattr(mod, n, wrapped)
         return self

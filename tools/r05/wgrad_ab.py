@@ -35,8 +35,7 @@ for (B, cin, cout, S) in ((2, 48, 48, 128), (2, 96, 48, 128), (2, 96, 96, 64), (
     ref = ops_raw.conv3d_k3_wgrad(hip, x, dy, torch.float32)
     line = f"wgrad B={B} {cin}->{cout} @{S}^3:"
     for name, env in (("v1", dict(SEGM_WGRAD_V1=1)), ("r5", {}), ("r5 ipw1", dict(SEGM_WGRAD_IPW=1)), ("r5 ipw2", dict(SEGM_WGRAD_IPW=2)),
-                      ("r5 ipw4", dict(SEGM_WGRAD_IPW=4)), ("nq1", dict(SEGM_WGRAD_NQ=1)), ("nq1 occ3", dict(SEGM_WGRAD_NQ=1, SEGM_WGRAD_OCC=3)),
-                      ("nq1 occ3 ipw2", dict(SEGM_WGRAD_NQ=1, SEGM_WGRAD_OCC=3, SEGM_WGRAD_IPW=2))):
+                      ("r5 ipw4", dict(SEGM_WGRAD_IPW=4))):
         setenv(**env)
         got = ops_raw.conv3d_k3_wgrad(hip, x, dy, torch.float32)
         err = ((got - ref).abs().max() / ref.abs().max()).item()
