@@ -467,6 +467,7 @@ def launch_forms(state, data, device, steps=10, warmup=3):
         state.exchange.record_exposed = True
         out["eager_hooks_ms"] = timed()
         out["eager_hooks_exposed_ms"] = round(state.exchange.exposed_ms(), 3)
+        out["eager_hooks_exposed_ms_per_step"] = [round(v, 2) for v in state.exchange.exposed_ms(per_step=True)]
         out["segments"] = len(state.exchange.ranges)
         out["segment_order"] = state.exchange.order
         out["fallback"] = state.exchange.fallback_reason

@@ -43,7 +43,7 @@ _cache: Dict[tuple, int] = {}
 _TUNE = os.environ.get("SEGM_CONV_AUTOTUNE", "0") == "1"
 # cat(up, skip) convolutions as one autograd node with the later parts added in place (_ConvSameCat, linear._PointwiseCat).  Timed in
 # round 3: no gain on the MI355X (66.2 ms per step either way), so it stays opt-in.
-_CAT_FUSED = os.environ.get("SEGM_CONV_CAT_FUSED", "0") == "1"
+_CAT_FUSED = os.environ.get("SEGM_CONV_CAT_FUSED", "1") == "1"     # round 5: default on (with the statistics epilogue the cat layers feed their InstanceNorm too; profiles/r05_inorm_epilogue_step.log)
 # round 5: the chained kernels' storing K part sums {count, y, y^2} of what it writes; the InstanceNorm behind the convolution
 # merges those partials instead of reading the volume again (csrc/conv3d_fwd.hip STATS; measured free on the convolution side,
 # profiles/r05_inorm_epilogue.log).  SEGM_CONV_STATS=0: every InstanceNorm makes its own statistics pass (A/B).

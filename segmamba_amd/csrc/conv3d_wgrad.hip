@@ -247,6 +247,10 @@ __global__ void __launch_bounds__(kWgThreads, 2) conv3d_k3_wgrad_v1_kernel(Wgrad
 // items) before it writes its 27 x 48 x 48 partial block: fewer partial slabs for the reduce kernel when items are short.
 // What bounds it now (profiles/r05_wgrad_pmc3.log): WAIT_INST_ANY 0.49 of the wave cycles with the matrix pipe busy 0.39 per wave -
 // six waves on four SIMDs (2, 2, 1, 1): the two shared SIMDs run at ~77 % of the matrix pipe, the other two at half of that.
+// Two attempts to even that out were measured and lost (tools/experiments/README.md): 32-wide blocks with three / four workgroups
+// per CU (168 registers: spills, 1.10 ms) and ONE WAVE PER WORKGROUP with every fragment loaded straight from memory - no LDS, no
+// barrier, two independent waves per SIMD (conv3d_wgrad_direct_r5.hip.txt: 1.12 ms against 0.52 - twelve 1-KB vector loads per
+// wave and step in place of nine LDS reads are what the CU's load path cannot feed).
 // SEGM_WGRAD_V1=1 launches the round-1..4 kernel (A/B, and the fallback for strides beyond 32-bit byte offsets).
 // ---------------------------------------------------------------------------------------------------------------------
 typedef __amdgpu_buffer_rsrc_t wg_rsrc_t;

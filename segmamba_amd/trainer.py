@@ -357,12 +357,17 @@ class SegmentedExchange:
             self.fallback_reason = self.failed or "another rank reported a failed gradient hook / a different segment order"
         self.steps_done += 1
 
-    def exposed_ms(self):
-        """average milliseconds per step the main stream waited for the exchange behind the backward pass"""
+    def exposed_ms(self, per_step: bool = False):
+        """average milliseconds per step the main stream waited for the exchange behind the backward pass (the first step, whose
+        segments are all sent in finish(), is left out); per_step: the list"""
         if not self.exposed_events:
             return None
         torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in self.exposed_events) / len(self.exposed_events)
+        ms = [a.elapsed_time(b) for a, b in self.exposed_events]
+        if per_step:
+            return ms
+        ms = ms[1:] if len(ms) > 1 else ms
+        return sum(ms) / len(ms)
 
 
 def forward_backward(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:

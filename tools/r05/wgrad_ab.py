@@ -21,7 +21,7 @@ def t(fn, n=10):
 
 
 def setenv(**kw):
-    for k in ("SEGM_WGRAD_V1", "SEGM_WGRAD_IPW", "SEGM_WGRAD_NQ", "SEGM_WGRAD_OCC"):
+    for k in ("SEGM_WGRAD_V1", "SEGM_WGRAD_IPW", "SEGM_WGRAD_DIRECT"):
         os.environ.pop(k, None)
     for k, v in kw.items():
         os.environ[k] = str(v)
