@@ -3,8 +3,11 @@ tests/test_oracle_golden.py) AT THE SIZES BASELINE.json names, forward and all e
 tolerances (1e-3 fp32 / 1e-2 bf16; tests/helpers.check_scan):
 
   stage 0 of config 2 / 3   B=2, D=96,  N=16, L=64^3 = 262144   all three time orders (fp32), slice-interleaved in bf16
-  config 1 (one Mamba block, d_model 384)   B=2, D=768, L=262144, bf16      every channel (dB / dC sum over all of them)
-  config 4 (long sequences)  B=1, D=96, bf16, L = 2^21 (everything) and L = 2^24 (32 channels; dB / dC checked at 2^21)
+  config 1 (one Mamba block, d_model 384)   B=2, D=768, L=262144, bf16      the first, a middle and the last 32-channel tile at the full
+                                             length; every channel - dB / dC sum over all 24 d-tiles - at L = 32768 (round 5: the
+                                             fp64 oracle over all 768 channels at the full length took 71 s of a suite that has to
+                                             stay well inside the driver's 20 minutes; the d-tile sum does not depend on L)
+  config 4 (long sequences)  B=1, D=96, bf16, L = 2^21 (everything) and L = 2^24 (16 channels; dB / dC checked at 2^21)
 
 so the carry kernel with 1024+ chunks, the backward beyond L = 4096 and the last steps of the longest sequences are
 compared with the oracle, not only checked for finiteness (reference test matrix stops at L = 4096:
@@ -85,9 +88,16 @@ def test_stage0_size_forward_and_all_gradients(hip, order, dtype):
     _run_and_check(hip, c, dtype, order, 64, f"stage0 L=262144 order={order} {dtype}")
 
 
-def test_config1_block_size_every_channel(hip):
+@pytest.mark.parametrize("tile", [0, 11, 23])
+def test_config1_block_size(hip, tile):
     c = _case(2, 768, 16, 64 ** 3, torch.bfloat16, seed=7)
-    _run_and_check(hip, c, torch.bfloat16, L.TIME_FORWARD, 1, "config1 D=768 L=262144 bf16")
+    _run_and_check(hip, c, torch.bfloat16, L.TIME_FORWARD, 1, f"config1 D=768 L=262144 bf16 ch {32 * tile}:{32 * tile + 32}",
+                   ch=slice(32 * tile, 32 * tile + 32), want_bc=False)
+
+
+def test_config1_width_every_channel(hip):
+    c = _case(2, 768, 16, 32768, torch.bfloat16, seed=8)
+    _run_and_check(hip, c, torch.bfloat16, L.TIME_FORWARD, 1, "config1 D=768 L=32768 bf16 (dB / dC over all 24 d-tiles)")
 
 
 def test_config4_two_million_steps(hip):
@@ -97,7 +107,7 @@ def test_config4_two_million_steps(hip):
 
 def test_config4_sixteen_million_steps(hip):
     c = _case(1, 96, 16, 1 << 24, torch.bfloat16, seed=24)
-    _run_and_check(hip, c, torch.bfloat16, L.TIME_FORWARD, 1, "config4 L=2^24 bf16 ch 32:64", ch=slice(32, 64), want_bc=False)
+    _run_and_check(hip, c, torch.bfloat16, L.TIME_FORWARD, 1, "config4 L=2^24 bf16 ch 32:48", ch=slice(32, 48), want_bc=False)
 
 
 def test_config4_sixteen_million_steps_fp32_reversed(hip):
@@ -109,5 +119,5 @@ def test_config4_sixteen_million_steps_fp32_reversed(hip):
     # magnitude of the running state, so the absolute term of the 1e-3 bound is scaled by max|out| / 64: 2e-5 of the signal
     # (measured: max |err| 1.2e-2 against the fp64 oracle - bit-identical before and after the round-3 rewrite of the forward row streams,
     # profiles/r03_fp32_2p24_ab.log)
-    _run_and_check(hip, c, torch.float32, L.TIME_REVERSED, 1, "config4 L=2^24 fp32 reversed ch 0:32", ch=slice(0, 32), want_bc=False,
+    _run_and_check(hip, c, torch.float32, L.TIME_REVERSED, 1, "config4 L=2^24 fp32 reversed ch 0:16", ch=slice(0, 16), want_bc=False,
                    elem_scale=lambda ref: max(1.0, float(ref["out"].abs().max()) / 64.0))

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Round 5, call 10: the whole GPU suite with durations + the driver's bench command
+mkdir -p gpurun_out
+timeout 1800 python -m pytest tests -m gpu -q --durations=45 2>&1 | grep -v "GridwiseOp\|amdgpu.ids\|MIOpen(HIP)" | tail -60 | tee gpurun_out/r05_gpu_tests_call10.log
+timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/r05_bench_call10.err | tail -1 > gpurun_out/r05_bench_call10.json
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r05_bench_call10.json"))
+r = d["roofline"]
+print("step ms", d["ms_per_step"], "vol/s", d["value"], "| scan fwd ms", r["ms"], "frac", r["frac"], "| bwd", r["backward"]["ms"], r["backward"]["frac"])
+print("launch_forms", d["config"].get("launch_forms"))
+print("dropin", {k: (v.get("ms_per_step") if isinstance(v, dict) else v) for k, v in d.get("dropin_step", {}).items()})
+PY
