@@ -551,6 +551,14 @@ def cpu_baseline(full=False):
     return out
 
 
+_T0 = time.time()
+
+
+def _stamp(what):
+    """wall-clock stamps on stderr (how long each part of the line takes; the JSON line on stdout is untouched)"""
+    print(f"[bench.py +{time.time() - _T0:6.1f} s] {what}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -691,6 +699,7 @@ def main():
                 allreduce_ms = f"{type(e).__name__}: {str(e)[:120]}"
 
     if rank == 0:
+        _stamp(f"timed loop done: {elapsed / args.steps * 1e3:.2f} ms per step")
         vols = world * args.batch * args.steps
         ddp = None
         if distributed:
@@ -737,12 +746,14 @@ def main():
             out["inference"] = inference_rate(state, device, args.size)
             out["roofline"] = scan_roofline(torch.bfloat16, device)
             out["roofline_fp32"] = scan_roofline(torch.float32, device)
+            _stamp("inference + roofline done")
             if not args.no_configs and world == 1:
                 if state.flat and not distributed:
                     try:
                         out["config"]["launch_forms"] = launch_forms(state, data, device)
                     except Exception as e:                  # noqa: BLE001
                         out["config"]["launch_forms"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+                _stamp("launch_forms done")
                 del state, data
                 torch.cuda.empty_cache()
                 if not args.no_dropin:
@@ -751,13 +762,16 @@ def main():
                     except Exception as e:                  # noqa: BLE001
                         out["dropin_step"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
                     torch.cuda.empty_cache()
+                    _stamp("dropin_step done")
                 for key, fn in (("config1", config1_mamba_block), ("config4", config4_long_scan)):
                     try:
                         out[key] = fn(device)
                     except Exception as e:                  # noqa: BLE001 - the step's number must not be lost to a side measurement
                         out[key] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         if not args.no_cpu_baseline and world == 1 and not dry:       # the host-core baseline is reported at N = 1 only
+            _stamp("configs done")
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)
+            _stamp("cpu_baseline done")
         # ONE JSON line, and the LAST line of stdout: the vendor libraries print diagnostics through C stdio ("GridwiseOp: ..." from the
         # solvers MIOpen tries on the drop-in path), fully buffered when stdout is a pipe - flush them out first, and send whatever a
         # library prints at teardown to /dev/null

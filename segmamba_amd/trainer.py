@@ -244,6 +244,7 @@ class SegmentedExchange:
         self.fallback_reason = None                        # why every rank went to the one-call form, if they did
         self._flag = torch.zeros(1, dtype=torch.float32, device=dev)
         self._pending = []                                 # (pinned flag copy, event) of the last steps: read two steps later
+        self._hosts = None
         self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in params if p.requires_grad]
 
     def close(self):
@@ -342,7 +343,9 @@ class SegmentedExchange:
         if self.stream is None:
             verdicts = [float(self._flag)]
         else:
-            host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            if self._hosts is None:                        # four pinned words, reused in turn (a pinned allocation per step is not free)
+                self._hosts = [torch.empty(1, dtype=torch.float32, pin_memory=True) for _ in range(4)]
+            host = self._hosts[self.steps_done % 4]
             host.copy_(self._flag, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))

@@ -397,3 +397,24 @@ def test_graft_entry_build_runs_and_checks_the_header_abi():
     ge.build()
     from segmamba_amd import lib as L
     assert L.header_abi_version() == L.SegmLib(L.LIB_PATH).dll.segm_abi_version()
+
+
+def test_bench_gpu_state_parses_rocm_smi_text(monkeypatch):
+    """bench.gpu_state: the clock / power lines of `rocm-smi --showclocks --showpower --showtemp --showperflevel` as the MI355X
+    boxes print them (sclk level 'S' when idle, a digit under load); never raises when the tool is missing"""
+    import subprocess
+    import bench
+    sample = ("GPU[0]\t\t: mclk clock level: 0: (2000Mhz)\nGPU[0]\t\t: sclk clock level: S: (99Mhz)\n"
+              "GPU[0]\t\t: Current Socket Graphics Package Power (W): 676.0\nGPU[0]\t\t: Temperature (Sensor junction) (C): 46.0\n"
+              "GPU[0]\t\t: Performance Level: auto\n")
+
+    class R:
+        stdout = sample
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: R())
+    st = bench.gpu_state(0)
+    assert st == {"sclk_mhz": 99, "mclk_mhz": 2000, "power_w": 676.0, "temp_c": 46.0, "perf_level": "auto"}, st
+
+    def boom(*a, **k):
+        raise FileNotFoundError("rocm-smi")
+    monkeypatch.setattr(subprocess, "run", boom)
+    assert "error" in bench.gpu_state(0)
