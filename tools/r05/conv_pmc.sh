@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round 5 (same passes as round 4): SQ counters of the shipped 3x3x3 kernels (forward chain, 32-wide chain, weight gradient): where do the wave cycles go -
+# parked (s_waitcnt / barrier), issue-stalled, issuing - and how much of it is LDS, MFMA, bank conflicts.  Separate --pmc passes.
+mkdir -p gpurun_out/prof; R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
+i=0
+for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"; do
+  i=$((i+1))
+  PYTHONPATH=$R SEGM_TIME_CONV_ONLY=1 timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/prof/c5f_$i -o pmc -- python $R/tools/gpu_chain_time.py > $R/gpurun_out/prof/c5f_$i.log 2>&1
+  echo "fwd pass $i rc=$?"
+  PYTHONPATH=$R timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/prof/c5w_$i -o pmc -- python $R/tools/gpu_conv_time.py > $R/gpurun_out/prof/c5w_$i.log 2>&1
+  echo "wgrad pass $i rc=$?"
+done
+python3 - $R <<'PY' | tee $R/gpurun_out/r05_conv_pmc.log
+import csv, glob, sys, collections, statistics
+R = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(R + "/gpurun_out/prof/c5*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "conv3d_k3" in k and "reduce" not in k:
+            agg[(k[:84], r.get("Grid_Size", ""))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+raw = ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")
+for (k, g), d in sorted(agg.items()):
+    m = {c: statistics.median(v) for c, v in d.items()}
+    wc = m.get("SQ_WAVE_CYCLES", 1) or 1
+    mf = m.get("SQ_INSTS_MFMA", 0) or 1
+    print(f"{k} grid {g}")
+    print("   per wave cycle: " + "  ".join(f"{c[3:]} {m[c] / wc:.3f}" for c in sorted(m) if c not in raw))
+    print("   counts: " + "  ".join(f"{c[3:]} {m[c]:.3g}" for c in raw if c in m))
+    if "SQ_INSTS_VALU" in m:
+        print(f"   per MFMA: other VALU {(m['SQ_INSTS_VALU'] - mf) / mf:.2f}  SALU {m.get('SQ_INSTS_SALU', 0) / mf:.2f}  LDS {m.get('SQ_INSTS_LDS', 0) / mf:.2f}  VMEM {(m.get('SQ_INSTS_VMEM_RD', 0) + m.get('SQ_INSTS_VMEM_WR', 0)) / mf:.2f}")
+PY
