@@ -48,6 +48,9 @@ _CAT_FUSED = os.environ.get("SEGM_CONV_CAT_FUSED", "1") == "1"     # round 5: de
 # merges those partials instead of reading the volume again (csrc/conv3d_fwd.hip STATS; measured free on the convolution side,
 # profiles/r05_inorm_epilogue.log).  SEGM_CONV_STATS=0: every InstanceNorm makes its own statistics pass (A/B).
 _STATS = os.environ.get("SEGM_CONV_STATS", "1") == "1"
+# round 5: conv1 + the 1x1x1 projection of a residual block's input as one node (_ResFront): the two data gradients of the input are
+# summed by the 3x3x3 kernel's accumulate mode instead of an element-wise add.  SEGM_RES_FRONT=0: two nodes (A/B).
+_RES_FRONT = os.environ.get("SEGM_RES_FRONT", "1") == "1"
 
 
 def _time(fn: Callable[[], torch.Tensor], reps: int = 3) -> float:
@@ -223,8 +226,8 @@ def _dgrad_as_fwd_blocked(dy, w, x, pad):
     return _fwd_blocked(dy, _flipT(w), pad)
 
 
-def _dgrad_hip(dy, w, x, pad, chain=False, pitch48=False, chain32=False):
-    return _fwd_hip(dy, w, pad, None, chain, pitch48, chain32, flipped=True)
+def _dgrad_hip(dy, w, x, pad, chain=False, pitch48=False, chain32=False, into=None):
+    return _fwd_hip(dy, w, pad, None, chain, pitch48, chain32, into=into, flipped=True)
 
 
 def _wgrad_native(x, dy, w, pad):
@@ -303,7 +306,9 @@ def _tuned_variant(key, cands, variants, width: int = 0):
     return variants[i] if i is not None else None
 
 
-def _dgrad(dy, w, x, pad):
+def _dgrad(dy, w, x, pad, into=None):
+    """`into`: a gradient of x that already exists (another consumer's, owned by the caller) - the result is added to it, in place
+    by the library kernel when the shape routes to one (`accumulate`), by an ordinary add otherwise"""
     cands, variants = [lambda: _dgrad_native(dy, w, x, pad), lambda: _dgrad_as_fwd(dy, w, x, pad)], [None, None]
     if max(w.shape[0], w.shape[1]) > _BLOCK and w.shape[0] % _BLOCK == 0 and w.shape[1] % _BLOCK == 0:
         cands.append(lambda: _dgrad_as_fwd_blocked(dy, w, x, pad))
@@ -314,7 +319,14 @@ def _dgrad(dy, w, x, pad):
     for v in _HIP_VARIANTS[:n]:
         cands.append(lambda v=v: _dgrad_hip(dy, w, x, pad, *v))
         variants.append(v)
-    return _pick(_key("dgrad", dy, w, hip, chain, _hip_untimed_ok()), cands, variants, dy.shape[4])
+    key = _key("dgrad", dy, w, hip, chain, _hip_untimed_ok())
+    if into is not None:
+        from . import ops_raw
+        v = _tuned_variant(key, cands, variants, dy.shape[4]) if w.shape[1] % _BLOCK == 0 and ops_raw.channel_dense(into) else None
+        if v is not None:
+            return _dgrad_hip(dy, w, x, pad, *v, into=into)
+        return into.add_(_pick(key, cands, variants, dy.shape[4]))
+    return _pick(key, cands, variants, dy.shape[4])
 
 
 def _wgrad(x, dy, w, pad, w_dtype):
@@ -415,6 +427,95 @@ class _ConvSameCat(torch.autograd.Function):
                 dws.append(_wgrad(x, dy, wi, pad, ctx.w_dtype))
         dw = torch.cat(dws, dim=1) if ctx.needs_input_grad[1] else None
         return (None, dw, *dxs)
+
+
+class _ResFront(torch.autograd.Function):
+    """The two convolutions a residual block with a projection skip applies to its input - conv1 (3x3x3) and conv3 (1x1x1),
+    dynunet_block.py:93-104 of the reference - on cat(xs, 1), as ONE node: each part then has ONE data gradient, written by the
+    1x1x1 kernel and added to in place by the 3x3x3 kernel, where two nodes leave autograd an element-wise add per part (three
+    passes over a 128^3 volume each).  Forward arithmetic = _ConvSameCat + linear._PointwiseCat.  -> (y1, stats of y1 or an empty
+    tensor, y3)."""
+
+    @staticmethod
+    def forward(ctx, want_stats, w1, w3, *xs):
+        from .param_bank import low_precision
+        ctx.w_dtypes = (w1.dtype, w3.dtype)
+        dt = xs[0].dtype
+        w1, w3 = low_precision(w1, dt), low_precision(w3, dt)
+        pad = w1.shape[2] // 2
+        ctx.save_for_backward(w1, w3, *xs)
+        y1, y3, c0, stats = None, None, 0, None
+        for j, x in enumerate(xs):
+            c1 = c0 + x.shape[1]
+            w1i, w3i, xf = w1[:, c0:c1], w3[:, c0:c1], x.flatten(2)
+            c0 = c1
+            last = want_stats and j + 1 == len(xs)
+            box = [] if last else None
+            if y1 is None:
+                key, cands, variants = _fwd_candidates(x, w1i, None, pad, box)
+                y1 = _pick(key, cands, variants, x.shape[4])
+                if last and box and _pick_was_hip(key, cands, variants, x.shape[4]):
+                    stats = box[-1]
+                y3 = linear._pw_hip(w3i, xf, None)
+                if y3 is None:
+                    y3 = linear._bmm_w(w3i, xf)
+                continue
+            key, cands, variants = _fwd_candidates(x, w1i, None, pad)
+            v = _tuned_variant(key, cands, variants, x.shape[4]) if w1i.shape[0] % _BLOCK == 0 else None
+            if v is not None:
+                y1 = _fwd_hip(x, w1i, pad, None, *v, into=y1, stats_box=box)
+                stats = box[-1] if box else None
+            else:
+                y1 = y1 + _pick(key, cands, variants, x.shape[4])
+            y = linear._pw_hip(w3i, xf, None, into=y3)
+            y3 = y if y is not None else y3 + linear._bmm_w(w3i, xf)
+        stats = stats if stats is not None else y1.new_empty(0, dtype=torch.float32)
+        ctx.mark_non_differentiable(stats)
+        return y1, stats, y3.view(y1.shape)
+
+    @staticmethod
+    def backward(ctx, dy1, _, dy3):
+        w1, w3, *xs = ctx.saved_tensors
+        pad = w1.shape[2] // 2
+        from . import ops_raw
+        if not ops_raw.channel_dense(dy1):
+            dy1 = dy1.contiguous()
+        dy3 = dy3.flatten(2) if ops_raw.channel_dense(dy3) else dy3.contiguous().flatten(2)
+        dxs, dw1, dw3, c0 = [], [], [], 0
+        for i, x in enumerate(xs):
+            c1 = c0 + x.shape[1]
+            w1i, w3i = w1[:, c0:c1], w3[:, c0:c1]
+            c0 = c1
+            dx = None
+            if ctx.needs_input_grad[3 + i]:
+                dx = linear._pw_hip(w3i.t(), dy3, None)
+                if dx is None:
+                    dx = linear._bmm_w(w3i.t(), dy3)
+                dx = _dgrad(dy1, w1i, x, pad, into=dx.view(x.shape))
+            dxs.append(dx)
+            if ctx.needs_input_grad[1]:
+                dw1.append(_wgrad(x, dy1, w1i, pad, ctx.w_dtypes[0]))
+            if ctx.needs_input_grad[2]:
+                dw3.append(linear.nt_matmul_rows(dy3, x.flatten(2)))
+        g1 = torch.cat(dw1, dim=1) if ctx.needs_input_grad[1] else None
+        g3 = torch.cat(dw3, dim=1).to(ctx.w_dtypes[1]) if ctx.needs_input_grad[2] else None
+        return (None, g1, g3, *dxs)
+
+
+def res_front(xs: Tuple[torch.Tensor, ...], w1: torch.Tensor, w3: torch.Tensor, want_stats: bool = False):
+    """(conv3d_same(cat(xs, 1), w1), its InstanceNorm partials or None, the 1x1x1 convolution of cat(xs, 1) with w3) as one autograd
+    node (_ResFront), or None when the parts are not the library kernels' (device, one 16-bit dtype, dense channels, more than 4
+    input channels) - the caller then runs the two convolutions on their own."""
+    from . import lib as L, ops_raw
+    if not (_RES_FRONT and _CAT_FUSED and all(L.on_device(x) for x in xs) and w1.shape[2:] == (3, 3, 3) and w1.shape[1] > 4):
+        return None
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype("cuda")
+        xs = tuple(x.to(dt) for x in xs)
+    if xs[0].dtype not in (torch.bfloat16, torch.float16) or any(x.dtype != xs[0].dtype or not ops_raw.channel_dense(x) for x in xs):
+        return None
+    y1, st, y3 = _ResFront.apply(bool(want_stats and _STATS), w1, w3.reshape(w3.shape[0], w3.shape[1]), *xs)
+    return y1, (st if st.numel() else None), y3
 
 
 def _unpack_stats(res):

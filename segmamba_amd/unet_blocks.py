@@ -138,11 +138,18 @@ class UnetResBlock(nn.Module):
 
     def forward(self, inp) -> torch.Tensor:
         """`inp`: a tensor, or a tuple of tensors meaning their channel concatenation (decoder: (upsampled, skip))."""
-        out, st = self.conv1(inp, want_stats=True)
+        skip = None
+        if self.downsample and self.conv1._same and self.conv3._pointwise and self.conv1.conv.bias is None and self.conv3.conv.bias is None:
+            front = _conv3d.res_front(tuple(inp) if isinstance(inp, (tuple, list)) else (inp,), self.conv1.conv.weight,
+                                      self.conv3.conv.weight, want_stats=True)
+            if front is not None:
+                out, st, skip = front
+        if skip is None:
+            out, st = self.conv1(inp, want_stats=True)
         out = fused_norm.instance_norm_act(out, act="leaky_relu", slope=self.NEG_SLOPE, eps=self.norm1.eps, stats=st)
         out, st = self.conv2(out, want_stats=True)
         if self.downsample:
-            residual = fused_norm.instance_norm_act(self.conv3(inp), act="none", eps=self.norm3.eps)
+            residual = fused_norm.instance_norm_act(self.conv3(inp) if skip is None else skip, act="none", eps=self.norm3.eps)
         else:
             residual = torch.cat(tuple(inp), dim=1) if isinstance(inp, (tuple, list)) else inp
         # IN(out) + residual -> LeakyReLU, one pass

@@ -1365,17 +1365,73 @@ def test_decoder_block_with_fused_concatenation_emulated(emu, monkeypatch):
     yr.backward(dy.float())
     refs = [yr.detach(), ar.grad, br.grad, w1.grad, w2.grad, w3.grad]
     errs = []
-    for fused in (False, True):
+    for fused, front in ((False, False), (True, False), (True, True)):      # front: conv1 + conv3 as one node too (conv3d._ResFront)
         monkeypatch.setattr(C3, "_CAT_FUSED", fused)
+        monkeypatch.setattr(C3, "_RES_FRONT", front)
         a, b = xa.clone().requires_grad_(), xb.clone().requires_grad_()
         blk.zero_grad()
         y = blk((a, b))
         y.backward(dy)
         got = [y.detach().float(), a.grad.float(), b.grad.float(), blk.conv1.conv.weight.grad, blk.conv2.conv.weight.grad, blk.conv3.conv.weight.grad]
         errs.append([float((u - r).norm() / r.norm()) for u, r in zip(got, refs)])
-    for e0, e1 in zip(*errs):
+    for e0, e1, e2 in zip(*errs):
         assert e1 <= 8e-2 and e1 <= 1.25 * e0 + 1e-3, errs
-    assert errs[1][0] <= 1e-2                                   # the forward output itself: bf16 rounding only
+        assert e2 <= 8e-2 and e2 <= 1.25 * e0 + 1e-3, errs
+    assert errs[1][0] <= 1e-2 and errs[2][0] <= 1e-2            # the forward output itself: bf16 rounding only
+
+
+@pytest.mark.parametrize("parts", [1, 2])
+def test_res_front_node_matches_the_two_convolutions_emulated(emu, monkeypatch, parts):
+    """conv3d.res_front: conv1 (3x3x3) and conv3 (1x1x1) of a residual block's input as one node.  Forward results and weight
+    gradients are the two separate nodes' bit for bit (same launches in the same order); the data gradient of a part is ONE tensor -
+    the 1x1x1 kernel writes it, the 3x3x3 kernel adds to it in place from its fp32 accumulators - where the two nodes round each
+    contribution to bf16 and autograd adds them: one bf16 rounding apart, checked against the fp32 gradient."""
+    import torch.nn.functional as F
+    from segmamba_amd import lib as L, conv3d as C3, linear as LN
+    monkeypatch.setattr(L, "get_lib", lambda: emu)
+    monkeypatch.setattr(L, "on_device", lambda t: True)
+    monkeypatch.setattr(C3, "_pick", lambda key, cands, *rest: cands[-1]())
+    monkeypatch.setattr(C3, "_tuned_variant", lambda key, cands, variants, *rest: variants[-1])
+    monkeypatch.setattr(C3, "_pick_was_hip", lambda *a, **k: True)
+    monkeypatch.setattr(C3, "_CAT_FUSED", True)
+    monkeypatch.setattr(LN, "_PW_MIN", 64)
+    g = torch.Generator().manual_seed(31 + parts)
+    shape = (1, 48, 2, 4, 64)
+    xs = [torch.randn(shape, generator=g).bfloat16() for _ in range(parts)]
+    cout = 48
+    w1 = (0.05 * torch.randn(cout, 48 * parts, 3, 3, 3, generator=g)).bfloat16().float()
+    w3 = (0.1 * torch.randn(cout, 48 * parts, 1, 1, 1, generator=g)).bfloat16().float()
+    dy1 = torch.randn(1, cout, 2, 4, 64, generator=g).bfloat16()
+    dy3 = torch.randn(1, cout, 2, 4, 64, generator=g).bfloat16()
+
+    def run(front):
+        ins = [x.clone().requires_grad_() for x in xs]
+        a1, a3 = w1.clone().requires_grad_(), w3.clone().requires_grad_()
+        if front:
+            y1, st, y3 = C3.res_front(tuple(ins), a1, a3, want_stats=True)
+            assert type(y1.grad_fn).__name__ == "_ResFrontBackward"
+        elif parts == 1:
+            (y1, st), y3 = C3.conv3d_same(ins[0], a1, None, want_stats=True), LN.pointwise(ins[0], a3.reshape(cout, -1))
+        else:
+            (y1, st), y3 = C3.conv3d_same_cat(tuple(ins), a1, want_stats=True), LN.pointwise_cat(tuple(ins), a3.reshape(cout, -1))
+        torch.autograd.backward([y1, y3], [dy1, dy3])
+        return y1.detach(), st, y3.detach(), a1.grad, a3.grad, [t.grad for t in ins]
+
+    y1, st, y3, g1, g3, dxs = run(True)
+    y1r, str_, y3r, g1r, g3r, dxr = run(False)
+    assert torch.equal(y1, y1r) and torch.equal(y3.reshape(y3r.shape), y3r)
+    assert st is not None and str_ is not None and torch.equal(st, str_)
+    assert torch.equal(g1, g1r) and torch.equal(g3, g3r)
+    # fp32 gradient of the parts
+    ref = [x.float().requires_grad_() for x in xs]
+    xc = torch.cat(ref, 1)
+    torch.autograd.backward([F.conv3d(xc, w1, None, 1, 1), F.conv3d(xc, w3)], [dy1.float(), dy3.float()])
+    for d, d2, r in zip(dxs, dxr, ref):
+        scale = float(r.grad.abs().max())
+        e1, e2 = float((d.float() - r.grad).abs().max()), float((d2.float() - r.grad).abs().max())
+        assert e1 <= 2.0 ** -7 * scale and e1 <= 1.25 * e2 + 1e-6, (e1, e2, scale)
+    monkeypatch.setattr(C3, "_RES_FRONT", False)
+    assert C3.res_front(tuple(xs), w1, w3) is None
 
 
 def test_every_routing_candidate_of_the_conv_dispatcher_runs_and_agrees(emu, monkeypatch):

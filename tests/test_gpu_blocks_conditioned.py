@@ -177,6 +177,44 @@ def test_conv3_forward_dgrad_wgrad_at_the_benchmarked_shape(cin):
     assert e <= 1e-2 * sc, (e, sc)
 
 
+def test_res_front_node_at_the_benchmarked_shape():
+    """decoder2's conv1 (3x3x3, 96 -> 48) and conv3 (1x1x1) on (upsampled, skip) at 2 x 128^3, padded channel strides, as ONE node
+    (conv3d._ResFront: the 3x3x3 data gradient added in place to the 1x1x1 one) against the two separate nodes: outputs, statistics
+    and weight gradients bit for bit, the data gradients one bf16 rounding apart."""
+    from segmamba_amd import conv3d as C3, linear as LN
+    B, S, cout = 2, 128, 48
+    g = torch.Generator(device=DEV).manual_seed(13)
+    xs = [_padded((0.5 * torch.randn(B, 48, S, S, S, device=DEV, generator=g)).bfloat16()) for _ in range(2)]
+    w1 = torch.randn(cout, 96, 3, 3, 3, device=DEV, generator=g) / (27 * 96) ** 0.5
+    w3 = torch.randn(cout, 96, 1, 1, 1, device=DEV, generator=g) / 96 ** 0.5
+    dy1 = _padded((0.5 * torch.randn(B, cout, S, S, S, device=DEV, generator=g)).bfloat16())
+    dy3 = _padded((0.5 * torch.randn(B, cout, S, S, S, device=DEV, generator=g)).bfloat16())
+
+    def run(front):
+        ins = [x.detach().requires_grad_() for x in xs]
+        a1, a3 = w1.clone().requires_grad_(), w3.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if front:
+                y1, st, y3 = C3.res_front(tuple(ins), a1, a3, want_stats=True)
+                assert type(y1.grad_fn).__name__ == "_ResFrontBackward"
+            else:
+                (y1, st), y3 = C3.conv3d_same_cat(tuple(ins), a1, want_stats=True), LN.pointwise_cat(tuple(ins), a3.reshape(cout, -1))
+        torch.autograd.backward([y1, y3], [dy1 if y1.stride() == dy1.stride() else dy1.contiguous(),
+                                           dy3 if y3.stride() == dy3.stride() else dy3.contiguous()])
+        return y1.detach(), st, y3.detach(), a1.grad, a3.grad, [t.grad for t in ins]
+
+    y1, st, y3, g1, g3, dxs = run(True)
+    y1r, str_, y3r, g1r, g3r, dxr = run(False)
+    assert torch.equal(y1, y1r) and torch.equal(y3, y3r.reshape(y3.shape))
+    assert st is not None and str_ is not None and torch.equal(st, str_)
+    assert torch.equal(g1, g1r) and torch.equal(g3, g3r)
+    for i, (d, r) in enumerate(zip(dxs, dxr)):
+        sc = float(r.float().abs().max())
+        e = float((d.float() - r.float()).abs().max())
+        _log(f"res front 96->48 @128^3 dx{i} vs two nodes", e, sc, 2.0 ** -7 * sc)
+        assert e <= 2.0 ** -7 * sc, (i, e, sc)
+
+
 # ---- fp16: the reference's AMP dtype ---------------------------------------------------------------------------------------------
 # (the fp16 scan at the stage-0 size against the fp64 C oracle: tests/test_gpu_at_size.py::test_stage0_size_forward_and_all_gradients)
 def test_segmamba_fp16_library_path_matches_fp32_64cube():
