@@ -13,6 +13,7 @@
 //   backward  K3 stats   g = dy act'(v);  per (instance, slab): sum g, sum g xhat  (g is parked in dresidual if asked)
 //             K4 apply   dx = rstd (g - mean(g) - xhat mean(g xhat))
 // The activation mask is taken from y when a residual was added (v is not recomputable from x alone), else from xhat.
+#include <stdlib.h>
 #include <string.h>
 
 #include "segm_device.h"
@@ -133,7 +134,8 @@ __device__ __forceinline__ float2 merge_ext(const NormDev& P, int inst, float2* 
     return r;
 }
 
-template <typename T, bool VEC>
+// NT: non-temporal accesses for what is streamed once; U: packets a thread has in flight per tensor
+template <typename T, bool VEC, bool NT = false, int U = 4>
 __global__ void __launch_bounds__(kBlock) inorm_fwd_stats_kernel(NormDev P) {
     using Pk = Pack<T, VEC>;
     __shared__ float2 lds[kWavesPerBlock];
@@ -141,25 +143,33 @@ __global__ void __launch_bounds__(kBlock) inorm_fwd_stats_kernel(NormDev P) {
     const T* x = reinterpret_cast<const T*>(P.x) + (int64_t)inst * P.xs;
     int64_t e0, e1;
     slab_range(P, split, e0, e1);
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    float s[U], q[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) s[k] = q[k] = 0.f;
     const int64_t step = (int64_t)kBlock * Pk::N;
     int64_t i = e0 + (int64_t)threadIdx.x * Pk::N;
-    for (; i + 3 * step < e1; i += 4 * step) {             // 4 independent packets in flight per thread
-        Pk p[4];
+    for (; i + (U - 1) * step < e1; i += U * step) {       // U independent packets in flight per thread
+        Pk p[U];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p[k].load(x + i + k * step);
+        for (int k = 0; k < U; ++k) p[k].template load<NT>(x + i + k * step);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < U; ++k)
 #pragma unroll
             for (int j = 0; j < Pk::N; ++j) { s[k] += p[k].v[j]; q[k] = fmaf(p[k].v[j], p[k].v[j], q[k]); }
     }
     for (; i < e1; i += step) {
         Pk p;
-        p.load(x + i);
+        p.template load<NT>(x + i);
 #pragma unroll
         for (int j = 0; j < Pk::N; ++j) { s[0] += p.v[j]; q[0] = fmaf(p.v[j], p.v[j], q[0]); }
     }
-    const float2 r = block_sum2((s[0] + s[1]) + (s[2] + s[3]), (q[0] + q[1]) + (q[2] + q[3]), lds);
+    float ss = 0.f, qq = 0.f;
+    if constexpr (U == 4) { ss = (s[0] + s[1]) + (s[2] + s[3]); qq = (q[0] + q[1]) + (q[2] + q[3]); }
+    else {
+#pragma unroll
+        for (int k = 0; k < U; ++k) { ss += s[k]; qq += q[k]; }
+    }
+    const float2 r = block_sum2(ss, qq, lds);
     if (threadIdx.x == 0) P.part[(int64_t)inst * P.nsplit + split] = r;
 }
 
@@ -168,7 +178,7 @@ __device__ __forceinline__ float act_fwd(float v, int act, float slope) {
     return v > 0.f ? v : v * slope;                      // relu: slope == 0
 }
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, bool NT = false, int U = 2>
 __global__ void __launch_bounds__(kBlock) inorm_fwd_apply_kernel(NormDev P) {
     using Pk = Pack<T, VEC>;
     __shared__ float2 lds[kWavesPerBlock];
@@ -184,28 +194,35 @@ __global__ void __launch_bounds__(kBlock) inorm_fwd_apply_kernel(NormDev P) {
     int64_t e0, e1;
     slab_range(P, split, e0, e1);
     const int64_t step = (int64_t)kBlock * Pk::N;
-    for (int64_t i = e0 + (int64_t)threadIdx.x * Pk::N; i < e1; i += 2 * step) {
-        const bool two = i + step < e1;
-        Pk a, b, ra, rb;
-        a.load(x + i);
-        if (two) b.load(x + i + step);
-        if (res) { ra.load(res + i); if (two) rb.load(res + i + step); }
+    auto one = [&](Pk& a, const Pk& r) {
 #pragma unroll
         for (int j = 0; j < Pk::N; ++j) {
             float v = fmaf(a.v[j], rstd, shift);
-            if (res) v += ra.v[j];
+            if (res) v += r.v[j];
             a.v[j] = act_fwd(v, P.act, slope);
         }
-        a.store(y + i);
-        if (two) {
+    };
+    int64_t i = e0 + (int64_t)threadIdx.x * Pk::N;
+    for (; i + (U - 1) * step < e1; i += U * step) {
+        Pk a[U], r[U];
 #pragma unroll
-            for (int j = 0; j < Pk::N; ++j) {
-                float v = fmaf(b.v[j], rstd, shift);
-                if (res) v += rb.v[j];
-                b.v[j] = act_fwd(v, P.act, slope);
-            }
-            b.store(y + i + step);
+        for (int k = 0; k < U; ++k) a[k].template load<NT>(x + i + k * step);
+        if (res) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) r[k].template load<NT>(res + i + k * step);
         }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            one(a[k], r[k]);
+            a[k].template store<NT>(y + i + k * step);
+        }
+    }
+    for (; i < e1; i += step) {
+        Pk a, r;
+        a.template load<NT>(x + i);
+        if (res) r.template load<NT>(res + i);
+        one(a, r);
+        a.template store<NT>(y + i);
     }
 }
 
@@ -220,7 +237,7 @@ __device__ __forceinline__ void grad_through_act(Pk& g, const Pk& xh, const Pk& 
     }
 }
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, bool NT = false, int U = 2>
 __global__ void __launch_bounds__(kBlock) inorm_bwd_stats_kernel(NormDev P) {
     using Pk = Pack<T, VEC>;
     __shared__ float2 lds[kWavesPerBlock];
@@ -235,37 +252,45 @@ __global__ void __launch_bounds__(kBlock) inorm_bwd_stats_kernel(NormDev P) {
     const bool use_y = ym != nullptr;
     int64_t e0, e1;
     slab_range(P, split, e0, e1);
-    float sg[2] = {0.f, 0.f}, sgx[2] = {0.f, 0.f};
+    float sg[U], sgx[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) sg[k] = sgx[k] = 0.f;
     const int64_t step = (int64_t)kBlock * Pk::N;
-    for (int64_t i = e0 + (int64_t)threadIdx.x * Pk::N; i < e1; i += 2 * step) {
-        const bool two = i + step < e1;
-        Pk xa, xb, ga, gb, ya, yb;
-        xa.load(x + i); ga.load(dy + i);
-        if (use_y && P.act) ya.load(ym + i);
-        if (two) {
-            xb.load(x + i + step); gb.load(dy + i + step);
-            if (use_y && P.act) yb.load(ym + i + step);
-        }
+    // (x, dy and y are read again by the apply pass: never non-temporal; the parked g is)
+    auto one = [&](Pk& xa, Pk& ga, const Pk& ya, float& a, float& b, int64_t at) {
 #pragma unroll
         for (int j = 0; j < Pk::N; ++j) xa.v[j] = fmaf(xa.v[j], rstd, shift);
         grad_through_act(ga, xa, ya, use_y, P.act, slope);
 #pragma unroll
-        for (int j = 0; j < Pk::N; ++j) { sg[0] += ga.v[j]; sgx[0] = fmaf(ga.v[j], xa.v[j], sgx[0]); }
-        if (dres) ga.store(dres + i);
-        if (two) {
+        for (int j = 0; j < Pk::N; ++j) { a += ga.v[j]; b = fmaf(ga.v[j], xa.v[j], b); }
+        if (dres) ga.store(dres + at);
+    };
+    int64_t i = e0 + (int64_t)threadIdx.x * Pk::N;
+    for (; i + (U - 1) * step < e1; i += U * step) {
+        Pk xa[U], ga[U], ya[U];
 #pragma unroll
-            for (int j = 0; j < Pk::N; ++j) xb.v[j] = fmaf(xb.v[j], rstd, shift);
-            grad_through_act(gb, xb, yb, use_y, P.act, slope);
+        for (int k = 0; k < U; ++k) { xa[k].template load<NT>(x + i + k * step); ga[k].template load<NT>(dy + i + k * step); }
+        if (use_y && P.act) {
 #pragma unroll
-            for (int j = 0; j < Pk::N; ++j) { sg[1] += gb.v[j]; sgx[1] = fmaf(gb.v[j], xb.v[j], sgx[1]); }
-            if (dres) gb.store(dres + i + step);
+            for (int k = 0; k < U; ++k) ya[k].template load<NT>(ym + i + k * step);
         }
+#pragma unroll
+        for (int k = 0; k < U; ++k) one(xa[k], ga[k], ya[k], sg[k], sgx[k], i + k * step);
     }
-    const float2 r = block_sum2(sg[0] + sg[1], sgx[0] + sgx[1], lds);
+    for (; i < e1; i += step) {
+        Pk xa, ga, ya;
+        xa.template load<NT>(x + i); ga.template load<NT>(dy + i);
+        if (use_y && P.act) ya.template load<NT>(ym + i);
+        one(xa, ga, ya, sg[0], sgx[0], i);
+    }
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < U; ++k) { a += sg[k]; b += sgx[k]; }
+    const float2 r = block_sum2(a, b, lds);
     if (threadIdx.x == 0) P.part[(int64_t)inst * P.nsplit + split] = r;
 }
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, bool NT = false, int U = 1>
 __global__ void __launch_bounds__(kBlock) inorm_bwd_apply_kernel(NormDev P) {
     using Pk = Pack<T, VEC>;
     __shared__ float2 lds[kWavesPerBlock];
@@ -292,27 +317,57 @@ __global__ void __launch_bounds__(kBlock) inorm_bwd_apply_kernel(NormDev P) {
     int64_t e0, e1;
     slab_range(P, split, e0, e1);
     const int64_t step = (int64_t)kBlock * Pk::N;
-    for (int64_t i = e0 + (int64_t)threadIdx.x * Pk::N; i < e1; i += step) {
-        Pk xa, ga, ya;
-        xa.load(x + i);
+    auto one = [&](Pk& xa, Pk& ga, const Pk& ya) {
 #pragma unroll
         for (int j = 0; j < Pk::N; ++j) xa.v[j] = fmaf(xa.v[j], rstd, shift);
-        if (gsrc) {
-            ga.load(gsrc + i);
-        } else {
-            ga.load(dy + i);
-            if (use_y && P.act) ya.load(ym + i);
-            grad_through_act(ga, xa, ya, use_y, P.act, slope);
-        }
+        if (!gsrc) grad_through_act(ga, xa, ya, use_y, P.act, slope);
 #pragma unroll
         for (int j = 0; j < Pk::N; ++j) ga.v[j] = rstd * (ga.v[j] - mg - xa.v[j] * mgx);
-        ga.store(dx + i);
+    };
+    int64_t i = e0 + (int64_t)threadIdx.x * Pk::N;
+    for (; i + (U - 1) * step < e1; i += U * step) {
+        Pk xa[U], ga[U], ya[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            xa[k].template load<NT>(x + i + k * step);
+            if (gsrc) ga[k].load(gsrc + i + k * step);         // (the residual's gradient: read again by its consumer)
+            else ga[k].template load<NT>(dy + i + k * step);
+        }
+        if (!gsrc && use_y && P.act) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) ya[k].template load<NT>(ym + i + k * step);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            one(xa[k], ga[k], ya[k]);
+            ga[k].template store<NT>(dx + i + k * step);
+        }
     }
+    if constexpr (U > 1) {
+        for (; i < e1; i += step) {
+            Pk xa, ga, ya;
+            xa.template load<NT>(x + i);
+            if (gsrc) ga.load(gsrc + i);
+            else {
+                ga.template load<NT>(dy + i);
+                if (use_y && P.act) ya.template load<NT>(ym + i);
+            }
+            one(xa, ga, ya);
+            ga.template store<NT>(dx + i);
+        }
+    }
+}
+
+// A/B knobs of these streaming passes (round 5; profiles/r05_inorm_tune.log), read per call
+static int norm_knob(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
 }
 
 static void norm_plan(int instances, int64_t S, int vecn, int& nsplit, int64_t& slab) {
     const int64_t quantum = (int64_t)kBlock * vecn * 4;           // the stats loop's full stride
-    int64_t want = (4096 + instances - 1) / instances;            // ~4096 workgroups in total
+    const int target = norm_knob("SEGM_NORM_WGS", 4096);
+    int64_t want = (target + instances - 1) / instances;          // ~`target` workgroups in total
     const int64_t maxs = (S + quantum - 1) / quantum;
     if (want > maxs) want = maxs;
     if (want > kNormMaxSplit) want = kNormMaxSplit;
@@ -329,12 +384,30 @@ static bool norm_stride(int64_t given, int64_t spatial, int64_t& out) {
     return out >= spatial;
 }
 
+// How a pass streams, by the bytes of ONE of its tensors (profiles/r05_inorm_tune.log, _tune2.log; 2 x 48 x 128^3 bf16 = 403 MB,
+// 2 x 96 x 64^3 = 101 MB):
+//   mode 0  < 64 MB    plain accesses, 2 / 1 packets in flight in the apply passes (rounds 1 - 4; the 256 MB last-level cache holds it)
+//   mode 1  >= 64 MB   apply passes: non-temporal loads and stores, 4 packets in flight; backward statistics 4 in flight
+//   mode 2  >= 192 MB  + non-temporal loads in the backward statistics pass (nothing survives between the passes anyway).  NOT in the
+//                      forward statistics pass: plain loads leave part of x in the last-level cache for the apply pass behind it
+//                      (403 MB: 0.200 ms with plain statistics loads, 0.212 ms without)
+// 403 MB: forward 0.243 -> 0.200 ms (6.0 TB/s), with a residual 0.313 -> 0.259, backward 0.377 -> 0.326 (6.2 TB/s).
+// SEGM_NORM_NT = 0 / 1 / 2 forces a mode (A/B).
+static int norm_mode(int instances, int64_t S, size_t esize) {
+    const int forced = norm_knob("SEGM_NORM_NT", -1);
+    if (forced >= 0) return forced > 2 ? 2 : forced;
+    const double bytes = (double)instances * (double)S * (double)esize;
+    return bytes >= 192e6 ? 2 : (bytes >= 64e6 ? 1 : 0);
+}
+
 template <typename T>
 static int launch_norm_fwd(NormDev& P, int instances, bool vec, hipStream_t st) {
     dim3 grid(P.nsplit, instances);
+    const int mode = vec ? norm_mode(instances, P.S, sizeof(T)) : 0;
     if (vec) {
         if (!P.ext) hipLaunchKernelGGL((inorm_fwd_stats_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
-        hipLaunchKernelGGL((inorm_fwd_apply_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
+        if (mode) hipLaunchKernelGGL((inorm_fwd_apply_kernel<T, true, true, 4>), grid, dim3(kBlock), 0, st, P);
+        else hipLaunchKernelGGL((inorm_fwd_apply_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
     } else {
         if (!P.ext) hipLaunchKernelGGL((inorm_fwd_stats_kernel<T, false>), grid, dim3(kBlock), 0, st, P);
         hipLaunchKernelGGL((inorm_fwd_apply_kernel<T, false>), grid, dim3(kBlock), 0, st, P);
@@ -345,9 +418,13 @@ static int launch_norm_fwd(NormDev& P, int instances, bool vec, hipStream_t st) 
 template <typename T>
 static int launch_norm_bwd(NormDev& P, int instances, bool vec, hipStream_t st) {
     dim3 grid(P.nsplit, instances);
+    const int mode = vec ? norm_mode(instances, P.S, sizeof(T)) : 0;
     if (vec) {
-        hipLaunchKernelGGL((inorm_bwd_stats_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
-        hipLaunchKernelGGL((inorm_bwd_apply_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
+        if (mode == 2) hipLaunchKernelGGL((inorm_bwd_stats_kernel<T, true, true, 4>), grid, dim3(kBlock), 0, st, P);
+        else if (mode == 1) hipLaunchKernelGGL((inorm_bwd_stats_kernel<T, true, false, 4>), grid, dim3(kBlock), 0, st, P);
+        else hipLaunchKernelGGL((inorm_bwd_stats_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
+        if (mode) hipLaunchKernelGGL((inorm_bwd_apply_kernel<T, true, true, 4>), grid, dim3(kBlock), 0, st, P);
+        else hipLaunchKernelGGL((inorm_bwd_apply_kernel<T, true>), grid, dim3(kBlock), 0, st, P);
     } else {
         hipLaunchKernelGGL((inorm_bwd_stats_kernel<T, false>), grid, dim3(kBlock), 0, st, P);
         hipLaunchKernelGGL((inorm_bwd_apply_kernel<T, false>), grid, dim3(kBlock), 0, st, P);

@@ -106,9 +106,12 @@ template <> struct Vec<bf16_t> { static constexpr int N = 8; };
 template <typename T, bool VEC> struct Pack {
     static constexpr int N = VEC ? Vec<T>::N : 1;
     float v[N];
+    template <bool NT = false>
     __device__ __forceinline__ void load(const T* p) {
         if (VEC) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(p);
+            typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
+            // NT: streamed once, no reuse expected (the 128^3 volumes are larger than the 256 MB last-level cache)
+            const raw4 raw = NT ? __builtin_nontemporal_load(reinterpret_cast<const raw4*>(p)) : *reinterpret_cast<const raw4*>(p);
             T tmp[N];
             memcpy(tmp, &raw, 16);
 #pragma unroll
@@ -117,14 +120,17 @@ template <typename T, bool VEC> struct Pack {
             v[0] = to_f32(p[0]);
         }
     }
+    template <bool NT = false>
     __device__ __forceinline__ void store(T* p) const {
         if (VEC) {
+            typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
             T tmp[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) tmp[i] = from_f32<T>(v[i]);
-            uint4 raw;
+            raw4 raw;
             memcpy(&raw, tmp, 16);
-            *reinterpret_cast<uint4*>(p) = raw;
+            if (NT) __builtin_nontemporal_store(raw, reinterpret_cast<raw4*>(p));
+            else *reinterpret_cast<raw4*>(p) = raw;
         } else {
             p[0] = from_f32<T>(v[0]);
         }

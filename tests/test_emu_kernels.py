@@ -208,8 +208,14 @@ def _instnorm_reference(x, res, act, slope, gy):
     ((1, 2, 16, 32, 48), "leaky_relu", True, torch.float32),     # several slabs per instance (Chan merge)
     ((2, 2, 4, 8, 16), "none", False, torch.bfloat16),
     ((1, 3, 4, 8, 16), "leaky_relu", True, torch.bfloat16),
+    ((1, 2, 18, 32, 48), "leaky_relu", True, torch.bfloat16),    # 13.5 thread-strides per instance: the unrolled loops and their tails
+    ((1, 2, 18, 32, 48), "relu", False, torch.bfloat16),
 ])
-def test_instance_norm_act_emulated(emu, shape, act, with_res, dtype):
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_instance_norm_act_emulated(emu, shape, act, with_res, dtype, mode, monkeypatch):
+    """mode: how the passes stream (csrc/instnorm.hip norm_mode: the library picks by tensor size - 1 and 2, non-temporal accesses and
+    four packets in flight per thread, are what the 64^3 / 128^3 levels take; forced here on test-sized tensors)"""
+    monkeypatch.setenv("SEGM_NORM_NT", str(mode))
     g = torch.Generator().manual_seed(sum(shape))
     x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(dtype)
     res = torch.randn(shape, generator=g).to(dtype) if with_res else None
