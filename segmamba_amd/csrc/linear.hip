@@ -9,9 +9,14 @@
 //   * W (N x K, at most 192 x 192 per block of output columns) is STATIONARY in registers as MFMA A-operand fragments;
 //   * a wave walks 16-row tiles of x: each lane loads its B-operand fragments straight from global memory (16 bytes of
 //     one row per fragment), the next tile's loads are in flight during the current tile's MFMAs;
-//   * D = W x^T, so a lane ends up with four consecutive output columns of one row: 8-byte stores, no LDS anywhere.
+//   * D = W x^T, so a lane ends up with four consecutive output columns of one row, no LDS anywhere.  Round 5 (WIDE): the rows of
+//     W are dealt to the A operands of a PAIR of column tiles so that the lane's 4 + 4 columns are eight consecutive ones -
+//     16-byte stores (and 16-byte reads of the old values in accumulate mode) where round 2 - 4 issued two 8-byte ones: output
+//     bytes dominate these operators (in_proj writes four times what it reads), and 8-byte accesses run at 0.54 - 0.70 of the
+//     16-byte rate on this part (MI355X_MICROARCH.md).
 // v_mfma_f32_16x16x32: A[i][k]: lane l holds A[i = l & 15][8 (l >> 4) .. +7]; B[k][j]: lane l holds B[8 (l >> 4) .. +7][j = l & 15];
 // D[row = 4 (l >> 4) + r][col = l & 15].  Here i = output column n, j = row m.
+#include <stdlib.h>
 #include <string.h>
 
 #include "segm_device.h"
@@ -38,22 +43,27 @@ struct LinDev {
 // KC = 32-wide chunks of K held per wave; NT = 16-column tiles of W per wave (at most 24 fragments = 96 VGPRs, which
 // leaves room for two to three waves per SIMD - the kernel lives on memory-level parallelism)
 constexpr int lin_tiles(int kc) { return kc <= 2 ? 12 : (kc == 3 ? 8 : (kc == 4 ? 6 : 4)); }
-template <typename T, int KC, bool ACCUM = false>
+// WIDE: tile pair p = t / 2 covers columns n0 + 32 p .. + 31; A-operand row i of tile t holds output column
+// n0 + 32 p + 8 (i >> 2) + 4 (t & 1) + (i & 3), so lane group g ends up with columns 8 g .. 8 g + 3 (tile 2 p) and 8 g + 4 .. 8 g + 7
+// (tile 2 p + 1) of the pair: one 16-byte store.  (y rows 16-byte aligned: ldy % 8 == 0, checked by the launcher.)
+template <typename T, int KC, bool ACCUM = false, bool WIDE = false>
 __global__ void __launch_bounds__(kLinWaves * 64) linear_rows_kernel(LinDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     constexpr int NT = lin_tiles(KC);
+    static_assert(NT % 2 == 0, "column tiles come in pairs");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.y * NT * 16;
     int nt_live = (P.n - n0 + 15) / 16;
+    if (WIDE) nt_live = (nt_live + 1) & ~1;               // whole pairs (columns past n are masked)
     nt_live = nt_live > NT ? NT : nt_live;
     const T* W = reinterpret_cast<const T*>(P.w);
 
     frag8 wf[NT][KC];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int n = n0 + 16 * t + i16;
+        const int n = WIDE ? n0 + 32 * (t >> 1) + 8 * (i16 >> 2) + 4 * (t & 1) + (i16 & 3) : n0 + 16 * t + i16;
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             const int k = 32 * c + 8 * g;
@@ -81,6 +91,47 @@ __global__ void __launch_bounds__(kLinWaves * 64) linear_rows_kernel(LinDev P) {
     auto compute = [&](const frag8 (&xf)[KC], int64_t tile) {
         const int64_t m = tile * 16 + i16;
         const bool row_ok = tile < ntiles && m < P.rows;
+        if constexpr (WIDE) {
+            T* yrow = reinterpret_cast<T*>(P.y) + (row_ok ? m : 0) * P.ldy + n0 + 8 * g;
+            lin_u32x4 oldv[ACCUM ? NT / 2 : 1];
+            if constexpr (ACCUM) {
+#pragma unroll
+                for (int p = 0; p < NT / 2; ++p)
+                    if (2 * p < nt_live && row_ok && n0 + 32 * p + 8 * g < P.n) oldv[p] = *reinterpret_cast<const lin_u32x4*>(yrow + 32 * p);
+            }
+#pragma unroll
+            for (int p = 0; p < NT / 2; ++p) {
+                if (2 * p < nt_live) {                       // uniform
+                    const int nb = n0 + 32 * p + 8 * g;      // this lane's eight output columns of the pair (n % 8 == 0: all or none)
+                    const bool col_ok = nb < P.n;
+                    lin_f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                    if (P.bias) {
+                        a0 = *reinterpret_cast<const lin_f32x4*>(P.bias + (col_ok ? nb : 0));
+                        a1 = *reinterpret_cast<const lin_f32x4*>(P.bias + (col_ok ? nb + 4 : 0));
+                    }
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) {
+                        a0 = Mfma16<T>::run(wf[2 * p][c], xf[c], a0);
+                        a1 = Mfma16<T>::run(wf[2 * p + 1][c], xf[c], a1);
+                    }
+                    if (row_ok && col_ok) {
+                        if constexpr (ACCUM) {
+                            T o[8];
+                            memcpy(o, &oldv[p], 16);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { a0[q] += to_f32(o[q]); a1[q] += to_f32(o[4 + q]); }
+                        }
+                        lin_u32x4 pk;
+                        pk[0] = pack2<T>(a0[0], a0[1]);
+                        pk[1] = pack2<T>(a0[2], a0[3]);
+                        pk[2] = pack2<T>(a1[0], a1[1]);
+                        pk[3] = pack2<T>(a1[2], a1[3]);
+                        *reinterpret_cast<lin_u32x4*>(yrow + 32 * p) = pk;
+                    }
+                }
+            }
+            return;
+        }
         T* yrow = reinterpret_cast<T*>(P.y) + (row_ok ? m : 0) * P.ldy + n0 + 4 * g;
         // accumulate: what y holds is fetched for ALL column tiles before the first MFMA (round 3 loaded each tile's old values
         // after its MFMAs and waited for them: one memory round trip per column tile and row tile on the critical path)
@@ -139,15 +190,24 @@ static int launch_linear(const LinDev& P, hipStream_t st) {
     if (gx >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;
     const dim3 grid((unsigned)gx, (unsigned)((P.n + nt * 16 - 1) / (nt * 16)));
     const dim3 block(kLinWaves * 64);
+    // 16-byte stores when every output row segment is 16-byte aligned and whole (SEGM_LINEAR_WIDE=0: the 8-byte form, A/B)
+    static const bool wide_on = [] { const char* e = getenv("SEGM_LINEAR_WIDE"); return !(e && e[0] == '0'); }();
+    const bool wide = wide_on && P.n % 8 == 0 && P.ldy % 8 == 0 && ((uintptr_t)P.y & 15) == 0;
+#define SEGM_LIN_LAUNCH(KC_, ACC_, WIDE_) hipLaunchKernelGGL((linear_rows_kernel<T, KC_, ACC_, WIDE_>), grid, block, 0, st, P)
+#define SEGM_LIN_KC(ACC_, WIDE_)                                   \
+    do {                                                           \
+        if (kc <= 2) SEGM_LIN_LAUNCH(2, ACC_, WIDE_);              \
+        else if (kc == 3) SEGM_LIN_LAUNCH(3, ACC_, WIDE_);         \
+        else if (kc == 4) SEGM_LIN_LAUNCH(4, ACC_, WIDE_);         \
+        else SEGM_LIN_LAUNCH(6, ACC_, WIDE_);                      \
+    } while (0)
     if (P.accumulate) {
-        if (kc <= 2) hipLaunchKernelGGL((linear_rows_kernel<T, 2, true>), grid, block, 0, st, P);
-        else if (kc == 3) hipLaunchKernelGGL((linear_rows_kernel<T, 3, true>), grid, block, 0, st, P);
-        else if (kc == 4) hipLaunchKernelGGL((linear_rows_kernel<T, 4, true>), grid, block, 0, st, P);
-        else hipLaunchKernelGGL((linear_rows_kernel<T, 6, true>), grid, block, 0, st, P);
-    } else if (kc <= 2) hipLaunchKernelGGL((linear_rows_kernel<T, 2>), grid, block, 0, st, P);
-    else if (kc == 3) hipLaunchKernelGGL((linear_rows_kernel<T, 3>), grid, block, 0, st, P);
-    else if (kc == 4) hipLaunchKernelGGL((linear_rows_kernel<T, 4>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((linear_rows_kernel<T, 6>), grid, block, 0, st, P);
+        if (wide) SEGM_LIN_KC(true, true); else SEGM_LIN_KC(true, false);
+    } else {
+        if (wide) SEGM_LIN_KC(false, true); else SEGM_LIN_KC(false, false);
+    }
+#undef SEGM_LIN_KC
+#undef SEGM_LIN_LAUNCH
     return (int)hipGetLastError();
 }
 
