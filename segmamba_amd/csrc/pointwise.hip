@@ -10,10 +10,14 @@
 //     paired with v_perm_b32 into {ci, ci + 1} dwords and written to a wave-private LDS tile [64 s][ci] - the transpose the
 //     MFMA operand needs (K = ci must be contiguous per lane); one ds_read_b128 per A fragment; the next strip's loads are
 //     in flight during the current strip's MFMAs;
-//   * D[s][co] = x^T W^T: a lane ends up with four consecutive voxels of one output channel: 8-byte stores, bias in the
-//     accumulator initialisation, optional accumulation into y (the second half of a concatenated input).
+//   * D[s][co] = x^T W^T: a lane ends up with four consecutive voxels of one output channel; bias in the accumulator
+//     initialisation, optional accumulation into y (the second half of a concatenated input).  Round 5 (WIDE): the tile rows of a
+//     PAIR of 16-voxel blocks are dealt so that the lane's 4 + 4 voxels are eight consecutive ones - 16-byte stores (and 16-byte
+//     reads of the old values) instead of two 8-byte ones, which run at 0.54 - 0.70 of the 16-byte rate (MI355X_MICROARCH.md); only
+//     the park's row index changes (and its bank conflicts drop from 4-way to 2-way), the fragment reads stay consecutive rows.
 // v_mfma_f32_16x16x32: A[i][k]: lane l holds A[i = l & 15][8 (l >> 4) .. +7]; B[k][j]: lane l holds B[8 (l >> 4) .. +7][j = l & 15];
 // D[row = 4 (l >> 4) + r][col = l & 15].  Here i = voxel, k = input channel, j = output channel.
+#include <stdlib.h>
 #include <string.h>
 
 #include "segm_device.h"
@@ -40,7 +44,9 @@ struct PwDev {
 };
 
 // KT = 32-wide chunks of cin, NT = 16-wide tiles of cout
-template <typename T, int KT, int NT>
+// WIDE: tile row 32 pb + 16 h + 4 q + r holds voxel 32 pb + 8 q + 4 h + r (pb: pair of 16-voxel blocks, h: block of the pair), so MFMA
+// output row 4 g + r of block 2 pb + h is voxel 32 pb + 8 g + 4 h + r: lane group g owns voxels 8 g .. 8 g + 7 of the pair.
+template <typename T, int KT, int NT, bool WIDE = false>
 __global__ void __launch_bounds__(kPwWaves * 64) pointwise_cf_kernel(PwDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     constexpr int PITCH = KT * 32 + 8;       // elements per LDS row: 16-byte aligned rows, consecutive rows 4 banks apart
@@ -93,14 +99,54 @@ __global__ void __launch_bounds__(kPwWaves * 64) pointwise_cf_kernel(PwDev P) {
 #pragma unroll
         for (int q = 0; q < G16; ++q) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)                           // {channel c0, channel c0 + 1} of voxel 8 sg + e
-                *reinterpret_cast<uint32_t*>(lt + (8 * sg + e) * PITCH + 16 * q + 2 * rp) =
+            for (int e = 0; e < 8; ++e) {                         // {channel c0, channel c0 + 1} of voxel 8 sg + e
+                const int row = WIDE ? 32 * (sg >> 2) + 16 * (e >> 2) + 4 * (sg & 3) + (e & 3) : 8 * sg + e;
+                *reinterpret_cast<uint32_t*>(lt + row * PITCH + 16 * q + 2 * rp) =
                     __builtin_amdgcn_perm(rc[q][e >> 1], ra[q][e >> 1], (e & 1) ? 0x07060302u : 0x05040100u);
+            }
         }
     };
     auto compute_strip = [&](int64_t strip) {
         const int64_t b = strip / strips_per_batch, s0 = (strip - b * strips_per_batch) * kPwStrip;
         T* yb = reinterpret_cast<T*>(P.y) + b * P.y_sb + s0;
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int pb = 0; pb < kPwStrip / 32; ++pb) {          // pairs of 16-voxel blocks
+                frag8 a0[KT], a1[KT];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    a0[kt] = __builtin_bit_cast(frag8, *reinterpret_cast<const pw_u32x4*>(lt + (32 * pb + i16) * PITCH + 32 * kt + 8 * g));
+                    a1[kt] = __builtin_bit_cast(frag8, *reinterpret_cast<const pw_u32x4*>(lt + (32 * pb + 16 + i16) * PITCH + 32 * kt + 8 * g));
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    pw_f32x4 c0 = {bias4[nt], bias4[nt], bias4[nt], bias4[nt]}, c1 = c0;
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        c0 = Mfma16<T>::run(a0[kt], wf[kt][nt], c0);
+                        c1 = Mfma16<T>::run(a1[kt], wf[kt][nt], c1);
+                    }
+                    const int co = 16 * nt + i16;
+                    if (co < P.cout) {                            // this lane: voxels 32 pb + 8 g .. + 7 of output channel co
+                        T* yp = yb + (int64_t)co * P.y_sc + 32 * pb + 8 * g;
+                        if (P.accumulate) {                       // uniform
+                            const pw_u32x4 old = *reinterpret_cast<const pw_u32x4*>(yp);
+                            T o[8];
+                            memcpy(o, &old, 16);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { c0[r] += to_f32(o[r]); c1[r] += to_f32(o[4 + r]); }
+                        }
+                        pw_u32x4 pk;
+                        pk[0] = pack2<T>(c0[0], c0[1]);
+                        pk[1] = pack2<T>(c0[2], c0[3]);
+                        pk[2] = pack2<T>(c1[0], c1[1]);
+                        pk[3] = pack2<T>(c1[2], c1[3]);
+                        *reinterpret_cast<pw_u32x4*>(yp) = pk;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int vb = 0; vb < kPwStrip / 16; ++vb) {              // 16-voxel blocks of the strip
             frag8 af[KT];
@@ -144,17 +190,17 @@ __global__ void __launch_bounds__(kPwWaves * 64) pointwise_cf_kernel(PwDev P) {
     }
 }
 
-template <typename T, int KT>
+template <typename T, int KT, bool WIDE>
 static int launch_pw_nt(const PwDev& P, hipStream_t st, dim3 grid) {
     const int nt = (P.cout + 15) / 16;
     const dim3 block(kPwWaves * 64);
     switch (nt) {
-        case 1: hipLaunchKernelGGL((pointwise_cf_kernel<T, KT, 1>), grid, block, 0, st, P); break;
-        case 2: hipLaunchKernelGGL((pointwise_cf_kernel<T, KT, 2>), grid, block, 0, st, P); break;
-        case 3: hipLaunchKernelGGL((pointwise_cf_kernel<T, KT, 3>), grid, block, 0, st, P); break;
-        case 4: hipLaunchKernelGGL((pointwise_cf_kernel<T, KT, 4>), grid, block, 0, st, P); break;
-        case 5: hipLaunchKernelGGL((pointwise_cf_kernel<T, KT, 5>), grid, block, 0, st, P); break;
-        default: hipLaunchKernelGGL((pointwise_cf_kernel<T, KT, 6>), grid, block, 0, st, P); break;
+        case 1: hipLaunchKernelGGL((pointwise_cf_kernel<T, KT, 1, WIDE>), grid, block, 0, st, P); break;
+        case 2: hipLaunchKernelGGL((pointwise_cf_kernel<T, KT, 2, WIDE>), grid, block, 0, st, P); break;
+        case 3: hipLaunchKernelGGL((pointwise_cf_kernel<T, KT, 3, WIDE>), grid, block, 0, st, P); break;
+        case 4: hipLaunchKernelGGL((pointwise_cf_kernel<T, KT, 4, WIDE>), grid, block, 0, st, P); break;
+        case 5: hipLaunchKernelGGL((pointwise_cf_kernel<T, KT, 5, WIDE>), grid, block, 0, st, P); break;
+        default: hipLaunchKernelGGL((pointwise_cf_kernel<T, KT, 6, WIDE>), grid, block, 0, st, P); break;
     }
     return (int)hipGetLastError();
 }
@@ -170,9 +216,17 @@ static int launch_pw(PwDev& P, hipStream_t st) {
     if (gx >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;
     const dim3 grid((unsigned)gx);
     const int kt = (P.cin + 31) / 32;
-    if (kt == 1) return launch_pw_nt<T, 1>(P, st, grid);
-    if (kt == 2) return launch_pw_nt<T, 2>(P, st, grid);
-    return launch_pw_nt<T, 3>(P, st, grid);
+    // 16-byte stores when every output row is 16-byte aligned (SEGM_POINTWISE_WIDE=0: the 8-byte form, A/B)
+    static const bool wide_on = [] { const char* e = getenv("SEGM_POINTWISE_WIDE"); return !(e && e[0] == '0'); }();
+    const bool wide = wide_on && P.y_sb % 8 == 0 && P.y_sc % 8 == 0 && ((uintptr_t)P.y & 15) == 0;
+    if (wide) {
+        if (kt == 1) return launch_pw_nt<T, 1, true>(P, st, grid);
+        if (kt == 2) return launch_pw_nt<T, 2, true>(P, st, grid);
+        return launch_pw_nt<T, 3, true>(P, st, grid);
+    }
+    if (kt == 1) return launch_pw_nt<T, 1, false>(P, st, grid);
+    if (kt == 2) return launch_pw_nt<T, 2, false>(P, st, grid);
+    return launch_pw_nt<T, 3, false>(P, st, grid);
 }
 
 }  // namespace segm

@@ -1119,6 +1119,13 @@ def test_pointwise_cf_emulated(emu, B, Cin, Cout, S, dtype, bias, view):
     y2 = ops_raw.pointwise_cf(emu, x, w, None, out=y.clone(), accumulate=True)
     ref2 = y.float() + torch.einsum("oc,bcs->bos", w.float(), x.float())
     assert (y2.float() - ref2).abs().max() <= tol * max(1.0, float(ref2.abs().max()))
+    # the result above went out in 16-byte stores (rows of the fresh output are 16-byte aligned: voxel blocks dealt in pairs); a
+    # destination whose channel rows are only 8-byte aligned takes the 8-byte form: the same values, nothing outside written
+    buf = torch.full((B, Cout, S + 4), 7.0).to(dtype)
+    y8 = ops_raw.pointwise_cf(emu, x, w, b, out=buf[:, :, :S])
+    assert torch.equal(y8, y) and (buf[:, :, S:] == 7).all()
+    y8b = ops_raw.pointwise_cf(emu, x, w, None, out=y8, accumulate=True)
+    assert torch.equal(y8b, y2)
     with pytest.raises(RuntimeError):
         ops_raw.pointwise_cf(emu, x[:, :, :S - 8], w)                      # voxels not a multiple of 64
 
