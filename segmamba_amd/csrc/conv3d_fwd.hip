@@ -80,6 +80,54 @@ __device__ __forceinline__ void store4(T* dst, const float (&v)[4]) {
     *reinterpret_cast<u32x2*>(dst) = pk;
 }
 
+// Round 5 (WIDE epilogue of the chained kernels): a lane holds four consecutive x of BOTH x tiles of its wave (lane group g: x = 4 g ..
+// of tile 0 and of tile 1).  v_permlane16_swap_b32 trades the odd lane groups' tile-0 values for the even groups' tile-1 values:
+// afterwards group g holds EIGHT consecutive x - 8 (g >> 1) .. + 7 of tile (g & 1) - one 16-byte store (and one 16-byte read of the
+// old values in the accumulate variants) instead of two 8-byte ones; a store instruction then writes 64 contiguous bytes per
+// channel row instead of 32.  (Dealing the tile rows in pairs, as the 1x1x1 kernel does, would put fragment rows r and r + 16 of the
+// ring on the same banks.)  The exchange runs on the PACKED values (two per tile), the arithmetic stays in the accumulators' layout:
+// exchanging fp32 values first kept eight more registers live per co tile and spilled (57 in the 32-wide accumulate + statistics kernel).
+// packed values of the two tiles (p0: tile 0, p1: tile 1; two dwords = four x each) -> the lane's eight consecutive x
+__device__ __forceinline__ u32x4 pair_swap(const u32x2& p0, const u32x2& p1) {
+    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(p0[0], p1[0], false, false);
+    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(p0[1], p1[1], false, false);
+    const u32x4 r = {s0[0], s1[0], s0[1], s1[1]};
+    return r;
+}
+// ... and back (the exchange is its own inverse): what a 16-byte read of y returned -> the old values in the accumulators' layout
+__device__ __forceinline__ void pair_unswap(const u32x4& o, u32x2& p0, u32x2& p1) {
+    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
+    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
+    p0[0] = s0[0]; p0[1] = s1[0];
+    p1[0] = s0[1]; p1[1] = s1[1];
+}
+// the wide epilogue of one co tile: (+ old values) (+ statistics) -> 16-byte store
+template <typename T, bool ACC, bool STATS>
+__device__ __forceinline__ void store_pair(char* dst, const f32x4& a0, const f32x4& a1, const u32x4& old, float& ssum, float& ssq) {
+    float v0[4], v1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v0[q] = a0[q]; v1[q] = a1[q]; }
+    if (ACC) {
+        u32x2 o0, o1;
+        pair_unswap(old, o0, o1);
+        T t0[4], t1[4];
+        memcpy(t0, &o0, 8);
+        memcpy(t1, &o1, 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v0[q] += to_f32(t0[q]); v1[q] += to_f32(t1[q]); }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ssum += v0[q]; ssq = fmaf(v0[q], v0[q], ssq); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ssum += v1[q]; ssq = fmaf(v1[q], v1[q], ssq); }
+    }
+    u32x2 p0, p1;
+    p0[0] = pack2<T>(v0[0], v0[1]); p0[1] = pack2<T>(v0[2], v0[3]);
+    p1[0] = pack2<T>(v1[0], v1[1]); p1[1] = pack2<T>(v1[2], v1[3]);
+    *reinterpret_cast<u32x4*>(dst) = pair_swap(p0, p1);
+}
+
 template <typename T, int NCO>
 __global__ void __launch_bounds__(kFwThreads) conv3d_k3_fwd_kernel(ConvFwdDev P) {
     typedef typename Mfma16<T>::v8 frag8;
@@ -493,7 +541,7 @@ __global__ void __launch_bounds__(kF48Threads, 2) conv3d_k3_fwd48_kernel(ConvFwd
 // InstanceNorm behind this convolution merges D x H / rows x W / 32 partials per instance (Chan's update, segm_instnorm_fwd's
 // `stats_partials`) instead of reading the volume once more.  MEASURED price (profiles/r05_inorm_epilogue.log): none - 48 -> 48
 // @128^3 0.569 vs 0.546 ms, 96 -> 48 @128^3 1.225 vs 1.241 ms with / without; the statistics pass it replaces: ~0.08 ms per 128^3 layer.
-template <typename T, bool ACC, int CP, int VAR = 0, bool STATS = false>
+template <typename T, bool ACC, int CP, int VAR = 0, bool STATS = false, bool WIDE = false>
 __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     constexpr bool SKIP = (VAR & 1) != 0;
@@ -578,6 +626,8 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
     // output addresses = uniform base (row, co tile, x tile: scalar arithmetic) + one 32-bit lane offset (co and x within the tile;
     // the host checks that 16 channel strides fit 32 bits)
     const uint32_t ylane = (uint32_t)(((int64_t)i16 * P.y_sc + 4 * g) * (int64_t)sizeof(T));
+    // WIDE: after pair_swap this lane stores x = 8 (g >> 1) .. + 7 of x tile (g & 1), relative to ybase(row, t, 0)
+    const uint32_t ylane16 = (uint32_t)(((int64_t)i16 * P.y_sc + 16 * (g & 1) + 8 * (g >> 1)) * (int64_t)sizeof(T));
     auto ybase = [&](int row, int t, int u) {
         return P.y + ((int64_t)b * P.y_sb + (int64_t)(cob * 48 + t * 16) * P.y_sc + (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + x0 +
                       (xp * XT + u) * 16) * (int64_t)sizeof(T);
@@ -664,7 +714,12 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
         fetch_s(r, s);                                    // in flight during this step's MFMAs
         // accumulate variant: what y holds for this row is fetched now and added after the MFMAs (see the 32-wide kernel)
         u32x2 oldy[XT][3];
-        if (ACC && active && prt == 3) {
+        u32x4 oldw[3];
+        if (ACC && WIDE && active && prt == 3) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) oldw[t] = *reinterpret_cast<const u32x4*>(ybase(row, t, 0) + ylane16);
+        }
+        if (ACC && !WIDE && active && prt == 3) {
 #pragma unroll
             for (int u = 0; u < XT; ++u) {
                 const int xg = x0 + (xp * XT + u) * 16 + 4 * g;
@@ -701,7 +756,15 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
         // the last K part stores AFTER the rows are parked: vmcnt counts loads and stores in order, so a park behind the stores
         // would wait for their write acknowledgements (a memory round trip on the critical path of every step); here the
         // stores drain during the next step
-        if (active && prt == 3) {
+        if (WIDE && active && prt == 3) {                 // (the launcher: W a multiple of the 64-wide block, nothing ragged)
+            static_assert(!WIDE || XT == 2, "the wide epilogue pairs the wave's two x tiles");
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if constexpr (STATS) store_pair<T, ACC, true>(ybase(row, t, 0) + ylane16, acc[t][0], acc[t][1], oldw[t], st_s[t], st_q[t]);
+                else { float d0 = 0.f, d1 = 0.f; store_pair<T, ACC, false>(ybase(row, t, 0) + ylane16, acc[t][0], acc[t][1], oldw[t], d0, d1); }
+            }
+        }
+        if (!WIDE && active && prt == 3) {
 #pragma unroll
             for (int u = 0; u < XT; ++u) {
                 const int xg = x0 + (xp * XT + u) * 16 + 4 * g;            // this lane's 4 output positions
@@ -799,7 +862,7 @@ __device__ __forceinline__ CopyLane copy_lane32(const ConvFwdDev& P, bool halo, 
     return L;
 }
 
-template <typename T, bool ACC, int VAR = 0, bool STATS = false>
+template <typename T, bool ACC, int VAR = 0, bool STATS = false, bool WIDE = false>
 __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwdDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     constexpr bool SKIP = (VAR & 1) != 0;
@@ -893,6 +956,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
     // within the tile; the host checks that 16 channel strides fit 32 bits).  (As a buffer resource + scalar offset the accumulate
     // variant's last K part - eleven chunks of weights, the old outputs in flight - spilled 22 registers; this form spills 3.)
     const uint32_t ylane = (uint32_t)(((int64_t)i16 * P.y_sc + 4 * g) * (int64_t)sizeof(T));
+    // WIDE: after pair_swap this lane stores x = 8 (g >> 1) .. + 7 of x tile (g & 1), relative to ybase(row, t, 0)
+    const uint32_t ylane16 = (uint32_t)(((int64_t)i16 * P.y_sc + 16 * (g & 1) + 8 * (g >> 1)) * (int64_t)sizeof(T));
     auto ybase = [&](int row, int t, int u) {
         return P.y + ((int64_t)b * P.y_sb + (int64_t)(cob * 48 + t * 16) * P.y_sc + (int64_t)z * P.y_sz + (int64_t)row * P.y_sy + x0 + u * 16) *
                          (int64_t)sizeof(T);
@@ -982,7 +1047,12 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
         // a memory round trip between the last MFMA and the stores of every row - profiles/r04_conv_pmc.log: the `_Accum`
         // launches took twice the wave cycles of the plain ones)
         u32x2 oldy[XT][3];
-        if (ACC && active && prt == 3) {
+        u32x4 oldw[3];
+        if (ACC && WIDE && active && prt == 3) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) oldw[t] = *reinterpret_cast<const u32x4*>(ybase(row, t, 0) + ylane16);
+        }
+        if (ACC && !WIDE && active && prt == 3) {
 #pragma unroll
             for (int u = 0; u < XT; ++u) {
                 const int xg = x0 + u * 16 + 4 * g;
@@ -1012,6 +1082,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
                     for (int u = 0; u < XT; ++u) hand[s & 1][prt][t * XT + u][lane] = acc[t][u];
+            } else if constexpr (WIDE) {                  // (the launcher: W a multiple of the 32-wide block, nothing ragged)
+                static_assert(!WIDE || XT == 2, "the wide epilogue pairs the wave's two x tiles");
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    if constexpr (STATS) store_pair<T, ACC, true>(ybase(row, t, 0) + ylane16, acc[t][0], acc[t][1], oldw[t], st_s[t], st_q[t]);
+                    else { float d0 = 0.f, d1 = 0.f; store_pair<T, ACC, false>(ybase(row, t, 0) + ylane16, acc[t][0], acc[t][1], oldw[t], d0, d1); }
+                }
             } else {
 #pragma unroll
                 for (int u = 0; u < XT; ++u) {
@@ -1085,6 +1162,13 @@ static FwPlan fwd_plan(int batch, int cout, int d, int h, int w, bool chain = fa
     return p;
 }
 
+// the wide epilogue of the chained kernels (pair_swap + 16-byte stores): every x block inside the row (nothing ragged to mask);
+// SEGM_CONV_WIDE=0: the 8-byte form (A/B)
+static bool conv_wide(int width, int xb) {
+    const char* e = getenv("SEGM_CONV_WIDE");             // (per launch: the tests switch it)
+    return !(e && e[0] == '0') && width % xb == 0;
+}
+
 static int chain_var() {                                // 3 = the shipped schedule, 0 = round 3's (A/B timing)
     static const int v = [] { const char* e = getenv("SEGM_CONV_CHAIN_VAR"); return e && atoi(e) == 0 ? 0 : 3; }();
     return v;
@@ -1093,17 +1177,17 @@ static int chain_var() {                                // 3 = the shipped sched
 template <int CHAIN>                                    // 0: reduce-per-row kernel; else the chained kernel with that ci pitch
 static void launch48(const ConvFwdDev& P, dim3 grid, bool f16, bool acc, hipStream_t stream) {
     if (CHAIN == 48 && chain_var() != 0) {
-    // the accumulate variant keeps the old outputs of a row in flight during its MFMAs: fragments ONE chunk ahead there (V & ~2)
-#define SEGM_LV(T, V) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, true, 48, (V) & ~2>), grid, dim3(512), 0, stream, P); \
-                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, false, 48, V>), grid, dim3(512), 0, stream, P); } while (0)
+    // the accumulate variant keeps the old outputs of a row in flight during its MFMAs: fragments ONE chunk ahead there (V & ~2).
+    // W_: the wide epilogue (16-byte stores; W a multiple of the x block - conv_wide())
+#define SEGM_LV(T, V, S_, W_) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, true, 48, (V) & ~2, S_, W_>), grid, dim3(512), 0, stream, P); \
+                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, false, 48, V, S_, W_>), grid, dim3(512), 0, stream, P); } while (0)
+#define SEGM_LW(T, S_) do { if (conv_wide(P.W, kFwXB)) SEGM_LV(T, 11, S_, true); else SEGM_LV(T, 11, S_, false); } while (0)
         if (P.stats) {                                  // + the statistics epilogue of the storing K part
-#define SEGM_LS(T) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, true, 48, 11 & ~2, true>), grid, dim3(512), 0, stream, P); \
-                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain_kernel<T, false, 48, 11, true>), grid, dim3(512), 0, stream, P); } while (0)
-            if (f16) SEGM_LS(f16_t); else SEGM_LS(bf16_t);
-#undef SEGM_LS
+            if (f16) SEGM_LW(f16_t, true); else SEGM_LW(bf16_t, true);
             return;
         }
-        if (f16) SEGM_LV(f16_t, 11); else SEGM_LV(bf16_t, 11);       // the 64-wide kernel: also instantiated per K part (bit 3)
+        if (f16) SEGM_LW(f16_t, false); else SEGM_LW(bf16_t, false);       // the 64-wide kernel: also instantiated per K part (bit 3)
+#undef SEGM_LW
 #undef SEGM_LV
         return;
     }
@@ -1174,19 +1258,19 @@ extern "C" int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* a) {
     if (chain32) {
         const dim3 grid(pl.nitems * (a->cout / 48));
 #define SEGM_L32(T, A) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, A>), grid, dim3(256), 0, stream, P)
-#define SEGM_LV(T, V) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, true, V>), grid, dim3(256), 0, stream, P); \
-                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, false, V>), grid, dim3(256), 0, stream, P); } while (0)
+#define SEGM_LV(T, V, S_, W_) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, true, V, S_, W_>), grid, dim3(256), 0, stream, P); \
+                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, false, V, S_, W_>), grid, dim3(256), 0, stream, P); } while (0)
+#define SEGM_LW(T, S_) do { if (conv_wide(P.W, kC32XB)) SEGM_LV(T, 9, S_, true); else SEGM_LV(T, 9, S_, false); } while (0)
         if (P.stats) {                                  // + the statistics epilogue of the storing K part
-#define SEGM_LS(T) do { if (acc) hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, true, 9, true>), grid, dim3(256), 0, stream, P); \
-                        else hipLaunchKernelGGL((conv3d_k3_fwd48_chain32_kernel<T, false, 9, true>), grid, dim3(256), 0, stream, P); } while (0)
-            if (f16) SEGM_LS(f16_t); else SEGM_LS(bf16_t);
-#undef SEGM_LS
+            if (f16) SEGM_LW(f16_t, true); else SEGM_LW(bf16_t, true);
             return (int)hipGetLastError();
         }
         if (chain_var() != 0) {
-            if (f16) SEGM_LV(f16_t, 9); else SEGM_LV(bf16_t, 9);     // two chunks ahead measured nothing here (profiles/r04_conv_chain32_pf2.log)     // 9: skip + per-part loop, fragments one chunk ahead (two ahead spills here)
+            // 9: skip + per-part loop, fragments one chunk ahead (two ahead measured nothing and spills here: profiles/r04_conv_chain32_pf2.log)
+            if (f16) SEGM_LW(f16_t, false); else SEGM_LW(bf16_t, false);
             return (int)hipGetLastError();
         }
+#undef SEGM_LW
 #undef SEGM_LV
         if (f16) { if (acc) SEGM_L32(f16_t, true); else SEGM_L32(f16_t, false); }
         else { if (acc) SEGM_L32(bf16_t, true); else SEGM_L32(bf16_t, false); }

@@ -273,6 +273,31 @@ def test_instance_norm_padded_channel_stride_emulated(emu, shape, act, with_res,
         assert torch.equal(dres1, dres0)
 
 
+@pytest.mark.parametrize("kw", [dict(chain=True, pitch48=True), dict(chain32=True)])
+@pytest.mark.parametrize("accumulate,stats", [(False, False), (True, False), (False, True), (True, True)])
+def test_conv3d_wide_epilogue_is_the_narrow_one_emulated(emu, monkeypatch, kw, accumulate, stats):
+    """the chained kernels' 16-byte epilogue (v_permlane16_swap_b32 pairs the wave's two x tiles; csrc/conv3d_fwd.hip store_pair)
+    against their 8-byte epilogue (SEGM_CONV_WIDE=0): outputs and statistics partials bit for bit, plain / accumulate / with the
+    statistics epilogue, on a padded destination"""
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 48, 3, 5, 64, generator=g).bfloat16()
+    w = (0.05 * torch.randn(48, 48, 3, 3, 3, generator=g)).bfloat16()
+    wp = ops_raw.pack_conv3d_weight(w)
+    y0 = torch.randn(2, 48, 3, 5, 64, generator=g).bfloat16()
+    outs = []
+    for wide in ("1", "0"):
+        monkeypatch.setenv("SEGM_CONV_WIDE", wide)
+        out = _channel_padded(y0.clone(), 64)
+        r = ops_raw.conv3d_k3_fwd(emu, x, wp, None, out=out, accumulate=accumulate, want_stats=stats, **kw)
+        outs.append(r if stats else (r, None))
+    (ya, sa), (yb, sb) = outs
+    assert torch.equal(ya, yb)
+    if stats:
+        assert sa is not None and torch.equal(sa, sb)
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), None, 1, 1) + (y0.float() if accumulate else 0)
+    assert (ya.float() - ref).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max()))
+
+
 def test_conv3d_chain_padded_channel_stride_emulated(emu):
     """the 3x3x3 kernels (all variants) and the 1x1x1 kernel on input / output volumes with a padded channel stride"""
     g = torch.Generator().manual_seed(5)
