@@ -11,6 +11,8 @@
 //   * the rows a workgroup's threads summed separately are folded through LDS in a fixed order, one partial (n x m) per slab is
 //     written, and reduce_partials adds the slabs in a fixed order: deterministic, no atomics.
 // (The first version - one lane per channel, 2-byte loads, wave-uniform reads of b - ran at 0.1 TB/s: profiles/r03_step_kernels_v4.txt.)
+// Round 5 (BVEC): the NT values of b's row are ONE 8- / 16-byte load where the row segment is that aligned (x_dbl in the padded
+// layout is), not NT two-byte loads - five load instructions per 16 useful bytes had the address unit, not HBM, as the limit.
 #include <stdlib.h>
 #include <string.h>
 
@@ -47,8 +49,9 @@ static inline void skinny_geometry(int32_t m, int32_t n, int64_t k, int32_t* thr
     *nslab = (int32_t)((k + *slab_rows - 1) / *slab_rows);
 }
 
-template <typename T, int NT, int kSkU>
+template <typename T, int NT, int kSkU, bool BVEC = false>
 __global__ void __launch_bounds__(kBlock) skinny_tn_kernel(SkinnyDev P) {
+    typedef uint32_t bvec_t __attribute__((ext_vector_type(NT / 2)));
     __shared__ float s_fold[kSkMaxLds];
     const int tid = threadIdx.x;
     const int row = tid / P.threads_per_row, cg = tid - row * P.threads_per_row;
@@ -73,8 +76,19 @@ __global__ void __launch_bounds__(kBlock) skinny_tn_kernel(SkinnyDev P) {
                 const int64_t ru = r + (int64_t)u * P.rows_per_pass;
                 const bool ok = ru < k1;
                 raw[u] = ok ? *reinterpret_cast<const uint4*>(a + ru * P.a_sr) : uint4{0u, 0u, 0u, 0u};
+                if constexpr (BVEC) {                     // the launcher: segment aligned, NT columns readable in every row
+                    bvec_t rb;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bv[u][j] = (ok && j < nj) ? b[ru * P.b_sr + j] : (T)0.f;
+                    for (int w = 0; w < NT / 2; ++w) rb[w] = 0u;
+                    if (ok) rb = *reinterpret_cast<const bvec_t*>(b + ru * P.b_sr);
+                    T tb[NT];
+                    memcpy(tb, &rb, NT * 2);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bv[u][j] = j < nj ? tb[j] : (T)0.f;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bv[u][j] = (ok && j < nj) ? b[ru * P.b_sr + j] : (T)0.f;
+                }
             }
 #pragma unroll
             for (int u = 0; u < kSkU; ++u) {
@@ -144,13 +158,19 @@ extern "C" int segm_skinny_tn(const segm_skinny_tn_args* a) {
     hipStream_t st = (hipStream_t)a->stream;
     const dim3 grid(P.nslab, (a->n + nt - 1) / nt), block(kBlock);
     const bool f16 = a->dtype == SEGM_F16;
-#define SEGM_SK(NN, UU)                                                                                     \
+    // one vector load per row of b: every column tile's segment aligned to its size, and nt columns readable in every row (the
+    // row stride covers the last tile); SEGM_SKINNY_BVEC=0: scalar loads (A/B)
+    const char* be = getenv("SEGM_SKINNY_BVEC");
+    const int ntiles = (a->n + nt - 1) / nt;
+    const bool bvec = !(be && be[0] == '0') && ((uintptr_t)a->skinny % (size_t)(nt * 2)) == 0 && a->skinny_stride_row % nt == 0 &&
+                      (int64_t)ntiles * nt <= a->skinny_stride_row;
+#define SEGM_SK(NN, UU, BV)                                                                                 \
     do {                                                                                                 \
-        if (f16) hipLaunchKernelGGL((skinny_tn_kernel<f16_t, NN, UU>), grid, block, 0, st, P);           \
-        else hipLaunchKernelGGL((skinny_tn_kernel<bf16_t, NN, UU>), grid, block, 0, st, P);              \
+        if (f16) hipLaunchKernelGGL((skinny_tn_kernel<f16_t, NN, UU, BV>), grid, block, 0, st, P);       \
+        else hipLaunchKernelGGL((skinny_tn_kernel<bf16_t, NN, UU, BV>), grid, block, 0, st, P);          \
     } while (0)
-    if (nt == 4) SEGM_SK(4, 8);            // (rows beyond the slab are masked, so the passes need not divide the slab)
-    else SEGM_SK(8, 4);
+    if (nt == 4) { if (bvec) SEGM_SK(4, 8, true); else SEGM_SK(4, 8, false); }      // (rows beyond the slab are masked, so the passes need not divide the slab)
+    else { if (bvec) SEGM_SK(8, 4, true); else SEGM_SK(8, 4, false); }
 #undef SEGM_SK
     launch_reduce_partials(P.part, P.nslab, a->n, a->m, a->out, a->n, nullptr, nullptr, st);
     return (int)hipGetLastError();

@@ -1520,6 +1520,21 @@ def test_skinny_tn_emulated(emu, K, M, N, dtype, lda, ldb):
         ops_raw.skinny_tn(emu, wide[:, :M - 2], skinny)
 
 
+@pytest.mark.parametrize("K,M,N,ldb,off", [(5000, 96, 3, 40, 0), (3000, 192, 6, 40, 8), (700, 96, 24, 24, 0), (900, 96, 4, 4, 0)])
+def test_skinny_tn_vector_rows_emulated(emu, monkeypatch, K, M, N, ldb, off):
+    """segm_skinny_tn with the skinny operand's row segment aligned to its column tile (x_dbl in the padded layout: dt columns first):
+    the tile's values come in ONE 8- / 16-byte load per row - the same sums, bit for bit, as the two-byte loads (SEGM_SKINNY_BVEC=0)"""
+    g = torch.Generator().manual_seed(K + N)
+    wide = torch.randn(K, M, generator=g).bfloat16()
+    skinny = torch.randn(K, ldb, generator=g).bfloat16()[:, off:off + N]
+    out = ops_raw.skinny_tn(emu, wide, skinny)
+    monkeypatch.setenv("SEGM_SKINNY_BVEC", "0")
+    out0 = ops_raw.skinny_tn(emu, wide, skinny)
+    assert torch.equal(out, out0)
+    ref = wide.float().t() @ skinny.float()
+    assert (out - ref).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("shape,dtype,pad", [((2, 48, 8, 16, 16), torch.bfloat16, 0), ((2, 6, 40, 40, 24), torch.bfloat16, 192),
                                              ((3, 5, 13), torch.float32, 0), ((1, 4, 70001), torch.float16, 0), ((2, 1, 9, 9, 9), torch.float32, 0)])
 def test_channel_sum_emulated(emu, shape, dtype, pad):
