@@ -14,6 +14,7 @@
 //   * D[voxel][co]: a lane holds four consecutive x of one output channel: 8-byte NCDHW stores, bias in the accumulators.
 // v_mfma_f32_16x16x32: A[i][k]: lane l holds A[i = l & 15][8 (l >> 4) .. +7]; B[k][j]: lane l holds B[8 (l >> 4) .. +7][j = l & 15];
 // D[row = 4 (l >> 4) + r][col = l & 15].  Here i = output voxel (16 consecutive x), k = (kx slot, ci), j = output channel.
+#include <stdlib.h>
 #include <string.h>
 
 #include "segm_device.h"
@@ -41,7 +42,7 @@ struct StemDev {
 
 // A wave owns a block of TX x TY = 8 tiles: TX 16-voxel tiles along x on each of TY consecutive output rows (TX = min(8, tiles
 // per row)), so its tiles differ only by compile-time offsets from one (batch, z, y0, x0).
-template <typename T, int NT, int TX, int KSZ, int STR>     // KSZ^3 taps, stride STR, padding KSZ / 2
+template <typename T, int NT, int TX, int KSZ, int STR, bool WIDE = false>     // KSZ^3 taps, stride STR, padding KSZ / 2
 __global__ void __launch_bounds__(kStemWaves * 64, 2) stem_conv_fwd_kernel(StemDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     constexpr int TY = kStemTiles / TX;
@@ -69,41 +70,105 @@ __global__ void __launch_bounds__(kStemWaves * 64, 2) stem_conv_fwd_kernel(StemD
     const T* W = reinterpret_cast<const T*>(P.wp);
     const int64_t row_el = (int64_t)P.win * 4, plane_el = (int64_t)P.hin * row_el, vol_el = (int64_t)P.din * plane_el;
 
-#pragma unroll 1
-    for (int kz = 0; kz < KSZ; ++kz) {
-#pragma unroll 1
-        for (int ky = 0; ky < KSZ; ++ky) {
-            frag8 wf[NT];
+    // One (kz, ky) step = the three weight fragments + the eight tiles' input fragments.  Round 5, two changes:
+    //  * the input fragments are RAW BUFFER loads: a tile row's descriptor (uniform: base of input row (iz, iy), num_records = the
+    //    row's bytes, or 0 for a padding row) + a lane offset that is fixed for the whole kernel (the lane's two input columns of the
+    //    tile; a column outside the row or a kx slot >= KSZ carries an offset beyond num_records).  The range check returns the
+    //    zeros: no per-step address arithmetic, masks or selects in vector registers - rounds 2 - 4 spent ~25 vector instructions per
+    //    tile and step on them, 1 800 per wave against 216 MFMAs (the 3^3 first layer ran 0.40 ms for 0.44 GB at 128^3);
+    //  * the NEXT step's loads are issued before this step's MFMAs (two register sets, alternating).
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    constexpr uint32_t kOob = 0xFFFFF000u;
+    uint32_t vo0[kStemTiles], vo1[kStemTiles];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int co = 16 * nt + i16;
-                const st_u32x4 zero = {0u, 0u, 0u, 0u};
-                const st_u32x4 v = *reinterpret_cast<const st_u32x4*>(W + (((int64_t)(co < P.cout ? co : 0) * KSZ + kz) * KSZ + ky) * 32 + 8 * g);
-                wf[nt] = __builtin_bit_cast(frag8, co < P.cout ? v : zero);
-            }
-            const int iz = STR * z0 + kz - PAD;                                          // wave-uniform
-            const bool z_ok = iz >= 0 && iz < P.din;
-            const T* planep = X + (int64_t)b0 * vol_el + (int64_t)(z_ok ? iz : 0) * plane_el;
+    for (int t = 0; t < kStemTiles; ++t) {
+        const int ix = STR * (x0 + 16 * (t % TX) + i16) + 2 * g - PAD;               // first of the lane's two input columns
+        vo0[t] = (ix >= 0 && ix < P.win && 2 * g < KSZ) ? (uint32_t)ix * 8u : kOob;
+        vo1[t] = (ix + 1 >= 0 && ix + 1 < P.win && 2 * g + 1 < KSZ) ? (uint32_t)(ix + 1) * 8u : kOob;
+    }
+    const T* wlane[NT];                                                               // this lane's weight fragment of step 0
 #pragma unroll
-            for (int t = 0; t < kStemTiles; ++t) {
-                const int iy = STR * (y0 + t / TX) + ky - PAD;
-                const bool row_ok = z_ok && iy >= 0 && iy < P.hin;
-                const int ix = STR * (x0 + 16 * (t % TX) + i16) + 2 * g - PAD;           // first of the lane's two input columns
-                const T* rowp = planep + (int64_t)(row_ok ? iy : 0) * row_el;
-                const bool ok0 = row_ok && ix >= 0 && ix < P.win && 2 * g < KSZ, ok1 = row_ok && ix + 1 >= 0 && ix + 1 < P.win && 2 * g + 1 < KSZ;   // slots >= KSZ: no tap
-                const st_u32x2 z2 = {0u, 0u};
-                const st_u32x2 v0 = *reinterpret_cast<const st_u32x2*>(rowp + (int64_t)(ok0 ? ix : 0) * 4);
-                const st_u32x2 v1 = *reinterpret_cast<const st_u32x2*>(rowp + (int64_t)(ok1 ? ix + 1 : 0) * 4);
-                const st_u32x2 a0 = ok0 ? v0 : z2, a1 = ok1 ? v1 : z2;
-                const st_u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
-                const frag8 af = __builtin_bit_cast(frag8, av);
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = 16 * nt + i16;
+        wlane[nt] = W + (int64_t)(co < P.cout ? co : 0) * KSZ * KSZ * 32 + 8 * g;
+    }
+    st_u32x4 wfa[NT], wfb[NT];
+    st_u32x4 ava[kStemTiles], avb[kStemTiles];
+    auto load_step = [&](int it, st_u32x4 (&wr)[NT], st_u32x4 (&av)[kStemTiles]) {
+        const int kz = it / KSZ, ky = it - kz * KSZ;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[t][nt] = Mfma16<T>::run(af, wf[nt], acc[t][nt]);
+        for (int nt = 0; nt < NT; ++nt) wr[nt] = *reinterpret_cast<const st_u32x4*>(wlane[nt] + it * 32);
+        const int iz = STR * z0 + kz - PAD;                                          // wave-uniform
+        const bool z_ok = iz >= 0 && iz < P.din;
+        const T* planep = X + (int64_t)b0 * vol_el + (int64_t)(z_ok ? iz : 0) * plane_el;
+#pragma unroll
+        for (int ty = 0; ty < TY; ++ty) {
+            const int iy = STR * (y0 + ty) + ky - PAD;
+            const bool row_ok = z_ok && iy >= 0 && iy < P.hin;
+            const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(planep + (int64_t)(row_ok ? iy : 0) * row_el), 0,
+                                                                row_ok ? P.win * 8 : 0, 0x00020000);
+#pragma unroll
+            for (int tx = 0; tx < TX; ++tx) {
+                const int t = ty * TX + tx;
+                const st_u32x2 v0 = __builtin_amdgcn_raw_buffer_load_b64(rs, vo0[t], 0, 0);
+                const st_u32x2 v1 = __builtin_amdgcn_raw_buffer_load_b64(rs, vo1[t], 0, 0);
+                av[t] = st_u32x4{v0[0], v0[1], v1[0], v1[1]};
             }
         }
+    };
+    auto mma_step = [&](const st_u32x4 (&wr)[NT], const st_u32x4 (&av)[kStemTiles]) {
+        frag8 wf[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const st_u32x4 zero = {0u, 0u, 0u, 0u};
+            wf[nt] = __builtin_bit_cast(frag8, 16 * nt + i16 < P.cout ? wr[nt] : zero);
+        }
+#pragma unroll
+        for (int t = 0; t < kStemTiles; ++t) {
+            const frag8 af = __builtin_bit_cast(frag8, av[t]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = Mfma16<T>::run(af, wf[nt], acc[t][nt]);
+        }
+    };
+    constexpr int STEPS = KSZ * KSZ;
+    load_step(0, wfa, ava);
+#pragma unroll 1
+    for (int it = 0; it < STEPS; it += 2) {
+        if (it + 1 < STEPS) load_step(it + 1, wfb, avb);
+        SEGM_SCHED_FENCE();
+        mma_step(wfa, ava);
+        SEGM_SCHED_FENCE();
+        if (it + 2 < STEPS) load_step(it + 2, wfa, ava);
+        SEGM_SCHED_FENCE();
+        if (it + 1 < STEPS) mma_step(wfb, avb);
+        SEGM_SCHED_FENCE();
     }
     T* Y = reinterpret_cast<T*>(P.y);
     const int64_t oplane = (int64_t)P.hout * P.wout, ovol = P.y_sc;
+    if constexpr (WIDE) {
+        // x-adjacent tiles (t, t + 1) of a row: v_permlane16_swap_b32 on the packed values leaves lane group g with EIGHT consecutive x
+        // - 8 (g >> 1) .. + 7 of tile t + (g & 1) - one 16-byte store instead of two 8-byte ones (conv3d_fwd.hip has the derivation)
+        static_assert(!WIDE || TX >= 2, "pairs are tiles along x");
+#pragma unroll
+        for (int t = 0; t < kStemTiles; t += 2) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = 16 * nt + i16;
+                st_u32x2 p0, p1;
+                p0[0] = pack2<T>(acc[t][nt][0], acc[t][nt][1]);         p0[1] = pack2<T>(acc[t][nt][2], acc[t][nt][3]);
+                p1[0] = pack2<T>(acc[t + 1][nt][0], acc[t + 1][nt][1]); p1[1] = pack2<T>(acc[t + 1][nt][2], acc[t + 1][nt][3]);
+                const st_u32x2 s0 = __builtin_amdgcn_permlane16_swap(p0[0], p1[0], false, false);
+                const st_u32x2 s1 = __builtin_amdgcn_permlane16_swap(p0[1], p1[1], false, false);
+                const st_u32x4 pk = {s0[0], s1[0], s0[1], s1[1]};
+                if (co < P.cout) {
+                    T* yp = Y + ((int64_t)b0 * P.cout + co) * ovol + (int64_t)z0 * oplane + (int64_t)(y0 + t / TX) * P.wout + x0 + 16 * (t % TX) +
+                            16 * (g & 1) + 8 * (g >> 1);
+                    *reinterpret_cast<st_u32x4*>(yp) = pk;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < kStemTiles; ++t) {
 #pragma unroll
@@ -126,6 +191,17 @@ static int launch_stem_tx(const StemDev& P, hipStream_t st) {
     if (gx >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;
     const dim3 grid((unsigned)gx), block(kStemWaves * 64);
     const int nt = (P.cout + 15) / 16;
+    // 16-byte stores: tiles pair along x and every row segment is 16-byte aligned (SEGM_STEM_WIDE=0: the 8-byte form, A/B)
+    const char* we = getenv("SEGM_STEM_WIDE");
+    const bool wide = TX >= 2 && !(we && we[0] == '0') && P.wout % 8 == 0 && P.y_sc % 8 == 0 && ((uintptr_t)P.y & 15) == 0;
+    if constexpr (TX >= 2) {
+        if (wide) {
+            if (nt == 1) hipLaunchKernelGGL((stem_conv_fwd_kernel<T, 1, TX, KSZ, STR, true>), grid, block, 0, st, P);
+            else if (nt == 2) hipLaunchKernelGGL((stem_conv_fwd_kernel<T, 2, TX, KSZ, STR, true>), grid, block, 0, st, P);
+            else hipLaunchKernelGGL((stem_conv_fwd_kernel<T, 3, TX, KSZ, STR, true>), grid, block, 0, st, P);
+            return (int)hipGetLastError();
+        }
+    }
     if (nt == 1) hipLaunchKernelGGL((stem_conv_fwd_kernel<T, 1, TX, KSZ, STR>), grid, block, 0, st, P);
     else if (nt == 2) hipLaunchKernelGGL((stem_conv_fwd_kernel<T, 2, TX, KSZ, STR>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((stem_conv_fwd_kernel<T, 3, TX, KSZ, STR>), grid, block, 0, st, P);

@@ -1181,7 +1181,7 @@ def test_pointwise_autograd_route_on_emulated_kernels(emu, monkeypatch):
 @pytest.mark.parametrize("B,Cin,Cout,D,H,W,dtype,bias", [(1, 4, 48, 4, 16, 32, torch.bfloat16, True), (2, 1, 16, 2, 8, 64, torch.bfloat16, False),
                                                        (1, 3, 32, 6, 16, 32, torch.float16, True), (1, 4, 48, 2, 4, 128, torch.bfloat16, False),
                                                        (1, 2, 16, 2, 2, 256, torch.bfloat16, True)])
-def test_stem_conv_fwd_emulated(emu, B, Cin, Cout, D, H, W, dtype, bias):
+def test_stem_conv_fwd_emulated(emu, monkeypatch, B, Cin, Cout, D, H, W, dtype, bias):
     """segm_stem_conv_fwd (7^3, stride 2, padding 3: implicit GEMM with K = (kz, ky, kx slot, ci), channel-last-4 input, packed
     weights) against torch's conv3d in fp32 on the same 16-bit operands: every tile-block shape (TX x TY), fewer than 4 input
     channels, fewer than 48 output channels, volumes smaller than the kernel (all padding cases)"""
@@ -1195,6 +1195,9 @@ def test_stem_conv_fwd_emulated(emu, B, Cin, Cout, D, H, W, dtype, bias):
     assert y.shape == ref.shape and y.dtype == dtype
     tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
     assert (y.float() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    # tiles that pair along x (output width >= 32) leave in 16-byte stores; the 8-byte form gives the same values
+    monkeypatch.setenv("SEGM_STEM_WIDE", "0")
+    assert torch.equal(ops_raw.stem_conv_fwd(emu, x, w, b), y)
 
 
 def test_thin_input_conv3_emulated(emu):
