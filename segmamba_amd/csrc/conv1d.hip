@@ -195,9 +195,8 @@ __global__ void __launch_bounds__(kBlock) conv1d_bwd_kernel(ConvDevN PP) {
 // out0[d*K0 + k] = sum_rows part[row][k][d] (k < K0) ; out1[d] = ... k == K0 ; out2[d] = ... k == K0+1
 // grid (ceil(dim/64), K), block 16 waves: wave w sums rows w, w+16, ... then a 16-entry LDS fold.
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kCarrySegs * 64) reduce_partials_kernel(const float* __restrict__ part, int64_t nrows,
-                                                                          int K, int dim, float* out0, int K0,
-                                                                          float* out1, float* out2) {
+__device__ __forceinline__ void reduce_partials_body(const float* __restrict__ part, int64_t nrows, int K, int dim, float* out0, int K0,
+                                                     float* out1, float* out2) {
     __shared__ float s_acc[kCarrySegs][64];
     const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const int d = blockIdx.x * 64 + lane, k = blockIdx.y;
@@ -226,11 +225,25 @@ __global__ void __launch_bounds__(kCarrySegs * 64) reduce_partials_kernel(const 
         else if (out2) out2[d] = t;
     }
 }
+__global__ void __launch_bounds__(kCarrySegs * 64) reduce_partials_kernel(const float* __restrict__ part, int64_t nrows,
+                                                                          int K, int dim, float* out0, int K0,
+                                                                          float* out1, float* out2) {
+    reduce_partials_body(part, nrows, K, dim, out0, K0, out1, out2);
+}
+// the same sums for up to four problems of one geometry in ONE launch (blockIdx.z: the directions of a Mamba layer - their partials
+// come out of one scan / conv1d launch too; round 5: 48 launches of ~5 us less per step)
+__global__ void __launch_bounds__(kCarrySegs * 64) reduce_partials_multi_kernel(ReduceN R, int64_t nrows, int K, int dim, int K0) {
+    const int z = blockIdx.z;
+    reduce_partials_body(R.part[z], nrows, K, dim, R.out0[z], K0, R.out1[z], R.out2[z]);
+}
 
 void launch_reduce_partials(const float* part, int64_t nrows, int K, int dim, float* out0, int K0, float* out1,
                             float* out2, hipStream_t stream) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 63) / 64, K), dim3(kCarrySegs * 64), 0, stream, part, nrows, K,
                        dim, out0, K0, out1, out2);
+}
+void launch_reduce_partials_multi(const ReduceN& R, int n, int64_t nrows, int K, int dim, int K0, hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3((dim + 63) / 64, K, n), dim3(kCarrySegs * 64), 0, stream, R, nrows, K, dim, K0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -327,12 +340,15 @@ static int conv_multi(const segm_conv1d_args* args, int32_t n, bool bwd) {
         hipStream_t stream = (hipStream_t)args[i].stream;
         const int rc = launch_conv_t(PP, m, args[i].dtype, args[i].width, bwd, stream);
         if (rc != 0) return rc;
-        if (bwd)
+        if (bwd) {                                         // (conv_same_launch: one geometry - one reduce launch for the m problems)
+            ReduceN R;
+            memset(&R, 0, sizeof(R));
             for (int k = 0; k < m; ++k) {
-                const segm_conv1d_args* a = &args[i + k];
-                launch_reduce_partials(PP.d[k].part, (int64_t)a->batch * PP.d[k].gm.nchunks, a->width + 1, a->dim, a->dweight, a->width,
-                                       a->dbias, nullptr, stream);
+                R.part[k] = PP.d[k].part; R.out0[k] = args[i + k].dweight; R.out1[k] = args[i + k].dbias;
             }
+            const segm_conv1d_args* a = &args[i];
+            launch_reduce_partials_multi(R, m, (int64_t)a->batch * PP.d[0].gm.nchunks, a->width + 1, a->dim, a->width, stream);
+        }
         i += m;
     }
     return (int)hipGetLastError();

@@ -28,6 +28,7 @@ namespace segm {
 
 void launch_reduce_partials(const float* part, int64_t nrows, int K, int dim, float* out0, int K0, float* out1,
                             float* out2, hipStream_t stream);
+void launch_reduce_partials_multi(const ReduceN& R, int n, int64_t nrows, int K, int dim, int K0, hipStream_t stream);
 
 constexpr int kWin = 16;   // window length of the backward main kernel = spacing of the forward checkpoints
 
@@ -565,9 +566,12 @@ extern "C" int segm_selective_scan_bwd_multi(const segm_scan_bwd_args* args, int
             launch_scan_carry(PP, n, true, stream);
             launch_scan_bwd_fast(PP, n, a->dtype, true, stream);
             const int64_t nch = (a->seqlen + a->chunk - 1) / a->chunk;
-            for (int i = 0; i < n; ++i)
-                launch_reduce_partials(PP.d[i].part, (int64_t)a->batch * nch, a->dstate + 2, a->dim, args[i].dA, a->dstate,
-                                       args[i].dD, args[i].ddelta_bias, stream);
+            ReduceN R;                                     // one launch for the n directions (scan_same_launch: one geometry)
+            memset(&R, 0, sizeof(R));
+            for (int i = 0; i < n; ++i) {
+                R.part[i] = PP.d[i].part; R.out0[i] = args[i].dA; R.out1[i] = args[i].dD; R.out2[i] = args[i].ddelta_bias;
+            }
+            launch_reduce_partials_multi(R, n, (int64_t)a->batch * nch, a->dstate + 2, a->dim, a->dstate, stream);
             return (int)hipGetLastError();
         }
         if (rc != SEGM_E_SHAPE) return rc;                  // (a clear enqueued for an earlier block is repeated below: harmless)

@@ -519,6 +519,26 @@ __global__ void __launch_bounds__(256) scan_bwd_dbc_sum_kernel(ScanDevN PP) {
     const int64_t sb = m ? P.dC_sb : P.dB_sb, st = m ? P.dC_st : P.dB_st, sn = m ? P.dC_sn : P.dB_sn;
     char* base = reinterpret_cast<char*>(m ? P.dC : P.dB);
     const int64_t off = (int64_t)b * sb + t * st + (int64_t)n0 * sn;
+    if (sn == 1) {                                         // the states are adjacent (dx_dbl's B | C columns): one store, not four
+        if (P.dbc_native) {
+            if constexpr (sizeof(T) == 2) {
+                T* d = reinterpret_cast<T*>(base) + off;
+                if ((reinterpret_cast<uintptr_t>(d) & 7u) == 0) {
+                    u32x2_t pk;
+                    pk[0] = pack2<T>(r[0], r[1]);
+                    pk[1] = pack2<T>(r[2], r[3]);
+                    *reinterpret_cast<u32x2_t*>(d) = pk;
+                    return;
+                }
+            }
+        } else {
+            float* d = reinterpret_cast<float*>(base) + off;
+            if ((reinterpret_cast<uintptr_t>(d) & 15u) == 0) {
+                *reinterpret_cast<float4*>(d) = s;
+                return;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (P.dbc_native) reinterpret_cast<T*>(base)[off + i * sn] = from_f32<T>(r[i]);

@@ -63,6 +63,14 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, t2));
 }
 
+// up to four fixed-order partial reductions of one geometry in one launch (conv1d.hip reduce_partials_multi_kernel)
+struct ReduceN {
+    const float* part[4];
+    float* out0[4];
+    float* out1[4];
+    float* out2[4];
+};
+
 // ---- XCD-aware work item order (conv3d_fwd.hip, conv3d_wgrad.hip) -----------------------------------------------------
 // Workgroups are handed to the 8 XCDs round robin (workgroup i -> XCD i % 8), each XCD with its own L2.  Work items that are
 // neighbours in z read the same input rows (the convolution kernels stage every row for the three planes around it), so
