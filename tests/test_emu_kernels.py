@@ -459,6 +459,32 @@ def test_scan_three_directions_in_one_launch_emulated(emu, dim, seqlen, chunk, d
                 assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-5), k
 
 
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_conv1d_three_directions_in_one_launch_emulated(emu, with_bias):
+    """segm_causal_conv1d_fwd_multi / _bwd_multi: the three directions of a Mamba v3 layer (own weights, one shared input) as one grid,
+    their dW / db partials summed by ONE reduce launch with a direction axis (conv1d.hip reduce_partials_multi_kernel): outputs, dx, dW
+    and db equal three separate calls bit for bit"""
+    g = torch.Generator().manual_seed(41)
+    B, Ln, D, W = 2, 256, 96, 4
+    x = torch.randn(B, Ln, D, generator=g).bfloat16()
+    orders = [(L.TIME_FORWARD, 1), (L.TIME_REVERSED, 1), (L.TIME_INTERLEAVED, 8)]
+    ws = [torch.randn(D, W, generator=g) for _ in orders]
+    bs = [torch.randn(D, generator=g) if with_bias else None for _ in orders]
+    douts = [torch.randn(B, Ln, D, generator=g).bfloat16() for _ in orders]
+    fcalls = [dict(x=x, weight=w, bias=b, silu=True, channel_last=True, time_order=o, nslices=ns) for w, b, (o, ns) in zip(ws, bs, orders)]
+    single = [ops_raw.conv1d_fwd(emu, **c) for c in fcalls]
+    multi = ops_raw.conv1d_fwd_multi(emu, fcalls)
+    for a, b in zip(single, multi):
+        assert torch.equal(a, b)
+    bcalls = [dict(c, dout=d) for c, d in zip(fcalls, douts)]
+    single_b = [ops_raw.conv1d_bwd(emu, c["x"], c["weight"], c["bias"], c["dout"], True, channel_last=True, time_order=c["time_order"],
+                                   nslices=c["nslices"]) for c in bcalls]
+    multi_b = ops_raw.conv1d_bwd_multi(emu, bcalls)
+    for (dx0, dw0, db0), (dx1, dw1, db1) in zip(single_b, multi_b):
+        assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
+        assert (db0 is None and db1 is None) or torch.equal(db0, db1)
+
+
 def test_scan_multi_call_with_different_flags_per_block_emulated(emu):
     """One segm_selective_scan_{fwd,bwd}_multi call whose blocks share the geometry but NOT the per-block flags - one without a
     gate, one without softplus, one with both, different time orders: the launch falls back to the kernels that read the flags
