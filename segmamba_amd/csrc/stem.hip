@@ -7,11 +7,13 @@
 //   * the input is channel-last with 4 channels, x4[b][z][y][x][4] (one transposing copy of the small input, made by the
 //     host); K = (kz, ky, kx slot 0..7, ci 0..3): one K = 32 chunk per (kz, ky) pair = 49 MFMA steps (slot 7 has zero weights);
 //   * A fragment of output voxel (z, y, x) for kx slots 2 g, 2 g + 1 = the 4 channels of input positions 2 x + 2 g - 3 and
-//     2 x + 2 g - 2 on row (2 z + kz - 3, 2 y + ky - 3): two 8-byte loads with their own bounds masks (padding = zero);
+//     2 x + 2 g - 2 on row (2 z + kz - 3, 2 y + ky - 3): two 8-byte raw buffer loads whose range check supplies the zero padding
+//     (round 5: uniform row descriptor + fixed lane offsets, see the kernel);
 //   * weights packed as wp[co][kz][ky][slot][ci]: a B fragment is 16 contiguous bytes; a wave keeps the three 16-channel
 //     fragments of a (kz, ky) step for EIGHT 16-voxel tiles (96 accumulator registers), so weight traffic is 1/8 of the
 //     activation traffic and both come from L1 / L2;
-//   * D[voxel][co]: a lane holds four consecutive x of one output channel: 8-byte NCDHW stores, bias in the accumulators.
+//   * D[voxel][co]: a lane holds four consecutive x of one output channel; x-adjacent tiles exchange halves (v_permlane16_swap_b32)
+//     and store 16 bytes per lane; bias in the accumulators.
 // v_mfma_f32_16x16x32: A[i][k]: lane l holds A[i = l & 15][8 (l >> 4) .. +7]; B[k][j]: lane l holds B[8 (l >> 4) .. +7][j = l & 15];
 // D[row = 4 (l >> 4) + r][col = l & 15].  Here i = output voxel (16 consecutive x), k = (kx slot, ci), j = output channel.
 #include <stdlib.h>
