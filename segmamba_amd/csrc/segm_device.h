@@ -63,6 +63,22 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, t2));
 }
 
+// gfx950 LDS transpose read (ds_read_b64_tr_b16), measured semantics (tools/experiments/tr16_probe.hip, profiles/r05_tr16_probe.txt):
+// every lane supplies an 8-byte aligned LDS address; with E[p] the four 16-bit values at lane p's address, lane i of a 16-lane group
+// receives E[4 j + (i >> 2)][i & 3] for j = 0 .. 3.  tr16_fragment: two such reads = the eight k values of one MFMA operand fragment.
+typedef short tr16_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ tr16_v4 lds_read_tr16(const void* p) {
+    typedef __attribute__((address_space(3))) tr16_v4 lds_v4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p));
+}
+template <typename F>
+__device__ __forceinline__ F tr16_fragment(const void* lo, const void* hi) {
+    typedef short tr16_v8 __attribute__((ext_vector_type(8)));
+    const tr16_v4 a = lds_read_tr16(lo), b = lds_read_tr16(hi);
+    const tr16_v8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(F, v);
+}
+
 // up to four fixed-order partial reductions of one geometry in one launch (conv1d.hip reduce_partials_multi_kernel)
 struct ReduceN {
     const float* part[4];

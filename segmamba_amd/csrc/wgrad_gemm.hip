@@ -10,8 +10,15 @@
 //   layout TN  a (K, M), b (K, N) row-major (token-major activations: the Mamba projections).  MFMA wants 8 consecutive k per
 //              lane but k is the row index, so a wave stages 32-row tiles [32][<= 64] of a and [32][<= 96] of b in a private
 //              LDS strip (16-byte loads when the rows are 16-byte aligned, 2-byte loads otherwise - x_dbl has 35 columns) and
-//              gathers the fragments with ds_read_u16 at pitches (68 / 100 elements) that put the four 8-row groups of a
-//              fragment 16 banks apart;
+//              reads the fragments back TRANSPOSED with gfx950's ds_read_b64_tr_b16 (round 5; rounds 2 - 4 gathered them with
+//              eight ds_read_u16 + packing each - 80 LDS reads per 32-row chunk - and lost to split-K rocBLAS).  What the
+//              instruction does was measured (tools/experiments/tr16_probe.hip): with E[p] the four 16-bit values at lane p's
+//              address, lane i of a 16-lane group receives E[4 j + (i >> 2)][i & 3], j = 0 .. 3.  Lane p = 4 r + c pointing at row
+//              k0 + r, columns m0 + 4 c .. of the row-major strip, lane i gets column m0 + i of rows k0 .. k0 + 3: two reads are
+//              one MFMA operand fragment.  Which four rows a lane group takes is free as long as both operands agree (the
+//              contraction is a sum): group g reads rows 4 g .. and 16 + 4 g .., so the 32 lanes the LDS serves together
+//              (groups 0 / 1, then 2 / 3) touch eight consecutive rows, and at pitches of 40 / 56 dwords (80 / 112 elements) those
+//              are eight 8-dword windows on 64 distinct banks;
 //   layout NT  a (B, M, K), b (B, N, K) with unit stride along K (channel-first volumes: the 1x1x1 convolutions): both operand
 //              fragments are 16 contiguous bytes in memory - no staging at all.
 //
@@ -32,7 +39,7 @@ typedef uint32_t wg_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kGwWaves = 4;
 constexpr int kTnMB = 64, kTnNB = 96;        // columns of a / b per workgroup
 constexpr int kTnMT = kTnMB / 16, kTnNT = kTnNB / 16;
-constexpr int kTnPA = kTnMB + 4, kTnPB = kTnNB + 4;      // LDS pitches (elements): 8 rows apart = 16 banks apart
+constexpr int kTnPA = kTnMB + 16, kTnPB = kTnNB + 16;    // LDS pitches (elements): 40 / 56 dwords - eight consecutive rows = 64 distinct banks for the transposing reads
 constexpr int kNtMax = 6;                    // 16-row tiles per operand of the NT kernel (m, n <= 96)
 
 struct GemmDev {
@@ -82,9 +89,8 @@ __device__ __forceinline__ void tn_park(T* lds, int lane, const wg_u32x4 (&r)[CB
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int id = q * 64 + lane, row = id / PIECES, pc = id - row * PIECES;
-        wg_u32x2* dst = reinterpret_cast<wg_u32x2*>(lds + row * PITCH + 8 * pc);       // PITCH * 2 B is a multiple of 8
-        dst[0] = wg_u32x2{r[q][0], r[q][1]};
-        dst[1] = wg_u32x2{r[q][2], r[q][3]};
+        static_assert(PITCH % 8 == 0, "16-byte aligned strip rows");
+        *reinterpret_cast<wg_u32x4*>(lds + row * PITCH + 8 * pc) = r[q];
     }
 }
 
@@ -128,24 +134,20 @@ __global__ void __launch_bounds__(kGwWaves * 64) wgemm_tn_kernel(GemmDev P) {
             tn_fetch<T, kTnPA, kTnMB, ALIGNED_A>(A, P.a_sr, (c + 1) * 32, P.k, m0, P.m, lane, ra);
             tn_fetch<T, kTnPB, kTnNB, ALIGNED_B>(B, P.b_sr, (c + 1) * 32, P.k, n0, P.n, lane, rb);
         }
+        // fragment k slots 0 .. 3 = strip rows 4 g .., slots 4 .. 7 = rows 16 + 4 g .. (the same assignment in both operands)
         frag8 bf[kTnNT];
 #pragma unroll
         for (int nt = 0; nt < kTnNT; ++nt) {
             if (nt < nt_n) {
-                T e[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) e[j] = lb[(8 * g + j) * kTnPB + 16 * nt + i16];
-                memcpy(&bf[nt], e, 16);
+                const T* p0 = lb + (4 * g + (i16 >> 2)) * kTnPB + 16 * nt + 4 * (i16 & 3);
+                bf[nt] = tr16_fragment<frag8>(p0, p0 + 16 * kTnPB);
             }
         }
 #pragma unroll
         for (int mt = 0; mt < kTnMT; ++mt) {
             if (mt < mt_n) {
-                T e[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) e[j] = la[(8 * g + j) * kTnPA + 16 * mt + i16];
-                frag8 af;
-                memcpy(&af, e, 16);
+                const T* p0 = la + (4 * g + (i16 >> 2)) * kTnPA + 16 * mt + 4 * (i16 & 3);
+                const frag8 af = tr16_fragment<frag8>(p0, p0 + 16 * kTnPA);
 #pragma unroll
                 for (int nt = 0; nt < kTnNT; ++nt)
                     if (nt < nt_n) acc[mt][nt] = Mfma16<T>::run(af, bf[nt], acc[mt][nt]);

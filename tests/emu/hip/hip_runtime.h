@@ -183,6 +183,26 @@ static inline hipemu_u32x2 hipemu_permlane16_swap(uint32_t vdst, uint32_t vsrc, 
     return r;
 }
 #define __builtin_amdgcn_permlane16_swap hipemu_permlane16_swap
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read) as measured on the hardware (tools/experiments/tr16_probe.hip): every lane reads the
+// four 16-bit values E at its own address; lane i of a 16-lane group then receives E[4 j + (i >> 2)][i & 3] for j = 0 .. 3
+typedef short hipemu_v4s __attribute__((ext_vector_type(4)));
+static inline hipemu_v4s hipemu_ds_read_tr16(const void* p) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, static_cast<const char*>(p) + 4, 4);
+    const int lane = hipemu::t_linear % 64, grp = lane >> 4, i = lane & 15;
+    hipemu_v4s r;
+    for (int j = 0; j < 4; ++j) {
+        const int src = grp * 16 + 4 * j + (i >> 2);
+        const uint32_t slo = hipemu::exchange(lo, src), shi = hipemu::exchange(hi, src);
+        short e[4];
+        memcpy(e, &slo, 4);
+        memcpy(e + 2, &shi, 4);
+        r[j] = e[i & 3];
+    }
+    return r;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) hipemu_ds_read_tr16((const void*)(p))
 // v_permlane32_swap_b32 vdst, vsrc: the upper 32 lanes of vdst trade places with the lower 32 lanes of vsrc
 static inline hipemu_u32x2 hipemu_permlane32_swap(uint32_t vdst, uint32_t vsrc, bool, bool) {
     const int lane = hipemu::t_linear % 64;
