@@ -330,8 +330,21 @@ def inference_rate(state, device, size):
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             return model(x)
     ms = time_gpu(run, 10, warmup=3)
+    # memory of the forward alone: the training state (gradients, momenta, the captured graph's pool) stays resident in this process,
+    # so the figure is the peak ABOVE what is held before the call, plus the parameters an inference process would hold
+    torch.cuda.synchronize()
+    held = torch.cuda.memory_allocated(device)
+    torch.cuda.reset_peak_memory_stats(device)
+    run()
+    torch.cuda.synchronize()
+    act = (torch.cuda.max_memory_allocated(device) - held) / 2 ** 20
+    par = sum(p.numel() * p.element_size() for p in model.parameters()) / 2 ** 20
     model.train(was_training)
     return {"cases_per_s": round(1e3 / ms, 2), "ms_per_case": round(ms, 3), "input": [1, 4, size, size, size],
+            "peak_mem_mb": {"activations_peak_mb": round(act, 1), "parameters_fp32_mb": round(par, 1),
+                            "parameters_16bit_twin_mb": round(par / 2, 1), "standalone_total_mb": round(act + 1.5 * par, 1),
+                            "what": "peak of one forward above what the process held before it + fp32 parameters + their 16-bit copies",
+                            "reference_published_mb": 6279},
             "published_reference": {"cases_per_s": 1.51, "hardware": "not stated (reference README table 5)"}}
 
 
@@ -648,6 +661,8 @@ def main():
             state_during.update(gpu_state(local_rank))
         sampler = threading.Thread(target=_sample, daemon=True)
         sampler.start()
+    if not dry:
+        torch.cuda.reset_peak_memory_stats(device)         # peak of the TIMED steps (the capture warm-up and --warmup are behind us)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -655,6 +670,15 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    # the only figures the reference publishes beside its 1.51 case/s: training / inference memory, 17 976 / 6 279 MB (README.md:15-16)
+    peak_mem = None if dry else {
+        "peak_allocated_mb": round(torch.cuda.max_memory_allocated(device) / 2 ** 20, 1),
+        "peak_reserved_mb": round(torch.cuda.max_memory_reserved(device) / 2 ** 20, 1),
+        "allocated_between_steps_mb": round(torch.cuda.memory_allocated(device) / 2 ** 20, 1),
+        "what": "torch caching allocator on rank 0 over the timed steps (graph pool included): parameters fp32 + 16-bit twin, flat "
+                "gradients, momenta, kept activations of a 2 x 4 x 128^3 batch, scan checkpoints / workspaces",
+        "recompute": os.environ.get("SEGM_RECOMPUTE", "0"),
+        "reference_published_mb": {"training": 17976, "inference": 6279, "source": "reference README.md:15-16 (Table 5), batch and GPU not stated"}}
     if sampler is not None:
         sampler.join(timeout=30)
     state_after = gpu_state(local_rank) if (rank == 0 and not dry) else {}
@@ -733,7 +757,7 @@ def main():
                                     f"{amp_name} autocast, CE loss, clip 12, SGD nesterov") if not dry else
                                    "tiny SegMamba, 1x4x32^3 per process, plumbing only",
                        "volumes_per_gpu": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}", "ddp": ddp,
-                       "loss": round(float(loss), 5),
+                       "loss": round(float(loss), 5), "peak_mem_mb": peak_mem,
                        # host-side arrangements that do not change the arithmetic: the step's 16-bit parameter copies in one launch
                        # (param_bank.py), 128^3 volumes with a padded channel stride (ops_raw.volume_empty)
                        "param_bank": state.bank is not None, "volume_pad": os.environ.get("SEGM_VOLUME_PAD", "1") == "1",

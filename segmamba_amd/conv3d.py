@@ -258,7 +258,7 @@ def _mfma_wgrad_ok(x, dy, w) -> bool:
             x.dtype not in (torch.bfloat16, torch.float16):
         return False
     return (x.shape[1] % 48 == 0 or x.shape[1] < 48) and dy.shape[1] % 48 == 0 and x.shape[4] % 8 == 0 and \
-        x.shape[0] == dy.shape[0]
+        x.shape[0] == dy.shape[0] and ops_raw.conv3d_k3_wgrad_spans_fit(x, dy)
 
 
 _HIP_VARIANTS = ((False, False, False), (True, False, False), (True, True, False), (False, False, True))   # (chain, pitch48, chain32)

@@ -24,6 +24,10 @@
 
 #include "scan_fast.h"
 
+#ifndef SEGM_BWD_CKPT_AUX
+#define SEGM_BWD_CKPT_AUX 0            // cache policy of the checkpoint loads (2 = nt: read once)
+#endif
+
 namespace segm {
 
 constexpr int kW8 = 8;                 // steps per window = spacing of the forward checkpoints
@@ -330,7 +334,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_W8_MIN_WAVES) scan_bwd_main_w8_ke
     {                                                      // the first window's inputs (the only exposed fetch of the chunk)
         const int32_t U = wr.bias + fast_U_of(P.tm, nwin - 1);
 #pragma unroll
-        for (int p = 0; p < kFS / 2; ++p) rh[p] = __builtin_amdgcn_raw_buffer_load_b64(ckr, ck_voff, (uint32_t)((nwin - 1) * ck_row + p * ck_pair), 0);
+        for (int p = 0; p < kFS / 2; ++p) rh[p] = __builtin_amdgcn_raw_buffer_load_b64(ckr, ck_voff, (uint32_t)((nwin - 1) * ck_row + p * ck_pair), SEGM_BWD_CKPT_AUX);
         stage_fetch_raw<T, RW>(nbv, sb, U, wr.dT);
         stage_fetch_raw<T, RW>(ncv, sc, U, wr.dT);
         stream_fetch_raw<T>(rz, zp, U, wr.dT);
@@ -380,7 +384,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_W8_MIN_WAVES) scan_bwd_main_w8_ke
         {
             const uint32_t so = (uint32_t)((w > 0 ? w - 1 : 0) * ck_row);
 #pragma unroll
-            for (int p = 0; p < kFS / 2; ++p) rh[p] = __builtin_amdgcn_raw_buffer_load_b64(ckr, ck_voff, so + (uint32_t)(p * ck_pair), 0);
+            for (int p = 0; p < kFS / 2; ++p) rh[p] = __builtin_amdgcn_raw_buffer_load_b64(ckr, ck_voff, so + (uint32_t)(p * ck_pair), SEGM_BWD_CKPT_AUX);
         }
         stage_fetch_raw<T, RW>(nbv, sb, Un, wr.dT);
         stage_fetch_raw<T, RW>(ncv, sc, Un, wr.dT);

@@ -17,6 +17,45 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define SEGM_FAST_MIN_WAVES 3       // waves per SIMD the apply kernel is register-limited to (3072 waves at stage 0 = 3 per SIMD)
 #endif
 
+// ---- per-wave timeline (experiments only: -DSEGM_SCAN_TIMELINE, tools/gpu_scan_timeline.py) ------------------------------------
+// Four s_memtime stamps per wave (entry, loop head, end of the first sub-tile, loop exit) plus the constant 100 MHz clock at entry and
+// exit (comparable across CUs / XCDs) and the hardware id (SIMD / CU / SE / XCC), written to a side buffer
+// [kernel slot][wave][8 x u64] that segm_debug_set_timeline() installs.  The product build compiles none of this.
+#ifdef SEGM_SCAN_TIMELINE
+extern __device__ unsigned long long* g_segm_timeline;
+extern __device__ unsigned int g_segm_timeline_waves;      // waves per kernel slot
+struct WaveTimeline {
+    unsigned long long t[4], rt0;
+    __device__ __forceinline__ void stamp(int i) {
+        unsigned long long v;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : : "memory");
+        t[i] = v;
+    }
+    __device__ __forceinline__ void begin() {
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) : : "memory");
+        stamp(0);
+    }
+    __device__ __forceinline__ void end(int slot, unsigned wave_id, int lane) {
+        unsigned long long t4, rt1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t4) : : "memory");
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) : : "memory");
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        if (lane == 0 && g_segm_timeline && wave_id < g_segm_timeline_waves) {
+            unsigned long long* o = g_segm_timeline + ((size_t)slot * g_segm_timeline_waves + wave_id) * 8;
+            o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; o[4] = t4; o[5] = rt0; o[6] = rt1;
+            o[7] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+};
+#define SEGM_TL_DECL() WaveTimeline tl_; tl_.begin()
+#define SEGM_TL_STAMP(i) tl_.stamp(i)
+#define SEGM_TL_END(slot, wid, lane) tl_.end(slot, wid, lane)
+#else
+#define SEGM_TL_DECL() ((void)0)
+#define SEGM_TL_STAMP(i) ((void)0)
+#define SEGM_TL_END(slot, wid, lane) ((void)0)
+#endif
+
 constexpr int kFS = 16;     // states
 constexpr int kFT = 8;      // steps per sub-tile
 
@@ -139,8 +178,9 @@ template <> struct BufIO<float> {
     static __device__ __forceinline__ float ld(rsrc_t r, uint32_t voff, uint32_t soff) {
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
     }
+    template <int AUX = 0>
     static __device__ __forceinline__ void st(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, AUX);
     }
 };
 template <> struct BufIO<bf16_t> {
@@ -151,8 +191,9 @@ template <> struct BufIO<bf16_t> {
     static __device__ __forceinline__ float ld(rsrc_t r, uint32_t voff, uint32_t soff) {
         return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0) << 16);
     }
+    template <int AUX = 0>
     static __device__ __forceinline__ void st(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
-        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, from_f32<bf16_t>(v)), r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, from_f32<bf16_t>(v)), r, voff, soff, AUX);
     }
 };
 template <> struct BufIO<f16_t> {
@@ -163,8 +204,9 @@ template <> struct BufIO<f16_t> {
     static __device__ __forceinline__ float ld(rsrc_t r, uint32_t voff, uint32_t soff) {
         return to_f32(__builtin_bit_cast(f16_t, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0)));
     }
+    template <int AUX = 0>
     static __device__ __forceinline__ void st(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
-        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, from_f32<f16_t>(v)), r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, from_f32<f16_t>(v)), r, voff, soff, AUX);
     }
 };
 

@@ -26,7 +26,24 @@
 
 #include "scan_fast.h"
 
+// Round 6: the state checkpoints (402 MB of fp32 per direction at stage 0) are written once and read by the backward pass tens of
+// milliseconds later: non-temporal stores keep them from evicting the rows the apply pass is about to read.  Measured
+// (profiles/r06_scan_nt_policy.log, r06_scan_ckpt_forms.log): three directions per launch 1.27 -> 1.155 ms, one direction unchanged
+// (0.44 ms); 16-byte stores of a [quad][dim][4] layout instead of 8-byte pairs: no gain (the cost is bytes, not store width);
+// nt on the un-gated y and on the backward's checkpoint loads: nothing.  -DSEGM_CKPT_AUX=0 restores the default policy.
+#ifndef SEGM_CKPT_AUX
+#define SEGM_CKPT_AUX 2                 // cache policy of the checkpoint stores (2 = nt)
+#endif
+#ifndef SEGM_OUT_AUX
+#define SEGM_OUT_AUX 0                  // ... of the un-gated output y, which only the backward pass reads
+#endif
+
 namespace segm {
+
+#ifdef SEGM_SCAN_TIMELINE
+__device__ unsigned long long* g_segm_timeline = nullptr;
+__device__ unsigned int g_segm_timeline_waves = 0;
+#endif
 
 // ------------------------------------------------------------------------------------------------------
 // K1 (regular shapes): chunk aggregates.  grid.y = direction (up to kMaxDirs launches of identical geometry in one).
@@ -135,6 +152,7 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
     constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     __shared__ __attribute__((aligned(16))) float s_b[2][kWavesPerBlock][G][kFT * kFS];
     __shared__ __attribute__((aligned(16))) float s_dt[2][kWavesPerBlock][G][DTR > 0 ? kFT * DTR : 4];
+    SEGM_TL_DECL();
     const ScanDev& P = PP.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
@@ -182,7 +200,11 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
     float sumd = 0.f;
     int buf = 0;
     const int nsub = gm.chunk / kFT;
+    SEGM_TL_STAMP(1);
     for (int s = 0; s < nsub; ++s) {
+#ifdef SEGM_SCAN_TIMELINE
+        if (s == 1) SEGM_TL_STAMP(2);
+#endif
         float* lb = &s_b[buf][wave][it.gi][0];
         float* ldt = &s_dt[buf][wave][it.gi][0];
         stage_park_buf<RW>(nb, sb, lb);
@@ -240,6 +262,7 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
         }
         buf ^= 1;
     }
+    SEGM_TL_STAMP(3);
     const int64_t row = (int64_t)it.b * gm.nchunks + it.chunk;
     P.agg_sd[row * gm.dim + it.d] = sumd;
 #pragma unroll
@@ -247,6 +270,7 @@ __global__ void __launch_bounds__(kBlock) scan_fwd_agg_fast_kernel(ScanDevN PP) 
         P.agg_h[(row * kFS + 2 * n) * gm.dim + it.d] = h[n].x;
         P.agg_h[(row * kFS + 2 * n + 1) * gm.dim + it.d] = h[n].y;
     }
+    SEGM_TL_END(0, (blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -257,6 +281,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
     constexpr int G = 64 / RW, EPL = StageStream<RW>::EPL;
     __shared__ __attribute__((aligned(16))) float s_bc[2][kWavesPerBlock][G][2][kFT * kFS];
     __shared__ __attribute__((aligned(16))) float s_dt[2][kWavesPerBlock][G][DTR > 0 ? kFT * DTR : 4];
+    SEGM_TL_DECL();
     const ScanDev& P = PP.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Geom& gm = P.gm;
@@ -319,7 +344,11 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
 
     int buf = 0;
     const int nsub = gm.chunk / kFT;
+    SEGM_TL_STAMP(1);
     for (int s = 0; s < nsub; ++s) {
+#ifdef SEGM_SCAN_TIMELINE
+        if (s == 1) SEGM_TL_STAMP(2);
+#endif
         float* lb = &s_bc[buf][wave][it.gi][0][0];
         float* lc = &s_bc[buf][wave][it.gi][1][0];
         float* ldt = &s_dt[buf][wave][it.gi][0];
@@ -337,14 +366,26 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
         uint32_t su = (uint32_t)Un * (uint32_t)up.stb, sd = (uint32_t)Un * (uint32_t)dp.stb, sz = (uint32_t)Un * (uint32_t)zp.stb;
         const uint32_t iu = (uint32_t)(wr.dT * up.stb), id = (uint32_t)(wr.dT * dp.stb), iz = (uint32_t)(wr.dT * zp.stb);
         if (P.ckpt) {                                      // kCkpt = one sub-tile
+#ifdef SEGM_CKPT_QUAD_EXPERIMENT
+            // timing experiment only (the backward still reads pairs): [quad][dim][4], four 16-byte stores of 64 lanes x 16 bytes
+            uint32_t kso = (uint32_t)(s * (kFS / 2) * ck_pair);
+#pragma unroll
+            for (int n = 0; n < kFS / 4; ++n) {
+                typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                const u32x4_t v = {__float_as_uint(h[2 * n].x), __float_as_uint(h[2 * n].y), __float_as_uint(h[2 * n + 1].x), __float_as_uint(h[2 * n + 1].y)};
+                __builtin_amdgcn_raw_buffer_store_b128(v, ckr, ck_voff + 8u * (uint32_t)it.d, kso, SEGM_CKPT_AUX);
+                kso += 2u * (uint32_t)ck_pair;
+            }
+#else
             uint32_t kso = (uint32_t)(s * (kFS / 2) * ck_pair);
 #pragma unroll
             for (int n = 0; n < kFS / 2; ++n) {
                 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
                 const u32x2_t v = {__float_as_uint(h[n].x), __float_as_uint(h[n].y)};
-                __builtin_amdgcn_raw_buffer_store_b64(v, ckr, ck_voff, kso, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(v, ckr, ck_voff, kso, SEGM_CKPT_AUX);
                 kso += (uint32_t)ck_pair;
             }
+#endif
         }
         uint32_t oso = (uint32_t)Uc * (uint32_t)op.stb, ozso = (uint32_t)Uc * (uint32_t)ozp.stb;     // running scalar offsets
         const uint32_t oinc = (uint32_t)(wr.dT * op.stb), ozinc = (uint32_t)(wr.dT * ozp.stb);
@@ -395,7 +436,7 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
                 yb = c1 * h[2 * q + 1] + yb;
             }
             const float y = (ya.x + yb.x) + (ya.y + yb.y);
-            if (has_out) BufIO<T>::st(op.rs, op.voff, oso, y);
+            if (has_out) BufIO<T>::template st<SEGM_OUT_AUX>(op.rs, op.voff, oso, y);
             if (has_z) BufIO<T>::st(ozp.rs, ozp.voff, ozso, y * zz * sigmoidf(zz));
             oso += oinc;
             ozso += ozinc;
@@ -404,6 +445,8 @@ __global__ void __launch_bounds__(kBlock, SEGM_FAST_MIN_WAVES) scan_fwd_apply_fa
         }
         buf ^= 1;
     }
+    SEGM_TL_STAMP(3);
+    SEGM_TL_END(1, (blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave, lane);
     (void)tau0;
 }
 
@@ -473,3 +516,13 @@ void launch_scan_fwd_fast(const ScanDevN& PP, int ndir, int dtype, bool apply, h
 }
 
 }  // namespace segm
+
+#ifdef SEGM_SCAN_TIMELINE
+// experiments only (tools/gpu_scan_timeline.py): installs the side buffer of the per-wave stamps, [2 kernels][waves][8] u64
+extern "C" int segm_debug_set_timeline(void* buf, unsigned int waves) {
+    unsigned long long* p = (unsigned long long*)buf;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(segm::g_segm_timeline), &p, sizeof(p)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(segm::g_segm_timeline_waves), &waves, sizeof(waves)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

@@ -379,6 +379,19 @@ def conv3d_k3_wgrad_supported(x: torch.Tensor, dy: torch.Tensor) -> bool:
     for t in (x, dy):
         if t.stride(4) != 1 or any(t.stride(i) % 8 for i in range(4)) or t.data_ptr() % 16:
             return False
+    return conv3d_k3_wgrad_spans_fit(x, dy)
+
+
+def conv3d_k3_wgrad_spans_fit(x: torch.Tensor, dy: torch.Tensor) -> bool:
+    """The weight-gradient kernel addresses a (batch, plane, 48-channel block) through 32-bit byte offsets: 48 channel strides and
+    a plane's rows must stay below the buffer descriptor's 0xFFFFF000 bytes - the same bound segm_conv3d_k3_wgrad checks
+    (csrc/conv3d_wgrad.hip, `fits32`; volumes up to ~350^3 elements per channel).  Beyond it the routing falls back to the
+    vendor route instead of raising."""
+    lim = 0xFFFFF000 - 4096
+    W, H = x.shape[4], x.shape[3]
+    for t in (x, dy):
+        if t.stride(1) * 96 + 2 * W >= lim or t.stride(3) * 2 * H >= lim:
+            return False
     return True
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, call 13: 16-byte stores in segm_pointwise_cf / segm_linear_rows: stand-alone, then the step with / without, interleaved
 mkdir -p gpurun_out
-(SEGM_POINTWISE_WIDE=0 python tools/r05/pointwise_wide.py; SEGM_POINTWISE_WIDE=1 python tools/r05/pointwise_wide.py) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05_pointwise_wide.log
+(SEGM_POINTWISE_WIDE=0 python tools/history/r05/pointwise_wide.py; SEGM_POINTWISE_WIDE=1 python tools/history/r05/pointwise_wide.py) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05_pointwise_wide.log
 for i in 1 2 3; do
   for f in 1 0; do
     SEGM_POINTWISE_WIDE=$f SEGM_LINEAR_WIDE=$f timeout 300 python bench.py --steps 20 --warmup 5 --no-roofline --no-cpu-baseline --no-configs 2>/dev/null | tail -1 > gpurun_out/wd_${f}_${i}.json

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, call 2: ablations of the weight-gradient row loop + L2 / HBM counters for v1 and r5 (separate --pmc passes)
 mkdir -p gpurun_out/prof; R=$GRAFT_REPO_ROOT
-timeout 600 python tools/r05/wgrad_abl.py 2>&1 | grep -v "GridwiseOp\|amdgpu.ids" | tee gpurun_out/r05_wgrad_abl3.log
+timeout 600 python tools/history/r05/wgrad_abl.py 2>&1 | grep -v "GridwiseOp\|amdgpu.ids" | tee gpurun_out/r05_wgrad_abl3.log
 cd /tmp; export TMPDIR=/tmp
 i=0
 for pass in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE" "FETCH_SIZE" \
@@ -9,7 +9,7 @@ for pass in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE" "FETCH_SIZE" 
             "SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM"; do
   i=$((i+1))
   for v in "ct ipw1" "pipe ipw1"; do
-    WG_ONLY="$v" PYTHONPATH=$R timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/prof/w7_${v// /_}_$i -o pmc -- python $R/tools/r05/wgrad_abl.py > $R/gpurun_out/prof/w7_${v// /_}_$i.log 2>&1
+    WG_ONLY="$v" PYTHONPATH=$R timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/prof/w7_${v// /_}_$i -o pmc -- python $R/tools/history/r05/wgrad_abl.py > $R/gpurun_out/prof/w7_${v// /_}_$i.log 2>&1
     echo "pass $i $v rc=$?"
   done
 done
