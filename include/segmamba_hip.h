@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SEGM_ABI_VERSION 8
+#define SEGM_ABI_VERSION 9
 
 enum segm_dtype { SEGM_F32 = 0, SEGM_F16 = 1, SEGM_BF16 = 2 };
 enum segm_time_order { SEGM_TIME_FORWARD = 0, SEGM_TIME_REVERSED = 1, SEGM_TIME_INTERLEAVED = 2 };
@@ -298,6 +298,36 @@ typedef struct segm_conv3d_fwd_args {
 
 int segm_conv3d_k3_fwd(const segm_conv3d_fwd_args* args);
 int32_t segm_conv3d_k3_fwd_stats_parts(int32_t depth, int32_t height, int32_t width, int32_t batch, int32_t cout, int32_t flags);
+
+/* ------------------------------------------------------------------------------------------------
+ * ABI 9 (round 6): the same convolution on CHANNEL-LAST volumes, 48 -> 48 channels (csrc/conv3d_cl.hip).
+ * Replaces the same reference calls as segm_conv3d_k3_fwd (model_segmamba/segmamba.py:91-132,
+ * monai/networks/blocks/dynunet_block.py:44-111) for activations stored (batch, depth, height, width, channel):
+ *
+ *   y[b, z, y, x, co] = bias[co] + sum_{ci, kz, ky, kx} w[co, ci, kz, ky, kx] * x[b, z+kz-1, y+ky-1, x+kx-1, ci]
+ *
+ * x, y: bf16 or fp16 (one dtype), channels contiguous, every other stride a multiple of 8 elements and >= 48, 16-byte aligned
+ * bases, width a multiple of 16, channels == 48 (wider layers: sums over 48-channel blocks with SEGM_CONV_CL_ACCUMULATE).
+ * w_image: the weights as MFMA operand fragments, (14, 9, 64, 8) elements of the activations' dtype: element i is
+ * w.flatten()[index[i]] (0 where index[i] < 0) with index from segm_conv3d_k3_cl_pack_index (host function, no GPU work).
+ * The data gradient is the same call on dy with the image of flip(w, (2, 3, 4)).transpose(0, 1).
+ * bias: (48) fp32 or NULL.  flags: SEGM_CONV_CL_ACCUMULATE adds to what y holds; SEGM_CONV_CL_WAVES8 runs eight waves of two
+ * voxel tiles per workgroup instead of four waves of four (a scheduling choice, same results).
+ * ------------------------------------------------------------------------------------------------ */
+enum segm_conv_cl_flags { SEGM_CONV_CL_ACCUMULATE = 1, SEGM_CONV_CL_WAVES8 = 2 };
+
+typedef struct segm_conv3d_cl_args {
+    int32_t batch, channels, depth, height, width;
+    int32_t dtype, flags, reserved;
+    const void* x;   int64_t x_stride_b, x_stride_z, x_stride_y, x_stride_x;
+    void* y;         int64_t y_stride_b, y_stride_z, y_stride_y, y_stride_x;
+    const void* w_image;
+    const float* bias;
+    void* stream;
+} segm_conv3d_cl_args;
+
+int segm_conv3d_k3_fwd_cl(const segm_conv3d_cl_args* args);
+int segm_conv3d_k3_cl_pack_index(int32_t* out, int64_t n);
 
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d (+ residual) (+ activation), forward and backward.

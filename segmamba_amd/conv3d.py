@@ -100,7 +100,9 @@ def _table_choice(kind: str, width: int, variants) -> int:
     return 0
 
 
-def _pick(key: tuple, cands: List[Callable[[], torch.Tensor]], variants=None, width: int = 0) -> torch.Tensor:
+def _pick(key: tuple, cands: List[Callable[[], torch.Tensor]], variants=None, width: int = 0, box: list = None) -> torch.Tensor:
+    """`box`: the statistics the candidates append to - emptied before the launch whose result is returned, so that what it
+    holds afterwards belongs to that launch and not to a timed candidate"""
     if len(cands) == 1 or not torch.cuda.is_available():
         return cands[0]()
     if not _TUNE:
@@ -122,6 +124,8 @@ def _pick(key: tuple, cands: List[Callable[[], torch.Tensor]], variants=None, wi
         _cache[key] = i
         if os.environ.get("SEGM_CONV_VERBOSE"):
             print(f"[conv3d autotune] {key}: " + ", ".join(f"{t:.2f} ms" for t in times) + f" -> {i}", flush=True)
+    if box is not None:
+        box.clear()
     return cands[i]()
 
 
@@ -254,6 +258,7 @@ def _wgrad_mfma(x, dy, w, pad, out_dtype=None):
 
 
 def _mfma_wgrad_ok(x, dy, w) -> bool:
+    from . import ops_raw
     if w.shape[2:] != (3, 3, 3) or w.dtype not in (torch.bfloat16, torch.float16, torch.float32) or \
             x.dtype not in (torch.bfloat16, torch.float16):
         return False
@@ -351,11 +356,12 @@ class _ConvSame(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         box = [] if want_stats else None
         key, cands, variants = _fwd_candidates(x, w, bias, w.shape[2] // 2, box)
-        out = _pick(key, cands, variants, x.shape[4])
+        out = _pick(key, cands, variants, x.shape[4], box)
         ctx.with_stats = bool(want_stats)
         if not want_stats:
             return out
-        # (the tuner may have run several candidates: the last launch is the one whose result is returned)
+        # the tuner empties the box before the launch whose result is returned: what it holds now came from that launch (and a
+        # winning variant without the statistics epilogue leaves it empty)
         stats = box[-1] if box and _pick_was_hip(key, cands, variants, x.shape[4]) else out.new_empty(0, dtype=torch.float32)
         ctx.mark_non_differentiable(stats)
         return out, stats
@@ -453,7 +459,7 @@ class _ResFront(torch.autograd.Function):
             box = [] if last else None
             if y1 is None:
                 key, cands, variants = _fwd_candidates(x, w1i, None, pad, box)
-                y1 = _pick(key, cands, variants, x.shape[4])
+                y1 = _pick(key, cands, variants, x.shape[4], box)
                 if last and box and _pick_was_hip(key, cands, variants, x.shape[4]):
                     stats = box[-1]
                 y3 = linear._pw_hip(w3i, xf, None)

@@ -1209,6 +1209,7 @@ extern "C" int32_t segm_conv3d_k3_fwd_stats_parts(int32_t depth, int32_t height,
     if (depth <= 0 || height <= 0 || width <= 0 || batch <= 0 || cout <= 0) return 0;
     const bool chain32 = (flags & SEGM_CONV_FWD_CHAIN32) != 0;
     if (!chain32 && !(flags & SEGM_CONV_FWD_CHAIN)) return 0;
+    if (!chain32 && chain_var() == 0) return 0;           // SEGM_CONV_CHAIN_VAR=0: the 64-wide schedule without the statistics epilogue
     const FwPlan pl = fwd_plan(batch, cout, depth, height, width, true, chain32 ? kC32XB : kFwXB);
     return depth * pl.ysplit * pl.nxb * (chain32 ? 1 : 2);
 }

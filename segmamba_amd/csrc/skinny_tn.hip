@@ -80,9 +80,17 @@ __global__ void __launch_bounds__(kBlock) skinny_tn_kernel(SkinnyDev P) {
                     bvec_t rb;
 #pragma unroll
                     for (int w = 0; w < NT / 2; ++w) rb[w] = 0u;
-                    if (ok) rb = *reinterpret_cast<const bvec_t*>(b + ru * P.b_sr);
+                    // the LAST row of the matrix with a partial column tile: the vector would read up to NT - 1 elements beyond the
+                    // row, i.e. beyond the allocation when `skinny` is a column slice at the end of its buffer -> masked
+                    // element loads for that one row
+                    const bool edge = nj < NT && ru == P.k - 1;
+                    if (ok && !edge) rb = *reinterpret_cast<const bvec_t*>(b + ru * P.b_sr);
                     T tb[NT];
                     memcpy(tb, &rb, NT * 2);
+                    if (ok && edge) {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) tb[j] = j < nj ? b[ru * P.b_sr + j] : (T)0.f;
+                    }
 #pragma unroll
                     for (int j = 0; j < NT; ++j) bv[u][j] = j < nj ? tb[j] : (T)0.f;
                 } else {

@@ -108,6 +108,16 @@ class Conv3dFwdArgs(C.Structure):
     ]
 
 
+class Conv3dClArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("channels", C.c_int32), ("depth", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+        ("dtype", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32),
+        ("x", C.c_void_p), ("x_stride_b", C.c_int64), ("x_stride_z", C.c_int64), ("x_stride_y", C.c_int64), ("x_stride_x", C.c_int64),
+        ("y", C.c_void_p), ("y_stride_b", C.c_int64), ("y_stride_z", C.c_int64), ("y_stride_y", C.c_int64), ("y_stride_x", C.c_int64),
+        ("w_image", C.c_void_p), ("bias", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
 class InstNormFwdArgs(C.Structure):
     _fields_ = [
         ("instances", C.c_int32), ("dtype", C.c_int32), ("act", C.c_int32), ("reserved", C.c_int32),
@@ -255,6 +265,7 @@ EXPORTS = (
     "segm_selective_scan_fwd_multi", "segm_selective_scan_bwd_multi", "segm_causal_conv1d_fwd_multi", "segm_causal_conv1d_bwd_multi",
     "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
     "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes", "segm_conv3d_k3_fwd", "segm_conv3d_k3_fwd_stats_parts",
+    "segm_conv3d_k3_fwd_cl", "segm_conv3d_k3_cl_pack_index",
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add", "segm_depth_to_space2",
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
@@ -319,6 +330,8 @@ class SegmLib:
         sig("segm_conv3d_k3_wgrad_workspace_bytes", [C.c_int32] * 6, C.c_size_t)
         sig("segm_conv3d_k3_fwd", [C.POINTER(Conv3dFwdArgs)], C.c_int)
         sig("segm_conv3d_k3_fwd_stats_parts", [C.c_int32] * 6, C.c_int32)
+        sig("segm_conv3d_k3_fwd_cl", [C.POINTER(Conv3dClArgs)], C.c_int)
+        sig("segm_conv3d_k3_cl_pack_index", [C.c_void_p, C.c_int64], C.c_int)
         sig("segm_instnorm_fwd", [C.POINTER(InstNormFwdArgs)], C.c_int)
         sig("segm_instnorm_bwd", [C.POINTER(InstNormBwdArgs)], C.c_int)
         sig("segm_instnorm_workspace_bytes", [C.c_int32, C.c_int64], C.c_size_t)

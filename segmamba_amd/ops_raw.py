@@ -490,10 +490,58 @@ def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias:
     if want_stats and ((chain and pitch48) or chain32):
         nparts = lib.dll.segm_conv3d_k3_fwd_stats_parts(D, H, W, B, cout, a.flags)
         if nparts > 0:
-            stats = torch.empty(B, cout, nparts, 4, dtype=torch.float32, device=x.device)
+            # zeros, not empty: a workgroup whose y part is empty (ysplit >= 16 with H not a multiple of it) returns before it
+            # writes its {count, sum, sumsq} slot, and the merge folds every slot whose count is > 0
+            stats = torch.zeros(B, cout, nparts, 4, dtype=torch.float32, device=x.device)
             a.stats_partials, a.stats_nparts = stats.data_ptr(), nparts
     lib.check(lib.dll.segm_conv3d_k3_fwd(a), "conv3d_k3_fwd")
     return (y, stats) if want_stats else y
+
+
+# ---------------------------------------------------------------------------------------------------------
+# channel-last 3x3x3 convolution (round 6 prototype, csrc/conv3d_cl.hip)
+CONV_CL_ACCUMULATE, CONV_CL_WAVES8 = 1, 2
+_cl_index_cache = {}
+
+
+def conv3d_cl_weight_image(lib: L.SegmLib, w: torch.Tensor, dtype=None) -> torch.Tensor:
+    """(48, 48, 3, 3, 3) weights -> the (14, 9, 64, 8) image of MFMA operand fragments segm_conv3d_k3_fwd_cl keeps in LDS (one
+    gather through the index map the library exports).  For the data gradient pass flip(w, (2, 3, 4)).transpose(0, 1)."""
+    if tuple(w.shape) != (48, 48, 3, 3, 3):
+        raise RuntimeError("conv3d_cl_weight_image: weights must be (48, 48, 3, 3, 3)")
+    key = str(w.device)
+    idx = _cl_index_cache.get(key)
+    if idx is None:
+        n = 14 * 9 * 64 * 8
+        host = torch.empty(n, dtype=torch.int32)
+        lib.check(lib.dll.segm_conv3d_k3_cl_pack_index(host.data_ptr(), n), "conv3d_k3_cl_pack_index")
+        idx = host.to(w.device).long()
+        _cl_index_cache[key] = idx
+    flat = torch.cat([w.reshape(-1), w.new_zeros(1)])       # index -1 -> the appended zero
+    return flat[idx].view(14, 9, 64, 8).to(dtype or w.dtype).contiguous()
+
+
+def conv3d_k3_fwd_cl(lib: L.SegmLib, x: torch.Tensor, w_image: torch.Tensor, bias=None, out=None, accumulate=False, waves8=False):
+    """y (B, D, H, W, 48) = conv3d(x (B, D, H, W, 48) channel-last, 3x3x3, stride 1, pad 1); bf16 / fp16."""
+    if x.dim() != 5 or x.shape[4] != 48 or x.stride(4) != 1 or x.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError("conv3d_k3_fwd_cl: x must be a (B, D, H, W, 48) 16-bit tensor with contiguous channels")
+    B, D, H, W, _ = x.shape
+    y = out if out is not None else torch.empty(B, D, H, W, 48, dtype=x.dtype, device=x.device)
+    if accumulate and out is None:
+        raise RuntimeError("conv3d_k3_fwd_cl: accumulate needs `out`")
+    a = L.Conv3dClArgs()
+    a.batch, a.channels, a.depth, a.height, a.width = B, 48, D, H, W
+    a.dtype = L.dtype_code(x)
+    a.flags = (CONV_CL_ACCUMULATE if accumulate else 0) | (CONV_CL_WAVES8 if waves8 else 0)
+    a.x, a.y, a.w_image = x.data_ptr(), y.data_ptr(), w_image.data_ptr()
+    a.x_stride_b, a.x_stride_z, a.x_stride_y, a.x_stride_x = x.stride()[:4]
+    a.y_stride_b, a.y_stride_z, a.y_stride_y, a.y_stride_x = y.stride()[:4]
+    if bias is not None:
+        bias = bias.float().contiguous()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.stream = L.stream_handle(x)
+    lib.check(lib.dll.segm_conv3d_k3_fwd_cl(a), "conv3d_k3_fwd_cl")
+    return y
 
 
 # ---------------------------------------------------------------------------------------------------------

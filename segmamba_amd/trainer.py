@@ -115,6 +115,8 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
     if flat is None:
         flat = os.environ.get("SEGM_FLAT_GRADS", "1") == "1"
     flat = bool(flat and bank is not None and fused_ok)
+    if flat and amp == "fp16" and not _grad_scaler_internals_ok():
+        flat = False                                       # this torch's GradScaler lacks what flat fp16 leans on: the public route
     world = 1
     if distributed and flat and ddp == "flat":
         import torch.distributed as dist
@@ -162,6 +164,21 @@ def build_training_state(device, distributed: bool = False, local_rank: int = 0,
             st.scaler._lazy_init_scale_growth_tracker(device)
             st.found_inf = opt.use_loss_scale(st.scaler._scale)
     return st
+
+
+def _grad_scaler_internals_ok() -> bool:
+    """fp16 in flat mode keeps GradScaler as the holder of the scale / growth-tracker tensors and runs its update op itself
+    (`_lazy_init_scale_growth_tracker`, `_scale`, `_growth_tracker`, `torch._amp_update_scale_`: private names of torch 2.x).
+    A torch that lacks any of them gets the per-tensor `scale -> unscale_ -> clip -> scaler.step -> update` route instead of an
+    AttributeError in the first step.  One difference of the fused route, for extreme values only: its inf check is
+    the fp32 sum of squares of the SCALED gradients, so a step is also skipped when that sum overflows although every unscaled
+    gradient is finite (|g| * scale > ~1.8e19 somewhere); `GradScaler.unscale_` would keep such a step."""
+    try:
+        sc = torch.amp.GradScaler("cpu", enabled=True)
+        return all(hasattr(sc, n) for n in ("_lazy_init_scale_growth_tracker", "_scale", "_growth_tracker", "get_growth_factor",
+                                            "get_backoff_factor", "get_growth_interval")) and hasattr(torch, "_amp_update_scale_")
+    except Exception:                                      # noqa: BLE001 - any surprise in a private API: the public route
+        return False
 
 
 def train_step(st: TrainingState, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:

@@ -1890,3 +1890,47 @@ def test_unet_res_block_with_statistics_from_the_convolutions_emulated(emu, monk
         # 512-voxel volume a handful of flips are ~1 % of a gradient tensor; the forward output must agree everywhere)
         bad = ((u.float() - v.float()).abs() > 2e-2 * max(1.0, float(u.float().abs().max()))).float().mean()
         assert bad <= (0.0 if u is res[0][0] else 2e-2), float(bad)
+
+
+# ---- channel-last 3x3x3 convolution (round 6 prototype, csrc/conv3d_cl.hip) ---------------------------------------------------------
+@pytest.mark.parametrize("shape,waves8", [((1, 2, 3, 16), False), ((1, 1, 2, 32), False), ((2, 2, 2, 64), False), ((1, 1, 1, 128), False),
+                                          ((1, 2, 2, 32), True), ((1, 1, 2, 64), True), ((1, 1, 3, 16), True)])
+def test_conv3d_k3_fwd_channel_last_emulated(emu, shape, waves8):
+    """kx taps in N + shift-and-add of accumulators along x (DPP row shifts, the tile that waits for the next group's first voxel),
+    zero padding by buffer range check (rows outside the volume) and by absence (x), the weight image in LDS, the channel deal
+    of the three co tiles, bias, in-place accumulation; every group width (one, two, four tiles), one and two groups per row."""
+    B, D, H_, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + (7 if waves8 else 0))
+    x = torch.randn(B, 48, D, H_, W, generator=g).bfloat16()
+    w = (0.1 * torch.randn(48, 48, 3, 3, 3, generator=g)).bfloat16()
+    bias = torch.randn(48, generator=g)
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), bias, 1, 1)
+    tol = 1e-2 * max(1.0, float(ref.abs().max()))
+    xcl = x.permute(0, 2, 3, 4, 1).contiguous()
+    img = ops_raw.conv3d_cl_weight_image(emu, w)
+    y = ops_raw.conv3d_k3_fwd_cl(emu, xcl, img, bias, waves8=waves8)
+    assert y.shape == (B, D, H_, W, 48) and y.dtype == torch.bfloat16
+    assert (y.permute(0, 4, 1, 2, 3).float() - ref).abs().max() <= tol
+    # a second 48-channel input block accumulated in place, on padded (strided) volumes
+    x2 = torch.randn(B, 48, D, H_, W, generator=g).bfloat16()
+    w2 = (0.1 * torch.randn(48, 48, 3, 3, 3, generator=g)).bfloat16()
+    ref2 = ref + torch.nn.functional.conv3d(x2.float(), w2.float(), None, 1, 1)
+    pad = torch.zeros(B, D, H_, W, 56, dtype=torch.bfloat16)
+    pad[..., :48] = x2.permute(0, 2, 3, 4, 1)
+    ya = torch.full((B, D, H_, W, 64), 7.0, dtype=torch.bfloat16)
+    ya[..., :48] = y
+    ops_raw.conv3d_k3_fwd_cl(emu, pad[..., :48], ops_raw.conv3d_cl_weight_image(emu, w2), None, out=ya[..., :48], accumulate=True, waves8=waves8)
+    assert (ya[..., :48].permute(0, 4, 1, 2, 3).float() - ref2).abs().max() <= 2 * tol
+    assert bool((ya[..., 48:] == 7.0).all())              # nothing written beyond the 48 channels of a voxel
+
+
+def test_conv3d_k3_dgrad_channel_last_emulated(emu):
+    """the data gradient is the same kernel on dy with the image of flip(w).transpose(0, 1)"""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 48, 2, 3, 32, generator=g, requires_grad=True)
+    w = 0.1 * torch.randn(48, 48, 3, 3, 3, generator=g)
+    dy = torch.randn(1, 48, 2, 3, 32, generator=g).bfloat16()
+    torch.nn.functional.conv3d(x, w.bfloat16().float(), None, 1, 1).backward(dy.float())
+    wt = torch.flip(w, (2, 3, 4)).transpose(0, 1).contiguous().bfloat16()
+    dx = ops_raw.conv3d_k3_fwd_cl(emu, dy.permute(0, 2, 3, 4, 1).contiguous(), ops_raw.conv3d_cl_weight_image(emu, wt))
+    assert (dx.permute(0, 4, 1, 2, 3).float() - x.grad).abs().max() <= 1e-2 * max(1.0, float(x.grad.abs().max()))
