@@ -896,3 +896,43 @@ def test_depth_to_space2(hip, shape, dtype):
     assert torch.equal(padded, ref)
     assert torch.equal(ops_raw.space_to_depth2(hip, padded), blk)
     assert torch.equal(ops_raw.space_to_depth2(hip, vol), blk)
+
+
+# ---- channel-last 3x3x3 convolution (round 6 prototype, csrc/conv3d_cl.hip) ---------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("waves8", [False, True])
+def test_conv3d_k3_channel_last_forward_and_dgrad_at_the_benchmarked_shape(waves8):
+    """48 -> 48 at 2 x 128^3, channels last: forward (+ bias) and data gradient (the same kernel on dy with the image of
+    flip(w).transpose(0, 1)) against fp32 ATen on the same bf16-rounded operands; the bound of the NCDHW at-size test (1e-2 of the
+    largest reference value).  Also one 2 x 64^3 accumulate call on padded voxel strides."""
+    from segmamba_amd import lib as L, ops_raw
+    hip = L.get_lib()
+    dev = torch.device("cuda")
+    B, S = 2, 128
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = (0.5 * torch.randn(B, 48, S, S, S, device=dev, generator=g)).bfloat16()
+    w = (torch.randn(48, 48, 3, 3, 3, device=dev, generator=g) / (27 * 48) ** 0.5).bfloat16()
+    bias = torch.randn(48, device=dev, generator=g)
+    dy = (0.5 * torch.randn(B, 48, S, S, S, device=dev, generator=g)).bfloat16()
+    xcl = x.permute(0, 2, 3, 4, 1).contiguous()
+    y = ops_raw.conv3d_k3_fwd_cl(hip, xcl, ops_raw.conv3d_cl_weight_image(hip, w), bias, waves8=waves8)
+    wt = torch.flip(w, (2, 3, 4)).transpose(0, 1).contiguous()
+    dx = ops_raw.conv3d_k3_fwd_cl(hip, dy.permute(0, 2, 3, 4, 1).contiguous(), ops_raw.conv3d_cl_weight_image(hip, wt), None, waves8=waves8)
+    for b in range(B):                                    # fp32 activations at this size are 1.6 GB per batch of two
+        xr = x[b:b + 1].float().requires_grad_()
+        yr = torch.nn.functional.conv3d(xr, w.float(), bias, 1, 1)
+        yr.backward(dy[b:b + 1].float())
+        sc = float(yr.detach().abs().max())
+        assert float((y[b:b + 1].permute(0, 4, 1, 2, 3).float() - yr.detach()).abs().max()) <= 1e-2 * sc
+        sc = float(xr.grad.abs().max())
+        assert float((dx[b:b + 1].permute(0, 4, 1, 2, 3).float() - xr.grad).abs().max()) <= 1e-2 * sc
+        del xr, yr
+    S2 = 64
+    x2 = torch.zeros(B, S2, S2, S2, 56, device=dev, dtype=torch.bfloat16)
+    x2[..., :48] = 0.5 * torch.randn(B, S2, S2, S2, 48, device=dev, generator=g)
+    out = torch.zeros(B, S2, S2, S2, 64, device=dev, dtype=torch.bfloat16)
+    out[..., :48] = torch.randn(B, S2, S2, S2, 48, device=dev, generator=g)
+    ref = out[..., :48].permute(0, 4, 1, 2, 3).float() + torch.nn.functional.conv3d(x2[..., :48].permute(0, 4, 1, 2, 3).float(), w.float(), None, 1, 1)
+    ops_raw.conv3d_k3_fwd_cl(hip, x2[..., :48], ops_raw.conv3d_cl_weight_image(hip, w), None, out=out[..., :48], accumulate=True, waves8=waves8)
+    assert float((out[..., :48].permute(0, 4, 1, 2, 3).float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
+    assert bool((out[..., 48:] == 0).all())

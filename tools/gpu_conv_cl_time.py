@@ -43,7 +43,11 @@ for (B, S) in ((2, 128), (2, 64), (2, 32)):
     flop = 2.0 * B * S ** 3 * 27 * 48 * 48
     ref = torch.nn.functional.conv3d(x.float(), w.float(), None, 1, 1)
     scale = float(ref.abs().max())
-    xcl = x.permute(0, 2, 3, 4, 1).contiguous()
+    # row pitch padded by PADX voxels: a dense 128-voxel row is 12 KB = 3 x 4096 bytes and the 16 rows a fragment load touches would
+    # all sit on one memory channel (the same aliasing the NCDHW volumes avoid with a padded channel stride)
+    PADX = int(os.environ.get("SEGM_CL_PADX", "0"))
+    xcl = torch.zeros(B, S, S, S + PADX, 48, dtype=x.dtype, device=dev)[:, :, :, :S]
+    xcl.copy_(x.permute(0, 2, 3, 4, 1))
     img = ops_raw.conv3d_cl_weight_image(hip, w)
     # shipped NCDHW kernel (padded channel stride as the step uses it at 128^3)
     xp = ops_raw.volume_empty(B, 48, (S, S, S), x.dtype, dev)
@@ -57,7 +61,7 @@ for (B, S) in ((2, 128), (2, 64), (2, 32)):
     for w8 in (False, True):
         y = ops_raw.conv3d_k3_fwd_cl(hip, xcl, img, None, waves8=w8)
         e = float((y.permute(0, 4, 1, 2, 3).float() - ref).abs().max()) / scale
-        out = torch.empty_like(y)
+        out = torch.zeros(B, S, S, S + PADX, 48, dtype=x.dtype, device=dev)[:, :, :, :S]
         t = time_ms(lambda: ops_raw.conv3d_k3_fwd_cl(hip, xcl, img, None, out=out, waves8=w8))
         ta = time_ms(lambda: ops_raw.conv3d_k3_fwd_cl(hip, xcl, img, None, out=out, accumulate=True, waves8=w8))
         say("                       channel-last %s: %.3f ms = %.0f TF/s (%.1f %% of 2.5 PF)   err %.2e   accumulate %.3f ms" % (
