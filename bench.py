@@ -523,8 +523,9 @@ def cpu_baseline(full=False):
     bf, bb = algorithmic_bytes_scan(B, D, Lq, N, 4), algorithmic_bytes_scan(B, D, Lq, N, 4, backward=True)
     out.update({"value": round(bf / tf * 1e-9, 3), "unit": "GB/s", "cores": scan_ref.threads(), "kind": "port",
                 "seconds": round(tf, 2),
-                "sample": f"C port of selective_scan_ref (oracle/scan_ref.c, OpenMP, fp64), forward, fp32 I/O, B={B} D={D} N={N} "
-                          f"L={Lq} (the whole roofline shape), same algorithmic-bytes formula",
+                "sample": f"HEADLINE VALUE = the C port of selective_scan_ref (oracle/scan_ref.c, OpenMP, fp64 arithmetic; NOT the reference's "
+                          f"own path: that is `torch_ref` below, a Python loop over time, ~500 x slower), forward, fp32 I/O, B={B} D={D} "
+                          f"N={N} L={Lq} (the whole roofline shape), same algorithmic-bytes formula",
                 "scan_fwd_bwd": {"value": round((bf + bb) / (tf + tb) * 1e-9, 3), "unit": "GB/s", "seconds": round(tf + tb, 2)}})
     # the reference's own CPU path is a Python loop over time: L = 2048
     Ls = 2048
@@ -535,7 +536,9 @@ def cpu_baseline(full=False):
     t1 = time.time()
     y.backward(c["g"])
     t2 = time.time()
-    out["torch_ref"] = {"sample": f"PyTorch port of selective_scan_ref, fp32, B={B} D={D} N={N} L={Ls}",
+    out["torch_ref"] = {"sample": f"THE REFERENCE-PATH FIGURE: the pure-PyTorch selective_scan_ref the north star names (restated in "
+                                  f"oracle/ref_ops.py - /root/reference does not exist on the GPU box), fp32, B={B} D={D} N={N} L={Ls}; "
+                                  "cost is linear in L: extrapolated to the roofline shape below",
                         "cores": torch.get_num_threads(), "fwd_seconds": round(t1 - t0, 2), "fwd_bwd_seconds": round(t2 - t0, 2),
                         "fwd_GBps": round(algorithmic_bytes_scan(B, D, Ls, N, 4) / (t1 - t0) * 1e-9, 5),
                         "seconds_per_stage0_scan_extrapolated": round((t2 - t0) * Lq / Ls, 1)}
@@ -675,8 +678,11 @@ def main():
         "peak_allocated_mb": round(torch.cuda.max_memory_allocated(device) / 2 ** 20, 1),
         "peak_reserved_mb": round(torch.cuda.max_memory_reserved(device) / 2 ** 20, 1),
         "allocated_between_steps_mb": round(torch.cuda.memory_allocated(device) / 2 ** 20, 1),
-        "what": "torch caching allocator on rank 0 over the timed steps (graph pool included): parameters fp32 + 16-bit twin, flat "
-                "gradients, momenta, kept activations of a 2 x 4 x 128^3 batch, scan checkpoints / workspaces",
+        "what": "torch caching allocator on rank 0 over the timed steps: parameters fp32 + 16-bit twin, flat gradients, momenta, kept "
+                "activations of a 2 x 4 x 128^3 batch, scan checkpoints / workspaces.  Under a graph replay the step's tensors live in "
+                "the graph's private pool, which peak_allocated does not see: there peak_reserved is the footprint; an eager run "
+                "(--no-graph) reports the step's own peak in peak_allocated (README: both, with SEGM_RECOMPUTE 0 / 1)",
+        "launch": "graph replay" if state.graphed is not None else "eager",
         "recompute": os.environ.get("SEGM_RECOMPUTE", "0"),
         "reference_published_mb": {"training": 17976, "inference": 6279, "source": "reference README.md:15-16 (Table 5), batch and GPU not stated"}}
     if sampler is not None:
@@ -688,21 +694,37 @@ def main():
     if distributed and state.exchange is not None and not dry:
         exposed_ms = state.exchange.exposed_ms() if state.exchange.record_exposed else None
         state.exchange.record_exposed = False
-        # the other form behind the timed region (captured bracket + one call): opt-in - a capture that fails on one rank only would
-        # leave the ranks in different collectives, and the driver's scaling run is not the place to find that out
-        if state.graphed is None and not args.no_graph and os.environ.get("SEGM_BENCH_OTHER_FORM", "0") == "1":
+        # the other form behind the timed region (captured bracket + one call).
+        # Round 6: on by default, and unable to split the ranks - every rank attempts the capture on its own (no
+        # collective inside), then ONE all-reduce (MIN) of a success flag decides for all of them whether the three extra steps run;
+        # only when the overlapped form ran the timed region without a fallback.  SEGM_BENCH_OTHER_FORM=0 skips it.
+        if state.graphed is None and not args.no_graph and os.environ.get("SEGM_BENCH_OTHER_FORM", "1") == "1" and \
+                state.exchange.fallback_reason is None:
+            from segmamba_amd.trainer import GraphedStep
+            err = None
             try:
-                from segmamba_amd.trainer import GraphedStep
                 GraphedStep(state, *data.next())
-                step()
-                dist.barrier(); sync()
-                t1 = time.perf_counter()
-                for _ in range(3):
-                    step()
-                dist.barrier(); sync()
-                other_form = {"form": "hipGraph replay + one all-reduce behind it", "ms_per_step": round((time.perf_counter() - t1) / 3 * 1e3, 3)}
             except Exception as e:                          # noqa: BLE001
-                other_form = {"form": "hipGraph replay + one all-reduce behind it", "error": f"{type(e).__name__}: {str(e)[:160]}"}
+                err = f"{type(e).__name__}: {str(e)[:160]}"
+                state.graphed = None
+                torch.cuda.synchronize()
+            okf = torch.tensor([0.0 if err else 1.0], device=device)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if float(okf.item()) >= 1.0:
+                try:
+                    step()
+                    dist.barrier(); sync()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        step()
+                    dist.barrier(); sync()
+                    other_form = {"form": "hipGraph replay + one all-reduce behind it", "ms_per_step": round((time.perf_counter() - t1) / 3 * 1e3, 3)}
+                except Exception as e:                      # noqa: BLE001
+                    other_form = {"form": "hipGraph replay + one all-reduce behind it", "error": f"{type(e).__name__}: {str(e)[:160]}"}
+            else:
+                state.graphed = None
+                other_form = {"form": "hipGraph replay + one all-reduce behind it", "skipped": "the capture failed on at least one rank",
+                              "this_rank": err}
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]

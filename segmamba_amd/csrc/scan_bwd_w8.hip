@@ -86,7 +86,6 @@ __device__ __forceinline__ int bc_index(int m, int j, int n) { return (j * (kFS 
 // DPP add whose untouched lanes keep a value that is not one of its sources, hence inline assembly; the hardware wants two wait
 // states between a vector write of a register and a DPP read of it, which the compiler does not track through asm operands:
 // every block starts with s_nop 1 (its DPP sources are inputs), and no block reads through DPP what it wrote itself.
-// (The CPU emulation build takes the intrinsic form: tests/emu models __builtin_amdgcn_update_dpp, not assembly text.)
 #ifndef SEGM_W8_DPP_ASM
 #define SEGM_W8_DPP_ASM 1
 #endif
@@ -95,32 +94,37 @@ template <int CTRL> __device__ __forceinline__ float row_pick(float lo, float hi
     return up ? shi : slo;
 }
 // BIT = 3 (partner lane ^ 8) or 2 (partner lane ^ 7); `up` = the lane's bit
+// ONE list of operations per stage feeds both builds: the GPU build pastes it into the assembly text, the CPU emulation build
+// runs the same (destination, DPP source, plain source, control, bank mask) tuples through tests/emu's model of v_add_f32_dpp - so
+// the lane masks and controls of the assembly are checked off the GPU too (round 6; the hazards, s_nop placement, stay GPU-only).
+//   OP(d, a, b, ctl, bank):  v_add_f32_dpp %d, %a, %b <ctl> row_mask:0xf bank_mask:<bank>   =   r[d] = r[a](dpp lane) + r[b]  on the
+//   lanes of the enabled banks, the others keep r[d]
+#define SEGM_W8_CTL_STR_ROR8 "row_ror:8"
+#define SEGM_W8_CTL_NUM_ROR8 0x128
+#define SEGM_W8_CTL_STR_HMIR "row_half_mirror"
+#define SEGM_W8_CTL_NUM_HMIR 0x141
+#define SEGM_W8_ASM(d, a, b, ctl, bank) "v_add_f32_dpp %" #d ", %" #a ", %" #b " " SEGM_W8_CTL_STR_##ctl " row_mask:0xf bank_mask:" #bank "\n\t"
+#define SEGM_W8_EMU(d, a, b, ctl, bank) r[d] = hipemu_v_add_f32_dpp(r[d], r[a], r[b], SEGM_W8_CTL_NUM_##ctl, 0xf, bank);
+// four (two) elements: first the lanes whose bit is clear keep lo + partner's lo, then the lanes whose bit is set take hi + partner's hi
+#define SEGM_W8_LIST4(OP, ctl, bk0, bk1) OP(0, 0, 0, ctl, bk0) OP(1, 1, 1, ctl, bk0) OP(2, 2, 2, ctl, bk0) OP(3, 3, 3, ctl, bk0) \
+                                         OP(0, 4, 4, ctl, bk1) OP(1, 5, 5, ctl, bk1) OP(2, 6, 6, ctl, bk1) OP(3, 7, 7, ctl, bk1)
+#define SEGM_W8_LIST2(OP, ctl, bk0, bk1) OP(0, 0, 0, ctl, bk0) OP(1, 1, 1, ctl, bk0) OP(0, 2, 2, ctl, bk1) OP(1, 3, 3, ctl, bk1)
 template <int BIT>
 __device__ __forceinline__ void row_stage4(float& x0, float& x1, float& x2, float& x3, float y0, float y1, float y2, float y3, bool up) {
 #if SEGM_W8_DPP_ASM && !defined(SEGM_EMU)
     (void)up;
     if constexpr (BIT == 3)
-        asm volatile("s_nop 1\n\t"
-                     "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                     "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                     "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                     "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc"
+        asm volatile("s_nop 1\n\t" SEGM_W8_LIST4(SEGM_W8_ASM, ROR8, 0x3, 0xc)
                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(y0), "v"(y1), "v"(y2), "v"(y3));
     else
-        asm volatile("s_nop 1\n\t"
-                     "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                     "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                     "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                     "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                     "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-                     "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-                     "v_add_f32_dpp %2, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-                     "v_add_f32_dpp %3, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa"
+        asm volatile("s_nop 1\n\t" SEGM_W8_LIST4(SEGM_W8_ASM, HMIR, 0x5, 0xa)
                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(y0), "v"(y1), "v"(y2), "v"(y3));
+#elif SEGM_W8_DPP_ASM
+    (void)up;
+    float r[8] = {x0, x1, x2, x3, y0, y1, y2, y3};
+    if constexpr (BIT == 3) { SEGM_W8_LIST4(SEGM_W8_EMU, ROR8, 0x3, 0xc) }
+    else { SEGM_W8_LIST4(SEGM_W8_EMU, HMIR, 0x5, 0xa) }
+    x0 = r[0]; x1 = r[1]; x2 = r[2]; x3 = r[3];
 #else
     constexpr int CTRL = BIT == 3 ? 0x128 : 0x141;
     x0 = row_pick<CTRL>(x0, y0, up); x1 = row_pick<CTRL>(x1, y1, up); x2 = row_pick<CTRL>(x2, y2, up); x3 = row_pick<CTRL>(x3, y3, up);
@@ -131,19 +135,15 @@ __device__ __forceinline__ void row_stage2(float& x0, float& x1, float y0, float
 #if SEGM_W8_DPP_ASM && !defined(SEGM_EMU)
     (void)up;
     if constexpr (BIT == 3)
-        asm volatile("s_nop 1\n\t"
-                     "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                     "v_add_f32_dpp %1, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc"
-                     : "+v"(x0), "+v"(x1) : "v"(y0), "v"(y1));
+        asm volatile("s_nop 1\n\t" SEGM_W8_LIST2(SEGM_W8_ASM, ROR8, 0x3, 0xc) : "+v"(x0), "+v"(x1) : "v"(y0), "v"(y1));
     else
-        asm volatile("s_nop 1\n\t"
-                     "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                     "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                     "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-                     "v_add_f32_dpp %1, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa"
-                     : "+v"(x0), "+v"(x1) : "v"(y0), "v"(y1));
+        asm volatile("s_nop 1\n\t" SEGM_W8_LIST2(SEGM_W8_ASM, HMIR, 0x5, 0xa) : "+v"(x0), "+v"(x1) : "v"(y0), "v"(y1));
+#elif SEGM_W8_DPP_ASM
+    (void)up;
+    float r[4] = {x0, x1, y0, y1};
+    if constexpr (BIT == 3) { SEGM_W8_LIST2(SEGM_W8_EMU, ROR8, 0x3, 0xc) }
+    else { SEGM_W8_LIST2(SEGM_W8_EMU, HMIR, 0x5, 0xa) }
+    x0 = r[0]; x1 = r[1];
 #else
     constexpr int CTRL = BIT == 3 ? 0x128 : 0x141;
     x0 = row_pick<CTRL>(x0, y0, up); x1 = row_pick<CTRL>(x1, y1, up);

@@ -169,6 +169,22 @@ static inline uint32_t hipemu_update_dpp(uint32_t old, uint32_t src, int ctrl, i
     return valid ? got : (bound_ctrl ? 0u : old);
 }
 #define __builtin_amdgcn_update_dpp hipemu_update_dpp
+// v_add_f32_dpp vdst, vsrc0, vsrc1 <ctrl> row_mask bank_mask (no bound_ctrl): on the lanes of the enabled rows / banks
+// vdst = vsrc0[the lane ctrl selects] + vsrc1[this lane] (a lane without a source is not written); every other lane keeps vdst.
+// Models the bank-masked assembly of csrc/scan_bwd_w8.hip (the same operand / control / mask tuples are pasted into its asm text).
+static inline float hipemu_v_add_f32_dpp(float vdst, float vsrc0, float vsrc1, int ctrl, int row_mask, int bank_mask) {
+    uint32_t s0, d;
+    memcpy(&s0, &vsrc0, 4);
+    memcpy(&d, &vdst, 4);
+    const uint32_t marker = 0x7fc0dead;                      // what a lane without write would see: detected below
+    const uint32_t got = hipemu_update_dpp(marker, s0, ctrl, row_mask, bank_mask, false);
+    const int lane = hipemu::t_linear % 64, row = lane >> 4, i = lane & 15;
+    const bool enabled = ((row_mask >> row) & 1) && ((bank_mask >> (i >> 2)) & 1);
+    if (!enabled || (got == marker && s0 != marker)) return vdst;
+    float g;
+    memcpy(&g, &got, 4);
+    return g + vsrc1;
+}
 // v_permlane16_swap_b32 vdst, vsrc: the odd rows of 16 lanes of vdst trade places with the even rows of vsrc (lanes 16..31 of
 // vdst <-> lanes 0..15 of vsrc, 48..63 <-> 32..47); returns {new vdst, new vsrc}
 typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));

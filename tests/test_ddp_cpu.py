@@ -206,6 +206,32 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     assert r2.returncode != 0 and "WORLD_SIZE=1" in r2.stderr
 
 
+def test_bench_eight_ranks_cpu_dry_run():
+    """the driver's scaling command shape - `bench.py --gpus 8` - as 8 gloo ranks on the emulated kernels:
+    rendezvous on 127.0.0.1, the record-only first step, hook sends from the second, rank-0-only extras while seven ranks sit in
+    the final barrier, ONE JSON line with n_gpus = 8 and no fallback."""
+    import json
+    import subprocess
+    import sys
+    from tests import emu_util
+    if not emu_util.emu_available():
+        pytest.skip("no host clang for the emulation build")
+    emu_util.build_emu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--cpu-dry-run", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    rec = json.loads(line[0])
+    ddp = rec["config"]["ddp"]
+    assert rec["n_gpus"] == 8 and rec["config"]["parallelism"] == "dp8" and rec["scaling"] == "weak"
+    assert ddp["mode"].startswith("flat") and ddp["fallback"] is None and sorted(ddp["segment_order"]) == list(range(ddp["segments"]))
+    assert ddp["rendezvous"]["MASTER_ADDR"] == "127.0.0.1" and ddp["rendezvous"]["WORLD_SIZE"] == "8"
+    assert rec["value"] > 0 and abs(rec["value"] - 8 * 1 / (rec["ms_per_step"] * 1e-3)) <= 1e-2 * rec["value"]
+
+
 def _failing_worker(rank, world, port, out, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import datetime
