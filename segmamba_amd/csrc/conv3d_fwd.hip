@@ -613,7 +613,15 @@ __global__ void __launch_bounds__(512, 2) conv3d_k3_fwd48_chain_kernel(ConvFwdDe
         if (second) row_park<T, CP>(r[1], ring + (2 * 4 + ((yb + 8) & 3)) * kSlot * (int)sizeof(T), cl, halo_wave);
     };
 
-    if (y1 <= y0) return;
+    if (y1 <= y0) {                                       // an empty y part (ysplit does not divide H): nothing to compute, but its
+        if (P.stats && part == 3 && g == 0) {             // statistics slot must hold count 0 - the merge folds every slot
+            const int nparts = P.D * P.ysplit * P.nxb * XP, pid = ((z * P.ysplit + ypart) * P.nxb + xb) * XP + xp;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                reinterpret_cast<float4*>(P.stats)[((int64_t)b * P.cout + cob * 48 + t * 16 + i16) * nparts + pid] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
     {   // prologue: rows y0 - 1, y0, y0 + 1 of every plane (planes 1 and 2 re-park theirs on schedule; same slot, same data)
         RowRegs r[2];
 #pragma unroll
@@ -942,7 +950,15 @@ __global__ void __launch_bounds__(256, 2) conv3d_k3_fwd48_chain32_kernel(ConvFwd
         }
     };
 
-    if (y1 <= y0) return;
+    if (y1 <= y0) {                                       // an empty y part: its statistics slot must hold count 0 (see the 64-wide kernel)
+        if (P.stats && part == 3 && g == 0) {
+            const int nparts = P.D * P.ysplit * P.nxb, pid = (z * P.ysplit + ypart) * P.nxb + xb;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                reinterpret_cast<float4*>(P.stats)[((int64_t)b * P.cout + cob * 48 + t * 16 + i16) * nparts + pid] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
     {   // prologue: rows y0 - 1, y0, y0 + 1 of every plane (planes 1 and 2 re-park theirs on schedule; same slot, same data)
         RowRegs r[3];
 #pragma unroll

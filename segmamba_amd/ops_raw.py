@@ -490,9 +490,8 @@ def conv3d_k3_fwd(lib: L.SegmLib, x: torch.Tensor, w_packed: torch.Tensor, bias:
     if want_stats and ((chain and pitch48) or chain32):
         nparts = lib.dll.segm_conv3d_k3_fwd_stats_parts(D, H, W, B, cout, a.flags)
         if nparts > 0:
-            # zeros, not empty: a workgroup whose y part is empty (ysplit >= 16 with H not a multiple of it) returns before it
-            # writes its {count, sum, sumsq} slot, and the merge folds every slot whose count is > 0
-            stats = torch.zeros(B, cout, nparts, 4, dtype=torch.float32, device=x.device)
+            # (a workgroup whose y part is empty - ysplit >= 16 with H not a multiple of it - writes a zero-count slot: ADVICE r05)
+            stats = torch.empty(B, cout, nparts, 4, dtype=torch.float32, device=x.device)
             a.stats_partials, a.stats_nparts = stats.data_ptr(), nparts
     lib.check(lib.dll.segm_conv3d_k3_fwd(a), "conv3d_k3_fwd")
     return (y, stats) if want_stats else y

@@ -1819,7 +1819,10 @@ def test_conv3d_k3_wgrad_items_per_workgroup_emulated(emu, monkeypatch, ipw):
 
 
 @pytest.mark.parametrize("variant,shape", [("chain48", (2, 48, 48, 2, 5, 64)), ("chain48", (1, 96, 48, 2, 3, 72)), ("chain32", (1, 48, 96, 2, 4, 32)),
-                                           ("chain32", (1, 96, 48, 1, 9, 40))])
+                                           ("chain32", (1, 96, 48, 1, 9, 40)),
+                                           # H = 129 cut into 16 y parts of 9 rows: the last part is EMPTY and must still write a
+                                           # zero-count slot (the partials buffer is torch.empty)
+                                           ("chain48", (1, 48, 48, 1, 129, 16)), ("chain32", (1, 48, 48, 1, 129, 16))])
 def test_conv3d_statistics_epilogue_feeds_instnorm_emulated(emu, variant, shape):
     """round 5: the chained 3x3x3 kernels sum {count, y, y^2} of what their storing K part writes (per workgroup and x pair); the
     InstanceNorm behind the convolution merges those partials instead of reading the volume again.  Same y as without the epilogue;
