@@ -402,6 +402,25 @@ typedef struct segm_transpose_args {
 int segm_transpose_add(const segm_transpose_args* args);
 
 /* ------------------------------------------------------------------------------------------------
+ * ABI 9: out = a + b + c, element-wise, one pass (fp32 sum, one rounding).  Replaces the two binary adds of
+ * `out + out_b + out_s` in front of out_proj (reference mamba/mamba_ssm/modules/mamba_simple.py:160 / :264) and of the three
+ * directions' `dxz` contributions in the backward pass of the v3 block (autograd's fan-in adds in the reference).
+ * a, b, c, out: `count` elements of one dtype (fp32 / fp16 / bf16), dense, 16-byte aligned, count a multiple of 16 bytes' worth;
+ * out may be a.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_add3_args {
+    int64_t count;
+    int32_t dtype, reserved;
+    const void* a;
+    const void* b;
+    const void* c;
+    void* out;
+    void* stream;
+} segm_add3_args;
+
+int segm_add3(const segm_add3_args* args);
+
+/* ------------------------------------------------------------------------------------------------
  * Volume -> tokens with LayerNorm over the channels, forward and backward.
  * Replaces `x.reshape(B, C, n).transpose(-1, -2)` followed by `nn.LayerNorm(C)` at the entry of a Mamba layer
  * (reference model_segmamba/segmamba.py:60-66): a transposing copy, an fp32 LayerNorm and a cast in the reference.

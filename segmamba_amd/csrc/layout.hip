@@ -130,9 +130,60 @@ __global__ void __launch_bounds__(256) depth_to_space2_kernel(D2sDev P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// out = a + b + c (C ABI: segm_add3; round 6).  The v3 Mamba block sums its three directions twice per layer - `out + out_b + out_s`
+// in front of out_proj (reference mamba_simple.py:160 / :264) and the three `dxz` contributions in the backward pass - and
+// ATen does each as two binary adds: six tensor passes (and a 16-bit rounding in between) where four do.  One streaming pass, fp32
+// sum, one rounding; `out` may be `a`.
+// ------------------------------------------------------------------------------------------------------
+struct Add3Dev { const void* a; const void* b; const void* c; void* out; int64_t npack; };
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) add3_kernel(Add3Dev P) {
+    using Pk = Pack<T, true>;
+    constexpr int N = Pk::N;
+    const T* a = reinterpret_cast<const T*>(P.a);
+    const T* b = reinterpret_cast<const T*>(P.b);
+    const T* c = reinterpret_cast<const T*>(P.c);
+    T* out = reinterpret_cast<T*>(P.out);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < P.npack; i += 2 * stride) {     // two packets of each in flight
+        const int64_t j = i + stride;
+        const bool two = j < P.npack;
+        Pk va, vb, vc, wa, wb, wc;
+        va.load(a + i * N); vb.load(b + i * N); vc.load(c + i * N);
+        if (two) { wa.load(a + j * N); wb.load(b + j * N); wc.load(c + j * N); }
+#pragma unroll
+        for (int q = 0; q < N; ++q) va.v[q] = (va.v[q] + vb.v[q]) + vc.v[q];
+        va.store(out + i * N);
+        if (two) {
+#pragma unroll
+            for (int q = 0; q < N; ++q) wa.v[q] = (wa.v[q] + wb.v[q]) + wc.v[q];
+            wa.store(out + j * N);
+        }
+    }
+}
+
 }  // namespace segm
 
 using namespace segm;
+
+extern "C" int segm_add3(const segm_add3_args* p) {
+    if (!p) return SEGM_E_NULL;
+    if (!p->a || !p->b || !p->c || !p->out) return SEGM_E_NULL;
+    if (p->dtype != SEGM_F32 && p->dtype != SEGM_F16 && p->dtype != SEGM_BF16) return SEGM_E_DTYPE;
+    const int n = p->dtype == SEGM_F32 ? 4 : 8;
+    if (p->count <= 0 || p->count % n != 0) return SEGM_E_SHAPE;
+    if (((uintptr_t)p->a | (uintptr_t)p->b | (uintptr_t)p->c | (uintptr_t)p->out) & 15) return SEGM_E_SHAPE;
+    Add3Dev P{p->a, p->b, p->c, p->out, p->count / n};
+    int64_t blocks = (P.npack + 2 * kBlock - 1) / (2 * kBlock);
+    blocks = blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks);
+    hipStream_t st = (hipStream_t)p->stream;
+    if (p->dtype == SEGM_F32) hipLaunchKernelGGL((add3_kernel<float>), dim3((unsigned)blocks), dim3(kBlock), 0, st, P);
+    else if (p->dtype == SEGM_F16) hipLaunchKernelGGL((add3_kernel<f16_t>), dim3((unsigned)blocks), dim3(kBlock), 0, st, P);
+    else hipLaunchKernelGGL((add3_kernel<bf16_t>), dim3((unsigned)blocks), dim3(kBlock), 0, st, P);
+    return (int)hipGetLastError();
+}
 
 extern "C" int segm_depth_to_space2(const segm_d2s_args* a) {
     if (!a) return SEGM_E_NULL;

@@ -28,6 +28,28 @@ from .selective_scan_interface import MambaInnerCore3, _inner
 _FUSED3 = os.environ.get("SEGM_MAMBA_FUSED3", "1") == "1"     # 0: one autograd node per direction (round 2)
 
 
+class _Sum3(torch.autograd.Function):
+    """out + out_b + out_s (reference mamba_simple.py:160 / :264) as one pass over the three tensors (segm_add3: fp32 sum, one
+    rounding) instead of two binary adds; every operand receives the incoming gradient unchanged."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        from . import ops_raw
+        return ops_raw.add3(L.get_lib(), a, b, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g, g
+
+
+def _sum3(a, b, c):
+    from . import ops_raw
+    from .selective_scan_interface import _ADD3
+    if _ADD3 and L.on_device(a) and ops_raw.add3_supported(a, b, c):
+        return _Sum3.apply(a, b, c)
+    return a + b + c
+
+
 class Mamba(nn.Module):
     def __init__(
         self,
@@ -157,7 +179,7 @@ class Mamba(nn.Module):
             out = self._direction(xz, "", L.TIME_FORWARD)
             out_b = self._direction(xz, "_b", L.TIME_REVERSED)
             out_s = self._direction(xz, "_s", L.TIME_INTERLEAVED, self.nslices)
-        return linear_cl(out + out_b + out_s, self.out_proj.weight, self.out_proj.bias)
+        return linear_cl(_sum3(out, out_b, out_s), self.out_proj.weight, self.out_proj.bias)
 
     # ---- autoregressive decoding (reference :196-201, :265-310, :356-436).  SegMamba never takes this path; with
     # `inference_params` the reference runs its uni-directional branch on the forward-direction parameters only. -------------

@@ -715,6 +715,28 @@ def _d2s_call(lib, blk, vol, direction):
 # ---------------------------------------------------------------------------------------------------------
 # channel-first <-> channel-last
 # ---------------------------------------------------------------------------------------------------------
+def add3_supported(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> bool:
+    n = 4 if a.dtype == torch.float32 else 8
+    return a.dtype in (torch.float32, torch.float16, torch.bfloat16) and a.shape == b.shape == c.shape and a.dtype == b.dtype == c.dtype \
+        and a.is_contiguous() and b.is_contiguous() and c.is_contiguous() and a.numel() > 0 and a.numel() % n == 0 \
+        and not ((a.data_ptr() | b.data_ptr() | c.data_ptr()) & 15)
+
+
+def add3(lib: L.SegmLib, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a + b + c in one pass (fp32 sum, one rounding); `out` may be `a`."""
+    if not add3_supported(a, b, c):
+        raise RuntimeError("add3: three dense 16-byte aligned tensors of one shape and dtype")
+    out = torch.empty_like(a) if out is None else out
+    if out.shape != a.shape or out.dtype != a.dtype or not out.is_contiguous() or out.data_ptr() & 15:
+        raise RuntimeError("add3: `out` must match the operands")
+    p = L.Add3Args()
+    p.count, p.dtype = a.numel(), L.dtype_code(a)
+    p.a, p.b, p.c, p.out = a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr()
+    p.stream = L.stream_handle(a)
+    lib.check(lib.dll.segm_add3(p), "add3")
+    return out
+
+
 def transpose_add(lib: L.SegmLib, x: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x (B, R, C) contiguous -> (B, C, R) contiguous (+ add, which already has the output layout)."""
     if x.dim() != 3 or not x.is_contiguous():

@@ -155,6 +155,7 @@ def _scan_constant_bc(u, delta, A, B, C, D, z, delta_bias, delta_softplus, retur
 
 
 _RECOMPUTE = os.environ.get("SEGM_RECOMPUTE", "0") == "1"     # reference trade: recompute conv output / delta in backward
+_ADD3 = os.environ.get("SEGM_ADD3", "1") == "1"               # three-way sums of the v3 block as one pass (segm_add3)
 _FUSED_CONV1D = os.environ.get("SEGM_SCAN_FUSED_CONV1D", "0") == "1"     # conv1d + SiLU inside the scan passes (opt-in, slower)
 _FUSED_DTPROJ = os.environ.get("SEGM_SCAN_FUSED_DTPROJ", "0") == "1"     # dt_proj inside the scan passes (opt-in)
 
@@ -427,10 +428,16 @@ class MambaInnerCore3(torch.autograd.Function):
                                time_order=order, nslices=ns, dx=dx))
             part.append((dx_proj_weight, ddelta_proj_weight))
         cres = ops_raw.conv1d_bwd_multi(lib, ccalls)
+        # the three dxz contributions: one pass a + b + c (segm_add3) instead of two in-place binary adds (SEGM_ADD3=0: those)
+        all_dxz = [d[16] for d in dirs]
+        use3 = _ADD3 and len(all_dxz) == 3 and ops_raw.add3_supported(*all_dxz)
+        if use3:
+            dxz_sum = ops_raw.add3(lib, *all_dxz, out=all_dxz[0])
         for i, ((conv_w, conv_b, x_dbl, xw, dtw, A, D, dbias, conv_out, R, N, order, ns, w32, cb32, rows_route, dxz, dx, dx_dbl), g) in enumerate(zip(dirs, gs)):
             _, dconv_w, dconv_b = cres[i]
             dx_proj_weight, ddelta_proj_weight = part[i]
-            dxz_sum = dxz if dxz_sum is None else dxz_sum.add_(dxz)
+            if not use3:
+                dxz_sum = dxz if dxz_sum is None else dxz_sum.add_(dxz)
             grads += [dconv_w.reshape(conv_w.shape).to(conv_w.dtype), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
                       dx_proj_weight.to(wdt[i][0]), ddelta_proj_weight.to(wdt[i][1]), g["dA"].to(A.dtype),
                       g["dD"].to(D.dtype) if D is not None else None,

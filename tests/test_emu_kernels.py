@@ -1937,3 +1937,19 @@ def test_conv3d_k3_dgrad_channel_last_emulated(emu):
     wt = torch.flip(w, (2, 3, 4)).transpose(0, 1).contiguous().bfloat16()
     dx = ops_raw.conv3d_k3_fwd_cl(emu, dy.permute(0, 2, 3, 4, 1).contiguous(), ops_raw.conv3d_cl_weight_image(emu, wt))
     assert (dx.permute(0, 4, 1, 2, 3).float() - x.grad).abs().max() <= 1e-2 * max(1.0, float(x.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_add3_emulated(emu, dtype):
+    """segm_add3: a + b + c in one pass (fp32 sum, one rounding), also in place on a; packet counts that are odd / below one
+    grid stride (the two-packets-in-flight loop)"""
+    g = torch.Generator().manual_seed(3)
+    for n in (8, 8 * 257, 8 * 4096 + 24):
+        a, b, c = (torch.randn(n, generator=g).to(dtype) for _ in range(3))
+        ref = (a.float() + b.float() + c.float()).to(dtype)
+        out = ops_raw.add3(emu, a, b, c)
+        assert torch.equal(out, ref)
+        a2 = a.clone()
+        assert ops_raw.add3(emu, a2, b, c, out=a2) is a2 and torch.equal(a2, ref)
+    with pytest.raises(RuntimeError):
+        ops_raw.add3(emu, a[:10], b[:10], c[:10])           # not whole 16-byte packets

@@ -936,3 +936,17 @@ def test_conv3d_k3_channel_last_forward_and_dgrad_at_the_benchmarked_shape(waves
     ops_raw.conv3d_k3_fwd_cl(hip, x2[..., :48], ops_raw.conv3d_cl_weight_image(hip, w), None, out=out[..., :48], accumulate=True, waves8=waves8)
     assert float((out[..., :48].permute(0, 4, 1, 2, 3).float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
     assert bool((out[..., 48:] == 0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_add3_on_the_gpu(dtype):
+    """segm_add3 at the size of a stage-0 dxz tensor (2 x 262144 x 192) and at a small odd packet count: == fp32 sum rounded once"""
+    from segmamba_amd import lib as L, ops_raw
+    hip = L.get_lib()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for shape in ((2, 262144, 192), (3, 8 * 37)):
+        a, b, c = (torch.randn(*shape, device="cuda", generator=g).to(dtype) for _ in range(3))
+        ref = (a.float() + b.float() + c.float()).to(dtype)
+        assert torch.equal(ops_raw.add3(hip, a, b, c), ref)
+        assert torch.equal(ops_raw.add3(hip, a, b, c, out=a), ref)
