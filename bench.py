@@ -694,37 +694,6 @@ def main():
     if distributed and state.exchange is not None and not dry:
         exposed_ms = state.exchange.exposed_ms() if state.exchange.record_exposed else None
         state.exchange.record_exposed = False
-        # the other form behind the timed region (captured bracket + one call).
-        # Round 6: on by default, and unable to split the ranks - every rank attempts the capture on its own (no
-        # collective inside), then ONE all-reduce (MIN) of a success flag decides for all of them whether the three extra steps run;
-        # only when the overlapped form ran the timed region without a fallback.  SEGM_BENCH_OTHER_FORM=0 skips it.
-        if state.graphed is None and not args.no_graph and os.environ.get("SEGM_BENCH_OTHER_FORM", "1") == "1" and \
-                state.exchange.fallback_reason is None:
-            from segmamba_amd.trainer import GraphedStep
-            err = None
-            try:
-                GraphedStep(state, *data.next())
-            except Exception as e:                          # noqa: BLE001
-                err = f"{type(e).__name__}: {str(e)[:160]}"
-                state.graphed = None
-                torch.cuda.synchronize()
-            okf = torch.tensor([0.0 if err else 1.0], device=device)
-            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-            if float(okf.item()) >= 1.0:
-                try:
-                    step()
-                    dist.barrier(); sync()
-                    t1 = time.perf_counter()
-                    for _ in range(3):
-                        step()
-                    dist.barrier(); sync()
-                    other_form = {"form": "hipGraph replay + one all-reduce behind it", "ms_per_step": round((time.perf_counter() - t1) / 3 * 1e3, 3)}
-                except Exception as e:                      # noqa: BLE001
-                    other_form = {"form": "hipGraph replay + one all-reduce behind it", "error": f"{type(e).__name__}: {str(e)[:160]}"}
-            else:
-                state.graphed = None
-                other_form = {"form": "hipGraph replay + one all-reduce behind it", "skipped": "the capture failed on at least one rank",
-                              "this_rank": err}
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
@@ -744,6 +713,7 @@ def main():
             except Exception as e:                          # noqa: BLE001 - the line survives a failed side measurement
                 allreduce_ms = f"{type(e).__name__}: {str(e)[:120]}"
 
+    out = None
     if rank == 0:
         _stamp(f"timed loop done: {elapsed / args.steps * 1e3:.2f} ms per step")
         vols = world * args.batch * args.steps
@@ -800,7 +770,7 @@ def main():
                     except Exception as e:                  # noqa: BLE001
                         out["config"]["launch_forms"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
                 _stamp("launch_forms done")
-                del state, data
+                state = data = None                           # (released, not deleted: the closing block below looks at `state`)
                 torch.cuda.empty_cache()
                 if not args.no_dropin:
                     try:
@@ -818,6 +788,7 @@ def main():
             _stamp("configs done")
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)
             _stamp("cpu_baseline done")
+    def emit(line):
         # ONE JSON line, and the LAST line of stdout: the vendor libraries print diagnostics through C stdio ("GridwiseOp: ..." from the
         # solvers MIOpen tries on the drop-in path), fully buffered when stdout is a pipe - flush them out first, and send whatever a
         # library prints at teardown to /dev/null
@@ -827,12 +798,64 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:                                   # noqa: BLE001
             pass
-        print(json.dumps(out), flush=True)
+        print(json.dumps(line), flush=True)
         try:
             devnull = os.open(os.devnull, os.O_WRONLY)
             os.dup2(devnull, 1)
         except OSError:
             pass
+
+    # N > 1 only, LAST, behind everything the line needs: the other launch form - captured bracket + one
+    # all-reduce behind it - for three steps, so that the line carries both forms.  It cannot cost the measurement: every rank
+    # attempts the capture on its own (no collective inside), ONE all-reduce (MIN) of a success flag decides for all of them whether
+    # the extra steps run, and a watchdog thread ends the job cleanly - rank 0 prints the finished line first - if this block does
+    # not come back within SEGM_BENCH_OTHER_FORM_TIMEOUT_S seconds (default 90).  SEGM_BENCH_OTHER_FORM=0 skips it.
+    if distributed and not dry and state is not None and state.exchange is not None and state.graphed is None and not args.no_graph \
+            and os.environ.get("SEGM_BENCH_OTHER_FORM", "1") == "1" and state.exchange.fallback_reason is None:
+        import threading
+        done = threading.Event()
+        limit = float(os.environ.get("SEGM_BENCH_OTHER_FORM_TIMEOUT_S", "90"))
+
+        def _watchdog():
+            if done.wait(limit):
+                return
+            if rank == 0:
+                out["config"]["ddp"]["other_form"] = {"form": "hipGraph replay + one all-reduce behind it",
+                                                      "skipped": f"did not finish within {limit:.0f} s; the line was printed by the watchdog"}
+                emit(out)
+            os._exit(0)
+        dist.barrier()                                       # rank 0 arrives behind its extras (inference, roofline): start the clocks together
+        threading.Thread(target=_watchdog, daemon=True).start()
+        other_form = {"form": "hipGraph replay + one all-reduce behind it"}
+        err = None
+        try:
+            from segmamba_amd.trainer import GraphedStep
+            GraphedStep(state, *data.next())
+        except Exception as e:                              # noqa: BLE001
+            err = f"{type(e).__name__}: {str(e)[:160]}"
+            state.graphed = None
+            torch.cuda.synchronize()
+        okf = torch.tensor([0.0 if err else 1.0], device=device)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if float(okf.item()) >= 1.0:
+            try:
+                step()
+                dist.barrier(); sync()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                dist.barrier(); sync()
+                other_form["ms_per_step"] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
+            except Exception as e:                          # noqa: BLE001
+                other_form["error"] = f"{type(e).__name__}: {str(e)[:160]}"
+        else:
+            state.graphed = None
+            other_form.update(skipped="the capture failed on at least one rank", this_rank=err)
+        done.set()
+        if rank == 0:
+            out["config"]["ddp"]["other_form"] = other_form
+    if rank == 0:
+        emit(out)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
