@@ -58,7 +58,12 @@ struct GemmDev {
 // TN
 // ------------------------------------------------------------------------------------------------------
 // stage rows [k0, k0 + 32) x columns [c0, c0 + cw) of a row-major matrix into lds[32][PITCH]; rows >= K and columns >= cols are zero
-template <typename T, int PITCH, int CB, bool ALIGNED>
+// MODE 1: cols % 8 == 0 and 16-byte aligned rows - every piece is whole.  MODE 2 (round 6): 16-byte aligned rows whose STRIDE covers
+// the columns rounded up to 8 (x_dbl / dx_dbl's padded layout: 36 of 40 columns) - the piece that straddles `cols` is read whole too:
+// what it brings beyond `cols` only reaches output rows / columns beyond m / n, which nobody reads; the matrix's LAST row takes the
+// masked element loads (its padding may lie outside the allocation when the operand is a column slice at the end of a buffer).
+// MODE 0: element loads.
+template <typename T, int PITCH, int CB, int MODE>
 __device__ __forceinline__ void tn_fetch(const T* base, int64_t sr, int64_t k0, int64_t K, int c0, int cols, int lane, wg_u32x4 (&r)[CB * 32 / 8 / 64]) {
     constexpr int PIECES = CB / 8;           // 16-byte pieces per row
     constexpr int PER = CB * 32 / 8 / 64;    // pieces per lane
@@ -70,7 +75,7 @@ __device__ __forceinline__ void tn_fetch(const T* base, int64_t sr, int64_t k0, 
         wg_u32x4 v = {0u, 0u, 0u, 0u};
         if (kk < K && col < cols) {
             const T* src = base + kk * sr + col;
-            if (ALIGNED) {                   // cols % 8 == 0 and 16-byte aligned rows: the whole piece is inside
+            if (MODE == 1 || (MODE == 2 && (kk + 1 < K || col + 8 <= cols))) {
                 v = *reinterpret_cast<const wg_u32x4*>(src);
             } else {
                 T e[8];
@@ -94,53 +99,56 @@ __device__ __forceinline__ void tn_park(T* lds, int lane, const wg_u32x4 (&r)[CB
     }
 }
 
-template <typename T, bool ALIGNED_A, bool ALIGNED_B>
+// Round 6: NB = columns of b per workgroup (48 or 96: half the accumulators and a smaller strip for the n <= 48 shapes - in_proj's
+// and the 1x1x1 layers' - so that more waves fit a SIMD) and TWO chunks of both operands in flight per wave (registers set 0 / 1,
+// the loop runs two chunks per trip): the kernel is a latency pipeline - a chunk's MFMAs are 200 cycles, its loads 2 000+ away.
+template <typename T, int NB, int MODE_A, int MODE_B>
 __global__ void __launch_bounds__(kGwWaves * 64) wgemm_tn_kernel(GemmDev P) {
     typedef typename Mfma16<T>::v8 frag8;
+    constexpr int NT_ = NB / 16, PB = NB == 48 ? 80 : NB + 16;    // 40 / 56 dwords: eight consecutive rows on 64 distinct banks (32 dwords would not be)
     __shared__ __attribute__((aligned(16))) T s_a[kGwWaves][32 * kTnPA];
-    __shared__ __attribute__((aligned(16))) T s_b[kGwWaves][32 * kTnPB];
+    __shared__ __attribute__((aligned(16))) T s_b[kGwWaves][32 * PB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, g = lane >> 4;
     const int kw = blockIdx.x * kGwWaves + wave;                 // this wave's share of k
-    const int m0 = blockIdx.y * kTnMB, n0 = blockIdx.z * kTnNB;
+    const int m0 = blockIdx.y * kTnMB, n0 = blockIdx.z * NB;
     if (kw >= P.kwaves) return;                                   // whole waves; no workgroup barrier in this kernel
-    const int mw = P.m - m0 < kTnMB ? P.m - m0 : kTnMB, nw = P.n - n0 < kTnNB ? P.n - n0 : kTnNB;
+    const int mw = P.m - m0 < kTnMB ? P.m - m0 : kTnMB, nw = P.n - n0 < NB ? P.n - n0 : NB;
     const int mt_n = (mw + 15) / 16, nt_n = (nw + 15) / 16;
     const T* A = reinterpret_cast<const T*>(P.a);
     const T* B = reinterpret_cast<const T*>(P.b);
     T* la = &s_a[wave][0];
     T* lb = &s_b[wave][0];
 
-    wg_f32x4 acc[kTnMT][kTnNT];
+    wg_f32x4 acc[kTnMT][NT_];
 #pragma unroll
     for (int mt = 0; mt < kTnMT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < kTnNT; ++nt) acc[mt][nt] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT_; ++nt) acc[mt][nt] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int64_t c_begin = (int64_t)kw * P.chunks_per_wave;
     const int64_t c_end = c_begin + P.chunks_per_wave < P.chunks ? c_begin + P.chunks_per_wave : P.chunks;
-    wg_u32x4 ra[kTnMB * 32 / 8 / 64], rb[kTnNB * 32 / 8 / 64];
-    if (c_begin < c_end) {
-        tn_fetch<T, kTnPA, kTnMB, ALIGNED_A>(A, P.a_sr, c_begin * 32, P.k, m0, P.m, lane, ra);
-        tn_fetch<T, kTnPB, kTnNB, ALIGNED_B>(B, P.b_sr, c_begin * 32, P.k, n0, P.n, lane, rb);
-    }
-    for (int64_t c = c_begin; c < c_end; ++c) {
-        SEGM_WAVE_LDS_SYNC();                                     // the previous chunk's gathers are done
-        tn_park<T, kTnPA, kTnMB>(la, lane, ra);
-        tn_park<T, kTnPB, kTnNB>(lb, lane, rb);
-        SEGM_WAVE_LDS_SYNC();
-        if (c + 1 < c_end) {                                      // in flight during this chunk's gathers and MFMAs
-            tn_fetch<T, kTnPA, kTnMB, ALIGNED_A>(A, P.a_sr, (c + 1) * 32, P.k, m0, P.m, lane, ra);
-            tn_fetch<T, kTnPB, kTnNB, ALIGNED_B>(B, P.b_sr, (c + 1) * 32, P.k, n0, P.n, lane, rb);
+    wg_u32x4 ra[2][kTnMB * 32 / 8 / 64], rb[2][NB * 32 / 8 / 64];
+    auto fetch = [&](int set, int64_t c) {
+        if (c < c_end) {
+            tn_fetch<T, kTnPA, kTnMB, MODE_A>(A, P.a_sr, c * 32, P.k, m0, P.m, lane, ra[set]);
+            tn_fetch<T, PB, NB, MODE_B>(B, P.b_sr, c * 32, P.k, n0, P.n, lane, rb[set]);
         }
+    };
+    auto chunk = [&](int set, int64_t c) {
+        SEGM_WAVE_LDS_SYNC();                                     // the previous chunk's gathers are done
+        tn_park<T, kTnPA, kTnMB>(la, lane, ra[set]);
+        tn_park<T, PB, NB>(lb, lane, rb[set]);
+        SEGM_WAVE_LDS_SYNC();
+        fetch(set, c + 2);                                        // in flight during this chunk's and the next chunk's gathers and MFMAs
         // fragment k slots 0 .. 3 = strip rows 4 g .., slots 4 .. 7 = rows 16 + 4 g .. (the same assignment in both operands)
-        frag8 bf[kTnNT];
+        frag8 bf[NT_];
 #pragma unroll
-        for (int nt = 0; nt < kTnNT; ++nt) {
+        for (int nt = 0; nt < NT_; ++nt) {
             if (nt < nt_n) {
-                const T* p0 = lb + (4 * g + (i16 >> 2)) * kTnPB + 16 * nt + 4 * (i16 & 3);
-                bf[nt] = tr16_fragment<frag8>(p0, p0 + 16 * kTnPB);
+                const T* p0 = lb + (4 * g + (i16 >> 2)) * PB + 16 * nt + 4 * (i16 & 3);
+                bf[nt] = tr16_fragment<frag8>(p0, p0 + 16 * PB);
             }
         }
 #pragma unroll
@@ -149,17 +157,23 @@ __global__ void __launch_bounds__(kGwWaves * 64) wgemm_tn_kernel(GemmDev P) {
                 const T* p0 = la + (4 * g + (i16 >> 2)) * kTnPA + 16 * mt + 4 * (i16 & 3);
                 const frag8 af = tr16_fragment<frag8>(p0, p0 + 16 * kTnPA);
 #pragma unroll
-                for (int nt = 0; nt < kTnNT; ++nt)
+                for (int nt = 0; nt < NT_; ++nt)
                     if (nt < nt_n) acc[mt][nt] = Mfma16<T>::run(af, bf[nt], acc[mt][nt]);
             }
         }
+    };
+    fetch(0, c_begin);
+    fetch(1, c_begin + 1);
+    for (int64_t c = c_begin; c < c_end; c += 2) {
+        chunk(0, c);
+        if (c + 1 < c_end) chunk(1, c + 1);
     }
     // partial [kw][m16][n16]: D[m = 16 mt + 4 g + r][n = 16 nt + i16]
     float* pp = P.part + (int64_t)kw * P.m16 * P.n16;
 #pragma unroll
     for (int mt = 0; mt < kTnMT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < kTnNT; ++nt)
+        for (int nt = 0; nt < NT_; ++nt)
             if (mt < mt_n && nt < nt_n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -291,7 +305,7 @@ static GemmPlan gemm_plan(int layout, int m, int n, int64_t k, int batch) {
         pl.n16 = 16 * (nt <= 1 ? 1 : (nt <= 3 ? 3 : 6));
     }
     pl.mb = layout == SEGM_WGEMM_TN ? (m + kTnMB - 1) / kTnMB : 1;
-    pl.nb = layout == SEGM_WGEMM_TN ? (n + kTnNB - 1) / kTnNB : 1;
+    pl.nb = layout == SEGM_WGEMM_TN ? (n <= 48 ? 1 : (n + kTnNB - 1) / kTnNB) : 1;
     pl.chunks = layout == SEGM_WGEMM_TN ? (k + 31) / 32 : (int64_t)batch * (k / 32);
     // ~2048 waves on the chip (8 per CU), at least 8 chunks each, and at most 32 MB of partials
     int64_t want = 2048 / ((int64_t)pl.mb * pl.nb);
@@ -348,17 +362,26 @@ extern "C" int segm_wgrad_gemm(const segm_wgrad_gemm_args* a) {
     const dim3 block(kGwWaves * 64);
     const unsigned gx = (unsigned)((pl.kwaves + kGwWaves - 1) / kGwWaves);
     if (a->layout == SEGM_WGEMM_TN) {
-        const bool al_a = a->a_stride_row % 8 == 0 && ((uintptr_t)a->a & 15) == 0 && a->m % 8 == 0;
-        const bool al_b = a->b_stride_row % 8 == 0 && ((uintptr_t)a->b & 15) == 0 && a->n % 8 == 0;
+        auto mode = [](const void* p, int64_t stride, int cols) {
+            if (stride % 8 != 0 || ((uintptr_t)p & 15) != 0) return 0;
+            if (cols % 8 == 0) return 1;
+            return (cols + 7) / 8 * 8 <= stride ? 2 : 0;
+        };
+        const int ma = mode(a->a, a->a_stride_row, a->m), mb_ = mode(a->b, a->b_stride_row, a->n);
         const dim3 grid(gx, pl.mb, pl.nb);
-#define SEGM_TN(TT)                                                                                             \
-        do {                                                                                                    \
-            if (al_a && al_b) hipLaunchKernelGGL((wgemm_tn_kernel<TT, true, true>), grid, block, 0, st, P);      \
-            else if (al_a) hipLaunchKernelGGL((wgemm_tn_kernel<TT, true, false>), grid, block, 0, st, P);        \
-            else if (al_b) hipLaunchKernelGGL((wgemm_tn_kernel<TT, false, true>), grid, block, 0, st, P);        \
-            else hipLaunchKernelGGL((wgemm_tn_kernel<TT, false, false>), grid, block, 0, st, P);                 \
+#define SEGM_TN3(TT, NB_, MA_)                                                                                   \
+        do {                                                                                                     \
+            if (mb_ == 1) hipLaunchKernelGGL((wgemm_tn_kernel<TT, NB_, MA_, 1>), grid, block, 0, st, P);          \
+            else if (mb_ == 2) hipLaunchKernelGGL((wgemm_tn_kernel<TT, NB_, MA_, 2>), grid, block, 0, st, P);     \
+            else hipLaunchKernelGGL((wgemm_tn_kernel<TT, NB_, MA_, 0>), grid, block, 0, st, P);                   \
         } while (0)
-        if (f16) SEGM_TN(f16_t); else SEGM_TN(bf16_t);
+#define SEGM_TN(TT, NB_)                                                                                         \
+        do {                                                                                                     \
+            if (ma == 1) SEGM_TN3(TT, NB_, 1); else if (ma == 2) SEGM_TN3(TT, NB_, 2); else SEGM_TN3(TT, NB_, 0);  \
+        } while (0)
+        if (a->n <= 48) { if (f16) SEGM_TN(f16_t, 48); else SEGM_TN(bf16_t, 48); }
+        else { if (f16) SEGM_TN(f16_t, 96); else SEGM_TN(bf16_t, 96); }
+#undef SEGM_TN3
 #undef SEGM_TN
     } else {
         const int mc = pl.m16 / 16, nc = pl.n16 / 16;          // 1, 3 or 6 (gemm_plan)

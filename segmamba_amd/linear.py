@@ -33,10 +33,15 @@ _PW_HIP = os.environ.get("SEGM_POINTWISE_HIP", "1") == "1"
 _PW_MIN = 32768       # voxels per channel below which the BLAS call stays
 # The weight gradients of the 1x1x1 convolutions on channel-first volumes through csrc/wgrad_gemm.hip (layout NT: 135 - 270 us
 # against 205 - 310 us for slab-batched BLAS GEMMs + a sum at 128^3, profiles/r02_wgrad_gemm_time.log); SEGM_WGRAD_GEMM_HIP=0
-# restores those.  The token-major layout (TN: the Mamba projections) stays on the BLAS slabs, which stream at 3 - 3.9 TB/s
-# where the library's LDS-gather kernel reaches 1.1 - 2.6; SEGM_WGRAD_GEMM_TN=1 switches it on (measurements, tests).
+# restores those.  The token-major layout (TN: the Mamba projections): rounds 2 - 5 left it on the BLAS slabs (3 - 3.9 TB/s against
+# 1.1 - 2.6 for the library's kernel); round 6's kernel (two chunks in flight per wave, 48-column blocks for n <= 48, whole 16-byte
+# pieces on x_dbl's padded rows) is level or ahead on every shape the step has from 4096 tokens up - in_proj s0 59 vs 66 us, the
+# stage-1 shapes 22 - 46 vs 34 - 58 us, the stage-2 shapes (ONE vendor GEMM of 52 us each before: no split over K) 21 - 35 us - and
+# returns fp32 sums where the short-K vendor path rounded to 16 bits (profiles/r06_wgemm_tn_v3.log, _v4.log): default on, step
+# -0.17 ms (r06_wgemm_tn_step2.log); SEGM_WGRAD_GEMM_TN=0 restores the vendor route.
 _WG_HIP = os.environ.get("SEGM_WGRAD_GEMM_HIP", "1") == "1"
-_WG_TN = os.environ.get("SEGM_WGRAD_GEMM_TN", "0") == "1"
+_WG_TN = os.environ.get("SEGM_WGRAD_GEMM_TN", "1") == "1"      # round 6: default on (two chunks in flight, 48-column blocks, padded rows)
+_TN_MIN_K = int(os.environ.get("SEGM_WGRAD_GEMM_TN_MIN_K", "4096"))   # the TN kernel splits K over waves: also ahead of ONE GEMM on short K
 
 
 def _on_device(t: torch.Tensor) -> bool:
@@ -89,7 +94,7 @@ def tn_matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         from . import lib as L, ops_raw
         if ops_raw.skinny_tn_supported(a, b):               # a tall-and-wide, b tall-and-skinny (dt_proj's weight gradient)
             return ops_raw.skinny_tn(L.get_lib(), a, b)
-    if _WG_HIP and _WG_TN and K >= _MIN_K and _on_device(a):
+    if _WG_HIP and _WG_TN and K >= _TN_MIN_K and _on_device(a):
         from . import lib as L, ops_raw
         if ops_raw.wgrad_gemm_tn_supported(a, b):
             return ops_raw.wgrad_gemm(L.get_lib(), a, b, ops_raw.WGEMM_TN)

@@ -1276,6 +1276,9 @@ def test_stem_conv_wgrad_emulated(emu, B, Cin, Cout, D, H, W, dtype):
     (640, 96, 3, torch.float16, None, 35),              # dt_proj: b = the first 3 columns of the 35-column x_dbl
     (2048, 72, 200, torch.bfloat16, 80, 208),           # padded row strides, column blocks of b (96 + 96 + 8), m tail tile
     (96, 8, 8, torch.bfloat16, None, None),             # fewer chunks than waves
+    (1000, 36, 96, torch.bfloat16, 40, None),           # round 6: x_dbl's padded layout (36 of 40 columns): whole 16-byte pieces that
+    (999, 96, 38, torch.float16, None, 40),             # straddle `cols`, masked element loads in the matrix's last row; odd chunk counts
+    (2080, 192, 48, torch.bfloat16, None, None),        # 65 chunks: the two-chunks-per-trip loop ends on its first half
 ])
 def test_wgrad_gemm_tn_emulated(emu, K, M, N, dtype, lda, ldb):
     """segm_wgrad_gemm, layout TN (a^T b for token-major operands: the Mamba projections' weight gradients): LDS-staged 32-row

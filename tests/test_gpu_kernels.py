@@ -771,7 +771,8 @@ def test_stem_conv_wgrad_matches_autograd(B, Cin, Cout, size, dtype):
     assert torch.equal(dw, ops_raw.stem_conv_wgrad(hip, x4, dy, Cin))
 
 
-@pytest.mark.parametrize("K,M,N,lda,ldb", [(524288, 192, 48, 192, 48), (524288, 35, 96, 35, 96), (65536, 192, 6, 192, 38), (70001, 100, 130, 104, 136)])
+@pytest.mark.parametrize("K,M,N,lda,ldb", [(524288, 192, 48, 192, 48), (524288, 35, 96, 35, 96), (65536, 192, 6, 192, 38), (70001, 100, 130, 104, 136),
+                                           (524288, 36, 96, 40, 96), (65535, 96, 38, 96, 40)])
 def test_wgrad_gemm_tn_matches_fp32_product(K, M, N, lda, ldb):
     """segm_wgrad_gemm (TN) at the stage-0 / stage-1 token counts against the fp64-accumulated product of the same bf16 operands
     (K up to 524 288 terms per entry: 1e-3 of the largest entry), bitwise repeatable"""

@@ -35,9 +35,11 @@ def blas(fn, *args):
 
 print("TN: a (K, M)^T b (K, N)")
 for K, M, N, lda, ldb, what in [(524288, 192, 48, 192, 48, "in_proj s0"), (524288, 48, 96, 48, 96, "out_proj s0"),
-                                (524288, 35, 96, 35, 96, "x_proj s0"), (524288, 96, 3, 96, 35, "dt_proj s0"),
+                                (524288, 35, 96, 35, 96, "x_proj s0"), (524288, 36, 96, 40, 96, "x_proj s0 (40-col)"), (524288, 96, 3, 96, 35, "dt_proj s0"),
                                 (65536, 384, 96, 384, 96, "in_proj s1"), (65536, 96, 192, 96, 192, "out_proj s1"),
-                                (65536, 38, 192, 38, 192, "x_proj s1"), (65536, 192, 6, 192, 38, "dt_proj s1")]:
+                                (65536, 38, 192, 38, 192, "x_proj s1"), (65536, 40, 192, 40, 192, "x_proj s1 (40-col)"), (65536, 192, 6, 192, 38, "dt_proj s1"),
+                                (8192, 768, 192, 768, 192, "in_proj s2"), (8192, 192, 384, 192, 384, "out_proj s2"), (8192, 44, 384, 48, 384, "x_proj s2"),
+                                (1024, 1536, 384, 1536, 384, "in_proj s3"), (1024, 384, 768, 384, 768, "out_proj s3")]:
     a = torch.randn(K, lda, device=dev).bfloat16()[:, :M]
     b = torch.randn(K, ldb, device=dev).bfloat16()[:, :N]
     t1 = timeit(lambda: LN.tn_matmul(a, b))
