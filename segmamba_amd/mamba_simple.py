@@ -42,6 +42,26 @@ class _Sum3(torch.autograd.Function):
         return g, g, g
 
 
+class _NegExp3(torch.autograd.Function):
+    """A = -exp(A_log) for the three directions of a layer (reference mamba_simple.py:209 / :232 / :248) as two multi-tensor
+    launches, and its backward dA_log = dA * A as one - ATen's per-tensor exp / neg and their autograd nodes were twelve launches
+    per layer and step (96 of the step's ~190 parameter-sized element-wise launches).  Same values: (-g) * exp(A_log) == g * A."""
+
+    @staticmethod
+    def forward(ctx, a_log, b_log, s_log):
+        outs = torch._foreach_neg(torch._foreach_exp([a_log.float(), b_log.float(), s_log.float()]))
+        ctx.save_for_backward(*outs)
+        ctx.dtypes = (a_log.dtype, b_log.dtype, s_log.dtype)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        outs = ctx.saved_tensors
+        if any(g is None for g in gs):
+            return tuple(None if g is None else (g * o).to(dt) for g, o, dt in zip(gs, outs, ctx.dtypes))
+        return tuple(r.to(dt) for r, dt in zip(torch._foreach_mul(list(gs), list(outs)), ctx.dtypes))
+
+
 def _sum3(a, b, c):
     from . import ops_raw
     from .selective_scan_interface import _ADD3
@@ -168,11 +188,11 @@ class Mamba(nn.Module):
         if _FUSED3 and L.on_device(xz):
             # the three directions as one autograd node: their scans share one grid (selective_scan_interface.MambaInnerCore3)
             params = []
-            for sfx in ("", "_b", "_s"):
+            As = _NegExp3.apply(self.A_log, self.A_b_log, self.A_s_log)
+            for sfx, A in zip(("", "_b", "_s"), As):
                 conv, dt_proj = getattr(self, "conv1d" + sfx), getattr(self, "dt_proj" + sfx)
                 params += [conv.weight, conv.bias, getattr(self, "x_proj" + sfx).weight, dt_proj.weight,
-                           -torch.exp(getattr(self, "A" + sfx + "_log").float()), getattr(self, "D" + sfx).float(),
-                           dt_proj.bias.float()]
+                           A, getattr(self, "D" + sfx).float(), dt_proj.bias.float()]
             train = torch.is_grad_enabled() and (xz.requires_grad or any(p.requires_grad for p in params))
             out, out_b, out_s = MambaInnerCore3.apply(xz, self.nslices, train, *params)
         else:
