@@ -100,6 +100,11 @@ def tn_matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
             return ops_raw.wgrad_gemm(L.get_lib(), a, b, ops_raw.WGEMM_TN)
     s = _split(K) if (_on_device(a) or _FORCE_SPLIT) else 1
     if s == 1:
+        if a.is_cuda:                                      # fp32 out of the GEMM itself: no cast launch, no 16-bit rounding of the sums
+            try:
+                return torch.mm(a.t(), b, out_dtype=torch.float32)
+            except (TypeError, RuntimeError, NotImplementedError):
+                pass
         return (a.t() @ b).float()
     part = torch.bmm(a.unflatten(0, (s, K // s)).transpose(1, 2), b.unflatten(0, (s, K // s)))      # (s, M, N)
     return part.sum(0, dtype=torch.float32)
