@@ -568,7 +568,8 @@ int segm_selective_state_update(const segm_state_update_args* args);
  * out_proj - and their data gradients (reference mamba_simple.py:204-208, 264; selective_scan_interface.py:185-205,
  * 247-275), which the reference hands to cuBLAS.  x (rows, k) and y (rows, n) with element row strides (views into wider
  * tensors are fine), w (n, k) contiguous - the nn.Linear layout - all of one 16-bit dtype; bias (n) fp32 or NULL.
- * k a multiple of 8, at most 192; n a multiple of 4; x rows 16-byte aligned, y rows 8-byte aligned.
+ * k a multiple of 8, at most 2048 (up to 192: W stationary in registers; beyond, round 6: W streamed from L2 as well - the
+ * projections of stages 2 / 3); n a multiple of 4; x rows 16-byte aligned, y rows 8-byte aligned.
  * accumulate != 0: y += x W^T (+ bias), e.g. `torch.addmm(dconv, dx_dbl, x_proj_weight)` of the reference's backward
  * (selective_scan_interface.py:276).
  * ------------------------------------------------------------------------------------------------ */

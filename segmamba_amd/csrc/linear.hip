@@ -181,6 +181,107 @@ __global__ void __launch_bounds__(kLinWaves * 64) linear_rows_kernel(LinDev P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Round 6: the same product for K > 192 (the projections of stages 2 / 3: d_inner = 384 / 768, a few thousand rows).  W no longer
+// fits a wave's registers; both operands are streamed - W is a few hundred KB and stays in L2 - as 16-byte fragments straight from
+// memory, 32 rows x 96 columns per wave, four k chunks in flight.  Measured (profiles/r06_linear_small_gpu.log, GPU durations): 6 - 25 us
+// on the stage-2 / 3 shapes where the vendor GEMM takes 5.6 - 12.7 us - plain NN products of this size are the vendor library's home
+// ground; the host routing therefore keeps them there (linear._ROWS_MIN), and this kernel only widens what the entry point accepts.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kLkNT = 6, kLkMT = 2;
+template <typename T, bool ACCUM>
+__global__ void __launch_bounds__(kLinWaves * 64) linear_rows_k_kernel(LinDev P) {
+    typedef typename Mfma16<T>::v8 frag8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.y * kLkNT * 16;
+    const int64_t m0 = ((int64_t)blockIdx.x * kLinWaves + wave) * (kLkMT * 16);
+    if (m0 >= P.rows) return;
+    const T* W = reinterpret_cast<const T*>(P.w);
+    const T* X = reinterpret_cast<const T*>(P.x);
+    const lin_u32x4 zero = {0u, 0u, 0u, 0u};
+    // fixed per lane: the W rows (output columns) and x rows of its fragments
+    int64_t wrow[kLkNT], xrow[kLkMT];
+    bool wlive[kLkNT];
+#pragma unroll
+    for (int t = 0; t < kLkNT; ++t) { const int n = n0 + 16 * t + i16; wlive[t] = n < P.n; wrow[t] = (int64_t)(wlive[t] ? n : 0) * P.k; }
+#pragma unroll
+    for (int mt = 0; mt < kLkMT; ++mt) { int64_t m = m0 + 16 * mt + i16; m = m < P.rows ? m : P.rows - 1; xrow[mt] = m * P.ldx; }
+    lin_f32x4 acc[kLkMT][kLkNT];
+#pragma unroll
+    for (int mt = 0; mt < kLkMT; ++mt)
+#pragma unroll
+        for (int t = 0; t < kLkNT; ++t) {
+            const int nb = n0 + 16 * t + 4 * g;
+            acc[mt][t] = (P.bias && nb < P.n) ? *reinterpret_cast<const lin_f32x4*>(P.bias + nb) : lin_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    const int chunks = (P.k + 31) / 32;
+    // FOUR chunks in flight: the operands sit in L2 (~1 us away) and a chunk's MFMAs are ~200 cycles - with one chunk of prefetch
+    // the wave's time was chunks x latency (24 chunks at K = 768: no faster than the vendor call)
+    constexpr int DEPTH = 4;
+    lin_u32x4 wf[DEPTH][kLkNT], xf[DEPTH][kLkMT];
+    auto fetch = [&](int buf, int c) {
+        const int k = 32 * c + 8 * g;
+        const bool kin = c < chunks && k < P.k;
+        const int kk = kin ? k : 0;
+#pragma unroll
+        for (int t = 0; t < kLkNT; ++t) wf[buf][t] = (kin && wlive[t]) ? *reinterpret_cast<const lin_u32x4*>(W + wrow[t] + kk) : zero;
+#pragma unroll
+        for (int mt = 0; mt < kLkMT; ++mt) xf[buf][mt] = kin ? *reinterpret_cast<const lin_u32x4*>(X + xrow[mt] + kk) : zero;
+    };
+    auto consume = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < kLkNT; ++t)
+#pragma unroll
+            for (int mt = 0; mt < kLkMT; ++mt)
+                acc[mt][t] = Mfma16<T>::run(__builtin_bit_cast(frag8, wf[buf][t]), __builtin_bit_cast(frag8, xf[buf][mt]), acc[mt][t]);
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH - 1; ++i) fetch(i, i);
+    for (int c = 0; c < chunks; c += DEPTH) {                    // DEPTH chunks per trip: every register set addressed statically
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            fetch((i + DEPTH - 1) % DEPTH, c + i + DEPTH - 1);
+            if (c + i < chunks) consume(i);
+            SEGM_SCHED_FENCE();
+        }
+    }
+    // D = W x^T: a lane holds four consecutive output columns of one row
+#pragma unroll
+    for (int mt = 0; mt < kLkMT; ++mt) {
+        const int64_t m = m0 + 16 * mt + i16;
+        if (m >= P.rows) continue;
+        T* yrow = reinterpret_cast<T*>(P.y) + m * P.ldy + n0 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < kLkNT; ++t) {
+            if (n0 + 16 * t + 4 * g >= P.n) continue;
+            lin_f32x4 a = acc[mt][t];
+            if constexpr (ACCUM) {
+                const lin_u32x2 old = *reinterpret_cast<const lin_u32x2*>(yrow + 16 * t);
+                T o[4];
+                memcpy(o, &old, 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] += to_f32(o[q]);
+            }
+            lin_u32x2 pk;
+            pk[0] = pack2<T>(a[0], a[1]);
+            pk[1] = pack2<T>(a[2], a[3]);
+            *reinterpret_cast<lin_u32x2*>(yrow + 16 * t) = pk;
+        }
+    }
+}
+
+template <typename T>
+static int launch_linear_k(const LinDev& P, hipStream_t st) {
+    const int64_t gx = (P.rows + kLinWaves * kLkMT * 16 - 1) / (kLinWaves * kLkMT * 16);
+    if (gx >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;
+    const dim3 grid((unsigned)gx, (unsigned)((P.n + kLkNT * 16 - 1) / (kLkNT * 16)));
+    if (P.accumulate) hipLaunchKernelGGL((linear_rows_k_kernel<T, true>), grid, dim3(kLinWaves * 64), 0, st, P);
+    else hipLaunchKernelGGL((linear_rows_k_kernel<T, false>), grid, dim3(kLinWaves * 64), 0, st, P);
+    return (int)hipGetLastError();
+}
+
 template <typename T>
 static int launch_linear(const LinDev& P, hipStream_t st) {
     const int kc = (P.k + 31) / 32;
@@ -218,7 +319,7 @@ using namespace segm;
 extern "C" int segm_linear_rows(const segm_linear_args* a) {
     if (!a) return SEGM_E_NULL;
     if (a->rows <= 0 || a->k <= 0 || a->n <= 0) return SEGM_E_SHAPE;
-    if (a->k % 8 != 0 || a->k > 192 || a->n % 4 != 0) return SEGM_E_SHAPE;
+    if (a->k % 8 != 0 || a->k > 2048 || a->n % 4 != 0) return SEGM_E_SHAPE;
     if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
     if (!a->x || !a->w || !a->y) return SEGM_E_NULL;
     if (a->x_stride_row % 8 != 0 || a->x_stride_row < a->k || a->y_stride_row % 4 != 0 || a->y_stride_row < a->n) return SEGM_E_SHAPE;
@@ -231,5 +332,6 @@ extern "C" int segm_linear_rows(const segm_linear_args* a) {
     P.rows = a->rows; P.k = a->k; P.n = a->n;
     P.accumulate = a->accumulate != 0;
     hipStream_t st = (hipStream_t)a->stream;
+    if (a->k > 192) return a->dtype == SEGM_F16 ? launch_linear_k<f16_t>(P, st) : launch_linear_k<bf16_t>(P, st);
     return a->dtype == SEGM_F16 ? launch_linear<f16_t>(P, st) : launch_linear<bf16_t>(P, st);
 }

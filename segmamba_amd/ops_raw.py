@@ -935,7 +935,7 @@ def linear_rows_supported(x2: torch.Tensor, w: torch.Tensor, n_out: Optional[int
     if x2.dim() != 2 or w.dim() != 2 or x2.dtype not in (torch.bfloat16, torch.float16) or w.dtype != x2.dtype:
         return False
     K, N = x2.shape[1], w.shape[0]
-    return w.shape[1] == K and K % 8 == 0 and K <= 192 and N % 4 == 0 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and \
+    return w.shape[1] == K and K % 8 == 0 and K <= 2048 and N % 4 == 0 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and \
         x2.data_ptr() % 16 == 0 and x2.shape[0] > 0
 
 
@@ -944,7 +944,7 @@ def linear_rows(lib: L.SegmLib, x2: torch.Tensor, w: torch.Tensor, bias: Optiona
     """y (rows, N) = x2 (rows, K) @ w (N, K)^T + bias; `out` may be a column slice of a wider row-major tensor;
     `accumulate` adds to what `out` holds."""
     if not linear_rows_supported(x2, w):
-        raise RuntimeError("linear_rows: x (rows, K <= 192, K % 8 == 0) with unit column stride and 16-byte rows, w (N % 4 == 0, K), bf16 / fp16")
+        raise RuntimeError("linear_rows: x (rows, K <= 2048, K % 8 == 0) with unit column stride and 16-byte rows, w (N % 4 == 0, K), bf16 / fp16")
     M, K = x2.shape
     N = w.shape[0]
     w = w.contiguous()
