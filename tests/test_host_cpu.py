@@ -272,8 +272,8 @@ def test_argument_errors_of_the_newer_entry_points_without_gpu(built_lib):
     assert d.segm_selective_state_update(t) == -4
 
     g = lib.LinearArgs()
-    g.rows, g.k, g.n, g.dtype = 64, 200, 48, lib.SEGM_BF16
-    assert d.segm_linear_rows(g) == -2                     # k <= 192
+    g.rows, g.k, g.n, g.dtype = 64, 2056, 48, lib.SEGM_BF16
+    assert d.segm_linear_rows(g) == -2                     # k <= 2048 (round 6; 192 before)
     g.k, g.n = 48, 50
     assert d.segm_linear_rows(g) == -2                     # n % 4
     g.n, g.dtype = 48, lib.SEGM_F32
