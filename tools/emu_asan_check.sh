@@ -76,5 +76,20 @@ xq = torch.full((2, 3, 5 * 6 * 8 + 24), float("nan"), dtype=torch.bfloat16)[:, :
 xq.copy_(torch.randn(2, 3, 5, 6, 8, generator=g))
 yq, mq, rq = ops_raw.instnorm_fwd(emu, xq, None, "leaky_relu"); ops_raw.instnorm_bwd(emu, xq, xq, mq, rq, None, "leaky_relu")
 print("instnorm on padded instances ok", flush=True)
+# round 6
+xc = torch.zeros(1, 2, 2, 40, 56, dtype=torch.bfloat16)[:, :, :, :32, :48]                                       # padded voxel / row strides
+xc.copy_(torch.randn(1, 2, 2, 32, 48, generator=g)); wc = (0.1 * torch.randn(48, 48, 3, 3, 3, generator=g)).bfloat16()
+for w8 in (False, True):
+    yc = ops_raw.conv3d_k3_fwd_cl(emu, xc, ops_raw.conv3d_cl_weight_image(emu, wc), torch.randn(48), waves8=w8)
+    ops_raw.conv3d_k3_fwd_cl(emu, xc, ops_raw.conv3d_cl_weight_image(emu, wc), None, out=yc, accumulate=True, waves8=w8)
+print("channel-last 3^3 forward ok", flush=True)
+a3 = [torch.randn(8 * 515, generator=g).bfloat16() for _ in range(3)]
+ops_raw.add3(emu, *a3, out=a3[0]); print("add3 ok", flush=True)
+ak = torch.randn(70, 400, generator=g).bfloat16()[:, 8:392]; wk = torch.randn(44, 384, generator=g).bfloat16()
+yk = torch.zeros(70, 48, dtype=torch.bfloat16)[:, :44]
+ops_raw.linear_rows(emu, ak, wk, torch.randn(44), out=yk); ops_raw.linear_rows(emu, ak, wk, None, out=yk, accumulate=True)
+print("linear_rows K > 192 ok", flush=True)
+ta = torch.randn(999, 40, generator=g).bfloat16()[:, :36]; tb = torch.randn(999, 48, generator=g).bfloat16()
+ops_raw.wgrad_gemm(emu, ta, tb, ops_raw.WGEMM_TN); print("wgrad_gemm TN on padded rows / 48-column blocks ok", flush=True)
 print("AddressSanitizer run finished without reports")
 PY

@@ -21,7 +21,7 @@ wait
 $CLANG -shared -pthread -fsanitize=thread -shared-libsan $OBJS -o $OUT/libsegmamba_emu_tsan.so
 LD_PRELOAD=$RT TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=7" python - 2> $OUT/tsan.log <<'PY'
 import sys; sys.path.insert(0, ".")
-import torch
+import torch; torch.set_num_threads(1)          # ATen's OpenMP workers are not instrumented: their copies would be reported
 from segmamba_amd import lib as L, ops_raw
 from tests import helpers as H
 emu = L.SegmLib("build/emu_tsan/libsegmamba_emu_tsan.so")
@@ -59,6 +59,15 @@ ops_raw.stem_conv_fwd(emu, x3, (0.1 * torch.randn(48, 4, 3, 3, 3, generator=g)).
 ops_raw.stem_conv_wgrad(emu, ops_raw.stem_channel_last4(x3), torch.randn(1, 48, 2, 8, 32, generator=g).bfloat16(), 4, 3)
 ops_raw.wgrad_gemm(emu, torch.randn(2000, 72, generator=g).bfloat16(), torch.randn(2000, 200, generator=g).bfloat16(), ops_raw.WGEMM_TN)
 ops_raw.wgrad_gemm(emu, torch.randn(2, 48, 512, generator=g).bfloat16(), torch.randn(2, 20, 512, generator=g).bfloat16(), ops_raw.WGEMM_NT)
+# round 6: the channel-last 3^3 forward (weight rows and the x ring are shared by the waves of a workgroup), add3, the
+# streamed-W linear_rows, wgemm_tn on padded rows with 48-column blocks
+xc = torch.randn(1, 2, 3, 32, 48, generator=g).bfloat16(); wc = (0.1 * torch.randn(48, 48, 3, 3, 3, generator=g)).bfloat16()
+for w8 in (False, True):
+    ops_raw.conv3d_k3_fwd_cl(emu, xc, ops_raw.conv3d_cl_weight_image(emu, wc), torch.randn(48), waves8=w8)
+a3 = [torch.randn(8 * 515, generator=g).bfloat16() for _ in range(3)]
+ops_raw.add3(emu, *a3)
+ops_raw.linear_rows(emu, torch.randn(70, 384, generator=g).bfloat16(), torch.randn(44, 384, generator=g).bfloat16(), torch.randn(44))
+ops_raw.wgrad_gemm(emu, torch.randn(999, 40, generator=g).bfloat16()[:, :36], torch.randn(999, 48, generator=g).bfloat16(), ops_raw.WGEMM_TN)
 PY
 N=$(grep -c "WARNING: ThreadSanitizer" $OUT/tsan.log || true)
 echo "ThreadSanitizer reports: $N"
