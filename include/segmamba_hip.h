@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SEGM_ABI_VERSION 9
+#define SEGM_ABI_VERSION 10
 
 enum segm_dtype { SEGM_F32 = 0, SEGM_F16 = 1, SEGM_BF16 = 2 };
 enum segm_time_order { SEGM_TIME_FORWARD = 0, SEGM_TIME_REVERSED = 1, SEGM_TIME_INTERLEAVED = 2 };
@@ -328,6 +328,41 @@ typedef struct segm_conv3d_cl_args {
 
 int segm_conv3d_k3_fwd_cl(const segm_conv3d_cl_args* args);
 int segm_conv3d_k3_cl_pack_index(int32_t* out, int64_t n);
+
+/* ------------------------------------------------------------------------------------------------
+ * ABI 10: 3x3x3 stride-1 pad-1 convolution of WIDE layers on SMALL volumes (csrc/conv3d_cube.hip): NCDHW, cin % 32 == 0,
+ * cout a multiple of 64 or 96, depth / height / width multiples of 8 - the 16^3 / 8^3 levels of SegMamba's encoder and decoder (192 ... 768
+ * channels; reference model_segmamba/segmamba.py:91-132, monai/networks/blocks/dynunet_block.py:44-111, unetr_block.py:82-84;
+ * torch.nn.Conv3d -> cuDNN there).  A workgroup owns 8 x 8 x 8 voxels x 64 / 96 / 128 output channels, stages the halo cube of
+ * 32 input channels per round in LDS and runs all 27 taps from it; the contraction is split over workgroups and a second launch
+ * adds the fp32 partial sums in a fixed order (+ bias, + the existing y with SEGM_CONV_CUBE_ACCUMULATE) and rounds once.
+ *
+ * x: (batch, cin, D, H, W), y: (batch, cout, D, H, W), element strides for b / c / z / y (x contiguous), every stride a multiple
+ * of 8, 16-byte aligned bases.  w_image: cout * cin * 27 elements of x's dtype arranged by segm_conv3d_k3_cube_pack_index:
+ * out[i] = flat index into the (cout_w, cin_w, 3, 3, 3) weight; flipped = 1 gives the image of the DATA GRADIENT (a convolution
+ * of dy with cout = cin_w, cin = cout_w and mirrored taps) - the same launch computes it.
+ * segm_conv3d_k3_cube_plan: the column tiles per wave (nt: 2 / 3 / 4 = 64 / 96 / 128 channels per workgroup) and the number of
+ * splits the launch will use (values > 0 on entry are kept when valid), and the fp32 elements the workspace must hold.
+ * ------------------------------------------------------------------------------------------------ */
+enum segm_conv_cube_flags { SEGM_CONV_CUBE_ACCUMULATE = 1 };
+
+typedef struct segm_conv3d_cube_args {
+    int32_t batch, cin, cout, depth, height, width;
+    int32_t dtype, flags;
+    int32_t nt, splits;       /* 0 = the plan's choice */
+    const void* x;   int64_t x_stride_b, x_stride_c, x_stride_z, x_stride_y;
+    void* y;         int64_t y_stride_b, y_stride_c, y_stride_z, y_stride_y;
+    const void* w_image;
+    const float* bias;        /* (cout) fp32 or NULL */
+    void* workspace;          /* fp32, segm_conv3d_k3_cube_plan's workspace_elems */
+    int64_t workspace_elems;
+    void* stream;
+} segm_conv3d_cube_args;
+
+int segm_conv3d_k3_cube_fwd(const segm_conv3d_cube_args* args);
+int segm_conv3d_k3_cube_plan(int32_t batch, int32_t cin, int32_t cout, int32_t depth, int32_t height, int32_t width,
+                             int32_t* nt, int32_t* splits, int64_t* workspace_elems);
+int segm_conv3d_k3_cube_pack_index(int32_t* out, int64_t n, int32_t cout_w, int32_t cin_w, int32_t flipped);
 
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d (+ residual) (+ activation), forward and backward.

@@ -1,0 +1,344 @@
+// 3x3x3 stride-1 pad-1 convolution of WIDE layers on SMALL volumes (C ABI: segm_conv3d_k3_cube_fwd): NCDHW 16-bit activations,
+// Cin % 32 == 0, Cout a multiple of 64 or 96, depth / height / width multiples of 8 - the 16^3 and 8^3 levels of SegMamba's encoder / decoder
+// (192 ... 768 channels; reference model_segmamba/segmamba.py:91-132 GSC blocks, monai/networks/blocks/dynunet_block.py:44-111
+// UnetResBlock, unetr_block.py:82-84 decoder blocks; torch.nn.Conv3d -> cuDNN there).  Forward and, with the image of
+// flip(W)^T, data gradient.
+//
+// Why another kernel: csrc/conv3d_fwd.hip walks ROWS of 32 / 64 voxels with one 48-channel input block per launch - built for the
+// 128-wide rows where 60 % of the convolution flops are.  At 16^3 a 384 -> 384 layer is 8 launches that each re-read and re-write
+// the whole output for 1/8 of the contraction, on rows half as wide as the kernel's tile: 120 - 300 TF/s; the 8^3 layers went to
+// the vendor's im2col + GEMM (60 - 340 TF/s, one GEMM per sample).  Together 5.4 ms of a 53 ms step for 7 % of its flops
+// (profiles/r06_conv_layers.txt).  Here the unit of work is a CUBE:
+//
+//   * a workgroup (8 waves) owns 8 x 8 x 8 output voxels x NB output channels and walks the input channels in rounds of 32:
+//     per round the 10 x 10 x 10 halo cube of 32 channels is staged in LDS VOXEL-major (channels of a voxel contiguous - what
+//     the MFMA operand wants; NCDHW has x contiguous, so the transposition happens once per staged element in the LDS write, two
+//     channels per 32-bit write), zeros where the cube leaves the volume, and then serves all 27 taps: the fragment of tap
+//     (kz, ky, kx) is the same LDS image at a voxel offset - an immediate in the ds_read_b128;
+//   * implicit GEMM per tap and round: M = 512 voxels (32 tiles of 4 x 4 in a z plane), N = NB, K = 32.  Wave (wm, wn) owns the two
+//     z planes 2 wm, 2 wm + 1 (8 tiles) x NT column tiles: 8 input fragments from LDS and NT weight fragments straight from global
+//     memory (host-arranged as fragments: 1 KB contiguous per wave and load) feed 8 NT MFMAs;
+//   * LDS row / plane pitch 12 / 120 voxels of 96 bytes: with 4 x 4 tiles every ds_read_b128 of every tap is conflict-free
+//     (tools/lds_conflicts.py model: 4.0 cycles); 115 KB, one workgroup per CU;
+//   * small volumes have few cubes, so the contraction is SPLIT over workgroups (`splits` ranges of rounds): every workgroup stores
+//     fp32 partial sums, and a second launch adds them in a fixed order, adds the bias (and, in accumulate mode, the existing
+//     values - the later parts of a concatenated input) and rounds once.  No atomics: results are run-to-run identical.
+//
+// v_mfma_f32_16x16x32: A[i][k]: lane l holds A[i = l & 15][8 (l >> 4) .. +7]; B[k][j]: lane l holds B[8 (l >> 4) .. +7][j = l & 15];
+// D[row = 4 (l >> 4) + r][col = l & 15].  Here row = voxel (4 x 4 tile: row = 4 y + x), col = output channel: a lane ends up with
+// four x-consecutive voxels of one channel = one 16-byte store into the partial sums.
+#include <stdlib.h>
+#include <string.h>
+
+#include "segm_device.h"
+
+namespace segm {
+
+typedef uint32_t cube_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kCubeP = 96;                    // LDS bytes per staged voxel: 32 channels + 32 bytes of padding
+constexpr int kCubeRow = 12;                  // voxels between rows of the staged cube (10 used)
+constexpr int kCubePlane = 120;               // voxels between planes
+constexpr int kCubeLds = 10 * kCubePlane * kCubeP;
+constexpr int kCubePairRows = 10 * 10 * 16;   // (z', y', channel pair) rows of one round
+constexpr int kCubeIters = (kCubePairRows + 511) / 512;
+
+struct CubeDev {
+    const char* x;  int64_t x_sb, x_sc, x_sz, x_sy;      // element strides; x contiguous
+    const char* wimg;                                    // [Cout / 16][R][27][64][8] fragments (segm_conv3d_k3_cube_pack_index)
+    float* part;                                         // [S][B][Cout][D][H][W]
+    int32_t B, Cin, Cout, D, H, W;
+    int32_t R, S, tz, ty, tx, ncb;
+};
+
+template <typename T> struct CubeStage {                 // one thread's share of a round on its way from global memory to LDS
+    cube_u32x4 a[kCubeIters], b[kCubeIters];             // channels 2 cp and 2 cp + 1: eight x of the row
+    uint32_t hl[kCubeIters], hr[kCubeIters];             // the voxels left and right of them, both channels packed
+};
+
+// NT = 16-channel tiles per wave; NB = 32 NT output channels per workgroup (two waves side by side in N, four in M)
+template <typename T, int NT>
+__global__ void __launch_bounds__(512, 1) conv3d_k3_cube_kernel(CubeDev P) {
+    typedef typename Mfma16<T>::v8 frag8;
+    constexpr int NB = 32 * NT;
+    __shared__ __attribute__((aligned(16))) unsigned char s_x[kCubeLds];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+
+    // work item: spatial cube fastest (the cubes of one (channel block, split) share its weights in one L2), then block, then split
+    const int item = xcd_item(blockIdx.x, gridDim.x);
+    const int ncube = P.tz * P.ty * P.tx;
+    const int nsp = ncube * P.B;
+    const int sp = item % nsp, rest = item / nsp;
+    const int cb = rest % P.ncb, s = rest / P.ncb;
+    const int b = sp / ncube, cube = sp - b * ncube;
+    const int cz = cube / (P.ty * P.tx), cy = (cube / P.tx) % P.ty, cx = cube % P.tx;
+    const int z0 = 8 * cz, y0 = 8 * cy, x0 = 8 * cx;
+    const int r0 = (int)((int64_t)s * P.R / P.S), r1 = (int)((int64_t)(s + 1) * P.R / P.S);
+    const bool has_left = x0 > 0, has_right = x0 + 8 < P.W;
+
+    // ---- staging: pair row q = (z', y', cp) -> thread; the same rows every round, only the channel base moves
+    int64_t src_off[kCubeIters];                          // element offset of (b, channel 2 cp, row) from P.x at round 0; < 0: outside
+    uint32_t dst_off[kCubeIters];
+#pragma unroll
+    for (int it = 0; it < kCubeIters; ++it) {
+        const int q = it * 512 + tid;
+        const int cp = q & 15, yz = q >> 4, yp = yz % 10, zp = yz / 10;
+        const int gz = z0 - 1 + zp, gy = y0 - 1 + yp;
+        const bool live = q < kCubePairRows && gz >= 0 && gz < P.D && gy >= 0 && gy < P.H;
+        src_off[it] = live ? (int64_t)b * P.x_sb + (int64_t)(2 * cp) * P.x_sc + (int64_t)gz * P.x_sz + (int64_t)gy * P.x_sy + x0 : -1;
+        dst_off[it] = q < kCubePairRows ? (uint32_t)((zp * kCubePlane + yp * kCubeRow) * kCubeP + cp * 4) : 0xffffffffu;
+    }
+    CubeStage<T> st;
+    auto load_round = [&](int r) {
+        const int64_t cbase = (int64_t)r * 32 * P.x_sc;
+#pragma unroll
+        for (int it = 0; it < kCubeIters; ++it) {
+            st.a[it] = cube_u32x4{0, 0, 0, 0}; st.b[it] = cube_u32x4{0, 0, 0, 0}; st.hl[it] = 0; st.hr[it] = 0;
+            if (src_off[it] >= 0) {
+                const uint16_t* pa = reinterpret_cast<const uint16_t*>(P.x) + src_off[it] + cbase;
+                const uint16_t* pb = pa + P.x_sc;
+                st.a[it] = *reinterpret_cast<const cube_u32x4*>(pa);
+                st.b[it] = *reinterpret_cast<const cube_u32x4*>(pb);
+                if (has_left) st.hl[it] = (uint32_t)pa[-1] | ((uint32_t)pb[-1] << 16);
+                if (has_right) st.hr[it] = (uint32_t)pa[8] | ((uint32_t)pb[8] << 16);
+            }
+        }
+    };
+    auto store_round = [&]() {
+#pragma unroll
+        for (int it = 0; it < kCubeIters; ++it) {
+            if (dst_off[it] != 0xffffffffu) {
+                unsigned char* d = s_x + dst_off[it];
+                *reinterpret_cast<uint32_t*>(d) = st.hl[it];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = st.a[it][j], bb = st.b[it][j];
+                    *reinterpret_cast<uint32_t*>(d + (1 + 2 * j) * kCubeP) = (a & 0xffffu) | (bb << 16);
+                    *reinterpret_cast<uint32_t*>(d + (2 + 2 * j) * kCubeP) = (a >> 16) | (bb & 0xffff0000u);
+                }
+                *reinterpret_cast<uint32_t*>(d + 9 * kCubeP) = st.hr[it];
+            }
+        }
+    };
+
+    // ---- fragments: lane (m = voxel of the 4 x 4 tile, g = channel group of 8)
+    const int m16 = lane & 15, g = lane >> 4;
+    const unsigned char* a_base = s_x + (2 * wm * kCubePlane + (m16 >> 2) * kCubeRow + (m16 & 3)) * kCubeP + g * 16;
+    const char* w_base = P.wimg + ((int64_t)(cb * (NB / 16) + wn * NT) * P.R * 27 * 64 + lane) * 16;
+    const int64_t w_tile = (int64_t)P.R * 27 * 1024;       // bytes between column tiles
+
+    mfma_f32x4 acc[8][NT];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (r0 < r1) load_round(r0);
+    for (int r = r0; r < r1; ++r) {
+        __syncthreads();                                   // the previous round's fragments are all read
+        store_round();
+        __syncthreads();
+        if (r + 1 < r1) load_round(r + 1);                 // in flight under this round's MFMAs
+        const char* wr = w_base + (int64_t)r * 27 * 1024;
+        frag8 bw[2][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bw[0][j] = *reinterpret_cast<const frag8*>(wr + j * w_tile);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+            if (tap + 1 < 27) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bw[(tap + 1) & 1][j] = *reinterpret_cast<const frag8*>(wr + (tap + 1) * 1024 + j * w_tile);
+            }
+            frag8 av[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int vox = (i >> 2) * kCubePlane + ((i >> 1) & 1) * 4 * kCubeRow + (i & 1) * 4 + kz * kCubePlane + ky * kCubeRow + kx;
+                av[i] = *reinterpret_cast<const frag8*>(a_base + vox * kCubeP);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = Mfma16<T>::run(av[i], bw[tap & 1][j], acc[i][j]);
+            SEGM_SCHED_FENCE();                            // one tap's fragments in registers at a time (27 x 8 hoisted reads spill)
+        }
+    }
+
+    // ---- partial sums: lane = (channel m16 of the column tile, row g of the 4 x 4 tile): four x-consecutive voxels
+    const int64_t plane = (int64_t)P.H * P.W, vol = (int64_t)P.D * plane;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = cb * NB + (wn * NT + j) * 16 + m16;
+        float* pc = P.part + (((int64_t)s * P.B + b) * P.Cout + co) * vol;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int z = z0 + 2 * wm + (i >> 2), y = y0 + ((i >> 1) & 1) * 4 + g, x = x0 + (i & 1) * 4;
+            *reinterpret_cast<mfma_f32x4*>(pc + z * plane + (int64_t)y * P.W + x) = acc[i][j];
+        }
+    }
+}
+
+struct CubeReduceDev {
+    const float* part;                                   // [S][B][Cout][vol]
+    const float* bias;
+    char* y;  int64_t y_sb, y_sc, y_sz, y_sy;            // element strides
+    int32_t S, B, Cout, D, H, W;
+    int64_t n8;                                          // B * Cout * vol / 8
+};
+
+// y = sum over splits (fixed order) + bias (+ y): eight x-consecutive voxels per thread (W % 8 == 0: never across a row)
+template <typename T, bool ACC>
+__global__ void __launch_bounds__(256) conv3d_k3_cube_reduce_kernel(CubeReduceDev P) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.n8) return;
+    const int64_t vol = (int64_t)P.D * P.H * P.W, e = i * 8;
+    const int64_t bc = e / vol, v = e - bc * vol;
+    const int bi = (int)(bc / P.Cout), co = (int)(bc - (int64_t)bi * P.Cout);
+    const int z = (int)(v / ((int64_t)P.H * P.W)), yx = (int)(v - (int64_t)z * P.H * P.W), yy = yx / P.W, xx = yx - yy * P.W;
+    const int64_t total = (int64_t)P.B * P.Cout * vol;
+    float sum[8];
+    const float bv = P.bias ? P.bias[co] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum[k] = 0.f;
+    for (int s = 0; s < P.S; ++s) {
+        const mfma_f32x4 lo = *reinterpret_cast<const mfma_f32x4*>(P.part + s * total + e);
+        const mfma_f32x4 hi = *reinterpret_cast<const mfma_f32x4*>(P.part + s * total + e + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sum[k] += lo[k]; sum[4 + k] += hi[k]; }
+    }
+    T* dst = reinterpret_cast<T*>(P.y) + (int64_t)bi * P.y_sb + (int64_t)co * P.y_sc + (int64_t)z * P.y_sz + (int64_t)yy * P.y_sy + xx;
+    T out[8];
+    if (ACC) {
+        const cube_u32x4 old = *reinterpret_cast<const cube_u32x4*>(dst);
+        memcpy(out, &old, 16);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum[k] += to_f32(out[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[k] = from_f32<T>(sum[k] + bv);
+    cube_u32x4 packed;
+    memcpy(&packed, out, 16);
+    *reinterpret_cast<cube_u32x4*>(dst) = packed;
+}
+
+static int cube_nt(int cout, int forced) {                 // column tiles per wave the layer can use: 4 (NB = 128), 3 (96), 2 (64)
+    if (forced >= 2 && forced <= 4 && cout % (32 * forced) == 0) return forced;
+    return 0;
+}
+
+}  // namespace segm
+
+using namespace segm;
+
+// The launch plan of a layer: NT column tiles per wave (NB = 32 NT channels per workgroup) and the number of splits of the
+// contraction, chosen so that the grid fills the 256 CUs with as few partial sums as that takes; workspace = fp32 elements of the
+// partial sums.  nt / splits > 0 on entry are kept if the layer can use them (experiments, tests).
+extern "C" int segm_conv3d_k3_cube_plan(int32_t batch, int32_t cin, int32_t cout, int32_t depth, int32_t height, int32_t width,
+                                        int32_t* nt, int32_t* splits, int64_t* workspace_elems) {
+    if (!nt || !splits || !workspace_elems) return SEGM_E_NULL;
+    if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return SEGM_E_SHAPE;
+    if (cin % 32 != 0 || (cout % 64 != 0 && cout % 96 != 0) || depth % 8 != 0 || height % 8 != 0 || width % 8 != 0) return SEGM_E_SHAPE;
+    const int R = cin / 32;
+    const int64_t cubes = (int64_t)(depth / 8) * (height / 8) * (width / 8) * batch;
+    static const int env_nt = [] { const char* e = getenv("SEGM_CUBE_NT"); return e ? atoi(e) : 0; }();
+    static const int env_s = [] { const char* e = getenv("SEGM_CUBE_SPLITS"); return e ? atoi(e) : 0; }();
+    static const int target = [] { const char* e = getenv("SEGM_CUBE_WORKGROUPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    if ((*nt > 0 && !cube_nt(cout, *nt)) || *nt < 0 || *splits < 0 || *splits > R) return SEGM_E_SHAPE;     // an explicit request the layer cannot run
+    int want_nt = *nt > 0 ? *nt : env_nt, want_s = *splits > 0 ? *splits : env_s;
+    int best_nt = 0, best_s = 0;
+    int64_t best_wg = -1;
+    for (int c = 4; c >= 2; --c) {
+        if (cout % (32 * c) != 0 || (want_nt > 0 && cube_nt(cout, want_nt) && c != want_nt)) continue;
+        const int64_t base = cubes * (cout / (32 * c));
+        int s = (int)((target + base - 1) / base);
+        if (s < 1) s = 1;
+        if (s > R) s = R;
+        while (R % s != 0) ++s;                            // equal ranges of rounds
+        const int64_t wg = base * s;
+        if (best_wg < 0 || (best_wg < target && wg > best_wg)) { best_nt = c; best_s = s; best_wg = wg; }
+        if (best_wg >= target) break;
+    }
+    if (best_nt == 0) return SEGM_E_SHAPE;
+    if (want_s > 0 && want_s <= R) best_s = want_s;
+    *nt = best_nt; *splits = best_s;
+    *workspace_elems = (int64_t)best_s * batch * cout * depth * height * width;
+    return SEGM_OK;
+}
+
+// Index map of the weight image: out[i] = flat index into w (cout_w, cin_w, 3, 3, 3) contiguous for i over
+// [Cout / 16][Cin / 32][27][64][8] of the convolution the image is FOR: flipped = 0: the forward convolution (Cout = cout_w,
+// Cin = cin_w); flipped = 1: its data gradient as a convolution of dy (Cout = cin_w, Cin = cout_w, taps mirrored).
+extern "C" int segm_conv3d_k3_cube_pack_index(int32_t* out, int64_t n, int32_t cout_w, int32_t cin_w, int32_t flipped) {
+    if (!out) return SEGM_E_NULL;
+    const int Cout = flipped ? cin_w : cout_w, Cin = flipped ? cout_w : cin_w;
+    if (cout_w <= 0 || cin_w <= 0 || Cout % 16 != 0 || Cin % 32 != 0) return SEGM_E_SHAPE;
+    if (n != (int64_t)Cout * Cin * 27 || n >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;
+    const int R = Cin / 32;
+    int64_t o = 0;
+    for (int ct = 0; ct < Cout / 16; ++ct)
+        for (int r = 0; r < R; ++r)
+            for (int tap = 0; tap < 27; ++tap)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e) {
+                        const int co = ct * 16 + (l & 15), ci = r * 32 + (l >> 4) * 8 + e;
+                        out[o++] = flipped ? (int32_t)(((int64_t)ci * cin_w + co) * 27 + (26 - tap))
+                                           : (int32_t)(((int64_t)co * cin_w + ci) * 27 + tap);
+                    }
+    return SEGM_OK;
+}
+
+extern "C" int segm_conv3d_k3_cube_fwd(const segm_conv3d_cube_args* a) {
+    if (!a) return SEGM_E_NULL;
+    if (!a->x || !a->y || !a->w_image) return SEGM_E_NULL;
+    if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
+    if (a->flags & ~SEGM_CONV_CUBE_ACCUMULATE) return SEGM_E_SHAPE;
+    int32_t nt = a->nt, splits = a->splits;
+    int64_t need = 0;
+    const int rc = segm_conv3d_k3_cube_plan(a->batch, a->cin, a->cout, a->depth, a->height, a->width, &nt, &splits, &need);
+    if (rc != SEGM_OK) return rc;
+    if ((a->nt > 0 && nt != a->nt) || (a->splits > 0 && splits != a->splits)) return SEGM_E_SHAPE;
+    if (!a->workspace || a->workspace_elems < need) return SEGM_E_WORKSPACE;
+    const int64_t st[8] = {a->x_stride_b, a->x_stride_c, a->x_stride_z, a->x_stride_y, a->y_stride_b, a->y_stride_c, a->y_stride_z, a->y_stride_y};
+    for (int64_t s : st)
+        if (s % 8 != 0 || s <= 0) return SEGM_E_SHAPE;      // 16-byte aligned rows
+    if (((uintptr_t)a->x & 15) || ((uintptr_t)a->y & 15) || ((uintptr_t)a->w_image & 15) || ((uintptr_t)a->workspace & 15)) return SEGM_E_SHAPE;
+
+    CubeDev P;
+    memset(&P, 0, sizeof(P));
+    P.x = (const char*)a->x; P.x_sb = a->x_stride_b; P.x_sc = a->x_stride_c; P.x_sz = a->x_stride_z; P.x_sy = a->x_stride_y;
+    P.wimg = (const char*)a->w_image; P.part = (float*)a->workspace;
+    P.B = a->batch; P.Cin = a->cin; P.Cout = a->cout; P.D = a->depth; P.H = a->height; P.W = a->width;
+    P.R = a->cin / 32; P.S = splits; P.tz = a->depth / 8; P.ty = a->height / 8; P.tx = a->width / 8; P.ncb = a->cout / (32 * nt);
+    const int64_t nwg = (int64_t)P.tz * P.ty * P.tx * P.B * P.ncb * P.S;
+    if (nwg >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;
+    hipStream_t stream = (hipStream_t)a->stream;
+    const bool f16 = a->dtype == SEGM_F16;
+#define SEGM_CUBE_LAUNCH(NT_)                                                                                                \
+    do {                                                                                                                       \
+        if (f16) hipLaunchKernelGGL((conv3d_k3_cube_kernel<f16_t, NT_>), dim3((unsigned)nwg), dim3(512), 0, stream, P);         \
+        else hipLaunchKernelGGL((conv3d_k3_cube_kernel<bf16_t, NT_>), dim3((unsigned)nwg), dim3(512), 0, stream, P);            \
+    } while (0)
+    if (nt == 4) SEGM_CUBE_LAUNCH(4); else if (nt == 3) SEGM_CUBE_LAUNCH(3); else SEGM_CUBE_LAUNCH(2);
+#undef SEGM_CUBE_LAUNCH
+    int err = (int)hipGetLastError();
+    if (err) return err;
+
+    CubeReduceDev Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.part = (const float*)a->workspace; Q.bias = a->bias;
+    Q.y = (char*)a->y; Q.y_sb = a->y_stride_b; Q.y_sc = a->y_stride_c; Q.y_sz = a->y_stride_z; Q.y_sy = a->y_stride_y;
+    Q.S = splits; Q.B = a->batch; Q.Cout = a->cout; Q.D = a->depth; Q.H = a->height; Q.W = a->width;
+    Q.n8 = (int64_t)a->batch * a->cout * a->depth * a->height * a->width / 8;
+    const unsigned nb = (unsigned)((Q.n8 + 255) / 256);
+    const bool acc = (a->flags & SEGM_CONV_CUBE_ACCUMULATE) != 0;
+    if (f16) {
+        if (acc) hipLaunchKernelGGL((conv3d_k3_cube_reduce_kernel<f16_t, true>), dim3(nb), dim3(256), 0, stream, Q);
+        else hipLaunchKernelGGL((conv3d_k3_cube_reduce_kernel<f16_t, false>), dim3(nb), dim3(256), 0, stream, Q);
+    } else {
+        if (acc) hipLaunchKernelGGL((conv3d_k3_cube_reduce_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, stream, Q);
+        else hipLaunchKernelGGL((conv3d_k3_cube_reduce_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, stream, Q);
+    }
+    return (int)hipGetLastError();
+}

@@ -118,6 +118,16 @@ class Conv3dClArgs(C.Structure):
     ]
 
 
+class Conv3dCubeArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("depth", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+        ("dtype", C.c_int32), ("flags", C.c_int32), ("nt", C.c_int32), ("splits", C.c_int32),
+        ("x", C.c_void_p), ("x_stride_b", C.c_int64), ("x_stride_c", C.c_int64), ("x_stride_z", C.c_int64), ("x_stride_y", C.c_int64),
+        ("y", C.c_void_p), ("y_stride_b", C.c_int64), ("y_stride_c", C.c_int64), ("y_stride_z", C.c_int64), ("y_stride_y", C.c_int64),
+        ("w_image", C.c_void_p), ("bias", C.c_void_p), ("workspace", C.c_void_p), ("workspace_elems", C.c_int64), ("stream", C.c_void_p),
+    ]
+
+
 class Add3Args(C.Structure):
     _fields_ = [("count", C.c_int64), ("dtype", C.c_int32), ("reserved", C.c_int32),
                 ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("out", C.c_void_p), ("stream", C.c_void_p)]
@@ -337,6 +347,9 @@ class SegmLib:
         sig("segm_conv3d_k3_fwd_stats_parts", [C.c_int32] * 6, C.c_int32)
         sig("segm_conv3d_k3_fwd_cl", [C.POINTER(Conv3dClArgs)], C.c_int)
         sig("segm_conv3d_k3_cl_pack_index", [C.c_void_p, C.c_int64], C.c_int)
+        sig("segm_conv3d_k3_cube_fwd", [C.POINTER(Conv3dCubeArgs)], C.c_int)
+        sig("segm_conv3d_k3_cube_plan", [C.c_int32] * 6 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)], C.c_int)
+        sig("segm_conv3d_k3_cube_pack_index", [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32], C.c_int)
         sig("segm_add3", [C.POINTER(Add3Args)], C.c_int)
         sig("segm_instnorm_fwd", [C.POINTER(InstNormFwdArgs)], C.c_int)
         sig("segm_instnorm_bwd", [C.POINTER(InstNormBwdArgs)], C.c_int)

@@ -544,6 +544,85 @@ def conv3d_k3_fwd_cl(lib: L.SegmLib, x: torch.Tensor, w_image: torch.Tensor, bia
 
 
 # ---------------------------------------------------------------------------------------------------------
+# 3x3x3 convolution of wide layers on small volumes (csrc/conv3d_cube.hip, ABI 10)
+# ---------------------------------------------------------------------------------------------------------
+CONV_CUBE_ACCUMULATE = 1
+_cube_index_cache = {}
+_cube_ws = {}
+
+
+def conv3d_cube_supported(x: torch.Tensor, cout: int) -> bool:
+    """does segm_conv3d_k3_cube_fwd take this input (B, Cin, D, H, W) for `cout` output channels"""
+    if x.dim() != 5 or x.dtype not in (torch.bfloat16, torch.float16) or x.stride(4) != 1:
+        return False
+    B, C, D, H, W = x.shape
+    if C % 32 != 0 or (cout % 64 != 0 and cout % 96 != 0) or D % 8 or H % 8 or W % 8 or min(B, C, D, H, W) <= 0:
+        return False
+    return all(s % 8 == 0 and s > 0 for s in x.stride()[:4]) and x.data_ptr() % 16 == 0
+
+
+def conv3d_cube_index(lib: L.SegmLib, cout_w: int, cin_w: int, flipped: bool, device) -> torch.Tensor:
+    """int32 map: element i of the kernel's weight image <- flat index into the (cout_w, cin_w, 3, 3, 3) weight"""
+    key = (cout_w, cin_w, bool(flipped), str(device))
+    idx = _cube_index_cache.get(key)
+    if idx is None:
+        n = cout_w * cin_w * 27
+        host = torch.empty(n, dtype=torch.int32)
+        lib.check(lib.dll.segm_conv3d_k3_cube_pack_index(host.data_ptr(), n, cout_w, cin_w, 1 if flipped else 0), "conv3d_k3_cube_pack_index")
+        idx = host.to(device)
+        _cube_index_cache[key] = idx
+    return idx
+
+
+def conv3d_cube_weight_image(lib: L.SegmLib, w: torch.Tensor, flipped: bool = False, dtype=None) -> torch.Tensor:
+    """(Cout, Cin, 3, 3, 3) weights -> the fragment image segm_conv3d_k3_cube_fwd streams (`flipped`: the image of the data
+    gradient, a convolution of dy with flip(w)^T) - one gather through the index map the library exports; a pure re-arrangement,
+    so inside a bank step it is one of the bank's derived packs (param_bank.packed)."""
+    idx = conv3d_cube_index(lib, w.shape[0], w.shape[1], flipped, w.device)
+    img = torch.index_select(w.reshape(-1), 0, idx)
+    return img if dtype is None or dtype == img.dtype else img.to(dtype)
+
+
+def conv3d_cube_plan(lib: L.SegmLib, B, cin, cout, D, H, W, nt=0, splits=0):
+    c_nt, c_s, c_ws = C.c_int32(nt), C.c_int32(splits), C.c_int64(0)
+    lib.check(lib.dll.segm_conv3d_k3_cube_plan(B, cin, cout, D, H, W, C.byref(c_nt), C.byref(c_s), C.byref(c_ws)), "conv3d_k3_cube_plan")
+    return c_nt.value, c_s.value, c_ws.value
+
+
+def conv3d_k3_cube_fwd(lib: L.SegmLib, x: torch.Tensor, w_image: torch.Tensor, cout: int, bias=None, out=None, accumulate=False,
+                       nt=0, splits=0):
+    """y (B, cout, D, H, W) = conv3d(x (B, Cin, D, H, W), 3x3x3, stride 1, pad 1) through the cube kernel; bf16 / fp16.  The
+    fp32 partial sums live in a per-device scratch buffer that grows to the largest layer seen (stream-ordered reuse)."""
+    if not conv3d_cube_supported(x, cout):
+        raise RuntimeError("conv3d_k3_cube_fwd: unsupported input")
+    B, cin, D, H, W = x.shape
+    if accumulate and out is None:
+        raise RuntimeError("conv3d_k3_cube_fwd: accumulate needs `out`")
+    y = out if out is not None else torch.empty(B, cout, D, H, W, dtype=x.dtype, device=x.device)
+    nt, splits, need = conv3d_cube_plan(lib, B, cin, cout, D, H, W, nt, splits)
+    key = str(x.device)
+    ws = _cube_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=x.device)
+        _cube_ws[key] = ws
+    a = L.Conv3dCubeArgs()
+    a.batch, a.cin, a.cout, a.depth, a.height, a.width = B, cin, cout, D, H, W
+    a.dtype = L.dtype_code(x)
+    a.flags = CONV_CUBE_ACCUMULATE if accumulate else 0
+    a.nt, a.splits = nt, splits
+    a.x, a.y, a.w_image = x.data_ptr(), y.data_ptr(), w_image.data_ptr()
+    a.x_stride_b, a.x_stride_c, a.x_stride_z, a.x_stride_y = x.stride()[:4]
+    a.y_stride_b, a.y_stride_c, a.y_stride_z, a.y_stride_y = y.stride()[:4]
+    if bias is not None:
+        bias = bias.float().contiguous()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.workspace, a.workspace_elems = ws.data_ptr(), ws.numel()
+    a.stream = L.stream_handle(x)
+    lib.check(lib.dll.segm_conv3d_k3_cube_fwd(a), "conv3d_k3_cube_fwd")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------------
 # InstanceNorm3d (+ residual) (+ activation)
 # ---------------------------------------------------------------------------------------------------------
 ACT_CODES = {"none": 0, "relu": 1, "leaky_relu": 2}

@@ -1962,3 +1962,62 @@ def test_add3_emulated(emu, dtype):
         assert ops_raw.add3(emu, a2, b, c, out=a2) is a2 and torch.equal(a2, ref)
     with pytest.raises(RuntimeError):
         ops_raw.add3(emu, a[:10], b[:10], c[:10])           # not whole 16-byte packets
+
+
+@pytest.mark.parametrize("shape,nt,splits", [((1, 32, 64, 8, 8, 8), 2, 1), ((2, 64, 64, 8, 8, 8), 2, 2), ((1, 96, 128, 8, 16, 8), 4, 3),
+                                             ((1, 32, 96, 16, 8, 16), 3, 1), ((1, 64, 192, 8, 8, 16), 0, 0)])
+def test_conv3d_k3_cube_forward_emulated(emu, shape, nt, splits):
+    """segm_conv3d_k3_cube_fwd (ABI 10): 8 x 8 x 8 cubes x 64 / 96 / 128 output channels per workgroup, the halo cube of 32 input
+    channels per round through LDS, split contraction + fixed-order reduction; against fp32 ATen on the 16-bit inputs.  Volumes of
+    one cube (all halos are padding) and of several (halos from the neighbour cube, left / right x halo loads), bias, and a second
+    input part accumulated in place on strided tensors"""
+    B, cin, cout, D, H_, W = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, cin, D, H_, W, generator=g).bfloat16()
+    w = (0.1 * torch.randn(cout, cin, 3, 3, 3, generator=g)).bfloat16()
+    bias = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), bias, 1, 1)
+    tol = 1e-2 * max(1.0, float(ref.abs().max()))
+    img = ops_raw.conv3d_cube_weight_image(emu, w)
+    pnt, ps, need = ops_raw.conv3d_cube_plan(emu, B, cin, cout, D, H_, W, nt, splits)
+    assert (nt == 0 or pnt == nt) and (splits == 0 or ps == splits) and need == ps * B * cout * D * H_ * W
+    y = ops_raw.conv3d_k3_cube_fwd(emu, x, img, cout, bias, nt=nt, splits=splits)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    assert (y.float() - ref).abs().max() <= tol
+    # the same launch with another plan: the same sums in another association
+    y1 = ops_raw.conv3d_k3_cube_fwd(emu, x, img, cout, bias, nt=2 if cout % 64 == 0 else 3, splits=cin // 32)
+    assert (y1.float() - ref).abs().max() <= tol
+    # a second part of the input accumulated in place; input and output with padded channel / batch strides
+    x2 = torch.randn(B, cin, D, H_, W, generator=g).bfloat16()
+    w2 = (0.1 * torch.randn(cout, cin, 3, 3, 3, generator=g)).bfloat16()
+    ref2 = ref + torch.nn.functional.conv3d(x2.float(), w2.float(), None, 1, 1)
+    xp = torch.zeros(B, cin + 1, D, H_, W + 8, dtype=torch.bfloat16)[:, :cin, :, :, :W]
+    xp.copy_(x2)
+    yp = torch.full((B, cout + 2, D, H_, W + 8), 7.0, dtype=torch.bfloat16)
+    yv = yp[:, :cout, :, :, :W]
+    yv.copy_(y)
+    ops_raw.conv3d_k3_cube_fwd(emu, xp, ops_raw.conv3d_cube_weight_image(emu, w2), cout, None, out=yv, accumulate=True, nt=nt, splits=splits)
+    assert (yv.float() - ref2).abs().max() <= 2 * tol
+    assert bool((yp[:, cout:] == 7.0).all()) and bool((yp[:, :, :, :, W:] == 7.0).all())      # nothing written outside the view
+
+
+def test_conv3d_k3_cube_dgrad_and_errors_emulated(emu):
+    """the data gradient is the same launch on dy with the flipped image (Cout = the weight's Cin); argument errors"""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(1, 64, 8, 8, 16, generator=g, requires_grad=True)
+    w = (0.1 * torch.randn(96, 64, 3, 3, 3, generator=g)).bfloat16()
+    dy = torch.randn(1, 96, 8, 8, 16, generator=g).bfloat16()
+    torch.nn.functional.conv3d(x, w.float(), None, 1, 1).backward(dy.float())
+    dx = ops_raw.conv3d_k3_cube_fwd(emu, dy, ops_raw.conv3d_cube_weight_image(emu, w, flipped=True), 64)
+    assert (dx.float() - x.grad).abs().max() <= 1e-2 * max(1.0, float(x.grad.abs().max()))
+    img = ops_raw.conv3d_cube_weight_image(emu, w)
+    assert not ops_raw.conv3d_cube_supported(dy[:, :, :, :, :12], 64)              # width not a multiple of 8
+    assert not ops_raw.conv3d_cube_supported(dy[:, :40], 64)                        # Cin not a multiple of 32
+    assert not ops_raw.conv3d_cube_supported(dy, 160)                               # Cout neither a multiple of 64 nor of 96
+    with pytest.raises(RuntimeError):
+        ops_raw.conv3d_cube_plan(emu, 1, 64, 96, 8, 8, 12)
+    xs = x.detach().bfloat16()
+    with pytest.raises(RuntimeError):
+        ops_raw.conv3d_k3_cube_fwd(emu, xs, img, 96, nt=4)                          # 96 channels cannot run 128-channel blocks
+    with pytest.raises(RuntimeError):
+        ops_raw.conv3d_k3_cube_fwd(emu, xs, img, 96, splits=3)                      # only two rounds to split
