@@ -357,6 +357,10 @@ typedef struct segm_conv3d_cube_args {
     void* workspace;          /* fp32, segm_conv3d_k3_cube_plan's workspace_elems */
     int64_t workspace_elems;
     void* stream;
+    /* InstanceNorm partials of what the launch stores (segm_instnorm_fwd_args.stats_partials): fp32 (batch * cout, stats_nparts, 4)
+     * {count, sum, sum of squares, -}, stats_nparts = depth * height * width / 512; NULL = not wanted */
+    float* stats_partials;
+    int32_t stats_nparts, reserved;
 } segm_conv3d_cube_args;
 
 int segm_conv3d_k3_cube_fwd(const segm_conv3d_cube_args* args);

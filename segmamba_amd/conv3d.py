@@ -53,6 +53,12 @@ _STATS = os.environ.get("SEGM_CONV_STATS", "1") == "1"
 _RES_FRONT = os.environ.get("SEGM_RES_FRONT", "1") == "1"
 
 
+# round 6 (late): the wide layers of the 8^3 / 16^3 / 32^3 levels on segm_conv3d_k3_cube_fwd (csrc/conv3d_cube.hip) - forward and data
+# gradient; 2.5 - 6x over the row kernels / the vendor route there (profiles/r06_conv_cube_v2.txt).  SEGM_CONV_CUBE=0: the round-5 routing.
+_CUBE = os.environ.get("SEGM_CONV_CUBE", "1") == "1"
+_CUBE_MAX_WIDTH = int(os.environ.get("SEGM_CONV_CUBE_MAX_WIDTH", "32"))
+
+
 def _time(fn: Callable[[], torch.Tensor], reps: int = 3) -> float:
     """median of `reps` timed calls after one warm-up call (close candidates differ by a few per cent)"""
     fn()
@@ -82,6 +88,11 @@ def _table_variant(width: int):
     return (True, True, False) if width >= 128 else (False, False, True)
 
 
+def _is_lib(v) -> bool:
+    """a routing variant that is a library kernel: the row kernels' flag tuple, or "cube" """
+    return isinstance(v, tuple) or v == "cube"
+
+
 def _table_choice(kind: str, width: int, variants) -> int:
     """index of the routing the table prescribes among `variants` (None = a vendor route, tuple = library kernel flags, "mfma" =
     the library's weight-gradient kernel).  Measured on MI355X (profiles/r02_bench_variants.log): the library's kernels win every
@@ -90,6 +101,8 @@ def _table_choice(kind: str, width: int, variants) -> int:
     weight-bandwidth-bound GEMMs."""
     if kind == "wgrad":
         return variants.index("mfma") if width >= 16 and "mfma" in variants else 0
+    if "cube" in variants:                               # only offered where it is the table's choice (_cube_ok)
+        return variants.index("cube")
     if width >= 16:
         want = _table_variant(width)
         if want in variants:
@@ -186,6 +199,45 @@ def _fwd_hip(x, w, pad, bias=None, chain=False, pitch48=False, chain32=False, in
     return out
 
 
+def _cube_ok(x, cout: int, cin_w: int) -> bool:
+    """the cube kernel takes this convolution AND the table prefers it: every supported layer of width <= 16, at 32^3 the layers from
+    96 -> 192 channels up (96 -> 96 is level with the row kernel, which also carries the statistics epilogue); with the tuner on,
+    wherever it is supported"""
+    from . import ops_raw
+    if not _CUBE or not ops_raw.conv3d_cube_supported(x, cout) or x.shape[1] != cin_w:
+        return False
+    if _TUNE:
+        return True
+    width = x.shape[4]
+    return width <= min(16, _CUBE_MAX_WIDTH) or (width <= _CUBE_MAX_WIDTH and width <= 32 and x.shape[1] * cout >= 96 * 192)
+
+
+def _fwd_cube(x, w, bias=None, into=None, flipped=False, stats_box=None):
+    """segm_conv3d_k3_cube_fwd: the whole contraction in one launch (+ its reduction); `flipped`: w is the forward weight and x
+    the output gradient (the data gradient); `into`: an existing result the launch adds to; `stats_box`: the InstanceNorm partials of
+    what the launch stores are appended"""
+    from . import lib as L, ops_raw
+    from .param_bank import packed
+    hip = L.get_lib()
+    cout = w.shape[1] if flipped else w.shape[0]
+    if w.dtype != x.dtype:
+        img = ops_raw.conv3d_cube_weight_image(hip, w, flipped, x.dtype)
+    else:
+        img = packed(w, ("conv3d_cube", bool(flipped)), lambda t: ops_raw.conv3d_cube_weight_image(hip, t, flipped))
+    res = ops_raw.conv3d_k3_cube_fwd(hip, x, img, cout, bias, out=into, accumulate=into is not None, want_stats=stats_box is not None)
+    if stats_box is not None:
+        res, st = res
+        stats_box.append(st)
+    return res
+
+
+def _fwd_lib(v, x, w, pad, bias=None, into=None, stats_box=None, flipped=False):
+    """the library kernel variant `v` (a row-kernel flag tuple or "cube") on one part of a convolution"""
+    if v == "cube":
+        return _fwd_cube(x, w, bias, into=into, flipped=flipped, stats_box=stats_box)
+    return _fwd_hip(x, w, pad, bias, *v, into=into, flipped=flipped, stats_box=stats_box)
+
+
 def _hip_chain_ok(w) -> bool:
     """The chained-K-parts kernel (eight-wave layout) as an extra autotune candidate: on MI355X it beats the
     reduce-per-row kernel by 5 - 16 % on the 128^3 / 64^3 layers and loses ~4 % at 32^3 (profiles/r01_conv_chain_ab.log), so the
@@ -274,7 +326,7 @@ def _fwd_candidates(x, w, bias, pad, stats_box=None):
     the library kernel's (chain, pitch48, chain32) flags, None for the vendor routes"""
     hip = _hip_fwd_ok(x, w)
     chain = hip and _hip_chain_ok(w)
-    key = _key("fwd", x, w, hip, chain, _hip_untimed_ok())
+    key = _key("fwd", x, w, hip, chain, _hip_untimed_ok(), _CUBE)
 
     def with_bias(y):
         return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
@@ -287,17 +339,20 @@ def _fwd_candidates(x, w, bias, pad, stats_box=None):
     for v in _HIP_VARIANTS[:n]:                          # bias fused into the kernel's epilogue
         cands.append(lambda v=v: _fwd_hip(x, w, pad, bias, *v, stats_box=stats_box))
         variants.append(v)
+    if w.shape[2:] == (3, 3, 3) and w.dtype == x.dtype and _cube_ok(x, w.shape[0], w.shape[1]):
+        cands.append(lambda: _fwd_cube(x, w, bias, stats_box=stats_box))
+        variants.append("cube")
     return key, cands, variants
 
 
 def _pick_was_hip(key, cands, variants, width: int = 0) -> bool:
     """did `_pick` return the result of a library-kernel candidate (only then are statistics in the box those of the result)"""
     if len(cands) == 1 or not torch.cuda.is_available():
-        return isinstance(variants[0], tuple)
+        return _is_lib(variants[0])
     if not _TUNE:
-        return isinstance(variants[_table_choice(key[0], width, variants)], tuple)
+        return _is_lib(variants[_table_choice(key[0], width, variants)])
     i = _cache.get(key)
-    return i is not None and isinstance(variants[i], tuple)
+    return i is not None and _is_lib(variants[i])
 
 
 def _tuned_variant(key, cands, variants, width: int = 0):
@@ -306,9 +361,9 @@ def _tuned_variant(key, cands, variants, width: int = 0):
         return None
     if not _TUNE:
         v = variants[_table_choice(key[0], width, variants)]
-        return v if isinstance(v, tuple) else None
+        return v if _is_lib(v) else None
     i = _cache.get(key)
-    return variants[i] if i is not None else None
+    return variants[i] if i is not None and _is_lib(variants[i]) else None
 
 
 def _dgrad(dy, w, x, pad, into=None):
@@ -324,12 +379,15 @@ def _dgrad(dy, w, x, pad, into=None):
     for v in _HIP_VARIANTS[:n]:
         cands.append(lambda v=v: _dgrad_hip(dy, w, x, pad, *v))
         variants.append(v)
-    key = _key("dgrad", dy, w, hip, chain, _hip_untimed_ok())
+    if w.shape[2:] == (3, 3, 3) and w.dtype == dy.dtype and _cube_ok(dy, w.shape[1], w.shape[0]):
+        cands.append(lambda: _fwd_cube(dy, w, flipped=True))
+        variants.append("cube")
+    key = _key("dgrad", dy, w, hip, chain, _hip_untimed_ok(), _CUBE)
     if into is not None:
         from . import ops_raw
         v = _tuned_variant(key, cands, variants, dy.shape[4]) if w.shape[1] % _BLOCK == 0 and ops_raw.channel_dense(into) else None
         if v is not None:
-            return _dgrad_hip(dy, w, x, pad, *v, into=into)
+            return _fwd_lib(v, dy, w, pad, into=into, flipped=True)
         return into.add_(_pick(key, cands, variants, dy.shape[4]))
     return _pick(key, cands, variants, dy.shape[4])
 
@@ -407,7 +465,7 @@ class _ConvSameCat(torch.autograd.Function):
             v = _tuned_variant(key, cands, variants, x.shape[4]) if wi.shape[0] % _BLOCK == 0 else None
             if v is not None:
                 box = [] if (want_stats and j + 1 == len(xs)) else None      # the launch that stores the finished values
-                out = _fwd_hip(x, wi, pad, None, *v, into=out, stats_box=box)
+                out = _fwd_lib(v, x, wi, pad, into=out, stats_box=box)
                 stats = box[-1] if box else None
             else:                                        # not tuned yet (this call does it) or a vendor route won
                 out = out + _pick(key, cands, variants, x.shape[4])
@@ -469,7 +527,7 @@ class _ResFront(torch.autograd.Function):
             key, cands, variants = _fwd_candidates(x, w1i, None, pad)
             v = _tuned_variant(key, cands, variants, x.shape[4]) if w1i.shape[0] % _BLOCK == 0 else None
             if v is not None:
-                y1 = _fwd_hip(x, w1i, pad, None, *v, into=y1, stats_box=box)
+                y1 = _fwd_lib(v, x, w1i, pad, into=y1, stats_box=box)
                 stats = box[-1] if box else None
             else:
                 y1 = y1 + _pick(key, cands, variants, x.shape[4])

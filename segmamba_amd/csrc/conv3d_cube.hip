@@ -142,27 +142,36 @@ __global__ void __launch_bounds__(512, 1) conv3d_k3_cube_kernel(CubeDev P) {
         __syncthreads();
         if (r + 1 < r1) load_round(r + 1);                 // in flight under this round's MFMAs
         const char* wr = w_base + (int64_t)r * 27 * 1024;
-        frag8 bw[2][NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bw[0][j] = *reinterpret_cast<const frag8*>(wr + j * w_tile);
-#pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
+        // software pipeline over the 27 taps: the input fragments of tap + 1 (LDS) and the weight fragments of tap + 2 (global / L2)
+        // are requested before the MFMAs of tap; the fence keeps the compiler from hoisting more than that (27 x 8 reads spill)
+        frag8 av[2][8], bw[3][NT];
+        auto read_a = [&](int tap, frag8* dst) {
             const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-            if (tap + 1 < 27) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bw[(tap + 1) & 1][j] = *reinterpret_cast<const frag8*>(wr + (tap + 1) * 1024 + j * w_tile);
-            }
-            frag8 av[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int vox = (i >> 2) * kCubePlane + ((i >> 1) & 1) * 4 * kCubeRow + (i & 1) * 4 + kz * kCubePlane + ky * kCubeRow + kx;
-                av[i] = *reinterpret_cast<const frag8*>(a_base + vox * kCubeP);
+                dst[i] = *reinterpret_cast<const frag8*>(a_base + vox * kCubeP);
             }
+        };
+        auto read_b = [&](int tap, frag8* dst) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) dst[j] = *reinterpret_cast<const frag8*>(wr + tap * 1024 + j * w_tile);
+        };
+        read_b(0, bw[0]);
+        read_b(1, bw[1]);
+        constexpr bool PIPE_A = NT < 4;                    // 128 accumulator registers leave no room for a second set of input fragments
+        if (PIPE_A) read_a(0, av[0]);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 2 < 27) read_b(tap + 2, bw[(tap + 2) % 3]);
+            if (PIPE_A) { if (tap + 1 < 27) read_a(tap + 1, av[(tap + 1) & 1]); }
+            else read_a(tap, av[0]);
+            const int cur = PIPE_A ? (tap & 1) : 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = Mfma16<T>::run(av[i], bw[tap & 1][j], acc[i][j]);
-            SEGM_SCHED_FENCE();                            // one tap's fragments in registers at a time (27 x 8 hoisted reads spill)
+                for (int j = 0; j < NT; ++j) acc[i][j] = Mfma16<T>::run(av[cur][i], bw[tap % 3][j], acc[i][j]);
+            SEGM_SCHED_FENCE();
         }
     }
 
@@ -186,10 +195,13 @@ struct CubeReduceDev {
     char* y;  int64_t y_sb, y_sc, y_sz, y_sy;            // element strides
     int32_t S, B, Cout, D, H, W;
     int64_t n8;                                          // B * Cout * vol / 8
+    float* stats;                                        // STATS: (B * Cout, vol / 512, 4) {count, sum, sum of squares, -} of what is stored
 };
 
 // y = sum over splits (fixed order) + bias (+ y): eight x-consecutive voxels per thread (W % 8 == 0: never across a row)
-template <typename T, bool ACC>
+// STATS: the InstanceNorm behind the convolution merges the per-wave sums (a wave = 512 consecutive voxels of one (batch, channel)
+// instance, vol % 512 == 0) instead of reading the volume again - the epilogue csrc/conv3d_fwd.hip's chained kernels have
+template <typename T, bool ACC, bool STATS>
 __global__ void __launch_bounds__(256) conv3d_k3_cube_reduce_kernel(CubeReduceDev P) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= P.n8) return;
@@ -217,7 +229,16 @@ __global__ void __launch_bounds__(256) conv3d_k3_cube_reduce_kernel(CubeReduceDe
         for (int k = 0; k < 8; ++k) sum[k] += to_f32(out[k]);
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) out[k] = from_f32<T>(sum[k] + bv);
+    for (int k = 0; k < 8; ++k) { sum[k] += bv; out[k] = from_f32<T>(sum[k]); }
+    if (STATS) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1 += sum[k]; s2 = fmaf(sum[k], sum[k], s2); }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+        if ((threadIdx.x & 63) == 0)
+            reinterpret_cast<float4*>(P.stats)[bc * (vol / 512) + v / 512] = float4{512.f, s1, s2, 0.f};
+    }
     cube_u32x4 packed;
     memcpy(&packed, out, 16);
     *reinterpret_cast<cube_u32x4*>(dst) = packed;
@@ -247,21 +268,25 @@ extern "C" int segm_conv3d_k3_cube_plan(int32_t batch, int32_t cin, int32_t cout
     static const int target = [] { const char* e = getenv("SEGM_CUBE_WORKGROUPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
     if ((*nt > 0 && !cube_nt(cout, *nt)) || *nt < 0 || *splits < 0 || *splits > R) return SEGM_E_SHAPE;     // an explicit request the layer cannot run
     int want_nt = *nt > 0 ? *nt : env_nt, want_s = *splits > 0 ? *splits : env_s;
+    // every (column tiles, divisor of the rounds) by a cost model fitted to profiles/r06_conv_cube_v2.txt: a round is 6 912 MFMA cycles per
+    // column tile + ~3 000 of staging and barriers (the 128-channel variant has no room to pipeline its fragment reads: + 5 000), a
+    // workgroup ~12 000 of prologue and partial-sum stores; more than `target` workgroups run as a second wave of workgroups
+    // behind the first; every split costs a pass over the output's partial sums in the reduction
     int best_nt = 0, best_s = 0;
-    int64_t best_wg = -1;
+    double best_cost = 0;
+    const double red = 0.0028 * (double)batch * cout * depth * height * width;
     for (int c = 4; c >= 2; --c) {
         if (cout % (32 * c) != 0 || (want_nt > 0 && cube_nt(cout, want_nt) && c != want_nt)) continue;
         const int64_t base = cubes * (cout / (32 * c));
-        int s = (int)((target + base - 1) / base);
-        if (s < 1) s = 1;
-        if (s > R) s = R;
-        while (R % s != 0) ++s;                            // equal ranges of rounds
-        const int64_t wg = base * s;
-        if (best_wg < 0 || (best_wg < target && wg > best_wg)) { best_nt = c; best_s = s; best_wg = wg; }
-        if (best_wg >= target) break;
+        for (int sp = 1; sp <= R; ++sp) {
+            if (R % sp != 0 || (want_s > 0 && want_s <= R && sp != want_s && R % want_s == 0)) continue;
+            const int64_t wg = base * sp, waves = (wg + target - 1) / target;
+            const double cost = (double)waves * ((double)(R / sp) * (6912.0 * c + (c == 4 ? 8000.0 : 3000.0)) + 12000.0) + red * sp;
+            if (best_nt == 0 || cost < best_cost) { best_nt = c; best_s = sp; best_cost = cost; }
+        }
     }
     if (best_nt == 0) return SEGM_E_SHAPE;
-    if (want_s > 0 && want_s <= R) best_s = want_s;
+    if (want_s > 0 && want_s <= R && R % want_s != 0) best_s = want_s;      // an uneven split on request (the kernel deals the rounds floor / ceil)
     *nt = best_nt; *splits = best_s;
     *workspace_elems = (int64_t)best_s * batch * cout * depth * height * width;
     return SEGM_OK;
@@ -300,6 +325,7 @@ extern "C" int segm_conv3d_k3_cube_fwd(const segm_conv3d_cube_args* a) {
     if (rc != SEGM_OK) return rc;
     if ((a->nt > 0 && nt != a->nt) || (a->splits > 0 && splits != a->splits)) return SEGM_E_SHAPE;
     if (!a->workspace || a->workspace_elems < need) return SEGM_E_WORKSPACE;
+    if (a->stats_partials && a->stats_nparts != (int64_t)a->depth * a->height * a->width / 512) return SEGM_E_WORKSPACE;
     const int64_t st[8] = {a->x_stride_b, a->x_stride_c, a->x_stride_z, a->x_stride_y, a->y_stride_b, a->y_stride_c, a->y_stride_z, a->y_stride_y};
     for (int64_t s : st)
         if (s % 8 != 0 || s <= 0) return SEGM_E_SHAPE;      // 16-byte aligned rows
@@ -333,12 +359,14 @@ extern "C" int segm_conv3d_k3_cube_fwd(const segm_conv3d_cube_args* a) {
     Q.n8 = (int64_t)a->batch * a->cout * a->depth * a->height * a->width / 8;
     const unsigned nb = (unsigned)((Q.n8 + 255) / 256);
     const bool acc = (a->flags & SEGM_CONV_CUBE_ACCUMULATE) != 0;
-    if (f16) {
-        if (acc) hipLaunchKernelGGL((conv3d_k3_cube_reduce_kernel<f16_t, true>), dim3(nb), dim3(256), 0, stream, Q);
-        else hipLaunchKernelGGL((conv3d_k3_cube_reduce_kernel<f16_t, false>), dim3(nb), dim3(256), 0, stream, Q);
-    } else {
-        if (acc) hipLaunchKernelGGL((conv3d_k3_cube_reduce_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, stream, Q);
-        else hipLaunchKernelGGL((conv3d_k3_cube_reduce_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, stream, Q);
-    }
+    Q.stats = a->stats_partials;
+#define SEGM_CUBE_RED(T, A_)                                                                                                     \
+    do {                                                                                                                          \
+        if (Q.stats) hipLaunchKernelGGL((conv3d_k3_cube_reduce_kernel<T, A_, true>), dim3(nb), dim3(256), 0, stream, Q);           \
+        else hipLaunchKernelGGL((conv3d_k3_cube_reduce_kernel<T, A_, false>), dim3(nb), dim3(256), 0, stream, Q);                  \
+    } while (0)
+    if (f16) { if (acc) SEGM_CUBE_RED(f16_t, true); else SEGM_CUBE_RED(f16_t, false); }
+    else { if (acc) SEGM_CUBE_RED(bf16_t, true); else SEGM_CUBE_RED(bf16_t, false); }
+#undef SEGM_CUBE_RED
     return (int)hipGetLastError();
 }

@@ -125,6 +125,7 @@ class Conv3dCubeArgs(C.Structure):
         ("x", C.c_void_p), ("x_stride_b", C.c_int64), ("x_stride_c", C.c_int64), ("x_stride_z", C.c_int64), ("x_stride_y", C.c_int64),
         ("y", C.c_void_p), ("y_stride_b", C.c_int64), ("y_stride_c", C.c_int64), ("y_stride_z", C.c_int64), ("y_stride_y", C.c_int64),
         ("w_image", C.c_void_p), ("bias", C.c_void_p), ("workspace", C.c_void_p), ("workspace_elems", C.c_int64), ("stream", C.c_void_p),
+        ("stats_partials", C.c_void_p), ("stats_nparts", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -281,6 +282,7 @@ EXPORTS = (
     "segm_causal_conv1d_fwd", "segm_causal_conv1d_bwd", "segm_causal_conv1d_bwd_workspace_bytes",
     "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes", "segm_conv3d_k3_fwd", "segm_conv3d_k3_fwd_stats_parts",
     "segm_conv3d_k3_fwd_cl", "segm_conv3d_k3_cl_pack_index", "segm_add3",
+    "segm_conv3d_k3_cube_fwd", "segm_conv3d_k3_cube_plan", "segm_conv3d_k3_cube_pack_index",
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add", "segm_depth_to_space2",
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",

@@ -1985,8 +1985,17 @@ def test_conv3d_k3_cube_forward_emulated(emu, shape, nt, splits):
     assert y.shape == ref.shape and y.dtype == torch.bfloat16
     assert (y.float() - ref).abs().max() <= tol
     # the same launch with another plan: the same sums in another association
-    y1 = ops_raw.conv3d_k3_cube_fwd(emu, x, img, cout, bias, nt=2 if cout % 64 == 0 else 3, splits=cin // 32)
+    y1, st = ops_raw.conv3d_k3_cube_fwd(emu, x, img, cout, bias, nt=2 if cout % 64 == 0 else 3, splits=cin // 32, want_stats=True)
     assert (y1.float() - ref).abs().max() <= tol
+    # the InstanceNorm partials of that launch: per (batch, channel) 512-voxel parts of {count, sum, sum of squares}
+    vol = D * H_ * W
+    assert st.shape == (B, cout, vol // 512, 4) and bool((st[..., 0] == 512).all())
+    r64 = ref.double().reshape(B, cout, vol // 512, 512)
+    assert (st[..., 1].double() - r64.sum(-1)).abs().max() <= 512 * tol
+    assert (st[..., 2].double() - (r64 * r64).sum(-1)).abs().max() <= 1e-2 * float((r64 * r64).sum(-1).max())
+    yn, m_, r_ = ops_raw.instnorm_fwd(emu, y1, None, "none", stats=st)
+    yn0, m0, r0 = ops_raw.instnorm_fwd(emu, y1, None, "none")
+    assert (m_ - m0).abs().max() <= 2e-2 * max(1.0, float(m0.abs().max())) and (r_ / r0 - 1).abs().max() <= 2e-2
     # a second part of the input accumulated in place; input and output with padded channel / batch strides
     x2 = torch.randn(B, cin, D, H_, W, generator=g).bfloat16()
     w2 = (0.1 * torch.randn(cout, cin, 3, 3, 3, generator=g)).bfloat16()

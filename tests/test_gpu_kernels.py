@@ -951,3 +951,47 @@ def test_add3_on_the_gpu(dtype):
         ref = (a.float() + b.float() + c.float()).to(dtype)
         assert torch.equal(ops_raw.add3(hip, a, b, c), ref)
         assert torch.equal(ops_raw.add3(hip, a, b, c, out=a), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,S,dtype", [(384, 384, 16, torch.bfloat16), (768, 768, 8, torch.bfloat16), (384, 192, 32, torch.bfloat16),
+                                              (192, 384, 16, torch.float16), (96, 192, 32, torch.bfloat16)])
+def test_conv3d_k3_cube_at_the_benchmarked_shapes(cin, cout, S, dtype):
+    """segm_conv3d_k3_cube_fwd (ABI 10) on the wide layers of the 8^3 / 16^3 / 32^3 levels, batch 2: forward (+ bias, + InstanceNorm
+    partials) and data gradient (the same launch on dy with the flipped image) against fp32 ATen on the same 16-bit operands - the
+    1e-2 of the largest reference value bound of the other convolution kernels' at-size tests; every plan (column tiles x splits) of
+    one layer gives the same result within that bound; run-to-run bit-identical (fixed-order reduction, no atomics); a second
+    input part accumulated in place"""
+    from segmamba_amd import lib as L, ops_raw
+    hip = L.get_lib()
+    dev = torch.device("cuda")
+    B = 2
+    g = torch.Generator(device=dev).manual_seed(cin + cout + S)
+    x = (0.5 * torch.randn(B, cin, S, S, S, device=dev, generator=g)).to(dtype)
+    w = (torch.randn(cout, cin, 3, 3, 3, device=dev, generator=g) / (27 * cin) ** 0.5).to(dtype)
+    bias = torch.randn(cout, device=dev, generator=g)
+    dy = (0.5 * torch.randn(B, cout, S, S, S, device=dev, generator=g)).to(dtype)
+    xr = x.float().requires_grad_()
+    yr = torch.nn.functional.conv3d(xr, w.float(), bias, 1, 1)
+    yr.backward(dy.float())
+    yr = yr.detach()
+    img, imgT = ops_raw.conv3d_cube_weight_image(hip, w), ops_raw.conv3d_cube_weight_image(hip, w, flipped=True)
+    y, st = ops_raw.conv3d_k3_cube_fwd(hip, x, img, cout, bias, want_stats=True)
+    assert float((y.float() - yr).abs().max()) <= 1e-2 * float(yr.abs().max())
+    assert torch.equal(y, ops_raw.conv3d_k3_cube_fwd(hip, x, img, cout, bias))
+    dx = ops_raw.conv3d_k3_cube_fwd(hip, dy, imgT, cin)
+    assert float((dx.float() - xr.grad).abs().max()) <= 1e-2 * float(xr.grad.abs().max())
+    # statistics partials -> the same mean / rstd as InstanceNorm's own pass over y
+    _, m1, r1 = ops_raw.instnorm_fwd(hip, y, None, "none", stats=st)
+    _, m0, r0 = ops_raw.instnorm_fwd(hip, y, None, "none")
+    assert float((m1 - m0).abs().max()) <= 1e-2 * max(1.0, float(m0.abs().max())) and float((r1 / r0 - 1).abs().max()) <= 1e-2
+    R = cin // 32
+    for nt in (2, 3, 4):
+        if cout % (32 * nt):
+            continue
+        for s in sorted({1, R, max(d for d in range(1, R + 1) if R % d == 0 and d <= 4)}):
+            yy = ops_raw.conv3d_k3_cube_fwd(hip, x, img, cout, bias, nt=nt, splits=s)
+            assert float((yy.float() - yr).abs().max()) <= 1e-2 * float(yr.abs().max()), (nt, s)
+    out = y.clone()
+    ops_raw.conv3d_k3_cube_fwd(hip, x, img, cout, None, out=out, accumulate=True)
+    assert float((out.float() - (2 * yr - bias.view(1, -1, 1, 1, 1))).abs().max()) <= 2e-2 * float(yr.abs().max())

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_abi_queries_without_gpu(built_lib):
     from segmamba_amd import lib
     l = lib.SegmLib(built_lib)
-    assert l.dll.segm_abi_version() == 9 == lib.header_abi_version()
+    assert l.dll.segm_abi_version() == 10 == lib.header_abi_version()
     assert l.dll.segm_status_string(-3).decode().startswith("dstate")
     # SegMamba stage 0: B=2, D=96, L=64^3 -> 256-step work items, 8-step checkpoints
     assert l.dll.segm_selective_scan_default_chunk(2, 96, 262144) == 256
