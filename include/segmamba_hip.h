@@ -368,6 +368,15 @@ int segm_conv3d_k3_cube_plan(int32_t batch, int32_t cin, int32_t cout, int32_t d
                              int32_t* nt, int32_t* splits, int64_t* workspace_elems);
 int segm_conv3d_k3_cube_pack_index(int32_t* out, int64_t n, int32_t cout_w, int32_t cin_w, int32_t flipped);
 
+/* The weight gradient of those layers (segm_conv3d_wgrad_args as for segm_conv3d_k3_wgrad): cin % 32 == 0, cout % 64 == 0, depth /
+ * height / width multiples of 8.  The contraction runs over voxels and NCDHW has x contiguous: both operands are staged in LDS in
+ * their native row layout (dY cube and X halo cube of 64 x 32 channels), a wave owns a 16 x 16 (co, ci) tile for all 27 taps, the
+ * kx = 0 / 2 operands are register shifts; cube ranges are split over workgroups and a second launch adds the partial sums in a
+ * fixed order.  Replaces what autograd asks cuDNN for in the backward of those Conv3d layers. */
+int segm_conv3d_k3_cube_wgrad(const segm_conv3d_wgrad_args* args);
+size_t segm_conv3d_k3_cube_wgrad_workspace_bytes(int32_t batch, int32_t cin, int32_t cout, int32_t depth, int32_t height,
+                                                 int32_t width);
+
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d (+ residual) (+ activation), forward and backward.
  * Replaces the torch.nn.InstanceNorm3d -> [+ residual] -> ReLU / LeakyReLU chains of the stem and decoder

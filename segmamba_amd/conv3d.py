@@ -57,6 +57,10 @@ _RES_FRONT = os.environ.get("SEGM_RES_FRONT", "1") == "1"
 # gradient; 2.5 - 6x over the row kernels / the vendor route there (profiles/r06_conv_cube_v2.txt).  SEGM_CONV_CUBE=0: the round-5 routing.
 _CUBE = os.environ.get("SEGM_CONV_CUBE", "1") == "1"
 _CUBE_MAX_WIDTH = int(os.environ.get("SEGM_CONV_CUBE_MAX_WIDTH", "32"))
+# ... and the weight gradients of the 8^3 level on segm_conv3d_k3_cube_wgrad (dY cube and X halo cube in LDS, a wave = a 16 x 16 (co, ci)
+# tile x 27 taps): 1.6 - 2.1x over the vendor route there - the last MIOpen convolution of the step
+_CUBE_WGRAD = os.environ.get("SEGM_CONV_CUBE_WGRAD", "1") == "1"
+_CUBE_WGRAD_MAX_WIDTH = int(os.environ.get("SEGM_CONV_CUBE_WGRAD_MAX_WIDTH", "8"))     # 16^3: level with the row kernel (profiles/r06_conv_cube_wgrad_v2.txt)
 
 
 def _time(fn: Callable[[], torch.Tensor], reps: int = 3) -> float:
@@ -100,6 +104,8 @@ def _table_choice(kind: str, width: int, variants) -> int:
     gradient; the 8^3 bottleneck layers (768 / 384 channels, 0.1 ms each) stay on the vendor GEMM route, where they are
     weight-bandwidth-bound GEMMs."""
     if kind == "wgrad":
+        if "cube" in variants:                           # only offered where it is the table's choice (_wgrad)
+            return variants.index("cube")
         return variants.index("mfma") if width >= 16 and "mfma" in variants else 0
     if "cube" in variants:                               # only offered where it is the table's choice (_cube_ok)
         return variants.index("cube")
@@ -309,6 +315,20 @@ def _wgrad_mfma(x, dy, w, pad, out_dtype=None):
     return ops_raw.conv3d_k3_wgrad(L.get_lib(), x, dy, out_dtype or w.dtype)
 
 
+def _cube_wgrad_ok(x, dy, w) -> bool:
+    """segm_conv3d_k3_cube_wgrad takes the layer AND the table prefers it (wide layers of width <= SEGM_CONV_CUBE_WGRAD_MAX_WIDTH;
+    with the tuner on, wherever it is supported)"""
+    from . import ops_raw
+    if not _CUBE_WGRAD or w.shape[2:] != (3, 3, 3) or not ops_raw.conv3d_cube_wgrad_supported(x, dy):
+        return False
+    return _TUNE or (x.shape[4] <= _CUBE_WGRAD_MAX_WIDTH and x.shape[1] * dy.shape[1] >= 96 * 192)
+
+
+def _wgrad_cube(x, dy, out_dtype):
+    from . import lib as L, ops_raw
+    return ops_raw.conv3d_k3_cube_wgrad(L.get_lib(), x, dy, out_dtype if out_dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32)
+
+
 def _mfma_wgrad_ok(x, dy, w) -> bool:
     from . import ops_raw
     if w.shape[2:] != (3, 3, 3) or w.dtype not in (torch.bfloat16, torch.float16, torch.float32) or \
@@ -401,7 +421,11 @@ def _wgrad(x, dy, w, pad, w_dtype):
     if mfma:
         cands.append(lambda: _wgrad_mfma(x, dy, w, pad, w_dtype))
         variants.append("mfma")
-    return _pick(_key("wgrad", x, w, mfma, w_dtype), cands, variants, x.shape[4]).to(w_dtype)
+    cube = _cube_wgrad_ok(x, dy, w)
+    if cube:
+        cands.append(lambda: _wgrad_cube(x, dy, w_dtype))
+        variants.append("cube")
+    return _pick(_key("wgrad", x, w, mfma, w_dtype, cube), cands, variants, x.shape[4]).to(w_dtype)
 
 
 class _ConvSame(torch.autograd.Function):

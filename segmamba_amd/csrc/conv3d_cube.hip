@@ -244,6 +244,166 @@ __global__ void __launch_bounds__(256) conv3d_k3_cube_reduce_kernel(CubeReduceDe
     *reinterpret_cast<cube_u32x4*>(dst) = packed;
 }
 
+// ---- weight gradient ---------------------------------------------------------------------------------------------------------
+// dW[co][ci][kz][ky][kx] = sum over (b, z, y, x) of dY[b, co, z, y, x] * X[b, ci, z + kz - 1, y + ky - 1, x + kx - 1] - per tap a GEMM whose
+// contraction runs over VOXELS, and NCDHW has x contiguous: an operand fragment (8 consecutive k per lane) is one x octet of a
+// row, for both operands - no transposition anywhere.  A workgroup (8 waves) owns 64 output x 32 input channels for ALL 27 taps
+// and walks a range of 8 x 8 x 8 cubes: per cube the dY cube (64 channels x 64 rows of 16 bytes) and the X halo cube (32 channels x
+// 10 x 10 rows + the two x neighbours of every row) are staged in LDS in their native row layout (channel pitches 1 056 / 1 632
+// bytes: conflict-free ds_read_b128 by the tools/lds_conflicts.py model), the next cube's rows already in registers.  Wave
+// (cot, cit) owns one 16 x 16 (co, ci) tile = 27 accumulator tiles; a k-step is four y-consecutive rows (lane group g = row): one
+// dY fragment and nine X fragments - rows (z + kz, y + ky) of the halo cube - each also shifted one element left / right for the
+// kx = 0 / 2 taps in registers (v_alignbyte with the neighbour elements), 27 MFMAs.  Partial sums per cube range in
+// [split][tap][co][ci] (64-byte segments per store); a second launch adds them in a fixed order into the weight's (co, ci, 27)
+// layout.  (Round 6 first tried both operands straight from global memory - correct, 90 - 170 TF/s: ten scattered 1-KB loads per
+// 27 MFMAs and wave is more than a CU's load path delivers, as round 5's direct variant of the row kernel had already shown.)
+// The row kernels of csrc/conv3d_wgrad.hip want rows of >= 16 voxels and 48-channel blocks: 260 - 370 TF/s at 16^3; the vendor
+// route ran the 8^3 layers at 90 - 200 TF/s.
+constexpr int kWgXP = 1632, kWgDP = 1056, kWgHP = 412;          // LDS bytes per channel: X rows, dY rows, X row neighbours
+constexpr int kWgLdsX = 32 * kWgXP, kWgLdsD = 64 * kWgDP, kWgLdsH = 32 * kWgHP;
+constexpr int kWgXIters = (3200 + 511) / 512, kWgDIters = 4096 / 512;
+
+struct CubeWgDev {
+    const char* x;   int64_t x_sb, x_sc, x_sz, x_sy;
+    const char* dy;  int64_t d_sb, d_sc, d_sz, d_sy;
+    float* part;                                         // [S][27][Cout][Cin]
+    int32_t B, Cin, Cout, D, H, W;
+    int32_t ncib, ntasks, S, ncubes, tz, ty, tx;         // 32-channel input blocks; (64 co, 32 ci) blocks; splits; cubes over the batch
+};
+
+struct CubeWgStage {
+    cube_u32x4 xr[kWgXIters];  uint32_t xh[kWgXIters];
+    cube_u32x4 dr[kWgDIters];
+};
+
+template <typename T, bool HALO>
+__global__ void __launch_bounds__(512, 1) conv3d_k3_cube_wgrad_kernel(CubeWgDev P) {
+    typedef typename Mfma16<T>::v8 frag8;
+    __shared__ __attribute__((aligned(16))) unsigned char s_x[kWgLdsX];
+    __shared__ __attribute__((aligned(16))) unsigned char s_d[kWgLdsD];
+    __shared__ __attribute__((aligned(16))) unsigned char s_h[HALO ? kWgLdsH : 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cot = wave & 3, cit = wave >> 2;
+    const int item = xcd_item(blockIdx.x, gridDim.x);
+    const int s = item / P.ntasks, t2 = item - s * P.ntasks;       // the blocks of one split next to each other: they read the same cubes
+    const int cob = t2 / P.ncib, cib = t2 - cob * P.ncib;
+    const int c0 = (int)((int64_t)s * P.ncubes / P.S), c1 = (int)((int64_t)(s + 1) * P.ncubes / P.S);
+    const int n16 = lane & 15, g = lane >> 4;
+    const int per_b = P.tz * P.ty * P.tx;
+
+    const uint16_t* xg = reinterpret_cast<const uint16_t*>(P.x) + (int64_t)(cib * 32) * P.x_sc;
+    const uint16_t* dg = reinterpret_cast<const uint16_t*>(P.dy) + (int64_t)(cob * 64) * P.d_sc;
+    CubeWgStage st;
+    auto load_cube = [&](int c) {
+        const int b = c / per_b, cc = c - b * per_b;
+        const int z0 = 8 * (cc / (P.ty * P.tx)), y0 = 8 * ((cc / P.tx) % P.ty), x0 = 8 * (cc % P.tx);
+#pragma unroll
+        for (int it = 0; it < kWgXIters; ++it) {
+            const int q = it * 512 + tid, ci = q / 100, row = q - ci * 100, zp = row / 10, yp = row - zp * 10;
+            const int gz = z0 - 1 + zp, gy = y0 - 1 + yp;
+            st.xr[it] = cube_u32x4{0, 0, 0, 0}; st.xh[it] = 0;
+            if (q < 3200 && gz >= 0 && gz < P.D && gy >= 0 && gy < P.H) {
+                const uint16_t* r = xg + (int64_t)b * P.x_sb + (int64_t)ci * P.x_sc + (int64_t)gz * P.x_sz + (int64_t)gy * P.x_sy + x0;
+                st.xr[it] = *reinterpret_cast<const cube_u32x4*>(r);
+                if (HALO) st.xh[it] = (x0 > 0 ? (uint32_t)r[-1] : 0u) | (x0 + 8 < P.W ? (uint32_t)r[8] << 16 : 0u);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kWgDIters; ++it) {
+            const int q = it * 512 + tid, co = q >> 6, row = q & 63;
+            st.dr[it] = *reinterpret_cast<const cube_u32x4*>(dg + (int64_t)b * P.d_sb + (int64_t)co * P.d_sc + (int64_t)(z0 + (row >> 3)) * P.d_sz +
+                                                            (int64_t)(y0 + (row & 7)) * P.d_sy + x0);
+        }
+    };
+    auto store_cube = [&]() {
+#pragma unroll
+        for (int it = 0; it < kWgXIters; ++it) {
+            const int q = it * 512 + tid, ci = q / 100, row = q - ci * 100;
+            if (q < 3200) {
+                *reinterpret_cast<cube_u32x4*>(s_x + ci * kWgXP + row * 16) = st.xr[it];
+                if (HALO) *reinterpret_cast<uint32_t*>(s_h + ci * kWgHP + row * 4) = st.xh[it];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kWgDIters; ++it) {
+            const int q = it * 512 + tid, co = q >> 6, row = q & 63;
+            *reinterpret_cast<cube_u32x4*>(s_d + co * kWgDP + row * 16) = st.dr[it];
+        }
+    };
+
+    mfma_f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = mfma_f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* a_base = s_d + (cot * 16 + n16) * kWgDP + g * 16;
+    const unsigned char* b_base = s_x + (cit * 16 + n16) * kWgXP + g * 16;
+    const unsigned char* h_base = s_h + (HALO ? (cit * 16 + n16) * kWgHP + g * 4 : 0);
+
+    if (c0 < c1) load_cube(c0);
+    for (int c = c0; c < c1; ++c) {
+        __syncthreads();
+        store_cube();
+        __syncthreads();
+        if (c + 1 < c1) load_cube(c + 1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {                     // k-step: plane z = j / 2, rows y = 4 (j & 1) + g
+            const int z = j >> 1, yb = 4 * (j & 1);
+            frag8 af = *reinterpret_cast<const frag8*>(a_base + (z * 8 + yb) * 16);
+#pragma unroll
+            for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int row = (z + kz) * 10 + yb + ky;
+                    const cube_u32x4 o = *reinterpret_cast<const cube_u32x4*>(b_base + row * 16);
+                    uint32_t lw = 0, rw = 0;
+                    if (HALO) {
+                        const uint32_t h = *reinterpret_cast<const uint32_t*>(h_base + row * 4);
+                        lw = h << 16; rw = h >> 16;
+                    }
+                    const uint32_t s01 = __builtin_amdgcn_alignbyte(o[1], o[0], 2), s12 = __builtin_amdgcn_alignbyte(o[2], o[1], 2),
+                                   s23 = __builtin_amdgcn_alignbyte(o[3], o[2], 2);
+                    const cube_u32x4 l = cube_u32x4{__builtin_amdgcn_alignbyte(o[0], lw, 2), s01, s12, s23};       // element i = x[i - 1]
+                    const cube_u32x4 r = cube_u32x4{s01, s12, s23, __builtin_amdgcn_alignbyte(rw, o[3], 2)};       // element i = x[i + 1]
+                    frag8 b0, b1, b2;
+                    memcpy(&b0, &l, 16); memcpy(&b1, &o, 16); memcpy(&b2, &r, 16);
+                    const int t = (kz * 3 + ky) * 3;
+                    acc[t] = Mfma16<T>::run(af, b0, acc[t]);
+                    acc[t + 1] = Mfma16<T>::run(af, b1, acc[t + 1]);
+                    acc[t + 2] = Mfma16<T>::run(af, b2, acc[t + 2]);
+                }
+            SEGM_SCHED_FENCE();
+        }
+    }
+    // D[row = co 4 g + i][col = ci n16]
+    float* pp = P.part + (int64_t)s * 27 * P.Cout * P.Cin + (int64_t)(cob * 64 + cot * 16 + 4 * g) * P.Cin + cib * 32 + cit * 16 + n16;
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pp[(int64_t)t * P.Cout * P.Cin + (int64_t)i * P.Cin] = acc[t][i];
+}
+
+// partial sums [S][27][n] (n = Cout * Cin pairs) -> dw[n][27]: a block sums 256 pairs tap by tap (coalesced along the pairs), turns the
+// (tap, pair) tile through LDS (pitch 27 dwords: odd, conflict-free) and writes 256 * 27 contiguous values.  (A thread per pair writing its
+// 27 values directly put 4-byte pieces 108 bytes apart: the reduction then took 4 - 10 times as long as the MFMA launch.)
+template <typename OUT>
+__global__ void __launch_bounds__(256) conv3d_k3_cube_wgrad_reduce_kernel(const float* __restrict__ part, OUT* __restrict__ dw, int S, int64_t n) {
+    __shared__ float s_t[256 * 27];
+    const int64_t i0 = (int64_t)blockIdx.x * 256;
+    const int tid = threadIdx.x;
+    const int cnt = n - i0 < 256 ? (int)(n - i0) : 256;
+    if (tid < cnt) {
+#pragma unroll 3
+        for (int t = 0; t < 27; ++t) {
+            float v = 0.f;
+            for (int s = 0; s < S; ++s) v += part[((int64_t)s * 27 + t) * n + i0 + tid];
+            s_t[tid * 27 + t] = v;
+        }
+    }
+    __syncthreads();
+    OUT* o = dw + i0 * 27;
+    for (int e = tid; e < cnt * 27; e += 256) o[e] = from_f32<OUT>(s_t[e]);
+}
+
 static int cube_nt(int cout, int forced) {                 // column tiles per wave the layer can use: 4 (NB = 128), 3 (96), 2 (64)
     if (forced >= 2 && forced <= 4 && cout % (32 * forced) == 0) return forced;
     return 0;
@@ -368,5 +528,74 @@ extern "C" int segm_conv3d_k3_cube_fwd(const segm_conv3d_cube_args* a) {
     if (f16) { if (acc) SEGM_CUBE_RED(f16_t, true); else SEGM_CUBE_RED(f16_t, false); }
     else { if (acc) SEGM_CUBE_RED(bf16_t, true); else SEGM_CUBE_RED(bf16_t, false); }
 #undef SEGM_CUBE_RED
+    return (int)hipGetLastError();
+}
+
+static void cube_wgrad_plan(int batch, int cin, int cout, int depth, int height, int width, int* splits, int* ncubes) {
+    const int64_t cubes = (int64_t)batch * (depth / 8) * (height / 8) * (width / 8);
+    const int64_t tasks = (int64_t)(cout / 64) * (cin / 32);
+    static const int target = [] { const char* e = getenv("SEGM_CUBE_WGRAD_WORKGROUPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    // as many splits as fill the CUs once, never more than cubes; with more tasks than CUs no split
+    int64_t sp = target / tasks;
+    if (sp > cubes) sp = cubes;
+    if (sp < 1) sp = 1;
+    *splits = (int)sp;
+    *ncubes = (int)cubes;
+}
+
+static bool cube_wgrad_shape_ok(int batch, int cin, int cout, int depth, int height, int width) {
+    return batch > 0 && cin > 0 && cout > 0 && depth > 0 && height > 0 && width > 0 && cin % 32 == 0 && cout % 64 == 0 && depth % 8 == 0 &&
+           height % 8 == 0 && width % 8 == 0 && (int64_t)batch * (depth / 8) * (height / 8) * (width / 8) < ((int64_t)1 << 24) &&
+           (int64_t)cin * cout * 27 < ((int64_t)1 << 31);
+}
+
+extern "C" size_t segm_conv3d_k3_cube_wgrad_workspace_bytes(int32_t batch, int32_t cin, int32_t cout, int32_t depth, int32_t height, int32_t width) {
+    if (!cube_wgrad_shape_ok(batch, cin, cout, depth, height, width)) return 0;
+    int sp, nc;
+    cube_wgrad_plan(batch, cin, cout, depth, height, width, &sp, &nc);
+    return (size_t)sp * 27 * cout * cin * sizeof(float);
+}
+
+// the weight gradient of the same layers (same argument block as segm_conv3d_k3_wgrad): cin % 32 == 0, cout % 64 == 0, depth /
+// height / width multiples of 8
+extern "C" int segm_conv3d_k3_cube_wgrad(const segm_conv3d_wgrad_args* a) {
+    if (!a) return SEGM_E_NULL;
+    if (!a->x || !a->dy || !a->dw) return SEGM_E_NULL;
+    if (a->dtype != SEGM_BF16 && a->dtype != SEGM_F16) return SEGM_E_DTYPE;
+    if (a->dw_dtype != SEGM_BF16 && a->dw_dtype != SEGM_F16 && a->dw_dtype != SEGM_F32) return SEGM_E_DTYPE;
+    if (!cube_wgrad_shape_ok(a->batch, a->cin, a->cout, a->depth, a->height, a->width)) return SEGM_E_SHAPE;
+    const int64_t st[8] = {a->x_stride_b, a->x_stride_c, a->x_stride_z, a->x_stride_y, a->dy_stride_b, a->dy_stride_c, a->dy_stride_z, a->dy_stride_y};
+    for (int64_t v : st)
+        if (v % 8 != 0 || v <= 0) return SEGM_E_SHAPE;
+    if (((uintptr_t)a->x & 15) || ((uintptr_t)a->dy & 15) || ((uintptr_t)a->workspace & 15)) return SEGM_E_SHAPE;
+    int sp, nc;
+    cube_wgrad_plan(a->batch, a->cin, a->cout, a->depth, a->height, a->width, &sp, &nc);
+    const size_t need = (size_t)sp * 27 * a->cout * a->cin * sizeof(float);
+    if (!a->workspace || a->workspace_bytes < need) return SEGM_E_WORKSPACE;
+    CubeWgDev P;
+    memset(&P, 0, sizeof(P));
+    P.x = (const char*)a->x; P.x_sb = a->x_stride_b; P.x_sc = a->x_stride_c; P.x_sz = a->x_stride_z; P.x_sy = a->x_stride_y;
+    P.dy = (const char*)a->dy; P.d_sb = a->dy_stride_b; P.d_sc = a->dy_stride_c; P.d_sz = a->dy_stride_z; P.d_sy = a->dy_stride_y;
+    P.part = (float*)a->workspace;
+    P.B = a->batch; P.Cin = a->cin; P.Cout = a->cout; P.D = a->depth; P.H = a->height; P.W = a->width;
+    P.ncib = a->cin / 32; P.ntasks = (a->cout / 64) * P.ncib; P.S = sp; P.ncubes = nc;
+    P.tz = a->depth / 8; P.ty = a->height / 8; P.tx = a->width / 8;
+    hipStream_t stream = (hipStream_t)a->stream;
+    const unsigned nwg = (unsigned)((int64_t)P.ntasks * sp);
+    const bool halo = a->width > 8, f16 = a->dtype == SEGM_F16;
+    if (f16) {
+        if (halo) hipLaunchKernelGGL((conv3d_k3_cube_wgrad_kernel<f16_t, true>), dim3(nwg), dim3(512), 0, stream, P);
+        else hipLaunchKernelGGL((conv3d_k3_cube_wgrad_kernel<f16_t, false>), dim3(nwg), dim3(512), 0, stream, P);
+    } else {
+        if (halo) hipLaunchKernelGGL((conv3d_k3_cube_wgrad_kernel<bf16_t, true>), dim3(nwg), dim3(512), 0, stream, P);
+        else hipLaunchKernelGGL((conv3d_k3_cube_wgrad_kernel<bf16_t, false>), dim3(nwg), dim3(512), 0, stream, P);
+    }
+    int err = (int)hipGetLastError();
+    if (err) return err;
+    const int64_t n = (int64_t)a->cout * a->cin;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (a->dw_dtype == SEGM_F32) hipLaunchKernelGGL((conv3d_k3_cube_wgrad_reduce_kernel<float>), dim3(nb), dim3(256), 0, stream, (const float*)a->workspace, (float*)a->dw, sp, n);
+    else if (a->dw_dtype == SEGM_F16) hipLaunchKernelGGL((conv3d_k3_cube_wgrad_reduce_kernel<f16_t>), dim3(nb), dim3(256), 0, stream, (const float*)a->workspace, (f16_t*)a->dw, sp, n);
+    else hipLaunchKernelGGL((conv3d_k3_cube_wgrad_reduce_kernel<bf16_t>), dim3(nb), dim3(256), 0, stream, (const float*)a->workspace, (bf16_t*)a->dw, sp, n);
     return (int)hipGetLastError();
 }

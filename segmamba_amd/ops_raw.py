@@ -628,6 +628,44 @@ def conv3d_k3_cube_fwd(lib: L.SegmLib, x: torch.Tensor, w_image: torch.Tensor, c
     return (y, stats) if want_stats else y
 
 
+def conv3d_cube_wgrad_supported(x: torch.Tensor, dy: torch.Tensor) -> bool:
+    if x.dim() != 5 or dy.dim() != 5 or x.dtype not in (torch.bfloat16, torch.float16) or dy.dtype != x.dtype:
+        return False
+    if x.shape[0] != dy.shape[0] or x.shape[2:] != dy.shape[2:] or x.shape[1] % 32 or dy.shape[1] % 64 or x.shape[2] % 8 or x.shape[3] % 8 or x.shape[4] % 8:
+        return False
+    for t in (x, dy):
+        if t.stride(4) != 1 or any(t.stride(i) % 8 or t.stride(i) <= 0 for i in range(4)) or t.data_ptr() % 16:
+            return False
+    return True
+
+
+def conv3d_k3_cube_wgrad(lib: L.SegmLib, x: torch.Tensor, dy: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+    """dW (Cout, Cin, 3, 3, 3) of a stride-1 pad-1 3x3x3 convolution through segm_conv3d_k3_cube_wgrad; x (B, Cin, D, H, W),
+    dy (B, Cout, D, H, W), bf16 / fp16"""
+    if not conv3d_cube_wgrad_supported(x, dy):
+        raise RuntimeError("conv3d_k3_cube_wgrad: unsupported shape / dtype / layout")
+    B, cin, D, H, W = x.shape
+    cout = dy.shape[1]
+    a = L.Conv3dWgradArgs()
+    a.batch, a.cin, a.cout, a.depth, a.height, a.width = B, cin, cout, D, H, W
+    a.dtype = L.dtype_code(x)
+    a.dw_dtype = L.dtype_code(torch.empty(0, dtype=out_dtype))
+    a.x, a.dy = x.data_ptr(), dy.data_ptr()
+    a.x_stride_b, a.x_stride_c, a.x_stride_z, a.x_stride_y = x.stride()[:4]
+    a.dy_stride_b, a.dy_stride_c, a.dy_stride_z, a.dy_stride_y = dy.stride()[:4]
+    dw = torch.empty(cout, cin, 3, 3, 3, dtype=out_dtype, device=x.device)
+    ws_bytes = lib.dll.segm_conv3d_k3_cube_wgrad_workspace_bytes(B, cin, cout, D, H, W)
+    key = ("wgrad", str(x.device))
+    ws = _cube_ws.get(key)
+    if ws is None or ws.numel() * 4 < ws_bytes:
+        ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=x.device)
+        _cube_ws[key] = ws
+    a.dw, a.workspace, a.workspace_bytes = dw.data_ptr(), ws.data_ptr(), ws.numel() * 4
+    a.stream = L.stream_handle(x)
+    lib.check(lib.dll.segm_conv3d_k3_cube_wgrad(a), "conv3d_k3_cube_wgrad")
+    return dw
+
+
 # ---------------------------------------------------------------------------------------------------------
 # InstanceNorm3d (+ residual) (+ activation)
 # ---------------------------------------------------------------------------------------------------------

@@ -2030,3 +2030,31 @@ def test_conv3d_k3_cube_dgrad_and_errors_emulated(emu):
         ops_raw.conv3d_k3_cube_fwd(emu, xs, img, 96, nt=4)                          # 96 channels cannot run 128-channel blocks
     with pytest.raises(RuntimeError):
         ops_raw.conv3d_k3_cube_fwd(emu, xs, img, 96, splits=3)                      # only two rounds to split
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 64, 8, 8, 8), (2, 32, 64, 8, 8, 16), (1, 64, 128, 8, 16, 24), (3, 32, 64, 16, 8, 8)])
+def test_conv3d_k3_cube_wgrad_emulated(emu, shape):
+    """segm_conv3d_k3_cube_wgrad: 64 x 32 (co, ci) channels x 27 taps per workgroup, dY cube and X halo cube in LDS in their row
+    layout, the kx = 0 / 2 operands by register shifts with the neighbour elements (interior octets of wider rows: left and right
+    neighbours; 8-wide rows: padding), cube ranges split over workgroups + fixed-order reduction; against autograd on the 16-bit
+    operands, fp32 and 16-bit results, strided inputs"""
+    B, cin, cout, D, H_, W = shape
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, cin, D, H_, W, generator=g).bfloat16()
+    dy = torch.randn(B, cout, D, H_, W, generator=g).bfloat16()
+    w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    torch.nn.functional.conv3d(x.float(), w, None, 1, 1).backward(dy.float())
+    ref = w.grad
+    tol = 1e-2 * float(ref.abs().max())
+    assert ops_raw.conv3d_cube_wgrad_supported(x, dy)
+    dw = ops_raw.conv3d_k3_cube_wgrad(emu, x, dy, torch.float32)
+    assert dw.shape == ref.shape and (dw - ref).abs().max() <= 1e-3 * float(ref.abs().max())        # fp32 accumulation of exact products
+    dwb = ops_raw.conv3d_k3_cube_wgrad(emu, x, dy, torch.bfloat16)
+    assert dwb.dtype == torch.bfloat16 and (dwb.float() - ref).abs().max() <= tol
+    xp = torch.zeros(B, cin + 3, D, H_, W + 8, dtype=torch.bfloat16)[:, :cin, :, :, :W]
+    xp.copy_(x)
+    dyp = torch.zeros(B + 1, cout, D, H_, W + 16, dtype=torch.bfloat16)[:B, :, :, :, :W]
+    dyp.copy_(dy)
+    assert torch.equal(ops_raw.conv3d_k3_cube_wgrad(emu, xp, dyp, torch.float32), dw)
+    assert not ops_raw.conv3d_cube_wgrad_supported(x[:, :, :, :, :4], dy[:, :, :, :, :4])
+    assert not ops_raw.conv3d_cube_wgrad_supported(x[:, :16], dy)

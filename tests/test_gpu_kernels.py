@@ -995,3 +995,28 @@ def test_conv3d_k3_cube_at_the_benchmarked_shapes(cin, cout, S, dtype):
     out = y.clone()
     ops_raw.conv3d_k3_cube_fwd(hip, x, img, cout, None, out=out, accumulate=True)
     assert float((out.float() - (2 * yr - bias.view(1, -1, 1, 1, 1))).abs().max()) <= 2e-2 * float(yr.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,S,dtype", [(384, 384, 8, torch.bfloat16), (768, 768, 8, torch.bfloat16), (384, 768, 8, torch.float16),
+                                              (384, 384, 16, torch.bfloat16), (192, 192, 32, torch.bfloat16)])
+def test_conv3d_k3_cube_wgrad_at_the_benchmarked_shapes(cin, cout, S, dtype):
+    """segm_conv3d_k3_cube_wgrad, batch 2, against fp32 ATen's weight gradient on the same 16-bit operands: fp32 result within 1e-3
+    of the largest reference value (fp32 accumulation of exact products, another order), 16-bit result within the 1e-2 bound of the
+    other kernels; run-to-run bit-identical; and through the dispatcher (conv3d._wgrad) at the 8^3 level"""
+    from segmamba_amd import conv3d as C, lib as L, ops_raw
+    hip = L.get_lib()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(cin + cout + S)
+    x = (0.5 * torch.randn(2, cin, S, S, S, device=dev, generator=g)).to(dtype)
+    dy = (0.5 * torch.randn(2, cout, S, S, S, device=dev, generator=g)).to(dtype)
+    w = torch.zeros(cout, cin, 3, 3, 3, device=dev)
+    ref = torch.ops.aten.convolution_backward(dy.float(), x.float(), w, None, [1] * 3, [1] * 3, [1] * 3, False, [0] * 3, 1, [False, True, False])[1]
+    sc = float(ref.abs().max())
+    dw = ops_raw.conv3d_k3_cube_wgrad(hip, x, dy, torch.float32)
+    assert float((dw - ref).abs().max()) <= 1e-3 * sc
+    assert torch.equal(dw, ops_raw.conv3d_k3_cube_wgrad(hip, x, dy, torch.float32))
+    assert float((ops_raw.conv3d_k3_cube_wgrad(hip, x, dy, dtype).float() - ref).abs().max()) <= 1e-2 * sc
+    if S == 8:
+        got = C._wgrad(x, dy, w.to(dtype), 1, torch.float32)
+        assert got.dtype == torch.float32 and float((got - ref).abs().max()) <= 1e-3 * sc
