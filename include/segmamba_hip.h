@@ -469,6 +469,23 @@ typedef struct segm_add3_args {
 int segm_add3(const segm_add3_args* args);
 
 /* ------------------------------------------------------------------------------------------------
+ * ABI 10: out[i] = src[map(i)] for 16-bit elements, i < count (count % 8 == 0, out and map 16-byte aligned) - the one gather per
+ * training step that refreshes every re-arranged 16-bit copy of a weight (fragment images, packed blocks; the reference casts and
+ * re-lays-out nothing: torch.nn.Conv3d -> cuDNN reads the fp32 / autocast weight as it is).  mode 0: map = int32 source index per
+ * element; mode 1: map = int32 (first index, step) per group of eight consecutive elements (an arithmetic progression in src).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segm_gather16_args {
+    int64_t count;
+    int32_t mode, reserved;
+    const void* src;
+    const int32_t* map;
+    void* out;
+    void* stream;
+} segm_gather16_args;
+
+int segm_gather16(const segm_gather16_args* args);
+
+/* ------------------------------------------------------------------------------------------------
  * Volume -> tokens with LayerNorm over the channels, forward and backward.
  * Replaces `x.reshape(B, C, n).transpose(-1, -2)` followed by `nn.LayerNorm(C)` at the entry of a Mamba layer
  * (reference model_segmamba/segmamba.py:60-66): a transposing copy, an fp32 LayerNorm and a cast in the reference.

@@ -57,10 +57,11 @@ _RES_FRONT = os.environ.get("SEGM_RES_FRONT", "1") == "1"
 # gradient; 2.5 - 6x over the row kernels / the vendor route there (profiles/r06_conv_cube_v2.txt).  SEGM_CONV_CUBE=0: the round-5 routing.
 _CUBE = os.environ.get("SEGM_CONV_CUBE", "1") == "1"
 _CUBE_MAX_WIDTH = int(os.environ.get("SEGM_CONV_CUBE_MAX_WIDTH", "32"))
-# ... and the weight gradients of the 8^3 level on segm_conv3d_k3_cube_wgrad (dY cube and X halo cube in LDS, a wave = a 16 x 16 (co, ci)
-# tile x 27 taps): 1.6 - 2.1x over the vendor route there - the last MIOpen convolution of the step
+# ... and the weight gradients of the 8^3 level and of the 384-channel layers at 16^3 on segm_conv3d_k3_cube_wgrad (dY cube and X halo
+# cube in LDS, a wave = a 16 x 16 (co, ci) tile x 27 taps): 2.1 - 2.6x over the vendor route at 8^3 - the last MIOpen convolution of the
+# step -, 1.7 - 1.8x over the row kernel at 384 -> 384 @16^3; behind it below 384 channels and at 32^3 (profiles/r06_conv_cube_wgrad_v5.txt)
 _CUBE_WGRAD = os.environ.get("SEGM_CONV_CUBE_WGRAD", "1") == "1"
-_CUBE_WGRAD_MAX_WIDTH = int(os.environ.get("SEGM_CONV_CUBE_WGRAD_MAX_WIDTH", "8"))     # 16^3: level with the row kernel (profiles/r06_conv_cube_wgrad_v2.txt)
+_CUBE_WGRAD_MAX_WIDTH = int(os.environ.get("SEGM_CONV_CUBE_WGRAD_MAX_WIDTH", "16"))
 
 
 def _time(fn: Callable[[], torch.Tensor], reps: int = 3) -> float:
@@ -316,12 +317,15 @@ def _wgrad_mfma(x, dy, w, pad, out_dtype=None):
 
 
 def _cube_wgrad_ok(x, dy, w) -> bool:
-    """segm_conv3d_k3_cube_wgrad takes the layer AND the table prefers it (wide layers of width <= SEGM_CONV_CUBE_WGRAD_MAX_WIDTH;
-    with the tuner on, wherever it is supported)"""
+    """segm_conv3d_k3_cube_wgrad takes the layer AND the table prefers it (8^3: every wide layer; 16^3: from 384 x 384 channels; with
+    the tuner on, wherever it is supported)"""
     from . import ops_raw
     if not _CUBE_WGRAD or w.shape[2:] != (3, 3, 3) or not ops_raw.conv3d_cube_wgrad_supported(x, dy):
         return False
-    return _TUNE or (x.shape[4] <= _CUBE_WGRAD_MAX_WIDTH and x.shape[1] * dy.shape[1] >= 96 * 192)
+    if _TUNE:
+        return True
+    width, prod = x.shape[4], x.shape[1] * dy.shape[1]
+    return width <= _CUBE_WGRAD_MAX_WIDTH and ((width <= 8 and prod >= 96 * 192) or (width <= 16 and prod >= 384 * 384))
 
 
 def _wgrad_cube(x, dy, out_dtype):

@@ -249,19 +249,19 @@ __global__ void __launch_bounds__(256) conv3d_k3_cube_reduce_kernel(CubeReduceDe
 // contraction runs over VOXELS, and NCDHW has x contiguous: an operand fragment (8 consecutive k per lane) is one x octet of a
 // row, for both operands - no transposition anywhere.  A workgroup (8 waves) owns 64 output x 32 input channels for ALL 27 taps
 // and walks a range of 8 x 8 x 8 cubes: per cube the dY cube (64 channels x 64 rows of 16 bytes) and the X halo cube (32 channels x
-// 10 x 10 rows + the two x neighbours of every row) are staged in LDS in their native row layout (channel pitches 1 056 / 1 632
-// bytes: conflict-free ds_read_b128 by the tools/lds_conflicts.py model), the next cube's rows already in registers.  Wave
-// (cot, cit) owns one 16 x 16 (co, ci) tile = 27 accumulator tiles; a k-step is four y-consecutive rows (lane group g = row): one
-// dY fragment and nine X fragments - rows (z + kz, y + ky) of the halo cube - each also shifted one element left / right for the
-// kx = 0 / 2 taps in registers (v_alignbyte with the neighbour elements), 27 MFMAs.  Partial sums per cube range in
+// 10 x 10 rows) are staged in LDS in their native row layout (channel pitches 1 056 / 1 632 bytes: conflict-free ds_read_b128 by
+// the tools/lds_conflicts.py model; + the two x neighbours of every dY row), the next cube's rows already in registers.  Wave
+// (cot, cit) owns one 16 x 16 (co, ci) tile = 27 accumulator tiles; a k-step is four y-consecutive rows (lane group g = row): ONE dY
+// fragment, shifted one element left / right in registers for the kx = 2 / 0 taps (v_alignbyte with the neighbour elements), and
+// nine X fragments - rows (z + kz, y + ky) of the halo cube as they lie -, 27 MFMAs.  Partial sums per cube range in
 // [split][tap][co][ci] (64-byte segments per store); a second launch adds them in a fixed order into the weight's (co, ci, 27)
 // layout.  (Round 6 first tried both operands straight from global memory - correct, 90 - 170 TF/s: ten scattered 1-KB loads per
 // 27 MFMAs and wave is more than a CU's load path delivers, as round 5's direct variant of the row kernel had already shown.)
 // The row kernels of csrc/conv3d_wgrad.hip want rows of >= 16 voxels and 48-channel blocks: 260 - 370 TF/s at 16^3; the vendor
 // route ran the 8^3 layers at 90 - 200 TF/s.
-constexpr int kWgXP = 1632, kWgDP = 1056, kWgHP = 412;          // LDS bytes per channel: X rows, dY rows, X row neighbours
-constexpr int kWgLdsX = 32 * kWgXP, kWgLdsD = 64 * kWgDP, kWgLdsH = 32 * kWgHP;
-constexpr int kWgXIters = (3200 + 511) / 512, kWgDIters = 4096 / 512;
+constexpr int kWgXP = 1632, kWgDP = 1056, kWgHP = 260;          // LDS bytes per channel: X rows, dY rows, dY row neighbours
+constexpr int kWgLdsX = 32 * kWgXP, kWgLdsD = 64 * kWgDP, kWgLdsH = 64 * kWgHP;
+constexpr int kWgXIters = 7, kWgDIters = 8;               // 16 x 7 >= 100 halo rows per channel; 8 planes of the dY cube
 
 struct CubeWgDev {
     const char* x;   int64_t x_sb, x_sc, x_sz, x_sy;
@@ -272,8 +272,8 @@ struct CubeWgDev {
 };
 
 struct CubeWgStage {
-    cube_u32x4 xr[kWgXIters];  uint32_t xh[kWgXIters];
-    cube_u32x4 dr[kWgDIters];
+    cube_u32x4 xr[kWgXIters];
+    cube_u32x4 dr[kWgDIters];  uint32_t dh[kWgDIters];
 };
 
 template <typename T, bool HALO>
@@ -295,40 +295,42 @@ __global__ void __launch_bounds__(512, 1) conv3d_k3_cube_wgrad_kernel(CubeWgDev 
     const uint16_t* xg = reinterpret_cast<const uint16_t*>(P.x) + (int64_t)(cib * 32) * P.x_sc;
     const uint16_t* dg = reinterpret_cast<const uint16_t*>(P.dy) + (int64_t)(cob * 64) * P.d_sc;
     CubeWgStage st;
+    // staging map (index arithmetic kept trivial - a general (channel, row) = divmod(q, 100) map cost 500 instructions per thread and cube):
+    // X: thread -> channel tid / 16, rows tid % 16 + 16 it of the 100 halo rows;  dY: thread -> channel tid / 8, row y = tid % 8 of plane it
+    const int x_ci = tid >> 4, x_r0 = tid & 15, d_co = tid >> 3, d_y = tid & 7;
+    const uint16_t* xt = xg + (int64_t)x_ci * P.x_sc;
+    const uint16_t* dt = dg + (int64_t)d_co * P.d_sc + (int64_t)d_y * P.d_sy;
     auto load_cube = [&](int c) {
         const int b = c / per_b, cc = c - b * per_b;
         const int z0 = 8 * (cc / (P.ty * P.tx)), y0 = 8 * ((cc / P.tx) % P.ty), x0 = 8 * (cc % P.tx);
+        const uint16_t* xc = xt + (int64_t)b * P.x_sb + (int64_t)(z0 - 1) * P.x_sz + (int64_t)(y0 - 1) * P.x_sy + x0;
 #pragma unroll
         for (int it = 0; it < kWgXIters; ++it) {
-            const int q = it * 512 + tid, ci = q / 100, row = q - ci * 100, zp = row / 10, yp = row - zp * 10;
+            const int row = x_r0 + 16 * it, zp = row / 10, yp = row - zp * 10;
             const int gz = z0 - 1 + zp, gy = y0 - 1 + yp;
-            st.xr[it] = cube_u32x4{0, 0, 0, 0}; st.xh[it] = 0;
-            if (q < 3200 && gz >= 0 && gz < P.D && gy >= 0 && gy < P.H) {
-                const uint16_t* r = xg + (int64_t)b * P.x_sb + (int64_t)ci * P.x_sc + (int64_t)gz * P.x_sz + (int64_t)gy * P.x_sy + x0;
-                st.xr[it] = *reinterpret_cast<const cube_u32x4*>(r);
-                if (HALO) st.xh[it] = (x0 > 0 ? (uint32_t)r[-1] : 0u) | (x0 + 8 < P.W ? (uint32_t)r[8] << 16 : 0u);
-            }
+            st.xr[it] = cube_u32x4{0, 0, 0, 0};
+            if (row < 100 && gz >= 0 && gz < P.D && gy >= 0 && gy < P.H)
+                st.xr[it] = *reinterpret_cast<const cube_u32x4*>(xc + (int64_t)zp * P.x_sz + (int64_t)yp * P.x_sy);
         }
+        const uint16_t* dc = dt + (int64_t)b * P.d_sb + (int64_t)z0 * P.d_sz + (int64_t)y0 * P.d_sy + x0;
 #pragma unroll
         for (int it = 0; it < kWgDIters; ++it) {
-            const int q = it * 512 + tid, co = q >> 6, row = q & 63;
-            st.dr[it] = *reinterpret_cast<const cube_u32x4*>(dg + (int64_t)b * P.d_sb + (int64_t)co * P.d_sc + (int64_t)(z0 + (row >> 3)) * P.d_sz +
-                                                            (int64_t)(y0 + (row & 7)) * P.d_sy + x0);
+            const uint16_t* r = dc + (int64_t)it * P.d_sz;
+            st.dr[it] = *reinterpret_cast<const cube_u32x4*>(r);
+            if (HALO) st.dh[it] = (x0 > 0 ? (uint32_t)r[-1] : 0u) | (x0 + 8 < P.W ? (uint32_t)r[8] << 16 : 0u);
         }
     };
     auto store_cube = [&]() {
 #pragma unroll
         for (int it = 0; it < kWgXIters; ++it) {
-            const int q = it * 512 + tid, ci = q / 100, row = q - ci * 100;
-            if (q < 3200) {
-                *reinterpret_cast<cube_u32x4*>(s_x + ci * kWgXP + row * 16) = st.xr[it];
-                if (HALO) *reinterpret_cast<uint32_t*>(s_h + ci * kWgHP + row * 4) = st.xh[it];
-            }
+            const int row = x_r0 + 16 * it;
+            if (row < 100) *reinterpret_cast<cube_u32x4*>(s_x + x_ci * kWgXP + row * 16) = st.xr[it];
         }
 #pragma unroll
         for (int it = 0; it < kWgDIters; ++it) {
-            const int q = it * 512 + tid, co = q >> 6, row = q & 63;
-            *reinterpret_cast<cube_u32x4*>(s_d + co * kWgDP + row * 16) = st.dr[it];
+            const int row = it * 8 + d_y;
+            *reinterpret_cast<cube_u32x4*>(s_d + d_co * kWgDP + row * 16) = st.dr[it];
+            if (HALO) *reinterpret_cast<uint32_t*>(s_h + d_co * kWgHP + row * 4) = st.dh[it];
         }
     };
 
@@ -337,41 +339,67 @@ __global__ void __launch_bounds__(512, 1) conv3d_k3_cube_wgrad_kernel(CubeWgDev 
     for (int t = 0; t < 27; ++t) acc[t] = mfma_f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned char* a_base = s_d + (cot * 16 + n16) * kWgDP + g * 16;
     const unsigned char* b_base = s_x + (cit * 16 + n16) * kWgXP + g * 16;
-    const unsigned char* h_base = s_h + (HALO ? (cit * 16 + n16) * kWgHP + g * 4 : 0);
+    const unsigned char* h_base = s_h + (HALO ? (cot * 16 + n16) * kWgHP + g * 4 : 0);
 
+#ifndef SEGM_WG_NOPF
     if (c0 < c1) load_cube(c0);
+#endif
     for (int c = c0; c < c1; ++c) {
+#ifdef SEGM_WG_NOPF                                       /* experiment: no register prefetch of the next cube (67 registers less) */
+        load_cube(c);
+#endif
         __syncthreads();
         store_cube();
         __syncthreads();
+#if !defined(SEGM_WG_NOPF) && !defined(SEGM_WG_ABL_NOLOAD)
         if (c + 1 < c1) load_cube(c + 1);
+#endif
+        // 16 k-steps (plane z = j / 2, rows y = 4 (j & 1) + g): the dY fragment and its two one-element shifts (the kx = 2 / 0 taps:
+        // sum_x dY[x] X[x + kx - 1] = sum_x' dY[x' - kx + 1] X[x'] - shifting the ONE dY fragment of a k-step instead of its nine X
+        // fragments: five funnel shifts per 27 MFMAs instead of 45), then nine X fragments - rows (z + kz, y + ky) of the halo cube,
+        // read as they lie - with three MFMAs each.  X fragments are requested two reads ahead (ring of three), the dY fragment one
+        // k-step ahead; the fences keep the compiler from hoisting more reads than the rings hold.
+        cube_u32x4 ring_o[3];
+        auto rd = [&](int j, int kk, int slot) {
+            const int row = ((j >> 1) + kk / 3) * 10 + 4 * (j & 1) + kk % 3;
+            ring_o[slot] = *reinterpret_cast<const cube_u32x4*>(b_base + row * 16);
+        };
+        cube_u32x4 a_next;
+        uint32_t h_next = 0;
+        auto rd_a = [&](int j) {
+            const int row = (j >> 1) * 8 + 4 * (j & 1);
+            a_next = *reinterpret_cast<const cube_u32x4*>(a_base + row * 16);
+            if (HALO) h_next = *reinterpret_cast<const uint32_t*>(h_base + row * 4);
+        };
+        rd_a(0);
+        rd(0, 0, 0);
+        rd(0, 1, 1);
+#ifdef SEGM_WG_ABL_NOMFMA
+        for (int j = 0; j < 0; ++j) {
+#else
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {                     // k-step: plane z = j / 2, rows y = 4 (j & 1) + g
-            const int z = j >> 1, yb = 4 * (j & 1);
-            frag8 af = *reinterpret_cast<const frag8*>(a_base + (z * 8 + yb) * 16);
+        for (int j = 0; j < 16; ++j) {
+#endif
+            const cube_u32x4 o = a_next;
+            const uint32_t lw = HALO ? h_next << 16 : 0u, rw = HALO ? h_next >> 16 : 0u;
+            if (j + 1 < 16) rd_a(j + 1);
+            const uint32_t s01 = __builtin_amdgcn_alignbyte(o[1], o[0], 2), s12 = __builtin_amdgcn_alignbyte(o[2], o[1], 2),
+                           s23 = __builtin_amdgcn_alignbyte(o[3], o[2], 2);
+            const cube_u32x4 l = cube_u32x4{__builtin_amdgcn_alignbyte(o[0], lw, 2), s01, s12, s23};       // element i = dY[i - 1]: kx = 2
+            const cube_u32x4 r = cube_u32x4{s01, s12, s23, __builtin_amdgcn_alignbyte(rw, o[3], 2)};       // element i = dY[i + 1]: kx = 0
+            const frag8 a0 = __builtin_bit_cast(frag8, r), a1 = __builtin_bit_cast(frag8, o), a2 = __builtin_bit_cast(frag8, l);
 #pragma unroll
-            for (int kz = 0; kz < 3; ++kz)
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int row = (z + kz) * 10 + yb + ky;
-                    const cube_u32x4 o = *reinterpret_cast<const cube_u32x4*>(b_base + row * 16);
-                    uint32_t lw = 0, rw = 0;
-                    if (HALO) {
-                        const uint32_t h = *reinterpret_cast<const uint32_t*>(h_base + row * 4);
-                        lw = h << 16; rw = h >> 16;
-                    }
-                    const uint32_t s01 = __builtin_amdgcn_alignbyte(o[1], o[0], 2), s12 = __builtin_amdgcn_alignbyte(o[2], o[1], 2),
-                                   s23 = __builtin_amdgcn_alignbyte(o[3], o[2], 2);
-                    const cube_u32x4 l = cube_u32x4{__builtin_amdgcn_alignbyte(o[0], lw, 2), s01, s12, s23};       // element i = x[i - 1]
-                    const cube_u32x4 r = cube_u32x4{s01, s12, s23, __builtin_amdgcn_alignbyte(rw, o[3], 2)};       // element i = x[i + 1]
-                    frag8 b0, b1, b2;
-                    memcpy(&b0, &l, 16); memcpy(&b1, &o, 16); memcpy(&b2, &r, 16);
-                    const int t = (kz * 3 + ky) * 3;
-                    acc[t] = Mfma16<T>::run(af, b0, acc[t]);
-                    acc[t + 1] = Mfma16<T>::run(af, b1, acc[t + 1]);
-                    acc[t + 2] = Mfma16<T>::run(af, b2, acc[t + 2]);
-                }
-            SEGM_SCHED_FENCE();
+            for (int kk = 0; kk < 9; ++kk) {
+                const int q = j * 9 + kk;
+                if (q + 2 < 144) rd((q + 2) / 9, (q + 2) % 9, (q + 2) % 3);
+                const frag8 bf = __builtin_bit_cast(frag8, ring_o[q % 3]);
+                acc[3 * kk] = Mfma16<T>::run(a0, bf, acc[3 * kk]);
+                acc[3 * kk + 1] = Mfma16<T>::run(a1, bf, acc[3 * kk + 1]);
+                acc[3 * kk + 2] = Mfma16<T>::run(a2, bf, acc[3 * kk + 2]);
+#ifndef SEGM_WG_NOFENCE
+                SEGM_SCHED_FENCE();
+#endif
+            }
         }
     }
     // D[row = co 4 g + i][col = ci n16]

@@ -226,3 +226,51 @@ extern "C" int segm_transpose_add(const segm_transpose_args* a) {
     if (a->dtype == SEGM_F16) return launch_transpose<f16_t>(P, a->batch, vec, st);
     return launch_transpose<bf16_t>(P, a->batch, vec, st);
 }
+
+// ---- out[i] = src[map(i)] for 16-bit elements (C ABI: segm_gather16; round 6) -------------------------------------------------
+// The parameter bank refreshes every re-arranged copy of a weight (the convolution kernels' fragment images and packed blocks) with
+// ONE gather per training step (param_bank.refresh) - torch.index_select with a 4-byte index per element there: 0.48 ms for the
+// 118 M elements of the benchmarked network, index traffic twice the payload.  Every group of eight consecutive packed elements is
+// eight input channels of one (output channel, tap), i.e. an arithmetic progression in the source - mode 1 stores (first index,
+// step) per group: 1 byte of map per element.  A thread produces eight elements = one 16-byte store.
+namespace segm {
+struct Gather16Dev { const uint16_t* src; const int32_t* map; uint16_t* out; int64_t groups; };
+
+template <int MODE>
+__global__ void __launch_bounds__(256) gather16_kernel(Gather16Dev P) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+    for (int64_t gI = (int64_t)blockIdx.x * 256 + threadIdx.x; gI < P.groups; gI += (int64_t)gridDim.x * 256) {
+        int32_t ix[8];
+        if (MODE == 0) {
+            const i32x4 a = reinterpret_cast<const i32x4*>(P.map)[2 * gI], b = reinterpret_cast<const i32x4*>(P.map)[2 * gI + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ix[e] = a[e]; ix[4 + e] = b[e]; }
+        } else {
+            const i32x2 bs = reinterpret_cast<const i32x2*>(P.map)[gI];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ix[e] = bs[0] + e * bs[1];
+        }
+        uint32_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = P.src[ix[e]];
+        reinterpret_cast<u32x4*>(P.out)[gI] = u32x4{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+    }
+}
+}  // namespace segm
+
+extern "C" int segm_gather16(const segm_gather16_args* p) {
+    if (!p) return SEGM_E_NULL;
+    if (p->count == 0) return SEGM_OK;
+    if (!p->src || !p->map || !p->out) return SEGM_E_NULL;
+    if (p->count < 0 || p->count % 8 != 0 || (p->mode != 0 && p->mode != 1)) return SEGM_E_SHAPE;
+    if (((uintptr_t)p->out & 15) || ((uintptr_t)p->map & 15)) return SEGM_E_SHAPE;
+    segm::Gather16Dev P{(const uint16_t*)p->src, (const int32_t*)p->map, (uint16_t*)p->out, p->count / 8};
+    int64_t blocks = (P.groups + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t st = (hipStream_t)p->stream;
+    if (p->mode == 0) hipLaunchKernelGGL((segm::gather16_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((segm::gather16_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, P);
+    return (int)hipGetLastError();
+}

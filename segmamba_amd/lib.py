@@ -134,6 +134,11 @@ class Add3Args(C.Structure):
                 ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("out", C.c_void_p), ("stream", C.c_void_p)]
 
 
+class Gather16Args(C.Structure):
+    _fields_ = [("count", C.c_int64), ("mode", C.c_int32), ("reserved", C.c_int32),
+                ("src", C.c_void_p), ("map", C.c_void_p), ("out", C.c_void_p), ("stream", C.c_void_p)]
+
+
 class InstNormFwdArgs(C.Structure):
     _fields_ = [
         ("instances", C.c_int32), ("dtype", C.c_int32), ("act", C.c_int32), ("reserved", C.c_int32),
@@ -283,7 +288,7 @@ EXPORTS = (
     "segm_conv3d_k3_wgrad", "segm_conv3d_k3_wgrad_workspace_bytes", "segm_conv3d_k3_fwd", "segm_conv3d_k3_fwd_stats_parts",
     "segm_conv3d_k3_fwd_cl", "segm_conv3d_k3_cl_pack_index", "segm_add3",
     "segm_conv3d_k3_cube_fwd", "segm_conv3d_k3_cube_plan", "segm_conv3d_k3_cube_pack_index",
-    "segm_conv3d_k3_cube_wgrad", "segm_conv3d_k3_cube_wgrad_workspace_bytes",
+    "segm_conv3d_k3_cube_wgrad", "segm_conv3d_k3_cube_wgrad_workspace_bytes", "segm_gather16",
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add", "segm_depth_to_space2",
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
@@ -356,6 +361,7 @@ class SegmLib:
         sig("segm_conv3d_k3_cube_wgrad", [C.POINTER(Conv3dWgradArgs)], C.c_int)
         sig("segm_conv3d_k3_cube_wgrad_workspace_bytes", [C.c_int32] * 6, C.c_size_t)
         sig("segm_add3", [C.POINTER(Add3Args)], C.c_int)
+        sig("segm_gather16", [C.POINTER(Gather16Args)], C.c_int)
         sig("segm_instnorm_fwd", [C.POINTER(InstNormFwdArgs)], C.c_int)
         sig("segm_instnorm_bwd", [C.POINTER(InstNormBwdArgs)], C.c_int)
         sig("segm_instnorm_workspace_bytes", [C.c_int32, C.c_int64], C.c_size_t)

@@ -860,6 +860,34 @@ def add3(lib: L.SegmLib, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, out:
     return out
 
 
+def gather16_compact_map(idx: torch.Tensor) -> Optional[torch.Tensor]:
+    """int32 (n,) source indices, n % 8 == 0 -> int32 (n / 8, 2) (first index, step) when every group of eight consecutive indices
+    is an arithmetic progression (the packed weight layouts are: eight input channels of one (output channel, tap)), else None"""
+    if idx.numel() == 0 or idx.numel() % 8:
+        return None
+    m = idx.view(-1, 8)
+    step = m[:, 1] - m[:, 0]
+    ar = torch.arange(8, dtype=idx.dtype, device=idx.device)
+    if not bool((m == m[:, :1] + step[:, None] * ar).all()):
+        return None
+    return torch.stack([m[:, 0], step], 1).contiguous()
+
+
+def gather16(lib: L.SegmLib, src: torch.Tensor, idx: torch.Tensor, out: torch.Tensor, compact: bool = False) -> torch.Tensor:
+    """out[i] = src[idx[i]] (16-bit elements, one launch); `compact`: idx is gather16_compact_map's (n / 8, 2) form"""
+    n = out.numel()
+    if src.dtype not in (torch.bfloat16, torch.float16) or out.dtype != src.dtype or idx.dtype != torch.int32 or n % 8 or \
+            not (src.is_contiguous() and out.is_contiguous() and idx.is_contiguous()) or idx.numel() != (n // 4 if compact else n) or \
+            (out.data_ptr() | idx.data_ptr()) & 15:
+        raise RuntimeError("gather16: 16-bit src / out, int32 map, whole 16-byte groups")
+    p = L.Gather16Args()
+    p.count, p.mode = n, 1 if compact else 0
+    p.src, p.map, p.out = src.data_ptr(), idx.data_ptr(), out.data_ptr()
+    p.stream = L.stream_handle(out)
+    lib.check(lib.dll.segm_gather16(p), "gather16")
+    return out
+
+
 def transpose_add(lib: L.SegmLib, x: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x (B, R, C) contiguous -> (B, C, R) contiguous (+ add, which already has the output layout)."""
     if x.dim() != 3 or not x.is_contiguous():

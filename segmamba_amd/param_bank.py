@@ -25,7 +25,14 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
+from . import lib as _lib
+
 _ACTIVE: Optional["ParamBank"] = None
+
+
+def _ops_raw():
+    from . import ops_raw
+    return ops_raw
 
 
 class ParamBank:
@@ -67,6 +74,7 @@ class ParamBank:
         self._dtotal = 0
         self._dmap: Optional[torch.Tensor] = None              # the maps concatenated (rebuilt when a pack was registered)
         self._dbuf: Optional[torch.Tensor] = None
+        self._dcompact: Optional[torch.Tensor] = None          # the maps as (first index, step) per eight elements, when they all are progressions
         self.frozen = False                                    # a captured graph gathers through _dmap into _dbuf: no new packs
         self._dready = 0                                       # packs [0, _dready) of _dkeys were filled by the last refresh
 
@@ -149,7 +157,18 @@ class ParamBank:
                 if self._dmap is None or self._dmap.numel() != self._dtotal:
                     self._dmap = torch.cat(self._dmaps)
                     self._dbuf = torch.empty(self._dtotal, dtype=self.dtype, device=self.flat16.device)
-                torch.index_select(self.flat16z, 0, self._dmap, out=self._dbuf)      # every derived pack, one launch
+                    self._dcompact = None
+                    if _lib.on_device(self._dbuf):
+                        # eight consecutive packed elements = eight channels of one (row, tap): (first index, step) per group
+                        # instead of an index per element (segm_gather16 mode 1), when every pack is laid out that way
+                        self._dcompact = _ops_raw().gather16_compact_map(self._dmap)
+                if _lib.on_device(self._dbuf):                 # every derived pack, one launch
+                    if self._dcompact is not None:
+                        _ops_raw().gather16(_lib.get_lib(), self.flat16z, self._dcompact, self._dbuf, compact=True)
+                    else:
+                        _ops_raw().gather16(_lib.get_lib(), self.flat16z, self._dmap, self._dbuf)
+                else:
+                    torch.index_select(self.flat16z, 0, self._dmap, out=self._dbuf)
                 self._dready = len(self._dmaps)
         self.fresh = True
 

@@ -2058,3 +2058,23 @@ def test_conv3d_k3_cube_wgrad_emulated(emu, shape):
     assert torch.equal(ops_raw.conv3d_k3_cube_wgrad(emu, xp, dyp, torch.float32), dw)
     assert not ops_raw.conv3d_cube_wgrad_supported(x[:, :, :, :, :4], dy[:, :, :, :, :4])
     assert not ops_raw.conv3d_cube_wgrad_supported(x[:, :16], dy)
+
+
+def test_gather16_emulated(emu):
+    """segm_gather16: out[i] = src[map(i)], an index per element (mode 0) or (first index, step) per eight elements (mode 1); the
+    compact form exists exactly when every group of eight is an arithmetic progression - e.g. the cube kernels' weight images"""
+    g = torch.Generator().manual_seed(2)
+    src = torch.randn(5000, generator=g).bfloat16()
+    idx = torch.randint(0, 5000, (8 * 333,), generator=g, dtype=torch.int32)
+    out = torch.empty(idx.numel(), dtype=torch.bfloat16)
+    assert torch.equal(ops_raw.gather16(emu, src, idx, out), src[idx.long()])
+    assert ops_raw.gather16_compact_map(idx) is None
+    w = torch.randn(64, 32, 3, 3, 3, generator=g).bfloat16()
+    for flipped in (False, True):
+        m = ops_raw.conv3d_cube_index(emu, 64, 32, flipped, "cpu")
+        cm = ops_raw.gather16_compact_map(m)
+        assert cm is not None and cm.shape == (m.numel() // 8, 2)
+        out = torch.empty(m.numel(), dtype=torch.bfloat16)
+        assert torch.equal(ops_raw.gather16(emu, w.reshape(-1), cm, out, compact=True), w.reshape(-1)[m.long()])
+    with pytest.raises(RuntimeError):
+        ops_raw.gather16(emu, src, idx[:12], torch.empty(12, dtype=torch.bfloat16))
