@@ -91,5 +91,22 @@ ops_raw.linear_rows(emu, ak, wk, torch.randn(44), out=yk); ops_raw.linear_rows(e
 print("linear_rows K > 192 ok", flush=True)
 ta = torch.randn(999, 40, generator=g).bfloat16()[:, :36]; tb = torch.randn(999, 48, generator=g).bfloat16()
 ops_raw.wgrad_gemm(emu, ta, tb, ops_raw.WGEMM_TN); print("wgrad_gemm TN on padded rows / 48-column blocks ok", flush=True)
+# round 6, second half: the cube kernels and the bank's gather
+xq = torch.zeros(1, 65, 8, 16, 24, dtype=torch.bfloat16)[:, :64, :, :, :16]                                     # padded strides, two cubes in x and y
+xq.copy_(torch.randn(1, 64, 8, 16, 16, generator=g)); wq = (0.1 * torch.randn(192, 64, 3, 3, 3, generator=g)).bfloat16()
+for nt, sp in ((2, 1), (3, 2), (4, 0)):
+    if 192 % (32 * nt) == 0:
+        yq, stq = ops_raw.conv3d_k3_cube_fwd(emu, xq, ops_raw.conv3d_cube_weight_image(emu, wq), 192, torch.randn(192), nt=nt, splits=sp, want_stats=True)
+        ops_raw.conv3d_k3_cube_fwd(emu, xq, ops_raw.conv3d_cube_weight_image(emu, wq), 192, None, out=yq, accumulate=True, nt=nt, splits=sp)
+dyq = torch.randn(1, 192, 8, 16, 16, generator=g).bfloat16()
+ops_raw.conv3d_k3_cube_fwd(emu, dyq, ops_raw.conv3d_cube_weight_image(emu, wq, flipped=True), 64)
+print("cube forward / data gradient ok", flush=True)
+ops_raw.conv3d_k3_cube_wgrad(emu, xq, dyq, torch.float32)                                                        # rows with x neighbours
+ops_raw.conv3d_k3_cube_wgrad(emu, xq[:, :32, :, :8, :8], dyq[:, :64, :, :8, :8], torch.bfloat16)                # 8-wide: padding only
+print("cube weight gradient ok", flush=True)
+mq = ops_raw.conv3d_cube_index(emu, 192, 64, False, "cpu")
+ops_raw.gather16(emu, wq.reshape(-1), mq, torch.empty(mq.numel(), dtype=torch.bfloat16))
+ops_raw.gather16(emu, wq.reshape(-1), ops_raw.gather16_compact_map(mq), torch.empty(mq.numel(), dtype=torch.bfloat16), compact=True)
+print("gather16 ok", flush=True)
 print("AddressSanitizer run finished without reports")
 PY
