@@ -368,6 +368,21 @@ int segm_conv3d_k3_cube_plan(int32_t batch, int32_t cin, int32_t cout, int32_t d
                              int32_t* nt, int32_t* splits, int64_t* workspace_elems);
 int segm_conv3d_k3_cube_pack_index(int32_t* out, int64_t n, int32_t cout_w, int32_t cin_w, int32_t flipped);
 
+/* The images of many weights in ONE launch (what a training step needs after every weight update): descriptor i says where the
+ * (cout_w, cin_w, 3, 3, 3) weight starts in `src` (element offset; co_stride = elements between its output channels - a channel
+ * slice of a wider weight keeps the wide stride; the (cin, 27) part contiguous), where its image starts in `out` (a multiple of
+ * 8), whether it is the data-gradient image, and the first block of the grid that works on it; blocks per image =
+ * (Cout / 16) * (Cin / 32) of the convolution the image is for.  descs is a DEVICE array, first_block ascending.  The result is
+ * element for element what segm_conv3d_k3_cube_pack_index describes. */
+typedef struct segm_cube_pack_desc {
+    int64_t src_off, out_off;
+    int32_t cout_w, cin_w, co_stride, flipped;
+    int32_t first_block, reserved;
+} segm_cube_pack_desc;
+
+int segm_conv3d_k3_cube_pack_multi(const void* src, void* out, const segm_cube_pack_desc* descs, int32_t ndesc, int32_t nblocks,
+                                   void* stream);
+
 /* The weight gradient of those layers (segm_conv3d_wgrad_args as for segm_conv3d_k3_wgrad): cin % 32 == 0, cout % 64 == 0, depth /
  * height / width multiples of 8.  The contraction runs over voxels and NCDHW has x contiguous: both operands are staged in LDS in
  * their native row layout (dY cube and X halo cube of 64 x 32 channels), a wave owns a 16 x 16 (co, ci) tile for all 27 taps, the

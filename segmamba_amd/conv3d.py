@@ -224,13 +224,13 @@ def _fwd_cube(x, w, bias=None, into=None, flipped=False, stats_box=None):
     the output gradient (the data gradient); `into`: an existing result the launch adds to; `stats_box`: the InstanceNorm partials of
     what the launch stores are appended"""
     from . import lib as L, ops_raw
-    from .param_bank import packed
+    from .param_bank import packed_cube_image
     hip = L.get_lib()
     cout = w.shape[1] if flipped else w.shape[0]
     if w.dtype != x.dtype:
         img = ops_raw.conv3d_cube_weight_image(hip, w, flipped, x.dtype)
-    else:
-        img = packed(w, ("conv3d_cube", bool(flipped)), lambda t: ops_raw.conv3d_cube_weight_image(hip, t, flipped))
+    else:                                                  # inside a bank step: one of the images the step's pack launch refreshes
+        img = packed_cube_image(w, flipped, lambda t: ops_raw.conv3d_cube_weight_image(hip, t, flipped))
     res = ops_raw.conv3d_k3_cube_fwd(hip, x, img, cout, bias, out=into, accumulate=into is not None, want_stats=stats_box is not None)
     if stats_box is not None:
         res, st = res

@@ -432,6 +432,50 @@ __global__ void __launch_bounds__(256) conv3d_k3_cube_wgrad_reduce_kernel(const 
     for (int e = tid; e < cnt * 27; e += 256) o[e] = from_f32<OUT>(s_t[e]);
 }
 
+// ---- the weight images of a whole network in ONE launch (segm_conv3d_k3_cube_pack_multi) ---------------------------------------
+// A training step changes every weight, so every fragment image is rebuilt once per step from the step's 16-bit weight copy.  As
+// packs of the parameter bank's generic gather (an index per element, eight 2-byte gathers per 16-byte store) the 112 M image
+// elements of the benchmarked network took 0.45 ms per step.  Here a block takes the (16 output x 32 input channel) tile of one
+// image - 16 (forward) or 32 (data gradient) contiguous runs of the weight - through LDS with coalesced loads and writes its 27
+// fragments with coalesced 16-byte stores; a descriptor table deals the blocks of all images to one grid.
+struct CubePackDev { const uint16_t* src; uint16_t* out; const segm_cube_pack_desc* descs; int32_t ndesc; };
+
+__global__ void __launch_bounds__(256) conv3d_k3_cube_pack_kernel(CubePackDev P) {
+    __shared__ uint16_t s_t[16 * 866];                    // forward: [16 co][864 (+2)]; flipped: [32 co][432 (+1)] - odd dword pitches
+    __shared__ int s_d;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int d = 0;
+        while (d + 1 < P.ndesc && P.descs[d + 1].first_block <= (int)blockIdx.x) ++d;
+        s_d = d;
+    }
+    __syncthreads();
+    const segm_cube_pack_desc D = P.descs[s_d];
+    const int lb = (int)blockIdx.x - D.first_block;
+    const uint16_t* src = P.src + D.src_off;
+    const bool fl = D.flipped != 0;
+    const int R = (fl ? D.cout_w : D.cin_w) / 32;          // rounds of the convolution the image is for
+    const int ct = lb / R, r = lb - ct * R;
+    const int rows = fl ? 32 : 16, run = fl ? 432 : 864, pitch = fl ? 433 : 866;
+    // row i of the tile: forward: w[ct 16 + i][r 32 .. + 31][27]; flipped: w[r 32 + i][ct 16 .. + 15][27]
+    const int64_t base = fl ? (int64_t)(r * 32) * D.co_stride + (int64_t)ct * 16 * 27 : (int64_t)(ct * 16) * D.co_stride + (int64_t)r * 32 * 27;
+    for (int e = tid; e < rows * run; e += 256) {
+        const int i = e / run, j = e - i * run;
+        s_t[i * pitch + j] = src[base + (int64_t)i * D.co_stride + j];
+    }
+    __syncthreads();
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4* out = reinterpret_cast<u32x4*>(P.out + D.out_off) + (int64_t)lb * 27 * 64;
+    for (int gI = tid; gI < 27 * 64; gI += 256) {
+        const int tap = gI >> 6, lane = gI & 63, n = lane & 15, kg = lane >> 4;
+        uint32_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = fl ? s_t[(kg * 8 + e) * pitch + n * 27 + (26 - tap)] : s_t[n * pitch + (kg * 8 + e) * 27 + tap];
+        out[gI] = u32x4{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+    }
+}
+
 static int cube_nt(int cout, int forced) {                 // column tiles per wave the layer can use: 4 (NB = 128), 3 (96), 2 (64)
     if (forced >= 2 && forced <= 4 && cout % (32 * forced) == 0) return forced;
     return 0;
@@ -625,5 +669,16 @@ extern "C" int segm_conv3d_k3_cube_wgrad(const segm_conv3d_wgrad_args* a) {
     if (a->dw_dtype == SEGM_F32) hipLaunchKernelGGL((conv3d_k3_cube_wgrad_reduce_kernel<float>), dim3(nb), dim3(256), 0, stream, (const float*)a->workspace, (float*)a->dw, sp, n);
     else if (a->dw_dtype == SEGM_F16) hipLaunchKernelGGL((conv3d_k3_cube_wgrad_reduce_kernel<f16_t>), dim3(nb), dim3(256), 0, stream, (const float*)a->workspace, (f16_t*)a->dw, sp, n);
     else hipLaunchKernelGGL((conv3d_k3_cube_wgrad_reduce_kernel<bf16_t>), dim3(nb), dim3(256), 0, stream, (const float*)a->workspace, (bf16_t*)a->dw, sp, n);
+    return (int)hipGetLastError();
+}
+
+// descs: DEVICE array of ndesc descriptors with ascending first_block; nblocks = sum over the images of (Cout / 16) * (Cin / 32) of the
+// convolution each image is for.  src / out: the 16-bit weight buffer and the image buffer the descriptors' element offsets refer to.
+extern "C" int segm_conv3d_k3_cube_pack_multi(const void* src, void* out, const segm_cube_pack_desc* descs, int32_t ndesc, int32_t nblocks, void* stream) {
+    if (ndesc == 0 || nblocks == 0) return SEGM_OK;
+    if (!src || !out || !descs) return SEGM_E_NULL;
+    if (ndesc < 0 || nblocks < 0 || ((uintptr_t)out & 15)) return SEGM_E_SHAPE;
+    CubePackDev P{(const uint16_t*)src, (uint16_t*)out, descs, ndesc};
+    hipLaunchKernelGGL(conv3d_k3_cube_pack_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, P);
     return (int)hipGetLastError();
 }

@@ -583,6 +583,27 @@ def conv3d_cube_weight_image(lib: L.SegmLib, w: torch.Tensor, flipped: bool = Fa
     return img if dtype is None or dtype == img.dtype else img.to(dtype)
 
 
+def cube_pack_descs(items, device) -> tuple:
+    """items: [(src_off, out_off, cout_w, cin_w, co_stride, flipped)] -> (int32 (n, 8) device tensor laid out as
+    segm_cube_pack_desc, total blocks) for conv3d_cube_pack_multi"""
+    rows, first = [], 0
+    for src_off, out_off, cout_w, cin_w, co_stride, flipped in items:
+        rows.append([src_off & 0xffffffff, src_off >> 32, out_off & 0xffffffff, out_off >> 32, cout_w, cin_w, co_stride, int(bool(flipped)), first, 0])
+        first += (cin_w // 16) * (cout_w // 32) if flipped else (cout_w // 16) * (cin_w // 32)
+    t = torch.tensor(rows, dtype=torch.int64).to(torch.int32).to(device).contiguous()
+    return t, first
+
+
+def conv3d_cube_pack_multi(lib: L.SegmLib, src: torch.Tensor, out: torch.Tensor, descs: torch.Tensor, nblocks: int) -> torch.Tensor:
+    """every weight image described by `descs` (cube_pack_descs) from the 16-bit weight buffer `src` into `out`, one launch"""
+    if src.dtype not in (torch.bfloat16, torch.float16) or out.dtype != src.dtype or descs.dtype != torch.int32 or descs.dim() != 2 or \
+            descs.shape[1] != 10 or not (src.is_contiguous() and out.is_contiguous() and descs.is_contiguous()) or out.data_ptr() & 15:
+        raise RuntimeError("conv3d_cube_pack_multi: 16-bit src / out, int32 (n, 10) descriptors")
+    lib.check(lib.dll.segm_conv3d_k3_cube_pack_multi(src.data_ptr(), out.data_ptr(), descs.data_ptr(), descs.shape[0], nblocks,
+                                                     L.stream_handle(out)), "conv3d_k3_cube_pack_multi")
+    return out
+
+
 def conv3d_cube_plan(lib: L.SegmLib, B, cin, cout, D, H, W, nt=0, splits=0):
     c_nt, c_s, c_ws = C.c_int32(nt), C.c_int32(splits), C.c_int64(0)
     lib.check(lib.dll.segm_conv3d_k3_cube_plan(B, cin, cout, D, H, W, C.byref(c_nt), C.byref(c_s), C.byref(c_ws)), "conv3d_k3_cube_plan")

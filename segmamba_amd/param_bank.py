@@ -75,6 +75,13 @@ class ParamBank:
         self._dmap: Optional[torch.Tensor] = None              # the maps concatenated (rebuilt when a pack was registered)
         self._dbuf: Optional[torch.Tensor] = None
         self._dcompact: Optional[torch.Tensor] = None          # the maps as (first index, step) per eight elements, when they all are progressions
+        # packs with a dedicated kernel instead of a map (the cube convolutions' weight images: segm_conv3d_k3_cube_pack_multi)
+        self._ckeys: Dict[tuple, tuple] = {}                   # key -> (index, offset, shape) inside _cbuf
+        self._citems: list = []                                # per pack: (src_off, out_off, cout_w, cin_w, co_stride, flipped)
+        self._ctotal = 0
+        self._cbuf: Optional[torch.Tensor] = None
+        self._cdesc = None                                     # (device descriptor table, blocks)
+        self._cready = 0
         self.frozen = False                                    # a captured graph gathers through _dmap into _dbuf: no new packs
         self._dready = 0                                       # packs [0, _dready) of _dkeys were filled by the last refresh
 
@@ -170,6 +177,12 @@ class ParamBank:
                 else:
                     torch.index_select(self.flat16z, 0, self._dmap, out=self._dbuf)
                 self._dready = len(self._dmaps)
+            if self._citems and _lib.on_device(self.flat16):
+                if self._cbuf is None or self._cbuf.numel() != self._ctotal:
+                    self._cbuf = torch.empty(self._ctotal, dtype=self.dtype, device=self.flat16.device)
+                    self._cdesc = _ops_raw().cube_pack_descs(self._citems, self.flat16.device)
+                _ops_raw().conv3d_cube_pack_multi(_lib.get_lib(), self.flat16, self._cbuf, *self._cdesc)      # every cube image, one launch
+                self._cready = len(self._citems)
         self.fresh = True
 
     # ---- derived packs ---------------------------------------------------------------------------------------------------------
@@ -181,6 +194,29 @@ class ParamBank:
         if d < 0 or d >= 2 * self.flat16.numel() or w.untyped_storage().data_ptr() != self.flat16z.untyped_storage().data_ptr():
             return None
         return d // 2
+
+    def derived_cube_image(self, w: torch.Tensor, flipped: bool, fn):
+        """The cube convolutions' weight image of a window `w` (Cout, Cin, 3, 3, 3) of the step's 16-bit copies (a whole weight or a
+        channel slice of one): like `derived`, but filled by the dedicated pack launch instead of the generic gather.  `fn(w)`
+        computes the image directly (first call, and whenever the window is not one the pack kernel takes)."""
+        off = self._window_offset(w)
+        ok = (off is not None and self.fresh and _lib.on_device(w) and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and
+              tuple(w.stride()[1:]) == (27, 9, 3, 1) and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 and w.stride(0) < (1 << 31))
+        if not ok:
+            return self.derived(w, ("conv3d_cube", bool(flipped)), fn)
+        key = (bool(flipped), off, tuple(w.shape), w.stride(0))
+        hit = self._ckeys.get(key)
+        if hit is not None:
+            idx, o, n = hit
+            return self._cbuf[o:o + n] if idx < self._cready else fn(w)
+        out = fn(w)
+        if self.frozen:
+            return out
+        n = w.shape[0] * w.shape[1] * 27
+        self._ckeys[key] = (len(self._citems), self._ctotal, n)
+        self._citems.append((off, self._ctotal, w.shape[0], w.shape[1], w.stride(0), bool(flipped)))
+        self._ctotal += n
+        return out
 
     def derived(self, w: torch.Tensor, tag, fn):
         """`fn(w)` for a window `w` of the step's 16-bit copies, where `fn` only RE-ARRANGES elements (slice, permute, flip,
@@ -249,6 +285,13 @@ def packed(w: torch.Tensor, tag, fn):
     a window of the bank's 16-bit copies it comes out of the bank's one-launch gather (`ParamBank.derived`), else `fn(w)`."""
     if _ACTIVE is not None:
         return _ACTIVE.derived(w, tag, fn)
+    return fn(w)
+
+
+def packed_cube_image(w: torch.Tensor, flipped: bool, fn):
+    """the cube convolutions' weight image of `w`: inside a bank step from the bank's dedicated pack launch, else `fn(w)`"""
+    if _ACTIVE is not None:
+        return _ACTIVE.derived_cube_image(w, flipped, fn)
     return fn(w)
 
 

@@ -2078,3 +2078,25 @@ def test_gather16_emulated(emu):
         assert torch.equal(ops_raw.gather16(emu, w.reshape(-1), cm, out, compact=True), w.reshape(-1)[m.long()])
     with pytest.raises(RuntimeError):
         ops_raw.gather16(emu, src, idx[:12], torch.empty(12, dtype=torch.bfloat16))
+
+
+def test_conv3d_cube_pack_multi_emulated(emu):
+    """segm_conv3d_k3_cube_pack_multi: the fragment images of several weights (whole weights and a channel slice of a wider one, forward
+    and data-gradient images) from one 16-bit buffer in one launch == the images the exported index map describes, element for element"""
+    g = torch.Generator().manual_seed(8)
+    buf = torch.randn(8 + 64 * 32 * 27 + 64 * 96 * 27 + 16, generator=g).bfloat16()
+    w1 = buf[8:8 + 64 * 32 * 27].view(64, 32, 3, 3, 3)
+    wide = buf[8 + 64 * 32 * 27:8 + 64 * 32 * 27 + 64 * 96 * 27].view(64, 96, 3, 3, 3)
+    w2 = wide[:, 32:96]                                     # a cat part: (64, 64) with the wide weight's channel stride
+    items, expect, o = [], [], 0
+    for w, fl in ((w1, False), (w1, True), (w2, False), (w2, True)):
+        off = (w.data_ptr() - buf.data_ptr()) // 2
+        items.append((off, o, w.shape[0], w.shape[1], w.stride(0), fl))
+        expect.append(ops_raw.conv3d_cube_weight_image(emu, w, fl))
+        o += w.shape[0] * w.shape[1] * 27
+    descs, nblocks = ops_raw.cube_pack_descs(items, "cpu")
+    assert nblocks == sum((w.shape[0] // 16) * (w.shape[1] // 32) if not fl else (w.shape[1] // 16) * (w.shape[0] // 32)
+                          for w, fl in ((w1, False), (w1, True), (w2, False), (w2, True)))
+    out = torch.zeros(o, dtype=torch.bfloat16)
+    ops_raw.conv3d_cube_pack_multi(emu, buf, out, descs, nblocks)
+    assert torch.equal(out, torch.cat(expect))
