@@ -574,10 +574,27 @@ def conv3d_cube_index(lib: L.SegmLib, cout_w: int, cin_w: int, flipped: bool, de
     return idx
 
 
-def conv3d_cube_weight_image(lib: L.SegmLib, w: torch.Tensor, flipped: bool = False, dtype=None) -> torch.Tensor:
-    """(Cout, Cin, 3, 3, 3) weights -> the fragment image segm_conv3d_k3_cube_fwd streams (`flipped`: the image of the data
-    gradient, a convolution of dy with flip(w)^T) - one gather through the index map the library exports; a pure re-arrangement,
-    so inside a bank step it is one of the bank's derived packs (param_bank.packed)."""
+_cube_desc_cache = {}
+
+
+def conv3d_cube_weight_image(lib: L.SegmLib, w: torch.Tensor, flipped: bool = False, dtype=None, by_index: bool = False) -> torch.Tensor:
+    """(Cout, Cin, 3, 3, 3) weights (or a channel slice of a wider weight) -> the fragment image segm_conv3d_k3_cube_fwd streams
+    (`flipped`: the image of the data gradient, a convolution of dy with flip(w)^T).  On the device one launch of the pack kernel
+    (segm_conv3d_k3_cube_pack_multi with a single cached descriptor); `by_index` (and layouts the kernel does not take): a gather
+    through the index map the library exports - the definition the pack kernel is tested against."""
+    direct = (not by_index and L.on_device(w) and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and tuple(w.stride()[1:]) == (27, 9, 3, 1) and
+              w.dtype in (torch.bfloat16, torch.float16) and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 and 0 < w.stride(0) < (1 << 31) and
+              (dtype is None or dtype == w.dtype))
+    if direct:
+        key = (w.shape[0], w.shape[1], w.stride(0), bool(flipped), str(w.device))
+        hit = _cube_desc_cache.get(key)
+        if hit is None:
+            hit = cube_pack_descs([(0, 0, w.shape[0], w.shape[1], w.stride(0), flipped)], w.device)
+            _cube_desc_cache[key] = hit
+        out = torch.empty(w.shape[0] * w.shape[1] * 27, dtype=w.dtype, device=w.device)
+        lib.check(lib.dll.segm_conv3d_k3_cube_pack_multi(w.data_ptr(), out.data_ptr(), hit[0].data_ptr(), 1, hit[1], L.stream_handle(out)),
+                  "conv3d_k3_cube_pack_multi")
+        return out
     idx = conv3d_cube_index(lib, w.shape[0], w.shape[1], flipped, w.device)
     img = torch.index_select(w.reshape(-1), 0, idx)
     return img if dtype is None or dtype == img.dtype else img.to(dtype)

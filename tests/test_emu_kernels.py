@@ -2092,7 +2092,7 @@ def test_conv3d_cube_pack_multi_emulated(emu):
     for w, fl in ((w1, False), (w1, True), (w2, False), (w2, True)):
         off = (w.data_ptr() - buf.data_ptr()) // 2
         items.append((off, o, w.shape[0], w.shape[1], w.stride(0), fl))
-        expect.append(ops_raw.conv3d_cube_weight_image(emu, w, fl))
+        expect.append(ops_raw.conv3d_cube_weight_image(emu, w, fl, by_index=True))
         o += w.shape[0] * w.shape[1] * 27
     descs, nblocks = ops_raw.cube_pack_descs(items, "cpu")
     assert nblocks == sum((w.shape[0] // 16) * (w.shape[1] // 32) if not fl else (w.shape[1] // 16) * (w.shape[0] // 32)

@@ -976,6 +976,13 @@ def test_conv3d_k3_cube_at_the_benchmarked_shapes(cin, cout, S, dtype):
     yr.backward(dy.float())
     yr = yr.detach()
     img, imgT = ops_raw.conv3d_cube_weight_image(hip, w), ops_raw.conv3d_cube_weight_image(hip, w, flipped=True)
+    # the pack kernel (what the device path uses) against the gather through the exported index map, also on a channel slice
+    assert torch.equal(img, ops_raw.conv3d_cube_weight_image(hip, w, by_index=True))
+    assert torch.equal(imgT, ops_raw.conv3d_cube_weight_image(hip, w, flipped=True, by_index=True))
+    if cin >= 64:
+        part = w[:, 32:]
+        for fl in (False, True):
+            assert torch.equal(ops_raw.conv3d_cube_weight_image(hip, part, fl), ops_raw.conv3d_cube_weight_image(hip, part.contiguous(), fl, by_index=True))
     y, st = ops_raw.conv3d_k3_cube_fwd(hip, x, img, cout, bias, want_stats=True)
     assert float((y.float() - yr).abs().max()) <= 1e-2 * float(yr.abs().max())
     assert torch.equal(y, ops_raw.conv3d_k3_cube_fwd(hip, x, img, cout, bias))
