@@ -335,7 +335,8 @@ int segm_conv3d_k3_cl_pack_index(int32_t* out, int64_t n);
  * channels; reference model_segmamba/segmamba.py:91-132, monai/networks/blocks/dynunet_block.py:44-111, unetr_block.py:82-84;
  * torch.nn.Conv3d -> cuDNN there).  A workgroup owns 8 x 8 x 8 voxels x 64 / 96 / 128 output channels, stages the halo cube of
  * 32 input channels per round in LDS and runs all 27 taps from it; the contraction is split over workgroups and a second launch
- * adds the fp32 partial sums in a fixed order (+ bias, + the existing y with SEGM_CONV_CUBE_ACCUMULATE) and rounds once.
+ * adds the fp32 partial sums in a fixed order (+ bias, + the existing y with SEGM_CONV_CUBE_ACCUMULATE) and rounds once; with one
+ * split (enough cubes to fill the device) the first launch finishes the values itself.
  *
  * x: (batch, cin, D, H, W), y: (batch, cout, D, H, W), element strides for b / c / z / y (x contiguous), every stride a multiple
  * of 8, 16-byte aligned bases.  w_image: cout * cin * 27 elements of x's dtype arranged by segm_conv3d_k3_cube_pack_index:
@@ -358,7 +359,8 @@ typedef struct segm_conv3d_cube_args {
     int64_t workspace_elems;
     void* stream;
     /* InstanceNorm partials of what the launch stores (segm_instnorm_fwd_args.stats_partials): fp32 (batch * cout, stats_nparts, 4)
-     * {count, sum, sum of squares, -}, stats_nparts = depth * height * width / 512; NULL = not wanted */
+     * {count, sum, sum of squares, -}, stats_nparts = segm_conv3d_k3_cube_stats_parts(depth, height, width, the plan's splits);
+     * NULL = not wanted */
     float* stats_partials;
     int32_t stats_nparts, reserved;
 } segm_conv3d_cube_args;
@@ -367,6 +369,7 @@ int segm_conv3d_k3_cube_fwd(const segm_conv3d_cube_args* args);
 int segm_conv3d_k3_cube_plan(int32_t batch, int32_t cin, int32_t cout, int32_t depth, int32_t height, int32_t width,
                              int32_t* nt, int32_t* splits, int64_t* workspace_elems);
 int segm_conv3d_k3_cube_pack_index(int32_t* out, int64_t n, int32_t cout_w, int32_t cin_w, int32_t flipped);
+int32_t segm_conv3d_k3_cube_stats_parts(int32_t depth, int32_t height, int32_t width, int32_t splits);
 
 /* The images of many weights in ONE launch (what a training step needs after every weight update): descriptor i says where the
  * (cout_w, cin_w, 3, 3, 3) weight starts in `src` (element offset; co_stride = elements between its output channels - a channel

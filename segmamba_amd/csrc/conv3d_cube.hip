@@ -49,6 +49,10 @@ struct CubeDev {
     float* part;                                         // [S][B][Cout][D][H][W]
     int32_t B, Cin, Cout, D, H, W;
     int32_t R, S, tz, ty, tx, ncb;
+    // EPI 1 / 2 (one split: no partial sums, no second launch): the finished values go straight to y
+    char* y;  int64_t y_sb, y_sc, y_sz, y_sy;
+    const float* bias;
+    float* stats;                                        // (B * Cout, vol / 128, 4) {count, sum, sum of squares, -} per wave, or null
 };
 
 template <typename T> struct CubeStage {                 // one thread's share of a round on its way from global memory to LDS
@@ -57,7 +61,9 @@ template <typename T> struct CubeStage {                 // one thread's share o
 };
 
 // NT = 16-channel tiles per wave; NB = 32 NT output channels per workgroup (two waves side by side in N, four in M)
-template <typename T, int NT>
+// EPI: 0 = fp32 partial sums of this split (the reduction launch finishes them); 1 = the only split: + bias, rounded, stored to y
+// (+ the InstanceNorm partials of what is stored, per wave = 128 voxels of a channel); 2 = the same added to what y holds
+template <typename T, int NT, int EPI>
 __global__ void __launch_bounds__(512, 1) conv3d_k3_cube_kernel(CubeDev P) {
     typedef typename Mfma16<T>::v8 frag8;
     constexpr int NB = 32 * NT;
@@ -175,16 +181,53 @@ __global__ void __launch_bounds__(512, 1) conv3d_k3_cube_kernel(CubeDev P) {
         }
     }
 
-    // ---- partial sums: lane = (channel m16 of the column tile, row g of the 4 x 4 tile): four x-consecutive voxels
+    // ---- lane = (channel m16 of the column tile, row g of the 4 x 4 tile): four x-consecutive voxels
     const int64_t plane = (int64_t)P.H * P.W, vol = (int64_t)P.D * plane;
+    if (EPI == 0) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int co = cb * NB + (wn * NT + j) * 16 + m16;
-        float* pc = P.part + (((int64_t)s * P.B + b) * P.Cout + co) * vol;
+        for (int j = 0; j < NT; ++j) {
+            const int co = cb * NB + (wn * NT + j) * 16 + m16;
+            float* pc = P.part + (((int64_t)s * P.B + b) * P.Cout + co) * vol;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int z = z0 + 2 * wm + (i >> 2), y = y0 + ((i >> 1) & 1) * 4 + g, x = x0 + (i & 1) * 4;
-            *reinterpret_cast<mfma_f32x4*>(pc + z * plane + (int64_t)y * P.W + x) = acc[i][j];
+            for (int i = 0; i < 8; ++i) {
+                const int z = z0 + 2 * wm + (i >> 2), y = y0 + ((i >> 1) & 1) * 4 + g, x = x0 + (i & 1) * 4;
+                *reinterpret_cast<mfma_f32x4*>(pc + z * plane + (int64_t)y * P.W + x) = acc[i][j];
+            }
+        }
+    } else {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = cb * NB + (wn * NT + j) * 16 + m16;
+            const float bv = P.bias ? P.bias[co] : 0.f;
+            T* yc = reinterpret_cast<T*>(P.y) + (int64_t)b * P.y_sb + (int64_t)co * P.y_sc;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int z = z0 + 2 * wm + (i >> 2), y = y0 + ((i >> 1) & 1) * 4 + g, x = x0 + (i & 1) * 4;
+                T* dst = yc + (int64_t)z * P.y_sz + (int64_t)y * P.y_sy + x;
+                T o[4];
+                float v[4];
+                if (EPI == 2) {
+                    const u32x2 old = *reinterpret_cast<const u32x2*>(dst);
+                    memcpy(o, &old, 8);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = acc[i][j][q] + bv + (EPI == 2 ? to_f32(o[q]) : 0.f);
+                    s1 += v[q]; s2 = fmaf(v[q], v[q], s2);
+                    o[q] = from_f32<T>(v[q]);
+                }
+                u32x2 pk;
+                memcpy(&pk, o, 8);
+                *reinterpret_cast<u32x2*>(dst) = pk;
+            }
+            if (P.stats) {                                 // sum over the four rows of the tiles (lane groups); a wave = 128 voxels
+                s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (g == 0)
+                    reinterpret_cast<float4*>(P.stats)[((int64_t)b * P.Cout + co) * (vol / 128) + (int64_t)cube * 4 + wm] = float4{128.f, s1, s2, 0.f};
+            }
         }
     }
 }
@@ -476,6 +519,11 @@ __global__ void __launch_bounds__(256) conv3d_k3_cube_pack_kernel(CubePackDev P)
     }
 }
 
+static bool cube_direct() {                                // one split: the main launch finishes the values itself (SEGM_CUBE_DIRECT=0: always two launches)
+    static const bool v = [] { const char* e = getenv("SEGM_CUBE_DIRECT"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 static int cube_nt(int cout, int forced) {                 // column tiles per wave the layer can use: 4 (NB = 128), 3 (96), 2 (64)
     if (forced >= 2 && forced <= 4 && cout % (32 * forced) == 0) return forced;
     return 0;
@@ -513,7 +561,7 @@ extern "C" int segm_conv3d_k3_cube_plan(int32_t batch, int32_t cin, int32_t cout
         for (int sp = 1; sp <= R; ++sp) {
             if (R % sp != 0 || (want_s > 0 && want_s <= R && sp != want_s && R % want_s == 0)) continue;
             const int64_t wg = base * sp, waves = (wg + target - 1) / target;
-            const double cost = (double)waves * ((double)(R / sp) * (6912.0 * c + (c == 4 ? 8000.0 : 3000.0)) + 12000.0) + red * sp;
+            const double cost = (double)waves * ((double)(R / sp) * (6912.0 * c + (c == 4 ? 8000.0 : 3000.0)) + 12000.0) + (sp == 1 && cube_direct() ? 0.0 : red * sp);
             if (best_nt == 0 || cost < best_cost) { best_nt = c; best_s = sp; best_cost = cost; }
         }
     }
@@ -546,6 +594,13 @@ extern "C" int segm_conv3d_k3_cube_pack_index(int32_t* out, int64_t n, int32_t c
     return SEGM_OK;
 }
 
+// partials per (batch, channel) instance a launch with `splits` splits writes: per wave of the launch that stores the finished values -
+// the main launch (128 voxels per wave) with one split, the reduction launch (512) otherwise
+extern "C" int32_t segm_conv3d_k3_cube_stats_parts(int32_t depth, int32_t height, int32_t width, int32_t splits) {
+    const int64_t vol = (int64_t)depth * height * width;
+    return (int32_t)(splits == 1 && cube_direct() ? vol / 128 : vol / 512);
+}
+
 extern "C" int segm_conv3d_k3_cube_fwd(const segm_conv3d_cube_args* a) {
     if (!a) return SEGM_E_NULL;
     if (!a->x || !a->y || !a->w_image) return SEGM_E_NULL;
@@ -557,7 +612,8 @@ extern "C" int segm_conv3d_k3_cube_fwd(const segm_conv3d_cube_args* a) {
     if (rc != SEGM_OK) return rc;
     if ((a->nt > 0 && nt != a->nt) || (a->splits > 0 && splits != a->splits)) return SEGM_E_SHAPE;
     if (!a->workspace || a->workspace_elems < need) return SEGM_E_WORKSPACE;
-    if (a->stats_partials && a->stats_nparts != (int64_t)a->depth * a->height * a->width / 512) return SEGM_E_WORKSPACE;
+    const bool direct = splits == 1 && cube_direct();
+    if (a->stats_partials && a->stats_nparts != segm_conv3d_k3_cube_stats_parts(a->depth, a->height, a->width, splits)) return SEGM_E_WORKSPACE;
     const int64_t st[8] = {a->x_stride_b, a->x_stride_c, a->x_stride_z, a->x_stride_y, a->y_stride_b, a->y_stride_c, a->y_stride_z, a->y_stride_y};
     for (int64_t s : st)
         if (s % 8 != 0 || s <= 0) return SEGM_E_SHAPE;      // 16-byte aligned rows
@@ -573,15 +629,24 @@ extern "C" int segm_conv3d_k3_cube_fwd(const segm_conv3d_cube_args* a) {
     if (nwg >= ((int64_t)1 << 31)) return SEGM_E_SHAPE;
     hipStream_t stream = (hipStream_t)a->stream;
     const bool f16 = a->dtype == SEGM_F16;
-#define SEGM_CUBE_LAUNCH(NT_)                                                                                                \
-    do {                                                                                                                       \
-        if (f16) hipLaunchKernelGGL((conv3d_k3_cube_kernel<f16_t, NT_>), dim3((unsigned)nwg), dim3(512), 0, stream, P);         \
-        else hipLaunchKernelGGL((conv3d_k3_cube_kernel<bf16_t, NT_>), dim3((unsigned)nwg), dim3(512), 0, stream, P);            \
+    const bool acc = (a->flags & SEGM_CONV_CUBE_ACCUMULATE) != 0;
+    if (direct) {
+        P.y = (char*)a->y; P.y_sb = a->y_stride_b; P.y_sc = a->y_stride_c; P.y_sz = a->y_stride_z; P.y_sy = a->y_stride_y;
+        P.bias = a->bias; P.stats = a->stats_partials;
+    }
+    const int epi = direct ? (acc ? 2 : 1) : 0;
+#define SEGM_CUBE_LAUNCH2(T, NT_)                                                                                                                  \
+    do {                                                                                                                                            \
+        if (epi == 0) hipLaunchKernelGGL((conv3d_k3_cube_kernel<T, NT_, 0>), dim3((unsigned)nwg), dim3(512), 0, stream, P);                          \
+        else if (epi == 1) hipLaunchKernelGGL((conv3d_k3_cube_kernel<T, NT_, 1>), dim3((unsigned)nwg), dim3(512), 0, stream, P);                     \
+        else hipLaunchKernelGGL((conv3d_k3_cube_kernel<T, NT_, 2>), dim3((unsigned)nwg), dim3(512), 0, stream, P);                                   \
     } while (0)
+#define SEGM_CUBE_LAUNCH(NT_) do { if (f16) SEGM_CUBE_LAUNCH2(f16_t, NT_); else SEGM_CUBE_LAUNCH2(bf16_t, NT_); } while (0)
     if (nt == 4) SEGM_CUBE_LAUNCH(4); else if (nt == 3) SEGM_CUBE_LAUNCH(3); else SEGM_CUBE_LAUNCH(2);
 #undef SEGM_CUBE_LAUNCH
+#undef SEGM_CUBE_LAUNCH2
     int err = (int)hipGetLastError();
-    if (err) return err;
+    if (err || direct) return err;
 
     CubeReduceDev Q;
     memset(&Q, 0, sizeof(Q));
@@ -590,7 +655,6 @@ extern "C" int segm_conv3d_k3_cube_fwd(const segm_conv3d_cube_args* a) {
     Q.S = splits; Q.B = a->batch; Q.Cout = a->cout; Q.D = a->depth; Q.H = a->height; Q.W = a->width;
     Q.n8 = (int64_t)a->batch * a->cout * a->depth * a->height * a->width / 8;
     const unsigned nb = (unsigned)((Q.n8 + 255) / 256);
-    const bool acc = (a->flags & SEGM_CONV_CUBE_ACCUMULATE) != 0;
     Q.stats = a->stats_partials;
 #define SEGM_CUBE_RED(T, A_)                                                                                                     \
     do {                                                                                                                          \

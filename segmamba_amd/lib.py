@@ -289,7 +289,7 @@ EXPORTS = (
     "segm_conv3d_k3_fwd_cl", "segm_conv3d_k3_cl_pack_index", "segm_add3",
     "segm_conv3d_k3_cube_fwd", "segm_conv3d_k3_cube_plan", "segm_conv3d_k3_cube_pack_index",
     "segm_conv3d_k3_cube_wgrad", "segm_conv3d_k3_cube_wgrad_workspace_bytes", "segm_gather16",
-    "segm_conv3d_k3_cube_pack_multi",
+    "segm_conv3d_k3_cube_pack_multi", "segm_conv3d_k3_cube_stats_parts",
     "segm_instnorm_fwd", "segm_instnorm_bwd", "segm_instnorm_workspace_bytes", "segm_transpose_add", "segm_depth_to_space2",
     "segm_layernorm_tokens_fwd", "segm_layernorm_tokens_bwd", "segm_layernorm_tokens_workspace_bytes",
     "segm_sgd_clip_step", "segm_sgd_clip_step_workspace_bytes", "segm_cross_entropy", "segm_cross_entropy_partials",
@@ -360,6 +360,7 @@ class SegmLib:
         sig("segm_conv3d_k3_cube_plan", [C.c_int32] * 6 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)], C.c_int)
         sig("segm_conv3d_k3_cube_pack_index", [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32], C.c_int)
         sig("segm_conv3d_k3_cube_wgrad", [C.POINTER(Conv3dWgradArgs)], C.c_int)
+        sig("segm_conv3d_k3_cube_stats_parts", [C.c_int32] * 4, C.c_int32)
         sig("segm_conv3d_k3_cube_pack_multi", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p], C.c_int)
         sig("segm_conv3d_k3_cube_wgrad_workspace_bytes", [C.c_int32] * 6, C.c_size_t)
         sig("segm_add3", [C.POINTER(Add3Args)], C.c_int)

@@ -631,8 +631,8 @@ def conv3d_k3_cube_fwd(lib: L.SegmLib, x: torch.Tensor, w_image: torch.Tensor, c
                        nt=0, splits=0, want_stats=False):
     """y (B, cout, D, H, W) = conv3d(x (B, Cin, D, H, W), 3x3x3, stride 1, pad 1) through the cube kernel; bf16 / fp16.  The
     fp32 partial sums live in a per-device scratch buffer that grows to the largest layer seen (stream-ordered reuse).
-    want_stats: -> (y, stats), stats = fp32 (B, cout, D H W / 512, 4) partial {count, sum, sum of squares, -} of what the launch
-    stored, for instnorm_fwd(..., stats=stats)."""
+    want_stats: -> (y, stats), stats = fp32 (B, cout, nparts, 4) partial {count, sum, sum of squares, -} of what the launch stored
+    (per wave of the storing launch: 128 or 512 voxels), for instnorm_fwd(..., stats=stats)."""
     if not conv3d_cube_supported(x, cout):
         raise RuntimeError("conv3d_k3_cube_fwd: unsupported input")
     B, cin, D, H, W = x.shape
@@ -660,7 +660,7 @@ def conv3d_k3_cube_fwd(lib: L.SegmLib, x: torch.Tensor, w_image: torch.Tensor, c
     a.stream = L.stream_handle(x)
     stats = None
     if want_stats:
-        stats = torch.empty(B, cout, D * H * W // 512, 4, dtype=torch.float32, device=x.device)
+        stats = torch.empty(B, cout, lib.dll.segm_conv3d_k3_cube_stats_parts(D, H, W, splits), 4, dtype=torch.float32, device=x.device)
         a.stats_partials, a.stats_nparts = stats.data_ptr(), stats.shape[2]
     lib.check(lib.dll.segm_conv3d_k3_cube_fwd(a), "conv3d_k3_cube_fwd")
     return (y, stats) if want_stats else y
