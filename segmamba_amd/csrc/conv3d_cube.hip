@@ -36,6 +36,9 @@ namespace segm {
 
 typedef uint32_t cube_u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef SEGM_CUBE_BRING
+#define SEGM_CUBE_BRING 3
+#endif
 constexpr int kCubeP = 96;                    // LDS bytes per staged voxel: 32 channels + 32 bytes of padding
 constexpr int kCubeRow = 12;                  // voxels between rows of the staged cube (10 used)
 constexpr int kCubePlane = 120;               // voxels between planes
@@ -150,7 +153,8 @@ __global__ void __launch_bounds__(512, 1) conv3d_k3_cube_kernel(CubeDev P) {
         const char* wr = w_base + (int64_t)r * 27 * 1024;
         // software pipeline over the 27 taps: the input fragments of tap + 1 (LDS) and the weight fragments of tap + 2 (global / L2)
         // are requested before the MFMAs of tap; the fence keeps the compiler from hoisting more than that (27 x 8 reads spill)
-        frag8 av[2][8], bw[3][NT];
+        constexpr int BR = SEGM_CUBE_BRING;               // weight fragments of BR - 1 taps in flight (global memory / L2: the latency the counters show the waves waiting on)
+        frag8 av[2][8], bw[BR][NT];
         auto read_a = [&](int tap, frag8* dst) {
             const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
 #pragma unroll
@@ -163,20 +167,20 @@ __global__ void __launch_bounds__(512, 1) conv3d_k3_cube_kernel(CubeDev P) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) dst[j] = *reinterpret_cast<const frag8*>(wr + tap * 1024 + j * w_tile);
         };
-        read_b(0, bw[0]);
-        read_b(1, bw[1]);
+#pragma unroll
+        for (int t = 0; t + 1 < BR; ++t) read_b(t, bw[t]);
         constexpr bool PIPE_A = NT < 4;                    // 128 accumulator registers leave no room for a second set of input fragments
         if (PIPE_A) read_a(0, av[0]);
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
-            if (tap + 2 < 27) read_b(tap + 2, bw[(tap + 2) % 3]);
+            if (tap + BR - 1 < 27) read_b(tap + BR - 1, bw[(tap + BR - 1) % BR]);
             if (PIPE_A) { if (tap + 1 < 27) read_a(tap + 1, av[(tap + 1) & 1]); }
             else read_a(tap, av[0]);
             const int cur = PIPE_A ? (tap & 1) : 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = Mfma16<T>::run(av[cur][i], bw[tap % 3][j], acc[i][j]);
+                for (int j = 0; j < NT; ++j) acc[i][j] = Mfma16<T>::run(av[cur][i], bw[tap % BR][j], acc[i][j]);
             SEGM_SCHED_FENCE();
         }
     }
