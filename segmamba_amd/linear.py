@@ -26,6 +26,9 @@ _FORCE_SPLIT = False  # tests: exercise the split path on CPU tensors too
 # The library's row-streaming projection kernel (csrc/linear.hip) for tall activations: 3.4 - 4.9 TB/s against 1.4 - 2.9 TB/s
 # for the BLAS calls at stage 0, 1.7 - 2.4 against 1.2 - 2.3 at stage 1 (profiles/r02_linear.log).  SEGM_LINEAR_HIP=0 -> BLAS.
 _ROWS_HIP = os.environ.get("SEGM_LINEAR_HIP", "1") == "1"
+_ROWS_MAX_K = int(os.environ.get("SEGM_LINEAR_ROWS_MAX_K", "192"))  # widest contraction routed to segm_linear_rows: its streamed-W form for K > 192
+                                                                    # (round 6) is behind the vendor GEMM - at the stage-2 / 3 row counts AND at config 1's
+                                                                    # 524 288 rows, where routing it by mistake cost 3.6 ms of the block's 11.5 ms forward
 _ROWS_MIN = int(os.environ.get("SEGM_LINEAR_ROWS_MIN", "32768"))     # rows below which the BLAS call stays (round 6 measured the
 # library kernels on the stage-2 / 3 shapes: 6 - 25 us against 5.6 - 12.7 us for the vendor GEMM, step +0.2 ms: the threshold stays)
 # Channel-first 1x1x1 convolutions (csrc/pointwise.hip): the BLAS route runs y[b] = W x[b] on strided views at ~1.6 TB/s and
@@ -52,7 +55,7 @@ def _on_device(t: torch.Tensor) -> bool:
 
 def _rows_hip(x2: torch.Tensor, w: torch.Tensor, b):
     """x2 (rows, K) @ w (N, K)^T + b through segm_linear_rows, or None when the shape / layout is not the kernel's."""
-    if not (_ROWS_HIP and _on_device(x2) and x2.shape[0] >= _ROWS_MIN):
+    if not (_ROWS_HIP and _on_device(x2) and x2.shape[0] >= _ROWS_MIN and w.shape[1] <= _ROWS_MAX_K):
         return None
     from . import lib as L, ops_raw
     if not ops_raw.linear_rows_supported(x2, w):
