@@ -302,8 +302,8 @@ __global__ void __launch_bounds__(256) conv3d_k3_cube_reduce_kernel(CubeReduceDe
 // fragment, shifted one element left / right in registers for the kx = 2 / 0 taps (v_alignbyte with the neighbour elements), and
 // nine X fragments - rows (z + kz, y + ky) of the halo cube as they lie -, 27 MFMAs.  Partial sums per cube range in
 // [split][tap][co][ci] (64-byte segments per store); a second launch adds them in a fixed order into the weight's (co, ci, 27)
-// layout.  (Round 6 first tried both operands straight from global memory - correct, 90 - 170 TF/s: ten scattered 1-KB loads per
-// 27 MFMAs and wave is more than a CU's load path delivers, as round 5's direct variant of the row kernel had already shown.)
+// layout.  (Round 6 first tried both operands straight from global memory - correct, but ten scattered 1-KB loads per 27 MFMAs and
+// wave are more than a CU's load path delivers, as round 5's direct variant of the row kernel had already shown.)
 // The row kernels of csrc/conv3d_wgrad.hip want rows of >= 16 voxels and 48-channel blocks: 260 - 370 TF/s at 16^3; the vendor
 // route ran the 8^3 layers at 90 - 200 TF/s.
 constexpr int kWgXP = 1632, kWgDP = 1056, kWgHP = 260;          // LDS bytes per channel: X rows, dY rows, dY row neighbours
