@@ -355,7 +355,7 @@ typedef struct segm_conv3d_cube_args {
     void* y;         int64_t y_stride_b, y_stride_c, y_stride_z, y_stride_y;
     const void* w_image;
     const float* bias;        /* (cout) fp32 or NULL */
-    void* workspace;          /* fp32, segm_conv3d_k3_cube_plan's workspace_elems */
+    void* workspace;          /* fp32, segm_conv3d_k3_cube_plan's workspace_elems (0 with one split: may be NULL) */
     int64_t workspace_elems;
     void* stream;
     /* InstanceNorm partials of what the launch stores (segm_instnorm_fwd_args.stats_partials): fp32 (batch * cout, stats_nparts, 4)

@@ -572,7 +572,8 @@ extern "C" int segm_conv3d_k3_cube_plan(int32_t batch, int32_t cin, int32_t cout
     if (best_nt == 0) return SEGM_E_SHAPE;
     if (want_s > 0 && want_s <= R && R % want_s != 0) best_s = want_s;      // an uneven split on request (the kernel deals the rounds floor / ceil)
     *nt = best_nt; *splits = best_s;
-    *workspace_elems = (int64_t)best_s * batch * cout * depth * height * width;
+    // one split: the main launch stores the finished values itself - no partial sums
+    *workspace_elems = best_s == 1 && cube_direct() ? 0 : (int64_t)best_s * batch * cout * depth * height * width;
     return SEGM_OK;
 }
 
@@ -615,13 +616,13 @@ extern "C" int segm_conv3d_k3_cube_fwd(const segm_conv3d_cube_args* a) {
     const int rc = segm_conv3d_k3_cube_plan(a->batch, a->cin, a->cout, a->depth, a->height, a->width, &nt, &splits, &need);
     if (rc != SEGM_OK) return rc;
     if ((a->nt > 0 && nt != a->nt) || (a->splits > 0 && splits != a->splits)) return SEGM_E_SHAPE;
-    if (!a->workspace || a->workspace_elems < need) return SEGM_E_WORKSPACE;
     const bool direct = splits == 1 && cube_direct();
+    if (need > 0 && (!a->workspace || a->workspace_elems < need)) return SEGM_E_WORKSPACE;
     if (a->stats_partials && a->stats_nparts != segm_conv3d_k3_cube_stats_parts(a->depth, a->height, a->width, splits)) return SEGM_E_WORKSPACE;
     const int64_t st[8] = {a->x_stride_b, a->x_stride_c, a->x_stride_z, a->x_stride_y, a->y_stride_b, a->y_stride_c, a->y_stride_z, a->y_stride_y};
     for (int64_t s : st)
         if (s % 8 != 0 || s <= 0) return SEGM_E_SHAPE;      // 16-byte aligned rows
-    if (((uintptr_t)a->x & 15) || ((uintptr_t)a->y & 15) || ((uintptr_t)a->w_image & 15) || ((uintptr_t)a->workspace & 15)) return SEGM_E_SHAPE;
+    if (((uintptr_t)a->x & 15) || ((uintptr_t)a->y & 15) || ((uintptr_t)a->w_image & 15) || (need > 0 && ((uintptr_t)a->workspace & 15))) return SEGM_E_SHAPE;
 
     CubeDev P;
     memset(&P, 0, sizeof(P));

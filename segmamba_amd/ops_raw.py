@@ -548,7 +548,6 @@ def conv3d_k3_fwd_cl(lib: L.SegmLib, x: torch.Tensor, w_image: torch.Tensor, bia
 # ---------------------------------------------------------------------------------------------------------
 CONV_CUBE_ACCUMULATE = 1
 _cube_index_cache = {}
-_cube_ws = {}
 
 
 def conv3d_cube_supported(x: torch.Tensor, cout: int) -> bool:
@@ -640,11 +639,9 @@ def conv3d_k3_cube_fwd(lib: L.SegmLib, x: torch.Tensor, w_image: torch.Tensor, c
         raise RuntimeError("conv3d_k3_cube_fwd: accumulate needs `out`")
     y = out if out is not None else torch.empty(B, cout, D, H, W, dtype=x.dtype, device=x.device)
     nt, splits, need = conv3d_cube_plan(lib, B, cin, cout, D, H, W, nt, splits)
-    key = str(x.device)
-    ws = _cube_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.float32, device=x.device)
-        _cube_ws[key] = ws
+    # the partial sums of this call (none with one split): a fresh tensor per call - the caching allocator hands the same block back
+    # call after call on one stream, and a buffer shared between calls would be a race as soon as two streams convolve
+    ws = torch.empty(need, dtype=torch.float32, device=x.device) if need > 0 else None
     a = L.Conv3dCubeArgs()
     a.batch, a.cin, a.cout, a.depth, a.height, a.width = B, cin, cout, D, H, W
     a.dtype = L.dtype_code(x)
@@ -656,7 +653,7 @@ def conv3d_k3_cube_fwd(lib: L.SegmLib, x: torch.Tensor, w_image: torch.Tensor, c
     if bias is not None:
         bias = bias.float().contiguous()
     a.bias = bias.data_ptr() if bias is not None else None
-    a.workspace, a.workspace_elems = ws.data_ptr(), ws.numel()
+    a.workspace, a.workspace_elems = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
     a.stream = L.stream_handle(x)
     stats = None
     if want_stats:
@@ -693,11 +690,7 @@ def conv3d_k3_cube_wgrad(lib: L.SegmLib, x: torch.Tensor, dy: torch.Tensor, out_
     a.dy_stride_b, a.dy_stride_c, a.dy_stride_z, a.dy_stride_y = dy.stride()[:4]
     dw = torch.empty(cout, cin, 3, 3, 3, dtype=out_dtype, device=x.device)
     ws_bytes = lib.dll.segm_conv3d_k3_cube_wgrad_workspace_bytes(B, cin, cout, D, H, W)
-    key = ("wgrad", str(x.device))
-    ws = _cube_ws.get(key)
-    if ws is None or ws.numel() * 4 < ws_bytes:
-        ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=x.device)
-        _cube_ws[key] = ws
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=x.device)
     a.dw, a.workspace, a.workspace_bytes = dw.data_ptr(), ws.data_ptr(), ws.numel() * 4
     a.stream = L.stream_handle(x)
     lib.check(lib.dll.segm_conv3d_k3_cube_wgrad(a), "conv3d_k3_cube_wgrad")

@@ -1980,7 +1980,7 @@ def test_conv3d_k3_cube_forward_emulated(emu, shape, nt, splits):
     tol = 1e-2 * max(1.0, float(ref.abs().max()))
     img = ops_raw.conv3d_cube_weight_image(emu, w)
     pnt, ps, need = ops_raw.conv3d_cube_plan(emu, B, cin, cout, D, H_, W, nt, splits)
-    assert (nt == 0 or pnt == nt) and (splits == 0 or ps == splits) and need == ps * B * cout * D * H_ * W
+    assert (nt == 0 or pnt == nt) and (splits == 0 or ps == splits) and need == (0 if ps == 1 else ps * B * cout * D * H_ * W)
     y = ops_raw.conv3d_k3_cube_fwd(emu, x, img, cout, bias, nt=nt, splits=splits)
     assert y.shape == ref.shape and y.dtype == torch.bfloat16
     assert (y.float() - ref).abs().max() <= tol
