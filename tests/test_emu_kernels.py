@@ -1537,6 +1537,15 @@ def test_every_routing_candidate_of_the_conv_dispatcher_runs_and_agrees(emu, mon
     y.backward(torch.randn(y.shape, generator=g).bfloat16())
     assert seen == {"fwd": 6, "dgrad": 7, "wgrad": 3}, seen       # vendor, blocked, four library variants (+ dgrad-as-forward)
     assert w.grad.dtype == torch.float32 and b.grad.dtype == torch.float32 and x.grad.dtype == torch.bfloat16
+    # a layer the cube kernels take (96 -> 192 channels on an 8^3 volume): one more candidate each, the same results
+    seen.clear()
+    x2 = torch.randn(1, 96, 8, 8, 8, generator=g).bfloat16().requires_grad_()
+    w2 = (0.05 * torch.randn(192, 96, 3, 3, 3, generator=g)).requires_grad_()
+    y2, st = C3.conv3d_same(x2, w2, None, want_stats=True)
+    y2.backward(torch.randn(y2.shape, generator=g).bfloat16())
+    assert seen["fwd"] >= 2 and seen["dgrad"] >= 3 and seen["wgrad"] >= 2, seen
+    assert st is None                    # (without a GPU the dispatcher's own pick is the vendor route: it hands no statistics on)
+    assert w2.grad.dtype == torch.float32 and x2.grad.dtype == torch.bfloat16
 
 
 @pytest.mark.parametrize("K,M,N,dtype,lda,ldb", [(5000, 96, 3, torch.bfloat16, 96, 40), (4096 + 77, 192, 6, torch.bfloat16, 192, 6),
